@@ -1,0 +1,192 @@
+#!/usr/bin/env python3
+"""Benchmark of the multigrid V-cycle hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = one V-cycle (pre-smooth, residual, restrict, recurse, coarse solve, prolong +
+correct, post-smooth, residual norm — openmg/__init__.py:151-236) on a synthetic 3-D 7-point
+Poisson problem with b, x and the whole hierarchy already resident in HBM.  The workload at
+N = 1 is BASELINE.json configs[2]: 256^3, 5 grids, red-black Gauss-Seidel, fp64, V(1,1).
+
+Prints ONE JSON line (see README of the task): metric V-cycles/s, plus
+  roofline      the fine-grid residual kernel r = b - A x (the SpMV-class kernel the metric
+                names): algorithmic bytes / average launch time measured with hipEvents on
+                the kernel's own stream inside the timed region, against 8 TB/s;
+  cpu_baseline  the CPU oracle's V-cycle timed on this box's host (one core: the oracle's C
+                sweeps and SciPy's CSR kernels are single-threaded) on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def spmv_bytes(n, nnz, w=8):
+    """nnz*(w+4) + 4*(n+1) + 2*w*n."""
+    return nnz * (w + 4) + 4 * (n + 1) + 2 * w * n
+
+
+def residual_bytes(n, nnz, w=8):
+    return spmv_bytes(n, nnz, w) + w * n
+
+
+def build_problem(size, grids, smoother):
+    import openmg_amd
+    from openmg_amd import _hip, operators
+    shape = (size, size, size)
+    A0 = operators.stencil_poisson(shape)
+    u_true = np.random.default_rng(12345).random(A0.shape[0])
+    b = A0 @ u_true
+    R = operators.restrictionList(shape, grids - 1, 8)          # gridLevels = grids - 1 (D5)
+    A = operators.coeffecientList(A0, R)                        # Galerkin products on the device
+    h = _hip.Hierarchy(A, R, smoother=smoother)
+    meta = {"n": A0.shape[0], "nnz": A0.nnz, "grids": len(A),
+            "level_rows": [M.shape[0] for M in A], "level_nnz": [M.nnz for M in A]}
+    return h, b, meta
+
+
+def cpu_baseline(size, grids, cycles):
+    """The CPU oracle (oracle/, a 'port' of the reference's algorithm: the reference itself
+    is Python 2 and cannot run here) on a bounded sample: `size`^3, same grids, V(1,1)
+    red-black.  Returned in 256^3-equivalent V-cycles/s (work per cycle scales with n)."""
+    from oracle import mg_oracle as orc
+    shape = (size, size, size)
+    from openmg_amd import operators
+    A0 = operators.stencil_poisson(shape)                       # input generator only
+    b = A0 @ np.random.default_rng(12345).random(A0.shape[0])
+    R = orc.restriction_list(shape, grids - 1, 8)
+    A = orc.coefficient_list(A0, R)
+    orders = [orc.colour_order(orc.parity_colouring(tuple(s // 2 ** l for s in shape))) for l in range(len(A))]
+    sm = lambda M, bb, x, its, level: orc.gs_ordered(M, bb, x, orders[level], its)
+    p = {"preIterations": 1, "postIterations": 1, "coarsestLevel": len(R)}
+    x = None
+    x, _ = orc.mg_cycle(A, b, 0, R, p, initial=x, smoother=sm)  # warm-up
+    t0 = time.perf_counter()
+    for _ in range(cycles):
+        x, info = orc.mg_cycle(A, b, 0, R, p, initial=x, smoother=sm)
+    dt = time.perf_counter() - t0
+    return cycles / dt, dt, info["norm"]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--size", type=int, default=256, help="grid extent per axis (default: BASELINE config 3)")
+    ap.add_argument("--grids", type=int, default=5)
+    ap.add_argument("--smoother", default="colour")
+    ap.add_argument("--graph", type=int, default=0, help="replay the cycle from a hipGraph")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--cpu-size", type=int, default=128)
+    ap.add_argument("--cpu-cycles", type=int, default=8)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 or world > 1:
+        from openmg_amd import dist_bench
+        return dist_bench.main(args)
+
+    import torch                                   # device sync / contract plumbing only
+    from openmg_amd import _hip
+    _hip.require_gpu()
+    torch.cuda.set_device(0)
+
+    t_setup = time.perf_counter()
+    h, b, meta = build_problem(args.size, args.grids, args.smoother)
+    h.resident_load(b)
+    setup_s = time.perf_counter() - t_setup
+    pre = post = 1
+    if args.graph:
+        h.use_graph(True)
+    for _ in range(args.warmup):
+        h.resident_cycle(pre, post, want_norm=False)
+    h.sync()
+    torch.cuda.synchronize()
+
+    profiling = not args.graph
+    if profiling:
+        h.profile_enable(True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        h.resident_cycle(pre, post, want_norm=False)
+    h.sync()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    prof = h.profile_read() if profiling else None
+    if profiling:
+        h.profile_enable(False)
+    norm = h.resident_cycle(pre, post, want_norm=True)          # untimed: read the norm back once
+
+    if prof is None:                                            # graph mode: profile in a second region
+        h.use_graph(False)
+        h.profile_enable(True)
+        for _ in range(args.steps):
+            h.resident_cycle(pre, post, want_norm=False)
+        prof = h.profile_read()
+        h.profile_enable(False)
+
+    n, nnz = meta["n"], meta["nnz"]
+    launches, ms = prof["residual"]
+    avg_s = (ms / launches) * 1e-3
+    res_bytes = residual_bytes(n, nnz)
+    achieved = res_bytes / avg_s / 1e9
+    kernels = {}
+    for name, (cnt, tot) in prof.items():
+        if cnt:
+            kernels[name] = {"launches_per_cycle": cnt / args.steps, "avg_us": 1e3 * tot / cnt}
+    roofline = {"bound": "hbm", "kernel": "rows_kernel<ROW_RESIDUAL> (fine grid r = b - A x)",
+                "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "algorithmic_bytes": res_bytes, "avg_launch_us": round(avg_s * 1e6, 2),
+                "level0_kernels": kernels}
+
+    cpu = None
+    if not args.no_cpu:
+        rate, dt, _ = cpu_baseline(args.cpu_size, args.grids, args.cpu_cycles)
+        scale = (args.cpu_size / float(args.size)) ** 3
+        cpu = {"value": round(rate * scale, 5), "unit": "V-cycles/s", "cores": 1, "kind": "port",
+               "sample": "%d V(1,1) red-black cycles of the CPU oracle on %d^3 (%d grids) in %.1f s, "
+                         "scaled by (%d/%d)^3 to %d^3; host has %d cores, the oracle uses 1"
+                         % (args.cpu_cycles, args.cpu_size, args.grids, dt, args.cpu_size, args.size,
+                            args.size, os.cpu_count() or 0)}
+
+    out = {
+        "metric": "V-cycles/sec, 3-D 7-point Poisson %d^3" % args.size,
+        "value": round(args.steps / elapsed, 3),
+        "unit": "V-cycles/s",
+        "n_gpus": 1,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(1e3 * elapsed / args.steps, 4),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {"workload": "3-D 7-point Poisson %d^3, %d-grid V(1,1) cycle, %s Gauss-Seidel, fp64, "
+                               "int32 CSR (BASELINE configs[2])" % (args.size, meta["grids"],
+                                                                    "red-black" if args.smoother == "colour" else args.smoother),
+                   "unknowns": n, "nnz": nnz, "grids": meta["grids"], "pre": pre, "post": post,
+                   "smoother": args.smoother, "hipgraph": bool(args.graph),
+                   "final_residual_norm": norm, "setup_s": round(setup_s, 2)},
+        "roofline": roofline,
+        "cpu_baseline": cpu,
+    }
+    print(json.dumps(out))
+    h.close()
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -1,0 +1,166 @@
+/*
+ * openmg_hip.h — C ABI of libopenmg_hip.so, the MI355X (gfx950) implementation of the
+ * multigrid V-cycle hot path of tsbertalan/openmg.
+ *
+ * The reference is pure Python and has no FFI of its own, so every entry
+ * point below is defined by the reference CALL SITE it replaces; the citation after
+ * "replaces:" is a path under the reference root.  The host side (openmg_amd/, Python,
+ * ctypes) keeps the reference's function names and dict semantics and forwards here.
+ *
+ * Conventions
+ *   - every pointer is a HOST pointer borrowed for the duration of the call unless the
+ *     name ends in _dev; nothing is retained except inside an omg_hierarchy;
+ *   - matrices are CSR: int32 indptr[n_rows+1], int32 indices[nnz], float64 data[nnz];
+ *     column order inside a row is free (SciPy's SpGEMM leaves it unsorted) and row sums
+ *     run in STORED order like the reference's (openmg/solvers.py:63-65);
+ *   - vectors are float64;
+ *   - every function returns OMG_OK (0) or an OMG_ERR_* code; omg_last_error() gives text;
+ *   - there is NO CPU fallback: without a usable GPU every compute call returns
+ *     OMG_ERR_NO_DEVICE.
+ */
+#ifndef OPENMG_HIP_H
+#define OPENMG_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OMG_OK                0
+#define OMG_ERR_INVALID       1   /* bad argument / shape mismatch                         */
+#define OMG_ERR_NO_DEVICE     2   /* no HIP device visible                                 */
+#define OMG_ERR_HIP           3   /* a HIP runtime call failed                             */
+#define OMG_ERR_SINGULAR      4   /* coarse matrix is singular (reference: SuperLU error)  */
+#define OMG_ERR_NO_DIAGONAL   5   /* a row has no stored diagonal (reference: divide by 0) */
+#define OMG_ERR_ALLOC         6
+#define OMG_ERR_UNSUPPORTED   7
+
+/* Smoother orderings.  The reference has exactly one smoother: lexicographic in-place
+ * Gauss-Seidel (openmg/solvers.py:34-75).
+ *   GS_LEX    the same iterate as the reference: rows are level-scheduled (row i runs after
+ *             every coupled row j<i and before every coupled row j>i), so a sweep is a
+ *             sequence of independent row sets — identical arithmetic per row.
+ *   GS_COLOUR greedy multi-colour Gauss-Seidel (red-black on 5/7-point stencils, 8 colours
+ *             on 27-point); equals the reference's sweep on the colour-permuted system.
+ *   JACOBI    weighted Jacobi, x += omega D^-1 (b - A x); no reference counterpart.      */
+#define OMG_SMOOTH_GS_LEX     0
+#define OMG_SMOOTH_GS_COLOUR  1
+#define OMG_SMOOTH_JACOBI     2
+
+typedef struct {
+    int64_t n_rows, n_cols, nnz;
+    const int32_t *indptr;
+    const int32_t *indices;
+    const double  *data;
+} omg_csr;
+
+typedef struct omg_hierarchy omg_hierarchy;   /* device-resident level hierarchy            */
+typedef struct omg_csr_result omg_csr_result; /* device-built CSR waiting to be fetched     */
+
+const char *omg_last_error(void);
+int omg_device_count(int *count);
+int omg_set_device(int device);
+/* Build identification (git-independent): returns a static string. */
+const char *omg_version(void);
+
+/* ---- hierarchy --------------------------------------------------------------------
+ * replaces: the A and R lists built by openmg/__init__.py:103-109 and carried through
+ * every mgCycle call (openmg/__init__.py:151).  A[0..n_levels-1] are the level operators,
+ * R[0..n_levels-2] the restrictions (R[l]: level l -> l+1); prolongation is R[l]^T
+ * (openmg/__init__.py:214).  The coarsest operator A[n_levels-1] is factorised once here
+ * (the reference refactorises it on every cycle, openmg/solvers.py:23).
+ * n_levels == 1 is allowed (direct solve only).                                          */
+int omg_hierarchy_create(int n_levels, const omg_csr *A, const omg_csr *R,
+                         int smoother, double omega, omg_hierarchy **out);
+int omg_hierarchy_destroy(omg_hierarchy *h);
+/* Run on a caller-owned hipStream_t instead of the hierarchy's own stream (NULL = own). */
+int omg_hierarchy_set_stream(omg_hierarchy *h, void *hip_stream);
+int omg_hierarchy_sync(omg_hierarchy *h);
+/* Rows of level l; number of independent row sets one smoother sweep is split into. */
+int omg_hierarchy_level_rows(const omg_hierarchy *h, int level, int64_t *n_rows);
+int omg_hierarchy_level_sets(const omg_hierarchy *h, int level, int64_t *n_sets);
+
+/* replaces: openmg.mgCycle(A, b, level, R, parameters, initial) — openmg/__init__.py:151-236.
+ * One V-cycle entered at `level` with pre/post = parameters['preIterations'|'postIterations'].
+ * x holds `initial` on entry (zeros for initial=None, :191-192) and uOut on return.
+ * *norm (nullable) = ||b - A[level] uOut||_2 (:227), 0 when level is the coarsest (:232). */
+int omg_vcycle(omg_hierarchy *h, int level, const double *b, double *x,
+               int pre, int post, double *norm);
+
+/* replaces: the cycle loop of openmg.mgSolve — openmg/__init__.py:112-138.  At least one
+ * cycle, then until cycle >= max_cycles (if max_cycles > 0) or norm < threshold (if
+ * threshold > 0).  x: initial iterate in, solution out.  The both-off ValueError
+ * (:118-119) is raised by the Python caller after the first cycle; here both-off is
+ * OMG_ERR_INVALID.                                                                        */
+int omg_solve(omg_hierarchy *h, const double *b, double *x, int pre, int post,
+              int max_cycles, double threshold, int *cycles_done, double *norm);
+
+/* Device-resident variants used by bench.py and by repeated mgCycle calls: level-0 b and x
+ * live in HBM between calls.                                                             */
+int omg_resident_load(omg_hierarchy *h, const double *b, const double *x0 /* NULL = zeros */);
+int omg_resident_cycle(omg_hierarchy *h, int pre, int post, double *norm /* NULL = no readback */);
+int omg_resident_fetch(omg_hierarchy *h, double *x);
+/* Capture one resident cycle into a hipGraph and replay it on later omg_resident_cycle
+ * calls with the same (pre, post).  enable = 0 drops the graph.                          */
+int omg_resident_use_graph(omg_hierarchy *h, int enable);
+
+/* Per-kernel timing of level-0 launches with hipEvents on the hierarchy's stream.
+ * Classes: 0 smoother set-sweep, 1 residual, 2 restrict, 3 prolong-add, 4 residual+norm.
+ * omg_profile_read syncs and returns, per class, launches and total milliseconds since
+ * omg_profile_enable(h, 1).                                                               */
+#define OMG_PROFILE_CLASSES 5
+int omg_profile_enable(omg_hierarchy *h, int enable);
+int omg_profile_read(omg_hierarchy *h, int64_t *launches, double *total_ms);
+
+/* ---- single operations on one level of a hierarchy (kernel-level parity tests) ------- */
+/* replaces: solvers.smooth(A[l], b, x, iterations) — openmg/solvers.py:28-29; x in place. */
+int omg_level_smooth(omg_hierarchy *h, int level, const double *b, double *x, int iterations);
+/* replaces: tools.getresidual(b, A[l], x, N) — openmg/tools.py:12-15 (+ norm, __init__.py:227). */
+int omg_level_residual(omg_hierarchy *h, int level, const double *b, const double *x,
+                       double *r, double *norm /* nullable */);
+/* replaces: flexibleMmult(R[l], residual) — openmg/__init__.py:210. */
+int omg_level_restrict(omg_hierarchy *h, int level, const double *fine, double *coarse);
+/* replaces: uApx + flexibleMmult(R[l].transpose(), coarseCorrection) — openmg/__init__.py:214,220,224. */
+int omg_level_prolong_add(omg_hierarchy *h, int level, const double *coarse, double *fine_inout);
+/* replaces: solvers.coarseSolve(A[-1], b) — openmg/solvers.py:16-26. */
+int omg_coarse_solve(omg_hierarchy *h, const double *b, double *x);
+
+/* ---- standalone operations ----------------------------------------------------------- */
+/* replaces: tools.flexibleMmult(A, x) for sparse A, dense vector x — openmg/tools.py:26. */
+int omg_spmv(const omg_csr *A, const double *x, double *y);
+/* replaces: tools.getresidual — openmg/tools.py:12-15; *norm nullable. */
+int omg_residual(const omg_csr *A, const double *b, const double *x, double *r, double *norm);
+/* replaces: solvers.gaussSeidel(A, b, x, iterations, threshold) — openmg/solvers.py:34-75,
+ * incl. smoothToThreshold (:31-32).  iterations < 0 = None, threshold < 0 = None; both
+ * None = one sweep (:39-40).  The norm test runs before the first sweep and after every
+ * sweep (:43-54).  x in place.  *sweeps_done nullable.                                    */
+int omg_gauss_seidel(const omg_csr *A, const double *b, double *x, int smoother, double omega,
+                     int iterations, double threshold, int *sweeps_done);
+/* replaces: solvers.coarseSolve(A, b) for a one-off solve — openmg/solvers.py:16-26. */
+int omg_direct_solve(const omg_csr *A, const double *b, double *x);
+
+/* replaces: flexibleMmult(flexibleMmult(R, A), R.T) — openmg/operators.py:184-186.
+ * Galerkin triple product on the device.  Two steps because the output size is unknown:
+ * omg_rap() computes it and reports the shape, omg_csr_result_fetch() copies it into
+ * caller-allocated arrays (columns sorted ascending inside each row) and frees it.       */
+int omg_rap(const omg_csr *R, const omg_csr *A, omg_csr_result **out,
+            int64_t *n_rows, int64_t *n_cols, int64_t *nnz);
+/* replaces: tools.flexibleMmult(X, Y) with both operands sparse — openmg/tools.py:26 (SciPy
+ * csr_matmat).  C = X Y on the device; every C(i,j) is accumulated in SciPy's order.      */
+int omg_spgemm(const omg_csr *X, const omg_csr *Y, omg_csr_result **out,
+               int64_t *n_rows, int64_t *n_cols, int64_t *nnz);
+int omg_csr_result_fetch(omg_csr_result *res, int32_t *indptr, int32_t *indices, double *data);
+int omg_csr_result_free(omg_csr_result *res);
+
+/* replaces: operators.restriction(shape) — openmg/operators.py:15-89 — built on the device.
+ * shape[0..dim-1], dim in 1..3; same index quirks as the reference (second-axis offset is
+ * shape[0], third-axis offset shape[0]*shape[1]).  Output arrays are caller-allocated:
+ * indptr[n/2^dim + 1], indices[n], data[n] with n = prod(shape) when all extents are even. */
+int omg_restriction(int dim, const int64_t *shape, int32_t *indptr, int32_t *indices,
+                    double *data, int64_t *n_rows, int64_t *nnz);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OPENMG_HIP_H */

@@ -1,0 +1,185 @@
+"""
+openmg_amd — geometric multigrid V-cycle on AMD MI355X (gfx950), presenting the public
+names of tsbertalan/openmg: mgSolve, mgCycle (alias mg_cycle), defaults, smooth,
+smoothToThreshold, coarseSolve, tools, operators, solvers.
+
+All numerical work runs in hand-written HIP kernels behind libopenmg_hip.so
+(include/openmg_hip.h); this package is the NumPy/SciPy-facing host side.  There is no
+CPU fallback: without the library or without a GPU the calls raise.
+
+Extra keys understood in the `parameters` dict (ignored by the reference):
+    'smoother'  'gs' (default: the reference's lexicographic Gauss-Seidel iterate),
+                'colour' (multi-colour GS; red-black on 5/7-point stencils) or 'jacobi'
+    'omega'     relaxation weight for 'jacobi' (default 2/3)
+"""
+import numpy as np
+import scipy.sparse as sp
+
+from . import _hip
+from . import operators, solvers, tools
+from .solvers import coarseSolve, smooth, smoothToThreshold
+
+__all__ = ["mgSolve", "mgCycle", "mg_cycle", "defaults", "smooth", "smoothToThreshold",
+           "coarseSolve", "tools", "operators", "solvers", "clear_cache"]
+
+# Same keys and values as the reference (openmg/__init__.py:16-27).  Like there, this dict
+# is module-global and mgSolve writes 'coarsestLevel' into it on every call.
+defaults = {
+    "problemShape": (200,),
+    "gridLevels": 2,
+    "verbose": False,
+    "threshold": 0.1,
+    "cycles": 0,
+    "preIterations": 1,
+    "postIterations": 0,
+    "dense": False,
+    "giveInfo": False,
+    "minSize": 8,
+}
+
+_DEFAULT_OMEGA = 2.0 / 3.0
+
+
+def _smoother_of(parameters):
+    kind = parameters.get("smoother", "gs")
+    code = _hip.smoother_code(kind)
+    omega = float(parameters.get("omega", _DEFAULT_OMEGA if code == _hip.SMOOTH_JACOBI else 1.0))
+    return code, omega
+
+
+# ---- device hierarchy cache for repeated mgCycle calls ---------------------------------------
+# mgCycle receives the A and R lists on every call (openmg/__init__.py:151); uploading
+# them each time would dominate.  The device copy is keyed on the identity of the list
+# members and of their buffers; clear_cache() drops it (do that after editing a matrix in
+# place).
+_cache = {}
+_CACHE_SLOTS = 2
+
+
+def _fingerprint(A, R, n_levels, code, omega):
+    def one(M):
+        if sp.issparse(M):
+            return (id(M), M.shape, M.nnz, M.data.ctypes.data if M.nnz else 0)
+        return (id(M), np.shape(M))
+    return (tuple(one(M) for M in A[:n_levels]), tuple(one(M) for M in R[:n_levels - 1]), code, omega)
+
+
+def _hierarchy_for(A, R, n_levels, code, omega):
+    key = _fingerprint(A, R, n_levels, code, omega)
+    h = _cache.get(key)
+    if h is None:
+        while len(_cache) >= _CACHE_SLOTS:
+            _cache.pop(next(iter(_cache))).close()
+        h = _hip.Hierarchy(list(A[:n_levels]), list(R[:n_levels - 1]), smoother=code, omega=omega)
+        _cache[key] = h
+    return h
+
+
+def clear_cache():
+    """Free the device hierarchies kept for repeated mgCycle calls."""
+    while _cache:
+        _cache.popitem()[1].close()
+
+
+# ---- the two public drivers ---------------------------------------------------------------
+def mgSolve(A_in, b, parameters):
+    """Solve A_in u = b by V-cycles on the GPU; same contract as openmg.mgSolve
+    (openmg/__init__.py:28-148).
+
+    parameters must hold 'problemShape' and 'gridLevels'; the optional keys and their
+    defaults are those of `openmg_amd.defaults`.  gridLevels = g builds g restriction
+    operators, i.e. g+1 grids, unless 'minSize' stops the coarsening earlier.  At least one
+    cycle is run; cycling stops when 'cycles' (> 0) is reached or the absolute residual
+    2-norm falls below 'threshold' (> 0); if both are <= 0 a ValueError is raised (after the
+    first cycle, as in the reference).  The caller's dict is completed with the defaults
+    and its 'coarsestLevel' is overwritten with the depth actually built.
+
+    Returns u, or (u, infoDict) when parameters['giveInfo'] is true; infoDict holds
+    'cycle', 'norm', and the hierarchies 'R' and 'A' as SciPy CSR lists.
+    """
+    problemShape = parameters["problemShape"]
+    gridLevels = parameters["gridLevels"]
+    defaults["coarsestLevel"] = gridLevels - 1
+    tools.dictUpdateNoClobber(defaults, parameters)
+    verbose = parameters["verbose"]
+    dense = parameters["dense"]
+    code, omega = _smoother_of(parameters)
+
+    R = operators.restrictionList(problemShape, parameters["coarsestLevel"], parameters["minSize"],
+                                  dense=dense, verbose=verbose)
+    parameters["coarsestLevel"] = len(R)
+    A = operators.coeffecientList(A_in, R, dense=dense, verbose=verbose)
+
+    pre, post = parameters["preIterations"], parameters["postIterations"]
+    hierarchy = _hip.Hierarchy(A, R, smoother=code, omega=omega)
+    try:
+        hierarchy.resident_load(np.asarray(b, dtype=np.float64).reshape(-1))
+        if verbose:
+            _announce_descent(len(R))
+        norm = hierarchy.resident_cycle(pre, post)
+        cycle = 1
+        if verbose:
+            print("Residual norm from cycle %d is %f." % (cycle, norm))
+        if parameters["threshold"] <= 0 and parameters["cycles"] <= 0:
+            raise ValueError("Either parameters['threshold'] or parameters['cycles'] must be > 0.")
+
+        def finished():
+            by_count = parameters.get("cycles", 0) > 0 and cycle >= parameters["cycles"]
+            by_norm = "threshold" in parameters and parameters["threshold"] > 0 and norm < parameters["threshold"]
+            return by_count or by_norm
+
+        while not finished():
+            if verbose:
+                print("cycle %i < cycles %i" % (cycle, parameters["cycles"]))
+                _announce_descent(len(R))
+            cycle += 1
+            norm = hierarchy.resident_cycle(pre, post)
+            if verbose:
+                print("Residual norm from cycle %d is %f." % (cycle, norm))
+        result = hierarchy.resident_fetch()
+    finally:
+        hierarchy.close()
+
+    infoDict = {"norm": norm, "cycle": cycle, "R": R, "A": A}
+    if verbose:
+        print("Returning mgSolve after %i cycle(s) with norm %f" % (cycle, norm))
+    if parameters["giveInfo"]:
+        return result, infoDict
+    return result
+
+
+def _announce_descent(depth):
+    for level in range(depth):
+        print(level * " " + "calling mgCycle at level %i" % level)
+    print(depth * " " + "direct solving at level %i" % depth)
+
+
+def mgCycle(A, b, level, R, parameters, initial=None):
+    """One V-cycle entered at `level`; same contract as openmg.mgCycle
+    (openmg/__init__.py:151-236): pre-smooth, restrict the residual, recurse, prolong and
+    correct, post-smooth; direct solve at parameters['coarsestLevel'].
+
+    A, R are the lists made by operators.coeffecientList / restrictionList (any CSR lists
+    of matching shapes work).  Returns (uOut, {'norm': ||b - A[level] uOut||_2}); the norm
+    is 0 when `level` is the coarsest.  The device copy of the hierarchy is cached between
+    calls (see clear_cache)."""
+    coarsest = parameters["coarsestLevel"]
+    if coarsest >= len(A) or coarsest > len(R):
+        raise IndexError("parameters['coarsestLevel'] = %d but only %d operators / %d restrictions given"
+                         % (coarsest, len(A), len(R)))
+    code, omega = _smoother_of(parameters)
+    b = np.asarray(b, dtype=np.float64).reshape(-1)
+    if level >= coarsest:
+        # the reference's `else` branch (:229-234): direct solve with A[level], norm 0
+        return solvers.coarseSolve(A[level], b), {"norm": 0}
+    hierarchy = _hierarchy_for(A, R, coarsest + 1, code, omega)
+    x = np.zeros(b.size) if initial is None else np.array(np.asarray(initial, dtype=np.float64).reshape(-1), order="C")
+    if parameters.get("verbose", False):
+        for l in range(level, coarsest):
+            print(l * " " + "calling mgCycle at level %i" % l)
+        print(coarsest * " " + "direct solving at level %i" % coarsest)
+    norm = hierarchy.vcycle(b, x, parameters["preIterations"], parameters["postIterations"], level=level)
+    return x, {"norm": norm}
+
+
+mg_cycle = mgCycle   # BASELINE.json's spelling

@@ -1,0 +1,387 @@
+"""ctypes binding of libopenmg_hip.so (C ABI: include/openmg_hip.h).
+
+There is deliberately NO fallback: if the shared library is missing, or no MI355X is
+visible when a compute entry point is called, an exception is raised.
+"""
+import ctypes
+import os
+
+import numpy as np
+import scipy.sparse as sp
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libopenmg_hip.so")
+
+OMG_OK = 0
+ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_SINGULAR, ERR_NO_DIAGONAL, ERR_ALLOC, ERR_UNSUPPORTED = range(1, 8)
+SMOOTH_GS_LEX, SMOOTH_GS_COLOUR, SMOOTH_JACOBI = 0, 1, 2
+PROFILE_CLASSES = 5
+PROFILE_NAMES = ("smoother_set_sweep", "residual", "restrict", "prolong_add", "residual_norm")
+
+SMOOTHERS = {
+    "gs": SMOOTH_GS_LEX, "lex": SMOOTH_GS_LEX, "gauss-seidel": SMOOTH_GS_LEX, "gaussSeidel": SMOOTH_GS_LEX,
+    "colour": SMOOTH_GS_COLOUR, "color": SMOOTH_GS_COLOUR, "rbgs": SMOOTH_GS_COLOUR,
+    "red-black": SMOOTH_GS_COLOUR, "multicolour": SMOOTH_GS_COLOUR,
+    "jacobi": SMOOTH_JACOBI, "weighted-jacobi": SMOOTH_JACOBI,
+}
+
+
+class HipError(RuntimeError):
+    """A libopenmg_hip.so call failed; .code holds the OMG_ERR_* value."""
+
+    def __init__(self, code, message):
+        super().__init__("libopenmg_hip: %s (code %d)" % (message, code))
+        self.code = code
+
+
+class CsrView(ctypes.Structure):
+    _fields_ = [("n_rows", ctypes.c_int64), ("n_cols", ctypes.c_int64), ("nnz", ctypes.c_int64),
+                ("indptr", ctypes.c_void_p), ("indices", ctypes.c_void_p), ("data", ctypes.c_void_p)]
+
+
+_P = ctypes.c_void_p
+_I = ctypes.c_int
+_D = ctypes.c_double
+_PP = ctypes.POINTER(ctypes.c_void_p)
+_CSR = ctypes.POINTER(CsrView)
+_I64P = ctypes.POINTER(ctypes.c_int64)
+_IP = ctypes.POINTER(ctypes.c_int)
+_DP = ctypes.POINTER(ctypes.c_double)
+
+# name -> (restype, argtypes).  Must list EVERY symbol include/openmg_hip.h declares
+# (tests/test_cabi_symbols.py checks that against the header).
+SIGNATURES = {
+    "omg_last_error": (ctypes.c_char_p, []),
+    "omg_version": (ctypes.c_char_p, []),
+    "omg_device_count": (_I, [_IP]),
+    "omg_set_device": (_I, [_I]),
+    "omg_hierarchy_create": (_I, [_I, _CSR, _CSR, _I, _D, _PP]),
+    "omg_hierarchy_destroy": (_I, [_P]),
+    "omg_hierarchy_set_stream": (_I, [_P, _P]),
+    "omg_hierarchy_sync": (_I, [_P]),
+    "omg_hierarchy_level_rows": (_I, [_P, _I, _I64P]),
+    "omg_hierarchy_level_sets": (_I, [_P, _I, _I64P]),
+    "omg_vcycle": (_I, [_P, _I, _P, _P, _I, _I, _DP]),
+    "omg_solve": (_I, [_P, _P, _P, _I, _I, _I, _D, _IP, _DP]),
+    "omg_resident_load": (_I, [_P, _P, _P]),
+    "omg_resident_cycle": (_I, [_P, _I, _I, _DP]),
+    "omg_resident_fetch": (_I, [_P, _P]),
+    "omg_resident_use_graph": (_I, [_P, _I]),
+    "omg_profile_enable": (_I, [_P, _I]),
+    "omg_profile_read": (_I, [_P, _I64P, _DP]),
+    "omg_level_smooth": (_I, [_P, _I, _P, _P, _I]),
+    "omg_level_residual": (_I, [_P, _I, _P, _P, _P, _DP]),
+    "omg_level_restrict": (_I, [_P, _I, _P, _P]),
+    "omg_level_prolong_add": (_I, [_P, _I, _P, _P]),
+    "omg_coarse_solve": (_I, [_P, _P, _P]),
+    "omg_spmv": (_I, [_CSR, _P, _P]),
+    "omg_residual": (_I, [_CSR, _P, _P, _P, _DP]),
+    "omg_gauss_seidel": (_I, [_CSR, _P, _P, _I, _D, _I, _D, _IP]),
+    "omg_direct_solve": (_I, [_CSR, _P, _P]),
+    "omg_rap": (_I, [_CSR, _CSR, _PP, _I64P, _I64P, _I64P]),
+    "omg_spgemm": (_I, [_CSR, _CSR, _PP, _I64P, _I64P, _I64P]),
+    "omg_csr_result_fetch": (_I, [_P, _P, _P, _P]),
+    "omg_csr_result_free": (_I, [_P]),
+    "omg_restriction": (_I, [_I, _I64P, _P, _P, _P, _I64P, _I64P]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load the shared library once.  Raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                "%s is missing: build it with `make -C openmg_amd/csrc` (or __graft_entry__.build()). "
+                "openmg_amd has no CPU fallback." % LIB_PATH)
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def check(code):
+    if code != OMG_OK:
+        raise HipError(code, lib().omg_last_error().decode("utf-8", "replace"))
+
+
+def device_count():
+    n = ctypes.c_int(0)
+    check(lib().omg_device_count(ctypes.byref(n)))
+    return n.value
+
+
+def require_gpu():
+    if device_count() <= 0:
+        raise HipError(ERR_NO_DEVICE, "no MI355X / HIP device visible; openmg_amd has no CPU fallback")
+
+
+def smoother_code(kind):
+    if isinstance(kind, int):
+        return kind
+    try:
+        return SMOOTHERS[kind]
+    except KeyError:
+        raise ValueError("unknown smoother %r (choose from %s)" % (kind, sorted(set(SMOOTHERS))))
+
+
+def as_csr(A):
+    """CSR with int32 index arrays / float64 data; stored column order is kept as is."""
+    if not sp.isspmatrix_csr(A):
+        A = sp.csr_matrix(A)
+    if A.nnz >= 2 ** 31 - 1 or max(A.shape) >= 2 ** 31 - 1:
+        raise ValueError("operator too large for int32 indices; shard it first")
+    if A.indptr.dtype != np.int32 or A.indices.dtype != np.int32 or A.data.dtype != np.float64 \
+            or not (A.indptr.flags.c_contiguous and A.indices.flags.c_contiguous and A.data.flags.c_contiguous):
+        A = sp.csr_matrix((np.ascontiguousarray(A.data, dtype=np.float64),
+                           np.ascontiguousarray(A.indices, dtype=np.int32),
+                           np.ascontiguousarray(A.indptr, dtype=np.int32)), shape=A.shape)
+    return A
+
+
+def csr_view(A):
+    """(CsrView, keepalive) for a CSR matrix prepared by as_csr()."""
+    v = CsrView(A.shape[0], A.shape[1], A.nnz, A.indptr.ctypes.data, A.indices.ctypes.data, A.data.ctypes.data)
+    return v
+
+
+def vec(x, n=None, copy=False):
+    """Contiguous float64 1-D array (flattening (n,1) columns like the reference accepts)."""
+    a = np.asarray(x, dtype=np.float64)
+    a = a.reshape(-1)
+    if copy or not a.flags.c_contiguous:
+        a = np.array(a, dtype=np.float64, order="C", copy=True)
+    if n is not None and a.size != n:
+        raise ValueError("vector has %d entries, expected %d" % (a.size, n))
+    return a
+
+
+class Hierarchy:
+    """Device-resident A/R hierarchy (omg_hierarchy)."""
+
+    def __init__(self, A_list, R_list, smoother="gs", omega=1.0):
+        if len(R_list) != len(A_list) - 1:
+            raise ValueError("need len(R) == len(A) - 1")
+        self._A = [as_csr(M) for M in A_list]
+        self._R = [as_csr(M) for M in R_list]
+        arrA = (CsrView * len(self._A))(*[csr_view(M) for M in self._A])
+        arrR = (CsrView * max(len(self._R), 1))(*[csr_view(M) for M in self._R])
+        self.smoother = smoother_code(smoother)
+        self.omega = float(omega)
+        self.n_levels = len(self._A)
+        self.sizes = [M.shape[0] for M in self._A]
+        h = ctypes.c_void_p()
+        check(lib().omg_hierarchy_create(self.n_levels, arrA, arrR, self.smoother, self.omega, ctypes.byref(h)))
+        self._h = h
+        # the device copy is complete; the host copies are only kept for .sizes
+        self._A = self._R = None
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().omg_hierarchy_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # -- whole cycles -------------------------------------------------------------------
+    def vcycle(self, b, x, pre, post, level=0):
+        """x is updated in place; returns the residual norm."""
+        n = self.sizes[level]
+        b = vec(b, n)
+        assert x.dtype == np.float64 and x.flags.c_contiguous and x.size == n
+        norm = ctypes.c_double(0.0)
+        check(lib().omg_vcycle(self._h, level, b.ctypes.data, x.ctypes.data, int(pre), int(post), ctypes.byref(norm)))
+        return norm.value
+
+    def solve(self, b, x, pre, post, max_cycles, threshold):
+        n = self.sizes[0]
+        b = vec(b, n)
+        assert x.dtype == np.float64 and x.flags.c_contiguous and x.size == n
+        cycles = ctypes.c_int(0)
+        norm = ctypes.c_double(0.0)
+        check(lib().omg_solve(self._h, b.ctypes.data, x.ctypes.data, int(pre), int(post), int(max_cycles),
+                              float(threshold), ctypes.byref(cycles), ctypes.byref(norm)))
+        return cycles.value, norm.value
+
+    # -- resident ------------------------------------------------------------------------
+    def resident_load(self, b, x0=None):
+        b = vec(b, self.sizes[0])
+        x0p = None if x0 is None else vec(x0, self.sizes[0]).ctypes.data
+        check(lib().omg_resident_load(self._h, b.ctypes.data, x0p))
+
+    def resident_cycle(self, pre, post, want_norm=True):
+        if want_norm:
+            norm = ctypes.c_double(0.0)
+            check(lib().omg_resident_cycle(self._h, int(pre), int(post), ctypes.byref(norm)))
+            return norm.value
+        check(lib().omg_resident_cycle(self._h, int(pre), int(post), None))
+        return None
+
+    def resident_fetch(self):
+        x = np.empty(self.sizes[0], dtype=np.float64)
+        check(lib().omg_resident_fetch(self._h, x.ctypes.data))
+        return x
+
+    def use_graph(self, enable=True):
+        check(lib().omg_resident_use_graph(self._h, 1 if enable else 0))
+
+    def set_stream(self, hip_stream):
+        check(lib().omg_hierarchy_set_stream(self._h, ctypes.c_void_p(hip_stream or 0)))
+
+    def sync(self):
+        check(lib().omg_hierarchy_sync(self._h))
+
+    def level_sets(self, level):
+        v = ctypes.c_int64(0)
+        check(lib().omg_hierarchy_level_sets(self._h, level, ctypes.byref(v)))
+        return v.value
+
+    def profile_enable(self, enable=True):
+        check(lib().omg_profile_enable(self._h, 1 if enable else 0))
+
+    def profile_read(self):
+        n = (ctypes.c_int64 * PROFILE_CLASSES)()
+        ms = (ctypes.c_double * PROFILE_CLASSES)()
+        check(lib().omg_profile_read(self._h, n, ms))
+        return {PROFILE_NAMES[i]: (int(n[i]), float(ms[i])) for i in range(PROFILE_CLASSES)}
+
+    # -- single operations -----------------------------------------------------------------
+    def smooth(self, level, b, x, iterations):
+        n = self.sizes[level]
+        b = vec(b, n)
+        assert x.dtype == np.float64 and x.flags.c_contiguous and x.size == n
+        check(lib().omg_level_smooth(self._h, level, b.ctypes.data, x.ctypes.data, int(iterations)))
+        return x
+
+    def residual(self, level, b, x, want_norm=False):
+        n = self.sizes[level]
+        b, x = vec(b, n), vec(x, n)
+        r = np.empty(n)
+        if want_norm:
+            norm = ctypes.c_double(0.0)
+            check(lib().omg_level_residual(self._h, level, b.ctypes.data, x.ctypes.data, r.ctypes.data, ctypes.byref(norm)))
+            return r, norm.value
+        check(lib().omg_level_residual(self._h, level, b.ctypes.data, x.ctypes.data, r.ctypes.data, None))
+        return r
+
+    def restrict(self, level, fine):
+        fine = vec(fine, self.sizes[level])
+        out = np.empty(self.sizes[level + 1])
+        check(lib().omg_level_restrict(self._h, level, fine.ctypes.data, out.ctypes.data))
+        return out
+
+    def prolong_add(self, level, coarse, fine):
+        coarse = vec(coarse, self.sizes[level + 1])
+        out = vec(fine, self.sizes[level], copy=True)
+        check(lib().omg_level_prolong_add(self._h, level, coarse.ctypes.data, out.ctypes.data))
+        return out
+
+    def coarse_solve(self, b):
+        b = vec(b, self.sizes[-1])
+        x = np.empty(self.sizes[-1])
+        check(lib().omg_coarse_solve(self._h, b.ctypes.data, x.ctypes.data))
+        return x
+
+
+# ---- standalone ------------------------------------------------------------------------
+def spmv(A, x):
+    A = as_csr(A)
+    x = vec(x, A.shape[1])
+    y = np.empty(A.shape[0])
+    v = csr_view(A)
+    check(lib().omg_spmv(ctypes.byref(v), x.ctypes.data, y.ctypes.data))
+    return y
+
+
+def residual(A, b, x, want_norm=False):
+    A = as_csr(A)
+    b, x = vec(b, A.shape[0]), vec(x, A.shape[1])
+    r = np.empty(A.shape[0])
+    v = csr_view(A)
+    if want_norm:
+        norm = ctypes.c_double(0.0)
+        check(lib().omg_residual(ctypes.byref(v), b.ctypes.data, x.ctypes.data, r.ctypes.data, ctypes.byref(norm)))
+        return r, norm.value
+    check(lib().omg_residual(ctypes.byref(v), b.ctypes.data, x.ctypes.data, r.ctypes.data, None))
+    return r
+
+
+def gauss_seidel(A, b, x, smoother="gs", omega=1.0, iterations=None, threshold=None):
+    """x (contiguous float64) is updated in place; returns the number of sweeps done."""
+    A = as_csr(A)
+    b = vec(b, A.shape[0])
+    assert x.dtype == np.float64 and x.flags.c_contiguous and x.size == A.shape[0]
+    v = csr_view(A)
+    done = ctypes.c_int(0)
+    check(lib().omg_gauss_seidel(ctypes.byref(v), b.ctypes.data, x.ctypes.data, smoother_code(smoother),
+                                 float(omega), -1 if iterations is None else int(iterations),
+                                 -1.0 if threshold is None else float(threshold), ctypes.byref(done)))
+    return done.value
+
+
+def direct_solve(A, b):
+    A = as_csr(A)
+    b = vec(b, A.shape[0])
+    x = np.empty(A.shape[0])
+    v = csr_view(A)
+    check(lib().omg_direct_solve(ctypes.byref(v), b.ctypes.data, x.ctypes.data))
+    return x
+
+
+def _product(fn, X, Y):
+    X, Y = as_csr(X), as_csr(Y)
+    vx, vy = csr_view(X), csr_view(Y)
+    res = ctypes.c_void_p()
+    nr, nc, nnz = ctypes.c_int64(0), ctypes.c_int64(0), ctypes.c_int64(0)
+    check(fn(ctypes.byref(vx), ctypes.byref(vy), ctypes.byref(res), ctypes.byref(nr),
+             ctypes.byref(nc), ctypes.byref(nnz)))
+    indptr = np.empty(nr.value + 1, dtype=np.int32)
+    indices = np.empty(max(nnz.value, 0), dtype=np.int32)
+    data = np.empty(max(nnz.value, 0), dtype=np.float64)
+    check(lib().omg_csr_result_fetch(res, indptr.ctypes.data, indices.ctypes.data, data.ctypes.data))
+    return sp.csr_matrix((data, indices, indptr), shape=(nr.value, nc.value))
+
+
+def rap(R, A):
+    """Galerkin product (R A) R^T on the device -> scipy CSR (sorted columns)."""
+    return _product(lib().omg_rap, R, A)
+
+
+def spgemm(X, Y):
+    """Sparse product X Y on the device -> scipy CSR (sorted columns)."""
+    return _product(lib().omg_spgemm, X, Y)
+
+
+def restriction(shape):
+    """operators.restriction(shape) built on the device -> scipy CSR."""
+    shape = tuple(int(s) for s in shape)
+    dim = len(shape)
+    N = int(np.prod(shape))
+    n = N // (2 ** dim)
+    arr = (ctypes.c_int64 * dim)(*shape)
+    indptr = np.empty(n + 1, dtype=np.int32)
+    indices = np.empty(n * (2 ** dim), dtype=np.int32)
+    data = np.empty(n * (2 ** dim), dtype=np.float64)
+    nr, nnz = ctypes.c_int64(0), ctypes.c_int64(0)
+    check(lib().omg_restriction(dim, arr, indptr.ctypes.data, indices.ctypes.data, data.ctypes.data,
+                                ctypes.byref(nr), ctypes.byref(nnz)))
+    k = nnz.value
+    if k and int(indices[:k].max()) >= N:
+        # the reference's LIL assignment raises the same for shapes its offsets overrun
+        raise IndexError("column index (%d) out of range" % int(indices[:k].max()))
+    return sp.csr_matrix((data[:k], indices[:k], indptr[:nr.value + 1]), shape=(nr.value, N))

@@ -1,0 +1,153 @@
+// Shared declarations for libopenmg_hip.so (MI355X / gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/openmg_hip.h"
+
+namespace omg {
+
+// ---- errors -------------------------------------------------------------------------
+struct Error : std::runtime_error {
+    int code;
+    Error(int c, const std::string &m) : std::runtime_error(m), code(c) {}
+};
+void set_last_error(const std::string &m);
+
+#define OMG_HIP(call)                                                                       \
+    do {                                                                                    \
+        hipError_t e_ = (call);                                                             \
+        if (e_ != hipSuccess)                                                               \
+            throw omg::Error(e_ == hipErrorOutOfMemory ? OMG_ERR_ALLOC : OMG_ERR_HIP,       \
+                             std::string(#call) + ": " + hipGetErrorString(e_));            \
+    } while (0)
+
+#define OMG_REQUIRE(cond, msg)                                                              \
+    do {                                                                                    \
+        if (!(cond)) throw omg::Error(OMG_ERR_INVALID, std::string(msg));                   \
+    } while (0)
+
+void require_device();   // throws OMG_ERR_NO_DEVICE when no GPU is visible
+
+// ---- device buffers -----------------------------------------------------------------
+// Plain hipMalloc RAII.  Every allocation gets 64 bytes of slack so that the 16-byte
+// vector loads of the row kernels may run past the logical end of an array.
+template <typename T>
+struct DevBuf {
+    T *p = nullptr;
+    size_t n = 0;
+    DevBuf() = default;
+    explicit DevBuf(size_t count) { alloc(count); }
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    DevBuf(DevBuf &&o) noexcept : p(o.p), n(o.n) { o.p = nullptr; o.n = 0; }
+    DevBuf &operator=(DevBuf &&o) noexcept {
+        if (this != &o) { release(); p = o.p; n = o.n; o.p = nullptr; o.n = 0; }
+        return *this;
+    }
+    ~DevBuf() { release(); }
+    void alloc(size_t count) {
+        release();
+        n = count;
+        OMG_HIP(hipMalloc(reinterpret_cast<void **>(&p), count * sizeof(T) + 64));
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+    void upload(const T *host, size_t count, hipStream_t s) {
+        if (count) OMG_HIP(hipMemcpyAsync(p, host, count * sizeof(T), hipMemcpyHostToDevice, s));
+    }
+    void download(T *host, size_t count, hipStream_t s) const {
+        if (count) OMG_HIP(hipMemcpyAsync(host, p, count * sizeof(T), hipMemcpyDeviceToHost, s));
+    }
+    void zero(hipStream_t s) { if (n) OMG_HIP(hipMemsetAsync(p, 0, n * sizeof(T), s)); }
+};
+
+// ---- host-side CSR (setup only) -----------------------------------------------------
+struct HostCsr {
+    int64_t n_rows = 0, n_cols = 0, nnz = 0;
+    std::vector<int32_t> indptr, indices;
+    std::vector<double> data;
+};
+
+// A smoother ordering: rows renumbered so that each independent set is a contiguous range.
+//   perm[new] = old;  sets = offsets into the new numbering (size n_sets + 1).
+struct Ordering {
+    std::vector<int32_t> perm, inv;
+    std::vector<int64_t> sets;
+    bool identity = true;
+};
+
+// setup_host.cpp
+void validate_csr(const omg_csr &A, const char *what);
+Ordering make_ordering(const omg_csr &A, int smoother);
+HostCsr permute_csr(const omg_csr &A, const int32_t *row_perm /* new->old or null */,
+                    const int32_t *col_inv /* old->new or null */);
+HostCsr transpose_csr(const HostCsr &A);
+// Row blocks for the streaming kernels: greedy split of each set into blocks of at most
+// `max_rows` rows and `max_nnz` entries (a single longer row gets a block of its own).
+void make_row_blocks(const std::vector<int32_t> &indptr, const std::vector<int64_t> &sets,
+                     int max_rows, int max_nnz, std::vector<int32_t> &blk_rows,
+                     std::vector<int64_t> &set_blk);
+
+// ---- device CSR ---------------------------------------------------------------------
+constexpr int ROWBLK_THREADS = 256;   // threads per workgroup of the row kernels
+constexpr int ROWBLK_ROWS = 256;      // <= one row per thread
+constexpr int ROWBLK_NNZ = 2048;      // entries staged through LDS per workgroup
+
+struct DevCsr {
+    int64_t n_rows = 0, n_cols = 0, nnz = 0;
+    DevBuf<int32_t> indptr, indices;
+    DevBuf<double> data;
+    DevBuf<int32_t> blk_rows;          // first row of every row block (+ end sentinel)
+    std::vector<int64_t> set_blk;      // block offsets of the independent sets (host)
+    std::vector<int64_t> sets;         // row offsets of the sets (host)
+    void upload(const HostCsr &A, const std::vector<int64_t> &sets, hipStream_t s);
+    size_t n_sets() const { return sets.empty() ? 0 : sets.size() - 1; }
+    int64_t n_blocks() const { return set_blk.empty() ? 0 : set_blk.back(); }
+};
+
+// ---- kernel launchers (csr_kernels.hip) ---------------------------------------------
+enum RowMode : int {
+    ROW_SPMV = 0,       // y = A x
+    ROW_RESIDUAL = 1,   // y = b - A x
+    ROW_RESNORM = 2,    // y = b - A x, partial sums of y^2 per block
+    ROW_GS = 3,         // x += (b - A x) / diag      (in place, rows of one set)
+    ROW_JACOBI = 4,     // y = x + omega (b - A x) / diag
+    ROW_AXPY = 5,       // y += A x
+    ROW_NORM_ONLY = 6,  // partial sums of (b - A x)^2, nothing stored
+};
+
+struct RowArgs {
+    const double *x = nullptr;   // gathered vector
+    const double *b = nullptr;
+    double *y = nullptr;         // output (GS: the same pointer as x)
+    double omega = 1.0;
+    double *partials = nullptr;  // one double per row block (RESNORM / NORM_ONLY)
+};
+
+// Launch `mode` over row set `set` of A (set < 0: all sets in one launch).
+void launch_rows(const DevCsr &A, int mode, int set, const RowArgs &args, hipStream_t s);
+// Consecutive single-block sets [set_begin, set_end) of a Gauss-Seidel sweep, run back to
+// back by one workgroup (workgroup barrier between sets).
+void launch_gs_serial(const DevCsr &A, int set_begin, int set_end, const RowArgs &args,
+                      hipStream_t s);
+// sum of partials[0..n) -> *out (device), single workgroup, deterministic order
+void launch_sum(const double *partials, int64_t n, double *out, hipStream_t s);
+void launch_sum_sqrt(const double *partials, int64_t n, double *out, hipStream_t s);
+void launch_gather(const double *src, const int32_t *idx, double *dst, int64_t n, hipStream_t s);   // dst[i] = src[idx[i]]
+void launch_scatter(const double *src, const int32_t *idx, double *dst, int64_t n, hipStream_t s);  // dst[idx[i]] = src[i]
+void launch_dense_gemv(const double *M, const double *v, double *out, int64_t n, hipStream_t s);    // out = M v (row-major n x n)
+// Dense inverse (row-major n x n) of a square device CSR matrix by Gauss-Jordan with
+// partial pivoting on the device.  Throws OMG_ERR_SINGULAR / OMG_ERR_UNSUPPORTED (n > 16384).
+void dense_inverse_from_csr(const DevCsr &A, double *Minv, hipStream_t s);
+
+}  // namespace omg

@@ -1,0 +1,364 @@
+// CSR row kernels for gfx950 (MI355X).  Bandwidth-bound sparse path: no MFMA.
+//
+// One workgroup (256 threads = 4 wave64) owns one ROW BLOCK: a run of at most 256
+// consecutive rows holding at most ROWBLK_NNZ stored entries (partition made at setup,
+// setup_host.cpp:make_row_blocks).  Two phases:
+//   1. the block's slice of `indices` and `data` is streamed from HBM into LDS with
+//      16-byte-per-lane loads (1 KiB per wave instruction, fully coalesced, each byte of
+//      the matrix is fetched exactly once);
+//   2. one thread per row walks its entries in LDS IN STORED ORDER (the summation order
+//      of openmg/solvers.py:63-65 and of SciPy's csr_matvec), gathering x from global
+//      memory — for stencil-like matrices consecutive lanes touch consecutive x, so
+//      each gather is itself a coalesced 512-byte access served by L1/L2.
+// The epilogue is selected by MODE (SpMV, residual, residual norm, Gauss-Seidel set
+// sweep, weighted Jacobi, y += A x).
+//
+// Algorithmic HBM bytes per launch (fp64 values, int32 indices; DESIGN.md "Kernels"):
+//   SpMV      12*nnz + 4*(n+1) + 16*n
+//   residual / GS set sweep / Jacobi   SpMV + 8*n
+#include "common.h"
+
+namespace omg {
+
+namespace {
+
+constexpr int NT = ROWBLK_THREADS;
+constexpr int T = ROWBLK_NNZ;
+// LDS image: entry k lives at k + (k >> 5).  One pad slot per 32 entries makes the
+// thread-per-row reads conflict-free for EVERY row length up to 32 (row length 8 or 16
+// would otherwise hit 4 or 2 banks).  +4 entries of slack for the aligned-down start.
+constexpr int LDS_SLOTS = (T + 8) + ((T + 8) >> 5) + 1;
+
+__device__ __forceinline__ int slot(int k) { return k + (k >> 5); }
+
+struct KArgs {
+    const int32_t *blk_rows;
+    const int32_t *indptr;
+    const int32_t *indices;
+    const double *data;
+    const double *x;
+    const double *b;
+    double *y;
+    double *partials;
+    double omega;
+};
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+// Sum over the workgroup, result valid in thread 0.  Fixed order => deterministic.
+__device__ __forceinline__ double block_sum(double v, double *s_red) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) s_red[wave] = v;
+    __syncthreads();
+    double tot = 0.0;
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int w = 0; w < NT / 64; ++w) tot += s_red[w];
+    }
+    return tot;
+}
+
+template <int MODE>
+__device__ __forceinline__ void row_epilogue(const KArgs &a, int r, double sum, double diag,
+                                             double &sq) {
+    if constexpr (MODE == ROW_SPMV) {
+        a.y[r] = sum;
+    } else if constexpr (MODE == ROW_RESIDUAL) {
+        a.y[r] = a.b[r] - sum;
+    } else if constexpr (MODE == ROW_RESNORM) {
+        const double res = a.b[r] - sum;
+        a.y[r] = res;
+        sq += res * res;
+    } else if constexpr (MODE == ROW_NORM_ONLY) {
+        const double res = a.b[r] - sum;
+        sq += res * res;
+    } else if constexpr (MODE == ROW_GS) {
+        // openmg/solvers.py:68   x[i] = x[i] + (b[i] - Aix) / A[i, i]
+        a.y[r] = a.x[r] + (a.b[r] - sum) / diag;
+    } else if constexpr (MODE == ROW_JACOBI) {
+        a.y[r] = a.x[r] + a.omega * ((a.b[r] - sum) / diag);
+    } else if constexpr (MODE == ROW_AXPY) {
+        a.y[r] = a.y[r] + sum;
+    }
+}
+
+template <int MODE>
+__device__ void process_block(const KArgs &a, int blk, double *s_val, int *s_idx, double *s_red) {
+    constexpr bool NEED_DIAG = (MODE == ROW_GS || MODE == ROW_JACOBI);
+    constexpr bool NEED_NORM = (MODE == ROW_RESNORM || MODE == ROW_NORM_ONLY);
+    const int tid = threadIdx.x;
+    const int r0 = a.blk_rows[blk], r1 = a.blk_rows[blk + 1];
+    const int p0 = a.indptr[r0], p1 = a.indptr[r1];
+    double sq = 0.0;
+
+    if (p1 - p0 <= T) {
+        // ---- phase 1: stream the block's entries into LDS, 16 B per lane per load ------
+        const int base = p0 & ~3;              // 16-B aligned for int32, 32-B for fp64
+        const int cnt = p1 - base;
+        {
+            const int4 *gi = reinterpret_cast<const int4 *>(a.indices + base);
+            for (int k = 4 * tid; k < cnt; k += 4 * NT) {
+                const int4 v = gi[k >> 2];
+                const int s = slot(k);          // k % 4 == 0: the four slots are contiguous
+                s_idx[s] = v.x; s_idx[s + 1] = v.y; s_idx[s + 2] = v.z; s_idx[s + 3] = v.w;
+            }
+            const double2 *gd = reinterpret_cast<const double2 *>(a.data + base);
+            for (int k = 2 * tid; k < cnt; k += 2 * NT) {
+                const double2 v = gd[k >> 1];
+                const int s = slot(k);
+                s_val[s] = v.x; s_val[s + 1] = v.y;
+            }
+        }
+        __syncthreads();
+        // ---- phase 2: one thread per row, stored order ---------------------------------
+        const int r = r0 + tid;
+        if (r < r1) {
+            const int beg = a.indptr[r] - base, end = a.indptr[r + 1] - base;
+            double sum = 0.0, diag = 0.0;
+            for (int k = beg; k < end; k += 8) {
+                int c[8];
+                double v[8], xv[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int kk = min(k + j, end - 1);
+                    const int s = slot(kk);
+                    c[j] = s_idx[s];
+                    v[j] = s_val[s];
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) xv[j] = a.x[c[j]];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    if (k + j < end) {
+                        sum += v[j] * xv[j];
+                        if (NEED_DIAG && c[j] == r) diag += v[j];
+                    }
+                }
+            }
+            row_epilogue<MODE>(a, r, sum, diag, sq);
+        }
+    } else {
+        // ---- one long row: the whole workgroup strides over it (summation order differs
+        // from the stored order here; only rows longer than ROWBLK_NNZ take this path) ---
+        const int r = r0;
+        double part = 0.0, dpart = 0.0;
+        for (int p = p0 + tid; p < p1; p += NT) {
+            const int c = a.indices[p];
+            const double v = a.data[p];
+            part += v * a.x[c];
+            if (NEED_DIAG && c == r) dpart += v;
+        }
+        const double sum = block_sum(part, s_red);
+        double diag = 0.0;
+        if (NEED_DIAG) diag = block_sum(dpart, s_red);
+        if (tid == 0) row_epilogue<MODE>(a, r, sum, diag, sq);
+    }
+    if constexpr (NEED_NORM) {
+        const double tot = block_sum(sq, s_red);
+        if (tid == 0) a.partials[blk] = tot;
+    }
+}
+
+// XCD-aware block mapping: hardware deals workgroups round-robin over the 8 XCDs
+// (MI355X_MICROARCH.md "Workgroup dispatch"), so workgroups b and b+8 share an L2.  Give
+// every XCD one CONTIGUOUS eighth of the row blocks: the x entries a stencil row needs
+// from the planes above and below were fetched into the same L2 a few hundred blocks
+// earlier.  Bijective for any grid size.  Speed only; results do not depend on it.
+__device__ __forceinline__ int xcd_remap(int b, int n) {
+    const int q = n >> 3, r = n & 7;
+    const int xcd = b & 7, idx = b >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(NT) void rows_kernel(KArgs a, int blk0, int remap) {
+    __shared__ double s_val[LDS_SLOTS];
+    __shared__ int s_idx[LDS_SLOTS];
+    __shared__ double s_red[NT / 64];
+    const int local = remap ? xcd_remap(blockIdx.x, gridDim.x) : int(blockIdx.x);
+    process_block<MODE>(a, blk0 + local, s_val, s_idx, s_red);
+}
+
+// A run of consecutive tiny sets (one row block each), executed back to back by ONE
+// workgroup with a workgroup barrier between sets: the level-scheduled lexicographic
+// sweep of a 1-D operator is n single-row sets, and the first/last hyperplanes of a 3-D
+// grid are tiny too.  Stores of set s are visible to set s+1 through the barrier's
+// workgroup-scope fence (same CU, same L1).
+template <int MODE>
+__global__ __launch_bounds__(NT) void rows_serial_kernel(KArgs a, int blk_begin, int blk_end) {
+    __shared__ double s_val[LDS_SLOTS];
+    __shared__ int s_idx[LDS_SLOTS];
+    __shared__ double s_red[NT / 64];
+    for (int blk = blk_begin; blk < blk_end; ++blk) {
+        process_block<MODE>(a, blk, s_val, s_idx, s_red);
+        __threadfence_block();
+        __syncthreads();
+    }
+}
+
+int remap_enabled() {
+    static int v = -1;
+    if (v < 0) {
+        const char *e = getenv("OMG_XCD_REMAP");
+        v = (e && e[0] == '0') ? 0 : 1;
+    }
+    return v;
+}
+
+template <int MODE>
+void launch_mode(const DevCsr &A, int64_t blk0, int64_t nblk, const KArgs &k, hipStream_t s) {
+    if (nblk <= 0) return;
+    hipLaunchKernelGGL(rows_kernel<MODE>, dim3((unsigned)nblk), dim3(NT), 0, s, k, (int)blk0,
+                       nblk >= 64 ? remap_enabled() : 0);
+    OMG_HIP(hipGetLastError());
+}
+
+}  // namespace
+
+void launch_rows(const DevCsr &A, int mode, int set, const RowArgs &args, hipStream_t s) {
+    KArgs k;
+    k.blk_rows = A.blk_rows.p;
+    k.indptr = A.indptr.p;
+    k.indices = A.indices.p;
+    k.data = A.data.p;
+    k.x = args.x;
+    k.b = args.b;
+    k.y = args.y;
+    k.partials = args.partials;
+    k.omega = args.omega;
+    int64_t blk0 = 0, nblk = A.n_blocks();
+    if (set >= 0) {
+        OMG_REQUIRE(size_t(set) < A.n_sets(), "launch_rows: set out of range");
+        blk0 = A.set_blk[set];
+        nblk = A.set_blk[set + 1] - blk0;
+    }
+    switch (mode) {
+        case ROW_SPMV: launch_mode<ROW_SPMV>(A, blk0, nblk, k, s); break;
+        case ROW_RESIDUAL: launch_mode<ROW_RESIDUAL>(A, blk0, nblk, k, s); break;
+        case ROW_RESNORM: launch_mode<ROW_RESNORM>(A, blk0, nblk, k, s); break;
+        case ROW_NORM_ONLY: launch_mode<ROW_NORM_ONLY>(A, blk0, nblk, k, s); break;
+        case ROW_GS: launch_mode<ROW_GS>(A, blk0, nblk, k, s); break;
+        case ROW_JACOBI: launch_mode<ROW_JACOBI>(A, blk0, nblk, k, s); break;
+        case ROW_AXPY: launch_mode<ROW_AXPY>(A, blk0, nblk, k, s); break;
+        default: throw Error(OMG_ERR_INVALID, "launch_rows: unknown mode");
+    }
+}
+
+void launch_gs_serial(const DevCsr &A, int set_begin, int set_end, const RowArgs &args,
+                      hipStream_t s) {
+    KArgs k;
+    k.blk_rows = A.blk_rows.p;
+    k.indptr = A.indptr.p;
+    k.indices = A.indices.p;
+    k.data = A.data.p;
+    k.x = args.x;
+    k.b = args.b;
+    k.y = args.y;
+    k.partials = nullptr;
+    k.omega = args.omega;
+    const int b0 = (int)A.set_blk[set_begin], b1 = (int)A.set_blk[set_end];
+    if (b1 <= b0) return;
+    hipLaunchKernelGGL(rows_serial_kernel<ROW_GS>, dim3(1), dim3(NT), 0, s, k, b0, b1);
+    OMG_HIP(hipGetLastError());
+}
+
+// ---- small vector kernels --------------------------------------------------------------
+namespace {
+
+__global__ __launch_bounds__(1024) void sum_kernel(const double *__restrict__ p, int64_t n,
+                                                   double *__restrict__ out, int take_sqrt) {
+    __shared__ double s_red[16];
+    double acc = 0.0;
+    for (int64_t i = threadIdx.x; i < n; i += 1024) acc += p[i];
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int w = 0; w < 16; ++w) t += s_red[w];
+        *out = take_sqrt ? sqrt(t) : t;
+    }
+}
+
+__global__ void gather_kernel(const double *__restrict__ src, const int32_t *__restrict__ idx,
+                              double *__restrict__ dst, int64_t n) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x)
+        dst[i] = src[idx[i]];
+}
+
+__global__ void scatter_kernel(const double *__restrict__ src, const int32_t *__restrict__ idx,
+                               double *__restrict__ dst, int64_t n) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x)
+        dst[idx[i]] = src[i];
+}
+
+// out = M v, M row-major n x n.  One wave per row, 16-byte loads, 4 rows per workgroup.
+__global__ __launch_bounds__(256) void dense_gemv_kernel(const double *__restrict__ M,
+                                                         const double *__restrict__ v,
+                                                         double *__restrict__ out, int64_t n) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n) return;
+    const double *m = M + row * n;
+    double acc = 0.0;
+    if ((n & 1) == 0) {
+        const double2 *m2 = reinterpret_cast<const double2 *>(m);
+        const double2 *v2 = reinterpret_cast<const double2 *>(v);
+        for (int64_t j = lane; j < (n >> 1); j += 64) {
+            const double2 a = m2[j], b = v2[j];
+            acc += a.x * b.x;
+            acc += a.y * b.y;
+        }
+    } else {
+        for (int64_t j = lane; j < n; j += 64) acc += m[j] * v[j];
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) out[row] = acc;
+}
+
+int grid_for(int64_t n, int threads) {
+    int64_t g = (n + threads - 1) / threads;
+    if (g > 256 * 8) g = 256 * 8;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+}  // namespace
+
+void launch_sum(const double *partials, int64_t n, double *out, hipStream_t s) {
+    hipLaunchKernelGGL(sum_kernel, dim3(1), dim3(1024), 0, s, partials, n, out, 0);
+    OMG_HIP(hipGetLastError());
+}
+
+void launch_sum_sqrt(const double *partials, int64_t n, double *out, hipStream_t s) {
+    hipLaunchKernelGGL(sum_kernel, dim3(1), dim3(1024), 0, s, partials, n, out, 1);
+    OMG_HIP(hipGetLastError());
+}
+
+void launch_gather(const double *src, const int32_t *idx, double *dst, int64_t n, hipStream_t s) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(gather_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, src, idx, dst, n);
+    OMG_HIP(hipGetLastError());
+}
+
+void launch_scatter(const double *src, const int32_t *idx, double *dst, int64_t n, hipStream_t s) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(scatter_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, src, idx, dst, n);
+    OMG_HIP(hipGetLastError());
+}
+
+void launch_dense_gemv(const double *M, const double *v, double *out, int64_t n, hipStream_t s) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(dense_gemv_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, M, v, out, n);
+    OMG_HIP(hipGetLastError());
+}
+
+}  // namespace omg

@@ -1,0 +1,775 @@
+// Device-resident level hierarchy and the V-cycle driver (openmg/__init__.py:151-236),
+// plus the extern "C" surface declared in include/openmg_hip.h.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <memory>
+#include <mutex>
+
+#include "common.h"
+
+namespace omg {
+
+static thread_local std::string g_last_error;
+void set_last_error(const std::string &m) { g_last_error = m; }
+
+void require_device() {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        throw Error(OMG_ERR_NO_DEVICE,
+                    "no HIP device visible: libopenmg_hip.so has no CPU fallback "
+                    "(hipGetDeviceCount: " + std::string(hipGetErrorString(e)) + ")");
+}
+
+namespace {
+
+struct SweepStep {
+    int set_begin, set_end;   // [begin, end)
+    bool serial;              // run of single-block sets -> one workgroup
+};
+
+struct Level {
+    int64_t n = 0;
+    DevCsr A;                 // P A P^T in this level's smoother ordering
+    DevCsr R;                 // to level+1: rows in next ordering, columns in this ordering
+    DevCsr P;                 // R^T: rows in this ordering, columns in next ordering
+    Ordering ord;
+    DevBuf<int32_t> perm;     // new -> old (empty when identity)
+    DevBuf<double> x, b, r, tmp;
+    DevBuf<double> partials;
+    DevBuf<double> nat;       // natural-order staging for host I/O at this level
+    double *xp = nullptr, *tp = nullptr;   // current iterate / Jacobi scratch (swap)
+    std::vector<SweepStep> plan;
+};
+
+struct ProfEvent {
+    int cls;
+    hipEvent_t a, b;
+};
+
+}  // namespace
+}  // namespace omg
+
+struct omg_hierarchy {
+    std::vector<omg::Level> lv;
+    omg::DevBuf<double> coarse_inv;
+    omg::DevBuf<double> norm_dev;
+    int smoother = OMG_SMOOTH_GS_LEX;
+    double omega = 1.0;
+    hipStream_t own = nullptr, stream = nullptr;
+    // resident state
+    bool resident = false;
+    // graph
+    bool want_graph = false;
+    hipGraphExec_t gexec = nullptr;
+    int g_pre = -1, g_post = -1;
+    // profile
+    bool profiling = false;
+    std::vector<omg::ProfEvent> events;
+    int64_t prof_n[OMG_PROFILE_CLASSES] = {0};
+    double prof_ms[OMG_PROFILE_CLASSES] = {0};
+    std::vector<hipEvent_t> event_pool;
+
+    ~omg_hierarchy() {
+        if (gexec) (void)hipGraphExecDestroy(gexec);
+        for (auto &e : events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+        for (auto &e : event_pool) (void)hipEventDestroy(e);
+        if (own) (void)hipStreamDestroy(own);
+    }
+};
+
+namespace omg {
+namespace {
+
+using H = omg_hierarchy;
+
+void check_diagonal(const omg_csr &A, int level) {
+    for (int64_t i = 0; i < A.n_rows; ++i) {
+        double d = 0.0;
+        bool have = false;
+        for (int32_t p = A.indptr[i]; p < A.indptr[i + 1]; ++p)
+            if (A.indices[p] == i) { d += A.data[p]; have = true; }
+        if (!have || d == 0.0)
+            throw Error(OMG_ERR_NO_DIAGONAL, "level " + std::to_string(level) + ": row " +
+                                                 std::to_string(i) + " has no nonzero diagonal entry");
+    }
+}
+
+omg_csr view(const HostCsr &A) {
+    return omg_csr{A.n_rows, A.n_cols, A.nnz, A.indptr.data(), A.indices.data(), A.data.data()};
+}
+
+void build_plan(Level &L) {
+    L.plan.clear();
+    const int ns = (int)L.A.n_sets();
+    int s = 0;
+    while (s < ns) {
+        auto one_block = [&](int k) { return L.A.set_blk[k + 1] - L.A.set_blk[k] == 1; };
+        if (one_block(s)) {
+            int e = s + 1;
+            while (e < ns && one_block(e)) ++e;
+            L.plan.push_back({s, e, e - s >= 2});
+            s = e;
+        } else {
+            L.plan.push_back({s, s + 1, false});
+            ++s;
+        }
+    }
+}
+
+struct Prof {
+    H *h;
+    int idx = -1;
+    Prof(H *hh, int level, int cls) : h(hh) {
+        if (!h->profiling || level != 0) return;
+        ProfEvent e;
+        e.cls = cls;
+        auto get = [&]() {
+            hipEvent_t ev;
+            if (!h->event_pool.empty()) { ev = h->event_pool.back(); h->event_pool.pop_back(); }
+            else OMG_HIP(hipEventCreate(&ev));
+            return ev;
+        };
+        e.a = get();
+        e.b = get();
+        OMG_HIP(hipEventRecord(e.a, h->stream));
+        h->events.push_back(e);
+        idx = (int)h->events.size() - 1;
+    }
+    ~Prof() {
+        if (idx >= 0) (void)hipEventRecord(h->events[idx].b, h->stream);
+    }
+};
+
+// ---- level operations (device vectors in the level's ordering) ---------------------------
+void smooth_level(H *h, int l, int iterations) {
+    Level &L = h->lv[l];
+    for (int it = 0; it < iterations; ++it) {
+        if (h->smoother == OMG_SMOOTH_JACOBI) {
+            Prof p(h, l, 0);
+            RowArgs a;
+            a.x = L.xp; a.b = L.b.p; a.y = L.tp; a.omega = h->omega;
+            launch_rows(L.A, ROW_JACOBI, -1, a, h->stream);
+            std::swap(L.xp, L.tp);
+        } else {
+            RowArgs a;
+            a.x = L.xp; a.b = L.b.p; a.y = L.xp;
+            for (const SweepStep &st : L.plan) {
+                Prof p(h, l, 0);
+                if (st.serial) launch_gs_serial(L.A, st.set_begin, st.set_end, a, h->stream);
+                else launch_rows(L.A, ROW_GS, st.set_begin, a, h->stream);
+            }
+        }
+    }
+}
+
+void residual_level(H *h, int l, double *r_out) {
+    Level &L = h->lv[l];
+    Prof p(h, l, 1);
+    RowArgs a;
+    a.x = L.xp; a.b = L.b.p; a.y = r_out;
+    launch_rows(L.A, ROW_RESIDUAL, -1, a, h->stream);
+}
+
+// ||b - A x||_2 of level l into h->norm_dev (device scalar); r_out optional.
+void norm_level(H *h, int l, double *r_out) {
+    Level &L = h->lv[l];
+    {
+        Prof p(h, l, 4);
+        RowArgs a;
+        a.x = L.xp; a.b = L.b.p; a.y = r_out; a.partials = L.partials.p;
+        launch_rows(L.A, r_out ? ROW_RESNORM : ROW_NORM_ONLY, -1, a, h->stream);
+    }
+    launch_sum_sqrt(L.partials.p, L.A.n_blocks(), h->norm_dev.p, h->stream);
+}
+
+void restrict_level(H *h, int l, const double *fine, double *coarse) {
+    Level &L = h->lv[l];
+    Prof p(h, l, 2);
+    RowArgs a;
+    a.x = fine; a.y = coarse;
+    launch_rows(L.R, ROW_SPMV, -1, a, h->stream);
+}
+
+void prolong_add_level(H *h, int l, const double *coarse, double *fine) {
+    Level &L = h->lv[l];
+    Prof p(h, l, 3);
+    RowArgs a;
+    a.x = coarse; a.y = fine;
+    launch_rows(L.P, ROW_AXPY, -1, a, h->stream);
+}
+
+void coarse_solve_level(H *h) {
+    Level &L = h->lv.back();
+    launch_dense_gemv(h->coarse_inv.p, L.b.p, L.xp, L.n, h->stream);
+}
+
+// openmg/__init__.py:199-234 with the dead work removed: R[l]*b (:205-206) is computed by the
+// reference only for its length, and the norm at levels > entry (:227) is discarded by the
+// caller (:213 takes [0]); neither changes any returned value.
+void cycle_body(H *h, int l, int pre, int post) {
+    const int last = (int)h->lv.size() - 1;
+    if (l >= last) {
+        coarse_solve_level(h);
+        return;
+    }
+    Level &L = h->lv[l];
+    Level &C = h->lv[l + 1];
+    smooth_level(h, l, pre);                                  // :201
+    residual_level(h, l, L.r.p);                              // :209
+    restrict_level(h, l, L.r.p, C.b.p);                       // :210
+    if (l + 1 < last) OMG_HIP(hipMemsetAsync(C.xp, 0, C.n * sizeof(double), h->stream));   // :191-192
+    cycle_body(h, l + 1, pre, post);                          // :213
+    prolong_add_level(h, l, C.xp, L.xp);                      // :214, :220/:224
+    if (post > 0) smooth_level(h, l, post);                   // :216-222
+}
+
+void load_vec(H *h, int l, const double *host, double *dst) {
+    Level &L = h->lv[l];
+    if (L.ord.identity) {
+        OMG_HIP(hipMemcpyAsync(dst, host, L.n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    } else {
+        L.nat.upload(host, L.n, h->stream);
+        launch_gather(L.nat.p, L.perm.p, dst, L.n, h->stream);
+    }
+}
+
+void fetch_vec(H *h, int l, const double *src, double *host) {
+    Level &L = h->lv[l];
+    if (L.ord.identity) {
+        OMG_HIP(hipMemcpyAsync(host, src, L.n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    } else {
+        launch_scatter(src, L.perm.p, L.nat.p, L.n, h->stream);
+        L.nat.download(host, L.n, h->stream);
+    }
+    OMG_HIP(hipStreamSynchronize(h->stream));
+}
+
+double read_norm(H *h) {
+    double v = 0.0;
+    OMG_HIP(hipMemcpyAsync(&v, h->norm_dev.p, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    OMG_HIP(hipStreamSynchronize(h->stream));
+    return v;
+}
+
+void drop_graph(H *h) {
+    if (h->gexec) (void)hipGraphExecDestroy(h->gexec);
+    h->gexec = nullptr;
+    h->g_pre = h->g_post = -1;
+}
+
+// One level-0 cycle + residual norm into norm_dev; optionally replayed from a hipGraph.
+void run_cycle0(H *h, int pre, int post) {
+    const bool single = h->lv.size() == 1;
+    auto body = [&]() {
+        cycle_body(h, 0, pre, post);
+        if (!single) norm_level(h, 0, nullptr);               // :227
+        else OMG_HIP(hipMemsetAsync(h->norm_dev.p, 0, sizeof(double), h->stream));   // :232
+    };
+    if (!h->want_graph || h->profiling) {
+        body();
+        return;
+    }
+    if (!h->gexec || h->g_pre != pre || h->g_post != post) {
+        drop_graph(h);
+        // Jacobi swaps xp/tp: an odd number of sweeps per cycle would leave the graph's
+        // baked-in pointers out of phase with the next replay.
+        if (h->smoother == OMG_SMOOTH_JACOBI && ((pre + post) & 1)) { body(); return; }
+        hipGraph_t g = nullptr;
+        OMG_HIP(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+        try {
+            body();
+        } catch (...) {
+            (void)hipStreamEndCapture(h->stream, &g);
+            if (g) (void)hipGraphDestroy(g);
+            throw;
+        }
+        OMG_HIP(hipStreamEndCapture(h->stream, &g));
+        hipError_t e = hipGraphInstantiate(&h->gexec, g, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(g);
+        if (e != hipSuccess) {
+            h->gexec = nullptr;
+            throw Error(OMG_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e));
+        }
+        h->g_pre = pre;
+        h->g_post = post;
+    }
+    OMG_HIP(hipGraphLaunch(h->gexec, h->stream));
+}
+
+void check_level(const H *h, int level) {
+    OMG_REQUIRE(h != nullptr, "null hierarchy");
+    OMG_REQUIRE(level >= 0 && level < (int)h->lv.size(), "level out of range");
+}
+
+std::unique_ptr<H> create(int n_levels, const omg_csr *A, const omg_csr *R, int smoother,
+                          double omega) {
+    OMG_REQUIRE(n_levels >= 1, "n_levels must be >= 1");
+    OMG_REQUIRE(A != nullptr && (n_levels == 1 || R != nullptr), "A / R array is null");
+    OMG_REQUIRE(smoother >= OMG_SMOOTH_GS_LEX && smoother <= OMG_SMOOTH_JACOBI, "unknown smoother");
+    for (int l = 0; l < n_levels; ++l) {
+        validate_csr(A[l], ("A[" + std::to_string(l) + "]").c_str());
+        OMG_REQUIRE(A[l].n_rows == A[l].n_cols, "A[l] must be square");
+        if (l + 1 < n_levels) {
+            validate_csr(R[l], ("R[" + std::to_string(l) + "]").c_str());
+            OMG_REQUIRE(R[l].n_cols == A[l].n_rows && R[l].n_rows == A[l + 1].n_rows,
+                        "R[l] shape does not match A[l], A[l+1]");
+            check_diagonal(A[l], l);
+        }
+    }
+    require_device();
+    std::unique_ptr<H> h(new H);
+    h->smoother = smoother;
+    h->omega = omega;
+    OMG_HIP(hipStreamCreateWithFlags(&h->own, hipStreamNonBlocking));
+    h->stream = h->own;
+    h->lv.resize(n_levels);
+    h->norm_dev.alloc(1);
+    // orderings first (restrictions need both neighbours')
+    for (int l = 0; l < n_levels; ++l) {
+        Level &L = h->lv[l];
+        L.n = A[l].n_rows;
+        if (l + 1 < n_levels) L.ord = make_ordering(A[l], smoother);
+        else { L.ord.identity = true; L.ord.sets = {0, L.n}; }     // coarsest: direct solve
+    }
+    for (int l = 0; l < n_levels; ++l) {
+        Level &L = h->lv[l];
+        const bool id = L.ord.identity;
+        {
+            HostCsr Ap = permute_csr(A[l], id ? nullptr : L.ord.perm.data(), id ? nullptr : L.ord.inv.data());
+            L.A.upload(Ap, L.ord.sets, h->stream);
+        }
+        if (!id) {
+            L.perm.alloc(L.n);
+            L.perm.upload(L.ord.perm.data(), L.n, h->stream);
+            OMG_HIP(hipStreamSynchronize(h->stream));
+        }
+        if (l + 1 < n_levels) {
+            const Ordering &co = h->lv[l + 1].ord;
+            HostCsr Rp = permute_csr(R[l], co.identity ? nullptr : co.perm.data(), id ? nullptr : L.ord.inv.data());
+            HostCsr Pt = transpose_csr(Rp);
+            L.R.upload(Rp, {}, h->stream);
+            L.P.upload(Pt, {}, h->stream);
+            L.r.alloc(L.n);
+            if (smoother == OMG_SMOOTH_JACOBI) L.tmp.alloc(L.n);
+            L.partials.alloc(std::max<int64_t>(L.A.n_blocks(), 1));
+            build_plan(L);
+        }
+        L.x.alloc(std::max<int64_t>(L.n, 1));
+        L.b.alloc(std::max<int64_t>(L.n, 1));
+        L.xp = L.x.p;
+        L.tp = L.tmp.p;
+    }
+    // coarsest level: invert once (reference: SuperLU factorisation on every cycle)
+    {
+        Level &L = h->lv.back();
+        h->coarse_inv.alloc(std::max<size_t>(size_t(L.n) * size_t(L.n), 1));
+        dense_inverse_from_csr(L.A, h->coarse_inv.p, h->stream);
+    }
+    OMG_HIP(hipStreamSynchronize(h->stream));
+    return h;
+}
+
+void ensure_nat(H *h, int l) {
+    Level &L = h->lv[l];
+    if (!L.ord.identity && L.nat.n < size_t(L.n)) L.nat.alloc(L.n);
+}
+
+// A throw-away single-level "hierarchy" for the standalone entry points.
+struct OneShot {
+    DevCsr A;
+    hipStream_t s = nullptr;
+    OneShot() { require_device(); OMG_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking)); }
+    ~OneShot() { if (s) (void)hipStreamDestroy(s); }
+};
+
+template <typename F>
+int guarded(F &&f) {
+    try {
+        f();
+        return OMG_OK;
+    } catch (const Error &e) {
+        set_last_error(e.what());
+        return e.code;
+    } catch (const std::bad_alloc &) {
+        set_last_error("host allocation failed");
+        return OMG_ERR_ALLOC;
+    } catch (const std::exception &e) {
+        set_last_error(e.what());
+        return OMG_ERR_INVALID;
+    }
+}
+
+}  // namespace
+}  // namespace omg
+
+using namespace omg;
+
+extern "C" {
+
+const char *omg_last_error(void) { return g_last_error.c_str(); }
+const char *omg_version(void) { return "openmg_hip 0.1 (gfx950)"; }
+
+int omg_device_count(int *count) {
+    return guarded([&] {
+        OMG_REQUIRE(count, "count is null");
+        int n = 0;
+        hipError_t e = hipGetDeviceCount(&n);
+        *count = (e == hipSuccess) ? n : 0;
+    });
+}
+
+int omg_set_device(int device) {
+    return guarded([&] { require_device(); OMG_HIP(hipSetDevice(device)); });
+}
+
+int omg_hierarchy_create(int n_levels, const omg_csr *A, const omg_csr *R, int smoother,
+                         double omega, omg_hierarchy **out) {
+    return guarded([&] {
+        OMG_REQUIRE(out, "out is null");
+        *out = nullptr;
+        *out = create(n_levels, A, R, smoother, omega).release();
+    });
+}
+
+int omg_hierarchy_destroy(omg_hierarchy *h) {
+    return guarded([&] {
+        if (!h) return;
+        (void)hipStreamSynchronize(h->stream);
+        delete h;
+    });
+}
+
+int omg_hierarchy_set_stream(omg_hierarchy *h, void *hip_stream) {
+    return guarded([&] {
+        OMG_REQUIRE(h, "null hierarchy");
+        OMG_HIP(hipStreamSynchronize(h->stream));
+        drop_graph(h);
+        h->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : h->own;
+    });
+}
+
+int omg_hierarchy_sync(omg_hierarchy *h) {
+    return guarded([&] { OMG_REQUIRE(h, "null hierarchy"); OMG_HIP(hipStreamSynchronize(h->stream)); });
+}
+
+int omg_hierarchy_level_rows(const omg_hierarchy *h, int level, int64_t *n_rows) {
+    return guarded([&] { check_level(h, level); OMG_REQUIRE(n_rows, "null"); *n_rows = h->lv[level].n; });
+}
+
+int omg_hierarchy_level_sets(const omg_hierarchy *h, int level, int64_t *n_sets) {
+    return guarded([&] { check_level(h, level); OMG_REQUIRE(n_sets, "null"); *n_sets = (int64_t)h->lv[level].A.n_sets(); });
+}
+
+int omg_vcycle(omg_hierarchy *h, int level, const double *b, double *x, int pre, int post,
+               double *norm) {
+    return guarded([&] {
+        check_level(h, level);
+        OMG_REQUIRE(b && x, "b / x is null");
+        OMG_REQUIRE(pre >= 0 && post >= 0, "negative sweep count");
+        ensure_nat(h, level);
+        Level &L = h->lv[level];
+        h->resident = false;
+        load_vec(h, level, b, L.b.p);
+        load_vec(h, level, x, L.xp);
+        const int last = (int)h->lv.size() - 1;
+        cycle_body(h, level, pre, post);
+        double nv = 0.0;
+        if (level < last) {
+            norm_level(h, level, nullptr);
+            nv = read_norm(h);
+        }
+        fetch_vec(h, level, L.xp, x);
+        if (norm) *norm = nv;
+    });
+}
+
+int omg_resident_load(omg_hierarchy *h, const double *b, const double *x0) {
+    return guarded([&] {
+        check_level(h, 0);
+        OMG_REQUIRE(b, "b is null");
+        ensure_nat(h, 0);
+        Level &L = h->lv[0];
+        load_vec(h, 0, b, L.b.p);
+        if (x0) load_vec(h, 0, x0, L.xp);
+        else OMG_HIP(hipMemsetAsync(L.xp, 0, L.n * sizeof(double), h->stream));
+        OMG_HIP(hipStreamSynchronize(h->stream));
+        h->resident = true;
+    });
+}
+
+int omg_resident_cycle(omg_hierarchy *h, int pre, int post, double *norm) {
+    return guarded([&] {
+        check_level(h, 0);
+        OMG_REQUIRE(h->resident, "omg_resident_load has not been called");
+        OMG_REQUIRE(pre >= 0 && post >= 0, "negative sweep count");
+        run_cycle0(h, pre, post);
+        if (norm) *norm = read_norm(h);
+    });
+}
+
+int omg_resident_fetch(omg_hierarchy *h, double *x) {
+    return guarded([&] {
+        check_level(h, 0);
+        OMG_REQUIRE(h->resident && x, "nothing resident / x is null");
+        fetch_vec(h, 0, h->lv[0].xp, x);
+    });
+}
+
+int omg_resident_use_graph(omg_hierarchy *h, int enable) {
+    return guarded([&] {
+        OMG_REQUIRE(h, "null hierarchy");
+        OMG_HIP(hipStreamSynchronize(h->stream));
+        h->want_graph = enable != 0;
+        if (!enable) drop_graph(h);
+    });
+}
+
+int omg_solve(omg_hierarchy *h, const double *b, double *x, int pre, int post, int max_cycles,
+              double threshold, int *cycles_done, double *norm) {
+    return guarded([&] {
+        check_level(h, 0);
+        OMG_REQUIRE(b && x, "b / x is null");
+        OMG_REQUIRE(max_cycles > 0 || threshold > 0.0,
+                    "Either threshold or cycles must be > 0");   // openmg/__init__.py:118-119
+        ensure_nat(h, 0);
+        Level &L = h->lv[0];
+        load_vec(h, 0, b, L.b.p);
+        load_vec(h, 0, x, L.xp);
+        h->resident = true;
+        int cycle = 0;
+        double nv = 0.0;
+        for (;;) {                                                // :112, :132-138
+            run_cycle0(h, pre, post);
+            nv = read_norm(h);
+            ++cycle;
+            const bool by_cycles = max_cycles > 0 && cycle >= max_cycles;
+            const bool by_norm = threshold > 0.0 && nv < threshold;
+            if (by_cycles || by_norm) break;
+        }
+        fetch_vec(h, 0, L.xp, x);
+        if (cycles_done) *cycles_done = cycle;
+        if (norm) *norm = nv;
+    });
+}
+
+int omg_profile_enable(omg_hierarchy *h, int enable) {
+    return guarded([&] {
+        OMG_REQUIRE(h, "null hierarchy");
+        OMG_HIP(hipStreamSynchronize(h->stream));
+        for (auto &e : h->events) { h->event_pool.push_back(e.a); h->event_pool.push_back(e.b); }
+        h->events.clear();
+        std::memset(h->prof_n, 0, sizeof(h->prof_n));
+        std::memset(h->prof_ms, 0, sizeof(h->prof_ms));
+        h->profiling = enable != 0;
+    });
+}
+
+int omg_profile_read(omg_hierarchy *h, int64_t *launches, double *total_ms) {
+    return guarded([&] {
+        OMG_REQUIRE(h && launches && total_ms, "null argument");
+        OMG_HIP(hipStreamSynchronize(h->stream));
+        for (auto &e : h->events) {
+            float ms = 0.f;
+            OMG_HIP(hipEventElapsedTime(&ms, e.a, e.b));
+            h->prof_n[e.cls] += 1;
+            h->prof_ms[e.cls] += ms;
+            h->event_pool.push_back(e.a);
+            h->event_pool.push_back(e.b);
+        }
+        h->events.clear();
+        for (int c = 0; c < OMG_PROFILE_CLASSES; ++c) { launches[c] = h->prof_n[c]; total_ms[c] = h->prof_ms[c]; }
+    });
+}
+
+// ---- single level operations ------------------------------------------------------------
+int omg_level_smooth(omg_hierarchy *h, int level, const double *b, double *x, int iterations) {
+    return guarded([&] {
+        check_level(h, level);
+        OMG_REQUIRE(level < (int)h->lv.size() - 1, "the coarsest level has no smoother");
+        OMG_REQUIRE(b && x && iterations >= 0, "bad argument");
+        ensure_nat(h, level);
+        Level &L = h->lv[level];
+        h->resident = false;
+        load_vec(h, level, b, L.b.p);
+        load_vec(h, level, x, L.xp);
+        smooth_level(h, level, iterations);
+        fetch_vec(h, level, L.xp, x);
+    });
+}
+
+int omg_level_residual(omg_hierarchy *h, int level, const double *b, const double *x, double *r,
+                       double *norm) {
+    return guarded([&] {
+        check_level(h, level);
+        OMG_REQUIRE(level < (int)h->lv.size() - 1, "use omg_residual for the coarsest operator");
+        OMG_REQUIRE(b && x && r, "null vector");
+        ensure_nat(h, level);
+        Level &L = h->lv[level];
+        h->resident = false;
+        load_vec(h, level, b, L.b.p);
+        load_vec(h, level, x, L.xp);
+        if (norm) {
+            norm_level(h, level, L.r.p);
+            *norm = read_norm(h);
+        } else {
+            residual_level(h, level, L.r.p);
+        }
+        fetch_vec(h, level, L.r.p, r);
+    });
+}
+
+int omg_level_restrict(omg_hierarchy *h, int level, const double *fine, double *coarse) {
+    return guarded([&] {
+        check_level(h, level);
+        OMG_REQUIRE(level < (int)h->lv.size() - 1, "no restriction below the coarsest level");
+        OMG_REQUIRE(fine && coarse, "null vector");
+        ensure_nat(h, level);
+        ensure_nat(h, level + 1);
+        Level &L = h->lv[level];
+        Level &C = h->lv[level + 1];
+        h->resident = false;
+        load_vec(h, level, fine, L.r.p);
+        restrict_level(h, level, L.r.p, C.b.p);
+        fetch_vec(h, level + 1, C.b.p, coarse);
+    });
+}
+
+int omg_level_prolong_add(omg_hierarchy *h, int level, const double *coarse, double *fine_inout) {
+    return guarded([&] {
+        check_level(h, level);
+        OMG_REQUIRE(level < (int)h->lv.size() - 1, "no prolongation below the coarsest level");
+        OMG_REQUIRE(coarse && fine_inout, "null vector");
+        ensure_nat(h, level);
+        ensure_nat(h, level + 1);
+        Level &L = h->lv[level];
+        Level &C = h->lv[level + 1];
+        h->resident = false;
+        load_vec(h, level + 1, coarse, C.xp);
+        load_vec(h, level, fine_inout, L.xp);
+        prolong_add_level(h, level, C.xp, L.xp);
+        fetch_vec(h, level, L.xp, fine_inout);
+    });
+}
+
+int omg_coarse_solve(omg_hierarchy *h, const double *b, double *x) {
+    return guarded([&] {
+        OMG_REQUIRE(h && b && x, "null argument");
+        const int last = (int)h->lv.size() - 1;
+        Level &L = h->lv[last];
+        h->resident = last != 0 ? h->resident : false;
+        load_vec(h, last, b, L.b.p);
+        coarse_solve_level(h);
+        fetch_vec(h, last, L.xp, x);
+    });
+}
+
+// ---- standalone --------------------------------------------------------------------------
+static void standalone_rows(const omg_csr *A, int mode, const double *x, const double *b,
+                            double *y, double *norm) {
+    OMG_REQUIRE(A && x && y, "null argument");
+    validate_csr(*A, "A");
+    OneShot os;
+    HostCsr Ah = permute_csr(*A, nullptr, nullptr);
+    os.A.upload(Ah, {}, os.s);
+    DevBuf<double> dx(std::max<int64_t>(A->n_cols, 1)), dy(std::max<int64_t>(A->n_rows, 1)), db, part, nrm;
+    dx.upload(x, A->n_cols, os.s);
+    RowArgs a;
+    a.x = dx.p; a.y = dy.p;
+    if (b) { db.alloc(std::max<int64_t>(A->n_rows, 1)); db.upload(b, A->n_rows, os.s); a.b = db.p; }
+    if (norm) { part.alloc(std::max<int64_t>(os.A.n_blocks(), 1)); nrm.alloc(1); a.partials = part.p; }
+    launch_rows(os.A, mode, -1, a, os.s);
+    if (norm) {
+        launch_sum_sqrt(part.p, os.A.n_blocks(), nrm.p, os.s);
+        nrm.download(norm, 1, os.s);
+    }
+    dy.download(y, A->n_rows, os.s);
+    OMG_HIP(hipStreamSynchronize(os.s));
+}
+
+int omg_spmv(const omg_csr *A, const double *x, double *y) {
+    return guarded([&] { standalone_rows(A, ROW_SPMV, x, nullptr, y, nullptr); });
+}
+
+int omg_residual(const omg_csr *A, const double *b, const double *x, double *r, double *norm) {
+    return guarded([&] {
+        OMG_REQUIRE(b, "b is null");
+        OMG_REQUIRE(A && A->n_rows == A->n_cols, "residual needs a square operator");
+        standalone_rows(A, norm ? ROW_RESNORM : ROW_RESIDUAL, x, b, r, norm);
+    });
+}
+
+int omg_gauss_seidel(const omg_csr *A, const double *b, double *x, int smoother, double omega,
+                     int iterations, double threshold, int *sweeps_done) {
+    return guarded([&] {
+        OMG_REQUIRE(A && b && x, "null argument");
+        OMG_REQUIRE(A->n_rows == A->n_cols, "smoother needs a square operator");
+        validate_csr(*A, "A");
+        check_diagonal(*A, 0);
+        if (iterations < 0 && threshold < 0.0) iterations = 1;      // openmg/solvers.py:39-40
+        // a two-"level" shell so that the level machinery (ordering, plan) is reused
+        require_device();
+        std::unique_ptr<H> h(new H);
+        h->smoother = smoother;
+        h->omega = omega;
+        OMG_HIP(hipStreamCreateWithFlags(&h->own, hipStreamNonBlocking));
+        h->stream = h->own;
+        h->lv.resize(2);           // level 1 is a dummy so that level 0 counts as "smoothed"
+        h->norm_dev.alloc(1);
+        Level &L = h->lv[0];
+        L.n = A->n_rows;
+        L.ord = make_ordering(*A, smoother);
+        const bool id = L.ord.identity;
+        {
+            HostCsr Ap = permute_csr(*A, id ? nullptr : L.ord.perm.data(), id ? nullptr : L.ord.inv.data());
+            L.A.upload(Ap, L.ord.sets, h->stream);
+        }
+        if (!id) { L.perm.alloc(L.n); L.perm.upload(L.ord.perm.data(), L.n, h->stream); L.nat.alloc(L.n); }
+        L.x.alloc(std::max<int64_t>(L.n, 1));
+        L.b.alloc(std::max<int64_t>(L.n, 1));
+        if (smoother == OMG_SMOOTH_JACOBI) L.tmp.alloc(std::max<int64_t>(L.n, 1));
+        L.partials.alloc(std::max<int64_t>(L.A.n_blocks(), 1));
+        L.xp = L.x.p;
+        L.tp = L.tmp.p;
+        build_plan(L);
+        load_vec(h.get(), 0, b, L.b.p);
+        load_vec(h.get(), 0, x, L.xp);
+        int it = 0;
+        auto stop = [&]() {                                          // openmg/solvers.py:43-50
+            const bool by_iter = iterations >= 0 && it >= iterations;
+            bool by_norm = false;
+            if (threshold >= 0.0) {
+                norm_level(h.get(), 0, nullptr);
+                by_norm = read_norm(h.get()) < threshold;
+            }
+            return by_iter || by_norm;
+        };
+        while (!stop()) {                                            // :52-54, :72-74
+            smooth_level(h.get(), 0, 1);
+            ++it;
+        }
+        fetch_vec(h.get(), 0, L.xp, x);
+        if (sweeps_done) *sweeps_done = it;
+    });
+}
+
+int omg_direct_solve(const omg_csr *A, const double *b, double *x) {
+    return guarded([&] {
+        OMG_REQUIRE(A && b && x, "null argument");
+        OMG_REQUIRE(A->n_rows == A->n_cols, "direct solve needs a square operator");
+        validate_csr(*A, "A");
+        OneShot os;
+        HostCsr Ah = permute_csr(*A, nullptr, nullptr);
+        os.A.upload(Ah, {}, os.s);
+        const int64_t n = A->n_rows;
+        DevBuf<double> inv(std::max<size_t>(size_t(n) * size_t(n), 1)), db(std::max<int64_t>(n, 1)), dx(std::max<int64_t>(n, 1));
+        dense_inverse_from_csr(os.A, inv.p, os.s);
+        db.upload(b, n, os.s);
+        launch_dense_gemv(inv.p, db.p, dx.p, n, os.s);
+        dx.download(x, n, os.s);
+        OMG_HIP(hipStreamSynchronize(os.s));
+    });
+}
+
+}  // extern "C"

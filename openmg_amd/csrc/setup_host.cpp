@@ -1,0 +1,229 @@
+// Host-side setup: smoother orderings, symmetric permutation of CSR matrices, transpose,
+// row-block partition.  Index work only — no floating-point arithmetic happens here.
+#include <algorithm>
+#include <cstring>
+#include <thread>
+
+#include "common.h"
+
+namespace omg {
+
+static unsigned host_threads() {
+    unsigned t = std::thread::hardware_concurrency();
+    if (t == 0) t = 4;
+    return std::min(t, 32u);
+}
+
+template <typename F>
+static void parallel_rows(int64_t n, F &&body) {
+    unsigned nt = host_threads();
+    if (n < (1 << 16) || nt == 1) {
+        body(int64_t(0), n);
+        return;
+    }
+    std::vector<std::thread> pool;
+    int64_t chunk = (n + nt - 1) / nt;
+    for (unsigned t = 0; t < nt; ++t) {
+        int64_t lo = t * chunk, hi = std::min<int64_t>(n, lo + chunk);
+        if (lo >= hi) break;
+        pool.emplace_back([&body, lo, hi] { body(lo, hi); });
+    }
+    for (auto &th : pool) th.join();
+}
+
+void validate_csr(const omg_csr &A, const char *what) {
+    std::string w(what);
+    OMG_REQUIRE(A.n_rows >= 0 && A.n_cols >= 0 && A.nnz >= 0, w + ": negative dimension");
+    OMG_REQUIRE(A.n_rows < INT32_MAX && A.n_cols < INT32_MAX && A.nnz < INT32_MAX,
+                w + ": int32 index range exceeded (shard the operator first)");
+    OMG_REQUIRE(A.indptr != nullptr, w + ": indptr is null");
+    OMG_REQUIRE(A.nnz == 0 || (A.indices && A.data), w + ": indices/data is null");
+    OMG_REQUIRE(A.indptr[0] == 0 && A.indptr[A.n_rows] == A.nnz, w + ": indptr does not span nnz");
+    bool ok = true;
+    parallel_rows(A.n_rows, [&](int64_t lo, int64_t hi) {
+        for (int64_t i = lo; i < hi && ok; ++i) {
+            if (A.indptr[i] > A.indptr[i + 1]) { ok = false; break; }
+            for (int32_t p = A.indptr[i]; p < A.indptr[i + 1]; ++p)
+                if (A.indices[p] < 0 || A.indices[p] >= A.n_cols) { ok = false; break; }
+        }
+    });
+    OMG_REQUIRE(ok, w + ": malformed CSR (indptr not monotone or column out of range)");
+}
+
+// ---- orderings ------------------------------------------------------------------------
+// GS_LEX: level schedule of the lexicographic sweep.  level(i) is the smallest value that is
+// larger than level(j) for every coupled j < i; "coupled" means a_ij != 0 or a_ji != 0
+// structurally.  Row i's own pattern supplies the j < i lower bounds directly and pushes a
+// lower bound onto every j > i it references, so unsymmetric patterns are covered in one
+// ascending pass.  Rows of one level are mutually uncoupled, every row sees the NEW value
+// of its lower neighbours and the OLD value of its upper neighbours: the same iterate as
+// the sequential loop at openmg/solvers.py:56-68.
+static void lex_levels(const omg_csr &A, std::vector<int32_t> &key, int32_t &n_keys) {
+    const int64_t n = A.n_rows;
+    key.assign(n, 0);
+    int32_t top = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        int32_t lv = key[i];
+        for (int32_t p = A.indptr[i]; p < A.indptr[i + 1]; ++p) {
+            int32_t j = A.indices[p];
+            if (j < i && key[j] + 1 > lv) lv = key[j] + 1;
+        }
+        key[i] = lv;
+        if (lv > top) top = lv;
+        for (int32_t p = A.indptr[i]; p < A.indptr[i + 1]; ++p) {
+            int32_t j = A.indices[p];
+            if (j > i && j < n && key[j] < lv + 1) key[j] = lv + 1;
+        }
+    }
+    n_keys = n ? top + 1 : 0;
+}
+
+// GS_COLOUR: smallest-free-colour greedy colouring in natural row order over the graph of
+// A + A^T (same push trick for the transposed couplings).  Up to 64 colours.
+static void greedy_colours(const omg_csr &A, std::vector<int32_t> &key, int32_t &n_keys) {
+    const int64_t n = A.n_rows;
+    key.assign(n, 0);
+    std::vector<uint64_t> forbidden(n, 0);
+    int32_t top = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        uint64_t f = forbidden[i];
+        for (int32_t p = A.indptr[i]; p < A.indptr[i + 1]; ++p) {
+            int32_t j = A.indices[p];
+            if (j < i) f |= (uint64_t(1) << key[j]);
+        }
+        if (f == ~uint64_t(0))
+            throw Error(OMG_ERR_UNSUPPORTED, "greedy colouring needs more than 64 colours; use GS_LEX");
+        int32_t c = __builtin_ctzll(~f);
+        key[i] = c;
+        if (c > top) top = c;
+        for (int32_t p = A.indptr[i]; p < A.indptr[i + 1]; ++p) {
+            int32_t j = A.indices[p];
+            if (j > i && j < n) forbidden[j] |= (uint64_t(1) << c);
+        }
+    }
+    n_keys = n ? top + 1 : 0;
+}
+
+Ordering make_ordering(const omg_csr &A, int smoother) {
+    const int64_t n = A.n_rows;
+    Ordering o;
+    if (smoother == OMG_SMOOTH_JACOBI || n == 0) {
+        o.sets = {0, n};
+        o.identity = true;
+        return o;
+    }
+    OMG_REQUIRE(A.n_rows == A.n_cols, "smoother needs a square operator");
+    std::vector<int32_t> key;
+    int32_t n_keys = 0;
+    if (smoother == OMG_SMOOTH_GS_LEX) lex_levels(A, key, n_keys);
+    else if (smoother == OMG_SMOOTH_GS_COLOUR) greedy_colours(A, key, n_keys);
+    else throw Error(OMG_ERR_INVALID, "unknown smoother kind");
+    // stable counting sort by key
+    o.sets.assign(size_t(n_keys) + 1, 0);
+    for (int64_t i = 0; i < n; ++i) o.sets[key[i] + 1]++;
+    for (int32_t k = 0; k < n_keys; ++k) o.sets[k + 1] += o.sets[k];
+    std::vector<int64_t> cursor(o.sets.begin(), o.sets.end() - 1);
+    o.perm.resize(n);
+    o.inv.resize(n);
+    bool ident = true;
+    for (int64_t i = 0; i < n; ++i) {
+        int64_t pos = cursor[key[i]]++;
+        o.perm[pos] = int32_t(i);
+        o.inv[i] = int32_t(pos);
+        if (pos != i) ident = false;
+    }
+    o.identity = ident;
+    if (ident) { o.perm.clear(); o.inv.clear(); }
+    return o;
+}
+
+// ---- permutation / transpose ----------------------------------------------------------
+HostCsr permute_csr(const omg_csr &A, const int32_t *row_perm, const int32_t *col_inv) {
+    HostCsr out;
+    out.n_rows = A.n_rows;
+    out.n_cols = A.n_cols;
+    out.nnz = A.nnz;
+    out.indptr.resize(A.n_rows + 1);
+    out.indices.resize(A.nnz);
+    out.data.resize(A.nnz);
+    out.indptr[0] = 0;
+    for (int64_t i = 0; i < A.n_rows; ++i) {
+        int64_t src = row_perm ? row_perm[i] : i;
+        out.indptr[i + 1] = out.indptr[i] + (A.indptr[src + 1] - A.indptr[src]);
+    }
+    parallel_rows(A.n_rows, [&](int64_t lo, int64_t hi) {
+        for (int64_t i = lo; i < hi; ++i) {
+            int64_t src = row_perm ? row_perm[i] : i;
+            int32_t q = out.indptr[i];
+            for (int32_t p = A.indptr[src]; p < A.indptr[src + 1]; ++p, ++q) {
+                int32_t c = A.indices[p];
+                out.indices[q] = col_inv ? col_inv[c] : c;   // stored order inside the row kept
+                out.data[q] = A.data[p];
+            }
+        }
+    });
+    return out;
+}
+
+HostCsr transpose_csr(const HostCsr &A) {
+    HostCsr T;
+    T.n_rows = A.n_cols;
+    T.n_cols = A.n_rows;
+    T.nnz = A.nnz;
+    T.indptr.assign(T.n_rows + 1, 0);
+    T.indices.resize(A.nnz);
+    T.data.resize(A.nnz);
+    for (int64_t p = 0; p < A.nnz; ++p) T.indptr[A.indices[p] + 1]++;
+    for (int64_t i = 0; i < T.n_rows; ++i) T.indptr[i + 1] += T.indptr[i];
+    std::vector<int32_t> cursor(T.indptr.begin(), T.indptr.end() - 1);
+    // ascending source row => ascending column inside every transposed row: the order in
+    // which SciPy's csc_matvec accumulates R^T e (openmg/__init__.py:214).
+    for (int64_t i = 0; i < A.n_rows; ++i)
+        for (int32_t p = A.indptr[i]; p < A.indptr[i + 1]; ++p) {
+            int32_t q = cursor[A.indices[p]]++;
+            T.indices[q] = int32_t(i);
+            T.data[q] = A.data[p];
+        }
+    return T;
+}
+
+void make_row_blocks(const std::vector<int32_t> &indptr, const std::vector<int64_t> &sets,
+                     int max_rows, int max_nnz, std::vector<int32_t> &blk_rows,
+                     std::vector<int64_t> &set_blk) {
+    blk_rows.clear();
+    set_blk.assign(1, 0);
+    for (size_t s = 0; s + 1 < sets.size(); ++s) {
+        int64_t r = sets[s];
+        const int64_t end = sets[s + 1];
+        while (r < end) {
+            blk_rows.push_back(int32_t(r));
+            int64_t r1 = r + 1;                       // a block always takes at least one row
+            const int64_t p0 = indptr[r];
+            while (r1 < end && r1 - r < max_rows && indptr[r1 + 1] - p0 <= max_nnz) ++r1;
+            r = r1;
+        }
+        set_blk.push_back(int64_t(blk_rows.size()));
+    }
+    blk_rows.push_back(int32_t(sets.empty() ? 0 : sets.back()));
+}
+
+void DevCsr::upload(const HostCsr &A, const std::vector<int64_t> &sets_in, hipStream_t s) {
+    n_rows = A.n_rows;
+    n_cols = A.n_cols;
+    nnz = A.nnz;
+    sets = sets_in;
+    if (sets.empty()) sets = {0, n_rows};
+    std::vector<int32_t> blocks;
+    make_row_blocks(A.indptr, sets, ROWBLK_ROWS, ROWBLK_NNZ, blocks, set_blk);
+    indptr.alloc(A.indptr.size());
+    indices.alloc(std::max<size_t>(A.indices.size(), 1));
+    data.alloc(std::max<size_t>(A.data.size(), 1));
+    blk_rows.alloc(blocks.size());
+    indptr.upload(A.indptr.data(), A.indptr.size(), s);
+    indices.upload(A.indices.data(), A.indices.size(), s);
+    data.upload(A.data.data(), A.data.size(), s);
+    blk_rows.upload(blocks.data(), blocks.size(), s);
+    OMG_HIP(hipStreamSynchronize(s));   // host staging vectors may die after return
+}
+
+}  // namespace omg

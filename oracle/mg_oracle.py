@@ -408,6 +408,13 @@ def greedy_colouring(A):
     return colour
 
 
+def parity_colouring(shape):
+    """Red-black colouring of a grid in C-order numbering: (sum of coordinates) mod 2.
+    Equal to greedy_colouring() on 3/5/7-point stencils (checked in tests) but vectorised,
+    for sizes where the Python loop above is too slow."""
+    return (np.indices(shape).reshape(len(shape), -1).sum(axis=0) % 2).astype(np.int32)
+
+
 def colour_order(colour):
     """Rows of colour 0 first, then colour 1, ... (stable inside a colour)."""
     return np.argsort(colour, kind="stable").astype(np.int32)
