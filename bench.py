@@ -46,7 +46,7 @@ def build_problem(size, grids, smoother):
     A0 = operators.stencil_poisson(shape)
     u_true = np.random.default_rng(12345).random(A0.shape[0])
     b = A0 @ u_true
-    R = operators.restrictionList(shape, grids - 1, 8)          # gridLevels = grids - 1 (D5)
+    R = operators.restrictionList(shape, grids - 2, 8)          # gridLevels = grids - 1 -> coarsestLevel = grids - 2 (D5)
     A = operators.coeffecientList(A0, R)                        # Galerkin products on the device
     h = _hip.Hierarchy(A, R, smoother=smoother)
     meta = {"n": A0.shape[0], "nnz": A0.nnz, "grids": len(A),
@@ -63,7 +63,7 @@ def cpu_baseline(size, grids, cycles):
     from openmg_amd import operators
     A0 = operators.stencil_poisson(shape)                       # input generator only
     b = A0 @ np.random.default_rng(12345).random(A0.shape[0])
-    R = orc.restriction_list(shape, grids - 1, 8)
+    R = orc.restriction_list(shape, grids - 2, 8)
     A = orc.coefficient_list(A0, R)
     orders = [orc.colour_order(orc.parity_colouring(tuple(s // 2 ** l for s in shape))) for l in range(len(A))]
     sm = lambda M, bb, x, its, level: orc.gs_ordered(M, bb, x, orders[level], its)

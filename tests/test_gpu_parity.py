@@ -454,7 +454,7 @@ def test_full_size_properties(n, levels):
     N = A0.shape[0]
     u_true = np.random.default_rng(12345).random(N)
     b = A0 @ u_true
-    R = operators.restrictionList(shape, levels, 8)
+    R = operators.restrictionList(shape, levels - 1, 8)
     A = operators.coeffecientList(A0, R)
     assert len(A) == levels + 1
     assert A[1].nnz == 7 * (n // 2) ** 3 - 6 * (n // 2) ** 2
