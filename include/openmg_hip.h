@@ -107,10 +107,12 @@ int omg_resident_use_graph(omg_hierarchy *h, int enable);
 
 /* Per-kernel timing of level-0 launches with hipEvents on the hierarchy's stream.
  * Classes: 0 smoother set-sweep, 1 residual, 2 restrict, 3 prolong-add, 4 residual+norm.
- * omg_profile_read syncs and returns, per class, launches and total milliseconds since
- * omg_profile_enable(h, 1).                                                               */
+ * omg_profile_enable(h, mask): bit c of mask switches class c on (-1 = all, 0 = off) and
+ * clears the totals; each timed launch costs two hipEventRecords (~10 us of stream gap), so
+ * bench.py times only class 1 inside its timed region.  omg_profile_read syncs and returns,
+ * per class, launches and total milliseconds since the last omg_profile_enable.           */
 #define OMG_PROFILE_CLASSES 5
-int omg_profile_enable(omg_hierarchy *h, int enable);
+int omg_profile_enable(omg_hierarchy *h, int mask);
 int omg_profile_read(omg_hierarchy *h, int64_t *launches, double *total_ms);
 
 /* ---- single operations on one level of a hierarchy (kernel-level parity tests) ------- */

@@ -251,8 +251,17 @@ class Hierarchy:
         check(lib().omg_hierarchy_level_sets(self._h, level, ctypes.byref(v)))
         return v.value
 
-    def profile_enable(self, enable=True):
-        check(lib().omg_profile_enable(self._h, 1 if enable else 0))
+    def profile_enable(self, classes=True):
+        """True = every class, False = off, or an iterable of class names (PROFILE_NAMES)."""
+        if classes is True:
+            mask = -1
+        elif not classes:
+            mask = 0
+        else:
+            mask = 0
+            for name in classes:
+                mask |= 1 << PROFILE_NAMES.index(name)
+        check(lib().omg_profile_enable(self._h, mask))
 
     def profile_read(self):
         n = (ctypes.c_int64 * PROFILE_CLASSES)()

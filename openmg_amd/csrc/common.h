@@ -140,9 +140,11 @@ void launch_rows(const DevCsr &A, int mode, int set, const RowArgs &args, hipStr
 // back by one workgroup (workgroup barrier between sets).
 void launch_gs_serial(const DevCsr &A, int set_begin, int set_end, const RowArgs &args,
                       hipStream_t s);
-// sum of partials[0..n) -> *out (device), single workgroup, deterministic order
-void launch_sum(const double *partials, int64_t n, double *out, hipStream_t s);
-void launch_sum_sqrt(const double *partials, int64_t n, double *out, hipStream_t s);
+// sum of partials[0..n) -> *out (device), fixed order => deterministic.  `partials` must
+// have SUM_FOLD spare doubles behind its n entries (stage-1 scratch).
+constexpr int SUM_FOLD = 64;
+void launch_sum(double *partials, int64_t n, double *out, hipStream_t s);
+void launch_sum_sqrt(double *partials, int64_t n, double *out, hipStream_t s);
 void launch_gather(const double *src, const int32_t *idx, double *dst, int64_t n, hipStream_t s);   // dst[i] = src[idx[i]]
 void launch_scatter(const double *src, const int32_t *idx, double *dst, int64_t n, hipStream_t s);  // dst[idx[i]] = src[i]
 void launch_dense_gemv(const double *M, const double *v, double *out, int64_t n, hipStream_t s);    // out = M v (row-major n x n)

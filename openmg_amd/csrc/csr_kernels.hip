@@ -31,6 +31,9 @@ constexpr int LDS_SLOTS = (T + 8) + ((T + 8) >> 5) + 1;
 
 __device__ __forceinline__ int slot(int k) { return k + (k >> 5); }
 
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef double v2d __attribute__((ext_vector_type(2)));
+
 struct KArgs {
     const int32_t *blk_rows;
     const int32_t *indptr;
@@ -88,7 +91,7 @@ __device__ __forceinline__ void row_epilogue(const KArgs &a, int r, double sum, 
     }
 }
 
-template <int MODE>
+template <int MODE, bool nt>
 __device__ void process_block(const KArgs &a, int blk, double *s_val, int *s_idx, double *s_red) {
     constexpr bool NEED_DIAG = (MODE == ROW_GS || MODE == ROW_JACOBI);
     constexpr bool NEED_NORM = (MODE == ROW_RESNORM || MODE == ROW_NORM_ONLY);
@@ -102,23 +105,26 @@ __device__ void process_block(const KArgs &a, int blk, double *s_val, int *s_idx
         const int base = p0 & ~3;              // 16-B aligned for int32, 32-B for fp64
         const int cnt = p1 - base;
         {
-            const int4 *gi = reinterpret_cast<const int4 *>(a.indices + base);
+            const v4i *gi = reinterpret_cast<const v4i *>(a.indices + base);
             for (int k = 4 * tid; k < cnt; k += 4 * NT) {
-                const int4 v = gi[k >> 2];
+                // matrix entries are read exactly once: non-temporal so that they do not push
+                // the re-used x lines out of L2 / Infinity Cache
+                const v4i v = nt ? __builtin_nontemporal_load(gi + (k >> 2)) : gi[k >> 2];
                 const int s = slot(k);          // k % 4 == 0: the four slots are contiguous
-                s_idx[s] = v.x; s_idx[s + 1] = v.y; s_idx[s + 2] = v.z; s_idx[s + 3] = v.w;
+                s_idx[s] = v[0]; s_idx[s + 1] = v[1]; s_idx[s + 2] = v[2]; s_idx[s + 3] = v[3];
             }
-            const double2 *gd = reinterpret_cast<const double2 *>(a.data + base);
+            const v2d *gd = reinterpret_cast<const v2d *>(a.data + base);
             for (int k = 2 * tid; k < cnt; k += 2 * NT) {
-                const double2 v = gd[k >> 1];
+                const v2d v = nt ? __builtin_nontemporal_load(gd + (k >> 1)) : gd[k >> 1];
                 const int s = slot(k);
-                s_val[s] = v.x; s_val[s + 1] = v.y;
+                s_val[s] = v[0]; s_val[s + 1] = v[1];
             }
         }
         __syncthreads();
         // ---- phase 2: one thread per row, stored order ---------------------------------
-        const int r = r0 + tid;
-        if (r < r1) {
+        // (blocks of very short rows — prolongation has one entry per row — hold up to
+        // ROWBLK_NNZ rows, so a thread may take several, NT apart: still coalesced)
+        for (int r = r0 + tid; r < r1; r += NT) {
             const int beg = a.indptr[r] - base, end = a.indptr[r + 1] - base;
             double sum = 0.0, diag = 0.0;
             for (int k = beg; k < end; k += 8) {
@@ -176,13 +182,13 @@ __device__ __forceinline__ int xcd_remap(int b, int n) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
 
-template <int MODE>
+template <int MODE, bool NTL>
 __global__ __launch_bounds__(NT) void rows_kernel(KArgs a, int blk0, int remap) {
     __shared__ double s_val[LDS_SLOTS];
     __shared__ int s_idx[LDS_SLOTS];
     __shared__ double s_red[NT / 64];
     const int local = remap ? xcd_remap(blockIdx.x, gridDim.x) : int(blockIdx.x);
-    process_block<MODE>(a, blk0 + local, s_val, s_idx, s_red);
+    process_block<MODE, NTL>(a, blk0 + local, s_val, s_idx, s_red);
 }
 
 // A run of consecutive tiny sets (one row block each), executed back to back by ONE
@@ -196,17 +202,20 @@ __global__ __launch_bounds__(NT) void rows_serial_kernel(KArgs a, int blk_begin,
     __shared__ int s_idx[LDS_SLOTS];
     __shared__ double s_red[NT / 64];
     for (int blk = blk_begin; blk < blk_end; ++blk) {
-        process_block<MODE>(a, blk, s_val, s_idx, s_red);
+        process_block<MODE, false>(a, blk, s_val, s_idx, s_red);
         __threadfence_block();
         __syncthreads();
     }
 }
 
-int remap_enabled() {
+// Tuning switches (speed only): OMG_XCD_REMAP=0 disables the XCD-aware block mapping,
+// OMG_NT_LOADS=0 the non-temporal matrix loads.
+int launch_flags() {
     static int v = -1;
     if (v < 0) {
         const char *e = getenv("OMG_XCD_REMAP");
-        v = (e && e[0] == '0') ? 0 : 1;
+        const char *n = getenv("OMG_NT_LOADS");
+        v = ((e && e[0] == '0') ? 0 : 1) | ((n && n[0] == '0') ? 0 : 2);
     }
     return v;
 }
@@ -214,8 +223,14 @@ int remap_enabled() {
 template <int MODE>
 void launch_mode(const DevCsr &A, int64_t blk0, int64_t nblk, const KArgs &k, hipStream_t s) {
     if (nblk <= 0) return;
-    hipLaunchKernelGGL(rows_kernel<MODE>, dim3((unsigned)nblk), dim3(NT), 0, s, k, (int)blk0,
-                       nblk >= 64 ? remap_enabled() : 0);
+    const int flags = launch_flags();
+    const int remap = (nblk >= 64) ? (flags & 1) : 0;
+    // small operators live in L2 / Infinity Cache across cycles: keep them cacheable
+    const bool ntl = (flags & 2) && A.nnz * 12 > (int64_t(192) << 20);
+    if (ntl)
+        hipLaunchKernelGGL((rows_kernel<MODE, true>), dim3((unsigned)nblk), dim3(NT), 0, s, k, (int)blk0, remap);
+    else
+        hipLaunchKernelGGL((rows_kernel<MODE, false>), dim3((unsigned)nblk), dim3(NT), 0, s, k, (int)blk0, remap);
     OMG_HIP(hipGetLastError());
 }
 
@@ -286,6 +301,19 @@ __global__ __launch_bounds__(1024) void sum_kernel(const double *__restrict__ p,
     }
 }
 
+__global__ __launch_bounds__(256) void fold_kernel(const double *__restrict__ p, int64_t n,
+                                                   double *__restrict__ scratch) {
+    __shared__ double s_red[4];
+    const int64_t chunk = (n + gridDim.x - 1) / gridDim.x;
+    const int64_t lo = blockIdx.x * chunk, hi = min(n, lo + chunk);
+    double acc = 0.0;
+    for (int64_t i = lo + threadIdx.x; i < hi; i += 256) acc += p[i];
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) scratch[blockIdx.x] = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+}
+
 __global__ void gather_kernel(const double *__restrict__ src, const int32_t *__restrict__ idx,
                               double *__restrict__ dst, int64_t n) {
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
@@ -333,14 +361,26 @@ int grid_for(int64_t n, int threads) {
 
 }  // namespace
 
-void launch_sum(const double *partials, int64_t n, double *out, hipStream_t s) {
-    hipLaunchKernelGGL(sum_kernel, dim3(1), dim3(1024), 0, s, partials, n, out, 0);
+// Deterministic two-stage sum: SUM_FOLD workgroups each add one contiguous chunk in a fixed
+// order into scratch[0..SUM_FOLD), then one workgroup adds those.  `partials` must have
+// room for n + SUM_FOLD doubles (the scratch lives behind the data).
+void launch_sum_impl(double *partials, int64_t n, double *out, int take_sqrt, hipStream_t s) {
+    if (n > 8192) {
+        double *scratch = partials + n;
+        hipLaunchKernelGGL(fold_kernel, dim3(SUM_FOLD), dim3(256), 0, s, partials, n, scratch);
+        hipLaunchKernelGGL(sum_kernel, dim3(1), dim3(1024), 0, s, scratch, (int64_t)SUM_FOLD, out, take_sqrt);
+    } else {
+        hipLaunchKernelGGL(sum_kernel, dim3(1), dim3(1024), 0, s, partials, n, out, take_sqrt);
+    }
     OMG_HIP(hipGetLastError());
 }
 
-void launch_sum_sqrt(const double *partials, int64_t n, double *out, hipStream_t s) {
-    hipLaunchKernelGGL(sum_kernel, dim3(1), dim3(1024), 0, s, partials, n, out, 1);
-    OMG_HIP(hipGetLastError());
+void launch_sum(double *partials, int64_t n, double *out, hipStream_t s) {
+    launch_sum_impl(partials, n, out, 0, s);
+}
+
+void launch_sum_sqrt(double *partials, int64_t n, double *out, hipStream_t s) {
+    launch_sum_impl(partials, n, out, 1, s);
 }
 
 void launch_gather(const double *src, const int32_t *idx, double *dst, int64_t n, hipStream_t s) {

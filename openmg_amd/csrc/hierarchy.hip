@@ -65,7 +65,7 @@ struct omg_hierarchy {
     hipGraphExec_t gexec = nullptr;
     int g_pre = -1, g_post = -1;
     // profile
-    bool profiling = false;
+    unsigned profiling = 0;   // bit c set: time level-0 launches of class c
     std::vector<omg::ProfEvent> events;
     int64_t prof_n[OMG_PROFILE_CLASSES] = {0};
     double prof_ms[OMG_PROFILE_CLASSES] = {0};
@@ -122,7 +122,7 @@ struct Prof {
     H *h;
     int idx = -1;
     Prof(H *hh, int level, int cls) : h(hh) {
-        if (!h->profiling || level != 0) return;
+        if (level != 0 || !((h->profiling >> cls) & 1u)) return;
         ProfEvent e;
         e.cls = cls;
         auto get = [&]() {
@@ -353,7 +353,7 @@ std::unique_ptr<H> create(int n_levels, const omg_csr *A, const omg_csr *R, int 
             L.P.upload(Pt, {}, h->stream);
             L.r.alloc(L.n);
             if (smoother == OMG_SMOOTH_JACOBI) L.tmp.alloc(L.n);
-            L.partials.alloc(std::max<int64_t>(L.A.n_blocks(), 1));
+            L.partials.alloc(L.A.n_blocks() + SUM_FOLD);
             build_plan(L);
         }
         L.x.alloc(std::max<int64_t>(L.n, 1));
@@ -562,7 +562,7 @@ int omg_profile_enable(omg_hierarchy *h, int enable) {
         h->events.clear();
         std::memset(h->prof_n, 0, sizeof(h->prof_n));
         std::memset(h->prof_ms, 0, sizeof(h->prof_ms));
-        h->profiling = enable != 0;
+        h->profiling = (unsigned)enable;   // bit c = class c; -1 = all classes
     });
 }
 
@@ -678,7 +678,7 @@ static void standalone_rows(const omg_csr *A, int mode, const double *x, const d
     RowArgs a;
     a.x = dx.p; a.y = dy.p;
     if (b) { db.alloc(std::max<int64_t>(A->n_rows, 1)); db.upload(b, A->n_rows, os.s); a.b = db.p; }
-    if (norm) { part.alloc(std::max<int64_t>(os.A.n_blocks(), 1)); nrm.alloc(1); a.partials = part.p; }
+    if (norm) { part.alloc(os.A.n_blocks() + SUM_FOLD); nrm.alloc(1); a.partials = part.p; }
     launch_rows(os.A, mode, -1, a, os.s);
     if (norm) {
         launch_sum_sqrt(part.p, os.A.n_blocks(), nrm.p, os.s);
@@ -729,7 +729,7 @@ int omg_gauss_seidel(const omg_csr *A, const double *b, double *x, int smoother,
         L.x.alloc(std::max<int64_t>(L.n, 1));
         L.b.alloc(std::max<int64_t>(L.n, 1));
         if (smoother == OMG_SMOOTH_JACOBI) L.tmp.alloc(std::max<int64_t>(L.n, 1));
-        L.partials.alloc(std::max<int64_t>(L.A.n_blocks(), 1));
+        L.partials.alloc(L.A.n_blocks() + SUM_FOLD);
         L.xp = L.x.p;
         L.tp = L.tmp.p;
         build_plan(L);

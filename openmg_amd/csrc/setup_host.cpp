@@ -214,7 +214,15 @@ void DevCsr::upload(const HostCsr &A, const std::vector<int64_t> &sets_in, hipSt
     sets = sets_in;
     if (sets.empty()) sets = {0, n_rows};
     std::vector<int32_t> blocks;
-    make_row_blocks(A.indptr, sets, ROWBLK_ROWS, ROWBLK_NNZ, blocks, set_blk);
+    // One row per thread for stencil-like rows; for very short rows (prolongation: one entry
+    // per row) let a block take as many rows as fit its LDS budget so that each workgroup
+    // still moves tens of KB.
+    int max_rows = ROWBLK_ROWS;
+    if (n_rows > 0) {
+        const double avg = double(nnz) / double(n_rows);
+        while (max_rows < ROWBLK_NNZ && avg * (2 * max_rows) <= ROWBLK_NNZ) max_rows *= 2;
+    }
+    make_row_blocks(A.indptr, sets, max_rows, ROWBLK_NNZ, blocks, set_blk);
     indptr.alloc(A.indptr.size());
     indices.alloc(std::max<size_t>(A.indices.size(), 1));
     data.alloc(std::max<size_t>(A.data.size(), 1));
