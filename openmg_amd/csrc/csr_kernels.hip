@@ -35,7 +35,7 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 typedef double v2d __attribute__((ext_vector_type(2)));
 
 struct KArgs {
-    const int32_t *blk_rows;
+    const int32_t *blk_info;   // (first row, first entry) per row block, + end sentinel
     const int32_t *indptr;
     const int32_t *indices;
     const double *data;
@@ -67,27 +67,48 @@ __device__ __forceinline__ double block_sum(double v, double *s_red) {
     return tot;
 }
 
+// Per-row operands that do not depend on the staged matrix entries.  They are loaded BEFORE
+// the staging loop so that their latency overlaps the matrix stream instead of adding a
+// third dependent memory round trip behind the workgroup barrier.
+struct RowPre {
+    int beg, end;     // CSR extent of the row (absolute entry offsets)
+    double bv, xv;    // b[r]; x[r] (GS, Jacobi) or y[r] (y += A x)
+};
+
 template <int MODE>
-__device__ __forceinline__ void row_epilogue(const KArgs &a, int r, double sum, double diag,
-                                             double &sq) {
+__device__ __forceinline__ RowPre row_preload(const KArgs &a, int r) {
+    RowPre p;
+    p.beg = a.indptr[r];
+    p.end = a.indptr[r + 1];
+    p.bv = 0.0;
+    p.xv = 0.0;
+    if constexpr (MODE != ROW_SPMV && MODE != ROW_AXPY) p.bv = a.b[r];
+    if constexpr (MODE == ROW_GS || MODE == ROW_JACOBI) p.xv = a.x[r];
+    if constexpr (MODE == ROW_AXPY) p.xv = a.y[r];
+    return p;
+}
+
+template <int MODE>
+__device__ __forceinline__ void row_epilogue(const KArgs &a, int r, const RowPre &p, double sum,
+                                             double diag, double &sq) {
     if constexpr (MODE == ROW_SPMV) {
         a.y[r] = sum;
     } else if constexpr (MODE == ROW_RESIDUAL) {
-        a.y[r] = a.b[r] - sum;
+        a.y[r] = p.bv - sum;
     } else if constexpr (MODE == ROW_RESNORM) {
-        const double res = a.b[r] - sum;
+        const double res = p.bv - sum;
         a.y[r] = res;
         sq += res * res;
     } else if constexpr (MODE == ROW_NORM_ONLY) {
-        const double res = a.b[r] - sum;
+        const double res = p.bv - sum;
         sq += res * res;
     } else if constexpr (MODE == ROW_GS) {
         // openmg/solvers.py:68   x[i] = x[i] + (b[i] - Aix) / A[i, i]
-        a.y[r] = a.x[r] + (a.b[r] - sum) / diag;
+        a.y[r] = p.xv + (p.bv - sum) / diag;
     } else if constexpr (MODE == ROW_JACOBI) {
-        a.y[r] = a.x[r] + a.omega * ((a.b[r] - sum) / diag);
+        a.y[r] = p.xv + a.omega * ((p.bv - sum) / diag);
     } else if constexpr (MODE == ROW_AXPY) {
-        a.y[r] = a.y[r] + sum;
+        a.y[r] = p.xv + sum;
     }
 }
 
@@ -96,11 +117,17 @@ __device__ void process_block(const KArgs &a, int blk, double *s_val, int *s_idx
     constexpr bool NEED_DIAG = (MODE == ROW_GS || MODE == ROW_JACOBI);
     constexpr bool NEED_NORM = (MODE == ROW_RESNORM || MODE == ROW_NORM_ONLY);
     const int tid = threadIdx.x;
-    const int r0 = a.blk_rows[blk], r1 = a.blk_rows[blk + 1];
-    const int p0 = a.indptr[r0], p1 = a.indptr[r1];
+    // (first row, first entry) of this block and of the next: one round trip instead of
+    // block table -> indptr
+    const int2 *info = reinterpret_cast<const int2 *>(a.blk_info);
+    const int2 lo = info[blk], hi = info[blk + 1];
+    const int r0 = lo.x, p0 = lo.y, r1 = hi.x, p1 = hi.y;
     double sq = 0.0;
 
     if (p1 - p0 <= T) {
+        int r = r0 + tid;
+        RowPre pre;
+        if (r < r1) pre = row_preload<MODE>(a, r);
         // ---- phase 1: stream the block's entries into LDS, 16 B per lane per load ------
         const int base = p0 & ~3;              // 16-B aligned for int32, 32-B for fp64
         const int cnt = p1 - base;
@@ -124,8 +151,8 @@ __device__ void process_block(const KArgs &a, int blk, double *s_val, int *s_idx
         // ---- phase 2: one thread per row, stored order ---------------------------------
         // (blocks of very short rows — prolongation has one entry per row — hold up to
         // ROWBLK_NNZ rows, so a thread may take several, NT apart: still coalesced)
-        for (int r = r0 + tid; r < r1; r += NT) {
-            const int beg = a.indptr[r] - base, end = a.indptr[r + 1] - base;
+        while (r < r1) {
+            const int beg = pre.beg - base, end = pre.end - base;
             double sum = 0.0, diag = 0.0;
             for (int k = beg; k < end; k += 8) {
                 int c[8];
@@ -147,7 +174,9 @@ __device__ void process_block(const KArgs &a, int blk, double *s_val, int *s_idx
                     }
                 }
             }
-            row_epilogue<MODE>(a, r, sum, diag, sq);
+            row_epilogue<MODE>(a, r, pre, sum, diag, sq);
+            r += NT;
+            if (r < r1) pre = row_preload<MODE>(a, r);
         }
     } else {
         // ---- one long row: the whole workgroup strides over it (summation order differs
@@ -163,7 +192,10 @@ __device__ void process_block(const KArgs &a, int blk, double *s_val, int *s_idx
         const double sum = block_sum(part, s_red);
         double diag = 0.0;
         if (NEED_DIAG) diag = block_sum(dpart, s_red);
-        if (tid == 0) row_epilogue<MODE>(a, r, sum, diag, sq);
+        if (tid == 0) {
+            const RowPre pre = row_preload<MODE>(a, r);
+            row_epilogue<MODE>(a, r, pre, sum, diag, sq);
+        }
     }
     if constexpr (NEED_NORM) {
         const double tot = block_sum(sq, s_red);
@@ -208,14 +240,15 @@ __global__ __launch_bounds__(NT) void rows_serial_kernel(KArgs a, int blk_begin,
     }
 }
 
-// Tuning switches (speed only): OMG_XCD_REMAP=0 disables the XCD-aware block mapping,
-// OMG_NT_LOADS=0 the non-temporal matrix loads.
+// Tuning switches (speed only): OMG_XCD_REMAP=1 enables the XCD-chunked block mapping
+// (measured slower than the hardware's round-robin on the 256^3 stencil: 390 vs 374 us for the
+// residual), OMG_NT_LOADS=0 disables the non-temporal matrix loads (measured 3-4 % slower).
 int launch_flags() {
     static int v = -1;
     if (v < 0) {
         const char *e = getenv("OMG_XCD_REMAP");
         const char *n = getenv("OMG_NT_LOADS");
-        v = ((e && e[0] == '0') ? 0 : 1) | ((n && n[0] == '0') ? 0 : 2);
+        v = ((e && e[0] == '1') ? 1 : 0) | ((n && n[0] == '0') ? 0 : 2);
     }
     return v;
 }
@@ -238,7 +271,7 @@ void launch_mode(const DevCsr &A, int64_t blk0, int64_t nblk, const KArgs &k, hi
 
 void launch_rows(const DevCsr &A, int mode, int set, const RowArgs &args, hipStream_t s) {
     KArgs k;
-    k.blk_rows = A.blk_rows.p;
+    k.blk_info = A.blk_rows.p;
     k.indptr = A.indptr.p;
     k.indices = A.indices.p;
     k.data = A.data.p;
@@ -268,7 +301,7 @@ void launch_rows(const DevCsr &A, int mode, int set, const RowArgs &args, hipStr
 void launch_gs_serial(const DevCsr &A, int set_begin, int set_end, const RowArgs &args,
                       hipStream_t s) {
     KArgs k;
-    k.blk_rows = A.blk_rows.p;
+    k.blk_info = A.blk_rows.p;
     k.indptr = A.indptr.p;
     k.indices = A.indices.p;
     k.data = A.data.p;

@@ -226,11 +226,17 @@ void DevCsr::upload(const HostCsr &A, const std::vector<int64_t> &sets_in, hipSt
     indptr.alloc(A.indptr.size());
     indices.alloc(std::max<size_t>(A.indices.size(), 1));
     data.alloc(std::max<size_t>(A.data.size(), 1));
-    blk_rows.alloc(blocks.size());
+    // interleave (first row, first entry) so that a block reads its extent with one load
+    std::vector<int32_t> info(2 * blocks.size());
+    for (size_t k = 0; k < blocks.size(); ++k) {
+        info[2 * k] = blocks[k];
+        info[2 * k + 1] = A.indptr[blocks[k]];
+    }
+    blk_rows.alloc(info.size());
     indptr.upload(A.indptr.data(), A.indptr.size(), s);
     indices.upload(A.indices.data(), A.indices.size(), s);
     data.upload(A.data.data(), A.data.size(), s);
-    blk_rows.upload(blocks.data(), blocks.size(), s);
+    blk_rows.upload(info.data(), info.size(), s);
     OMG_HIP(hipStreamSynchronize(s));   // host staging vectors may die after return
 }
 
