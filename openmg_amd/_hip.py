@@ -10,7 +10,7 @@ import numpy as np
 import scipy.sparse as sp
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libopenmg_hip.so")
+LIB_PATH = os.environ.get("OMG_LIB_PATH") or os.path.join(_HERE, "lib", "libopenmg_hip.so")   # override: kernel A/B builds
 
 OMG_OK = 0
 ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_SINGULAR, ERR_NO_DIAGONAL, ERR_ALLOC, ERR_UNSUPPORTED = range(1, 8)

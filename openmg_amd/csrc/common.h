@@ -101,7 +101,10 @@ void make_row_blocks(const std::vector<int32_t> &indptr, const std::vector<int64
 // ---- device CSR ---------------------------------------------------------------------
 constexpr int ROWBLK_THREADS = 256;   // threads per workgroup of the row kernels
 constexpr int ROWBLK_ROWS = 256;      // <= one row per thread
-constexpr int ROWBLK_NNZ = 2048;      // entries staged through LDS per workgroup
+#ifndef OMG_ROWBLK_NNZ
+#define OMG_ROWBLK_NNZ 2048
+#endif
+constexpr int ROWBLK_NNZ = OMG_ROWBLK_NNZ;   // entries staged through LDS per workgroup
 
 struct DevCsr {
     int64_t n_rows = 0, n_cols = 0, nnz = 0;
@@ -110,6 +113,7 @@ struct DevCsr {
     DevBuf<int32_t> blk_rows;          // first row of every row block (+ end sentinel)
     std::vector<int64_t> set_blk;      // block offsets of the independent sets (host)
     std::vector<int64_t> sets;         // row offsets of the sets (host)
+    int rows_cap = ROWBLK_ROWS;        // most rows a block may hold (> ROWBLK_THREADS: short rows)
     void upload(const HostCsr &A, const std::vector<int64_t> &sets, hipStream_t s);
     size_t n_sets() const { return sets.empty() ? 0 : sets.size() - 1; }
     int64_t n_blocks() const { return set_blk.empty() ? 0 : set_blk.back(); }
@@ -132,6 +136,7 @@ struct RowArgs {
     double *y = nullptr;         // output (GS: the same pointer as x)
     double omega = 1.0;
     double *partials = nullptr;  // one double per row block (RESNORM / NORM_ONLY)
+    double *zero = nullptr;      // ROW_SPMV: zero[r] = 0 alongside y[r] (fused clear)
 };
 
 // Launch `mode` over row set `set` of A (set < 0: all sets in one launch).

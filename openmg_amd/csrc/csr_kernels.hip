@@ -43,6 +43,7 @@ struct KArgs {
     const double *b;
     double *y;
     double *partials;
+    double *zero;              // SpMV only: also clear zero[r] (next level's initial iterate)
     double omega;
 };
 
@@ -93,6 +94,7 @@ __device__ __forceinline__ void row_epilogue(const KArgs &a, int r, const RowPre
                                              double diag, double &sq) {
     if constexpr (MODE == ROW_SPMV) {
         a.y[r] = sum;
+        if (a.zero) a.zero[r] = 0.0;
     } else if constexpr (MODE == ROW_RESIDUAL) {
         a.y[r] = p.bv - sum;
     } else if constexpr (MODE == ROW_RESNORM) {
@@ -112,7 +114,10 @@ __device__ __forceinline__ void row_epilogue(const KArgs &a, int r, const RowPre
     }
 }
 
-template <int MODE, bool nt>
+// SHORT selects the phase-2 variant for operators whose rows are so short (prolongation:
+// one entry per row) that a block holds several rows per thread: the rows of a thread are
+// then processed eight at a time with all their loads in flight together.
+template <int MODE, bool nt, bool SHORT>
 __device__ void process_block(const KArgs &a, int blk, double *s_val, int *s_idx, double *s_red) {
     constexpr bool NEED_DIAG = (MODE == ROW_GS || MODE == ROW_JACOBI);
     constexpr bool NEED_NORM = (MODE == ROW_RESNORM || MODE == ROW_NORM_ONLY);
@@ -127,7 +132,7 @@ __device__ void process_block(const KArgs &a, int blk, double *s_val, int *s_idx
     if (p1 - p0 <= T) {
         int r = r0 + tid;
         RowPre pre;
-        if (r < r1) pre = row_preload<MODE>(a, r);
+        if (!SHORT && r < r1) pre = row_preload<MODE>(a, r);
         // ---- phase 1: stream the block's entries into LDS, 16 B per lane per load ------
         const int base = p0 & ~3;              // 16-B aligned for int32, 32-B for fp64
         const int cnt = p1 - base;
@@ -151,32 +156,68 @@ __device__ void process_block(const KArgs &a, int blk, double *s_val, int *s_idx
         // ---- phase 2: one thread per row, stored order ---------------------------------
         // (blocks of very short rows — prolongation has one entry per row — hold up to
         // ROWBLK_NNZ rows, so a thread may take several, NT apart: still coalesced)
-        while (r < r1) {
-            const int beg = pre.beg - base, end = pre.end - base;
-            double sum = 0.0, diag = 0.0;
-            for (int k = beg; k < end; k += 8) {
-                int c[8];
-                double v[8], xv[8];
+        if constexpr (SHORT) {
+            constexpr int U = 8;
+            for (int rb = r; rb < r1; rb += U * NT) {
+                RowPre q[U];
+                int c0[U];
+                double v0[U], x0[U], sum[U];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int kk = min(k + j, end - 1);
-                    const int s = slot(kk);
-                    c[j] = s_idx[s];
-                    v[j] = s_val[s];
+                for (int u = 0; u < U; ++u) {
+                    const int ru = rb + u * NT;
+                    q[u].beg = q[u].end = 0;
+                    if (ru < r1) q[u] = row_preload<MODE>(a, ru);
                 }
 #pragma unroll
-                for (int j = 0; j < 8; ++j) xv[j] = a.x[c[j]];
+                for (int u = 0; u < U; ++u) {           // first entry of every row, batched
+                    const bool has = q[u].beg < q[u].end;
+                    const int sl = slot(has ? q[u].beg - base : 0);
+                    c0[u] = has ? s_idx[sl] : 0;
+                    v0[u] = has ? s_val[sl] : 0.0;
+                }
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    if (k + j < end) {
-                        sum += v[j] * xv[j];
-                        if (NEED_DIAG && c[j] == r) diag += v[j];
+                for (int u = 0; u < U; ++u) x0[u] = a.x[c0[u]];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int ru = rb + u * NT;
+                    if (ru >= r1) continue;
+                    sum[u] = (q[u].beg < q[u].end) ? v0[u] * x0[u] : 0.0;
+                    for (int k = q[u].beg + 1 - base; k < q[u].end - base; ++k) {   // rest, stored order
+                        const int sl = slot(k);
+                        sum[u] += s_val[sl] * a.x[s_idx[sl]];
                     }
+                    double unused = 0.0;
+                    row_epilogue<MODE>(a, ru, q[u], sum[u], 0.0, unused);
                 }
             }
-            row_epilogue<MODE>(a, r, pre, sum, diag, sq);
-            r += NT;
-            if (r < r1) pre = row_preload<MODE>(a, r);
+        } else {
+        while (r < r1) {
+                const int beg = pre.beg - base, end = pre.end - base;
+                double sum = 0.0, diag = 0.0;
+                for (int k = beg; k < end; k += 8) {
+                    int c[8];
+                    double v[8], xv[8];
+    #pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const int kk = min(k + j, end - 1);
+                        const int s = slot(kk);
+                        c[j] = s_idx[s];
+                        v[j] = s_val[s];
+                    }
+    #pragma unroll
+                    for (int j = 0; j < 8; ++j) xv[j] = a.x[c[j]];
+    #pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        if (k + j < end) {
+                            sum += v[j] * xv[j];
+                            if (NEED_DIAG && c[j] == r) diag += v[j];
+                        }
+                    }
+                }
+                row_epilogue<MODE>(a, r, pre, sum, diag, sq);
+                r += NT;
+                if (r < r1) pre = row_preload<MODE>(a, r);
+            }
         }
     } else {
         // ---- one long row: the whole workgroup strides over it (summation order differs
@@ -214,13 +255,13 @@ __device__ __forceinline__ int xcd_remap(int b, int n) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
 
-template <int MODE, bool NTL>
+template <int MODE, bool NTL, bool SHORT>
 __global__ __launch_bounds__(NT) void rows_kernel(KArgs a, int blk0, int remap) {
     __shared__ double s_val[LDS_SLOTS];
     __shared__ int s_idx[LDS_SLOTS];
     __shared__ double s_red[NT / 64];
     const int local = remap ? xcd_remap(blockIdx.x, gridDim.x) : int(blockIdx.x);
-    process_block<MODE, NTL>(a, blk0 + local, s_val, s_idx, s_red);
+    process_block<MODE, NTL, SHORT>(a, blk0 + local, s_val, s_idx, s_red);
 }
 
 // A run of consecutive tiny sets (one row block each), executed back to back by ONE
@@ -234,7 +275,7 @@ __global__ __launch_bounds__(NT) void rows_serial_kernel(KArgs a, int blk_begin,
     __shared__ int s_idx[LDS_SLOTS];
     __shared__ double s_red[NT / 64];
     for (int blk = blk_begin; blk < blk_end; ++blk) {
-        process_block<MODE, false>(a, blk, s_val, s_idx, s_red);
+        process_block<MODE, false, false>(a, blk, s_val, s_idx, s_red);
         __threadfence_block();
         __syncthreads();
     }
@@ -260,10 +301,20 @@ void launch_mode(const DevCsr &A, int64_t blk0, int64_t nblk, const KArgs &k, hi
     const int remap = (nblk >= 64) ? (flags & 1) : 0;
     // small operators live in L2 / Infinity Cache across cycles: keep them cacheable
     const bool ntl = (flags & 2) && A.nnz * 12 > (int64_t(192) << 20);
-    if (ntl)
-        hipLaunchKernelGGL((rows_kernel<MODE, true>), dim3((unsigned)nblk), dim3(NT), 0, s, k, (int)blk0, remap);
-    else
-        hipLaunchKernelGGL((rows_kernel<MODE, false>), dim3((unsigned)nblk), dim3(NT), 0, s, k, (int)blk0, remap);
+    // several rows per thread (short rows): batched variant, built for the modes such
+    // operators are used with; other modes fall back to the generic one-row-at-a-time loop
+    constexpr bool HAS_SHORT = (MODE == ROW_SPMV || MODE == ROW_AXPY || MODE == ROW_RESIDUAL);
+    const dim3 grid((unsigned)nblk), block(NT);
+    if constexpr (HAS_SHORT) {
+        if (A.rows_cap > NT) {
+            if (ntl) hipLaunchKernelGGL((rows_kernel<MODE, true, true>), grid, block, 0, s, k, (int)blk0, remap);
+            else hipLaunchKernelGGL((rows_kernel<MODE, false, true>), grid, block, 0, s, k, (int)blk0, remap);
+            OMG_HIP(hipGetLastError());
+            return;
+        }
+    }
+    if (ntl) hipLaunchKernelGGL((rows_kernel<MODE, true, false>), grid, block, 0, s, k, (int)blk0, remap);
+    else hipLaunchKernelGGL((rows_kernel<MODE, false, false>), grid, block, 0, s, k, (int)blk0, remap);
     OMG_HIP(hipGetLastError());
 }
 
@@ -279,6 +330,7 @@ void launch_rows(const DevCsr &A, int mode, int set, const RowArgs &args, hipStr
     k.b = args.b;
     k.y = args.y;
     k.partials = args.partials;
+    k.zero = args.zero;
     k.omega = args.omega;
     int64_t blk0 = 0, nblk = A.n_blocks();
     if (set >= 0) {
@@ -309,6 +361,7 @@ void launch_gs_serial(const DevCsr &A, int set_begin, int set_end, const RowArgs
     k.b = args.b;
     k.y = args.y;
     k.partials = nullptr;
+    k.zero = nullptr;
     k.omega = args.omega;
     const int b0 = (int)A.set_blk[set_begin], b1 = (int)A.set_blk[set_end];
     if (b1 <= b0) return;

@@ -184,11 +184,12 @@ void norm_level(H *h, int l, double *r_out) {
     launch_sum_sqrt(L.partials.p, L.A.n_blocks(), h->norm_dev.p, h->stream);
 }
 
-void restrict_level(H *h, int l, const double *fine, double *coarse) {
+// coarse = R fine; `clear` (nullable, coarse-sized) is zeroed by the same launch.
+void restrict_level(H *h, int l, const double *fine, double *coarse, double *clear = nullptr) {
     Level &L = h->lv[l];
     Prof p(h, l, 2);
     RowArgs a;
-    a.x = fine; a.y = coarse;
+    a.x = fine; a.y = coarse; a.zero = clear;
     launch_rows(L.R, ROW_SPMV, -1, a, h->stream);
 }
 
@@ -218,8 +219,8 @@ void cycle_body(H *h, int l, int pre, int post) {
     Level &C = h->lv[l + 1];
     smooth_level(h, l, pre);                                  // :201
     residual_level(h, l, L.r.p);                              // :209
-    restrict_level(h, l, L.r.p, C.b.p);                       // :210
-    if (l + 1 < last) OMG_HIP(hipMemsetAsync(C.xp, 0, C.n * sizeof(double), h->stream));   // :191-192
+    // :210, and the coarse cycle's initial=None -> zeros (:191-192) cleared by the same launch
+    restrict_level(h, l, L.r.p, C.b.p, l + 1 < last ? C.xp : nullptr);
     cycle_body(h, l + 1, pre, post);                          // :213
     prolong_add_level(h, l, C.xp, L.xp);                      // :214, :220/:224
     if (post > 0) smooth_level(h, l, post);                   // :216-222

@@ -222,6 +222,7 @@ void DevCsr::upload(const HostCsr &A, const std::vector<int64_t> &sets_in, hipSt
         const double avg = double(nnz) / double(n_rows);
         while (max_rows < ROWBLK_NNZ && avg * (2 * max_rows) <= ROWBLK_NNZ) max_rows *= 2;
     }
+    rows_cap = max_rows;
     make_row_blocks(A.indptr, sets, max_rows, ROWBLK_NNZ, blocks, set_blk);
     indptr.alloc(A.indptr.size());
     indices.alloc(std::max<size_t>(A.indices.size(), 1));
