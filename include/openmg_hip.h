@@ -162,6 +162,61 @@ int omg_csr_result_free(omg_csr_result *res);
 int omg_restriction(int dim, const int64_t *shape, int32_t *indptr, int32_t *indices,
                     double *data, int64_t *n_rows, int64_t *nnz);
 
+/* ---- multi-GPU: one process per GPU, 1-D slabs, RCCL halo exchange ---------------------------
+ * No reference counterpart (the reference is single-threaded): the same
+ * mgCycle (openmg/__init__.py:151-236) run on a row-partitioned hierarchy.  Each rank owns a
+ * contiguous row range of every level.  A level of one rank is described by:
+ *   A      owned rows; columns 0..n_loc-1 are the owned unknowns (local numbering), columns
+ *          n_loc..n_loc+n_halo-1 the remote unknowns its rows touch (the halo), grouped by
+ *          owning peer in the order of `peers`;
+ *   R      restriction to the next level, (coarse owned rows) x (fine owned rows) — slabs
+ *          must be cut on aggregate boundaries (ignored on the coarsest level);
+ *   keys   smoother set of every owned row, 0 <= key < n_sets, consistent across ranks
+ *          (NULL: one set, e.g. Jacobi; ignored on the coarsest level);
+ *   peers[n_peers], send_off[n_peers+1], send_idx[send_off[n_peers]] (owned rows, local
+ *          numbering, sent to each peer), recv_off[n_peers+1] (slots of the halo region
+ *          filled by each peer; recv_off[n_peers] == n_halo).
+ * coarse_global is the WHOLE coarsest operator (replicated direct solve); coarse_counts[q] =
+ * coarsest rows owned by rank q.                                                           */
+typedef struct {
+    omg_csr A;
+    omg_csr R;
+    int64_t n_halo;
+    const int32_t *keys;
+    int32_t n_sets;
+    int32_t n_peers;
+    const int32_t *peers;
+    const int64_t *send_off;
+    const int32_t *send_idx;
+    const int64_t *recv_off;
+} omg_dist_level;
+
+typedef struct omg_dist omg_dist;
+typedef struct omg_dist_group omg_dist_group;
+
+int omg_dist_create(int rank, int n_ranks, int n_levels, const omg_dist_level *levels,
+                    const omg_csr *coarse_global, const int64_t *coarse_counts,
+                    int smoother, double omega, omg_dist **out);
+int omg_dist_destroy(omg_dist *d);
+int omg_dist_set_stream(omg_dist *d, void *hip_stream);
+int omg_dist_sync(omg_dist *d);
+/* RCCL bootstrap: rank 0 makes a 128-byte id, the host broadcasts it (torch.distributed),
+ * every rank connects.  librccl is dlopen'ed on first use.                                */
+int omg_rccl_unique_id(void *out128);
+int omg_dist_connect(omg_dist *d, const void *unique_id128);
+/* owned part of b and of the initial iterate (NULL = zeros), natural local numbering */
+int omg_dist_load(omg_dist *d, const double *b_local, const double *x0_local);
+int omg_dist_fetch(omg_dist *d, double *x_local);
+/* One V-cycle over all ranks (collective: every rank calls it).  *norm (nullable) = the
+ * GLOBAL ||b - A x||_2 (openmg/__init__.py:227).                                          */
+int omg_dist_cycle(omg_dist *d, int pre, int post, double *norm);
+/* Loopback group: ALL ranks of a decomposition inside one process on one GPU, halos moved by
+ * device-to-device copies.  Same schedule as omg_dist_cycle; used to verify the distributed
+ * algorithm where only one GPU is available.                                               */
+int omg_dist_group_create(int n, omg_dist **ranks, omg_dist_group **out);
+int omg_dist_group_destroy(omg_dist_group *g);
+int omg_dist_group_cycle(omg_dist_group *g, int pre, int post, double *norm);
+
 #ifdef __cplusplus
 }
 #endif

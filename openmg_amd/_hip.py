@@ -83,7 +83,27 @@ SIGNATURES = {
     "omg_csr_result_fetch": (_I, [_P, _P, _P, _P]),
     "omg_csr_result_free": (_I, [_P]),
     "omg_restriction": (_I, [_I, _I64P, _P, _P, _P, _I64P, _I64P]),
+    "omg_dist_create": (_I, [_I, _I, _I, _P, _CSR, _I64P, _I, _D, _PP]),
+    "omg_dist_destroy": (_I, [_P]),
+    "omg_dist_set_stream": (_I, [_P, _P]),
+    "omg_dist_sync": (_I, [_P]),
+    "omg_rccl_unique_id": (_I, [_P]),
+    "omg_dist_connect": (_I, [_P, _P]),
+    "omg_dist_load": (_I, [_P, _P, _P]),
+    "omg_dist_fetch": (_I, [_P, _P]),
+    "omg_dist_cycle": (_I, [_P, _I, _I, _DP]),
+    "omg_dist_group_create": (_I, [_I, _PP, _PP]),
+    "omg_dist_group_destroy": (_I, [_P]),
+    "omg_dist_group_cycle": (_I, [_P, _I, _I, _DP]),
 }
+
+
+class DistLevelView(ctypes.Structure):
+    """omg_dist_level in include/openmg_hip.h."""
+    _fields_ = [("A", CsrView), ("R", CsrView), ("n_halo", ctypes.c_int64),
+                ("keys", ctypes.c_void_p), ("n_sets", ctypes.c_int32), ("n_peers", ctypes.c_int32),
+                ("peers", ctypes.c_void_p), ("send_off", ctypes.c_void_p),
+                ("send_idx", ctypes.c_void_p), ("recv_off", ctypes.c_void_p)]
 
 _lib = None
 

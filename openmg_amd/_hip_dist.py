@@ -1,0 +1,119 @@
+"""ctypes wrappers of the multi-GPU entry points (omg_dist_* in include/openmg_hip.h)."""
+import ctypes
+
+import numpy as np
+import scipy.sparse as sp
+
+from ._hip import DistLevelView, as_csr, check, csr_view, lib, smoother_code, vec
+
+
+def set_device(device):
+    check(lib().omg_set_device(int(device)))
+
+
+def rccl_unique_id():
+    """128-byte RCCL bootstrap id (make it on rank 0, broadcast it, connect everywhere)."""
+    buf = ctypes.create_string_buffer(128)
+    check(lib().omg_rccl_unique_id(buf))
+    return buf.raw
+
+
+class DistRank:
+    """One rank's slab of a row-partitioned hierarchy (omg_dist).  `levels` is the list made
+    by openmg_amd.dist: dicts with A, R (CSR, local column numbering), n_halo, keys, n_sets,
+    peers, send_off, send_idx, recv_off."""
+
+    def __init__(self, rank, n_ranks, levels, coarse_global, coarse_counts, smoother="colour", omega=1.0):
+        self.rank, self.n_ranks = int(rank), int(n_ranks)
+        keep = []
+        views = (DistLevelView * len(levels))()
+        empty = sp.csr_matrix((0, 0))
+        for l, lv in enumerate(levels):
+            A = as_csr(lv["A"])
+            R = as_csr(lv["R"]) if lv.get("R") is not None else as_csr(empty)
+            keys = None if lv.get("keys") is None else np.ascontiguousarray(lv["keys"], dtype=np.int32)
+            peers = np.ascontiguousarray(lv["peers"], dtype=np.int32)
+            send_off = np.ascontiguousarray(lv["send_off"], dtype=np.int64)
+            send_idx = np.ascontiguousarray(lv["send_idx"], dtype=np.int32)
+            recv_off = np.ascontiguousarray(lv["recv_off"], dtype=np.int64)
+            keep += [A, R, keys, peers, send_off, send_idx, recv_off]
+            v = views[l]
+            v.A, v.R = csr_view(A), csr_view(R)
+            v.n_halo = int(lv["n_halo"])
+            v.keys = None if keys is None else keys.ctypes.data
+            v.n_sets = int(lv.get("n_sets", 0))
+            v.n_peers = len(peers)
+            v.peers = peers.ctypes.data
+            v.send_off = send_off.ctypes.data
+            v.send_idx = send_idx.ctypes.data
+            v.recv_off = recv_off.ctypes.data
+        G = as_csr(coarse_global)
+        gv = csr_view(G)
+        counts = (ctypes.c_int64 * self.n_ranks)(*[int(c) for c in coarse_counts])
+        self.n_local = levels[0]["A"].shape[0]
+        h = ctypes.c_void_p()
+        check(lib().omg_dist_create(self.rank, self.n_ranks, len(levels), views, ctypes.byref(gv), counts,
+                                    smoother_code(smoother), float(omega), ctypes.byref(h)))
+        self._h = h
+        del keep
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().omg_dist_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def connect(self, unique_id):
+        check(lib().omg_dist_connect(self._h, ctypes.c_char_p(unique_id)))
+
+    def set_stream(self, hip_stream):
+        check(lib().omg_dist_set_stream(self._h, ctypes.c_void_p(hip_stream or 0)))
+
+    def sync(self):
+        check(lib().omg_dist_sync(self._h))
+
+    def load(self, b_local, x0_local=None):
+        b = vec(b_local, self.n_local)
+        x0 = None if x0_local is None else vec(x0_local, self.n_local)
+        check(lib().omg_dist_load(self._h, b.ctypes.data, None if x0 is None else x0.ctypes.data))
+
+    def fetch(self):
+        x = np.empty(self.n_local)
+        check(lib().omg_dist_fetch(self._h, x.ctypes.data))
+        return x
+
+    def cycle(self, pre, post, want_norm=True):
+        if want_norm:
+            norm = ctypes.c_double(0.0)
+            check(lib().omg_dist_cycle(self._h, int(pre), int(post), ctypes.byref(norm)))
+            return norm.value
+        check(lib().omg_dist_cycle(self._h, int(pre), int(post), None))
+        return None
+
+
+class DistGroup:
+    """Loopback group: every rank of a decomposition inside this process, on one GPU."""
+
+    def __init__(self, ranks):
+        self.ranks = list(ranks)
+        arr = (ctypes.c_void_p * len(self.ranks))(*[r._h for r in self.ranks])
+        g = ctypes.c_void_p()
+        check(lib().omg_dist_group_create(len(self.ranks), arr, ctypes.byref(g)))
+        self._g = g
+
+    def cycle(self, pre, post, want_norm=True):
+        norm = ctypes.c_double(0.0)
+        check(lib().omg_dist_group_cycle(self._g, int(pre), int(post), ctypes.byref(norm) if want_norm else None))
+        return norm.value if want_norm else None
+
+    def close(self):
+        if getattr(self, "_g", None):
+            lib().omg_dist_group_destroy(self._g)
+            self._g = None
+        for r in self.ranks:
+            r.close()

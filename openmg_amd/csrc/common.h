@@ -89,8 +89,13 @@ struct Ordering {
 // setup_host.cpp
 void validate_csr(const omg_csr &A, const char *what);
 Ordering make_ordering(const omg_csr &A, int smoother);
+// col_inv relabels only columns < n_inv (n_inv < 0: all of them); a distributed level keeps
+// its halo columns (>= number of owned rows) where they are.
 HostCsr permute_csr(const omg_csr &A, const int32_t *row_perm /* new->old or null */,
-                    const int32_t *col_inv /* old->new or null */);
+                    const int32_t *col_inv /* old->new or null */, int64_t n_inv = -1);
+// Ordering from caller-supplied set keys (0 <= key < n_sets) instead of a local colouring:
+// distributed runs need keys that agree across ranks.  Empty sets are kept.
+Ordering ordering_from_keys(const int32_t *keys, int64_t n, int32_t n_sets);
 HostCsr transpose_csr(const HostCsr &A);
 // Row blocks for the streaming kernels: greedy split of each set into blocks of at most
 // `max_rows` rows and `max_nnz` entries (a single longer row gets a block of its own).
@@ -153,6 +158,8 @@ void launch_sum_sqrt(double *partials, int64_t n, double *out, hipStream_t s);
 void launch_gather(const double *src, const int32_t *idx, double *dst, int64_t n, hipStream_t s);   // dst[i] = src[idx[i]]
 void launch_scatter(const double *src, const int32_t *idx, double *dst, int64_t n, hipStream_t s);  // dst[idx[i]] = src[i]
 void launch_dense_gemv(const double *M, const double *v, double *out, int64_t n, hipStream_t s);    // out = M v (row-major n x n)
+void launch_dense_gemv_rows(const double *M, const double *v, double *out, int64_t rows, int64_t n,
+                            hipStream_t s);                                                       // M: rows x n slab
 // Dense inverse (row-major n x n) of a square device CSR matrix by Gauss-Jordan with
 // partial pivoting on the device.  Throws OMG_ERR_SINGULAR / OMG_ERR_UNSUPPORTED (n > 16384).
 void dense_inverse_from_csr(const DevCsr &A, double *Minv, hipStream_t s);

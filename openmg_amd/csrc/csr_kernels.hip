@@ -414,13 +414,14 @@ __global__ void scatter_kernel(const double *__restrict__ src, const int32_t *__
         dst[idx[i]] = src[i];
 }
 
-// out = M v, M row-major n x n.  One wave per row, 16-byte loads, 4 rows per workgroup.
+// out = M v, M row-major rows x n.  One wave per row, 16-byte loads, 4 rows per workgroup.
 __global__ __launch_bounds__(256) void dense_gemv_kernel(const double *__restrict__ M,
                                                          const double *__restrict__ v,
-                                                         double *__restrict__ out, int64_t n) {
+                                                         double *__restrict__ out, int64_t rows,
+                                                         int64_t n) {
     const int lane = threadIdx.x & 63;
     const int64_t row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= n) return;
+    if (row >= rows) return;
     const double *m = M + row * n;
     double acc = 0.0;
     if ((n & 1) == 0) {
@@ -482,8 +483,13 @@ void launch_scatter(const double *src, const int32_t *idx, double *dst, int64_t 
 }
 
 void launch_dense_gemv(const double *M, const double *v, double *out, int64_t n, hipStream_t s) {
-    if (n <= 0) return;
-    hipLaunchKernelGGL(dense_gemv_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, M, v, out, n);
+    launch_dense_gemv_rows(M, v, out, n, n, s);
+}
+
+void launch_dense_gemv_rows(const double *M, const double *v, double *out, int64_t rows, int64_t n,
+                            hipStream_t s) {
+    if (rows <= 0 || n <= 0) return;
+    hipLaunchKernelGGL(dense_gemv_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, M, v, out, rows, n);
     OMG_HIP(hipGetLastError());
 }
 

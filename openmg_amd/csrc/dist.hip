@@ -1,0 +1,568 @@
+// Multi-GPU V-cycle: 1-D slab decomposition, one process per GPU, RCCL over xGMI.
+//
+// Each rank owns a contiguous range of rows of every level.  Its local operator A_l has the
+// owned columns first (local numbering) and the remote columns it touches — the HALO — behind
+// them; x_l is stored as [owned | halo].  The hot path of a cycle is the single-GPU one
+// (csr_kernels.hip) plus three exchanges:
+//   * after every smoother set and after prolongation: boundary values of x_l to the slab
+//     neighbours (pack kernel -> grouped ncclSend/ncclRecv straight into the halo region);
+//   * before the coarse solve: all-gather of the coarsest right-hand side, then every rank
+//     applies its own rows of the replicated inverse;
+//   * for the residual norm: one 8-byte all-reduce.
+// Restriction and prolongation are local: slabs are cut on aggregate boundaries (the host
+// checks it).  Rows of one smoother set are mutually uncoupled, so the iterate does not
+// depend on the number of ranks.
+//
+// The same schedule runs over a LOOPBACK group — several ranks living in one process on one
+// GPU, halos moved with device-to-device copies — which is how the distributed algorithm is
+// verified on a single-GPU box (tests/test_gpu_dist.py); only the thin RCCL calls differ.
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <memory>
+
+#include "common.h"
+
+namespace omg {
+namespace {
+
+// ---- RCCL, resolved at run time so that the library loads on hosts without it --------------
+struct Rccl {
+    void *handle = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclSend) Send = nullptr;
+    decltype(&ncclRecv) Recv = nullptr;
+    decltype(&ncclAllGather) AllGather = nullptr;
+    decltype(&ncclAllReduce) AllReduce = nullptr;
+
+    template <typename F>
+    void sym(F &fn, const char *name) {
+        fn = reinterpret_cast<F>(dlsym(handle, name));
+        if (!fn) throw Error(OMG_ERR_UNSUPPORTED, std::string("RCCL symbol missing: ") + name);
+    }
+    void load() {
+        if (handle) return;
+        // an already-loaded copy (e.g. the one PyTorch brought) wins; then the ROCm install
+        for (const char *n : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+            if (handle) break;
+        }
+        if (!handle) throw Error(OMG_ERR_UNSUPPORTED, std::string("cannot load librccl: ") + dlerror());
+        sym(GetUniqueId, "ncclGetUniqueId");
+        sym(CommInitRank, "ncclCommInitRank");
+        sym(CommDestroy, "ncclCommDestroy");
+        sym(GetErrorString, "ncclGetErrorString");
+        sym(GroupStart, "ncclGroupStart");
+        sym(GroupEnd, "ncclGroupEnd");
+        sym(Send, "ncclSend");
+        sym(Recv, "ncclRecv");
+        sym(AllGather, "ncclAllGather");
+        sym(AllReduce, "ncclAllReduce");
+    }
+};
+Rccl g_rccl;
+
+#define OMG_NCCL(call)                                                                        \
+    do {                                                                                      \
+        ncclResult_t r_ = (call);                                                             \
+        if (r_ != ncclSuccess)                                                                \
+            throw omg::Error(OMG_ERR_HIP, std::string(#call) + ": " + g_rccl.GetErrorString(r_)); \
+    } while (0)
+
+struct DLevel {
+    int64_t n_loc = 0, n_halo = 0;
+    DevCsr A, R, P;
+    Ordering ord;
+    DevBuf<int32_t> perm;
+    DevBuf<double> x, tmp, b, r, partials, nat;
+    double *xp = nullptr, *tp = nullptr;
+    // halo plan
+    std::vector<int> peers;
+    std::vector<int64_t> send_off, recv_off;   // per peer, size peers + 1
+    DevBuf<int32_t> send_idx;                  // rows (this level's ordering) to send, all peers
+    DevBuf<double> send_buf;
+};
+
+__global__ void sqrt_kernel(double *v) { *v = sqrt(*v); }
+
+}  // namespace
+}  // namespace omg
+
+using namespace omg;
+
+struct omg_dist {
+    int rank = 0, n_ranks = 1;
+    std::vector<DLevel> lv;
+    int smoother = OMG_SMOOTH_GS_COLOUR;
+    double omega = 1.0;
+    hipStream_t own = nullptr, stream = nullptr;
+    // coarsest level: replicated inverse, gathered right-hand side
+    int64_t n_coarse = 0, coarse_lo = 0;
+    std::vector<int64_t> coarse_counts;        // rows per rank at the coarsest level
+    DevBuf<double> coarse_inv, coarse_rhs;
+    DevBuf<double> sumsq;                      // device scalar
+    ncclComm_t comm = nullptr;
+    bool halo_dirty = true;
+    bool loaded = false;
+
+    ~omg_dist() {
+        if (comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(comm);
+        if (own) (void)hipStreamDestroy(own);
+    }
+};
+
+struct omg_dist_group {
+    std::vector<omg_dist *> ranks;             // borrowed; all on one device, one shared stream
+};
+
+namespace omg {
+namespace {
+
+using D = omg_dist;
+
+omg_csr view(const HostCsr &A) {
+    return omg_csr{A.n_rows, A.n_cols, A.nnz, A.indptr.data(), A.indices.data(), A.data.data()};
+}
+
+std::unique_ptr<D> create(int rank, int n_ranks, int n_levels, const omg_dist_level *lv,
+                          const omg_csr *coarse_global, const int64_t *coarse_counts, int smoother,
+                          double omega) {
+    OMG_REQUIRE(n_ranks >= 1 && rank >= 0 && rank < n_ranks, "bad rank / n_ranks");
+    OMG_REQUIRE(n_levels >= 1 && lv && coarse_global && coarse_counts, "null argument");
+    require_device();
+    std::unique_ptr<D> d(new D);
+    d->rank = rank;
+    d->n_ranks = n_ranks;
+    d->smoother = smoother;
+    d->omega = omega;
+    OMG_HIP(hipStreamCreateWithFlags(&d->own, hipStreamNonBlocking));
+    d->stream = d->own;
+    d->lv.resize(n_levels);
+    d->sumsq.alloc(1);
+    for (int l = 0; l < n_levels; ++l) {
+        const omg_dist_level &in = lv[l];
+        DLevel &L = d->lv[l];
+        validate_csr(in.A, ("A[" + std::to_string(l) + "]").c_str());
+        L.n_loc = in.A.n_rows;
+        L.n_halo = in.n_halo;
+        OMG_REQUIRE(in.A.n_cols == L.n_loc + L.n_halo, "local operator must have n_loc + n_halo columns");
+        const bool last = l + 1 == n_levels;
+        if (!last && in.keys) L.ord = ordering_from_keys(in.keys, L.n_loc, in.n_sets);
+        else { L.ord.identity = true; L.ord.sets = {0, L.n_loc}; }
+    }
+    for (int l = 0; l < n_levels; ++l) {
+        const omg_dist_level &in = lv[l];
+        DLevel &L = d->lv[l];
+        const bool last = l + 1 == n_levels;
+        const bool id = L.ord.identity;
+        {
+            HostCsr Ap = permute_csr(in.A, id ? nullptr : L.ord.perm.data(), id ? nullptr : L.ord.inv.data(), L.n_loc);
+            L.A.upload(Ap, L.ord.sets, d->stream);
+        }
+        if (!id) { L.perm.alloc(L.n_loc); L.perm.upload(L.ord.perm.data(), L.n_loc, d->stream); L.nat.alloc(L.n_loc); }
+        if (!last) {
+            // smoothed level: every owned row needs a diagonal
+            for (int64_t i = 0; i < L.n_loc; ++i) {
+                bool have = false;
+                for (int32_t p = in.A.indptr[i]; p < in.A.indptr[i + 1]; ++p) if (in.A.indices[p] == i) { have = true; break; }
+                if (!have) throw Error(OMG_ERR_NO_DIAGONAL, "level " + std::to_string(l) + ": local row " + std::to_string(i) + " has no diagonal entry");
+            }
+            validate_csr(in.R, ("R[" + std::to_string(l) + "]").c_str());
+            const DLevel &C = d->lv[l + 1];
+            OMG_REQUIRE(in.R.n_rows == C.n_loc && in.R.n_cols == L.n_loc,
+                        "R[l] must be (coarse owned rows) x (fine owned rows): slabs must be cut on aggregate boundaries");
+            HostCsr Rp = permute_csr(in.R, C.ord.identity ? nullptr : C.ord.perm.data(), id ? nullptr : L.ord.inv.data());
+            HostCsr Pt = transpose_csr(Rp);
+            L.R.upload(Rp, {}, d->stream);
+            L.P.upload(Pt, {}, d->stream);
+            L.r.alloc(std::max<int64_t>(L.n_loc, 1));
+            if (smoother == OMG_SMOOTH_JACOBI) L.tmp.alloc(std::max<int64_t>(L.n_loc + L.n_halo, 1));
+            L.partials.alloc(L.A.n_blocks() + SUM_FOLD);
+        }
+        L.x.alloc(std::max<int64_t>(L.n_loc + L.n_halo, 1));
+        L.x.zero(d->stream);
+        if (L.tmp.p) L.tmp.zero(d->stream);
+        L.b.alloc(std::max<int64_t>(L.n_loc, 1));
+        L.xp = L.x.p;
+        L.tp = L.tmp.p;
+        // halo plan
+        OMG_REQUIRE(in.n_peers >= 0, "negative peer count");
+        L.peers.assign(in.peers, in.peers + in.n_peers);
+        L.send_off.assign(in.send_off, in.send_off + in.n_peers + 1);
+        L.recv_off.assign(in.recv_off, in.recv_off + in.n_peers + 1);
+        OMG_REQUIRE(in.n_peers == 0 || L.recv_off.back() == L.n_halo, "recv offsets do not cover the halo");
+        const int64_t n_send = in.n_peers ? L.send_off.back() : 0;
+        std::vector<int32_t> idx(n_send);
+        for (int64_t k = 0; k < n_send; ++k) {
+            const int32_t i = in.send_idx[k];
+            OMG_REQUIRE(i >= 0 && i < L.n_loc, "send index out of range");
+            idx[k] = id ? i : L.ord.inv[i];
+        }
+        L.send_idx.alloc(std::max<int64_t>(n_send, 1));
+        L.send_idx.upload(idx.data(), n_send, d->stream);
+        L.send_buf.alloc(std::max<int64_t>(n_send, 1));
+        OMG_HIP(hipStreamSynchronize(d->stream));
+    }
+    // coarsest level: invert the replicated global operator, keep it whole (n_L is small)
+    {
+        validate_csr(*coarse_global, "coarse_global");
+        OMG_REQUIRE(coarse_global->n_rows == coarse_global->n_cols, "coarse operator must be square");
+        d->n_coarse = coarse_global->n_rows;
+        d->coarse_counts.assign(coarse_counts, coarse_counts + n_ranks);
+        int64_t lo = 0, tot = 0;
+        for (int q = 0; q < n_ranks; ++q) { if (q < rank) lo += coarse_counts[q]; tot += coarse_counts[q]; }
+        OMG_REQUIRE(tot == d->n_coarse, "coarse row counts do not add up");
+        OMG_REQUIRE(coarse_counts[rank] == d->lv.back().n_loc, "coarse row count of this rank differs from its level");
+        d->coarse_lo = lo;
+        DevCsr G;
+        HostCsr Gh = permute_csr(*coarse_global, nullptr, nullptr);
+        G.upload(Gh, {}, d->stream);
+        d->coarse_inv.alloc(std::max<size_t>(size_t(d->n_coarse) * size_t(d->n_coarse), 1));
+        dense_inverse_from_csr(G, d->coarse_inv.p, d->stream);
+        d->coarse_rhs.alloc(std::max<int64_t>(d->n_coarse, 1));
+    }
+    OMG_HIP(hipStreamSynchronize(d->stream));
+    return d;
+}
+
+// ---- the SPMD schedule over the ranks that live in this process ------------------------------
+struct Runner {
+    std::vector<D *> rs;
+    bool rccl;     // true: exactly one local rank, peers reached through RCCL
+
+    D *find(int rank) const {
+        for (D *d : rs) if (d->rank == rank) return d;
+        throw Error(OMG_ERR_INVALID, "loopback group lacks rank " + std::to_string(rank));
+    }
+
+    void pack(D *d, int l) {
+        DLevel &L = d->lv[l];
+        const int64_t n = L.peers.empty() ? 0 : L.send_off.back();
+        if (n) launch_gather(L.xp, L.send_idx.p, L.send_buf.p, n, d->stream);
+    }
+
+    // boundary values of x_l -> neighbours' halo regions
+    void exchange(int l) {
+        for (D *d : rs) pack(d, l);
+        if (rccl) {
+            D *d = rs[0];
+            DLevel &L = d->lv[l];
+            if (L.peers.empty()) return;
+            OMG_NCCL(g_rccl.GroupStart());
+            for (size_t k = 0; k < L.peers.size(); ++k) {
+                const int64_t ns = L.send_off[k + 1] - L.send_off[k], nr = L.recv_off[k + 1] - L.recv_off[k];
+                if (ns) OMG_NCCL(g_rccl.Send(L.send_buf.p + L.send_off[k], (size_t)ns, ncclDouble, L.peers[k], d->comm, d->stream));
+                if (nr) OMG_NCCL(g_rccl.Recv(L.xp + L.n_loc + L.recv_off[k], (size_t)nr, ncclDouble, L.peers[k], d->comm, d->stream));
+            }
+            OMG_NCCL(g_rccl.GroupEnd());
+        } else {
+            for (D *d : rs) {
+                DLevel &L = d->lv[l];
+                for (size_t k = 0; k < L.peers.size(); ++k) {
+                    D *p = find(L.peers[k]);
+                    DLevel &PL = p->lv[l];
+                    size_t j = 0;
+                    while (j < PL.peers.size() && PL.peers[j] != d->rank) ++j;
+                    OMG_REQUIRE(j < PL.peers.size(), "halo plan is not symmetric");
+                    const int64_t nr = L.recv_off[k + 1] - L.recv_off[k];
+                    OMG_REQUIRE(nr == PL.send_off[j + 1] - PL.send_off[j], "send/recv counts differ");
+                    if (nr) OMG_HIP(hipMemcpyAsync(L.xp + L.n_loc + L.recv_off[k], PL.send_buf.p + PL.send_off[j],
+                                                   nr * sizeof(double), hipMemcpyDeviceToDevice, d->stream));
+                }
+            }
+        }
+    }
+
+    void smooth(int l, int iterations) {
+        for (int it = 0; it < iterations; ++it) {
+            if (rs[0]->smoother == OMG_SMOOTH_JACOBI) {
+                for (D *d : rs) {
+                    DLevel &L = d->lv[l];
+                    RowArgs a;
+                    a.x = L.xp; a.b = L.b.p; a.y = L.tp; a.omega = d->omega;
+                    launch_rows(L.A, ROW_JACOBI, -1, a, d->stream);
+                    std::swap(L.xp, L.tp);
+                }
+                exchange(l);
+            } else {
+                const int n_sets = (int)rs[0]->lv[l].A.n_sets();
+                for (int s = 0; s < n_sets; ++s) {
+                    for (D *d : rs) {
+                        DLevel &L = d->lv[l];
+                        OMG_REQUIRE((int)L.A.n_sets() == n_sets, "ranks disagree on the number of smoother sets");
+                        RowArgs a;
+                        a.x = L.xp; a.b = L.b.p; a.y = L.xp;
+                        launch_rows(L.A, ROW_GS, s, a, d->stream);
+                    }
+                    exchange(l);
+                }
+            }
+        }
+    }
+
+    void coarse() {
+        // all-gather the coarsest right-hand side, then each rank applies ITS rows of the inverse
+        if (rccl) {
+            D *d = rs[0];
+            DLevel &L = d->lv.back();
+            bool equal = true;
+            for (int64_t c : d->coarse_counts) equal = equal && c == d->coarse_counts[0];
+            if (d->n_ranks == 1) {
+                OMG_HIP(hipMemcpyAsync(d->coarse_rhs.p, L.b.p, L.n_loc * sizeof(double), hipMemcpyDeviceToDevice, d->stream));
+            } else if (equal) {
+                OMG_NCCL(g_rccl.AllGather(L.b.p, d->coarse_rhs.p, (size_t)L.n_loc, ncclDouble, d->comm, d->stream));
+            } else {
+                OMG_NCCL(g_rccl.GroupStart());
+                int64_t off = 0;
+                for (int q = 0; q < d->n_ranks; ++q) {
+                    if (L.n_loc) OMG_NCCL(g_rccl.Send(L.b.p, (size_t)L.n_loc, ncclDouble, q, d->comm, d->stream));
+                    if (d->coarse_counts[q]) OMG_NCCL(g_rccl.Recv(d->coarse_rhs.p + off, (size_t)d->coarse_counts[q], ncclDouble, q, d->comm, d->stream));
+                    off += d->coarse_counts[q];
+                }
+                OMG_NCCL(g_rccl.GroupEnd());
+            }
+        } else {
+            for (D *d : rs)
+                for (D *p : rs) {
+                    DLevel &PL = p->lv.back();
+                    if (PL.n_loc) OMG_HIP(hipMemcpyAsync(d->coarse_rhs.p + p->coarse_lo, PL.b.p, PL.n_loc * sizeof(double),
+                                                         hipMemcpyDeviceToDevice, d->stream));
+                }
+        }
+        for (D *d : rs) {
+            DLevel &L = d->lv.back();
+            launch_dense_gemv_rows(d->coarse_inv.p + d->coarse_lo * d->n_coarse, d->coarse_rhs.p, L.xp, L.n_loc,
+                                   d->n_coarse, d->stream);
+        }
+    }
+
+    void cycle(int l, int pre, int post) {
+        const int last = (int)rs[0]->lv.size() - 1;
+        if (l >= last) { coarse(); return; }
+        smooth(l, pre);
+        for (D *d : rs) {
+            DLevel &L = d->lv[l];
+            DLevel &C = d->lv[l + 1];
+            RowArgs a;
+            a.x = L.xp; a.b = L.b.p; a.y = L.r.p;
+            launch_rows(L.A, ROW_RESIDUAL, -1, a, d->stream);
+            RowArgs q;
+            q.x = L.r.p; q.y = C.b.p; q.zero = (l + 1 < last) ? C.xp : nullptr;
+            launch_rows(L.R, ROW_SPMV, -1, q, d->stream);
+            if (l + 1 < last && C.n_halo)
+                OMG_HIP(hipMemsetAsync(C.xp + C.n_loc, 0, C.n_halo * sizeof(double), d->stream));
+        }
+        cycle(l + 1, pre, post);
+        for (D *d : rs) {
+            DLevel &L = d->lv[l];
+            DLevel &C = d->lv[l + 1];
+            RowArgs a;
+            a.x = C.xp; a.y = L.xp;
+            launch_rows(L.P, ROW_AXPY, -1, a, d->stream);
+        }
+        exchange(l);
+        if (post > 0) smooth(l, post);
+    }
+
+    // sum over all ranks of the local sums of squares -> sqrt, left in every rank's sumsq
+    void norm() {
+        const bool single = rs[0]->lv.size() == 1;
+        for (D *d : rs) {
+            if (single) { OMG_HIP(hipMemsetAsync(d->sumsq.p, 0, sizeof(double), d->stream)); continue; }
+            DLevel &L = d->lv[0];
+            RowArgs a;
+            a.x = L.xp; a.b = L.b.p; a.partials = L.partials.p;
+            launch_rows(L.A, ROW_NORM_ONLY, -1, a, d->stream);
+            launch_sum(L.partials.p, L.A.n_blocks(), d->sumsq.p, d->stream);
+        }
+        if (single) return;
+        if (rccl) {
+            D *d = rs[0];
+            if (d->n_ranks > 1)
+                OMG_NCCL(g_rccl.AllReduce(d->sumsq.p, d->sumsq.p, 1, ncclDouble, ncclSum, d->comm, d->stream));
+        } else if (rs.size() > 1) {
+            // loopback (test path): rank order, on the host
+            double tot = 0.0;
+            for (D *d : rs) {
+                double v = 0.0;
+                OMG_HIP(hipMemcpyAsync(&v, d->sumsq.p, sizeof(double), hipMemcpyDeviceToHost, d->stream));
+                OMG_HIP(hipStreamSynchronize(d->stream));
+                tot += v;
+            }
+            for (D *d : rs) OMG_HIP(hipMemcpyAsync(d->sumsq.p, &tot, sizeof(double), hipMemcpyHostToDevice, d->stream));
+            for (D *d : rs) OMG_HIP(hipStreamSynchronize(d->stream));
+        }
+        for (D *d : rs) hipLaunchKernelGGL(sqrt_kernel, dim3(1), dim3(1), 0, d->stream, d->sumsq.p);
+    }
+
+    void run(int pre, int post, double *norm_out) {
+        for (D *d : rs) OMG_REQUIRE(d->loaded, "omg_dist_load has not been called");
+        bool dirty = false;
+        for (D *d : rs) dirty = dirty || d->halo_dirty;
+        if (dirty) { exchange(0); for (D *d : rs) d->halo_dirty = false; }
+        cycle(0, pre, post);
+        norm();
+        if (norm_out) {
+            D *d = rs[0];
+            OMG_HIP(hipMemcpyAsync(norm_out, d->sumsq.p, sizeof(double), hipMemcpyDeviceToHost, d->stream));
+            OMG_HIP(hipStreamSynchronize(d->stream));
+        }
+    }
+};
+
+template <typename F>
+int guarded(F &&f) {
+    try {
+        f();
+        return OMG_OK;
+    } catch (const Error &e) {
+        set_last_error(e.what());
+        return e.code;
+    } catch (const std::bad_alloc &) {
+        set_last_error("host allocation failed");
+        return OMG_ERR_ALLOC;
+    } catch (const std::exception &e) {
+        set_last_error(e.what());
+        return OMG_ERR_INVALID;
+    }
+}
+
+}  // namespace
+}  // namespace omg
+
+extern "C" {
+
+int omg_dist_create(int rank, int n_ranks, int n_levels, const omg_dist_level *levels,
+                    const omg_csr *coarse_global, const int64_t *coarse_counts, int smoother,
+                    double omega, omg_dist **out) {
+    return guarded([&] {
+        OMG_REQUIRE(out, "out is null");
+        *out = nullptr;
+        *out = create(rank, n_ranks, n_levels, levels, coarse_global, coarse_counts, smoother, omega).release();
+    });
+}
+
+int omg_dist_destroy(omg_dist *d) {
+    return guarded([&] {
+        if (!d) return;
+        (void)hipStreamSynchronize(d->stream);
+        delete d;
+    });
+}
+
+int omg_dist_set_stream(omg_dist *d, void *hip_stream) {
+    return guarded([&] {
+        OMG_REQUIRE(d, "null handle");
+        OMG_HIP(hipStreamSynchronize(d->stream));
+        d->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : d->own;
+    });
+}
+
+int omg_dist_sync(omg_dist *d) {
+    return guarded([&] { OMG_REQUIRE(d, "null handle"); OMG_HIP(hipStreamSynchronize(d->stream)); });
+}
+
+int omg_rccl_unique_id(void *out128) {
+    return guarded([&] {
+        OMG_REQUIRE(out128, "null buffer");
+        g_rccl.load();
+        ncclUniqueId id;
+        OMG_NCCL(g_rccl.GetUniqueId(&id));
+        std::memcpy(out128, &id, sizeof(id));
+    });
+}
+
+int omg_dist_connect(omg_dist *d, const void *unique_id128) {
+    return guarded([&] {
+        OMG_REQUIRE(d && unique_id128, "null argument");
+        g_rccl.load();
+        ncclUniqueId id;
+        std::memcpy(&id, unique_id128, sizeof(id));
+        OMG_NCCL(g_rccl.CommInitRank(&d->comm, d->n_ranks, id, d->rank));
+    });
+}
+
+int omg_dist_load(omg_dist *d, const double *b_local, const double *x0_local) {
+    return guarded([&] {
+        OMG_REQUIRE(d && b_local, "null argument");
+        DLevel &L = d->lv[0];
+        auto put = [&](const double *host, double *dst) {
+            if (L.ord.identity) {
+                OMG_HIP(hipMemcpyAsync(dst, host, L.n_loc * sizeof(double), hipMemcpyHostToDevice, d->stream));
+            } else {
+                L.nat.upload(host, L.n_loc, d->stream);
+                launch_gather(L.nat.p, L.perm.p, dst, L.n_loc, d->stream);
+            }
+        };
+        put(b_local, L.b.p);
+        if (x0_local) put(x0_local, L.xp);
+        else OMG_HIP(hipMemsetAsync(L.xp, 0, (L.n_loc + L.n_halo) * sizeof(double), d->stream));
+        OMG_HIP(hipStreamSynchronize(d->stream));
+        d->halo_dirty = x0_local != nullptr;
+        d->loaded = true;
+    });
+}
+
+int omg_dist_fetch(omg_dist *d, double *x_local) {
+    return guarded([&] {
+        OMG_REQUIRE(d && x_local && d->loaded, "null argument / nothing loaded");
+        DLevel &L = d->lv[0];
+        if (L.ord.identity) {
+            OMG_HIP(hipMemcpyAsync(x_local, L.xp, L.n_loc * sizeof(double), hipMemcpyDeviceToHost, d->stream));
+        } else {
+            launch_scatter(L.xp, L.perm.p, L.nat.p, L.n_loc, d->stream);
+            L.nat.download(x_local, L.n_loc, d->stream);
+        }
+        OMG_HIP(hipStreamSynchronize(d->stream));
+    });
+}
+
+int omg_dist_cycle(omg_dist *d, int pre, int post, double *norm) {
+    return guarded([&] {
+        OMG_REQUIRE(d && pre >= 0 && post >= 0, "bad argument");
+        OMG_REQUIRE(d->n_ranks == 1 || d->comm, "omg_dist_connect has not been called");
+        Runner r;
+        r.rs = {d};
+        r.rccl = true;
+        r.run(pre, post, norm);
+    });
+}
+
+int omg_dist_group_create(int n, omg_dist **ranks, omg_dist_group **out) {
+    return guarded([&] {
+        OMG_REQUIRE(n >= 1 && ranks && out, "bad argument");
+        std::unique_ptr<omg_dist_group> g(new omg_dist_group);
+        for (int i = 0; i < n; ++i) {
+            OMG_REQUIRE(ranks[i] && ranks[i]->n_ranks == n, "group must hold every rank of the decomposition");
+            g->ranks.push_back(ranks[i]);
+        }
+        // one shared stream: the loopback exchange relies on in-order execution
+        for (omg_dist *d : g->ranks) { OMG_HIP(hipStreamSynchronize(d->stream)); d->stream = g->ranks[0]->own; }
+        *out = g.release();
+    });
+}
+
+int omg_dist_group_destroy(omg_dist_group *g) {
+    delete g;
+    return OMG_OK;
+}
+
+int omg_dist_group_cycle(omg_dist_group *g, int pre, int post, double *norm) {
+    return guarded([&] {
+        OMG_REQUIRE(g && pre >= 0 && post >= 0, "bad argument");
+        Runner r;
+        r.rs = g->ranks;
+        r.rccl = false;
+        r.run(pre, post, norm);
+    });
+}
+
+}  // extern "C"

@@ -118,16 +118,28 @@ Ordering make_ordering(const omg_csr &A, int smoother) {
     if (smoother == OMG_SMOOTH_GS_LEX) lex_levels(A, key, n_keys);
     else if (smoother == OMG_SMOOTH_GS_COLOUR) greedy_colours(A, key, n_keys);
     else throw Error(OMG_ERR_INVALID, "unknown smoother kind");
+    return ordering_from_keys(key.data(), n, n_keys);
+}
+
+Ordering ordering_from_keys(const int32_t *keys, int64_t n, int32_t n_keys) {
+    Ordering o;
+    if (keys == nullptr || n_keys <= 0) {
+        o.sets = {0, n};
+        o.identity = true;
+        return o;
+    }
+    for (int64_t i = 0; i < n; ++i)
+        OMG_REQUIRE(keys[i] >= 0 && keys[i] < n_keys, "ordering key out of range");
     // stable counting sort by key
     o.sets.assign(size_t(n_keys) + 1, 0);
-    for (int64_t i = 0; i < n; ++i) o.sets[key[i] + 1]++;
+    for (int64_t i = 0; i < n; ++i) o.sets[keys[i] + 1]++;
     for (int32_t k = 0; k < n_keys; ++k) o.sets[k + 1] += o.sets[k];
     std::vector<int64_t> cursor(o.sets.begin(), o.sets.end() - 1);
     o.perm.resize(n);
     o.inv.resize(n);
     bool ident = true;
     for (int64_t i = 0; i < n; ++i) {
-        int64_t pos = cursor[key[i]]++;
+        int64_t pos = cursor[keys[i]]++;
         o.perm[pos] = int32_t(i);
         o.inv[i] = int32_t(pos);
         if (pos != i) ident = false;
@@ -138,7 +150,8 @@ Ordering make_ordering(const omg_csr &A, int smoother) {
 }
 
 // ---- permutation / transpose ----------------------------------------------------------
-HostCsr permute_csr(const omg_csr &A, const int32_t *row_perm, const int32_t *col_inv) {
+HostCsr permute_csr(const omg_csr &A, const int32_t *row_perm, const int32_t *col_inv,
+                    int64_t n_inv) {
     HostCsr out;
     out.n_rows = A.n_rows;
     out.n_cols = A.n_cols;
@@ -157,7 +170,7 @@ HostCsr permute_csr(const omg_csr &A, const int32_t *row_perm, const int32_t *co
             int32_t q = out.indptr[i];
             for (int32_t p = A.indptr[src]; p < A.indptr[src + 1]; ++p, ++q) {
                 int32_t c = A.indices[p];
-                out.indices[q] = col_inv ? col_inv[c] : c;   // stored order inside the row kept
+                out.indices[q] = (col_inv && (n_inv < 0 || c < n_inv)) ? col_inv[c] : c;   // stored order inside the row kept
                 out.data[q] = A.data[p];
             }
         }

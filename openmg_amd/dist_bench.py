@@ -1,0 +1,104 @@
+"""bench.py's multi-GPU leg: one process per GPU (torch.distributed.run), weak scaling.
+
+Per-GPU work is fixed at 256^3 unknowns: N = 2 -> 256x512x256, N = 4 -> 512x256x512,
+N = 8 -> 512^3 (BASELINE configs[3]); shapes keep shape[0] == shape[2] because the
+reference's restriction uses shape[0] as its second-axis offset (openmg/operators.py:78).
+Six grids (configs[3]) for N >= 2.  `value` is in 256^3-equivalent V-cycles/s = cycles/s x
+(global unknowns / 256^3), so that it aggregates over GPUs."""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+SHAPES = {1: (256, 256, 256), 2: (256, 512, 256), 4: (512, 256, 512), 8: (512, 512, 512)}
+
+
+def main(args):
+    import torch
+    import torch.distributed as td
+    from . import _hip, _hip_dist, dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", str(args.gpus)))
+    local = int(os.environ.get("LOCAL_RANK", str(rank)))
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29511")
+    if world not in SHAPES:
+        raise SystemExit("bench.py --gpus must be 1, 2, 4 or 8")
+    torch.cuda.set_device(local)
+    _hip_dist.set_device(local)
+    # control plane (ids, barriers, timing max) over gloo; the data plane is RCCL inside
+    # libopenmg_hip.so on the rank's HIP stream
+    td.init_process_group("gloo", rank=rank, world_size=world)
+
+    def all_gather(obj):
+        out = [None] * world
+        td.all_gather_object(out, obj)
+        return out
+
+    scale = args.size / 256.0
+    shape = tuple(int(s * scale) for s in SHAPES[world])
+    grids = args.grids if world == 1 else args.grids + 1
+    t_setup = time.perf_counter()
+    part = dist.SlabPartition(shape, world, grids)
+    lo, hi = part.rows(0, rank)
+    A_rows = dist.stencil_rows(shape, lo, hi)
+    u = np.random.default_rng(12345).random(part.n_rows(0))
+    b_loc = A_rows @ u
+    del u
+    levels, coarse, counts = dist.build_this_rank(part, rank, A_rows, all_gather, smoother=args.smoother)
+    nnz_loc, n_loc = A_rows.nnz, hi - lo
+    del A_rows
+    r = _hip_dist.DistRank(rank, world, levels, coarse, counts, smoother=args.smoother)
+    ident = [_hip_dist.rccl_unique_id() if rank == 0 else None]
+    td.broadcast_object_list(ident, src=0)
+    r.connect(ident[0])
+    r.load(b_loc)
+    setup_s = time.perf_counter() - t_setup
+
+    pre = post = 1
+    for _ in range(args.warmup):
+        r.cycle(pre, post, want_norm=False)
+    r.sync()
+    torch.cuda.synchronize()
+    td.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        r.cycle(pre, post, want_norm=False)
+    r.sync()
+    torch.cuda.synchronize()
+    td.barrier()
+    elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed], dtype=torch.float64)
+    td.all_reduce(t, op=td.ReduceOp.MAX)
+    elapsed = float(t[0])
+    norm = r.cycle(pre, post, want_norm=True)
+
+    if rank == 0:
+        n_glob = part.n_rows(0)
+        equiv = n_glob / float(256 ** 3)
+        out = {
+            "metric": "V-cycles/sec (256^3-unknown equivalents), 3-D 7-point Poisson, weak scaling",
+            "value": round(args.steps / elapsed * equiv, 3),
+            "unit": "256^3-equivalent V-cycles/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "3-D 7-point Poisson %s, %d-grid V(1,1) cycle, %s Gauss-Seidel, fp64, int32 CSR, "
+                                   "1-D slabs over %d GPUs, RCCL halo exchange"
+                                   % ("x".join(map(str, shape)), grids,
+                                      "red-black" if args.smoother == "colour" else args.smoother, world),
+                       "unknowns": n_glob, "unknowns_per_gpu": n_loc, "nnz_per_gpu": nnz_loc, "grids": grids,
+                       "pre": pre, "post": post, "cycles_per_s": round(args.steps / elapsed, 3),
+                       "final_residual_norm": norm, "setup_s": round(setup_s, 2)},
+            "roofline": None, "cpu_baseline": None,
+        }
+        print(json.dumps(out))
+        sys.stdout.flush()
+    r.close()
+    td.barrier()
+    td.destroy_process_group()
+    return 0

@@ -1,0 +1,99 @@
+"""Distributed V-cycle on ONE GPU: every rank of a slab decomposition lives in this process
+(loopback group, halos moved by device copies) and runs the same schedule as the RCCL path.
+Checks that the iterate does not depend on the number of ranks, and that RCCL itself loads
+and works for a single-rank communicator.  Needs an MI355X: run with -m gpu."""
+import numpy as np
+import pytest
+
+from openmg_amd import _hip, _hip_dist, dist, operators
+
+pytestmark = pytest.mark.gpu
+
+
+def single_gpu(shape, grids, smoother, b, cycles, omega=0.8):
+    R = [operators.restriction(tuple(s // 2 ** l for s in shape)) for l in range(grids - 1)]
+    A = operators.coeffecientList(operators.stencil_poisson(shape), R)
+    with _hip.Hierarchy(A, R, smoother=smoother, omega=omega) as h:
+        h.resident_load(b)
+        norms = [h.resident_cycle(1, 1) for _ in range(cycles)]
+        return h.resident_fetch(), norms
+
+
+def loopback(shape, grids, n_ranks, smoother, b, cycles, omega=0.8):
+    part = dist.SlabPartition(shape, n_ranks, grids)
+    levels, coarse, counts = dist.build_all_ranks(
+        part, lambda q: dist.stencil_rows(shape, *part.rows(0, q)), smoother=smoother)
+    ranks = [_hip_dist.DistRank(q, n_ranks, levels[q], coarse, counts, smoother=smoother, omega=omega)
+             for q in range(n_ranks)]
+    group = _hip_dist.DistGroup(ranks)
+    try:
+        for q, r in enumerate(ranks):
+            r.load(b[slice(*part.rows(0, q))])
+        norms = [group.cycle(1, 1) for _ in range(cycles)]
+        x = np.concatenate([r.fetch() for r in ranks])
+    finally:
+        group.close()
+    return x, norms
+
+
+@pytest.mark.parametrize("shape,grids,n_ranks", [((32, 32, 32), 3, 2), ((32, 32, 32), 3, 4),
+                                                 ((64, 32, 64), 4, 4), ((64, 64), 3, 2)])
+def test_redblack_iterate_independent_of_rank_count(shape, grids, n_ranks):
+    N = int(np.prod(shape))
+    b = operators.stencil_poisson(shape) @ np.random.default_rng(12345).random(N)
+    x1, n1 = single_gpu(shape, grids, "colour", b, 3)
+    xd, nd = loopback(shape, grids, n_ranks, "colour", b, 3)
+    assert np.array_equal(xd, x1)                      # bitwise: same arithmetic per row
+    np.testing.assert_allclose(nd, n1, rtol=1e-13)     # norm: different summation grouping
+
+
+@pytest.mark.parametrize("smoother", ["gs", "jacobi"])
+def test_other_smoothers_loopback(smoother):
+    shape, grids = (16, 16, 16), 3
+    b = operators.stencil_poisson(shape) @ np.random.default_rng(5).random(4096)
+    x1, n1 = single_gpu(shape, grids, smoother, b, 2)
+    xd, nd = loopback(shape, grids, 2, smoother, b, 2)
+    np.testing.assert_allclose(xd, x1, rtol=1e-12, atol=1e-14)
+    np.testing.assert_allclose(nd, n1, rtol=1e-12)
+
+
+def test_initial_iterate_and_rccl_single_rank():
+    """x0 != 0 needs a halo exchange before the first sweep; a 1-rank communicator exercises
+    dlopen(librccl), ncclCommInitRank and the collective code path."""
+    shape, grids = (32, 32, 32), 3
+    N = 32 ** 3
+    rng = np.random.default_rng(9)
+    b = operators.stencil_poisson(shape) @ rng.random(N)
+    part = dist.SlabPartition(shape, 1, grids)
+    levels, coarse, counts = dist.build_all_ranks(part, lambda q: dist.stencil_rows(shape, 0, N), smoother="colour")
+    r = _hip_dist.DistRank(0, 1, levels[0], coarse, counts, smoother="colour")
+    try:
+        r.connect(_hip_dist.rccl_unique_id())
+        r.load(b)
+        norms = [r.cycle(1, 1) for _ in range(2)]
+        x = r.fetch()
+    finally:
+        r.close()
+    x1, n1 = single_gpu(shape, grids, "colour", b, 2)
+    assert np.array_equal(x, x1)
+    np.testing.assert_allclose(norms, n1, rtol=1e-13)
+    # non-zero initial iterate through the loopback group
+    x0 = rng.random(N)
+    part2 = dist.SlabPartition(shape, 2, grids)
+    lv2, c2, k2 = dist.build_all_ranks(part2, lambda q: dist.stencil_rows(shape, *part2.rows(0, q)), smoother="colour")
+    ranks = [_hip_dist.DistRank(q, 2, lv2[q], c2, k2, smoother="colour") for q in range(2)]
+    g = _hip_dist.DistGroup(ranks)
+    try:
+        for q, rk in enumerate(ranks):
+            sl = slice(*part2.rows(0, q))
+            rk.load(b[sl], x0[sl])
+        g.cycle(1, 1)
+        xd = np.concatenate([rk.fetch() for rk in ranks])
+    finally:
+        g.close()
+    Rl = [operators.restriction(tuple(s // 2 ** l for s in shape)) for l in range(grids - 1)]
+    Al = operators.coeffecientList(operators.stencil_poisson(shape), Rl)
+    with _hip.Hierarchy(Al, Rl, smoother="colour") as h:
+        h.resident_load(b, x0)
+        h.resident_cycle(1, 1)
+        assert np.array_equal(xd, h.resident_fetch())
