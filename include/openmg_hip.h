@@ -80,6 +80,12 @@ int omg_hierarchy_sync(omg_hierarchy *h);
 /* Rows of level l; number of independent row sets one smoother sweep is split into. */
 int omg_hierarchy_level_rows(const omg_hierarchy *h, int level, int64_t *n_rows);
 int omg_hierarchy_level_sets(const omg_hierarchy *h, int level, int64_t *n_sets);
+/* 1 when the smoother's last set launch of this level also produces that set's residual /
+ * norm share (ROW_GS_RES / ROW_GS_NORM in csrc/common.h), so that the residual and norm
+ * launches cover only the other sets.  Bit-identical results either way.                  */
+int omg_hierarchy_level_fused(const omg_hierarchy *h, int level, int *fused);
+/* Rows and stored entries of one smoother set (for byte accounting of per-set launches). */
+int omg_hierarchy_set_info(const omg_hierarchy *h, int level, int set, int64_t *rows, int64_t *nnz);
 
 /* replaces: openmg.mgCycle(A, b, level, R, parameters, initial) — openmg/__init__.py:151-236.
  * One V-cycle entered at `level` with pre/post = parameters['preIterations'|'postIterations'].

@@ -61,6 +61,8 @@ SIGNATURES = {
     "omg_hierarchy_sync": (_I, [_P]),
     "omg_hierarchy_level_rows": (_I, [_P, _I, _I64P]),
     "omg_hierarchy_level_sets": (_I, [_P, _I, _I64P]),
+    "omg_hierarchy_set_info": (_I, [_P, _I, _I, _I64P, _I64P]),
+    "omg_hierarchy_level_fused": (_I, [_P, _I, _IP]),
     "omg_vcycle": (_I, [_P, _I, _P, _P, _I, _I, _DP]),
     "omg_solve": (_I, [_P, _P, _P, _I, _I, _I, _D, _IP, _DP]),
     "omg_resident_load": (_I, [_P, _P, _P]),
@@ -270,6 +272,17 @@ class Hierarchy:
         v = ctypes.c_int64(0)
         check(lib().omg_hierarchy_level_sets(self._h, level, ctypes.byref(v)))
         return v.value
+
+    def level_fused(self, level):
+        v = ctypes.c_int(0)
+        check(lib().omg_hierarchy_level_fused(self._h, level, ctypes.byref(v)))
+        return bool(v.value)
+
+    def set_info(self, level, s):
+        """(rows, stored entries) of smoother set `s` of a level."""
+        rows, nnz = ctypes.c_int64(0), ctypes.c_int64(0)
+        check(lib().omg_hierarchy_set_info(self._h, level, s, ctypes.byref(rows), ctypes.byref(nnz)))
+        return rows.value, nnz.value
 
     def profile_enable(self, classes=True):
         """True = every class, False = off, or an iterable of class names (PROFILE_NAMES)."""

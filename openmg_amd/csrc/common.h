@@ -119,6 +119,7 @@ struct DevCsr {
     std::vector<int64_t> set_blk;      // block offsets of the independent sets (host)
     std::vector<int64_t> sets;         // row offsets of the sets (host)
     int rows_cap = ROWBLK_ROWS;        // most rows a block may hold (> ROWBLK_THREADS: short rows)
+    std::vector<int64_t> set_nnz;      // stored entries of each set (host)
     void upload(const HostCsr &A, const std::vector<int64_t> &sets, hipStream_t s);
     size_t n_sets() const { return sets.empty() ? 0 : sets.size() - 1; }
     int64_t n_blocks() const { return set_blk.empty() ? 0 : set_blk.back(); }
@@ -133,6 +134,14 @@ enum RowMode : int {
     ROW_JACOBI = 4,     // y = x + omega (b - A x) / diag
     ROW_AXPY = 5,       // y += A x
     ROW_NORM_ONLY = 6,  // partial sums of (b - A x)^2, nothing stored
+    // Gauss-Seidel sweep of the LAST set of a sweep, fused with the residual of the rows it
+    // has just relaxed.  Rows of a set are mutually uncoupled, so after its own update a
+    // row's residual b_i - sum_j a_ij x_j depends only on values no other row of this launch
+    // changes: it is recomputed from the entries already in LDS with x_i replaced by its new
+    // value — bit for bit what a separate residual pass would produce — and that pass then
+    // only has to visit the rows of the other sets.
+    ROW_GS_RES = 7,     // ... residual stored to `zero`-slot pointer aux
+    ROW_GS_NORM = 8,    // ... residual squared into the block partials
 };
 
 struct RowArgs {
@@ -141,11 +150,15 @@ struct RowArgs {
     double *y = nullptr;         // output (GS: the same pointer as x)
     double omega = 1.0;
     double *partials = nullptr;  // one double per row block (RESNORM / NORM_ONLY)
-    double *zero = nullptr;      // ROW_SPMV: zero[r] = 0 alongside y[r] (fused clear)
+    double *zero = nullptr;      // ROW_SPMV: zero[r] = 0 alongside y[r] (fused clear);
+                                 // ROW_GS_RES: residual of the relaxed rows goes here
 };
 
 // Launch `mode` over row set `set` of A (set < 0: all sets in one launch).
 void launch_rows(const DevCsr &A, int mode, int set, const RowArgs &args, hipStream_t s);
+// ... over the consecutive sets [set_begin, set_end) in one launch.
+void launch_rows_range(const DevCsr &A, int mode, int set_begin, int set_end, const RowArgs &args,
+                       hipStream_t s);
 // Consecutive single-block sets [set_begin, set_end) of a Gauss-Seidel sweep, run back to
 // back by one workgroup (workgroup barrier between sets).
 void launch_gs_serial(const DevCsr &A, int set_begin, int set_end, const RowArgs &args,

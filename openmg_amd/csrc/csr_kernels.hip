@@ -84,10 +84,15 @@ __device__ __forceinline__ RowPre row_preload(const KArgs &a, int r) {
     p.bv = 0.0;
     p.xv = 0.0;
     if constexpr (MODE != ROW_SPMV && MODE != ROW_AXPY) p.bv = a.b[r];
-    if constexpr (MODE == ROW_GS || MODE == ROW_JACOBI) p.xv = a.x[r];
+    if constexpr (MODE == ROW_GS || MODE == ROW_JACOBI || MODE == ROW_GS_RES || MODE == ROW_GS_NORM)
+        p.xv = a.x[r];
     if constexpr (MODE == ROW_AXPY) p.xv = a.y[r];
     return p;
 }
+
+// Row sums are spelled with an explicit fma everywhere so that the fused sweep+residual
+// modes reproduce the plain residual kernel bit for bit.
+__device__ __forceinline__ double madd(double v, double x, double acc) { return fma(v, x, acc); }
 
 template <int MODE>
 __device__ __forceinline__ void row_epilogue(const KArgs &a, int r, const RowPre &p, double sum,
@@ -119,8 +124,9 @@ __device__ __forceinline__ void row_epilogue(const KArgs &a, int r, const RowPre
 // then processed eight at a time with all their loads in flight together.
 template <int MODE, bool nt, bool SHORT>
 __device__ void process_block(const KArgs &a, int blk, double *s_val, int *s_idx, double *s_red) {
-    constexpr bool NEED_DIAG = (MODE == ROW_GS || MODE == ROW_JACOBI);
-    constexpr bool NEED_NORM = (MODE == ROW_RESNORM || MODE == ROW_NORM_ONLY);
+    constexpr bool FUSED = (MODE == ROW_GS_RES || MODE == ROW_GS_NORM);
+    constexpr bool NEED_DIAG = (MODE == ROW_GS || MODE == ROW_JACOBI || FUSED);
+    constexpr bool NEED_NORM = (MODE == ROW_RESNORM || MODE == ROW_NORM_ONLY || MODE == ROW_GS_NORM);
     const int tid = threadIdx.x;
     // (first row, first entry) of this block and of the next: one round trip instead of
     // block table -> indptr
@@ -181,40 +187,62 @@ __device__ void process_block(const KArgs &a, int blk, double *s_val, int *s_idx
                 for (int u = 0; u < U; ++u) {
                     const int ru = rb + u * NT;
                     if (ru >= r1) continue;
-                    sum[u] = (q[u].beg < q[u].end) ? v0[u] * x0[u] : 0.0;
+                    sum[u] = (q[u].beg < q[u].end) ? madd(v0[u], x0[u], 0.0) : 0.0;
                     for (int k = q[u].beg + 1 - base; k < q[u].end - base; ++k) {   // rest, stored order
                         const int sl = slot(k);
-                        sum[u] += s_val[sl] * a.x[s_idx[sl]];
+                        sum[u] = madd(s_val[sl], a.x[s_idx[sl]], sum[u]);
                     }
                     double unused = 0.0;
                     row_epilogue<MODE>(a, ru, q[u], sum[u], 0.0, unused);
                 }
             }
         } else {
-        while (r < r1) {
+            while (r < r1) {
                 const int beg = pre.beg - base, end = pre.end - base;
                 double sum = 0.0, diag = 0.0;
+                int c[8];
+                double v[8], xv[8];
                 for (int k = beg; k < end; k += 8) {
-                    int c[8];
-                    double v[8], xv[8];
-    #pragma unroll
+#pragma unroll
                     for (int j = 0; j < 8; ++j) {
                         const int kk = min(k + j, end - 1);
                         const int s = slot(kk);
                         c[j] = s_idx[s];
                         v[j] = s_val[s];
                     }
-    #pragma unroll
+#pragma unroll
                     for (int j = 0; j < 8; ++j) xv[j] = a.x[c[j]];
-    #pragma unroll
+#pragma unroll
                     for (int j = 0; j < 8; ++j) {
                         if (k + j < end) {
-                            sum += v[j] * xv[j];
+                            sum = madd(v[j], xv[j], sum);
                             if (NEED_DIAG && c[j] == r) diag += v[j];
                         }
                     }
                 }
-                row_epilogue<MODE>(a, r, pre, sum, diag, sq);
+                if constexpr (FUSED) {
+                    // relax the row, then its residual with the NEW x_i: same entries, same
+                    // order, same fma chain as ROW_RESIDUAL would run on the updated vector
+                    const double xnew = pre.xv + (pre.bv - sum) / diag;
+                    double sum2 = 0.0;
+                    if (end - beg <= 8) {            // the row's entries are still in registers
+#pragma unroll
+                        for (int j = 0; j < 8; ++j)
+                            if (beg + j < end) sum2 = madd(v[j], c[j] == r ? xnew : xv[j], sum2);
+                    } else {
+                        for (int k = beg; k < end; ++k) {
+                            const int s = slot(k);
+                            const int cc = s_idx[s];
+                            sum2 = madd(s_val[s], cc == r ? xnew : a.x[cc], sum2);
+                        }
+                    }
+                    a.y[r] = xnew;
+                    const double res = pre.bv - sum2;
+                    if constexpr (MODE == ROW_GS_RES) a.zero[r] = res;
+                    else sq += res * res;
+                } else {
+                    row_epilogue<MODE>(a, r, pre, sum, diag, sq);
+                }
                 r += NT;
                 if (r < r1) pre = row_preload<MODE>(a, r);
             }
@@ -227,13 +255,31 @@ __device__ void process_block(const KArgs &a, int blk, double *s_val, int *s_idx
         for (int p = p0 + tid; p < p1; p += NT) {
             const int c = a.indices[p];
             const double v = a.data[p];
-            part += v * a.x[c];
+            part = madd(v, a.x[c], part);
             if (NEED_DIAG && c == r) dpart += v;
         }
         const double sum = block_sum(part, s_red);
         double diag = 0.0;
         if (NEED_DIAG) diag = block_sum(dpart, s_red);
-        if (tid == 0) {
+        if constexpr (FUSED) {
+            const RowPre pre = row_preload<MODE>(a, r);
+            __syncthreads();
+            if (tid == 0) s_red[0] = pre.xv + (pre.bv - sum) / diag;
+            __syncthreads();
+            const double xnew = s_red[0];
+            double part2 = 0.0;
+            for (int p = p0 + tid; p < p1; p += NT) {
+                const int c = a.indices[p];
+                part2 = madd(a.data[p], c == r ? xnew : a.x[c], part2);
+            }
+            const double sum2 = block_sum(part2, s_red);
+            if (tid == 0) {
+                a.y[r] = xnew;
+                const double res = pre.bv - sum2;
+                if constexpr (MODE == ROW_GS_RES) a.zero[r] = res;
+                else sq += res * res;
+            }
+        } else if (tid == 0) {
             const RowPre pre = row_preload<MODE>(a, r);
             row_epilogue<MODE>(a, r, pre, sum, diag, sq);
         }
@@ -321,6 +367,12 @@ void launch_mode(const DevCsr &A, int64_t blk0, int64_t nblk, const KArgs &k, hi
 }  // namespace
 
 void launch_rows(const DevCsr &A, int mode, int set, const RowArgs &args, hipStream_t s) {
+    if (set < 0) launch_rows_range(A, mode, 0, (int)A.n_sets(), args, s);
+    else launch_rows_range(A, mode, set, set + 1, args, s);
+}
+
+void launch_rows_range(const DevCsr &A, int mode, int set_begin, int set_end, const RowArgs &args,
+                       hipStream_t s) {
     KArgs k;
     k.blk_info = A.blk_rows.p;
     k.indptr = A.indptr.p;
@@ -332,13 +384,13 @@ void launch_rows(const DevCsr &A, int mode, int set, const RowArgs &args, hipStr
     k.partials = args.partials;
     k.zero = args.zero;
     k.omega = args.omega;
-    int64_t blk0 = 0, nblk = A.n_blocks();
-    if (set >= 0) {
-        OMG_REQUIRE(size_t(set) < A.n_sets(), "launch_rows: set out of range");
-        blk0 = A.set_blk[set];
-        nblk = A.set_blk[set + 1] - blk0;
-    }
+    OMG_REQUIRE(set_begin >= 0 && set_begin <= set_end && size_t(set_end) <= A.n_sets(),
+                "launch_rows: set range out of bounds");
+    const int64_t blk0 = A.set_blk[set_begin];
+    const int64_t nblk = A.set_blk[set_end] - blk0;
     switch (mode) {
+        case ROW_GS_RES: launch_mode<ROW_GS_RES>(A, blk0, nblk, k, s); break;
+        case ROW_GS_NORM: launch_mode<ROW_GS_NORM>(A, blk0, nblk, k, s); break;
         case ROW_SPMV: launch_mode<ROW_SPMV>(A, blk0, nblk, k, s); break;
         case ROW_RESIDUAL: launch_mode<ROW_RESIDUAL>(A, blk0, nblk, k, s); break;
         case ROW_RESNORM: launch_mode<ROW_RESNORM>(A, blk0, nblk, k, s); break;

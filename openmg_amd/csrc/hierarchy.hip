@@ -60,6 +60,9 @@ struct omg_hierarchy {
     hipStream_t own = nullptr, stream = nullptr;
     // resident state
     bool resident = false;
+    // OMG_NO_FUSE=1: never fuse the last smoother set with the residual / norm (A/B switch;
+    // results are bit-identical either way, tests/test_gpu_parity.py checks that)
+    bool no_fuse = [] { const char *e = getenv("OMG_NO_FUSE"); return e && e[0] == '1'; }();
     // graph
     bool want_graph = false;
     hipGraphExec_t gexec = nullptr;
@@ -143,8 +146,20 @@ struct Prof {
 };
 
 // ---- level operations (device vectors in the level's ordering) ---------------------------
-void smooth_level(H *h, int l, int iterations) {
+// What the LAST set launch of a Gauss-Seidel smoothing call also produces for its own rows
+// (RowMode ROW_GS_RES / ROW_GS_NORM): the residual pass that follows then skips that set.
+enum Fuse { FUSE_NONE = 0, FUSE_RESIDUAL = 1, FUSE_NORM = 2 };
+
+// Fusion needs a Gauss-Seidel ordering whose final step is an ordinary set launch.
+bool can_fuse(const H *h, const Level &L) {
+    if (h->smoother == OMG_SMOOTH_JACOBI || L.plan.empty() || h->no_fuse) return false;
+    return !L.plan.back().serial;
+}
+
+// Returns true when the last set launch was fused (its rows' residual / norm is done).
+bool smooth_level(H *h, int l, int iterations, Fuse fuse = FUSE_NONE) {
     Level &L = h->lv[l];
+    bool fused = false;
     for (int it = 0; it < iterations; ++it) {
         if (h->smoother == OMG_SMOOTH_JACOBI) {
             Prof p(h, l, 0);
@@ -155,31 +170,48 @@ void smooth_level(H *h, int l, int iterations) {
         } else {
             RowArgs a;
             a.x = L.xp; a.b = L.b.p; a.y = L.xp;
-            for (const SweepStep &st : L.plan) {
+            const bool last_it = it + 1 == iterations;
+            for (size_t k = 0; k < L.plan.size(); ++k) {
+                const SweepStep &st = L.plan[k];
                 Prof p(h, l, 0);
-                if (st.serial) launch_gs_serial(L.A, st.set_begin, st.set_end, a, h->stream);
-                else launch_rows(L.A, ROW_GS, st.set_begin, a, h->stream);
+                if (st.serial) {
+                    launch_gs_serial(L.A, st.set_begin, st.set_end, a, h->stream);
+                } else if (last_it && k + 1 == L.plan.size() && fuse != FUSE_NONE && can_fuse(h, L)) {
+                    RowArgs f = a;
+                    f.zero = L.r.p;
+                    f.partials = L.partials.p;
+                    launch_rows(L.A, fuse == FUSE_RESIDUAL ? ROW_GS_RES : ROW_GS_NORM, st.set_begin, f, h->stream);
+                    fused = true;
+                } else {
+                    launch_rows(L.A, ROW_GS, st.set_begin, a, h->stream);
+                }
             }
         }
     }
+    return fused;
 }
 
-void residual_level(H *h, int l, double *r_out) {
+// r = b - A x over all sets, or over all but the last one when the smoother has already
+// produced the last set's residual.
+void residual_level(H *h, int l, double *r_out, bool last_set_done = false) {
     Level &L = h->lv[l];
     Prof p(h, l, 1);
     RowArgs a;
     a.x = L.xp; a.b = L.b.p; a.y = r_out;
-    launch_rows(L.A, ROW_RESIDUAL, -1, a, h->stream);
+    const int ns = (int)L.A.n_sets();
+    launch_rows_range(L.A, ROW_RESIDUAL, 0, last_set_done ? ns - 1 : ns, a, h->stream);
 }
 
-// ||b - A x||_2 of level l into h->norm_dev (device scalar); r_out optional.
-void norm_level(H *h, int l, double *r_out) {
+// ||b - A x||_2 of level l into h->norm_dev (device scalar); r_out optional.  With
+// last_set_done the last set's block partials are already in place.
+void norm_level(H *h, int l, double *r_out, bool last_set_done = false) {
     Level &L = h->lv[l];
     {
         Prof p(h, l, 4);
         RowArgs a;
         a.x = L.xp; a.b = L.b.p; a.y = r_out; a.partials = L.partials.p;
-        launch_rows(L.A, r_out ? ROW_RESNORM : ROW_NORM_ONLY, -1, a, h->stream);
+        const int ns = (int)L.A.n_sets();
+        launch_rows_range(L.A, r_out ? ROW_RESNORM : ROW_NORM_ONLY, 0, last_set_done ? ns - 1 : ns, a, h->stream);
     }
     launch_sum_sqrt(L.partials.p, L.A.n_blocks(), h->norm_dev.p, h->stream);
 }
@@ -209,21 +241,26 @@ void coarse_solve_level(H *h) {
 // openmg/__init__.py:199-234 with the dead work removed: R[l]*b (:205-206) is computed by the
 // reference only for its length, and the norm at levels > entry (:227) is discarded by the
 // caller (:213 takes [0]); neither changes any returned value.
-void cycle_body(H *h, int l, int pre, int post) {
+//
+// want_norm: the caller will ask for ||b - A x|| of THIS level right after the cycle; the
+// post-smoother's last set launch then also leaves that set's share of the norm in the block
+// partials.  Returns true when it did (norm_level(..., last_set_done = true) finishes it).
+bool cycle_body(H *h, int l, int pre, int post, bool want_norm = false) {
     const int last = (int)h->lv.size() - 1;
     if (l >= last) {
         coarse_solve_level(h);
-        return;
+        return false;
     }
     Level &L = h->lv[l];
     Level &C = h->lv[l + 1];
-    smooth_level(h, l, pre);                                  // :201
-    residual_level(h, l, L.r.p);                              // :209
+    const bool res_done = smooth_level(h, l, pre, FUSE_RESIDUAL);   // :201 (+ last set's share of :209)
+    residual_level(h, l, L.r.p, res_done);                          // :209
     // :210, and the coarse cycle's initial=None -> zeros (:191-192) cleared by the same launch
     restrict_level(h, l, L.r.p, C.b.p, l + 1 < last ? C.xp : nullptr);
-    cycle_body(h, l + 1, pre, post);                          // :213
-    prolong_add_level(h, l, C.xp, L.xp);                      // :214, :220/:224
-    if (post > 0) smooth_level(h, l, post);                   // :216-222
+    cycle_body(h, l + 1, pre, post);                                // :213
+    prolong_add_level(h, l, C.xp, L.xp);                            // :214, :220/:224
+    if (post > 0) return smooth_level(h, l, post, want_norm ? FUSE_NORM : FUSE_NONE);   // :216-222
+    return false;
 }
 
 void load_vec(H *h, int l, const double *host, double *dst) {
@@ -264,8 +301,8 @@ void drop_graph(H *h) {
 void run_cycle0(H *h, int pre, int post) {
     const bool single = h->lv.size() == 1;
     auto body = [&]() {
-        cycle_body(h, 0, pre, post);
-        if (!single) norm_level(h, 0, nullptr);               // :227
+        const bool part = cycle_body(h, 0, pre, post, !single);
+        if (!single) norm_level(h, 0, nullptr, part);         // :227
         else OMG_HIP(hipMemsetAsync(h->norm_dev.p, 0, sizeof(double), h->stream));   // :232
     };
     if (!h->want_graph || h->profiling) {
@@ -463,6 +500,24 @@ int omg_hierarchy_level_sets(const omg_hierarchy *h, int level, int64_t *n_sets)
     return guarded([&] { check_level(h, level); OMG_REQUIRE(n_sets, "null"); *n_sets = (int64_t)h->lv[level].A.n_sets(); });
 }
 
+int omg_hierarchy_level_fused(const omg_hierarchy *h, int level, int *fused) {
+    return guarded([&] {
+        check_level(h, level);
+        OMG_REQUIRE(fused, "null");
+        *fused = (level + 1 < (int)h->lv.size() && can_fuse(h, h->lv[level])) ? 1 : 0;
+    });
+}
+
+int omg_hierarchy_set_info(const omg_hierarchy *h, int level, int set, int64_t *rows, int64_t *nnz) {
+    return guarded([&] {
+        check_level(h, level);
+        const DevCsr &A = h->lv[level].A;
+        OMG_REQUIRE(set >= 0 && size_t(set) < A.n_sets() && rows && nnz, "set out of range / null");
+        *rows = A.sets[set + 1] - A.sets[set];
+        *nnz = A.set_nnz[set];
+    });
+}
+
 int omg_vcycle(omg_hierarchy *h, int level, const double *b, double *x, int pre, int post,
                double *norm) {
     return guarded([&] {
@@ -475,10 +530,10 @@ int omg_vcycle(omg_hierarchy *h, int level, const double *b, double *x, int pre,
         load_vec(h, level, b, L.b.p);
         load_vec(h, level, x, L.xp);
         const int last = (int)h->lv.size() - 1;
-        cycle_body(h, level, pre, post);
+        const bool part = cycle_body(h, level, pre, post, level < last);
         double nv = 0.0;
         if (level < last) {
-            norm_level(h, level, nullptr);
+            norm_level(h, level, nullptr, part);
             nv = read_norm(h);
         }
         fetch_vec(h, level, L.xp, x);

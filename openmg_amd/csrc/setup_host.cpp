@@ -236,6 +236,8 @@ void DevCsr::upload(const HostCsr &A, const std::vector<int64_t> &sets_in, hipSt
         while (max_rows < ROWBLK_NNZ && avg * (2 * max_rows) <= ROWBLK_NNZ) max_rows *= 2;
     }
     rows_cap = max_rows;
+    set_nnz.assign(sets.size() - 1, 0);
+    for (size_t k = 0; k + 1 < sets.size(); ++k) set_nnz[k] = A.indptr[sets[k + 1]] - A.indptr[sets[k]];
     make_row_blocks(A.indptr, sets, max_rows, ROWBLK_NNZ, blocks, set_blk);
     indptr.alloc(A.indptr.size());
     indices.alloc(std::max<size_t>(A.indices.size(), 1));

@@ -472,3 +472,30 @@ def test_full_size_properties(n, levels):
         x2 = h.resident_fetch()
         assert np.array_equal(x2, 2.0 * x)
         assert norms2 == [2.0 * v for v in norms]
+
+
+# ------------------------------------------------ fused last-set sweep + residual / norm --
+@pytest.mark.parametrize("smoother", ["colour", "gs"])
+@pytest.mark.parametrize("pre,post", [(1, 1), (2, 1), (1, 0), (0, 2)])
+def test_fused_last_set_is_bit_identical(monkeypatch, smoother, pre, post):
+    """The smoother's last set launch also emits that set's residual / norm share
+    (ROW_GS_RES / ROW_GS_NORM); OMG_NO_FUSE=1 runs the plain passes.  Same bits either way,
+    for 7-entry rows (register path) and 27-entry rows (LDS re-walk path)."""
+    n1 = 16
+    T = sp.diags([np.ones(n1 - 1), np.ones(n1), np.ones(n1 - 1)], [-1, 0, 1])
+    A27 = sp.csr_matrix(-sp.kron(sp.kron(T, T), T) + sp.diags(np.full(n1 ** 3, 28.0)))
+    for A0, shape in ((operators.stencil_poisson((32, 32, 32)), (32, 32, 32)), (A27, (n1,) * 3)):
+        R = operators.restrictionList(shape, 1, 8)
+        A = operators.coeffecientList(A0, R)
+        b = A0 @ np.random.default_rng(21).random(A0.shape[0])
+        out = []
+        for no_fuse in ("1", "0"):
+            monkeypatch.setenv("OMG_NO_FUSE", no_fuse)
+            with _hip.Hierarchy(A, R, smoother=smoother) as h:
+                if no_fuse == "0" and smoother == "colour":
+                    assert h.level_fused(0)
+                h.resident_load(b)
+                norms = [h.resident_cycle(pre, post) for _ in range(3)]
+                out.append((norms, h.resident_fetch()))
+        assert out[0][0] == out[1][0]
+        assert np.array_equal(out[0][1], out[1][1])
