@@ -281,7 +281,12 @@ struct Runner {
         }
     }
 
-    void smooth(int l, int iterations) {
+    // fuse: 0 none, 1 the last set launch also stores its rows' residual into r, 2 it adds
+    // their squared residual to the block partials (RowMode ROW_GS_RES / ROW_GS_NORM: exact,
+    // because a relaxed row's residual involves no other row of its own set).  Returns true
+    // when that happened.
+    bool smooth(int l, int iterations, int fuse = 0) {
+        bool fused = false;
         for (int it = 0; it < iterations; ++it) {
             if (rs[0]->smoother == OMG_SMOOTH_JACOBI) {
                 for (D *d : rs) {
@@ -300,12 +305,20 @@ struct Runner {
                         OMG_REQUIRE((int)L.A.n_sets() == n_sets, "ranks disagree on the number of smoother sets");
                         RowArgs a;
                         a.x = L.xp; a.b = L.b.p; a.y = L.xp;
-                        launch_rows(L.A, ROW_GS, s, a, d->stream);
+                        if (fuse && it + 1 == iterations && s + 1 == n_sets) {
+                            a.zero = L.r.p;
+                            a.partials = L.partials.p;
+                            launch_rows(L.A, fuse == 1 ? ROW_GS_RES : ROW_GS_NORM, s, a, d->stream);
+                            fused = true;
+                        } else {
+                            launch_rows(L.A, ROW_GS, s, a, d->stream);
+                        }
                     }
                     exchange(l);
                 }
             }
         }
+        return fused;
     }
 
     void coarse() {
@@ -344,16 +357,17 @@ struct Runner {
         }
     }
 
-    void cycle(int l, int pre, int post) {
+    bool cycle(int l, int pre, int post, bool want_norm = false) {
         const int last = (int)rs[0]->lv.size() - 1;
-        if (l >= last) { coarse(); return; }
-        smooth(l, pre);
+        if (l >= last) { coarse(); return false; }
+        const bool res_done = smooth(l, pre, 1);
         for (D *d : rs) {
             DLevel &L = d->lv[l];
             DLevel &C = d->lv[l + 1];
             RowArgs a;
             a.x = L.xp; a.b = L.b.p; a.y = L.r.p;
-            launch_rows(L.A, ROW_RESIDUAL, -1, a, d->stream);
+            const int ns = (int)L.A.n_sets();
+            launch_rows_range(L.A, ROW_RESIDUAL, 0, res_done ? ns - 1 : ns, a, d->stream);
             RowArgs q;
             q.x = L.r.p; q.y = C.b.p; q.zero = (l + 1 < last) ? C.xp : nullptr;
             launch_rows(L.R, ROW_SPMV, -1, q, d->stream);
@@ -369,18 +383,20 @@ struct Runner {
             launch_rows(L.P, ROW_AXPY, -1, a, d->stream);
         }
         exchange(l);
-        if (post > 0) smooth(l, post);
+        if (post > 0) return smooth(l, post, want_norm ? 2 : 0);
+        return false;
     }
 
     // sum over all ranks of the local sums of squares -> sqrt, left in every rank's sumsq
-    void norm() {
+    void norm(bool last_set_done) {
         const bool single = rs[0]->lv.size() == 1;
         for (D *d : rs) {
             if (single) { OMG_HIP(hipMemsetAsync(d->sumsq.p, 0, sizeof(double), d->stream)); continue; }
             DLevel &L = d->lv[0];
             RowArgs a;
             a.x = L.xp; a.b = L.b.p; a.partials = L.partials.p;
-            launch_rows(L.A, ROW_NORM_ONLY, -1, a, d->stream);
+            const int ns = (int)L.A.n_sets();
+            launch_rows_range(L.A, ROW_NORM_ONLY, 0, last_set_done ? ns - 1 : ns, a, d->stream);
             launch_sum(L.partials.p, L.A.n_blocks(), d->sumsq.p, d->stream);
         }
         if (single) return;
@@ -408,8 +424,8 @@ struct Runner {
         bool dirty = false;
         for (D *d : rs) dirty = dirty || d->halo_dirty;
         if (dirty) { exchange(0); for (D *d : rs) d->halo_dirty = false; }
-        cycle(0, pre, post);
-        norm();
+        const bool part = cycle(0, pre, post, rs[0]->lv.size() > 1);
+        norm(part);
         if (norm_out) {
             D *d = rs[0];
             OMG_HIP(hipMemcpyAsync(norm_out, d->sumsq.p, sizeof(double), hipMemcpyDeviceToHost, d->stream));

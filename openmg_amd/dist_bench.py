@@ -96,6 +96,10 @@ def main(args):
                        "final_residual_norm": norm, "setup_s": round(setup_s, 2)},
             "roofline": None, "cpu_baseline": None,
         }
+        # RCCL (NCCL_DEBUG=VERSION) and gloo write banners through C stdio; push them out first
+        # so that the JSON line is the LAST line of stdout
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
         print(json.dumps(out))
         sys.stdout.flush()
     r.close()
