@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""Summarise rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes per rows_kernel instantiation.
+
+    python tools/pmc_summary.py <fetch counter_collection.csv> <write counter_collection.csv>
+
+FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports half of the bytes of wide
+coalesced streaming reads (MI355X_MICROARCH.md, HBM section), so reads = 2 x FETCH_SIZE."""
+import collections
+import csv
+import re
+import sys
+
+
+def load(path):
+    agg = collections.defaultdict(list)
+    for r in csv.DictReader(open(path)):
+        m = re.search(r"rows_kernel<(\d+), (true|false), (true|false)>", r["Kernel_Name"])
+        if not m:
+            continue
+        key = (int(m.group(1)), int(r["Grid_Size"]) // 256)
+        agg[key].append((float(r["Counter_Value"]), (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3))
+    return agg
+
+
+MODES = {0: "spmv", 1: "residual", 2: "resnorm", 3: "gs", 4: "jacobi", 5: "axpy", 6: "norm_only", 7: "gs+res", 8: "gs+norm"}
+
+
+def main():
+    fetch, write = load(sys.argv[1]), load(sys.argv[2])
+    print("%-10s %9s %7s %12s %12s %12s %10s" % ("mode", "blocks", "n", "read MB(2xF)", "write MB", "total MB", "dur us*"))
+    for key in sorted(fetch, key=lambda k: -max(v[0] for v in fetch[k])):
+        f = sum(v[0] for v in fetch[key]) / len(fetch[key]) * 1024 / 1e6
+        w = sum(v[0] for v in write.get(key, [(0, 0)])) / max(len(write.get(key, [1])), 1) * 1024 / 1e6
+        d = sum(v[1] for v in fetch[key]) / len(fetch[key])
+        print("%-10s %9d %7d %12.1f %12.1f %12.1f %10.1f" % (MODES.get(key[0], key[0]), key[1], len(fetch[key]), 2 * f, w, 2 * f + w, d))
+    print("* duration under counter collection (serialised dispatches), not the benchmark's")
+
+
+if __name__ == "__main__":
+    main()
