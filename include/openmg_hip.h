@@ -102,6 +102,11 @@ int omg_vcycle(omg_hierarchy *h, int level, const double *b, double *x,
 int omg_solve(omg_hierarchy *h, const double *b, double *x, int pre, int post,
               int max_cycles, double threshold, int *cycles_done, double *norm);
 
+/* Device-pointer cycle: b_dev, x_dev are level-0 DEVICE vectors in natural numbering, x starts
+ * from zero, work is enqueued on hip_stream (NULL = the hierarchy's own) without host sync. */
+int omg_hierarchy_cycle_dev(omg_hierarchy *h, const double *b_dev, double *x_dev, int pre, int post,
+                            void *hip_stream);
+
 /* Device-resident variants used by bench.py and by repeated mgCycle calls: level-0 b and x
  * live in HBM between calls.                                                             */
 int omg_resident_load(omg_hierarchy *h, const double *b, const double *x0 /* NULL = zeros */);
@@ -204,6 +209,11 @@ int omg_dist_create(int rank, int n_ranks, int n_levels, const omg_dist_level *l
                     const omg_csr *coarse_global, const int64_t *coarse_counts,
                     int smoother, double omega, omg_dist **out);
 int omg_dist_destroy(omg_dist *d);
+/* Replicated tail: below the last distributed level every rank runs `tail` — an ordinary
+ * omg_hierarchy whose finest operator is the WHOLE operator of that level — on the gathered
+ * right-hand side and keeps its own slice of the correction; no exchange happens down there.
+ * Pass coarse_global = NULL to omg_dist_create when a tail will be set.  `tail` is borrowed. */
+int omg_dist_set_tail(omg_dist *d, omg_hierarchy *tail);
 int omg_dist_set_stream(omg_dist *d, void *hip_stream);
 int omg_dist_sync(omg_dist *d);
 /* RCCL bootstrap: rank 0 makes a 128-byte id, the host broadcasts it (torch.distributed),

@@ -87,6 +87,8 @@ SIGNATURES = {
     "omg_restriction": (_I, [_I, _I64P, _P, _P, _P, _I64P, _I64P]),
     "omg_dist_create": (_I, [_I, _I, _I, _P, _CSR, _I64P, _I, _D, _PP]),
     "omg_dist_destroy": (_I, [_P]),
+    "omg_dist_set_tail": (_I, [_P, _P]),
+    "omg_hierarchy_cycle_dev": (_I, [_P, _P, _P, _I, _I, _P]),
     "omg_dist_set_stream": (_I, [_P, _P]),
     "omg_dist_sync": (_I, [_P]),
     "omg_rccl_unique_id": (_I, [_P]),

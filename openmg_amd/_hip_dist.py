@@ -23,8 +23,12 @@ class DistRank:
     by openmg_amd.dist: dicts with A, R (CSR, local column numbering), n_halo, keys, n_sets,
     peers, send_off, send_idx, recv_off."""
 
-    def __init__(self, rank, n_ranks, levels, coarse_global, coarse_counts, smoother="colour", omega=1.0):
+    def __init__(self, rank, n_ranks, levels, coarse_global, coarse_counts, smoother="colour", omega=1.0,
+                 tail=None):
+        """coarse_global: the whole operator of the last distributed level (direct solve), or None
+        when `tail` — a _hip.Hierarchy over the levels below it — does that job."""
         self.rank, self.n_ranks = int(rank), int(n_ranks)
+        self._tail = tail
         keep = []
         views = (DistLevelView * len(levels))()
         empty = sp.csr_matrix((0, 0))
@@ -47,20 +51,26 @@ class DistRank:
             v.send_off = send_off.ctypes.data
             v.send_idx = send_idx.ctypes.data
             v.recv_off = recv_off.ctypes.data
-        G = as_csr(coarse_global)
-        gv = csr_view(G)
+        G = None if coarse_global is None else as_csr(coarse_global)
+        gv = None if G is None else csr_view(G)
         counts = (ctypes.c_int64 * self.n_ranks)(*[int(c) for c in coarse_counts])
         self.n_local = levels[0]["A"].shape[0]
         h = ctypes.c_void_p()
-        check(lib().omg_dist_create(self.rank, self.n_ranks, len(levels), views, ctypes.byref(gv), counts,
+        check(lib().omg_dist_create(self.rank, self.n_ranks, len(levels), views,
+                                    None if gv is None else ctypes.byref(gv), counts,
                                     smoother_code(smoother), float(omega), ctypes.byref(h)))
         self._h = h
+        if tail is not None:
+            check(lib().omg_dist_set_tail(self._h, tail._h))
         del keep
 
     def close(self):
         if getattr(self, "_h", None):
             lib().omg_dist_destroy(self._h)
             self._h = None
+        if getattr(self, "_tail", None) is not None:
+            self._tail.close()
+            self._tail = None
 
     def __del__(self):
         try:

@@ -107,7 +107,12 @@ struct omg_dist {
     // coarsest level: replicated inverse, gathered right-hand side
     int64_t n_coarse = 0, coarse_lo = 0;
     std::vector<int64_t> coarse_counts;        // rows per rank at the coarsest level
-    DevBuf<double> coarse_inv, coarse_rhs;
+    DevBuf<double> coarse_inv, coarse_rhs, coarse_sol;
+    // Optional replicated TAIL: instead of one direct solve, every rank runs the levels below
+    // the last distributed one as an ordinary single-GPU hierarchy on the gathered right-hand
+    // side (no communication down there; the coarse levels of a slab decomposition are pure
+    // exchange latency otherwise).  Borrowed, owned by the caller.
+    omg_hierarchy *tail = nullptr;
     DevBuf<double> sumsq;                      // device scalar
     ncclComm_t comm = nullptr;
     bool halo_dirty = true;
@@ -136,7 +141,7 @@ std::unique_ptr<D> create(int rank, int n_ranks, int n_levels, const omg_dist_le
                           const omg_csr *coarse_global, const int64_t *coarse_counts, int smoother,
                           double omega) {
     OMG_REQUIRE(n_ranks >= 1 && rank >= 0 && rank < n_ranks, "bad rank / n_ranks");
-    OMG_REQUIRE(n_levels >= 1 && lv && coarse_global && coarse_counts, "null argument");
+    OMG_REQUIRE(n_levels >= 1 && lv && coarse_counts, "null argument");
     require_device();
     std::unique_ptr<D> d(new D);
     d->rank = rank;
@@ -211,23 +216,27 @@ std::unique_ptr<D> create(int rank, int n_ranks, int n_levels, const omg_dist_le
         L.send_buf.alloc(std::max<int64_t>(n_send, 1));
         OMG_HIP(hipStreamSynchronize(d->stream));
     }
-    // coarsest level: invert the replicated global operator, keep it whole (n_L is small)
+    // coarsest distributed level: either invert the replicated global operator here (kept
+    // whole, n_L is small) or, with coarse_global == NULL, wait for omg_dist_set_tail
     {
-        validate_csr(*coarse_global, "coarse_global");
-        OMG_REQUIRE(coarse_global->n_rows == coarse_global->n_cols, "coarse operator must be square");
-        d->n_coarse = coarse_global->n_rows;
         d->coarse_counts.assign(coarse_counts, coarse_counts + n_ranks);
         int64_t lo = 0, tot = 0;
         for (int q = 0; q < n_ranks; ++q) { if (q < rank) lo += coarse_counts[q]; tot += coarse_counts[q]; }
-        OMG_REQUIRE(tot == d->n_coarse, "coarse row counts do not add up");
+        d->n_coarse = tot;
         OMG_REQUIRE(coarse_counts[rank] == d->lv.back().n_loc, "coarse row count of this rank differs from its level");
         d->coarse_lo = lo;
-        DevCsr G;
-        HostCsr Gh = permute_csr(*coarse_global, nullptr, nullptr);
-        G.upload(Gh, {}, d->stream);
-        d->coarse_inv.alloc(std::max<size_t>(size_t(d->n_coarse) * size_t(d->n_coarse), 1));
-        dense_inverse_from_csr(G, d->coarse_inv.p, d->stream);
+        if (coarse_global) {
+            validate_csr(*coarse_global, "coarse_global");
+            OMG_REQUIRE(coarse_global->n_rows == coarse_global->n_cols && coarse_global->n_rows == tot,
+                        "coarse operator must be square and match the coarse row counts");
+            DevCsr G;
+            HostCsr Gh = permute_csr(*coarse_global, nullptr, nullptr);
+            G.upload(Gh, {}, d->stream);
+            d->coarse_inv.alloc(std::max<size_t>(size_t(d->n_coarse) * size_t(d->n_coarse), 1));
+            dense_inverse_from_csr(G, d->coarse_inv.p, d->stream);
+        }
         d->coarse_rhs.alloc(std::max<int64_t>(d->n_coarse, 1));
+        d->coarse_sol.alloc(std::max<int64_t>(d->n_coarse, 1));
     }
     OMG_HIP(hipStreamSynchronize(d->stream));
     return d;
@@ -321,8 +330,9 @@ struct Runner {
         return fused;
     }
 
-    void coarse() {
-        // all-gather the coarsest right-hand side, then each rank applies ITS rows of the inverse
+    void coarse(int pre, int post) {
+        // all-gather the coarsest right-hand side, then each rank applies ITS rows of the
+        // inverse — or runs the replicated tail hierarchy and keeps its slice of the result
         if (rccl) {
             D *d = rs[0];
             DLevel &L = d->lv.back();
@@ -352,14 +362,22 @@ struct Runner {
         }
         for (D *d : rs) {
             DLevel &L = d->lv.back();
-            launch_dense_gemv_rows(d->coarse_inv.p + d->coarse_lo * d->n_coarse, d->coarse_rhs.p, L.xp, L.n_loc,
-                                   d->n_coarse, d->stream);
+            if (d->tail) {
+                const int rc = omg_hierarchy_cycle_dev(d->tail, d->coarse_rhs.p, d->coarse_sol.p, pre, post, d->stream);
+                if (rc != OMG_OK) throw Error(rc, std::string("tail hierarchy: ") + omg_last_error());
+                if (L.n_loc) OMG_HIP(hipMemcpyAsync(L.xp, d->coarse_sol.p + d->coarse_lo, L.n_loc * sizeof(double),
+                                                    hipMemcpyDeviceToDevice, d->stream));
+            } else {
+                OMG_REQUIRE(d->coarse_inv.p != nullptr, "no coarse solver: pass coarse_global or call omg_dist_set_tail");
+                launch_dense_gemv_rows(d->coarse_inv.p + d->coarse_lo * d->n_coarse, d->coarse_rhs.p, L.xp, L.n_loc,
+                                       d->n_coarse, d->stream);
+            }
         }
     }
 
     bool cycle(int l, int pre, int post, bool want_norm = false) {
         const int last = (int)rs[0]->lv.size() - 1;
-        if (l >= last) { coarse(); return false; }
+        if (l >= last) { coarse(pre, post); return false; }
         const bool res_done = smooth(l, pre, 1);
         for (D *d : rs) {
             DLevel &L = d->lv[l];
@@ -479,6 +497,18 @@ int omg_dist_set_stream(omg_dist *d, void *hip_stream) {
         OMG_REQUIRE(d, "null handle");
         OMG_HIP(hipStreamSynchronize(d->stream));
         d->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : d->own;
+    });
+}
+
+int omg_dist_set_tail(omg_dist *d, omg_hierarchy *tail) {
+    return guarded([&] {
+        OMG_REQUIRE(d, "null handle");
+        if (tail) {
+            int64_t n = 0;
+            OMG_REQUIRE(omg_hierarchy_level_rows(tail, 0, &n) == OMG_OK && n == d->n_coarse,
+                        "tail hierarchy's finest level must have as many rows as the last distributed level has in total");
+        }
+        d->tail = tail;
     });
 }
 

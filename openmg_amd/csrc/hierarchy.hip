@@ -541,6 +541,34 @@ int omg_vcycle(omg_hierarchy *h, int level, const double *b, double *x, int pre,
     });
 }
 
+// Device-pointer V-cycle for callers that already live on the GPU (the multi-GPU runner uses
+// a replicated hierarchy as its coarse solver): b_dev, x_dev are level-0 vectors in natural
+// numbering; x starts from zero (openmg/__init__.py:191-192); enqueued on `hip_stream`, no
+// host synchronisation.
+int omg_hierarchy_cycle_dev(omg_hierarchy *h, const double *b_dev, double *x_dev, int pre, int post,
+                            void *hip_stream) {
+    return guarded([&] {
+        check_level(h, 0);
+        OMG_REQUIRE(b_dev && x_dev && pre >= 0 && post >= 0, "bad argument");
+        Level &L = h->lv[0];
+        hipStream_t keep = h->stream;
+        h->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : h->own;
+        h->resident = false;
+        try {
+            if (L.ord.identity) OMG_HIP(hipMemcpyAsync(L.b.p, b_dev, L.n * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+            else launch_gather(b_dev, L.perm.p, L.b.p, L.n, h->stream);
+            if (h->lv.size() > 1) OMG_HIP(hipMemsetAsync(L.xp, 0, L.n * sizeof(double), h->stream));
+            cycle_body(h, 0, pre, post);
+            if (L.ord.identity) OMG_HIP(hipMemcpyAsync(x_dev, L.xp, L.n * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+            else launch_scatter(L.xp, L.perm.p, x_dev, L.n, h->stream);
+        } catch (...) {
+            h->stream = keep;
+            throw;
+        }
+        h->stream = keep;
+    });
+}
+
 int omg_resident_load(omg_hierarchy *h, const double *b, const double *x0) {
     return guarded([&] {
         check_level(h, 0);

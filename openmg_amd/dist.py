@@ -269,6 +269,19 @@ class RankSetup:
                              "(the distributed path supports 3/5/7-point grid stencils)")
 
 
+def make_tail(coarse_global, shape, n_grids, smoother="colour", omega=1.0):
+    """Replicated tail: an ordinary single-GPU hierarchy over the levels BELOW the last
+    distributed one.  `coarse_global` is the whole operator of that level (shape `shape`),
+    `n_grids` how many grids the tail has (1 = direct solve only).  Every rank builds the same
+    object; DistRank(..., coarse_global=None, tail=...) uses it as its coarse solver, so the
+    small levels — pure exchange latency in a slab decomposition — need no communication."""
+    from . import _hip, operators
+    shapes = [tuple(s // 2 ** l for s in shape) for l in range(n_grids)]
+    R = [operators.restriction(shapes[l]) for l in range(n_grids - 1)]
+    A = operators.coeffecientList(sp.csr_matrix(coarse_global), R)
+    return _hip.Hierarchy(A, R, smoother=smoother, omega=omega)
+
+
 def assemble_coarse(rows_per_rank):
     G = sp.vstack([sp.csr_matrix(r) for r in rows_per_rank], format="csr")
     G.sum_duplicates()

@@ -42,7 +42,10 @@ def main(args):
     shape = tuple(int(s * scale) for s in SHAPES[world])
     grids = args.grids if world == 1 else args.grids + 1
     t_setup = time.perf_counter()
-    part = dist.SlabPartition(shape, world, grids)
+    # levels 0..n_dist-2 are smoothed across ranks; level n_dist-1 and everything below it run
+    # replicated on every rank as an ordinary single-GPU hierarchy (dist.make_tail)
+    n_dist = max(2, min(args.dist_grids, grids))
+    part = dist.SlabPartition(shape, world, n_dist)
     lo, hi = part.rows(0, rank)
     A_rows = dist.stencil_rows(shape, lo, hi)
     u = np.random.default_rng(12345).random(part.n_rows(0))
@@ -51,7 +54,8 @@ def main(args):
     levels, coarse, counts = dist.build_this_rank(part, rank, A_rows, all_gather, smoother=args.smoother)
     nnz_loc, n_loc = A_rows.nnz, hi - lo
     del A_rows
-    r = _hip_dist.DistRank(rank, world, levels, coarse, counts, smoother=args.smoother)
+    tail = dist.make_tail(coarse, part.shapes[-1], grids - n_dist + 1, smoother=args.smoother)
+    r = _hip_dist.DistRank(rank, world, levels, None, counts, smoother=args.smoother, tail=tail)
     ident = [_hip_dist.rccl_unique_id() if rank == 0 else None]
     td.broadcast_object_list(ident, src=0)
     r.connect(ident[0])
@@ -92,6 +96,7 @@ def main(args):
                                    % ("x".join(map(str, shape)), grids,
                                       "red-black" if args.smoother == "colour" else args.smoother, world),
                        "unknowns": n_glob, "unknowns_per_gpu": n_loc, "nnz_per_gpu": nnz_loc, "grids": grids,
+                       "distributed_grids": n_dist - 1, "replicated_tail_grids": grids - n_dist + 1,
                        "pre": pre, "post": post, "cycles_per_s": round(args.steps / elapsed, 3),
                        "final_residual_norm": norm, "setup_s": round(setup_s, 2)},
             "roofline": None, "cpu_baseline": None,

@@ -97,3 +97,29 @@ def test_initial_iterate_and_rccl_single_rank():
         h.resident_load(b, x0)
         h.resident_cycle(1, 1)
         assert np.array_equal(xd, h.resident_fetch())
+
+
+@pytest.mark.parametrize("n_ranks,n_dist", [(2, 3), (4, 2), (2, 2)])
+def test_replicated_tail_matches_single_gpu(n_ranks, n_dist):
+    """Levels below the last distributed one run replicated on every rank (dist.make_tail):
+    still the same iterate as one GPU running all 5 grids."""
+    shape, grids = (64, 64, 64), 5
+    N = int(np.prod(shape))
+    b = operators.stencil_poisson(shape) @ np.random.default_rng(77).random(N)
+    x1, n1 = single_gpu(shape, grids, "colour", b, 3)
+    part = dist.SlabPartition(shape, n_ranks, n_dist)
+    levels, coarse, counts = dist.build_all_ranks(
+        part, lambda q: dist.stencil_rows(shape, *part.rows(0, q)), smoother="colour")
+    ranks = [_hip_dist.DistRank(q, n_ranks, levels[q], None, counts, smoother="colour",
+                                tail=dist.make_tail(coarse, part.shapes[-1], grids - n_dist + 1, smoother="colour"))
+             for q in range(n_ranks)]
+    group = _hip_dist.DistGroup(ranks)
+    try:
+        for q, r in enumerate(ranks):
+            r.load(b[slice(*part.rows(0, q))])
+        nd = [group.cycle(1, 1) for _ in range(3)]
+        xd = np.concatenate([r.fetch() for r in ranks])
+    finally:
+        group.close()
+    assert np.array_equal(xd, x1)
+    np.testing.assert_allclose(nd, n1, rtol=1e-13)
