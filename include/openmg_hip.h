@@ -200,6 +200,10 @@ typedef struct {
     const int64_t *send_off;
     const int32_t *send_idx;
     const int64_t *recv_off;
+    /* 1: plain sets.  2: sets come in (boundary, interior) pairs of one colour — rows that
+     * other ranks need first, the rest second; the halo exchange of a pair then runs on a
+     * second stream while the interior rows are still being relaxed.                        */
+    int32_t set_group;
 } omg_dist_level;
 
 typedef struct omg_dist omg_dist;

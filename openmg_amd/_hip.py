@@ -107,7 +107,8 @@ class DistLevelView(ctypes.Structure):
     _fields_ = [("A", CsrView), ("R", CsrView), ("n_halo", ctypes.c_int64),
                 ("keys", ctypes.c_void_p), ("n_sets", ctypes.c_int32), ("n_peers", ctypes.c_int32),
                 ("peers", ctypes.c_void_p), ("send_off", ctypes.c_void_p),
-                ("send_idx", ctypes.c_void_p), ("recv_off", ctypes.c_void_p)]
+                ("send_idx", ctypes.c_void_p), ("recv_off", ctypes.c_void_p),
+                ("set_group", ctypes.c_int32)]
 
 _lib = None
 

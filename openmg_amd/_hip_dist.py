@@ -51,6 +51,7 @@ class DistRank:
             v.send_off = send_off.ctypes.data
             v.send_idx = send_idx.ctypes.data
             v.recv_off = recv_off.ctypes.data
+            v.set_group = int(lv.get("set_group", 1))
         G = None if coarse_global is None else as_csr(coarse_global)
         gv = None if G is None else csr_view(G)
         counts = (ctypes.c_int64 * self.n_ranks)(*[int(c) for c in coarse_counts])

@@ -89,6 +89,7 @@ struct DLevel {
     std::vector<int64_t> send_off, recv_off;   // per peer, size peers + 1
     DevBuf<int32_t> send_idx;                  // rows (this level's ordering) to send, all peers
     DevBuf<double> send_buf;
+    int set_group = 1;                         // 2: sets are (boundary, interior) pairs
 };
 
 __global__ void sqrt_kernel(double *v) { *v = sqrt(*v); }
@@ -115,11 +116,18 @@ struct omg_dist {
     omg_hierarchy *tail = nullptr;
     DevBuf<double> sumsq;                      // device scalar
     ncclComm_t comm = nullptr;
+    // RCCL calls go to a second stream so that an exchange can overlap the interior rows of
+    // a (boundary, interior) set pair; two events order it against the compute stream.
+    hipStream_t cstream = nullptr;
+    hipEvent_t ev_go = nullptr, ev_done = nullptr;
     bool halo_dirty = true;
     bool loaded = false;
 
     ~omg_dist() {
         if (comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(comm);
+        if (ev_go) (void)hipEventDestroy(ev_go);
+        if (ev_done) (void)hipEventDestroy(ev_done);
+        if (cstream) (void)hipStreamDestroy(cstream);
         if (own) (void)hipStreamDestroy(own);
     }
 };
@@ -150,6 +158,9 @@ std::unique_ptr<D> create(int rank, int n_ranks, int n_levels, const omg_dist_le
     d->omega = omega;
     OMG_HIP(hipStreamCreateWithFlags(&d->own, hipStreamNonBlocking));
     d->stream = d->own;
+    OMG_HIP(hipStreamCreateWithFlags(&d->cstream, hipStreamNonBlocking));
+    OMG_HIP(hipEventCreateWithFlags(&d->ev_go, hipEventDisableTiming));
+    OMG_HIP(hipEventCreateWithFlags(&d->ev_done, hipEventDisableTiming));
     d->lv.resize(n_levels);
     d->sumsq.alloc(1);
     for (int l = 0; l < n_levels; ++l) {
@@ -200,6 +211,8 @@ std::unique_ptr<D> create(int rank, int n_ranks, int n_levels, const omg_dist_le
         L.tp = L.tmp.p;
         // halo plan
         OMG_REQUIRE(in.n_peers >= 0, "negative peer count");
+        L.set_group = (in.set_group == 2 && !last && in.keys) ? 2 : 1;
+        OMG_REQUIRE(L.set_group == 1 || in.n_sets % 2 == 0, "paired sets need an even set count");
         L.peers.assign(in.peers, in.peers + in.n_peers);
         L.send_off.assign(in.send_off, in.send_off + in.n_peers + 1);
         L.recv_off.assign(in.recv_off, in.recv_off + in.n_peers + 1);
@@ -252,24 +265,69 @@ struct Runner {
         throw Error(OMG_ERR_INVALID, "loopback group lacks rank " + std::to_string(rank));
     }
 
+    // Does level l's exchange run on the second (comm) stream so that it overlaps the
+    // interior launch?  Only where that pays: each cross-stream event pair costs a few us of
+    // bubble (measured: 25 of them slowed a one-rank 256^3 cycle from 1.53 to 1.80 ms), so
+    // small levels, single-rank runs and loopback groups keep everything on one stream.
+    static int64_t overlap_min_rows() {
+        static int64_t v = -1;
+        if (v < 0) {
+            const char *e = getenv("OMG_OVERLAP_MIN_ROWS");
+            v = e ? atoll(e) : (int64_t(1) << 19);
+        }
+        return v;
+    }
+    bool on_comm_stream(int l) const {
+        if (!rccl) return false;
+        const DLevel &L = rs[0]->lv[l];
+        return L.set_group == 2 && !L.peers.empty() && L.n_loc >= overlap_min_rows();
+    }
+    hipStream_t cs(D *d, int l) const { return on_comm_stream(l) ? d->cstream : d->stream; }
+    // comm stream waits for everything enqueued so far on the compute stream ...
+    void comm_begin(D *d, int l) {
+        if (!on_comm_stream(l)) return;
+        OMG_HIP(hipEventRecord(d->ev_go, d->stream));
+        OMG_HIP(hipStreamWaitEvent(d->cstream, d->ev_go, 0));
+    }
+    // ... and the compute stream waits for the communication enqueued since.
+    void comm_end(D *d, int l) {
+        if (!on_comm_stream(l)) return;
+        OMG_HIP(hipEventRecord(d->ev_done, d->cstream));
+        OMG_HIP(hipStreamWaitEvent(d->stream, d->ev_done, 0));
+    }
+
     void pack(D *d, int l) {
         DLevel &L = d->lv[l];
         const int64_t n = L.peers.empty() ? 0 : L.send_off.back();
-        if (n) launch_gather(L.xp, L.send_idx.p, L.send_buf.p, n, d->stream);
+        if (n) launch_gather(L.xp, L.send_idx.p, L.send_buf.p, n, cs(d, l));
     }
 
-    // boundary values of x_l -> neighbours' halo regions
+    // boundary values of x_l -> neighbours' halo regions.  exchange_start enqueues the
+    // transfer behind the work already on the compute stream; work enqueued on the compute
+    // stream between start and finish overlaps it (it must not read halo entries nor write
+    // rows that are being sent); exchange_finish makes the compute stream wait for it.
     void exchange(int l) {
+        exchange_start(l);
+        exchange_finish(l);
+    }
+
+    void exchange_finish(int l) {
+        for (D *d : rs) comm_end(d, l);
+    }
+
+    void exchange_start(int l) {
+        for (D *d : rs) comm_begin(d, l);
         for (D *d : rs) pack(d, l);
         if (rccl) {
             D *d = rs[0];
             DLevel &L = d->lv[l];
             if (L.peers.empty()) return;
+            hipStream_t s = cs(d, l);
             OMG_NCCL(g_rccl.GroupStart());
             for (size_t k = 0; k < L.peers.size(); ++k) {
                 const int64_t ns = L.send_off[k + 1] - L.send_off[k], nr = L.recv_off[k + 1] - L.recv_off[k];
-                if (ns) OMG_NCCL(g_rccl.Send(L.send_buf.p + L.send_off[k], (size_t)ns, ncclDouble, L.peers[k], d->comm, d->stream));
-                if (nr) OMG_NCCL(g_rccl.Recv(L.xp + L.n_loc + L.recv_off[k], (size_t)nr, ncclDouble, L.peers[k], d->comm, d->stream));
+                if (ns) OMG_NCCL(g_rccl.Send(L.send_buf.p + L.send_off[k], (size_t)ns, ncclDouble, L.peers[k], d->comm, s));
+                if (nr) OMG_NCCL(g_rccl.Recv(L.xp + L.n_loc + L.recv_off[k], (size_t)nr, ncclDouble, L.peers[k], d->comm, s));
             }
             OMG_NCCL(g_rccl.GroupEnd());
         } else {
@@ -308,13 +366,16 @@ struct Runner {
                 exchange(l);
             } else {
                 const int n_sets = (int)rs[0]->lv[l].A.n_sets();
-                for (int s = 0; s < n_sets; ++s) {
+                const int grp = rs[0]->lv[l].set_group;
+                for (D *d : rs)
+                    OMG_REQUIRE((int)d->lv[l].A.n_sets() == n_sets && d->lv[l].set_group == grp,
+                                "ranks disagree on the smoother sets of a level");
+                auto sweep_set = [&](int s, bool last_group) {
                     for (D *d : rs) {
                         DLevel &L = d->lv[l];
-                        OMG_REQUIRE((int)L.A.n_sets() == n_sets, "ranks disagree on the number of smoother sets");
                         RowArgs a;
                         a.x = L.xp; a.b = L.b.p; a.y = L.xp;
-                        if (fuse && it + 1 == iterations && s + 1 == n_sets) {
+                        if (fuse && it + 1 == iterations && last_group) {
                             a.zero = L.r.p;
                             a.partials = L.partials.p;
                             launch_rows(L.A, fuse == 1 ? ROW_GS_RES : ROW_GS_NORM, s, a, d->stream);
@@ -323,7 +384,14 @@ struct Runner {
                             launch_rows(L.A, ROW_GS, s, a, d->stream);
                         }
                     }
-                    exchange(l);
+                };
+                for (int s = 0; s < n_sets; s += grp) {
+                    const bool last_group = s + grp == n_sets;
+                    sweep_set(s, last_group);            // plain set, or the BOUNDARY rows of a colour
+                    exchange_start(l);
+                    // interior rows of the same colour: touch no halo entry, are not sent
+                    if (grp == 2) sweep_set(s + 1, last_group);
+                    exchange_finish(l);
                 }
             }
         }
@@ -385,7 +453,7 @@ struct Runner {
             RowArgs a;
             a.x = L.xp; a.b = L.b.p; a.y = L.r.p;
             const int ns = (int)L.A.n_sets();
-            launch_rows_range(L.A, ROW_RESIDUAL, 0, res_done ? ns - 1 : ns, a, d->stream);
+            launch_rows_range(L.A, ROW_RESIDUAL, 0, res_done ? ns - L.set_group : ns, a, d->stream);
             RowArgs q;
             q.x = L.r.p; q.y = C.b.p; q.zero = (l + 1 < last) ? C.xp : nullptr;
             launch_rows(L.R, ROW_SPMV, -1, q, d->stream);
@@ -414,7 +482,7 @@ struct Runner {
             RowArgs a;
             a.x = L.xp; a.b = L.b.p; a.partials = L.partials.p;
             const int ns = (int)L.A.n_sets();
-            launch_rows_range(L.A, ROW_NORM_ONLY, 0, last_set_done ? ns - 1 : ns, a, d->stream);
+            launch_rows_range(L.A, ROW_NORM_ONLY, 0, last_set_done ? ns - L.set_group : ns, a, d->stream);
             launch_sum(L.partials.p, L.A.n_blocks(), d->sumsq.p, d->stream);
         }
         if (single) return;

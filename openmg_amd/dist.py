@@ -191,8 +191,8 @@ class RankSetup:
 
     `spgemm(X, Y)` does the two Galerkin products (default: the device SpGEMM)."""
 
-    def __init__(self, part, rank, A0_rows, smoother="colour", spgemm=None):
-        self.part, self.rank, self.smoother = part, int(rank), smoother
+    def __init__(self, part, rank, A0_rows, smoother="colour", spgemm=None, overlap=True):
+        self.part, self.rank, self.smoother, self.overlap = part, int(rank), smoother, bool(overlap)
         if spgemm is None:
             from . import _hip
             spgemm = _hip.spgemm
@@ -216,6 +216,17 @@ class RankSetup:
             keys, n_sets = set_keys(part.shapes[l], np.arange(lo, hi), self.smoother)
             if keys is not None:
                 self._check_keys(A_loc, keys, set_keys(part.shapes[l], halo, self.smoother)[0], hi - lo)
+            lv["set_group"] = 1
+            if keys is not None and self.smoother == "colour" and self.overlap:
+                # rows that touch the halo (for a symmetric pattern: exactly the rows the
+                # neighbours need) go FIRST inside their colour, so that their exchange can run
+                # while the interior rows of the colour are still being relaxed
+                interior = np.ones(hi - lo, dtype=np.int32)
+                touches = np.unique(np.repeat(np.arange(hi - lo), np.diff(A_loc.indptr))[A_loc.indices >= hi - lo])
+                interior[touches] = 0
+                keys = (2 * keys + interior).astype(np.int32)
+                n_sets *= 2
+                lv["set_group"] = 2
             lv["keys"], lv["n_sets"] = keys, n_sets
             clo, chi = part.rows(l + 1, q)
             R_glob = restriction_rows(part.shapes[l], clo, chi)
@@ -288,10 +299,11 @@ def assemble_coarse(rows_per_rank):
     return G
 
 
-def build_all_ranks(part, A0_rows_of, smoother="colour", spgemm=None):
+def build_all_ranks(part, A0_rows_of, smoother="colour", spgemm=None, overlap=True):
     """In-process construction of EVERY rank (loopback groups, tests).  A0_rows_of(rank) gives
     that rank's fine rows.  Returns (levels_per_rank, coarse_global, coarse_counts)."""
-    setups = [RankSetup(part, q, A0_rows_of(q), smoother=smoother, spgemm=spgemm) for q in range(part.n_ranks)]
+    setups = [RankSetup(part, q, A0_rows_of(q), smoother=smoother, spgemm=spgemm, overlap=overlap)
+              for q in range(part.n_ranks)]
     for l in range(part.n_grids):
         halos = [s.begin_level(l) for s in setups]
         for s in setups:
@@ -302,10 +314,10 @@ def build_all_ranks(part, A0_rows_of, smoother="colour", spgemm=None):
     return [s.levels for s in setups], coarse, counts
 
 
-def build_this_rank(part, rank, A0_rows, all_gather, smoother="colour", spgemm=None):
+def build_this_rank(part, rank, A0_rows, all_gather, smoother="colour", spgemm=None, overlap=True):
     """SPMD construction: `all_gather(obj)` returns the list of every rank's obj (e.g.
     torch.distributed.all_gather_object).  Returns (levels, coarse_global, coarse_counts)."""
-    s = RankSetup(part, rank, A0_rows, smoother=smoother, spgemm=spgemm)
+    s = RankSetup(part, rank, A0_rows, smoother=smoother, spgemm=spgemm, overlap=overlap)
     for l in range(part.n_grids):
         halo = s.begin_level(l)
         s.finish_level(l, all_gather(halo))

@@ -51,7 +51,8 @@ def main(args):
     u = np.random.default_rng(12345).random(part.n_rows(0))
     b_loc = A_rows @ u
     del u
-    levels, coarse, counts = dist.build_this_rank(part, rank, A_rows, all_gather, smoother=args.smoother)
+    levels, coarse, counts = dist.build_this_rank(part, rank, A_rows, all_gather, smoother=args.smoother,
+                                                  overlap=bool(args.overlap))
     nnz_loc, n_loc = A_rows.nnz, hi - lo
     del A_rows
     tail = dist.make_tail(coarse, part.shapes[-1], grids - n_dist + 1, smoother=args.smoother)

@@ -123,3 +123,30 @@ def test_replicated_tail_matches_single_gpu(n_ranks, n_dist):
         group.close()
     assert np.array_equal(xd, x1)
     np.testing.assert_allclose(nd, n1, rtol=1e-13)
+
+
+def test_boundary_first_sets_do_not_change_the_iterate():
+    """overlap=True orders every colour as (rows the neighbours need, interior rows) so that
+    the exchange can run beside the interior launch; overlap=False keeps plain colour sets.
+    Same iterate either way (and the same as one GPU)."""
+    shape, grids, n_ranks = (32, 32, 32), 3, 4
+    b = operators.stencil_poisson(shape) @ np.random.default_rng(3).random(32 ** 3)
+    x1, n1 = single_gpu(shape, grids, "colour", b, 2)
+    part = dist.SlabPartition(shape, n_ranks, grids)
+    out = []
+    for overlap in (True, False):
+        levels, coarse, counts = dist.build_all_ranks(
+            part, lambda q: dist.stencil_rows(shape, *part.rows(0, q)), smoother="colour", overlap=overlap)
+        assert levels[1][0]["set_group"] == (2 if overlap else 1)
+        assert levels[1][0]["n_sets"] == (4 if overlap else 2)
+        ranks = [_hip_dist.DistRank(q, n_ranks, levels[q], coarse, counts, smoother="colour") for q in range(n_ranks)]
+        group = _hip_dist.DistGroup(ranks)
+        try:
+            for q, r in enumerate(ranks):
+                r.load(b[slice(*part.rows(0, q))])
+            norms = [group.cycle(1, 1) for _ in range(2)]
+            out.append((np.concatenate([r.fetch() for r in ranks]), norms))
+        finally:
+            group.close()
+    assert np.array_equal(out[0][0], x1) and np.array_equal(out[1][0], x1)
+    np.testing.assert_allclose(out[0][1], n1, rtol=1e-13)
