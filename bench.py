@@ -88,6 +88,7 @@ def main():
     ap.add_argument("--graph", type=int, default=0, help="replay the cycle from a hipGraph")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--dist", type=int, default=0, help="force the multi-GPU code path even with one rank (debug)")
+    ap.add_argument("--watchdog", type=int, default=900, help="multi-GPU: abort the rank after this many seconds")
     ap.add_argument("--overlap", type=int, default=1,
                     help="multi-GPU: relax boundary rows first and exchange them while the interior rows run")
     ap.add_argument("--dist-grids", type=int, default=4,

@@ -41,6 +41,17 @@ def main(args):
     scale = args.size / 256.0
     shape = tuple(int(s * scale) for s in SHAPES[world])
     grids = args.grids if world == 1 else args.grids + 1
+    # A collective that never completes would hang the whole node job: bail out hard instead.
+    import threading
+
+    def _abort():
+        sys.stderr.write("bench.py rank %d: watchdog expired after %d s, aborting\n" % (rank, args.watchdog))
+        sys.stderr.flush()
+        os._exit(3)
+
+    watchdog = threading.Timer(args.watchdog, _abort)
+    watchdog.daemon = True
+    watchdog.start()
     t_setup = time.perf_counter()
     # levels 0..n_dist-2 are smoothed across ranks; level n_dist-1 and everything below it run
     # replicated on every rank as an ordinary single-GPU hierarchy (dist.make_tail)
@@ -109,6 +120,7 @@ def main(args):
         print(json.dumps(out))
         sys.stdout.flush()
     r.close()
+    watchdog.cancel()
     td.barrier()
     td.destroy_process_group()
     return 0

@@ -499,3 +499,86 @@ def test_fused_last_set_is_bit_identical(monkeypatch, smoother, pre, post):
                 out.append((norms, h.resident_fetch()))
         assert out[0][0] == out[1][0]
         assert np.array_equal(out[0][1], out[1][1])
+
+
+# ------------------------------------------------------ irregular (non-stencil) hierarchies --
+def irregular_problem(rng, n=2600, long_row=True):
+    """Symmetric, strictly diagonally dominant, irregular sparsity, unsorted columns; one row
+    (and column) is denser than the LDS block budget so the whole-workgroup row path runs."""
+    S = sp.random(n, n, density=0.004, random_state=np.random.RandomState(int(rng.integers(1 << 30))), format="csr")
+    S = S + S.T
+    if long_row:
+        dense = sp.csr_matrix((rng.standard_normal(n) * 0.01, (np.full(n, 7), np.arange(n))), shape=(n, n))
+        S = S + dense + dense.T
+    S = sp.csr_matrix(S)
+    S.setdiag(0)
+    S.eliminate_zeros()
+    d = np.asarray(abs(S).sum(axis=1)).ravel() + 1.0
+    A = sp.csr_matrix(S + sp.diags(d))
+    A = random_csr_shuffle(A, rng)
+    # aggregation of consecutive pairs / triples with unequal weights
+    sizes = rng.integers(2, 4, size=n)
+    ends = np.cumsum(sizes)
+    ends = ends[ends < n]
+    starts = np.concatenate([[0], ends])
+    ends = np.concatenate([ends, [n]])
+    rows = np.repeat(np.arange(starts.size), ends - starts)
+    w = rng.random(n) + 0.5
+    R = sp.csr_matrix((w, (rows, np.arange(n))), shape=(starts.size, n))
+    return A, R
+
+
+@pytest.mark.parametrize("smoother", ["gs", "colour", "jacobi"])
+def test_irregular_two_level_cycle_against_oracle(smoother):
+    rng = np.random.default_rng(31)
+    A0, R0 = irregular_problem(rng)
+    assert np.diff(A0.indptr).max() > 2048                       # long-row path is exercised
+    A1 = _hip.rap(R0, A0)
+    np.testing.assert_allclose(A1.toarray(), (R0 @ A0 @ R0.T).toarray(), rtol=1e-12, atol=1e-13)
+    A, R = [A0, A1], [R0]
+    b = rng.standard_normal(A0.shape[0])
+    p = {"preIterations": 2, "postIterations": 1, "coarsestLevel": 1, "smoother": smoother, "omega": 0.6}
+    sm = orc.make_smoother(smoother, A, omega=0.6)
+    x, xo = None, None
+    for _ in range(3):
+        x, info = openmg_amd.mgCycle(A, b, 0, R, p, initial=x)
+        xo, inf = orc.mg_cycle(A, b, 0, R, p, initial=xo, smoother=sm)
+        assert rel(info["norm"], inf["norm"]) < 1e-9
+    np.testing.assert_allclose(x, xo, rtol=1e-8, atol=1e-11)
+    openmg_amd.clear_cache()
+
+
+def test_omg_solve_entry_point_and_mgcycle_cache():
+    """omg_solve (the C loop of mgSolve) and the device-hierarchy cache of repeated mgCycle calls."""
+    shape = (16, 16, 16)
+    A0 = operators.stencil_poisson(shape)
+    b = A0 @ np.random.default_rng(2).random(4096)
+    R = operators.restrictionList(shape, 1, 8)
+    A = operators.coeffecientList(A0, R)
+    with _hip.Hierarchy(A, R, smoother="gs") as h:
+        x = np.zeros(4096)
+        cycles, norm = h.solve(b, x, 1, 1, 0, 1e-3)               # threshold stop
+        assert norm < 1e-3 and cycles > 1
+        x2 = np.zeros(4096)
+        c2, n2 = h.solve(b, x2, 1, 1, cycles, 0.0)                # cycle-count stop, same work
+        assert c2 == cycles and n2 == norm and np.array_equal(x, x2)
+        with pytest.raises(_hip.HipError):
+            h.solve(b, x2, 1, 1, 0, 0.0)                          # both stop rules off
+    p = {"preIterations": 1, "postIterations": 1, "coarsestLevel": 2}
+    u = None
+    for _ in range(cycles):
+        u, info = openmg_amd.mg_cycle(A, b, 0, R, p, initial=u)
+    assert len(openmg_amd._cache) == 1                            # one upload for all calls
+    np.testing.assert_allclose(u, x, rtol=1e-12, atol=1e-14)
+    assert rel(info["norm"], norm) < 1e-12
+    # entering below the top: mgCycle(A, b_c, 1, R, ...) works on the sub-hierarchy
+    bc = np.random.default_rng(4).random(A[1].shape[0])
+    uc, ic = openmg_amd.mgCycle(A, bc, 1, R, p)
+    po = dict(p)
+    want, iw = orc.mg_cycle(A, bc, 1, R, po)
+    np.testing.assert_allclose(uc, want, rtol=1e-10, atol=1e-12)
+    assert rel(ic["norm"], iw["norm"]) < 1e-9
+    top, it = openmg_amd.mgCycle(A, np.ones(A[2].shape[0]), 2, R, p)   # at the coarsest: direct solve, norm 0
+    assert it["norm"] == 0
+    np.testing.assert_allclose(A[2] @ top, np.ones(A[2].shape[0]), rtol=1e-10)
+    openmg_amd.clear_cache()
