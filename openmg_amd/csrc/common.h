@@ -88,6 +88,8 @@ struct Ordering {
 
 // setup_host.cpp
 void validate_csr(const omg_csr &A, const char *what);
+// Smallest row whose stored diagonal entries are missing or sum to zero; -1 if none.
+int64_t first_row_without_diagonal(const omg_csr &A);
 Ordering make_ordering(const omg_csr &A, int smoother);
 // col_inv relabels only columns < n_inv (n_inv < 0: all of them); a distributed level keeps
 // its halo columns (>= number of owned rows) where they are.

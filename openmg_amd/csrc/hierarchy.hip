@@ -5,6 +5,7 @@
 #include <cstring>
 #include <memory>
 #include <mutex>
+#include <thread>
 
 #include "common.h"
 
@@ -88,15 +89,10 @@ namespace {
 using H = omg_hierarchy;
 
 void check_diagonal(const omg_csr &A, int level) {
-    for (int64_t i = 0; i < A.n_rows; ++i) {
-        double d = 0.0;
-        bool have = false;
-        for (int32_t p = A.indptr[i]; p < A.indptr[i + 1]; ++p)
-            if (A.indices[p] == i) { d += A.data[p]; have = true; }
-        if (!have || d == 0.0)
-            throw Error(OMG_ERR_NO_DIAGONAL, "level " + std::to_string(level) + ": row " +
-                                                 std::to_string(i) + " has no nonzero diagonal entry");
-    }
+    const int64_t bad = first_row_without_diagonal(A);
+    if (bad >= 0)
+        throw Error(OMG_ERR_NO_DIAGONAL, "level " + std::to_string(level) + ": row " +
+                                             std::to_string(bad) + " has no nonzero diagonal entry");
 }
 
 omg_csr view(const HostCsr &A) {
@@ -364,17 +360,49 @@ std::unique_ptr<H> create(int n_levels, const omg_csr *A, const omg_csr *R, int 
     h->stream = h->own;
     h->lv.resize(n_levels);
     h->norm_dev.alloc(1);
+    // The coarsest operator is inverted once (reference: SuperLU factorisation on every
+    // cycle).  That is ~16k tiny dependent launches, so it runs on a helper thread with its
+    // own stream while this thread does the index work of the smoothed levels.
+    int device = 0;
+    OMG_HIP(hipGetDevice(&device));
+    {
+        Level &L = h->lv.back();
+        L.n = A[n_levels - 1].n_rows;
+        L.ord.identity = true;
+        L.ord.sets = {0, L.n};
+    }
+    int inv_code = OMG_OK;
+    std::string inv_msg;
+    std::thread inverter([&] {
+        hipStream_t s = nullptr;
+        try {
+            OMG_HIP(hipSetDevice(device));
+            OMG_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+            Level &L = h->lv.back();
+            HostCsr Ap = permute_csr(A[n_levels - 1], nullptr, nullptr);
+            L.A.upload(Ap, L.ord.sets, s);
+            h->coarse_inv.alloc(std::max<size_t>(size_t(L.n) * size_t(L.n), 1));
+            dense_inverse_from_csr(L.A, h->coarse_inv.p, s);
+        } catch (const Error &e) {
+            inv_code = e.code;
+            inv_msg = e.what();
+        } catch (const std::exception &e) {
+            inv_code = OMG_ERR_HIP;
+            inv_msg = e.what();
+        }
+        if (s) { (void)hipStreamSynchronize(s); (void)hipStreamDestroy(s); }
+    });
+    struct Joiner { std::thread &t; ~Joiner() { if (t.joinable()) t.join(); } } joiner{inverter};
     // orderings first (restrictions need both neighbours')
-    for (int l = 0; l < n_levels; ++l) {
+    for (int l = 0; l + 1 < n_levels; ++l) {
         Level &L = h->lv[l];
         L.n = A[l].n_rows;
-        if (l + 1 < n_levels) L.ord = make_ordering(A[l], smoother);
-        else { L.ord.identity = true; L.ord.sets = {0, L.n}; }     // coarsest: direct solve
+        L.ord = make_ordering(A[l], smoother);
     }
     for (int l = 0; l < n_levels; ++l) {
         Level &L = h->lv[l];
         const bool id = L.ord.identity;
-        {
+        if (l + 1 < n_levels) {
             HostCsr Ap = permute_csr(A[l], id ? nullptr : L.ord.perm.data(), id ? nullptr : L.ord.inv.data());
             L.A.upload(Ap, L.ord.sets, h->stream);
         }
@@ -399,12 +427,8 @@ std::unique_ptr<H> create(int n_levels, const omg_csr *A, const omg_csr *R, int 
         L.xp = L.x.p;
         L.tp = L.tmp.p;
     }
-    // coarsest level: invert once (reference: SuperLU factorisation on every cycle)
-    {
-        Level &L = h->lv.back();
-        h->coarse_inv.alloc(std::max<size_t>(size_t(L.n) * size_t(L.n), 1));
-        dense_inverse_from_csr(L.A, h->coarse_inv.p, h->stream);
-    }
+    inverter.join();
+    if (inv_code != OMG_OK) throw Error(inv_code, inv_msg);
     OMG_HIP(hipStreamSynchronize(h->stream));
     return h;
 }

@@ -1,6 +1,7 @@
 // Host-side setup: smoother orderings, symmetric permutation of CSR matrices, transpose,
 // row-block partition.  Index work only — no floating-point arithmetic happens here.
 #include <algorithm>
+#include <atomic>
 #include <cstring>
 #include <thread>
 
@@ -48,6 +49,25 @@ void validate_csr(const omg_csr &A, const char *what) {
         }
     });
     OMG_REQUIRE(ok, w + ": malformed CSR (indptr not monotone or column out of range)");
+}
+
+int64_t first_row_without_diagonal(const omg_csr &A) {
+    std::atomic<int64_t> bad(INT64_MAX);
+    parallel_rows(A.n_rows, [&](int64_t lo, int64_t hi) {
+        for (int64_t i = lo; i < hi; ++i) {
+            double d = 0.0;
+            bool have = false;
+            for (int32_t p = A.indptr[i]; p < A.indptr[i + 1]; ++p)
+                if (A.indices[p] == i) { d += A.data[p]; have = true; }
+            if (!have || d == 0.0) {
+                int64_t cur = bad.load();
+                while (i < cur && !bad.compare_exchange_weak(cur, i)) {}
+                return;
+            }
+        }
+    });
+    const int64_t v = bad.load();
+    return v == INT64_MAX ? -1 : v;
 }
 
 // ---- orderings ------------------------------------------------------------------------
