@@ -171,10 +171,27 @@ def main():
             traffic, traffic_src = pmc["traffic_bytes"], pmc["source"]
     except (OSError, KeyError, ValueError):
         pass
+    # Per-class table of the level-0 launches (second region): average time and algorithmic
+    # bytes of ONE launch -> GB/s.  Smoother launches are per set; with the fused last set two
+    # of the 2*n_sets launches per cycle also write the residual (8 B per covered row more).
+    n_c = meta["level_rows"][1] if len(meta["level_rows"]) > 1 else 0
+    set_rows = [h.set_info(0, s)[0] for s in range(n_sets)]
+    set_nnz = [h.set_info(0, s)[1] for s in range(n_sets)]
+    avg_set_bytes = sum(12 * z + 4 * (r + 1) + 24 * r for r, z in zip(set_rows, set_nnz)) / max(n_sets, 1) + 8 * n / max(n_sets, 1)
+    class_bytes = {
+        "smoother_set_sweep": avg_set_bytes,
+        "residual": res_bytes,
+        "restrict": 12 * n + 4 * (n_c + 1) + 8 * n + 16 * n_c,            # R entries, indptr, r read, b_c + cleared x_c written
+        "prolong_add": 12 * n + 4 * (n + 1) + 8 * n_c + 16 * n,           # P entries, indptr, e read, x read + written
+        "residual_norm": res_bytes - 8 * rows_c,                          # as the residual launch, nothing stored
+    }
     kernels = {}
     for name, (cnt, tot) in prof.items():
         if cnt:
-            kernels[name] = {"launches_per_cycle": cnt / args.steps, "avg_us": 1e3 * tot / cnt}
+            us = 1e3 * tot / cnt
+            kernels[name] = {"launches_per_cycle": cnt / args.steps, "avg_us": round(us, 2),
+                             "algorithmic_bytes": int(class_bytes[name]),
+                             "GBps": round(class_bytes[name] / us / 1e3, 1)}
     roofline = {"bound": "hbm", "kernel": "rows_kernel<ROW_RESIDUAL> (fine grid r = b - A x)",
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
