@@ -198,7 +198,9 @@ std::unique_ptr<D> create(int rank, int n_ranks, int n_levels, const omg_dist_le
             HostCsr Rp = permute_csr(in.R, C.ord.identity ? nullptr : C.ord.perm.data(), id ? nullptr : L.ord.inv.data());
             HostCsr Pt = transpose_csr(Rp);
             L.R.upload(Rp, {}, d->stream);
-            L.P.upload(Pt, {}, d->stream);
+            // prolongation rows carry the fine level's sets: with (boundary, interior) pairs the
+            // boundary rows are corrected first and travel while the interior ones are corrected
+            L.P.upload(Pt, L.ord.sets, d->stream);
             L.r.alloc(std::max<int64_t>(L.n_loc, 1));
             if (smoother == OMG_SMOOTH_JACOBI) L.tmp.alloc(std::max<int64_t>(L.n_loc + L.n_halo, 1));
             L.partials.alloc(L.A.n_blocks() + SUM_FOLD);
@@ -270,29 +272,33 @@ struct Runner {
     // bubble (measured: 25 of them slowed a one-rank 256^3 cycle from 1.53 to 1.80 ms), so
     // small levels, single-rank runs and loopback groups keep everything on one stream.
     static int64_t overlap_min_rows() {
-        static int64_t v = -1;
-        if (v < 0) {
-            const char *e = getenv("OMG_OVERLAP_MIN_ROWS");
-            v = e ? atoll(e) : (int64_t(1) << 19);
-        }
-        return v;
+        const char *e = getenv("OMG_OVERLAP_MIN_ROWS");
+        return e ? atoll(e) : (int64_t(1) << 19);
+    }
+    // OMG_FORCE_OVERLAP=1 (tests): take the two-stream schedule in a loopback group too, so
+    // that its ordering is exercised on one GPU; all loopback ranks then share rank 0's
+    // comm stream the way they share its compute stream.
+    static bool force_overlap() {
+        const char *e = getenv("OMG_FORCE_OVERLAP");
+        return e && e[0] == '1';
     }
     bool on_comm_stream(int l) const {
-        if (!rccl) return false;
+        if (!rccl && !force_overlap()) return false;
         const DLevel &L = rs[0]->lv[l];
         return L.set_group == 2 && !L.peers.empty() && L.n_loc >= overlap_min_rows();
     }
-    hipStream_t cs(D *d, int l) const { return on_comm_stream(l) ? d->cstream : d->stream; }
+    hipStream_t comm_stream_of(D *d) const { return rccl ? d->cstream : rs[0]->cstream; }
+    hipStream_t cs(D *d, int l) const { return on_comm_stream(l) ? comm_stream_of(d) : d->stream; }
     // comm stream waits for everything enqueued so far on the compute stream ...
     void comm_begin(D *d, int l) {
         if (!on_comm_stream(l)) return;
         OMG_HIP(hipEventRecord(d->ev_go, d->stream));
-        OMG_HIP(hipStreamWaitEvent(d->cstream, d->ev_go, 0));
+        OMG_HIP(hipStreamWaitEvent(comm_stream_of(d), d->ev_go, 0));
     }
     // ... and the compute stream waits for the communication enqueued since.
     void comm_end(D *d, int l) {
         if (!on_comm_stream(l)) return;
-        OMG_HIP(hipEventRecord(d->ev_done, d->cstream));
+        OMG_HIP(hipEventRecord(d->ev_done, comm_stream_of(d)));
         OMG_HIP(hipStreamWaitEvent(d->stream, d->ev_done, 0));
     }
 
@@ -342,7 +348,7 @@ struct Runner {
                     const int64_t nr = L.recv_off[k + 1] - L.recv_off[k];
                     OMG_REQUIRE(nr == PL.send_off[j + 1] - PL.send_off[j], "send/recv counts differ");
                     if (nr) OMG_HIP(hipMemcpyAsync(L.xp + L.n_loc + L.recv_off[k], PL.send_buf.p + PL.send_off[j],
-                                                   nr * sizeof(double), hipMemcpyDeviceToDevice, d->stream));
+                                                   nr * sizeof(double), hipMemcpyDeviceToDevice, cs(d, l)));
                 }
             }
         }
@@ -461,14 +467,26 @@ struct Runner {
                 OMG_HIP(hipMemsetAsync(C.xp + C.n_loc, 0, C.n_halo * sizeof(double), d->stream));
         }
         cycle(l + 1, pre, post);
-        for (D *d : rs) {
-            DLevel &L = d->lv[l];
-            DLevel &C = d->lv[l + 1];
-            RowArgs a;
-            a.x = C.xp; a.y = L.xp;
-            launch_rows(L.P, ROW_AXPY, -1, a, d->stream);
+        // x_l += R^T x_{l+1} (:214, :220/:224), then everybody needs the corrected boundary values
+        auto prolong_sets = [&](int first, int step) {
+            for (D *d : rs) {
+                DLevel &L = d->lv[l];
+                DLevel &C = d->lv[l + 1];
+                RowArgs a;
+                a.x = C.xp; a.y = L.xp;
+                if (step == 0) { launch_rows(L.P, ROW_AXPY, -1, a, d->stream); continue; }
+                for (int s = first; s < (int)L.P.n_sets(); s += step) launch_rows(L.P, ROW_AXPY, s, a, d->stream);
+            }
+        };
+        if (on_comm_stream(l)) {
+            prolong_sets(0, 2);          // boundary rows of every colour
+            exchange_start(l);
+            prolong_sets(1, 2);          // interior rows, beside the exchange
+            exchange_finish(l);
+        } else {
+            prolong_sets(0, 0);
+            exchange(l);
         }
-        exchange(l);
         if (post > 0) return smooth(l, post, want_norm ? 2 : 0);
         return false;
     }

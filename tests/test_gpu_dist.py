@@ -150,3 +150,19 @@ def test_boundary_first_sets_do_not_change_the_iterate():
             group.close()
     assert np.array_equal(out[0][0], x1) and np.array_equal(out[1][0], x1)
     np.testing.assert_allclose(out[0][1], n1, rtol=1e-13)
+
+
+def test_two_stream_overlap_schedule_on_one_gpu(monkeypatch):
+    """OMG_FORCE_OVERLAP=1 makes the loopback group run the schedule the RCCL path uses on
+    large levels: boundary rows relaxed / corrected first, their exchange on a second stream
+    beside the interior launch, events between the streams.  Repeated to give a race a chance;
+    the iterate must stay bit-identical to one GPU."""
+    monkeypatch.setenv("OMG_FORCE_OVERLAP", "1")
+    monkeypatch.setenv("OMG_OVERLAP_MIN_ROWS", "0")
+    shape, grids, n_ranks = (64, 64, 64), 4, 4
+    b = operators.stencil_poisson(shape) @ np.random.default_rng(8).random(64 ** 3)
+    x1, n1 = single_gpu(shape, grids, "colour", b, 4)
+    for _ in range(3):
+        xd, nd = loopback(shape, grids, n_ranks, "colour", b, 4)
+        assert np.array_equal(xd, x1)
+        np.testing.assert_allclose(nd, n1, rtol=1e-13)
