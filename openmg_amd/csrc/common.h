@@ -122,6 +122,7 @@ struct DevCsr {
     std::vector<int64_t> sets;         // row offsets of the sets (host)
     int rows_cap = ROWBLK_ROWS;        // most rows a block may hold (> ROWBLK_THREADS: short rows)
     std::vector<int64_t> set_nnz;      // stored entries of each set (host)
+    int lanes_per_row = 1;             // 4 for operators with long rows (avg > 16 entries)
     void upload(const HostCsr &A, const std::vector<int64_t> &sets, hipStream_t s);
     size_t n_sets() const { return sets.empty() ? 0 : sets.size() - 1; }
     int64_t n_blocks() const { return set_blk.empty() ? 0 : set_blk.back(); }

@@ -122,7 +122,7 @@ __device__ __forceinline__ void row_epilogue(const KArgs &a, int r, const RowPre
 // SHORT selects the phase-2 variant for operators whose rows are so short (prolongation:
 // one entry per row) that a block holds several rows per thread: the rows of a thread are
 // then processed eight at a time with all their loads in flight together.
-template <int MODE, bool nt, bool SHORT>
+template <int MODE, bool nt, bool SHORT, int LPR>
 __device__ void process_block(const KArgs &a, int blk, double *s_val, int *s_idx, double *s_red) {
     constexpr bool FUSED = (MODE == ROW_GS_RES || MODE == ROW_GS_NORM);
     constexpr bool NEED_DIAG = (MODE == ROW_GS || MODE == ROW_JACOBI || FUSED);
@@ -136,7 +136,7 @@ __device__ void process_block(const KArgs &a, int blk, double *s_val, int *s_idx
     double sq = 0.0;
 
     if (p1 - p0 <= T) {
-        int r = r0 + tid;
+        int r = r0 + tid / LPR;
         RowPre pre;
         if (!SHORT && r < r1) pre = row_preload<MODE>(a, r);
         // ---- phase 1: stream the block's entries into LDS, 16 B per lane per load ------
@@ -197,15 +197,29 @@ __device__ void process_block(const KArgs &a, int blk, double *s_val, int *s_idx
                 }
             }
         } else {
+            // LPR lanes share a row (LPR = 1: one thread per row, strictly stored order).  With
+            // LPR = 4 — operators with long rows, e.g. 27-point stencils, where one thread per
+            // row would leave most of the workgroup idle — lane q of a row's quad takes entries
+            // q, q+4, q+8, ... in stored order and the four partial sums are added in lane
+            // order: a fixed, run-to-run reproducible association, the same in every mode.
+            const int sub = tid % LPR;
+            const int lane0 = (threadIdx.x & 63) & ~(LPR - 1);     // first lane of the quad
+            auto quad_sum = [&](double p) {
+                if constexpr (LPR == 1) return p;
+                double t = __shfl(p, lane0, 64);
+#pragma unroll
+                for (int q = 1; q < LPR; ++q) t += __shfl(p, lane0 + q, 64);
+                return t;
+            };
             while (r < r1) {
                 const int beg = pre.beg - base, end = pre.end - base;
                 double sum = 0.0, diag = 0.0;
                 int c[8];
                 double v[8], xv[8];
-                for (int k = beg; k < end; k += 8) {
+                for (int k = beg + sub; k < end; k += 8 * LPR) {
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
-                        const int kk = min(k + j, end - 1);
+                        const int kk = min(k + j * LPR, end - 1);
                         const int s = slot(kk);
                         c[j] = s_idx[s];
                         v[j] = s_val[s];
@@ -214,36 +228,47 @@ __device__ void process_block(const KArgs &a, int blk, double *s_val, int *s_idx
                     for (int j = 0; j < 8; ++j) xv[j] = a.x[c[j]];
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
-                        if (k + j < end) {
+                        if (k + j * LPR < end) {
                             sum = madd(v[j], xv[j], sum);
                             if (NEED_DIAG && c[j] == r) diag += v[j];
                         }
                     }
                 }
+                sum = quad_sum(sum);
+                if constexpr (NEED_DIAG) diag = quad_sum(diag);
                 if constexpr (FUSED) {
                     // relax the row, then its residual with the NEW x_i: same entries, same
                     // order, same fma chain as ROW_RESIDUAL would run on the updated vector
                     const double xnew = pre.xv + (pre.bv - sum) / diag;
                     double sum2 = 0.0;
-                    if (end - beg <= 8) {            // the row's entries are still in registers
+                    if (end - beg <= 8 * LPR) {      // the row's entries are still in registers
 #pragma unroll
                         for (int j = 0; j < 8; ++j)
-                            if (beg + j < end) sum2 = madd(v[j], c[j] == r ? xnew : xv[j], sum2);
+                            if (beg + sub + j * LPR < end) sum2 = madd(v[j], c[j] == r ? xnew : xv[j], sum2);
                     } else {
-                        for (int k = beg; k < end; ++k) {
-                            const int s = slot(k);
-                            const int cc = s_idx[s];
-                            sum2 = madd(s_val[s], cc == r ? xnew : a.x[cc], sum2);
+                        for (int k = beg + sub; k < end; k += 8 * LPR) {
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) {
+                                const int kk = k + j * LPR;
+                                if (kk < end) {
+                                    const int s = slot(kk);
+                                    const int cc = s_idx[s];
+                                    sum2 = madd(s_val[s], cc == r ? xnew : a.x[cc], sum2);
+                                }
+                            }
                         }
                     }
-                    a.y[r] = xnew;
+                    sum2 = quad_sum(sum2);
                     const double res = pre.bv - sum2;
-                    if constexpr (MODE == ROW_GS_RES) a.zero[r] = res;
-                    else sq += res * res;
-                } else {
+                    if (sub == 0) {
+                        a.y[r] = xnew;
+                        if constexpr (MODE == ROW_GS_RES) a.zero[r] = res;
+                        else sq += res * res;
+                    }
+                } else if (sub == 0) {
                     row_epilogue<MODE>(a, r, pre, sum, diag, sq);
                 }
-                r += NT;
+                r += NT / LPR;
                 if (r < r1) pre = row_preload<MODE>(a, r);
             }
         }
@@ -301,13 +326,29 @@ __device__ __forceinline__ int xcd_remap(int b, int n) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
 
-template <int MODE, bool NTL, bool SHORT>
-__global__ __launch_bounds__(NT) void rows_kernel(KArgs a, int blk0, int remap) {
+// Grouped variant: inside every window of 8*G consecutive row blocks, XCD k (workgroups with
+// id % 8 == k) takes the k-th run of G consecutive blocks, so neighbouring blocks — whose x
+// windows overlap by the stencil's in-plane reach — share an L2, while all eight XCDs still
+// stream from one 8*G-block region of the matrix.  The ragged tail keeps the identity map.
+__device__ __forceinline__ int xcd_remap_grouped(int b, int n, int G) {
+    const int span = 8 * G;
+    const int base = (b / span) * span;
+    if (base + span > n) return b;
+    const int r = b - base;
+    return base + (r & 7) * G + (r >> 3);
+}
+
+template <int MODE, bool NTL, bool SHORT, int LPR>
+// (NT, 6): six workgroups per CU is what the 25 KB LDS image allows; keep every variant within
+// 80 VGPRs so that registers do not cut that to five (the fused sweeps wanted 82-94).
+__global__ __launch_bounds__(NT, 6) void rows_kernel(KArgs a, int blk0, int remap) {
     __shared__ double s_val[LDS_SLOTS];
     __shared__ int s_idx[LDS_SLOTS];
     __shared__ double s_red[NT / 64];
-    const int local = remap ? xcd_remap(blockIdx.x, gridDim.x) : int(blockIdx.x);
-    process_block<MODE, NTL, SHORT>(a, blk0 + local, s_val, s_idx, s_red);
+    const int local = remap == 0 ? int(blockIdx.x)
+                    : remap == 1 ? xcd_remap(blockIdx.x, gridDim.x)
+                                 : xcd_remap_grouped(blockIdx.x, gridDim.x, remap);
+    process_block<MODE, NTL, SHORT, LPR>(a, blk0 + local, s_val, s_idx, s_red);
 }
 
 // A run of consecutive tiny sets (one row block each), executed back to back by ONE
@@ -321,7 +362,7 @@ __global__ __launch_bounds__(NT) void rows_serial_kernel(KArgs a, int blk_begin,
     __shared__ int s_idx[LDS_SLOTS];
     __shared__ double s_red[NT / 64];
     for (int blk = blk_begin; blk < blk_end; ++blk) {
-        process_block<MODE, false, false>(a, blk, s_val, s_idx, s_red);
+        process_block<MODE, false, false, 1>(a, blk, s_val, s_idx, s_red);
         __threadfence_block();
         __syncthreads();
     }
@@ -344,7 +385,8 @@ template <int MODE>
 void launch_mode(const DevCsr &A, int64_t blk0, int64_t nblk, const KArgs &k, hipStream_t s) {
     if (nblk <= 0) return;
     const int flags = launch_flags();
-    const int remap = (nblk >= 64) ? (flags & 1) : 0;
+    static const int group = [] { const char *e = getenv("OMG_XCD_GROUP"); return e ? atoi(e) : 0; }();
+    const int remap = (nblk < 64) ? 0 : (group > 1 ? group : (flags & 1));
     // small operators live in L2 / Infinity Cache across cycles: keep them cacheable
     const bool ntl = (flags & 2) && A.nnz * 12 > (int64_t(192) << 20);
     // several rows per thread (short rows): batched variant, built for the modes such
@@ -353,14 +395,20 @@ void launch_mode(const DevCsr &A, int64_t blk0, int64_t nblk, const KArgs &k, hi
     const dim3 grid((unsigned)nblk), block(NT);
     if constexpr (HAS_SHORT) {
         if (A.rows_cap > NT) {
-            if (ntl) hipLaunchKernelGGL((rows_kernel<MODE, true, true>), grid, block, 0, s, k, (int)blk0, remap);
-            else hipLaunchKernelGGL((rows_kernel<MODE, false, true>), grid, block, 0, s, k, (int)blk0, remap);
+            if (ntl) hipLaunchKernelGGL((rows_kernel<MODE, true, true, 1>), grid, block, 0, s, k, (int)blk0, remap);
+            else hipLaunchKernelGGL((rows_kernel<MODE, false, true, 1>), grid, block, 0, s, k, (int)blk0, remap);
             OMG_HIP(hipGetLastError());
             return;
         }
     }
-    if (ntl) hipLaunchKernelGGL((rows_kernel<MODE, true, false>), grid, block, 0, s, k, (int)blk0, remap);
-    else hipLaunchKernelGGL((rows_kernel<MODE, false, false>), grid, block, 0, s, k, (int)blk0, remap);
+    if (A.lanes_per_row == 4) {       // long rows: four lanes per row
+        if (ntl) hipLaunchKernelGGL((rows_kernel<MODE, true, false, 4>), grid, block, 0, s, k, (int)blk0, remap);
+        else hipLaunchKernelGGL((rows_kernel<MODE, false, false, 4>), grid, block, 0, s, k, (int)blk0, remap);
+        OMG_HIP(hipGetLastError());
+        return;
+    }
+    if (ntl) hipLaunchKernelGGL((rows_kernel<MODE, true, false, 1>), grid, block, 0, s, k, (int)blk0, remap);
+    else hipLaunchKernelGGL((rows_kernel<MODE, false, false, 1>), grid, block, 0, s, k, (int)blk0, remap);
     OMG_HIP(hipGetLastError());
 }
 

@@ -254,6 +254,13 @@ void DevCsr::upload(const HostCsr &A, const std::vector<int64_t> &sets_in, hipSt
     if (n_rows > 0) {
         const double avg = double(nnz) / double(n_rows);
         while (max_rows < ROWBLK_NNZ && avg * (2 * max_rows) <= ROWBLK_NNZ) max_rows *= 2;
+        // long rows (27-point stencils ...): one thread per row would leave most of the
+        // workgroup idle in the row phase, so four lanes share a row and a block holds at
+        // most ROWBLK_THREADS / 4 rows per pass
+        const char *e = getenv("OMG_LANES_PER_ROW");
+        lanes_per_row = e ? atoi(e) : (avg > 16.0 ? 4 : 1);
+        if (lanes_per_row != 4) lanes_per_row = 1;
+        if (lanes_per_row == 4) max_rows = ROWBLK_THREADS / 4;
     }
     rows_cap = max_rows;
     set_nnz.assign(sets.size() - 1, 0);
