@@ -154,6 +154,7 @@ struct RowArgs {
     double omega = 1.0;
     double *partials = nullptr;  // one double per row block (RESNORM / NORM_ONLY)
     double *zero = nullptr;      // ROW_SPMV: zero[r] = 0 alongside y[r] (fused clear);
+    const int32_t *ymap = nullptr;   // ROW_SPMV: result of row r goes to y[ymap[r]]
                                  // ROW_GS_RES: residual of the relaxed rows goes here
 };
 

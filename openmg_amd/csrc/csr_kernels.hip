@@ -44,6 +44,7 @@ struct KArgs {
     double *y;
     double *partials;
     double *zero;              // SpMV only: also clear zero[r] (next level's initial iterate)
+    const int32_t *ymap;       // SpMV only: row r is stored to y[ymap[r]] (NULL: y[r])
     double omega;
 };
 
@@ -73,6 +74,7 @@ __device__ __forceinline__ double block_sum(double v, double *s_red) {
 // third dependent memory round trip behind the workgroup barrier.
 struct RowPre {
     int beg, end;     // CSR extent of the row (absolute entry offsets)
+    int out;          // SpMV: where the result goes (ymap)
     double bv, xv;    // b[r]; x[r] (GS, Jacobi) or y[r] (y += A x)
 };
 
@@ -87,6 +89,8 @@ __device__ __forceinline__ RowPre row_preload(const KArgs &a, int r) {
     if constexpr (MODE == ROW_GS || MODE == ROW_JACOBI || MODE == ROW_GS_RES || MODE == ROW_GS_NORM)
         p.xv = a.x[r];
     if constexpr (MODE == ROW_AXPY) p.xv = a.y[r];
+    p.out = r;
+    if constexpr (MODE == ROW_SPMV) { if (a.ymap) p.out = a.ymap[r]; }
     return p;
 }
 
@@ -98,7 +102,7 @@ template <int MODE>
 __device__ __forceinline__ void row_epilogue(const KArgs &a, int r, const RowPre &p, double sum,
                                              double diag, double &sq) {
     if constexpr (MODE == ROW_SPMV) {
-        a.y[r] = sum;
+        a.y[p.out] = sum;
         if (a.zero) a.zero[r] = 0.0;
     } else if constexpr (MODE == ROW_RESIDUAL) {
         a.y[r] = p.bv - sum;
@@ -431,6 +435,7 @@ void launch_rows_range(const DevCsr &A, int mode, int set_begin, int set_end, co
     k.y = args.y;
     k.partials = args.partials;
     k.zero = args.zero;
+    k.ymap = args.ymap;
     k.omega = args.omega;
     OMG_REQUIRE(set_begin >= 0 && set_begin <= set_end && size_t(set_end) <= A.n_sets(),
                 "launch_rows: set range out of bounds");
@@ -462,6 +467,7 @@ void launch_gs_serial(const DevCsr &A, int set_begin, int set_end, const RowArgs
     k.y = args.y;
     k.partials = nullptr;
     k.zero = nullptr;
+    k.ymap = nullptr;
     k.omega = args.omega;
     const int b0 = (int)A.set_blk[set_begin], b1 = (int)A.set_blk[set_end];
     if (b1 <= b0) return;

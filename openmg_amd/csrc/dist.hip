@@ -82,6 +82,7 @@ struct DLevel {
     DevCsr A, R, P;
     Ordering ord;
     DevBuf<int32_t> perm;
+    DevBuf<int32_t> r_out;                     // restriction row -> slot in the next level's ordering
     DevBuf<double> x, tmp, b, r, partials, nat;
     double *xp = nullptr, *tp = nullptr;
     // halo plan
@@ -197,7 +198,16 @@ std::unique_ptr<D> create(int rank, int n_ranks, int n_levels, const omg_dist_le
                         "R[l] must be (coarse owned rows) x (fine owned rows): slabs must be cut on aggregate boundaries");
             HostCsr Rp = permute_csr(in.R, C.ord.identity ? nullptr : C.ord.perm.data(), id ? nullptr : L.ord.inv.data());
             HostCsr Pt = transpose_csr(Rp);
-            L.R.upload(Rp, {}, d->stream);
+            if (C.ord.identity) {
+                L.R.upload(Rp, {}, d->stream);
+            } else {
+                // rows in natural coarse order + output map: dense gathers (see hierarchy.hip)
+                HostCsr Rn = permute_csr(in.R, nullptr, id ? nullptr : L.ord.inv.data());
+                L.R.upload(Rn, {}, d->stream);
+                L.r_out.alloc(C.ord.inv.size());
+                L.r_out.upload(C.ord.inv.data(), C.ord.inv.size(), d->stream);
+                OMG_HIP(hipStreamSynchronize(d->stream));
+            }
             // prolongation rows carry the fine level's sets: with (boundary, interior) pairs the
             // boundary rows are corrected first and travel while the interior ones are corrected
             L.P.upload(Pt, L.ord.sets, d->stream);
@@ -461,7 +471,7 @@ struct Runner {
             const int ns = (int)L.A.n_sets();
             launch_rows_range(L.A, ROW_RESIDUAL, 0, res_done ? ns - L.set_group : ns, a, d->stream);
             RowArgs q;
-            q.x = L.r.p; q.y = C.b.p; q.zero = (l + 1 < last) ? C.xp : nullptr;
+            q.x = L.r.p; q.y = C.b.p; q.zero = (l + 1 < last) ? C.xp : nullptr; q.ymap = L.r_out.p;
             launch_rows(L.R, ROW_SPMV, -1, q, d->stream);
             if (l + 1 < last && C.n_halo)
                 OMG_HIP(hipMemsetAsync(C.xp + C.n_loc, 0, C.n_halo * sizeof(double), d->stream));

@@ -37,6 +37,7 @@ struct Level {
     DevCsr P;                 // R^T: rows in this ordering, columns in next ordering
     Ordering ord;
     DevBuf<int32_t> perm;     // new -> old (empty when identity)
+    DevBuf<int32_t> r_out;    // restriction row (natural coarse numbering) -> slot in the next level's ordering
     DevBuf<double> x, b, r, tmp;
     DevBuf<double> partials;
     DevBuf<double> nat;       // natural-order staging for host I/O at this level
@@ -217,7 +218,7 @@ void restrict_level(H *h, int l, const double *fine, double *coarse, double *cle
     Level &L = h->lv[l];
     Prof p(h, l, 2);
     RowArgs a;
-    a.x = fine; a.y = coarse; a.zero = clear;
+    a.x = fine; a.y = coarse; a.zero = clear; a.ymap = L.r_out.p;
     launch_rows(L.R, ROW_SPMV, -1, a, h->stream);
 }
 
@@ -415,8 +416,22 @@ std::unique_ptr<H> create(int n_levels, const omg_csr *A, const omg_csr *R, int 
             const Ordering &co = h->lv[l + 1].ord;
             HostCsr Rp = permute_csr(R[l], co.identity ? nullptr : co.perm.data(), id ? nullptr : L.ord.inv.data());
             HostCsr Pt = transpose_csr(Rp);
-            L.R.upload(Rp, {}, h->stream);
             L.P.upload(Pt, {}, h->stream);
+            if (co.identity) {
+                L.R.upload(Rp, {}, h->stream);
+            } else {
+                // Restriction rows stay in NATURAL coarse order and write through a map into the
+                // coarse level's ordering: consecutive rows are then consecutive aggregates,
+                // whose fine unknowns are consecutive inside each colour segment (dense
+                // gathers).  In the coarse COLOUR order consecutive rows are every other
+                // aggregate and each gather used half of every cache line (measured: 480 MB
+                // read for 343 MB algorithmic).
+                HostCsr Rn = permute_csr(R[l], nullptr, id ? nullptr : L.ord.inv.data());
+                L.R.upload(Rn, {}, h->stream);
+                L.r_out.alloc(co.inv.size());
+                L.r_out.upload(co.inv.data(), co.inv.size(), h->stream);
+                OMG_HIP(hipStreamSynchronize(h->stream));
+            }
             L.r.alloc(L.n);
             if (smoother == OMG_SMOOTH_JACOBI) L.tmp.alloc(L.n);
             L.partials.alloc(L.A.n_blocks() + SUM_FOLD);
