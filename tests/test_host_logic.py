@@ -66,3 +66,12 @@ def test_as_csr_keeps_stored_order():
     assert out.indices.tolist() == [2, 0, 1] and out.indices.dtype == np.int32
     M64 = sp.csr_matrix((M.data, M.indices.astype(np.int64), M.indptr.astype(np.int64)), shape=(2, 3))
     assert _hip.as_csr(M64).indices.dtype == np.int32
+
+
+def test_drop_in_alias_package():
+    import openmg
+    import openmg.tools
+    from openmg import operators as ops
+    assert openmg.mgSolve is openmg_amd.mgSolve and openmg.mg_cycle is openmg_amd.mgCycle
+    assert ops is openmg_amd.operators and openmg.tools is openmg_amd.tools
+    assert openmg.defaults is openmg_amd.defaults
