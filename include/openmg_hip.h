@@ -204,6 +204,11 @@ typedef struct {
      * other ranks need first, the rest second; the halo exchange of a pair then runs on a
      * second stream while the interior rows are still being relaxed.                        */
     int32_t set_group;
+    /* Optional, one per (peer) entry: the smoother colour whose values the entry carries
+     * (peers[] then repeats a rank once per colour).  After relaxing colour c only entries of
+     * group c travel; the exchange after prolongation moves all of them.  NULL: every entry
+     * is sent every time.                                                                  */
+    const int32_t *entry_group;
 } omg_dist_level;
 
 typedef struct omg_dist omg_dist;

@@ -108,7 +108,7 @@ class DistLevelView(ctypes.Structure):
                 ("keys", ctypes.c_void_p), ("n_sets", ctypes.c_int32), ("n_peers", ctypes.c_int32),
                 ("peers", ctypes.c_void_p), ("send_off", ctypes.c_void_p),
                 ("send_idx", ctypes.c_void_p), ("recv_off", ctypes.c_void_p),
-                ("set_group", ctypes.c_int32)]
+                ("set_group", ctypes.c_int32), ("entry_group", ctypes.c_void_p)]
 
 _lib = None
 

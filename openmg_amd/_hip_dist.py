@@ -52,6 +52,13 @@ class DistRank:
             v.send_idx = send_idx.ctypes.data
             v.recv_off = recv_off.ctypes.data
             v.set_group = int(lv.get("set_group", 1))
+            groups = lv.get("groups")
+            if groups is not None:
+                groups = np.ascontiguousarray(groups, dtype=np.int32)
+                keep.append(groups)
+                v.entry_group = groups.ctypes.data
+            else:
+                v.entry_group = None
         G = None if coarse_global is None else as_csr(coarse_global)
         gv = None if G is None else csr_view(G)
         counts = (ctypes.c_int64 * self.n_ranks)(*[int(c) for c in coarse_counts])

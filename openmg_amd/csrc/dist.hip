@@ -91,6 +91,8 @@ struct DLevel {
     DevBuf<int32_t> send_idx;                  // rows (this level's ordering) to send, all peers
     DevBuf<double> send_buf;
     int set_group = 1;                         // 2: sets are (boundary, interior) pairs
+    std::vector<int> entry_group;              // per plan entry: colour it carries, -1 = any
+    std::vector<int64_t> send_start;           // per entry: first row in x if contiguous, else -1
 };
 
 __global__ void sqrt_kernel(double *v) { *v = sqrt(*v); }
@@ -236,6 +238,18 @@ std::unique_ptr<D> create(int rank, int n_ranks, int n_levels, const omg_dist_le
             OMG_REQUIRE(i >= 0 && i < L.n_loc, "send index out of range");
             idx[k] = id ? i : L.ord.inv[i];
         }
+        // Per entry: its message group, and where its rows start in x when they happen to be
+        // one ascending run of this level's ordering — a slab's first / last plane inside a
+        // colour is — so that it can be sent straight from x without a pack kernel.
+        L.entry_group.assign(in.n_peers, -1);
+        if (in.entry_group) L.entry_group.assign(in.entry_group, in.entry_group + in.n_peers);
+        L.send_start.assign(in.n_peers, -1);
+        for (int e = 0; e < in.n_peers; ++e) {
+            const int64_t a = L.send_off[e], b = L.send_off[e + 1];
+            bool run = b > a;
+            for (int64_t k = a + 1; k < b && run; ++k) run = idx[k] == idx[k - 1] + 1;
+            if (run) L.send_start[e] = idx[a];
+        }
         L.send_idx.alloc(std::max<int64_t>(n_send, 1));
         L.send_idx.upload(idx.data(), n_send, d->stream);
         L.send_buf.alloc(std::max<int64_t>(n_send, 1));
@@ -322,8 +336,10 @@ struct Runner {
     // transfer behind the work already on the compute stream; work enqueued on the compute
     // stream between start and finish overlaps it (it must not read halo entries nor write
     // rows that are being sent); exchange_finish makes the compute stream wait for it.
-    void exchange(int l) {
-        exchange_start(l);
+    // group >= 0: only the entries that carry that colour (after relaxing it nothing else has
+    // changed); group < 0: everything.
+    void exchange(int l, int group = -1) {
+        exchange_start(l, group);
         exchange_finish(l);
     }
 
@@ -331,9 +347,25 @@ struct Runner {
         for (D *d : rs) comm_end(d, l);
     }
 
-    void exchange_start(int l) {
+    static bool selected(const DLevel &L, size_t e, int group) {
+        return group < 0 || L.entry_group[e] < 0 || L.entry_group[e] == group;
+    }
+
+    // Where entry e of level L is sent from: straight out of x when its rows are one run of
+    // the ordering, the packed copy otherwise.
+    static const double *send_ptr(const DLevel &L, size_t e) {
+        return L.send_start[e] >= 0 ? L.xp + L.send_start[e] : L.send_buf.p + L.send_off[e];
+    }
+
+    void exchange_start(int l, int group = -1) {
         for (D *d : rs) comm_begin(d, l);
-        for (D *d : rs) pack(d, l);
+        for (D *d : rs) {                        // pack only what cannot be sent in place
+            DLevel &L = d->lv[l];
+            bool need = false;
+            for (size_t e = 0; e < L.peers.size(); ++e)
+                need = need || (selected(L, e, group) && L.send_start[e] < 0 && L.send_off[e + 1] > L.send_off[e]);
+            if (need) pack(d, l);
+        }
         if (rccl) {
             D *d = rs[0];
             DLevel &L = d->lv[l];
@@ -341,8 +373,9 @@ struct Runner {
             hipStream_t s = cs(d, l);
             OMG_NCCL(g_rccl.GroupStart());
             for (size_t k = 0; k < L.peers.size(); ++k) {
+                if (!selected(L, k, group)) continue;
                 const int64_t ns = L.send_off[k + 1] - L.send_off[k], nr = L.recv_off[k + 1] - L.recv_off[k];
-                if (ns) OMG_NCCL(g_rccl.Send(L.send_buf.p + L.send_off[k], (size_t)ns, ncclDouble, L.peers[k], d->comm, s));
+                if (ns) OMG_NCCL(g_rccl.Send(send_ptr(L, k), (size_t)ns, ncclDouble, L.peers[k], d->comm, s));
                 if (nr) OMG_NCCL(g_rccl.Recv(L.xp + L.n_loc + L.recv_off[k], (size_t)nr, ncclDouble, L.peers[k], d->comm, s));
             }
             OMG_NCCL(g_rccl.GroupEnd());
@@ -350,14 +383,16 @@ struct Runner {
             for (D *d : rs) {
                 DLevel &L = d->lv[l];
                 for (size_t k = 0; k < L.peers.size(); ++k) {
+                    if (!selected(L, k, group)) continue;
                     D *p = find(L.peers[k]);
                     DLevel &PL = p->lv[l];
+                    // the peer's entry towards this rank with the same group tag
                     size_t j = 0;
-                    while (j < PL.peers.size() && PL.peers[j] != d->rank) ++j;
+                    while (j < PL.peers.size() && !(PL.peers[j] == d->rank && PL.entry_group[j] == L.entry_group[k])) ++j;
                     OMG_REQUIRE(j < PL.peers.size(), "halo plan is not symmetric");
                     const int64_t nr = L.recv_off[k + 1] - L.recv_off[k];
                     OMG_REQUIRE(nr == PL.send_off[j + 1] - PL.send_off[j], "send/recv counts differ");
-                    if (nr) OMG_HIP(hipMemcpyAsync(L.xp + L.n_loc + L.recv_off[k], PL.send_buf.p + PL.send_off[j],
+                    if (nr) OMG_HIP(hipMemcpyAsync(L.xp + L.n_loc + L.recv_off[k], send_ptr(PL, j),
                                                    nr * sizeof(double), hipMemcpyDeviceToDevice, cs(d, l)));
                 }
             }
@@ -404,7 +439,7 @@ struct Runner {
                 for (int s = 0; s < n_sets; s += grp) {
                     const bool last_group = s + grp == n_sets;
                     sweep_set(s, last_group);            // plain set, or the BOUNDARY rows of a colour
-                    exchange_start(l);
+                    exchange_start(l, s / grp);          // only this colour's values have changed
                     // interior rows of the same colour: touch no halo entry, are not sent
                     if (grp == 2) sweep_set(s + 1, last_group);
                     exchange_finish(l);

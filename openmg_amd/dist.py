@@ -16,6 +16,8 @@ every level.  This module builds, for ONE rank, what `omg_dist_create` needs:
 Index work only; the sparse products run wherever `spgemm` runs (the GPU by default).
 Nothing here has a counterpart in the reference, which is single-process.
 """
+import os
+
 import numpy as np
 import scipy.sparse as sp
 
@@ -140,40 +142,69 @@ def set_keys(shape, rows, smoother):
 
 
 # ------------------------------------------------------------------------------- one rank --
-def compress_columns(M, own_lo, own_hi):
-    """Renumber the GLOBAL columns of M: owned -> 0..n_loc-1, the others -> n_loc + position in
-    the sorted list of distinct remote columns.  Returns (M_local, halo_gids)."""
+def compress_columns(M, own_lo, own_hi, bounds=None, group_of=None):
+    """Renumber the GLOBAL columns of M: owned -> 0..n_loc-1, the others (the halo) -> n_loc +
+    position in the halo list, which is ordered by (owning rank, message group, global id).
+    `group_of(gids)` gives the message group of remote unknowns (their smoother colour, so that
+    after relaxing colour c only colour-c values travel); None = one group.
+    Returns (M_local, halo_gids, halo_groups)."""
     M = sp.csr_matrix(M)
     cols = M.indices.astype(np.int64)
     owned = (cols >= own_lo) & (cols < own_hi)
     halo = np.unique(cols[~owned])
+    groups = np.zeros(halo.size, dtype=np.int32) if group_of is None else np.asarray(group_of(halo), dtype=np.int32)
+    owner = np.zeros(halo.size, dtype=np.int64) if bounds is None else np.searchsorted(bounds, halo, side="right") - 1
+    order = np.lexsort((halo, groups, owner))
+    rank_of_sorted = np.empty(halo.size, dtype=np.int64)
+    rank_of_sorted[order] = np.arange(halo.size)
     new = np.empty_like(cols)
     new[owned] = cols[owned] - own_lo
-    new[~owned] = (own_hi - own_lo) + np.searchsorted(halo, cols[~owned])
+    new[~owned] = (own_hi - own_lo) + rank_of_sorted[np.searchsorted(halo, cols[~owned])]
     out = sp.csr_matrix((M.data.copy(), new.astype(np.int32), M.indptr.astype(np.int32)),
                         shape=(M.shape[0], (own_hi - own_lo) + halo.size))
-    return out, halo
+    return out, halo[order], groups[order]
 
 
-def make_halo_plans(halo_lists, bounds):
-    """halo_lists[q] = sorted global ids rank q needs; bounds = row offsets of the ranks.
-    Returns per rank: dict(peers, recv_off, send_off, send_idx) — send_idx in the sender's
-    local (natural) numbering.  Sorted halos are grouped by owner automatically."""
+def make_halo_plans(halo_lists, bounds, halo_groups=None):
+    """halo_lists[q] = global ids rank q needs, ordered by (owner, group, id) as
+    compress_columns leaves them; halo_groups[q] their message groups (None: one group);
+    bounds = row offsets of the ranks.  One plan ENTRY per (peer, group): returns per rank
+    dict(peers, groups, recv_off, send_off, send_idx) with peers/groups of length n_entries and
+    send_idx in the sender's local (natural) numbering, in the receiver's halo order."""
     n = len(halo_lists)
+    if halo_groups is None:
+        halo_groups = [np.zeros(len(h), dtype=np.int32) for h in halo_lists]
     owner = [np.searchsorted(bounds, h, side="right") - 1 for h in halo_lists]
-    want = [[halo_lists[q][owner[q] == p] for p in range(n)] for q in range(n)]   # q wants from p
+    n_groups = 1 + max([int(g.max()) for g in halo_groups if len(g)] + [0])
+
+    def want(q, p, g):                       # ids q wants from p in group g (q's halo order)
+        sel = (owner[q] == p) & (halo_groups[q] == g)
+        return halo_lists[q][sel]
+
     plans = []
     for q in range(n):
-        peers = sorted(set(p for p in range(n) if p != q and (want[q][p].size or want[p][q].size)))
-        recv_off, send_off, send_idx = [0], [0], []
-        for p in peers:
-            recv_off.append(recv_off[-1] + want[q][p].size)
-            idx = want[p][q] - bounds[q]
-            send_idx.append(idx)
-            send_off.append(send_off[-1] + idx.size)
-        if recv_off[-1] != halo_lists[q].size:
+        peers, groups, recv_off, send_off, send_idx = [], [], [0], [0], []
+        for p in range(n):
+            if p == q:
+                continue
+            for g in range(n_groups):
+                mine, theirs = want(q, p, g), want(p, q, g)
+                if mine.size == 0 and theirs.size == 0:
+                    continue
+                peers.append(p)
+                groups.append(g)
+                recv_off.append(recv_off[-1] + mine.size)
+                idx = theirs - bounds[q]
+                send_idx.append(idx)
+                send_off.append(send_off[-1] + idx.size)
+        if recv_off[-1] != len(halo_lists[q]):
             raise ValueError("rank %d: halo columns outside every rank's range" % q)
+        # the entries must tile the halo region in order
+        chk = np.concatenate([want(q, p, g) for p, g in zip(peers, groups)]) if peers else np.zeros(0, dtype=np.int64)
+        if not np.array_equal(chk, halo_lists[q]):
+            raise ValueError("rank %d: halo list is not ordered by (owner, group, id)" % q)
         plans.append({"peers": np.array(peers, dtype=np.int32),
+                      "groups": np.array(groups, dtype=np.int32),
                       "recv_off": np.array(recv_off, dtype=np.int64),
                       "send_off": np.array(send_off, dtype=np.int64),
                       "send_idx": (np.concatenate(send_idx) if send_idx else np.zeros(0)).astype(np.int32)})
@@ -209,15 +240,21 @@ class RankSetup:
     def begin_level(self, l):
         part, q = self.part, self.rank
         lo, hi = part.rows(l, q)
-        A_loc, halo = compress_columns(self._A_glob, lo, hi)
         last = l + 1 == part.n_grids
+        # message groups = smoother colours: after relaxing colour c only colour-c boundary
+        # values change, so only they are sent (half the bytes for red-black)
+        group_of = None
+        if not last and self.smoother == "colour":
+            group_of = lambda gids: set_keys(part.shapes[l], gids, "colour")[0]
+        A_loc, halo, halo_groups = compress_columns(self._A_glob, lo, hi, part.bounds(l), group_of)
         lv = {"A": A_loc, "R": None, "n_halo": int(halo.size), "keys": None, "n_sets": 0}
         if not last:
             keys, n_sets = set_keys(part.shapes[l], np.arange(lo, hi), self.smoother)
             if keys is not None:
                 self._check_keys(A_loc, keys, set_keys(part.shapes[l], halo, self.smoother)[0], hi - lo)
             lv["set_group"] = 1
-            if keys is not None and self.smoother == "colour" and self.overlap:
+            min_rows = int(os.environ.get("OMG_OVERLAP_MIN_ROWS", 1 << 19))   # same rule as csrc/dist.hip
+            if keys is not None and self.smoother == "colour" and self.overlap and hi - lo >= min_rows:
                 # rows that touch the halo (for a symmetric pattern: exactly the rows the
                 # neighbours need) go FIRST inside their colour, so that their exchange can run
                 # while the interior rows of the colour are still being relaxed
@@ -255,10 +292,15 @@ class RankSetup:
                                          shape=(chi - clo, part.n_rows(l + 1)))
         self.levels.append(lv)
         self._halo = halo
-        return halo
+        return halo, halo_groups
 
     def finish_level(self, l, all_halos):
-        plan = make_halo_plans(list(all_halos), self.part.bounds(l))[self.rank]
+        """all_halos: every rank's begin_level(l) result, in rank order."""
+        lists = [np.asarray(h[0], dtype=np.int64) for h in all_halos]
+        groups = [np.asarray(h[1], dtype=np.int32) for h in all_halos]
+        plan = make_halo_plans(lists, self.part.bounds(l), groups)[self.rank]
+        if self.smoother != "colour" or l + 1 == self.part.n_grids:
+            plan["groups"] = None                 # one message per peer, sent after every set
         self.levels[l].update(plan)
         if l + 1 < self.part.n_grids:
             self._A_glob = self._A_next

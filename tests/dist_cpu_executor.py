@@ -18,11 +18,15 @@ class CpuRank:
         self.b = [np.zeros(lv["A"].shape[0]) for lv in levels]
         self.csr = [orc._csr(lv["A"]) for lv in levels]
 
-    def exchange(self, l):
+    def exchange(self, l, group=-1):
+        """group >= 0: only the plan entries that carry that colour (like csrc/dist.hip)."""
         lv = self.levels[l]
         n_loc = lv["A"].shape[0]
         sends, recvs = [], []
+        tags = lv.get("groups")
         for k, p in enumerate(lv["peers"]):
+            if group >= 0 and tags is not None and int(tags[k]) != group:
+                continue
             idx = lv["send_idx"][lv["send_off"][k]:lv["send_off"][k + 1]]
             sends.append((int(p), np.ascontiguousarray(self.x[l][idx])))
             recvs.append((int(p), n_loc + int(lv["recv_off"][k]), n_loc + int(lv["recv_off"][k + 1])))
@@ -47,7 +51,7 @@ class CpuRank:
                 if order.size:
                     rc = orc._clib().oracle_gs_ordered(order.size, ip, ix, dv, self.b[l], self.x[l], order, 1)
                     assert rc == 0
-                self.exchange(l)
+                self.exchange(l, group=s // int(lv.get("set_group", 1)))
 
     def cycle(self, l, pre, post):
         last = len(self.levels) - 1

@@ -63,10 +63,17 @@ def test_local_hierarchy_equals_global(shape, n_ranks, grids):
             if l + 1 < grids:
                 clo, chi = part.rows(l + 1, q)
                 assert abs(lv["R"] - R[l][clo:chi, lo:hi]).max() == 0
-            for k, p in enumerate(lv["peers"]):
+            def tag(level, e):
+                return -1 if level.get("groups") is None else int(level["groups"][e])
+
+            for k, p in enumerate(lv["peers"]):                    # one entry per (peer, colour group)
                 other = levels[int(p)][l]
-                j = list(other["peers"]).index(q)
+                j = [e for e in range(len(other["peers"])) if other["peers"][e] == q and tag(other, e) == tag(lv, k)]
+                assert len(j) == 1
+                j = j[0]
                 assert (lv["recv_off"][k + 1] - lv["recv_off"][k]) == (other["send_off"][j + 1] - other["send_off"][j])
+            if l + 1 < grids and len(lv["peers"]):
+                assert lv["groups"] is not None and set(lv["groups"]) <= {0, 1}
 
 
 def _free_port():

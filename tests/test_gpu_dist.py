@@ -125,10 +125,12 @@ def test_replicated_tail_matches_single_gpu(n_ranks, n_dist):
     np.testing.assert_allclose(nd, n1, rtol=1e-13)
 
 
-def test_boundary_first_sets_do_not_change_the_iterate():
+def test_boundary_first_sets_do_not_change_the_iterate(monkeypatch):
     """overlap=True orders every colour as (rows the neighbours need, interior rows) so that
     the exchange can run beside the interior launch; overlap=False keeps plain colour sets.
-    Same iterate either way (and the same as one GPU)."""
+    Same iterate either way (and the same as one GPU).  (Small levels keep plain sets by
+    default; the threshold is lowered here.)"""
+    monkeypatch.setenv("OMG_OVERLAP_MIN_ROWS", "0")
     shape, grids, n_ranks = (32, 32, 32), 3, 4
     b = operators.stencil_poisson(shape) @ np.random.default_rng(3).random(32 ** 3)
     x1, n1 = single_gpu(shape, grids, "colour", b, 2)
