@@ -74,7 +74,15 @@ def cpu_baseline(size, grids, cycles):
     for _ in range(cycles):
         x, info = orc.mg_cycle(A, b, 0, R, p, initial=x, smoother=sm)
     dt = time.perf_counter() - t0
-    return cycles / dt, dt, info["norm"]
+    # fine-grid mat-vec on the CPU (SciPy csr_matvec, one core) with the same byte accounting
+    xv = np.ones(A0.shape[0])
+    A0 @ xv
+    t1 = time.perf_counter()
+    reps = 5
+    for _ in range(reps):
+        A0 @ xv
+    spmv_s = (time.perf_counter() - t1) / reps
+    return cycles / dt, dt, spmv_bytes(A0.shape[0], A0.nnz) / spmv_s / 1e9
 
 
 def main():
@@ -146,6 +154,13 @@ def main():
     h.profile_enable(False)
     if timed is None:
         timed = prof
+    # The metric's "fine-grid SpMV GB/s": plain y = A x over the whole level-0 operator as it
+    # sits in HBM for the cycle, 20 back-to-back launches in one hipEvent bracket (untimed region).
+    spmv_ms = h.spmv_time(20)
+    spmv_b = spmv_bytes(meta["n"], meta["nnz"])
+    fine_spmv = {"kernel": "rows_kernel<ROW_SPMV> (y = A x, all rows of the fine grid)", "avg_launch_us": round(spmv_ms * 1e3, 2),
+                 "algorithmic_bytes": spmv_b, "GBps": round(spmv_b / spmv_ms / 1e6, 1),
+                 "frac_of_peak": round(spmv_b / spmv_ms / 1e6 / HBM_PEAK_GBS, 4)}
 
     n, nnz = meta["n"], meta["nnz"]
     launches, ms = timed["residual"]
@@ -201,13 +216,14 @@ def main():
 
     cpu = None
     if not args.no_cpu:
-        rate, dt, _ = cpu_baseline(args.cpu_size, args.grids, args.cpu_cycles)
+        rate, dt, cpu_spmv = cpu_baseline(args.cpu_size, args.grids, args.cpu_cycles)
         scale = (args.cpu_size / float(args.size)) ** 3
         cpu = {"value": round(rate * scale, 5), "unit": "V-cycles/s", "cores": 1, "kind": "port",
                "sample": "%d V(1,1) red-black cycles of the CPU oracle on %d^3 (%d grids) in %.1f s, "
                          "scaled by (%d/%d)^3 to %d^3; host has %d cores, the oracle uses 1"
                          % (args.cpu_cycles, args.cpu_size, args.grids, dt, args.cpu_size, args.size,
-                            args.size, os.cpu_count() or 0)}
+                            args.size, os.cpu_count() or 0),
+               "fine_grid_spmv_GBps": round(cpu_spmv, 2)}
 
     out = {
         "metric": "V-cycles/sec, 3-D 7-point Poisson %d^3" % args.size,
@@ -229,6 +245,7 @@ def main():
                    "smoother": args.smoother, "hipgraph": bool(args.graph),
                    "final_residual_norm": norm, "setup_s": round(setup_s, 2)},
         "roofline": roofline,
+        "fine_grid_spmv": fine_spmv,
         "cpu_baseline": cpu,
     }
     print(json.dumps(out))

@@ -112,6 +112,9 @@ int omg_hierarchy_cycle_dev(omg_hierarchy *h, const double *b_dev, double *x_dev
 int omg_resident_load(omg_hierarchy *h, const double *b, const double *x0 /* NULL = zeros */);
 int omg_resident_cycle(omg_hierarchy *h, int pre, int post, double *norm /* NULL = no readback */);
 int omg_resident_fetch(omg_hierarchy *h, double *x);
+/* Fine-grid SpMV y = A[0] x (tools.flexibleMmult, openmg/tools.py:26) on the resident
+ * operator, `reps` back-to-back launches inside one hipEvent bracket; *avg_ms per launch. */
+int omg_resident_spmv_time(omg_hierarchy *h, int reps, double *avg_ms);
 /* Capture one resident cycle into a hipGraph and replay it on later omg_resident_cycle
  * calls with the same (pre, post).  enable = 0 drops the graph.                          */
 int omg_resident_use_graph(omg_hierarchy *h, int enable);

@@ -68,6 +68,7 @@ SIGNATURES = {
     "omg_resident_load": (_I, [_P, _P, _P]),
     "omg_resident_cycle": (_I, [_P, _I, _I, _DP]),
     "omg_resident_fetch": (_I, [_P, _P]),
+    "omg_resident_spmv_time": (_I, [_P, _I, _DP]),
     "omg_resident_use_graph": (_I, [_P, _I]),
     "omg_profile_enable": (_I, [_P, _I]),
     "omg_profile_read": (_I, [_P, _I64P, _DP]),
@@ -261,6 +262,12 @@ class Hierarchy:
         x = np.empty(self.sizes[0], dtype=np.float64)
         check(lib().omg_resident_fetch(self._h, x.ctypes.data))
         return x
+
+    def spmv_time(self, reps=20):
+        """Average milliseconds of one fine-grid y = A[0] x launch on the resident operator."""
+        ms = ctypes.c_double(0.0)
+        check(lib().omg_resident_spmv_time(self._h, int(reps), ctypes.byref(ms)))
+        return ms.value
 
     def use_graph(self, enable=True):
         check(lib().omg_resident_use_graph(self._h, 1 if enable else 0))

@@ -632,6 +632,34 @@ int omg_resident_cycle(omg_hierarchy *h, int pre, int post, double *norm) {
     });
 }
 
+// Plain fine-grid SpMV y = A_0 x over the WHOLE operator (x: the resident iterate, y: the
+// level's residual buffer, which every cycle overwrites anyway), `reps` launches timed as one
+// hipEvent bracket on the hierarchy's stream: the "fine-grid SpMV GB/s" of BASELINE.json's
+// metric, measured on the operator as it sits in HBM inside the V-cycle.
+int omg_resident_spmv_time(omg_hierarchy *h, int reps, double *avg_ms) {
+    return guarded([&] {
+        check_level(h, 0);
+        OMG_REQUIRE(h->resident && reps > 0 && avg_ms, "nothing resident / bad argument");
+        OMG_REQUIRE(h->lv.size() > 1, "single-level hierarchy has no smoothed operator");
+        Level &L = h->lv[0];
+        RowArgs a;
+        a.x = L.xp; a.y = L.r.p;
+        launch_rows(L.A, ROW_SPMV, -1, a, h->stream);              // warm-up
+        hipEvent_t e0, e1;
+        OMG_HIP(hipEventCreate(&e0));
+        OMG_HIP(hipEventCreate(&e1));
+        OMG_HIP(hipEventRecord(e0, h->stream));
+        for (int i = 0; i < reps; ++i) launch_rows(L.A, ROW_SPMV, -1, a, h->stream);
+        OMG_HIP(hipEventRecord(e1, h->stream));
+        OMG_HIP(hipEventSynchronize(e1));
+        float ms = 0.f;
+        OMG_HIP(hipEventElapsedTime(&ms, e0, e1));
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+        *avg_ms = double(ms) / reps;
+    });
+}
+
 int omg_resident_fetch(omg_hierarchy *h, double *x) {
     return guarded([&] {
         check_level(h, 0);
