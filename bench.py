@@ -101,8 +101,8 @@ def main():
                     help="multi-GPU: relax boundary rows first and exchange them while the interior rows run")
     ap.add_argument("--dist-grids", type=int, default=4,
                     help="multi-GPU: grids handled across ranks (the last of them and all below run replicated)")
-    ap.add_argument("--cpu-size", type=int, default=128)
-    ap.add_argument("--cpu-cycles", type=int, default=8)
+    ap.add_argument("--cpu-size", type=int, default=256, help="CPU baseline leg: grid extent (default: the full workload)")
+    ap.add_argument("--cpu-cycles", type=int, default=16)
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -219,10 +219,12 @@ def main():
         rate, dt, cpu_spmv = cpu_baseline(args.cpu_size, args.grids, args.cpu_cycles)
         scale = (args.cpu_size / float(args.size)) ** 3
         cpu = {"value": round(rate * scale, 5), "unit": "V-cycles/s", "cores": 1, "kind": "port",
-               "sample": "%d V(1,1) red-black cycles of the CPU oracle on %d^3 (%d grids) in %.1f s, "
-                         "scaled by (%d/%d)^3 to %d^3; host has %d cores, the oracle uses 1"
-                         % (args.cpu_cycles, args.cpu_size, args.grids, dt, args.cpu_size, args.size,
-                            args.size, os.cpu_count() or 0),
+               "sample": "%d V(1,1) red-black cycles of the CPU oracle on %d^3 (%d grids) in %.1f s%s; "
+                         "host has %d cores, the oracle uses 1"
+                         % (args.cpu_cycles, args.cpu_size, args.grids, dt,
+                            "" if args.cpu_size == args.size else
+                            ", scaled by (%d/%d)^3 to %d^3" % (args.cpu_size, args.size, args.size),
+                            os.cpu_count() or 0),
                "fine_grid_spmv_GBps": round(cpu_spmv, 2)}
 
     out = {
