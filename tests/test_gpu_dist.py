@@ -168,3 +168,32 @@ def test_two_stream_overlap_schedule_on_one_gpu(monkeypatch):
         xd, nd = loopback(shape, grids, n_ranks, "colour", b, 4)
         assert np.array_equal(xd, x1)
         np.testing.assert_allclose(nd, n1, rtol=1e-13)
+
+
+def test_default_thresholds_at_realistic_slab_size(monkeypatch):
+    """128^3 over 2 ranks: 1M rows per rank at level 0 — above the default 2^19-row threshold,
+    so boundary-first pairs and (forced here, as no RCCL peer exists) the two-stream schedule
+    are what the real multi-GPU run takes at its two finest levels; deeper levels keep plain
+    colour sets.  Replicated tail below level 2."""
+    monkeypatch.setenv("OMG_FORCE_OVERLAP", "1")
+    shape, grids, n_ranks, n_dist = (128, 128, 128), 5, 2, 3
+    b = operators.stencil_poisson(shape) @ np.random.default_rng(11).random(128 ** 3)
+    x1, n1 = single_gpu(shape, grids, "colour", b, 3)
+    part = dist.SlabPartition(shape, n_ranks, n_dist)
+    levels, coarse, counts = dist.build_all_ranks(
+        part, lambda q: dist.stencil_rows(shape, *part.rows(0, q)), smoother="colour")
+    assert [levels[0][l].get("set_group") for l in range(n_dist - 1)] == [2, 1]
+    assert levels[0][0]["groups"] is not None and len(levels[0][0]["peers"]) == 2      # one peer, two colours
+    ranks = [_hip_dist.DistRank(q, n_ranks, levels[q], None, counts, smoother="colour",
+                                tail=dist.make_tail(coarse, part.shapes[-1], grids - n_dist + 1))
+             for q in range(n_ranks)]
+    group = _hip_dist.DistGroup(ranks)
+    try:
+        for q, r in enumerate(ranks):
+            r.load(b[slice(*part.rows(0, q))])
+        nd = [group.cycle(1, 1) for _ in range(3)]
+        xd = np.concatenate([r.fetch() for r in ranks])
+    finally:
+        group.close()
+    assert np.array_equal(xd, x1)
+    np.testing.assert_allclose(nd, n1, rtol=1e-13)

@@ -582,3 +582,30 @@ def test_omg_solve_entry_point_and_mgcycle_cache():
     assert it["norm"] == 0
     np.testing.assert_allclose(A[2] @ top, np.ones(A[2].shape[0]), rtol=1e-10)
     openmg_amd.clear_cache()
+
+
+def test_converged_regime_tracks_the_oracle():
+    """Far beyond the 3-5 cycles of the fixtures: 40 V(1,1) cycles on 16^3 drive the residual
+    down ~8 orders of magnitude; the GPU norm trace must follow the CPU oracle's all the way
+    (relative difference grows only with the rounding noise floor ~1e-16 * ||b|| / ||r||)."""
+    shape = (16, 16, 16)
+    A0 = operators.stencil_poisson(shape)
+    b = A0 @ np.random.default_rng(12345).random(4096)
+    R = operators.restrictionList(shape, 1, 8)
+    A = operators.coeffecientList(A0, R)
+    Ro = orc.restriction_list(shape, 1, 8)
+    Ao = orc.coefficient_list(A0, Ro)
+    p = {"preIterations": 1, "postIterations": 1, "coarsestLevel": len(R)}
+    xo, norms_o = None, []
+    for _ in range(40):
+        xo, inf = orc.mg_cycle(Ao, b, 0, Ro, p, initial=xo)
+        norms_o.append(inf["norm"])
+    with _hip.Hierarchy(A, R, smoother="gs") as h:
+        h.resident_load(b)
+        norms = [h.resident_cycle(1, 1) for _ in range(40)]
+        x = h.resident_fetch()
+    assert norms_o[-1] < 1e-7 * norms_o[0]
+    bnorm = np.linalg.norm(b)
+    for k, (g, o) in enumerate(zip(norms, norms_o)):
+        assert abs(g - o) <= 1e-10 * o + 1e-14 * bnorm, (k, g, o)
+    np.testing.assert_allclose(x, xo, rtol=1e-10, atol=1e-12)
