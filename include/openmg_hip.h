@@ -73,6 +73,19 @@ const char *omg_version(void);
  * n_levels == 1 is allowed (direct solve only).                                          */
 int omg_hierarchy_create(int n_levels, const omg_csr *A, const omg_csr *R,
                          int smoother, double omega, omg_hierarchy **out);
+/* Same, choosing the precision the levels are STORED and COMPUTED in on the device
+ * (BASELINE.json configs[4] is fp32).  OMG_DTYPE_F64 is omg_hierarchy_create.  With
+ * OMG_DTYPE_F32 the operators are rounded to float once at upload, every vector lives in HBM
+ * as float, row sums run in float fma; residual norms are still accumulated in double, and
+ * the coarsest operator is inverted in double and then rounded.  Every entry point keeps its
+ * double host (and omg_hierarchy_cycle_dev device) vectors: the conversion happens on the
+ * device.  The reference has no such switch (it is fp64 throughout); parity for fp32 is
+ * "within single-precision rounding of the fp64 iterate", stated per test.               */
+#define OMG_DTYPE_F64 0
+#define OMG_DTYPE_F32 1
+int omg_hierarchy_create_ex(int n_levels, const omg_csr *A, const omg_csr *R, int smoother,
+                            double omega, int dtype, omg_hierarchy **out);
+int omg_hierarchy_dtype(const omg_hierarchy *h, int *dtype);
 int omg_hierarchy_destroy(omg_hierarchy *h);
 /* Run on a caller-owned hipStream_t instead of the hierarchy's own stream (NULL = own). */
 int omg_hierarchy_set_stream(omg_hierarchy *h, void *hip_stream);

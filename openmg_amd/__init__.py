@@ -11,6 +11,8 @@ Extra keys understood in the `parameters` dict (ignored by the reference):
     'smoother'  'gs' (default: the reference's lexicographic Gauss-Seidel iterate),
                 'colour' (multi-colour GS; red-black on 5/7-point stencils) or 'jacobi'
     'omega'     relaxation weight for 'jacobi' (default 2/3)
+    'dtype'     'float64' (default, the reference's precision) or 'float32': the precision the
+                levels are stored and computed in on the device (inputs / outputs stay float64)
 """
 import numpy as np
 import scipy.sparse as sp
@@ -47,6 +49,10 @@ def _smoother_of(parameters):
     return code, omega
 
 
+def _dtype_of(parameters):
+    return _hip.dtype_code(parameters.get("dtype", "float64"))
+
+
 # ---- device hierarchy cache for repeated mgCycle calls ---------------------------------------
 # mgCycle receives the A and R lists on every call (openmg/__init__.py:151); uploading
 # them each time would dominate.  The device copy is keyed on the identity of the list
@@ -56,21 +62,21 @@ _cache = {}
 _CACHE_SLOTS = 2
 
 
-def _fingerprint(A, R, n_levels, code, omega):
+def _fingerprint(A, R, n_levels, code, omega, dtype):
     def one(M):
         if sp.issparse(M):
             return (id(M), M.shape, M.nnz, M.data.ctypes.data if M.nnz else 0)
         return (id(M), np.shape(M))
-    return (tuple(one(M) for M in A[:n_levels]), tuple(one(M) for M in R[:n_levels - 1]), code, omega)
+    return (tuple(one(M) for M in A[:n_levels]), tuple(one(M) for M in R[:n_levels - 1]), code, omega, dtype)
 
 
-def _hierarchy_for(A, R, n_levels, code, omega):
-    key = _fingerprint(A, R, n_levels, code, omega)
+def _hierarchy_for(A, R, n_levels, code, omega, dtype=_hip.DTYPE_F64):
+    key = _fingerprint(A, R, n_levels, code, omega, dtype)
     h = _cache.get(key)
     if h is None:
         while len(_cache) >= _CACHE_SLOTS:
             _cache.pop(next(iter(_cache))).close()
-        h = _hip.Hierarchy(list(A[:n_levels]), list(R[:n_levels - 1]), smoother=code, omega=omega)
+        h = _hip.Hierarchy(list(A[:n_levels]), list(R[:n_levels - 1]), smoother=code, omega=omega, dtype=dtype)
         _cache[key] = h
     return h
 
@@ -111,7 +117,7 @@ def mgSolve(A_in, b, parameters):
     A = operators.coeffecientList(A_in, R, dense=dense, verbose=verbose)
 
     pre, post = parameters["preIterations"], parameters["postIterations"]
-    hierarchy = _hip.Hierarchy(A, R, smoother=code, omega=omega)
+    hierarchy = _hip.Hierarchy(A, R, smoother=code, omega=omega, dtype=_dtype_of(parameters))
     try:
         hierarchy.resident_load(np.asarray(b, dtype=np.float64).reshape(-1))
         if verbose:
@@ -172,7 +178,7 @@ def mgCycle(A, b, level, R, parameters, initial=None):
     if level >= coarsest:
         # the reference's `else` branch (:229-234): direct solve with A[level], norm 0
         return solvers.coarseSolve(A[level], b), {"norm": 0}
-    hierarchy = _hierarchy_for(A, R, coarsest + 1, code, omega)
+    hierarchy = _hierarchy_for(A, R, coarsest + 1, code, omega, _dtype_of(parameters))
     x = np.zeros(b.size) if initial is None else np.array(np.asarray(initial, dtype=np.float64).reshape(-1), order="C")
     if parameters.get("verbose", False):
         for l in range(level, coarsest):

@@ -56,6 +56,8 @@ SIGNATURES = {
     "omg_device_count": (_I, [_IP]),
     "omg_set_device": (_I, [_I]),
     "omg_hierarchy_create": (_I, [_I, _CSR, _CSR, _I, _D, _PP]),
+    "omg_hierarchy_create_ex": (_I, [_I, _CSR, _CSR, _I, _D, _I, _PP]),
+    "omg_hierarchy_dtype": (_I, [_P, _IP]),
     "omg_hierarchy_destroy": (_I, [_P]),
     "omg_hierarchy_set_stream": (_I, [_P, _P]),
     "omg_hierarchy_sync": (_I, [_P]),
@@ -156,6 +158,21 @@ def smoother_code(kind):
         raise ValueError("unknown smoother %r (choose from %s)" % (kind, sorted(set(SMOOTHERS))))
 
 
+DTYPE_F64, DTYPE_F32 = 0, 1
+
+
+def dtype_code(dtype):
+    """OMG_DTYPE_* for a numpy dtype / name."""
+    if isinstance(dtype, int) and not isinstance(dtype, bool) and dtype in (DTYPE_F64, DTYPE_F32):
+        return dtype
+    dt = np.dtype(dtype)
+    if dt == np.float64:
+        return DTYPE_F64
+    if dt == np.float32:
+        return DTYPE_F32
+    raise ValueError("dtype must be float64 or float32, not %r" % (dtype,))
+
+
 def as_csr(A):
     """CSR with int32 index arrays / float64 data; stored column order is kept as is."""
     if not sp.isspmatrix_csr(A):
@@ -190,7 +207,9 @@ def vec(x, n=None, copy=False):
 class Hierarchy:
     """Device-resident A/R hierarchy (omg_hierarchy)."""
 
-    def __init__(self, A_list, R_list, smoother="gs", omega=1.0):
+    def __init__(self, A_list, R_list, smoother="gs", omega=1.0, dtype="float64"):
+        """dtype: precision the levels are stored and computed in on the device ("float64", the
+        reference's, or "float32"); host vectors are float64 either way."""
         if len(R_list) != len(A_list) - 1:
             raise ValueError("need len(R) == len(A) - 1")
         self._A = [as_csr(M) for M in A_list]
@@ -202,7 +221,9 @@ class Hierarchy:
         self.n_levels = len(self._A)
         self.sizes = [M.shape[0] for M in self._A]
         h = ctypes.c_void_p()
-        check(lib().omg_hierarchy_create(self.n_levels, arrA, arrR, self.smoother, self.omega, ctypes.byref(h)))
+        self.dtype = dtype_code(dtype)
+        check(lib().omg_hierarchy_create_ex(self.n_levels, arrA, arrR, self.smoother, self.omega, self.dtype,
+                                            ctypes.byref(h)))
         self._h = h
         # the device copy is complete; the host copies are only kept for .sizes
         self._A = self._R = None
@@ -277,6 +298,12 @@ class Hierarchy:
 
     def sync(self):
         check(lib().omg_hierarchy_sync(self._h))
+
+    def device_dtype(self):
+        """np.dtype the levels are held in on the device (omg_hierarchy_dtype)."""
+        code = ctypes.c_int(-1)
+        check(lib().omg_hierarchy_dtype(self._h, ctypes.byref(code)))
+        return np.dtype(np.float32 if code.value == DTYPE_F32 else np.float64)
 
     def level_sets(self, level):
         v = ctypes.c_int64(0)

@@ -113,20 +113,24 @@ constexpr int ROWBLK_ROWS = 256;      // <= one row per thread
 #endif
 constexpr int ROWBLK_NNZ = OMG_ROWBLK_NNZ;   // entries staged through LDS per workgroup
 
-struct DevCsr {
+// V = value type of the stored entries and of the vectors the operator is applied to:
+// double (the reference's precision) or float (BASELINE configs[4]); indices are int32.
+template <typename V>
+struct DevCsrT {
     int64_t n_rows = 0, n_cols = 0, nnz = 0;
     DevBuf<int32_t> indptr, indices;
-    DevBuf<double> data;
+    DevBuf<V> data;
     DevBuf<int32_t> blk_rows;          // first row of every row block (+ end sentinel)
     std::vector<int64_t> set_blk;      // block offsets of the independent sets (host)
     std::vector<int64_t> sets;         // row offsets of the sets (host)
     int rows_cap = ROWBLK_ROWS;        // most rows a block may hold (> ROWBLK_THREADS: short rows)
     std::vector<int64_t> set_nnz;      // stored entries of each set (host)
     int lanes_per_row = 1;             // 4 for operators with long rows (avg > 16 entries)
-    void upload(const HostCsr &A, const std::vector<int64_t> &sets, hipStream_t s);
+    void upload(const HostCsr &A, const std::vector<int64_t> &sets, hipStream_t s);   // converts to V
     size_t n_sets() const { return sets.empty() ? 0 : sets.size() - 1; }
     int64_t n_blocks() const { return set_blk.empty() ? 0 : set_blk.back(); }
 };
+using DevCsr = DevCsrT<double>;
 
 // ---- kernel launchers (csr_kernels.hip) ---------------------------------------------
 enum RowMode : int {
@@ -147,36 +151,48 @@ enum RowMode : int {
     ROW_GS_NORM = 8,    // ... residual squared into the block partials
 };
 
-struct RowArgs {
-    const double *x = nullptr;   // gathered vector
-    const double *b = nullptr;
-    double *y = nullptr;         // output (GS: the same pointer as x)
+template <typename V>
+struct RowArgsT {
+    const V *x = nullptr;        // gathered vector
+    const V *b = nullptr;
+    V *y = nullptr;              // output (GS: the same pointer as x)
     double omega = 1.0;
-    double *partials = nullptr;  // one double per row block (RESNORM / NORM_ONLY)
-    double *zero = nullptr;      // ROW_SPMV: zero[r] = 0 alongside y[r] (fused clear);
-    const int32_t *ymap = nullptr;   // ROW_SPMV: result of row r goes to y[ymap[r]]
+    double *partials = nullptr;  // one DOUBLE per row block (RESNORM / NORM_ONLY), any V
+    V *zero = nullptr;           // ROW_SPMV: zero[r] = 0 alongside y[r] (fused clear);
                                  // ROW_GS_RES: residual of the relaxed rows goes here
+    const int32_t *ymap = nullptr;   // ROW_SPMV: result of row r goes to y[ymap[r]]
 };
+using RowArgs = RowArgsT<double>;
 
 // Launch `mode` over row set `set` of A (set < 0: all sets in one launch).
-void launch_rows(const DevCsr &A, int mode, int set, const RowArgs &args, hipStream_t s);
+// (all launchers are instantiated for V = double and V = float in csr_kernels.hip)
+template <typename V>
+void launch_rows(const DevCsrT<V> &A, int mode, int set, const RowArgsT<V> &args, hipStream_t s);
 // ... over the consecutive sets [set_begin, set_end) in one launch.
-void launch_rows_range(const DevCsr &A, int mode, int set_begin, int set_end, const RowArgs &args,
+template <typename V>
+void launch_rows_range(const DevCsrT<V> &A, int mode, int set_begin, int set_end, const RowArgsT<V> &args,
                        hipStream_t s);
 // Consecutive single-block sets [set_begin, set_end) of a Gauss-Seidel sweep, run back to
 // back by one workgroup (workgroup barrier between sets).
-void launch_gs_serial(const DevCsr &A, int set_begin, int set_end, const RowArgs &args,
+template <typename V>
+void launch_gs_serial(const DevCsrT<V> &A, int set_begin, int set_end, const RowArgsT<V> &args,
                       hipStream_t s);
 // sum of partials[0..n) -> *out (device), fixed order => deterministic.  `partials` must
 // have SUM_FOLD spare doubles behind its n entries (stage-1 scratch).
 constexpr int SUM_FOLD = 64;
 void launch_sum(double *partials, int64_t n, double *out, hipStream_t s);
 void launch_sum_sqrt(double *partials, int64_t n, double *out, hipStream_t s);
-void launch_gather(const double *src, const int32_t *idx, double *dst, int64_t n, hipStream_t s);   // dst[i] = src[idx[i]]
-void launch_scatter(const double *src, const int32_t *idx, double *dst, int64_t n, hipStream_t s);  // dst[idx[i]] = src[i]
-void launch_dense_gemv(const double *M, const double *v, double *out, int64_t n, hipStream_t s);    // out = M v (row-major n x n)
-void launch_dense_gemv_rows(const double *M, const double *v, double *out, int64_t rows, int64_t n,
-                            hipStream_t s);                                                       // M: rows x n slab
+// dst[i] = src[idx[i]] / dst[idx[i]] = src[i]; idx == NULL is the identity, S -> D converts
+// (the host boundary of a float hierarchy is double)
+template <typename S, typename D>
+void launch_gather(const S *src, const int32_t *idx, D *dst, int64_t n, hipStream_t s);
+template <typename S, typename D>
+void launch_scatter(const S *src, const int32_t *idx, D *dst, int64_t n, hipStream_t s);
+template <typename V>
+void launch_dense_gemv(const V *M, const V *v, V *out, int64_t n, hipStream_t s);    // out = M v (row-major n x n)
+template <typename V>
+void launch_dense_gemv_rows(const V *M, const V *v, V *out, int64_t rows, int64_t n,
+                            hipStream_t s);                                          // M: rows x n slab
 // Dense inverse (row-major n x n) of a square device CSR matrix by Gauss-Jordan with
 // partial pivoting on the device.  Throws OMG_ERR_SINGULAR / OMG_ERR_UNSUPPORTED (n > 16384).
 void dense_inverse_from_csr(const DevCsr &A, double *Minv, hipStream_t s);

@@ -11,11 +11,14 @@
 //      memory — for stencil-like matrices consecutive lanes touch consecutive x, so
 //      each gather is itself a coalesced 512-byte access served by L1/L2.
 // The epilogue is selected by MODE (SpMV, residual, residual norm, Gauss-Seidel set
-// sweep, weighted Jacobi, y += A x).
+// sweep, weighted Jacobi, y += A x, and the fused last-set sweeps).
 //
-// Algorithmic HBM bytes per launch (fp64 values, int32 indices; DESIGN.md "Kernels"):
-//   SpMV      12*nnz + 4*(n+1) + 16*n
-//   residual / GS set sweep / Jacobi   SpMV + 8*n
+// Everything is a template on the value type V (double: the reference's precision; float:
+// BASELINE configs[4]); indices are int32; norms are accumulated in double for either V.
+//
+// Algorithmic HBM bytes per launch (w = sizeof(V), int32 indices; DESIGN.md "Kernels"):
+//   SpMV      (w+4)*nnz + 4*(n+1) + 2*w*n
+//   residual / GS set sweep / Jacobi   SpMV + w*n
 #include "common.h"
 
 namespace omg {
@@ -32,23 +35,34 @@ constexpr int LDS_SLOTS = (T + 8) + ((T + 8) >> 5) + 1;
 __device__ __forceinline__ int slot(int k) { return k + (k >> 5); }
 
 typedef int v4i __attribute__((ext_vector_type(4)));
-typedef double v2d __attribute__((ext_vector_type(2)));
+// 16-byte vector of values: 2 doubles or 4 floats
+template <typename V> struct Vec16;
+template <> struct Vec16<double> {
+    typedef double type __attribute__((ext_vector_type(2)));
+    static constexpr int N = 2;
+};
+template <> struct Vec16<float> {
+    typedef float type __attribute__((ext_vector_type(4)));
+    static constexpr int N = 4;
+};
 
+template <typename V>
 struct KArgs {
     const int32_t *blk_info;   // (first row, first entry) per row block, + end sentinel
     const int32_t *indptr;
     const int32_t *indices;
-    const double *data;
-    const double *x;
-    const double *b;
-    double *y;
+    const V *data;
+    const V *x;
+    const V *b;
+    V *y;
     double *partials;
-    double *zero;              // SpMV only: also clear zero[r] (next level's initial iterate)
+    V *zero;                   // SpMV: also clear zero[r] (next level's initial iterate); GS_RES: residual
     const int32_t *ymap;       // SpMV only: row r is stored to y[ymap[r]] (NULL: y[r])
-    double omega;
+    V omega;
 };
 
-__device__ __forceinline__ double wave_sum(double v) {
+template <typename S>
+__device__ __forceinline__ S wave_sum(S v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
     return v;
@@ -72,19 +86,20 @@ __device__ __forceinline__ double block_sum(double v, double *s_red) {
 // Per-row operands that do not depend on the staged matrix entries.  They are loaded BEFORE
 // the staging loop so that their latency overlaps the matrix stream instead of adding a
 // third dependent memory round trip behind the workgroup barrier.
+template <typename V>
 struct RowPre {
     int beg, end;     // CSR extent of the row (absolute entry offsets)
     int out;          // SpMV: where the result goes (ymap)
-    double bv, xv;    // b[r]; x[r] (GS, Jacobi) or y[r] (y += A x)
+    V bv, xv;         // b[r]; x[r] (GS, Jacobi) or y[r] (y += A x)
 };
 
-template <int MODE>
-__device__ __forceinline__ RowPre row_preload(const KArgs &a, int r) {
-    RowPre p;
+template <int MODE, typename V>
+__device__ __forceinline__ RowPre<V> row_preload(const KArgs<V> &a, int r) {
+    RowPre<V> p;
     p.beg = a.indptr[r];
     p.end = a.indptr[r + 1];
-    p.bv = 0.0;
-    p.xv = 0.0;
+    p.bv = V(0);
+    p.xv = V(0);
     if constexpr (MODE != ROW_SPMV && MODE != ROW_AXPY) p.bv = a.b[r];
     if constexpr (MODE == ROW_GS || MODE == ROW_JACOBI || MODE == ROW_GS_RES || MODE == ROW_GS_NORM)
         p.xv = a.x[r];
@@ -97,22 +112,23 @@ __device__ __forceinline__ RowPre row_preload(const KArgs &a, int r) {
 // Row sums are spelled with an explicit fma everywhere so that the fused sweep+residual
 // modes reproduce the plain residual kernel bit for bit.
 __device__ __forceinline__ double madd(double v, double x, double acc) { return fma(v, x, acc); }
+__device__ __forceinline__ float madd(float v, float x, float acc) { return fmaf(v, x, acc); }
 
-template <int MODE>
-__device__ __forceinline__ void row_epilogue(const KArgs &a, int r, const RowPre &p, double sum,
-                                             double diag, double &sq) {
+template <int MODE, typename V>
+__device__ __forceinline__ void row_epilogue(const KArgs<V> &a, int r, const RowPre<V> &p, V sum,
+                                             V diag, double &sq) {
     if constexpr (MODE == ROW_SPMV) {
         a.y[p.out] = sum;
-        if (a.zero) a.zero[r] = 0.0;
+        if (a.zero) a.zero[r] = V(0);
     } else if constexpr (MODE == ROW_RESIDUAL) {
         a.y[r] = p.bv - sum;
     } else if constexpr (MODE == ROW_RESNORM) {
-        const double res = p.bv - sum;
+        const V res = p.bv - sum;
         a.y[r] = res;
-        sq += res * res;
+        sq += double(res) * double(res);
     } else if constexpr (MODE == ROW_NORM_ONLY) {
-        const double res = p.bv - sum;
-        sq += res * res;
+        const V res = p.bv - sum;
+        sq += double(res) * double(res);
     } else if constexpr (MODE == ROW_GS) {
         // openmg/solvers.py:68   x[i] = x[i] + (b[i] - Aix) / A[i, i]
         a.y[r] = p.xv + (p.bv - sum) / diag;
@@ -126,11 +142,13 @@ __device__ __forceinline__ void row_epilogue(const KArgs &a, int r, const RowPre
 // SHORT selects the phase-2 variant for operators whose rows are so short (prolongation:
 // one entry per row) that a block holds several rows per thread: the rows of a thread are
 // then processed eight at a time with all their loads in flight together.
-template <int MODE, bool nt, bool SHORT, int LPR>
-__device__ void process_block(const KArgs &a, int blk, double *s_val, int *s_idx, double *s_red) {
+template <int MODE, bool nt, bool SHORT, int LPR, typename V>
+__device__ void process_block(const KArgs<V> &a, int blk, V *s_val, int *s_idx, double *s_red) {
     constexpr bool FUSED = (MODE == ROW_GS_RES || MODE == ROW_GS_NORM);
     constexpr bool NEED_DIAG = (MODE == ROW_GS || MODE == ROW_JACOBI || FUSED);
     constexpr bool NEED_NORM = (MODE == ROW_RESNORM || MODE == ROW_NORM_ONLY || MODE == ROW_GS_NORM);
+    using vdat = typename Vec16<V>::type;
+    constexpr int VN = Vec16<V>::N;
     const int tid = threadIdx.x;
     // (first row, first entry) of this block and of the next: one round trip instead of
     // block table -> indptr
@@ -141,10 +159,10 @@ __device__ void process_block(const KArgs &a, int blk, double *s_val, int *s_idx
 
     if (p1 - p0 <= T) {
         int r = r0 + tid / LPR;
-        RowPre pre;
+        RowPre<V> pre;
         if (!SHORT && r < r1) pre = row_preload<MODE>(a, r);
         // ---- phase 1: stream the block's entries into LDS, 16 B per lane per load ------
-        const int base = p0 & ~3;              // 16-B aligned for int32, 32-B for fp64
+        const int base = p0 & ~3;              // 16-B aligned for int32 and fp32, 32-B for fp64
         const int cnt = p1 - base;
         {
             const v4i *gi = reinterpret_cast<const v4i *>(a.indices + base);
@@ -155,11 +173,12 @@ __device__ void process_block(const KArgs &a, int blk, double *s_val, int *s_idx
                 const int s = slot(k);          // k % 4 == 0: the four slots are contiguous
                 s_idx[s] = v[0]; s_idx[s + 1] = v[1]; s_idx[s + 2] = v[2]; s_idx[s + 3] = v[3];
             }
-            const v2d *gd = reinterpret_cast<const v2d *>(a.data + base);
-            for (int k = 2 * tid; k < cnt; k += 2 * NT) {
-                const v2d v = nt ? __builtin_nontemporal_load(gd + (k >> 1)) : gd[k >> 1];
-                const int s = slot(k);
-                s_val[s] = v[0]; s_val[s + 1] = v[1];
+            const vdat *gd = reinterpret_cast<const vdat *>(a.data + base);
+            for (int k = VN * tid; k < cnt; k += VN * NT) {
+                const vdat v = nt ? __builtin_nontemporal_load(gd + (k / VN)) : gd[k / VN];
+                const int s = slot(k);          // k % VN == 0 and VN <= 4: contiguous slots
+#pragma unroll
+                for (int j = 0; j < VN; ++j) s_val[s + j] = v[j];
             }
         }
         __syncthreads();
@@ -169,9 +188,9 @@ __device__ void process_block(const KArgs &a, int blk, double *s_val, int *s_idx
         if constexpr (SHORT) {
             constexpr int U = 8;
             for (int rb = r; rb < r1; rb += U * NT) {
-                RowPre q[U];
+                RowPre<V> q[U];
                 int c0[U];
-                double v0[U], x0[U], sum[U];
+                V v0[U], x0[U], sum[U];
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     const int ru = rb + u * NT;
@@ -183,7 +202,7 @@ __device__ void process_block(const KArgs &a, int blk, double *s_val, int *s_idx
                     const bool has = q[u].beg < q[u].end;
                     const int sl = slot(has ? q[u].beg - base : 0);
                     c0[u] = has ? s_idx[sl] : 0;
-                    v0[u] = has ? s_val[sl] : 0.0;
+                    v0[u] = has ? s_val[sl] : V(0);
                 }
 #pragma unroll
                 for (int u = 0; u < U; ++u) x0[u] = a.x[c0[u]];
@@ -191,13 +210,13 @@ __device__ void process_block(const KArgs &a, int blk, double *s_val, int *s_idx
                 for (int u = 0; u < U; ++u) {
                     const int ru = rb + u * NT;
                     if (ru >= r1) continue;
-                    sum[u] = (q[u].beg < q[u].end) ? madd(v0[u], x0[u], 0.0) : 0.0;
+                    sum[u] = (q[u].beg < q[u].end) ? madd(v0[u], x0[u], V(0)) : V(0);
                     for (int k = q[u].beg + 1 - base; k < q[u].end - base; ++k) {   // rest, stored order
                         const int sl = slot(k);
                         sum[u] = madd(s_val[sl], a.x[s_idx[sl]], sum[u]);
                     }
                     double unused = 0.0;
-                    row_epilogue<MODE>(a, ru, q[u], sum[u], 0.0, unused);
+                    row_epilogue<MODE>(a, ru, q[u], sum[u], V(0), unused);
                 }
             }
         } else {
@@ -208,18 +227,18 @@ __device__ void process_block(const KArgs &a, int blk, double *s_val, int *s_idx
             // order: a fixed, run-to-run reproducible association, the same in every mode.
             const int sub = tid % LPR;
             const int lane0 = (threadIdx.x & 63) & ~(LPR - 1);     // first lane of the quad
-            auto quad_sum = [&](double p) {
+            auto quad_sum = [&](V p) {
                 if constexpr (LPR == 1) return p;
-                double t = __shfl(p, lane0, 64);
+                V t = __shfl(p, lane0, 64);
 #pragma unroll
                 for (int q = 1; q < LPR; ++q) t += __shfl(p, lane0 + q, 64);
                 return t;
             };
             while (r < r1) {
                 const int beg = pre.beg - base, end = pre.end - base;
-                double sum = 0.0, diag = 0.0;
+                V sum = V(0), diag = V(0);
                 int c[8];
-                double v[8], xv[8];
+                V v[8], xv[8];
                 for (int k = beg + sub; k < end; k += 8 * LPR) {
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
@@ -243,8 +262,8 @@ __device__ void process_block(const KArgs &a, int blk, double *s_val, int *s_idx
                 if constexpr (FUSED) {
                     // relax the row, then its residual with the NEW x_i: same entries, same
                     // order, same fma chain as ROW_RESIDUAL would run on the updated vector
-                    const double xnew = pre.xv + (pre.bv - sum) / diag;
-                    double sum2 = 0.0;
+                    const V xnew = pre.xv + (pre.bv - sum) / diag;
+                    V sum2 = V(0);
                     if (end - beg <= 8 * LPR) {      // the row's entries are still in registers
 #pragma unroll
                         for (int j = 0; j < 8; ++j)
@@ -263,11 +282,11 @@ __device__ void process_block(const KArgs &a, int blk, double *s_val, int *s_idx
                         }
                     }
                     sum2 = quad_sum(sum2);
-                    const double res = pre.bv - sum2;
+                    const V res = pre.bv - sum2;
                     if (sub == 0) {
                         a.y[r] = xnew;
                         if constexpr (MODE == ROW_GS_RES) a.zero[r] = res;
-                        else sq += res * res;
+                        else sq += double(res) * double(res);
                     }
                 } else if (sub == 0) {
                     row_epilogue<MODE>(a, r, pre, sum, diag, sq);
@@ -278,38 +297,39 @@ __device__ void process_block(const KArgs &a, int blk, double *s_val, int *s_idx
         }
     } else {
         // ---- one long row: the whole workgroup strides over it (summation order differs
-        // from the stored order here; only rows longer than ROWBLK_NNZ take this path) ---
+        // from the stored order here; only rows longer than ROWBLK_NNZ take this path; the
+        // per-thread partial sums are combined in double for either V) --------------------
         const int r = r0;
-        double part = 0.0, dpart = 0.0;
+        V part = V(0), dpart = V(0);
         for (int p = p0 + tid; p < p1; p += NT) {
             const int c = a.indices[p];
-            const double v = a.data[p];
+            const V v = a.data[p];
             part = madd(v, a.x[c], part);
             if (NEED_DIAG && c == r) dpart += v;
         }
-        const double sum = block_sum(part, s_red);
-        double diag = 0.0;
-        if (NEED_DIAG) diag = block_sum(dpart, s_red);
+        const V sum = V(block_sum(double(part), s_red));
+        V diag = V(0);
+        if (NEED_DIAG) diag = V(block_sum(double(dpart), s_red));
         if constexpr (FUSED) {
-            const RowPre pre = row_preload<MODE>(a, r);
+            const RowPre<V> pre = row_preload<MODE>(a, r);
             __syncthreads();
-            if (tid == 0) s_red[0] = pre.xv + (pre.bv - sum) / diag;
+            if (tid == 0) s_red[0] = double(pre.xv + (pre.bv - sum) / diag);
             __syncthreads();
-            const double xnew = s_red[0];
-            double part2 = 0.0;
+            const V xnew = V(s_red[0]);
+            V part2 = V(0);
             for (int p = p0 + tid; p < p1; p += NT) {
                 const int c = a.indices[p];
                 part2 = madd(a.data[p], c == r ? xnew : a.x[c], part2);
             }
-            const double sum2 = block_sum(part2, s_red);
+            const V sum2 = V(block_sum(double(part2), s_red));
             if (tid == 0) {
                 a.y[r] = xnew;
-                const double res = pre.bv - sum2;
+                const V res = pre.bv - sum2;
                 if constexpr (MODE == ROW_GS_RES) a.zero[r] = res;
-                else sq += res * res;
+                else sq += double(res) * double(res);
             }
         } else if (tid == 0) {
-            const RowPre pre = row_preload<MODE>(a, r);
+            const RowPre<V> pre = row_preload<MODE>(a, r);
             row_epilogue<MODE>(a, r, pre, sum, diag, sq);
         }
     }
@@ -342,11 +362,11 @@ __device__ __forceinline__ int xcd_remap_grouped(int b, int n, int G) {
     return base + (r & 7) * G + (r >> 3);
 }
 
-template <int MODE, bool NTL, bool SHORT, int LPR>
-// (NT, 6): six workgroups per CU is what the 25 KB LDS image allows; keep every variant within
-// 80 VGPRs so that registers do not cut that to five (the fused sweeps wanted 82-94).
-__global__ __launch_bounds__(NT, 6) void rows_kernel(KArgs a, int blk0, int remap) {
-    __shared__ double s_val[LDS_SLOTS];
+// (NT, 6): six workgroups per CU is what the 25 KB fp64 LDS image allows; keep every variant
+// within 80 VGPRs so that registers do not cut that to five (the fused sweeps wanted 82-94).
+template <int MODE, bool NTL, bool SHORT, int LPR, typename V>
+__global__ __launch_bounds__(NT, 6) void rows_kernel(KArgs<V> a, int blk0, int remap) {
+    __shared__ V s_val[LDS_SLOTS];
     __shared__ int s_idx[LDS_SLOTS];
     __shared__ double s_red[NT / 64];
     const int local = remap == 0 ? int(blockIdx.x)
@@ -360,9 +380,9 @@ __global__ __launch_bounds__(NT, 6) void rows_kernel(KArgs a, int blk0, int rema
 // sweep of a 1-D operator is n single-row sets, and the first/last hyperplanes of a 3-D
 // grid are tiny too.  Stores of set s are visible to set s+1 through the barrier's
 // workgroup-scope fence (same CU, same L1).
-template <int MODE>
-__global__ __launch_bounds__(NT) void rows_serial_kernel(KArgs a, int blk_begin, int blk_end) {
-    __shared__ double s_val[LDS_SLOTS];
+template <int MODE, typename V>
+__global__ __launch_bounds__(NT) void rows_serial_kernel(KArgs<V> a, int blk_begin, int blk_end) {
+    __shared__ V s_val[LDS_SLOTS];
     __shared__ int s_idx[LDS_SLOTS];
     __shared__ double s_red[NT / 64];
     for (int blk = blk_begin; blk < blk_end; ++blk) {
@@ -385,47 +405,40 @@ int launch_flags() {
     return v;
 }
 
-template <int MODE>
-void launch_mode(const DevCsr &A, int64_t blk0, int64_t nblk, const KArgs &k, hipStream_t s) {
+template <int MODE, typename V>
+void launch_mode(const DevCsrT<V> &A, int64_t blk0, int64_t nblk, const KArgs<V> &k, hipStream_t s) {
     if (nblk <= 0) return;
     const int flags = launch_flags();
     static const int group = [] { const char *e = getenv("OMG_XCD_GROUP"); return e ? atoi(e) : 0; }();
     const int remap = (nblk < 64) ? 0 : (group > 1 ? group : (flags & 1));
     // small operators live in L2 / Infinity Cache across cycles: keep them cacheable
-    const bool ntl = (flags & 2) && A.nnz * 12 > (int64_t(192) << 20);
+    const bool ntl = (flags & 2) && A.nnz * int64_t(4 + sizeof(V)) > (int64_t(192) << 20);
     // several rows per thread (short rows): batched variant, built for the modes such
     // operators are used with; other modes fall back to the generic one-row-at-a-time loop
     constexpr bool HAS_SHORT = (MODE == ROW_SPMV || MODE == ROW_AXPY || MODE == ROW_RESIDUAL);
     const dim3 grid((unsigned)nblk), block(NT);
     if constexpr (HAS_SHORT) {
         if (A.rows_cap > NT) {
-            if (ntl) hipLaunchKernelGGL((rows_kernel<MODE, true, true, 1>), grid, block, 0, s, k, (int)blk0, remap);
-            else hipLaunchKernelGGL((rows_kernel<MODE, false, true, 1>), grid, block, 0, s, k, (int)blk0, remap);
+            if (ntl) hipLaunchKernelGGL((rows_kernel<MODE, true, true, 1, V>), grid, block, 0, s, k, (int)blk0, remap);
+            else hipLaunchKernelGGL((rows_kernel<MODE, false, true, 1, V>), grid, block, 0, s, k, (int)blk0, remap);
             OMG_HIP(hipGetLastError());
             return;
         }
     }
     if (A.lanes_per_row == 4) {       // long rows: four lanes per row
-        if (ntl) hipLaunchKernelGGL((rows_kernel<MODE, true, false, 4>), grid, block, 0, s, k, (int)blk0, remap);
-        else hipLaunchKernelGGL((rows_kernel<MODE, false, false, 4>), grid, block, 0, s, k, (int)blk0, remap);
+        if (ntl) hipLaunchKernelGGL((rows_kernel<MODE, true, false, 4, V>), grid, block, 0, s, k, (int)blk0, remap);
+        else hipLaunchKernelGGL((rows_kernel<MODE, false, false, 4, V>), grid, block, 0, s, k, (int)blk0, remap);
         OMG_HIP(hipGetLastError());
         return;
     }
-    if (ntl) hipLaunchKernelGGL((rows_kernel<MODE, true, false, 1>), grid, block, 0, s, k, (int)blk0, remap);
-    else hipLaunchKernelGGL((rows_kernel<MODE, false, false, 1>), grid, block, 0, s, k, (int)blk0, remap);
+    if (ntl) hipLaunchKernelGGL((rows_kernel<MODE, true, false, 1, V>), grid, block, 0, s, k, (int)blk0, remap);
+    else hipLaunchKernelGGL((rows_kernel<MODE, false, false, 1, V>), grid, block, 0, s, k, (int)blk0, remap);
     OMG_HIP(hipGetLastError());
 }
 
-}  // namespace
-
-void launch_rows(const DevCsr &A, int mode, int set, const RowArgs &args, hipStream_t s) {
-    if (set < 0) launch_rows_range(A, mode, 0, (int)A.n_sets(), args, s);
-    else launch_rows_range(A, mode, set, set + 1, args, s);
-}
-
-void launch_rows_range(const DevCsr &A, int mode, int set_begin, int set_end, const RowArgs &args,
-                       hipStream_t s) {
-    KArgs k;
+template <typename V>
+KArgs<V> make_kargs(const DevCsrT<V> &A, const RowArgsT<V> &args) {
+    KArgs<V> k;
     k.blk_info = A.blk_rows.p;
     k.indptr = A.indptr.p;
     k.indices = A.indices.p;
@@ -436,7 +449,22 @@ void launch_rows_range(const DevCsr &A, int mode, int set_begin, int set_end, co
     k.partials = args.partials;
     k.zero = args.zero;
     k.ymap = args.ymap;
-    k.omega = args.omega;
+    k.omega = V(args.omega);
+    return k;
+}
+
+}  // namespace
+
+template <typename V>
+void launch_rows(const DevCsrT<V> &A, int mode, int set, const RowArgsT<V> &args, hipStream_t s) {
+    if (set < 0) launch_rows_range(A, mode, 0, (int)A.n_sets(), args, s);
+    else launch_rows_range(A, mode, set, set + 1, args, s);
+}
+
+template <typename V>
+void launch_rows_range(const DevCsrT<V> &A, int mode, int set_begin, int set_end, const RowArgsT<V> &args,
+                       hipStream_t s) {
+    const KArgs<V> k = make_kargs(A, args);
     OMG_REQUIRE(set_begin >= 0 && set_begin <= set_end && size_t(set_end) <= A.n_sets(),
                 "launch_rows: set range out of bounds");
     const int64_t blk0 = A.set_blk[set_begin];
@@ -455,23 +483,16 @@ void launch_rows_range(const DevCsr &A, int mode, int set_begin, int set_end, co
     }
 }
 
-void launch_gs_serial(const DevCsr &A, int set_begin, int set_end, const RowArgs &args,
+template <typename V>
+void launch_gs_serial(const DevCsrT<V> &A, int set_begin, int set_end, const RowArgsT<V> &args,
                       hipStream_t s) {
-    KArgs k;
-    k.blk_info = A.blk_rows.p;
-    k.indptr = A.indptr.p;
-    k.indices = A.indices.p;
-    k.data = A.data.p;
-    k.x = args.x;
-    k.b = args.b;
-    k.y = args.y;
+    KArgs<V> k = make_kargs(A, args);
     k.partials = nullptr;
     k.zero = nullptr;
     k.ymap = nullptr;
-    k.omega = args.omega;
     const int b0 = (int)A.set_blk[set_begin], b1 = (int)A.set_blk[set_end];
     if (b1 <= b0) return;
-    hipLaunchKernelGGL(rows_serial_kernel<ROW_GS>, dim3(1), dim3(NT), 0, s, k, b0, b1);
+    hipLaunchKernelGGL((rows_serial_kernel<ROW_GS, V>), dim3(1), dim3(NT), 0, s, k, b0, b1);
     OMG_HIP(hipGetLastError());
 }
 
@@ -506,37 +527,40 @@ __global__ __launch_bounds__(256) void fold_kernel(const double *__restrict__ p,
     if (threadIdx.x == 0) scratch[blockIdx.x] = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
 }
 
-__global__ void gather_kernel(const double *__restrict__ src, const int32_t *__restrict__ idx,
-                              double *__restrict__ dst, int64_t n) {
+template <typename S, typename D>
+__global__ void gather_kernel(const S *__restrict__ src, const int32_t *__restrict__ idx,
+                              D *__restrict__ dst, int64_t n) {
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
          i += (int64_t)gridDim.x * blockDim.x)
-        dst[i] = src[idx[i]];
+        dst[i] = D(src[idx ? idx[i] : i]);
 }
 
-__global__ void scatter_kernel(const double *__restrict__ src, const int32_t *__restrict__ idx,
-                               double *__restrict__ dst, int64_t n) {
+template <typename S, typename D>
+__global__ void scatter_kernel(const S *__restrict__ src, const int32_t *__restrict__ idx,
+                               D *__restrict__ dst, int64_t n) {
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
          i += (int64_t)gridDim.x * blockDim.x)
-        dst[idx[i]] = src[i];
+        dst[idx ? idx[i] : i] = D(src[i]);
 }
 
 // out = M v, M row-major rows x n.  One wave per row, 16-byte loads, 4 rows per workgroup.
-__global__ __launch_bounds__(256) void dense_gemv_kernel(const double *__restrict__ M,
-                                                         const double *__restrict__ v,
-                                                         double *__restrict__ out, int64_t rows,
-                                                         int64_t n) {
+template <typename V>
+__global__ __launch_bounds__(256) void dense_gemv_kernel(const V *__restrict__ M, const V *__restrict__ v,
+                                                         V *__restrict__ out, int64_t rows, int64_t n) {
+    using vdat = typename Vec16<V>::type;
+    constexpr int VN = Vec16<V>::N;
     const int lane = threadIdx.x & 63;
     const int64_t row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
-    const double *m = M + row * n;
-    double acc = 0.0;
-    if ((n & 1) == 0) {
-        const double2 *m2 = reinterpret_cast<const double2 *>(m);
-        const double2 *v2 = reinterpret_cast<const double2 *>(v);
-        for (int64_t j = lane; j < (n >> 1); j += 64) {
-            const double2 a = m2[j], b = v2[j];
-            acc += a.x * b.x;
-            acc += a.y * b.y;
+    const V *m = M + row * n;
+    V acc = V(0);
+    if (n % VN == 0) {
+        const vdat *m2 = reinterpret_cast<const vdat *>(m);
+        const vdat *v2 = reinterpret_cast<const vdat *>(v);
+        for (int64_t j = lane; j < n / VN; j += 64) {
+            const vdat a = m2[j], b = v2[j];
+#pragma unroll
+            for (int q = 0; q < VN; ++q) acc += a[q] * b[q];
         }
     } else {
         for (int64_t j = lane; j < n; j += 64) acc += m[j] * v[j];
@@ -576,27 +600,49 @@ void launch_sum_sqrt(double *partials, int64_t n, double *out, hipStream_t s) {
     launch_sum_impl(partials, n, out, 1, s);
 }
 
-void launch_gather(const double *src, const int32_t *idx, double *dst, int64_t n, hipStream_t s) {
+template <typename S, typename D>
+void launch_gather(const S *src, const int32_t *idx, D *dst, int64_t n, hipStream_t s) {
     if (n <= 0) return;
-    hipLaunchKernelGGL(gather_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, src, idx, dst, n);
+    hipLaunchKernelGGL((gather_kernel<S, D>), dim3(grid_for(n, 256)), dim3(256), 0, s, src, idx, dst, n);
     OMG_HIP(hipGetLastError());
 }
 
-void launch_scatter(const double *src, const int32_t *idx, double *dst, int64_t n, hipStream_t s) {
+template <typename S, typename D>
+void launch_scatter(const S *src, const int32_t *idx, D *dst, int64_t n, hipStream_t s) {
     if (n <= 0) return;
-    hipLaunchKernelGGL(scatter_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, src, idx, dst, n);
+    hipLaunchKernelGGL((scatter_kernel<S, D>), dim3(grid_for(n, 256)), dim3(256), 0, s, src, idx, dst, n);
     OMG_HIP(hipGetLastError());
 }
 
-void launch_dense_gemv(const double *M, const double *v, double *out, int64_t n, hipStream_t s) {
+template <typename V>
+void launch_dense_gemv(const V *M, const V *v, V *out, int64_t n, hipStream_t s) {
     launch_dense_gemv_rows(M, v, out, n, n, s);
 }
 
-void launch_dense_gemv_rows(const double *M, const double *v, double *out, int64_t rows, int64_t n,
-                            hipStream_t s) {
+template <typename V>
+void launch_dense_gemv_rows(const V *M, const V *v, V *out, int64_t rows, int64_t n, hipStream_t s) {
     if (rows <= 0 || n <= 0) return;
-    hipLaunchKernelGGL(dense_gemv_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, M, v, out, rows, n);
+    hipLaunchKernelGGL((dense_gemv_kernel<V>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, M, v, out, rows, n);
     OMG_HIP(hipGetLastError());
 }
+
+// ---- explicit instantiations (V = double, float) -------------------------------------------
+#define OMG_INSTANTIATE(V)                                                                                \
+    template void launch_rows<V>(const DevCsrT<V> &, int, int, const RowArgsT<V> &, hipStream_t);         \
+    template void launch_rows_range<V>(const DevCsrT<V> &, int, int, int, const RowArgsT<V> &, hipStream_t); \
+    template void launch_gs_serial<V>(const DevCsrT<V> &, int, int, const RowArgsT<V> &, hipStream_t);    \
+    template void launch_dense_gemv<V>(const V *, const V *, V *, int64_t, hipStream_t);                   \
+    template void launch_dense_gemv_rows<V>(const V *, const V *, V *, int64_t, int64_t, hipStream_t);
+OMG_INSTANTIATE(double)
+OMG_INSTANTIATE(float)
+#undef OMG_INSTANTIATE
+#define OMG_INSTANTIATE_CVT(S, D)                                                                         \
+    template void launch_gather<S, D>(const S *, const int32_t *, D *, int64_t, hipStream_t);             \
+    template void launch_scatter<S, D>(const S *, const int32_t *, D *, int64_t, hipStream_t);
+OMG_INSTANTIATE_CVT(double, double)
+OMG_INSTANTIATE_CVT(double, float)
+OMG_INSTANTIATE_CVT(float, double)
+OMG_INSTANTIATE_CVT(float, float)
+#undef OMG_INSTANTIATE_CVT
 
 }  // namespace omg

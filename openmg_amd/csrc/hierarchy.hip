@@ -1,11 +1,16 @@
 // Device-resident level hierarchy and the V-cycle driver (openmg/__init__.py:151-236),
 // plus the extern "C" surface declared in include/openmg_hip.h.
+//
+// The implementation is a template on the value type V the levels are stored and computed
+// in (double: the reference's precision; float: BASELINE configs[4]).  The C handle holds
+// one of the two instantiations; the host boundary is double either way.
 #include <algorithm>
 #include <cmath>
 #include <cstring>
 #include <memory>
 #include <mutex>
 #include <thread>
+#include <type_traits>
 
 #include "common.h"
 
@@ -30,18 +35,19 @@ struct SweepStep {
     bool serial;              // run of single-block sets -> one workgroup
 };
 
+template <typename V>
 struct Level {
     int64_t n = 0;
-    DevCsr A;                 // P A P^T in this level's smoother ordering
-    DevCsr R;                 // to level+1: rows in next ordering, columns in this ordering
-    DevCsr P;                 // R^T: rows in this ordering, columns in next ordering
+    DevCsrT<V> A;             // P A P^T in this level's smoother ordering
+    DevCsrT<V> R;             // to level+1: rows in next ordering, columns in this ordering
+    DevCsrT<V> P;             // R^T: rows in this ordering, columns in next ordering
     Ordering ord;
     DevBuf<int32_t> perm;     // new -> old (empty when identity)
     DevBuf<int32_t> r_out;    // restriction row (natural coarse numbering) -> slot in the next level's ordering
-    DevBuf<double> x, b, r, tmp;
+    DevBuf<V> x, b, r, tmp;
     DevBuf<double> partials;
-    DevBuf<double> nat;       // natural-order staging for host I/O at this level
-    double *xp = nullptr, *tp = nullptr;   // current iterate / Jacobi scratch (swap)
+    DevBuf<double> nat;       // natural-order (double) staging for host I/O at this level
+    V *xp = nullptr, *tp = nullptr;   // current iterate / Jacobi scratch (swap)
     std::vector<SweepStep> plan;
 };
 
@@ -50,13 +56,12 @@ struct ProfEvent {
     hipEvent_t a, b;
 };
 
-}  // namespace
-}  // namespace omg
-
-struct omg_hierarchy {
-    std::vector<omg::Level> lv;
-    omg::DevBuf<double> coarse_inv;
-    omg::DevBuf<double> norm_dev;
+template <typename V>
+struct Hier {
+    using value_type = V;
+    std::vector<Level<V>> lv;
+    DevBuf<V> coarse_inv;
+    DevBuf<double> norm_dev;
     int smoother = OMG_SMOOTH_GS_LEX;
     double omega = 1.0;
     hipStream_t own = nullptr, stream = nullptr;
@@ -71,12 +76,15 @@ struct omg_hierarchy {
     int g_pre = -1, g_post = -1;
     // profile
     unsigned profiling = 0;   // bit c set: time level-0 launches of class c
-    std::vector<omg::ProfEvent> events;
+    std::vector<ProfEvent> events;
     int64_t prof_n[OMG_PROFILE_CLASSES] = {0};
     double prof_ms[OMG_PROFILE_CLASSES] = {0};
     std::vector<hipEvent_t> event_pool;
 
-    ~omg_hierarchy() {
+    Hier() = default;
+    Hier(const Hier &) = delete;
+    Hier &operator=(const Hier &) = delete;
+    ~Hier() {
         if (gexec) (void)hipGraphExecDestroy(gexec);
         for (auto &e : events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
         for (auto &e : event_pool) (void)hipEventDestroy(e);
@@ -84,10 +92,16 @@ struct omg_hierarchy {
     }
 };
 
+}  // namespace
+}  // namespace omg
+
+struct omg_hierarchy {
+    std::unique_ptr<omg::Hier<double>> d;
+    std::unique_ptr<omg::Hier<float>> f;
+};
+
 namespace omg {
 namespace {
-
-using H = omg_hierarchy;
 
 void check_diagonal(const omg_csr &A, int level) {
     const int64_t bad = first_row_without_diagonal(A);
@@ -100,7 +114,8 @@ omg_csr view(const HostCsr &A) {
     return omg_csr{A.n_rows, A.n_cols, A.nnz, A.indptr.data(), A.indices.data(), A.data.data()};
 }
 
-void build_plan(Level &L) {
+template <typename V>
+void build_plan(Level<V> &L) {
     L.plan.clear();
     const int ns = (int)L.A.n_sets();
     int s = 0;
@@ -118,10 +133,11 @@ void build_plan(Level &L) {
     }
 }
 
+template <typename V>
 struct Prof {
-    H *h;
+    Hier<V> *h;
     int idx = -1;
-    Prof(H *hh, int level, int cls) : h(hh) {
+    Prof(Hier<V> *hh, int level, int cls) : h(hh) {
         if (level != 0 || !((h->profiling >> cls) & 1u)) return;
         ProfEvent e;
         e.cls = cls;
@@ -148,33 +164,35 @@ struct Prof {
 enum Fuse { FUSE_NONE = 0, FUSE_RESIDUAL = 1, FUSE_NORM = 2 };
 
 // Fusion needs a Gauss-Seidel ordering whose final step is an ordinary set launch.
-bool can_fuse(const H *h, const Level &L) {
+template <typename V>
+bool can_fuse(const Hier<V> *h, const Level<V> &L) {
     if (h->smoother == OMG_SMOOTH_JACOBI || L.plan.empty() || h->no_fuse) return false;
     return !L.plan.back().serial;
 }
 
 // Returns true when the last set launch was fused (its rows' residual / norm is done).
-bool smooth_level(H *h, int l, int iterations, Fuse fuse = FUSE_NONE) {
-    Level &L = h->lv[l];
+template <typename V>
+bool smooth_level(Hier<V> *h, int l, int iterations, Fuse fuse = FUSE_NONE) {
+    Level<V> &L = h->lv[l];
     bool fused = false;
     for (int it = 0; it < iterations; ++it) {
         if (h->smoother == OMG_SMOOTH_JACOBI) {
-            Prof p(h, l, 0);
-            RowArgs a;
+            Prof<V> p(h, l, 0);
+            RowArgsT<V> a;
             a.x = L.xp; a.b = L.b.p; a.y = L.tp; a.omega = h->omega;
             launch_rows(L.A, ROW_JACOBI, -1, a, h->stream);
             std::swap(L.xp, L.tp);
         } else {
-            RowArgs a;
+            RowArgsT<V> a;
             a.x = L.xp; a.b = L.b.p; a.y = L.xp;
             const bool last_it = it + 1 == iterations;
             for (size_t k = 0; k < L.plan.size(); ++k) {
                 const SweepStep &st = L.plan[k];
-                Prof p(h, l, 0);
+                Prof<V> p(h, l, 0);
                 if (st.serial) {
                     launch_gs_serial(L.A, st.set_begin, st.set_end, a, h->stream);
                 } else if (last_it && k + 1 == L.plan.size() && fuse != FUSE_NONE && can_fuse(h, L)) {
-                    RowArgs f = a;
+                    RowArgsT<V> f = a;
                     f.zero = L.r.p;
                     f.partials = L.partials.p;
                     launch_rows(L.A, fuse == FUSE_RESIDUAL ? ROW_GS_RES : ROW_GS_NORM, st.set_begin, f, h->stream);
@@ -190,10 +208,11 @@ bool smooth_level(H *h, int l, int iterations, Fuse fuse = FUSE_NONE) {
 
 // r = b - A x over all sets, or over all but the last one when the smoother has already
 // produced the last set's residual.
-void residual_level(H *h, int l, double *r_out, bool last_set_done = false) {
-    Level &L = h->lv[l];
-    Prof p(h, l, 1);
-    RowArgs a;
+template <typename V>
+void residual_level(Hier<V> *h, int l, V *r_out, bool last_set_done = false) {
+    Level<V> &L = h->lv[l];
+    Prof<V> p(h, l, 1);
+    RowArgsT<V> a;
     a.x = L.xp; a.b = L.b.p; a.y = r_out;
     const int ns = (int)L.A.n_sets();
     launch_rows_range(L.A, ROW_RESIDUAL, 0, last_set_done ? ns - 1 : ns, a, h->stream);
@@ -201,11 +220,12 @@ void residual_level(H *h, int l, double *r_out, bool last_set_done = false) {
 
 // ||b - A x||_2 of level l into h->norm_dev (device scalar); r_out optional.  With
 // last_set_done the last set's block partials are already in place.
-void norm_level(H *h, int l, double *r_out, bool last_set_done = false) {
-    Level &L = h->lv[l];
+template <typename V>
+void norm_level(Hier<V> *h, int l, V *r_out, bool last_set_done = false) {
+    Level<V> &L = h->lv[l];
     {
-        Prof p(h, l, 4);
-        RowArgs a;
+        Prof<V> p(h, l, 4);
+        RowArgsT<V> a;
         a.x = L.xp; a.b = L.b.p; a.y = r_out; a.partials = L.partials.p;
         const int ns = (int)L.A.n_sets();
         launch_rows_range(L.A, r_out ? ROW_RESNORM : ROW_NORM_ONLY, 0, last_set_done ? ns - 1 : ns, a, h->stream);
@@ -214,25 +234,28 @@ void norm_level(H *h, int l, double *r_out, bool last_set_done = false) {
 }
 
 // coarse = R fine; `clear` (nullable, coarse-sized) is zeroed by the same launch.
-void restrict_level(H *h, int l, const double *fine, double *coarse, double *clear = nullptr) {
-    Level &L = h->lv[l];
-    Prof p(h, l, 2);
-    RowArgs a;
+template <typename V>
+void restrict_level(Hier<V> *h, int l, const V *fine, V *coarse, V *clear = nullptr) {
+    Level<V> &L = h->lv[l];
+    Prof<V> p(h, l, 2);
+    RowArgsT<V> a;
     a.x = fine; a.y = coarse; a.zero = clear; a.ymap = L.r_out.p;
     launch_rows(L.R, ROW_SPMV, -1, a, h->stream);
 }
 
-void prolong_add_level(H *h, int l, const double *coarse, double *fine) {
-    Level &L = h->lv[l];
-    Prof p(h, l, 3);
-    RowArgs a;
+template <typename V>
+void prolong_add_level(Hier<V> *h, int l, const V *coarse, V *fine) {
+    Level<V> &L = h->lv[l];
+    Prof<V> p(h, l, 3);
+    RowArgsT<V> a;
     a.x = coarse; a.y = fine;
     launch_rows(L.P, ROW_AXPY, -1, a, h->stream);
 }
 
-void coarse_solve_level(H *h) {
-    Level &L = h->lv.back();
-    launch_dense_gemv(h->coarse_inv.p, L.b.p, L.xp, L.n, h->stream);
+template <typename V>
+void coarse_solve_level(Hier<V> *h) {
+    Level<V> &L = h->lv.back();
+    launch_dense_gemv<V>(h->coarse_inv.p, L.b.p, L.xp, L.n, h->stream);
 }
 
 // openmg/__init__.py:199-234 with the dead work removed: R[l]*b (:205-206) is computed by the
@@ -242,64 +265,84 @@ void coarse_solve_level(H *h) {
 // want_norm: the caller will ask for ||b - A x|| of THIS level right after the cycle; the
 // post-smoother's last set launch then also leaves that set's share of the norm in the block
 // partials.  Returns true when it did (norm_level(..., last_set_done = true) finishes it).
-bool cycle_body(H *h, int l, int pre, int post, bool want_norm = false) {
+template <typename V>
+bool cycle_body(Hier<V> *h, int l, int pre, int post, bool want_norm = false) {
     const int last = (int)h->lv.size() - 1;
     if (l >= last) {
         coarse_solve_level(h);
         return false;
     }
-    Level &L = h->lv[l];
-    Level &C = h->lv[l + 1];
+    Level<V> &L = h->lv[l];
+    Level<V> &C = h->lv[l + 1];
     const bool res_done = smooth_level(h, l, pre, FUSE_RESIDUAL);   // :201 (+ last set's share of :209)
     residual_level(h, l, L.r.p, res_done);                          // :209
     // :210, and the coarse cycle's initial=None -> zeros (:191-192) cleared by the same launch
-    restrict_level(h, l, L.r.p, C.b.p, l + 1 < last ? C.xp : nullptr);
+    restrict_level<V>(h, l, L.r.p, C.b.p, l + 1 < last ? C.xp : nullptr);
     cycle_body(h, l + 1, pre, post);                                // :213
-    prolong_add_level(h, l, C.xp, L.xp);                            // :214, :220/:224
+    prolong_add_level<V>(h, l, C.xp, L.xp);                         // :214, :220/:224
     if (post > 0) return smooth_level(h, l, post, want_norm ? FUSE_NORM : FUSE_NONE);   // :216-222
     return false;
 }
 
-void load_vec(H *h, int l, const double *host, double *dst) {
-    Level &L = h->lv[l];
-    if (L.ord.identity) {
+// Host vectors are double for either V.  A double level in its natural ordering copies
+// straight through; otherwise the vector is staged in `nat` and permuted / converted by one
+// gather (idx == NULL: conversion only).
+template <typename V>
+constexpr bool direct_io(const Level<V> &L) { return std::is_same<V, double>::value && L.ord.identity; }
+
+template <typename V>
+void ensure_nat(Hier<V> *h, int l) {
+    Level<V> &L = h->lv[l];
+    if (!direct_io(L) && L.nat.n < size_t(std::max<int64_t>(L.n, 1))) L.nat.alloc(std::max<int64_t>(L.n, 1));
+}
+
+template <typename V>
+void load_vec(Hier<V> *h, int l, const double *host, V *dst) {
+    Level<V> &L = h->lv[l];
+    if (direct_io(L)) {
         OMG_HIP(hipMemcpyAsync(dst, host, L.n * sizeof(double), hipMemcpyHostToDevice, h->stream));
     } else {
+        ensure_nat(h, l);
         L.nat.upload(host, L.n, h->stream);
-        launch_gather(L.nat.p, L.perm.p, dst, L.n, h->stream);
+        launch_gather<double, V>(L.nat.p, L.ord.identity ? nullptr : L.perm.p, dst, L.n, h->stream);
     }
 }
 
-void fetch_vec(H *h, int l, const double *src, double *host) {
-    Level &L = h->lv[l];
-    if (L.ord.identity) {
+template <typename V>
+void fetch_vec(Hier<V> *h, int l, const V *src, double *host) {
+    Level<V> &L = h->lv[l];
+    if (direct_io(L)) {
         OMG_HIP(hipMemcpyAsync(host, src, L.n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     } else {
-        launch_scatter(src, L.perm.p, L.nat.p, L.n, h->stream);
+        ensure_nat(h, l);
+        launch_scatter<V, double>(src, L.ord.identity ? nullptr : L.perm.p, L.nat.p, L.n, h->stream);
         L.nat.download(host, L.n, h->stream);
     }
     OMG_HIP(hipStreamSynchronize(h->stream));
 }
 
-double read_norm(H *h) {
+template <typename V>
+double read_norm(Hier<V> *h) {
     double v = 0.0;
     OMG_HIP(hipMemcpyAsync(&v, h->norm_dev.p, sizeof(double), hipMemcpyDeviceToHost, h->stream));
     OMG_HIP(hipStreamSynchronize(h->stream));
     return v;
 }
 
-void drop_graph(H *h) {
+template <typename V>
+void drop_graph(Hier<V> *h) {
     if (h->gexec) (void)hipGraphExecDestroy(h->gexec);
     h->gexec = nullptr;
     h->g_pre = h->g_post = -1;
 }
 
 // One level-0 cycle + residual norm into norm_dev; optionally replayed from a hipGraph.
-void run_cycle0(H *h, int pre, int post) {
+template <typename V>
+void run_cycle0(Hier<V> *h, int pre, int post) {
     const bool single = h->lv.size() == 1;
     auto body = [&]() {
         const bool part = cycle_body(h, 0, pre, post, !single);
-        if (!single) norm_level(h, 0, nullptr, part);         // :227
+        if (!single) norm_level<V>(h, 0, nullptr, part);      // :227
         else OMG_HIP(hipMemsetAsync(h->norm_dev.p, 0, sizeof(double), h->stream));   // :232
     };
     if (!h->want_graph || h->profiling) {
@@ -333,13 +376,16 @@ void run_cycle0(H *h, int pre, int post) {
     OMG_HIP(hipGraphLaunch(h->gexec, h->stream));
 }
 
-void check_level(const H *h, int level) {
-    OMG_REQUIRE(h != nullptr, "null hierarchy");
+template <typename V>
+void check_level(const Hier<V> *h, int level) {
     OMG_REQUIRE(level >= 0 && level < (int)h->lv.size(), "level out of range");
 }
 
-std::unique_ptr<H> create(int n_levels, const omg_csr *A, const omg_csr *R, int smoother,
-                          double omega) {
+template <typename V>
+std::unique_ptr<Hier<V>> create(int n_levels, const omg_csr *A, const omg_csr *R, int smoother,
+                                double omega) {
+    using H = Hier<V>;
+    using Lv = Level<V>;
     OMG_REQUIRE(n_levels >= 1, "n_levels must be >= 1");
     OMG_REQUIRE(A != nullptr && (n_levels == 1 || R != nullptr), "A / R array is null");
     OMG_REQUIRE(smoother >= OMG_SMOOTH_GS_LEX && smoother <= OMG_SMOOTH_JACOBI, "unknown smoother");
@@ -363,11 +409,12 @@ std::unique_ptr<H> create(int n_levels, const omg_csr *A, const omg_csr *R, int 
     h->norm_dev.alloc(1);
     // The coarsest operator is inverted once (reference: SuperLU factorisation on every
     // cycle).  That is ~16k tiny dependent launches, so it runs on a helper thread with its
-    // own stream while this thread does the index work of the smoothed levels.
+    // own stream while this thread does the index work of the smoothed levels.  The inverse
+    // is always computed in double; a float hierarchy stores its rounding.
     int device = 0;
     OMG_HIP(hipGetDevice(&device));
     {
-        Level &L = h->lv.back();
+        Lv &L = h->lv.back();
         L.n = A[n_levels - 1].n_rows;
         L.ord.identity = true;
         L.ord.sets = {0, L.n};
@@ -379,11 +426,21 @@ std::unique_ptr<H> create(int n_levels, const omg_csr *A, const omg_csr *R, int 
         try {
             OMG_HIP(hipSetDevice(device));
             OMG_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
-            Level &L = h->lv.back();
+            Lv &L = h->lv.back();
             HostCsr Ap = permute_csr(A[n_levels - 1], nullptr, nullptr);
             L.A.upload(Ap, L.ord.sets, s);
-            h->coarse_inv.alloc(std::max<size_t>(size_t(L.n) * size_t(L.n), 1));
-            dense_inverse_from_csr(L.A, h->coarse_inv.p, s);
+            const size_t nn = std::max<size_t>(size_t(L.n) * size_t(L.n), 1);
+            h->coarse_inv.alloc(nn);
+            if constexpr (std::is_same<V, double>::value) {
+                dense_inverse_from_csr(L.A, h->coarse_inv.p, s);
+            } else {
+                DevCsr A64;
+                A64.upload(Ap, L.ord.sets, s);
+                DevBuf<double> inv64(nn);
+                dense_inverse_from_csr(A64, inv64.p, s);
+                launch_gather<double, V>(inv64.p, nullptr, h->coarse_inv.p, int64_t(size_t(L.n) * size_t(L.n)), s);
+                OMG_HIP(hipStreamSynchronize(s));     // before inv64 is released
+            }
         } catch (const Error &e) {
             inv_code = e.code;
             inv_msg = e.what();
@@ -396,12 +453,12 @@ std::unique_ptr<H> create(int n_levels, const omg_csr *A, const omg_csr *R, int 
     struct Joiner { std::thread &t; ~Joiner() { if (t.joinable()) t.join(); } } joiner{inverter};
     // orderings first (restrictions need both neighbours')
     for (int l = 0; l + 1 < n_levels; ++l) {
-        Level &L = h->lv[l];
+        Lv &L = h->lv[l];
         L.n = A[l].n_rows;
         L.ord = make_ordering(A[l], smoother);
     }
     for (int l = 0; l < n_levels; ++l) {
-        Level &L = h->lv[l];
+        Lv &L = h->lv[l];
         const bool id = L.ord.identity;
         if (l + 1 < n_levels) {
             HostCsr Ap = permute_csr(A[l], id ? nullptr : L.ord.perm.data(), id ? nullptr : L.ord.inv.data());
@@ -448,12 +505,7 @@ std::unique_ptr<H> create(int n_levels, const omg_csr *A, const omg_csr *R, int 
     return h;
 }
 
-void ensure_nat(H *h, int l) {
-    Level &L = h->lv[l];
-    if (!L.ord.identity && L.nat.n < size_t(L.n)) L.nat.alloc(L.n);
-}
-
-// A throw-away single-level "hierarchy" for the standalone entry points.
+// A throw-away single operator for the standalone entry points.
 struct OneShot {
     DevCsr A;
     hipStream_t s = nullptr;
@@ -478,6 +530,24 @@ int guarded(F &&f) {
     }
 }
 
+// Runs f(Hier<V> *) on whichever instantiation the handle holds.
+template <typename F>
+void with(omg_hierarchy *h, F &&f) {
+    OMG_REQUIRE(h != nullptr && (h->d || h->f), "null hierarchy");
+    if (h->f) f(h->f.get());
+    else f(h->d.get());
+}
+
+template <typename F>
+void with(const omg_hierarchy *h, F &&f) {
+    OMG_REQUIRE(h != nullptr && (h->d || h->f), "null hierarchy");
+    if (h->f) f(static_cast<const Hier<float> *>(h->f.get()));
+    else f(static_cast<const Hier<double> *>(h->d.get()));
+}
+
+template <typename HP>
+using value_of = typename std::remove_cv<typename std::remove_pointer<HP>::type>::type::value_type;
+
 }  // namespace
 }  // namespace omg
 
@@ -486,7 +556,7 @@ using namespace omg;
 extern "C" {
 
 const char *omg_last_error(void) { return g_last_error.c_str(); }
-const char *omg_version(void) { return "openmg_hip 0.1 (gfx950)"; }
+const char *omg_version(void) { return "openmg_hip 0.2 (gfx950; f64, f32)"; }
 
 int omg_device_count(int *count) {
     return guarded([&] {
@@ -501,134 +571,173 @@ int omg_set_device(int device) {
     return guarded([&] { require_device(); OMG_HIP(hipSetDevice(device)); });
 }
 
-int omg_hierarchy_create(int n_levels, const omg_csr *A, const omg_csr *R, int smoother,
-                         double omega, omg_hierarchy **out) {
+int omg_hierarchy_create_ex(int n_levels, const omg_csr *A, const omg_csr *R, int smoother,
+                            double omega, int dtype, omg_hierarchy **out) {
     return guarded([&] {
         OMG_REQUIRE(out, "out is null");
         *out = nullptr;
-        *out = create(n_levels, A, R, smoother, omega).release();
+        OMG_REQUIRE(dtype == OMG_DTYPE_F64 || dtype == OMG_DTYPE_F32, "unknown dtype");
+        std::unique_ptr<omg_hierarchy> h(new omg_hierarchy);
+        if (dtype == OMG_DTYPE_F32) h->f = create<float>(n_levels, A, R, smoother, omega);
+        else h->d = create<double>(n_levels, A, R, smoother, omega);
+        *out = h.release();
+    });
+}
+
+int omg_hierarchy_create(int n_levels, const omg_csr *A, const omg_csr *R, int smoother,
+                         double omega, omg_hierarchy **out) {
+    return omg_hierarchy_create_ex(n_levels, A, R, smoother, omega, OMG_DTYPE_F64, out);
+}
+
+int omg_hierarchy_dtype(const omg_hierarchy *h, int *dtype) {
+    return guarded([&] {
+        OMG_REQUIRE(h && dtype, "null argument");
+        *dtype = h->f ? OMG_DTYPE_F32 : OMG_DTYPE_F64;
     });
 }
 
 int omg_hierarchy_destroy(omg_hierarchy *h) {
     return guarded([&] {
         if (!h) return;
-        (void)hipStreamSynchronize(h->stream);
+        if (h->d || h->f) with(h, [&](auto *hh) { (void)hipStreamSynchronize(hh->stream); });
         delete h;
     });
 }
 
 int omg_hierarchy_set_stream(omg_hierarchy *h, void *hip_stream) {
     return guarded([&] {
-        OMG_REQUIRE(h, "null hierarchy");
-        OMG_HIP(hipStreamSynchronize(h->stream));
-        drop_graph(h);
-        h->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : h->own;
+        with(h, [&](auto *hh) {
+            OMG_HIP(hipStreamSynchronize(hh->stream));
+            drop_graph(hh);
+            hh->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : hh->own;
+        });
     });
 }
 
 int omg_hierarchy_sync(omg_hierarchy *h) {
-    return guarded([&] { OMG_REQUIRE(h, "null hierarchy"); OMG_HIP(hipStreamSynchronize(h->stream)); });
+    return guarded([&] { with(h, [&](auto *hh) { OMG_HIP(hipStreamSynchronize(hh->stream)); }); });
 }
 
 int omg_hierarchy_level_rows(const omg_hierarchy *h, int level, int64_t *n_rows) {
-    return guarded([&] { check_level(h, level); OMG_REQUIRE(n_rows, "null"); *n_rows = h->lv[level].n; });
+    return guarded([&] {
+        with(h, [&](auto *hh) { check_level(hh, level); OMG_REQUIRE(n_rows, "null"); *n_rows = hh->lv[level].n; });
+    });
 }
 
 int omg_hierarchy_level_sets(const omg_hierarchy *h, int level, int64_t *n_sets) {
-    return guarded([&] { check_level(h, level); OMG_REQUIRE(n_sets, "null"); *n_sets = (int64_t)h->lv[level].A.n_sets(); });
+    return guarded([&] {
+        with(h, [&](auto *hh) {
+            check_level(hh, level);
+            OMG_REQUIRE(n_sets, "null");
+            *n_sets = (int64_t)hh->lv[level].A.n_sets();
+        });
+    });
 }
 
 int omg_hierarchy_level_fused(const omg_hierarchy *h, int level, int *fused) {
     return guarded([&] {
-        check_level(h, level);
-        OMG_REQUIRE(fused, "null");
-        *fused = (level + 1 < (int)h->lv.size() && can_fuse(h, h->lv[level])) ? 1 : 0;
+        with(h, [&](auto *hh) {
+            check_level(hh, level);
+            OMG_REQUIRE(fused, "null");
+            *fused = (level + 1 < (int)hh->lv.size() && can_fuse(hh, hh->lv[level])) ? 1 : 0;
+        });
     });
 }
 
 int omg_hierarchy_set_info(const omg_hierarchy *h, int level, int set, int64_t *rows, int64_t *nnz) {
     return guarded([&] {
-        check_level(h, level);
-        const DevCsr &A = h->lv[level].A;
-        OMG_REQUIRE(set >= 0 && size_t(set) < A.n_sets() && rows && nnz, "set out of range / null");
-        *rows = A.sets[set + 1] - A.sets[set];
-        *nnz = A.set_nnz[set];
+        with(h, [&](auto *hh) {
+            check_level(hh, level);
+            const auto &A = hh->lv[level].A;
+            OMG_REQUIRE(set >= 0 && size_t(set) < A.n_sets() && rows && nnz, "set out of range / null");
+            *rows = A.sets[set + 1] - A.sets[set];
+            *nnz = A.set_nnz[set];
+        });
     });
 }
 
 int omg_vcycle(omg_hierarchy *h, int level, const double *b, double *x, int pre, int post,
                double *norm) {
     return guarded([&] {
-        check_level(h, level);
-        OMG_REQUIRE(b && x, "b / x is null");
-        OMG_REQUIRE(pre >= 0 && post >= 0, "negative sweep count");
-        ensure_nat(h, level);
-        Level &L = h->lv[level];
-        h->resident = false;
-        load_vec(h, level, b, L.b.p);
-        load_vec(h, level, x, L.xp);
-        const int last = (int)h->lv.size() - 1;
-        const bool part = cycle_body(h, level, pre, post, level < last);
-        double nv = 0.0;
-        if (level < last) {
-            norm_level(h, level, nullptr, part);
-            nv = read_norm(h);
-        }
-        fetch_vec(h, level, L.xp, x);
-        if (norm) *norm = nv;
+        with(h, [&](auto *hh) {
+            using V = value_of<decltype(hh)>;
+            check_level(hh, level);
+            OMG_REQUIRE(b && x, "b / x is null");
+            OMG_REQUIRE(pre >= 0 && post >= 0, "negative sweep count");
+            auto &L = hh->lv[level];
+            hh->resident = false;
+            load_vec(hh, level, b, L.b.p);
+            load_vec(hh, level, x, L.xp);
+            const int last = (int)hh->lv.size() - 1;
+            const bool part = cycle_body(hh, level, pre, post, level < last);
+            double nv = 0.0;
+            if (level < last) {
+                norm_level<V>(hh, level, nullptr, part);
+                nv = read_norm(hh);
+            }
+            fetch_vec<V>(hh, level, L.xp, x);
+            if (norm) *norm = nv;
+        });
     });
 }
 
 // Device-pointer V-cycle for callers that already live on the GPU (the multi-GPU runner uses
-// a replicated hierarchy as its coarse solver): b_dev, x_dev are level-0 vectors in natural
-// numbering; x starts from zero (openmg/__init__.py:191-192); enqueued on `hip_stream`, no
-// host synchronisation.
+// a replicated hierarchy as its coarse solver): b_dev, x_dev are level-0 DOUBLE vectors in
+// natural numbering; x starts from zero (openmg/__init__.py:191-192); enqueued on
+// `hip_stream`, no host synchronisation.
 int omg_hierarchy_cycle_dev(omg_hierarchy *h, const double *b_dev, double *x_dev, int pre, int post,
                             void *hip_stream) {
     return guarded([&] {
-        check_level(h, 0);
-        OMG_REQUIRE(b_dev && x_dev && pre >= 0 && post >= 0, "bad argument");
-        Level &L = h->lv[0];
-        hipStream_t keep = h->stream;
-        h->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : h->own;
-        h->resident = false;
-        try {
-            if (L.ord.identity) OMG_HIP(hipMemcpyAsync(L.b.p, b_dev, L.n * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
-            else launch_gather(b_dev, L.perm.p, L.b.p, L.n, h->stream);
-            if (h->lv.size() > 1) OMG_HIP(hipMemsetAsync(L.xp, 0, L.n * sizeof(double), h->stream));
-            cycle_body(h, 0, pre, post);
-            if (L.ord.identity) OMG_HIP(hipMemcpyAsync(x_dev, L.xp, L.n * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
-            else launch_scatter(L.xp, L.perm.p, x_dev, L.n, h->stream);
-        } catch (...) {
-            h->stream = keep;
-            throw;
-        }
-        h->stream = keep;
+        with(h, [&](auto *hh) {
+            using V = value_of<decltype(hh)>;
+            check_level(hh, 0);
+            OMG_REQUIRE(b_dev && x_dev && pre >= 0 && post >= 0, "bad argument");
+            auto &L = hh->lv[0];
+            hipStream_t keep = hh->stream;
+            hh->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : hh->own;
+            hh->resident = false;
+            try {
+                const int32_t *perm = L.ord.identity ? nullptr : L.perm.p;
+                if (direct_io(L)) OMG_HIP(hipMemcpyAsync(L.b.p, b_dev, L.n * sizeof(double), hipMemcpyDeviceToDevice, hh->stream));
+                else launch_gather<double, V>(b_dev, perm, L.b.p, L.n, hh->stream);
+                if (hh->lv.size() > 1) OMG_HIP(hipMemsetAsync(L.xp, 0, L.n * sizeof(V), hh->stream));
+                cycle_body(hh, 0, pre, post);
+                if (direct_io(L)) OMG_HIP(hipMemcpyAsync(x_dev, L.xp, L.n * sizeof(double), hipMemcpyDeviceToDevice, hh->stream));
+                else launch_scatter<V, double>(L.xp, perm, x_dev, L.n, hh->stream);
+            } catch (...) {
+                hh->stream = keep;
+                throw;
+            }
+            hh->stream = keep;
+        });
     });
 }
 
 int omg_resident_load(omg_hierarchy *h, const double *b, const double *x0) {
     return guarded([&] {
-        check_level(h, 0);
-        OMG_REQUIRE(b, "b is null");
-        ensure_nat(h, 0);
-        Level &L = h->lv[0];
-        load_vec(h, 0, b, L.b.p);
-        if (x0) load_vec(h, 0, x0, L.xp);
-        else OMG_HIP(hipMemsetAsync(L.xp, 0, L.n * sizeof(double), h->stream));
-        OMG_HIP(hipStreamSynchronize(h->stream));
-        h->resident = true;
+        with(h, [&](auto *hh) {
+            using V = value_of<decltype(hh)>;
+            check_level(hh, 0);
+            OMG_REQUIRE(b, "b is null");
+            auto &L = hh->lv[0];
+            load_vec(hh, 0, b, L.b.p);
+            if (x0) load_vec(hh, 0, x0, L.xp);
+            else OMG_HIP(hipMemsetAsync(L.xp, 0, L.n * sizeof(V), hh->stream));
+            OMG_HIP(hipStreamSynchronize(hh->stream));
+            hh->resident = true;
+        });
     });
 }
 
 int omg_resident_cycle(omg_hierarchy *h, int pre, int post, double *norm) {
     return guarded([&] {
-        check_level(h, 0);
-        OMG_REQUIRE(h->resident, "omg_resident_load has not been called");
-        OMG_REQUIRE(pre >= 0 && post >= 0, "negative sweep count");
-        run_cycle0(h, pre, post);
-        if (norm) *norm = read_norm(h);
+        with(h, [&](auto *hh) {
+            check_level(hh, 0);
+            OMG_REQUIRE(hh->resident, "omg_resident_load has not been called");
+            OMG_REQUIRE(pre >= 0 && post >= 0, "negative sweep count");
+            run_cycle0(hh, pre, post);
+            if (norm) *norm = read_norm(hh);
+        });
     });
 }
 
@@ -638,185 +747,206 @@ int omg_resident_cycle(omg_hierarchy *h, int pre, int post, double *norm) {
 // metric, measured on the operator as it sits in HBM inside the V-cycle.
 int omg_resident_spmv_time(omg_hierarchy *h, int reps, double *avg_ms) {
     return guarded([&] {
-        check_level(h, 0);
-        OMG_REQUIRE(h->resident && reps > 0 && avg_ms, "nothing resident / bad argument");
-        OMG_REQUIRE(h->lv.size() > 1, "single-level hierarchy has no smoothed operator");
-        Level &L = h->lv[0];
-        RowArgs a;
-        a.x = L.xp; a.y = L.r.p;
-        launch_rows(L.A, ROW_SPMV, -1, a, h->stream);              // warm-up
-        hipEvent_t e0, e1;
-        OMG_HIP(hipEventCreate(&e0));
-        OMG_HIP(hipEventCreate(&e1));
-        OMG_HIP(hipEventRecord(e0, h->stream));
-        for (int i = 0; i < reps; ++i) launch_rows(L.A, ROW_SPMV, -1, a, h->stream);
-        OMG_HIP(hipEventRecord(e1, h->stream));
-        OMG_HIP(hipEventSynchronize(e1));
-        float ms = 0.f;
-        OMG_HIP(hipEventElapsedTime(&ms, e0, e1));
-        (void)hipEventDestroy(e0);
-        (void)hipEventDestroy(e1);
-        *avg_ms = double(ms) / reps;
+        with(h, [&](auto *hh) {
+            using V = value_of<decltype(hh)>;
+            check_level(hh, 0);
+            OMG_REQUIRE(hh->resident && reps > 0 && avg_ms, "nothing resident / bad argument");
+            OMG_REQUIRE(hh->lv.size() > 1, "single-level hierarchy has no smoothed operator");
+            auto &L = hh->lv[0];
+            RowArgsT<V> a;
+            a.x = L.xp; a.y = L.r.p;
+            launch_rows(L.A, ROW_SPMV, -1, a, hh->stream);              // warm-up
+            hipEvent_t e0, e1;
+            OMG_HIP(hipEventCreate(&e0));
+            OMG_HIP(hipEventCreate(&e1));
+            OMG_HIP(hipEventRecord(e0, hh->stream));
+            for (int i = 0; i < reps; ++i) launch_rows(L.A, ROW_SPMV, -1, a, hh->stream);
+            OMG_HIP(hipEventRecord(e1, hh->stream));
+            OMG_HIP(hipEventSynchronize(e1));
+            float ms = 0.f;
+            OMG_HIP(hipEventElapsedTime(&ms, e0, e1));
+            (void)hipEventDestroy(e0);
+            (void)hipEventDestroy(e1);
+            *avg_ms = double(ms) / reps;
+        });
     });
 }
 
 int omg_resident_fetch(omg_hierarchy *h, double *x) {
     return guarded([&] {
-        check_level(h, 0);
-        OMG_REQUIRE(h->resident && x, "nothing resident / x is null");
-        fetch_vec(h, 0, h->lv[0].xp, x);
+        with(h, [&](auto *hh) {
+            using V = value_of<decltype(hh)>;
+            check_level(hh, 0);
+            OMG_REQUIRE(hh->resident && x, "nothing resident / x is null");
+            fetch_vec<V>(hh, 0, hh->lv[0].xp, x);
+        });
     });
 }
 
 int omg_resident_use_graph(omg_hierarchy *h, int enable) {
     return guarded([&] {
-        OMG_REQUIRE(h, "null hierarchy");
-        OMG_HIP(hipStreamSynchronize(h->stream));
-        h->want_graph = enable != 0;
-        if (!enable) drop_graph(h);
+        with(h, [&](auto *hh) {
+            OMG_HIP(hipStreamSynchronize(hh->stream));
+            hh->want_graph = enable != 0;
+            if (!enable) drop_graph(hh);
+        });
     });
 }
 
 int omg_solve(omg_hierarchy *h, const double *b, double *x, int pre, int post, int max_cycles,
               double threshold, int *cycles_done, double *norm) {
     return guarded([&] {
-        check_level(h, 0);
-        OMG_REQUIRE(b && x, "b / x is null");
-        OMG_REQUIRE(max_cycles > 0 || threshold > 0.0,
-                    "Either threshold or cycles must be > 0");   // openmg/__init__.py:118-119
-        ensure_nat(h, 0);
-        Level &L = h->lv[0];
-        load_vec(h, 0, b, L.b.p);
-        load_vec(h, 0, x, L.xp);
-        h->resident = true;
-        int cycle = 0;
-        double nv = 0.0;
-        for (;;) {                                                // :112, :132-138
-            run_cycle0(h, pre, post);
-            nv = read_norm(h);
-            ++cycle;
-            const bool by_cycles = max_cycles > 0 && cycle >= max_cycles;
-            const bool by_norm = threshold > 0.0 && nv < threshold;
-            if (by_cycles || by_norm) break;
-        }
-        fetch_vec(h, 0, L.xp, x);
-        if (cycles_done) *cycles_done = cycle;
-        if (norm) *norm = nv;
+        with(h, [&](auto *hh) {
+            using V = value_of<decltype(hh)>;
+            check_level(hh, 0);
+            OMG_REQUIRE(b && x, "b / x is null");
+            OMG_REQUIRE(max_cycles > 0 || threshold > 0.0,
+                        "Either threshold or cycles must be > 0");   // openmg/__init__.py:118-119
+            auto &L = hh->lv[0];
+            load_vec(hh, 0, b, L.b.p);
+            load_vec(hh, 0, x, L.xp);
+            hh->resident = true;
+            int cycle = 0;
+            double nv = 0.0;
+            for (;;) {                                                // :112, :132-138
+                run_cycle0(hh, pre, post);
+                nv = read_norm(hh);
+                ++cycle;
+                const bool by_cycles = max_cycles > 0 && cycle >= max_cycles;
+                const bool by_norm = threshold > 0.0 && nv < threshold;
+                if (by_cycles || by_norm) break;
+            }
+            fetch_vec<V>(hh, 0, L.xp, x);
+            if (cycles_done) *cycles_done = cycle;
+            if (norm) *norm = nv;
+        });
     });
 }
 
 int omg_profile_enable(omg_hierarchy *h, int enable) {
     return guarded([&] {
-        OMG_REQUIRE(h, "null hierarchy");
-        OMG_HIP(hipStreamSynchronize(h->stream));
-        for (auto &e : h->events) { h->event_pool.push_back(e.a); h->event_pool.push_back(e.b); }
-        h->events.clear();
-        std::memset(h->prof_n, 0, sizeof(h->prof_n));
-        std::memset(h->prof_ms, 0, sizeof(h->prof_ms));
-        h->profiling = (unsigned)enable;   // bit c = class c; -1 = all classes
+        with(h, [&](auto *hh) {
+            OMG_HIP(hipStreamSynchronize(hh->stream));
+            for (auto &e : hh->events) { hh->event_pool.push_back(e.a); hh->event_pool.push_back(e.b); }
+            hh->events.clear();
+            std::memset(hh->prof_n, 0, sizeof(hh->prof_n));
+            std::memset(hh->prof_ms, 0, sizeof(hh->prof_ms));
+            hh->profiling = (unsigned)enable;   // bit c = class c; -1 = all classes
+        });
     });
 }
 
 int omg_profile_read(omg_hierarchy *h, int64_t *launches, double *total_ms) {
     return guarded([&] {
-        OMG_REQUIRE(h && launches && total_ms, "null argument");
-        OMG_HIP(hipStreamSynchronize(h->stream));
-        for (auto &e : h->events) {
-            float ms = 0.f;
-            OMG_HIP(hipEventElapsedTime(&ms, e.a, e.b));
-            h->prof_n[e.cls] += 1;
-            h->prof_ms[e.cls] += ms;
-            h->event_pool.push_back(e.a);
-            h->event_pool.push_back(e.b);
-        }
-        h->events.clear();
-        for (int c = 0; c < OMG_PROFILE_CLASSES; ++c) { launches[c] = h->prof_n[c]; total_ms[c] = h->prof_ms[c]; }
+        OMG_REQUIRE(launches && total_ms, "null argument");
+        with(h, [&](auto *hh) {
+            OMG_HIP(hipStreamSynchronize(hh->stream));
+            for (auto &e : hh->events) {
+                float ms = 0.f;
+                OMG_HIP(hipEventElapsedTime(&ms, e.a, e.b));
+                hh->prof_n[e.cls] += 1;
+                hh->prof_ms[e.cls] += ms;
+                hh->event_pool.push_back(e.a);
+                hh->event_pool.push_back(e.b);
+            }
+            hh->events.clear();
+            for (int c = 0; c < OMG_PROFILE_CLASSES; ++c) { launches[c] = hh->prof_n[c]; total_ms[c] = hh->prof_ms[c]; }
+        });
     });
 }
 
 // ---- single level operations ------------------------------------------------------------
 int omg_level_smooth(omg_hierarchy *h, int level, const double *b, double *x, int iterations) {
     return guarded([&] {
-        check_level(h, level);
-        OMG_REQUIRE(level < (int)h->lv.size() - 1, "the coarsest level has no smoother");
-        OMG_REQUIRE(b && x && iterations >= 0, "bad argument");
-        ensure_nat(h, level);
-        Level &L = h->lv[level];
-        h->resident = false;
-        load_vec(h, level, b, L.b.p);
-        load_vec(h, level, x, L.xp);
-        smooth_level(h, level, iterations);
-        fetch_vec(h, level, L.xp, x);
+        with(h, [&](auto *hh) {
+            using V = value_of<decltype(hh)>;
+            check_level(hh, level);
+            OMG_REQUIRE(level < (int)hh->lv.size() - 1, "the coarsest level has no smoother");
+            OMG_REQUIRE(b && x && iterations >= 0, "bad argument");
+            auto &L = hh->lv[level];
+            hh->resident = false;
+            load_vec(hh, level, b, L.b.p);
+            load_vec(hh, level, x, L.xp);
+            smooth_level(hh, level, iterations);
+            fetch_vec<V>(hh, level, L.xp, x);
+        });
     });
 }
 
 int omg_level_residual(omg_hierarchy *h, int level, const double *b, const double *x, double *r,
                        double *norm) {
     return guarded([&] {
-        check_level(h, level);
-        OMG_REQUIRE(level < (int)h->lv.size() - 1, "use omg_residual for the coarsest operator");
-        OMG_REQUIRE(b && x && r, "null vector");
-        ensure_nat(h, level);
-        Level &L = h->lv[level];
-        h->resident = false;
-        load_vec(h, level, b, L.b.p);
-        load_vec(h, level, x, L.xp);
-        if (norm) {
-            norm_level(h, level, L.r.p);
-            *norm = read_norm(h);
-        } else {
-            residual_level(h, level, L.r.p);
-        }
-        fetch_vec(h, level, L.r.p, r);
+        with(h, [&](auto *hh) {
+            using V = value_of<decltype(hh)>;
+            check_level(hh, level);
+            OMG_REQUIRE(level < (int)hh->lv.size() - 1, "use omg_residual for the coarsest operator");
+            OMG_REQUIRE(b && x && r, "null vector");
+            auto &L = hh->lv[level];
+            hh->resident = false;
+            load_vec(hh, level, b, L.b.p);
+            load_vec(hh, level, x, L.xp);
+            if (norm) {
+                norm_level<V>(hh, level, L.r.p);
+                *norm = read_norm(hh);
+            } else {
+                residual_level<V>(hh, level, L.r.p);
+            }
+            fetch_vec<V>(hh, level, L.r.p, r);
+        });
     });
 }
 
 int omg_level_restrict(omg_hierarchy *h, int level, const double *fine, double *coarse) {
     return guarded([&] {
-        check_level(h, level);
-        OMG_REQUIRE(level < (int)h->lv.size() - 1, "no restriction below the coarsest level");
-        OMG_REQUIRE(fine && coarse, "null vector");
-        ensure_nat(h, level);
-        ensure_nat(h, level + 1);
-        Level &L = h->lv[level];
-        Level &C = h->lv[level + 1];
-        h->resident = false;
-        load_vec(h, level, fine, L.r.p);
-        restrict_level(h, level, L.r.p, C.b.p);
-        fetch_vec(h, level + 1, C.b.p, coarse);
+        with(h, [&](auto *hh) {
+            using V = value_of<decltype(hh)>;
+            check_level(hh, level);
+            OMG_REQUIRE(level < (int)hh->lv.size() - 1, "no restriction below the coarsest level");
+            OMG_REQUIRE(fine && coarse, "null vector");
+            auto &L = hh->lv[level];
+            auto &C = hh->lv[level + 1];
+            hh->resident = false;
+            load_vec(hh, level, fine, L.r.p);
+            restrict_level<V>(hh, level, L.r.p, C.b.p);
+            fetch_vec<V>(hh, level + 1, C.b.p, coarse);
+        });
     });
 }
 
 int omg_level_prolong_add(omg_hierarchy *h, int level, const double *coarse, double *fine_inout) {
     return guarded([&] {
-        check_level(h, level);
-        OMG_REQUIRE(level < (int)h->lv.size() - 1, "no prolongation below the coarsest level");
-        OMG_REQUIRE(coarse && fine_inout, "null vector");
-        ensure_nat(h, level);
-        ensure_nat(h, level + 1);
-        Level &L = h->lv[level];
-        Level &C = h->lv[level + 1];
-        h->resident = false;
-        load_vec(h, level + 1, coarse, C.xp);
-        load_vec(h, level, fine_inout, L.xp);
-        prolong_add_level(h, level, C.xp, L.xp);
-        fetch_vec(h, level, L.xp, fine_inout);
+        with(h, [&](auto *hh) {
+            using V = value_of<decltype(hh)>;
+            check_level(hh, level);
+            OMG_REQUIRE(level < (int)hh->lv.size() - 1, "no prolongation below the coarsest level");
+            OMG_REQUIRE(coarse && fine_inout, "null vector");
+            auto &L = hh->lv[level];
+            auto &C = hh->lv[level + 1];
+            hh->resident = false;
+            load_vec(hh, level + 1, coarse, C.xp);
+            load_vec(hh, level, fine_inout, L.xp);
+            prolong_add_level<V>(hh, level, C.xp, L.xp);
+            fetch_vec<V>(hh, level, L.xp, fine_inout);
+        });
     });
 }
 
 int omg_coarse_solve(omg_hierarchy *h, const double *b, double *x) {
     return guarded([&] {
-        OMG_REQUIRE(h && b && x, "null argument");
-        const int last = (int)h->lv.size() - 1;
-        Level &L = h->lv[last];
-        h->resident = last != 0 ? h->resident : false;
-        load_vec(h, last, b, L.b.p);
-        coarse_solve_level(h);
-        fetch_vec(h, last, L.xp, x);
+        OMG_REQUIRE(b && x, "null argument");
+        with(h, [&](auto *hh) {
+            using V = value_of<decltype(hh)>;
+            const int last = (int)hh->lv.size() - 1;
+            auto &L = hh->lv[last];
+            hh->resident = last != 0 ? hh->resident : false;
+            load_vec(hh, last, b, L.b.p);
+            coarse_solve_level(hh);
+            fetch_vec<V>(hh, last, L.xp, x);
+        });
     });
 }
 
-// ---- standalone --------------------------------------------------------------------------
+// ---- standalone (double only: these mirror the reference's fp64 operators one to one) -------
 static void standalone_rows(const omg_csr *A, int mode, const double *x, const double *b,
                             double *y, double *norm) {
     OMG_REQUIRE(A && x && y, "null argument");
@@ -854,6 +984,7 @@ int omg_residual(const omg_csr *A, const double *b, const double *x, double *r, 
 int omg_gauss_seidel(const omg_csr *A, const double *b, double *x, int smoother, double omega,
                      int iterations, double threshold, int *sweeps_done) {
     return guarded([&] {
+        using H = Hier<double>;
         OMG_REQUIRE(A && b && x, "null argument");
         OMG_REQUIRE(A->n_rows == A->n_cols, "smoother needs a square operator");
         validate_csr(*A, "A");
@@ -868,7 +999,7 @@ int omg_gauss_seidel(const omg_csr *A, const double *b, double *x, int smoother,
         h->stream = h->own;
         h->lv.resize(2);           // level 1 is a dummy so that level 0 counts as "smoothed"
         h->norm_dev.alloc(1);
-        Level &L = h->lv[0];
+        Level<double> &L = h->lv[0];
         L.n = A->n_rows;
         L.ord = make_ordering(*A, smoother);
         const bool id = L.ord.identity;
@@ -876,7 +1007,7 @@ int omg_gauss_seidel(const omg_csr *A, const double *b, double *x, int smoother,
             HostCsr Ap = permute_csr(*A, id ? nullptr : L.ord.perm.data(), id ? nullptr : L.ord.inv.data());
             L.A.upload(Ap, L.ord.sets, h->stream);
         }
-        if (!id) { L.perm.alloc(L.n); L.perm.upload(L.ord.perm.data(), L.n, h->stream); L.nat.alloc(L.n); }
+        if (!id) { L.perm.alloc(L.n); L.perm.upload(L.ord.perm.data(), L.n, h->stream); }
         L.x.alloc(std::max<int64_t>(L.n, 1));
         L.b.alloc(std::max<int64_t>(L.n, 1));
         if (smoother == OMG_SMOOTH_JACOBI) L.tmp.alloc(std::max<int64_t>(L.n, 1));
@@ -891,7 +1022,7 @@ int omg_gauss_seidel(const omg_csr *A, const double *b, double *x, int smoother,
             const bool by_iter = iterations >= 0 && it >= iterations;
             bool by_norm = false;
             if (threshold >= 0.0) {
-                norm_level(h.get(), 0, nullptr);
+                norm_level<double>(h.get(), 0, nullptr);
                 by_norm = read_norm(h.get()) < threshold;
             }
             return by_iter || by_norm;
@@ -900,7 +1031,7 @@ int omg_gauss_seidel(const omg_csr *A, const double *b, double *x, int smoother,
             smooth_level(h.get(), 0, 1);
             ++it;
         }
-        fetch_vec(h.get(), 0, L.xp, x);
+        fetch_vec<double>(h.get(), 0, L.xp, x);
         if (sweeps_done) *sweeps_done = it;
     });
 }
@@ -917,7 +1048,7 @@ int omg_direct_solve(const omg_csr *A, const double *b, double *x) {
         DevBuf<double> inv(std::max<size_t>(size_t(n) * size_t(n), 1)), db(std::max<int64_t>(n, 1)), dx(std::max<int64_t>(n, 1));
         dense_inverse_from_csr(os.A, inv.p, os.s);
         db.upload(b, n, os.s);
-        launch_dense_gemv(inv.p, db.p, dx.p, n, os.s);
+        launch_dense_gemv<double>(inv.p, db.p, dx.p, n, os.s);
         dx.download(x, n, os.s);
         OMG_HIP(hipStreamSynchronize(os.s));
     });

@@ -4,6 +4,7 @@
 #include <atomic>
 #include <cstring>
 #include <thread>
+#include <type_traits>
 
 #include "common.h"
 
@@ -240,7 +241,8 @@ void make_row_blocks(const std::vector<int32_t> &indptr, const std::vector<int64
     blk_rows.push_back(int32_t(sets.empty() ? 0 : sets.back()));
 }
 
-void DevCsr::upload(const HostCsr &A, const std::vector<int64_t> &sets_in, hipStream_t s) {
+template <typename V>
+void DevCsrT<V>::upload(const HostCsr &A, const std::vector<int64_t> &sets_in, hipStream_t s) {
     n_rows = A.n_rows;
     n_cols = A.n_cols;
     nnz = A.nnz;
@@ -278,9 +280,20 @@ void DevCsr::upload(const HostCsr &A, const std::vector<int64_t> &sets_in, hipSt
     blk_rows.alloc(info.size());
     indptr.upload(A.indptr.data(), A.indptr.size(), s);
     indices.upload(A.indices.data(), A.indices.size(), s);
-    data.upload(A.data.data(), A.data.size(), s);
+    std::vector<V> narrowed;             // float operator: round the fp64 entries once, here
+    const V *vals;
+    if constexpr (std::is_same<V, double>::value) {
+        vals = A.data.data();
+    } else {
+        narrowed.assign(A.data.begin(), A.data.end());
+        vals = narrowed.data();
+    }
+    data.upload(vals, A.data.size(), s);
     blk_rows.upload(info.data(), info.size(), s);
     OMG_HIP(hipStreamSynchronize(s));   // host staging vectors may die after return
 }
+
+template struct DevCsrT<double>;
+template struct DevCsrT<float>;
 
 }  // namespace omg
