@@ -39,7 +39,7 @@ def residual_bytes(n, nnz, w=8):
     return spmv_bytes(n, nnz, w) + w * n
 
 
-def build_problem(size, grids, smoother):
+def build_problem(size, grids, smoother, dtype="float64"):
     import openmg_amd
     from openmg_amd import _hip, operators
     shape = (size, size, size)
@@ -48,7 +48,7 @@ def build_problem(size, grids, smoother):
     b = A0 @ u_true
     R = operators.restrictionList(shape, grids - 2, 8)          # gridLevels = grids - 1 -> coarsestLevel = grids - 2 (D5)
     A = operators.coeffecientList(A0, R)                        # Galerkin products on the device
-    h = _hip.Hierarchy(A, R, smoother=smoother)
+    h = _hip.Hierarchy(A, R, smoother=smoother, dtype=dtype)
     meta = {"n": A0.shape[0], "nnz": A0.nnz, "grids": len(A),
             "level_rows": [M.shape[0] for M in A], "level_nnz": [M.nnz for M in A]}
     return h, b, meta
@@ -93,6 +93,8 @@ def main():
     ap.add_argument("--size", type=int, default=256, help="grid extent per axis (default: BASELINE config 3)")
     ap.add_argument("--grids", type=int, default=5)
     ap.add_argument("--smoother", default="colour")
+    ap.add_argument("--dtype", default="f64", choices=["f64", "f32"],
+                    help="precision the levels are stored / computed in (f64 = BASELINE configs[2], the default)")
     ap.add_argument("--graph", type=int, default=0, help="replay the cycle from a hipGraph")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--dist", type=int, default=0, help="force the multi-GPU code path even with one rank (debug)")
@@ -116,7 +118,8 @@ def main():
     torch.cuda.set_device(0)
 
     t_setup = time.perf_counter()
-    h, b, meta = build_problem(args.size, args.grids, args.smoother)
+    w = 8 if args.dtype == "f64" else 4
+    h, b, meta = build_problem(args.size, args.grids, args.smoother, "float64" if w == 8 else "float32")
     h.resident_load(b)
     setup_s = time.perf_counter() - t_setup
     pre = post = 1
@@ -157,7 +160,7 @@ def main():
     # The metric's "fine-grid SpMV GB/s": plain y = A x over the whole level-0 operator as it
     # sits in HBM for the cycle, 20 back-to-back launches in one hipEvent bracket (untimed region).
     spmv_ms = h.spmv_time(20)
-    spmv_b = spmv_bytes(meta["n"], meta["nnz"])
+    spmv_b = spmv_bytes(meta["n"], meta["nnz"], w)
     fine_spmv = {"kernel": "rows_kernel<ROW_SPMV> (y = A x, all rows of the fine grid)", "avg_launch_us": round(spmv_ms * 1e3, 2),
                  "algorithmic_bytes": spmv_b, "GBps": round(spmv_b / spmv_ms / 1e6, 1),
                  "frac_of_peak": round(spmv_b / spmv_ms / 1e6 / HBM_PEAK_GBS, 4)}
@@ -172,9 +175,9 @@ def main():
     covered = range(n_sets - 1) if h.level_fused(0) else range(n_sets)
     rows_c = sum(h.set_info(0, s)[0] for s in covered)
     nnz_c = sum(h.set_info(0, s)[1] for s in covered)
-    # algorithmic bytes: entries 12 B, row pointers 4 B, b and r 8 B per covered row, and the
-    # whole of x once (the covered rows together reference every unknown)
-    res_bytes = 12 * nnz_c + 4 * (rows_c + 1) + 16 * rows_c + 8 * n
+    # algorithmic bytes (w = value width): entries w+4 B, row pointers 4 B, b and r w B per
+    # covered row, and the whole of x once (the covered rows together reference every unknown)
+    res_bytes = (w + 4) * nnz_c + 4 * (rows_c + 1) + 2 * w * rows_c + w * n
     achieved = res_bytes / avg_s / 1e9
     # HBM traffic of that launch from the PMC counters cannot be collected from inside this
     # process; it is taken from the committed rocprofv3 pass of the SAME kernel and problem
@@ -182,7 +185,7 @@ def main():
     traffic, traffic_src = None, None
     try:
         pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_residual.json")))
-        if int(pmc["algorithmic_bytes"]) == int(res_bytes):
+        if int(pmc["algorithmic_bytes"]) == int(res_bytes) and w == 8:
             traffic, traffic_src = pmc["traffic_bytes"], pmc["source"]
     except (OSError, KeyError, ValueError):
         pass
@@ -192,13 +195,13 @@ def main():
     n_c = meta["level_rows"][1] if len(meta["level_rows"]) > 1 else 0
     set_rows = [h.set_info(0, s)[0] for s in range(n_sets)]
     set_nnz = [h.set_info(0, s)[1] for s in range(n_sets)]
-    avg_set_bytes = sum(12 * z + 4 * (r + 1) + 24 * r for r, z in zip(set_rows, set_nnz)) / max(n_sets, 1) + 8 * n / max(n_sets, 1)
+    avg_set_bytes = sum((w + 4) * z + 4 * (r + 1) + 3 * w * r for r, z in zip(set_rows, set_nnz)) / max(n_sets, 1) + w * n / max(n_sets, 1)
     class_bytes = {
         "smoother_set_sweep": avg_set_bytes,
         "residual": res_bytes,
-        "restrict": 12 * n + 4 * (n_c + 1) + 8 * n + 16 * n_c,            # R entries, indptr, r read, b_c + cleared x_c written
-        "prolong_add": 12 * n + 4 * (n + 1) + 8 * n_c + 16 * n,           # P entries, indptr, e read, x read + written
-        "residual_norm": res_bytes - 8 * rows_c,                          # as the residual launch, nothing stored
+        "restrict": (w + 4) * n + 4 * (n_c + 1) + w * n + 2 * w * n_c,    # R entries, indptr, r read, b_c + cleared x_c written
+        "prolong_add": (w + 4) * n + 4 * (n + 1) + w * n_c + 2 * w * n,   # P entries, indptr, e read, x read + written
+        "residual_norm": res_bytes - w * rows_c,                          # as the residual launch, nothing stored
     }
     kernels = {}
     for name, (cnt, tot) in prof.items():
@@ -238,11 +241,13 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "f64",
+        "dtype": args.dtype,
         "data": "synthetic",
-        "config": {"workload": "3-D 7-point Poisson %d^3, %d-grid V(1,1) cycle, %s Gauss-Seidel, fp64, "
-                               "int32 CSR (BASELINE configs[2])" % (args.size, meta["grids"],
-                                                                    "red-black" if args.smoother == "colour" else args.smoother),
+        "config": {"workload": "3-D 7-point Poisson %d^3, %d-grid V(1,1) cycle, %s Gauss-Seidel, %s, "
+                               "int32 CSR (BASELINE configs[2]%s)" % (args.size, meta["grids"],
+                                                                      "red-black" if args.smoother == "colour" else args.smoother,
+                                                                      "fp64" if w == 8 else "fp32",
+                                                                      "" if w == 8 else " run in fp32: NOT the headline configuration"),
                    "unknowns": n, "nnz": nnz, "grids": meta["grids"], "pre": pre, "post": post,
                    "smoother": args.smoother, "hipgraph": bool(args.graph),
                    "final_residual_norm": norm, "setup_s": round(setup_s, 2)},
