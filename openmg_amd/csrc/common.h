@@ -112,6 +112,9 @@ constexpr int ROWBLK_ROWS = 256;      // <= one row per thread
 #define OMG_ROWBLK_NNZ 2048
 #endif
 constexpr int ROWBLK_NNZ = OMG_ROWBLK_NNZ;   // entries staged through LDS per workgroup
+constexpr int DICT_MAX = 64;                 // entries of a block dictionary (power of two)
+constexpr int DICT_SHIFT = 7;                // table word = (pool offset << DICT_SHIFT) | entries
+constexpr int BLK_INFO_INTS = 4;             // ints per row-block table record
 
 // V = value type of the stored entries and of the vectors the operator is applied to:
 // double (the reference's precision) or float (BASELINE configs[4]); indices are int32.
@@ -120,7 +123,21 @@ struct DevCsrT {
     int64_t n_rows = 0, n_cols = 0, nnz = 0;
     DevBuf<int32_t> indptr, indices;
     DevBuf<V> data;
-    DevBuf<int32_t> blk_rows;          // first row of every row block (+ end sentinel)
+    // Row-block table, 4 ints per block (+ end sentinel): first row, first entry, and the
+    // block's column / value dictionaries as (pool offset << DICT_SHIFT) | entries, 0 = none.
+    DevBuf<int32_t> blk_rows;
+    // Block-dictionary coding (lossless; DESIGN.md "Device format").  Stencil-like operators
+    // repeat a handful of (column - row) offsets and of values inside a row block: such a
+    // block keeps the distinct ones in a dictionary of at most DICT_MAX entries and one byte
+    // per stored entry for each, and the kernels rebuild the int32 column / V value in LDS —
+    // 2 bytes from HBM per entry instead of 4 + sizeof(V).  Blocks that do not fit (irregular
+    // sparsity, variable coefficients) read the plain arrays; the choice is per block and
+    // separate for columns and values.  The plain arrays above are always present.
+    DevBuf<uint8_t> ccode, vcode;      // one byte per stored entry (meaningful in coded blocks)
+    DevBuf<int32_t> cdict;             // pool of column-offset dictionaries (shared between blocks)
+    DevBuf<V> vdict;                   // pool of value dictionaries
+    int64_t blocks_ccoded = 0, blocks_vcoded = 0;   // blocks using each dictionary (host, stats)
+    int64_t nnz_ccoded = 0, nnz_vcoded = 0;         // their stored entries
     std::vector<int64_t> set_blk;      // block offsets of the independent sets (host)
     std::vector<int64_t> sets;         // row offsets of the sets (host)
     int rows_cap = ROWBLK_ROWS;        // most rows a block may hold (> ROWBLK_THREADS: short rows)

@@ -27,14 +27,15 @@ namespace {
 
 constexpr int NT = ROWBLK_THREADS;
 constexpr int T = ROWBLK_NNZ;
-// LDS image: entry k lives at k + (k >> 5).  One pad slot per 32 entries makes the
+// LDS image: entry k (counted from the block's 8-aligned first entry) lives at k + (k >> 5).  One pad slot per 32 entries makes the
 // thread-per-row reads conflict-free for EVERY row length up to 32 (row length 8 or 16
-// would otherwise hit 4 or 2 banks).  +4 entries of slack for the aligned-down start.
+// would otherwise hit 4 or 2 banks).  +8 entries of slack for the aligned-down start.
 constexpr int LDS_SLOTS = (T + 8) + ((T + 8) >> 5) + 1;
 
 __device__ __forceinline__ int slot(int k) { return k + (k >> 5); }
 
 typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v2i __attribute__((ext_vector_type(2)));
 // 16-byte vector of values: 2 doubles or 4 floats
 template <typename V> struct Vec16;
 template <> struct Vec16<double> {
@@ -48,7 +49,11 @@ template <> struct Vec16<float> {
 
 template <typename V>
 struct KArgs {
-    const int32_t *blk_info;   // (first row, first entry) per row block, + end sentinel
+    const int32_t *blk_info;   // (first row, first entry, column dict, value dict) per row block, + end sentinel
+    const uint8_t *ccode;      // per entry: index into the block's column-offset dictionary
+    const uint8_t *vcode;      // per entry: index into the block's value dictionary
+    const int32_t *cdict;      // dictionary pools (common.h "Block-dictionary coding")
+    const V *vdict;
     const int32_t *indptr;
     const int32_t *indices;
     const V *data;
@@ -143,7 +148,8 @@ __device__ __forceinline__ void row_epilogue(const KArgs<V> &a, int r, const Row
 // one entry per row) that a block holds several rows per thread: the rows of a thread are
 // then processed eight at a time with all their loads in flight together.
 template <int MODE, bool nt, bool SHORT, int LPR, typename V>
-__device__ void process_block(const KArgs<V> &a, int blk, V *s_val, int *s_idx, double *s_red) {
+__device__ void process_block(const KArgs<V> &a, int blk, V *s_val, int *s_idx, double *s_red, int *s_cd,
+                              V *s_vd) {
     constexpr bool FUSED = (MODE == ROW_GS_RES || MODE == ROW_GS_NORM);
     constexpr bool NEED_DIAG = (MODE == ROW_GS || MODE == ROW_JACOBI || FUSED);
     constexpr bool NEED_NORM = (MODE == ROW_RESNORM || MODE == ROW_NORM_ONLY || MODE == ROW_GS_NORM);
@@ -152,19 +158,33 @@ __device__ void process_block(const KArgs<V> &a, int blk, V *s_val, int *s_idx, 
     const int tid = threadIdx.x;
     // (first row, first entry) of this block and of the next: one round trip instead of
     // block table -> indptr
-    const int2 *info = reinterpret_cast<const int2 *>(a.blk_info);
-    const int2 lo = info[blk], hi = info[blk + 1];
-    const int r0 = lo.x, p0 = lo.y, r1 = hi.x, p1 = hi.y;
+    const v4i *info = reinterpret_cast<const v4i *>(a.blk_info);
+    const v4i lo = info[blk], hi = info[blk + 1];
+    const int r0 = lo[0], p0 = lo[1], r1 = hi[0], p1 = hi[1];
+    // block dictionaries: (pool offset << DICT_SHIFT) | entries, 0 = this block reads the plain array
+    const int cinfo = lo[2], vinfo = lo[3];
+    const bool crel = cinfo != 0;          // LDS then holds (column - row), not the column
     double sq = 0.0;
 
     if (p1 - p0 <= T) {
         int r = r0 + tid / LPR;
         RowPre<V> pre;
         if (!SHORT && r < r1) pre = row_preload<MODE>(a, r);
-        // ---- phase 1: stream the block's entries into LDS, 16 B per lane per load ------
-        const int base = p0 & ~3;              // 16-B aligned for int32 and fp32, 32-B for fp64
+        // ---- phase 1: the block's entries into LDS --------------------------------------
+        // plain side: streamed from HBM, 16 B per lane per load; coded side: 8 one-byte codes
+        // per lane per load, expanded through the block's dictionary (held in LDS)
+        const int base = p0 & ~7;              // 8-entry aligned: 8 B of codes, 32 B of int32, 64 B of fp64
         const int cnt = p1 - base;
-        {
+        const int k0 = 8 * tid;
+        v2i ccw = {0, 0}, vcw = {0, 0};
+        if (cinfo | vinfo) {
+            const int ncd = cinfo & (2 * DICT_MAX - 1), nvd = vinfo & (2 * DICT_MAX - 1);
+            if (tid < ncd) s_cd[tid] = a.cdict[(cinfo >> DICT_SHIFT) + tid];
+            if (tid < nvd) s_vd[tid] = a.vdict[(vinfo >> DICT_SHIFT) + tid];
+            if (cinfo && k0 < cnt) ccw = *reinterpret_cast<const v2i *>(a.ccode + base + k0);
+            if (vinfo && k0 < cnt) vcw = *reinterpret_cast<const v2i *>(a.vcode + base + k0);
+        }
+        if (!cinfo) {
             const v4i *gi = reinterpret_cast<const v4i *>(a.indices + base);
             for (int k = 4 * tid; k < cnt; k += 4 * NT) {
                 // matrix entries are read exactly once: non-temporal so that they do not push
@@ -173,12 +193,36 @@ __device__ void process_block(const KArgs<V> &a, int blk, V *s_val, int *s_idx, 
                 const int s = slot(k);          // k % 4 == 0: the four slots are contiguous
                 s_idx[s] = v[0]; s_idx[s + 1] = v[1]; s_idx[s + 2] = v[2]; s_idx[s + 3] = v[3];
             }
+        }
+        if (!vinfo) {
             const vdat *gd = reinterpret_cast<const vdat *>(a.data + base);
             for (int k = VN * tid; k < cnt; k += VN * NT) {
                 const vdat v = nt ? __builtin_nontemporal_load(gd + (k / VN)) : gd[k / VN];
                 const int s = slot(k);          // k % VN == 0 and VN <= 4: contiguous slots
 #pragma unroll
                 for (int j = 0; j < VN; ++j) s_val[s + j] = v[j];
+            }
+        }
+        if (cinfo | vinfo) {
+            __syncthreads();                    // dictionaries are in LDS
+            // entries base+k .. base+k+7 sit in one 32-entry group: contiguous slots
+            if (cinfo) {
+                for (int k = k0; k < cnt; k += 8 * NT) {
+                    if (k != k0) ccw = *reinterpret_cast<const v2i *>(a.ccode + base + k);
+                    const int s = slot(k);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        s_idx[s + j] = s_cd[(ccw[j >> 2] >> (8 * (j & 3))) & (DICT_MAX - 1)];
+                }
+            }
+            if (vinfo) {
+                for (int k = k0; k < cnt; k += 8 * NT) {
+                    if (k != k0) vcw = *reinterpret_cast<const v2i *>(a.vcode + base + k);
+                    const int s = slot(k);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        s_val[s + j] = s_vd[(vcw[j >> 2] >> (8 * (j & 3))) & (DICT_MAX - 1)];
+                }
             }
         }
         __syncthreads();
@@ -201,7 +245,7 @@ __device__ void process_block(const KArgs<V> &a, int blk, V *s_val, int *s_idx, 
                 for (int u = 0; u < U; ++u) {           // first entry of every row, batched
                     const bool has = q[u].beg < q[u].end;
                     const int sl = slot(has ? q[u].beg - base : 0);
-                    c0[u] = has ? s_idx[sl] : 0;
+                    c0[u] = has ? s_idx[sl] + (crel ? rb + u * NT : 0) : 0;
                     v0[u] = has ? s_val[sl] : V(0);
                 }
 #pragma unroll
@@ -213,7 +257,7 @@ __device__ void process_block(const KArgs<V> &a, int blk, V *s_val, int *s_idx, 
                     sum[u] = (q[u].beg < q[u].end) ? madd(v0[u], x0[u], V(0)) : V(0);
                     for (int k = q[u].beg + 1 - base; k < q[u].end - base; ++k) {   // rest, stored order
                         const int sl = slot(k);
-                        sum[u] = madd(s_val[sl], a.x[s_idx[sl]], sum[u]);
+                        sum[u] = madd(s_val[sl], a.x[s_idx[sl] + (crel ? ru : 0)], sum[u]);
                     }
                     double unused = 0.0;
                     row_epilogue<MODE>(a, ru, q[u], sum[u], V(0), unused);
@@ -236,6 +280,7 @@ __device__ void process_block(const KArgs<V> &a, int blk, V *s_val, int *s_idx, 
             };
             while (r < r1) {
                 const int beg = pre.beg - base, end = pre.end - base;
+                const int radd = crel ? r : 0;
                 V sum = V(0), diag = V(0);
                 int c[8];
                 V v[8], xv[8];
@@ -244,7 +289,7 @@ __device__ void process_block(const KArgs<V> &a, int blk, V *s_val, int *s_idx, 
                     for (int j = 0; j < 8; ++j) {
                         const int kk = min(k + j * LPR, end - 1);
                         const int s = slot(kk);
-                        c[j] = s_idx[s];
+                        c[j] = s_idx[s] + radd;
                         v[j] = s_val[s];
                     }
 #pragma unroll
@@ -275,7 +320,7 @@ __device__ void process_block(const KArgs<V> &a, int blk, V *s_val, int *s_idx, 
                                 const int kk = k + j * LPR;
                                 if (kk < end) {
                                     const int s = slot(kk);
-                                    const int cc = s_idx[s];
+                                    const int cc = s_idx[s] + radd;
                                     sum2 = madd(s_val[s], cc == r ? xnew : a.x[cc], sum2);
                                 }
                             }
@@ -369,10 +414,12 @@ __global__ __launch_bounds__(NT, 6) void rows_kernel(KArgs<V> a, int blk0, int r
     __shared__ V s_val[LDS_SLOTS];
     __shared__ int s_idx[LDS_SLOTS];
     __shared__ double s_red[NT / 64];
+    __shared__ int s_cd[DICT_MAX];
+    __shared__ V s_vd[DICT_MAX];
     const int local = remap == 0 ? int(blockIdx.x)
                     : remap == 1 ? xcd_remap(blockIdx.x, gridDim.x)
                                  : xcd_remap_grouped(blockIdx.x, gridDim.x, remap);
-    process_block<MODE, NTL, SHORT, LPR>(a, blk0 + local, s_val, s_idx, s_red);
+    process_block<MODE, NTL, SHORT, LPR>(a, blk0 + local, s_val, s_idx, s_red, s_cd, s_vd);
 }
 
 // A run of consecutive tiny sets (one row block each), executed back to back by ONE
@@ -385,8 +432,10 @@ __global__ __launch_bounds__(NT) void rows_serial_kernel(KArgs<V> a, int blk_beg
     __shared__ V s_val[LDS_SLOTS];
     __shared__ int s_idx[LDS_SLOTS];
     __shared__ double s_red[NT / 64];
+    __shared__ int s_cd[DICT_MAX];
+    __shared__ V s_vd[DICT_MAX];
     for (int blk = blk_begin; blk < blk_end; ++blk) {
-        process_block<MODE, false, false, 1>(a, blk, s_val, s_idx, s_red);
+        process_block<MODE, false, false, 1>(a, blk, s_val, s_idx, s_red, s_cd, s_vd);
         __threadfence_block();
         __syncthreads();
     }
@@ -443,6 +492,10 @@ KArgs<V> make_kargs(const DevCsrT<V> &A, const RowArgsT<V> &args) {
     k.indptr = A.indptr.p;
     k.indices = A.indices.p;
     k.data = A.data.p;
+    k.ccode = A.ccode.p;
+    k.vcode = A.vcode.p;
+    k.cdict = A.cdict.p;
+    k.vdict = A.vdict.p;
     k.x = args.x;
     k.b = args.b;
     k.y = args.y;

@@ -3,7 +3,9 @@
 #include <algorithm>
 #include <atomic>
 #include <cstring>
+#include <string>
 #include <thread>
+#include <unordered_map>
 #include <type_traits>
 
 #include "common.h"
@@ -241,6 +243,45 @@ void make_row_blocks(const std::vector<int32_t> &indptr, const std::vector<int64
     blk_rows.push_back(int32_t(sets.empty() ? 0 : sets.back()));
 }
 
+namespace {
+
+// OMG_COMPRESS: 0 = plain CSR only, 1 = column dictionaries, 2 = value dictionaries,
+// 3 (default) = both.  Results are bit-identical in every mode (tests/test_gpu_parity.py).
+int compress_mode() {
+    const char *e = getenv("OMG_COMPRESS");
+    if (!e || !e[0]) return 3;
+    const int v = atoi(e);
+    return (v < 0 || v > 3) ? 3 : v;
+}
+
+template <typename V> struct Bits;
+template <> struct Bits<double> {
+    typedef uint64_t type;
+    static uint64_t of(double v) { uint64_t u; std::memcpy(&u, &v, sizeof u); return u; }
+};
+template <> struct Bits<float> {
+    typedef uint32_t type;
+    static uint32_t of(float v) { uint32_t u; std::memcpy(&u, &v, sizeof u); return u; }
+};
+
+// At most DICT_MAX distinct keys in order of first appearance; code() returns -1 once full.
+template <typename K>
+struct SmallDict {
+    K key[DICT_MAX];
+    int n = 0, last = 0;
+    int code(K k) {
+        if (n && key[last] == k) return last;
+        for (int i = 0; i < n; ++i)
+            if (key[i] == k) { last = i; return i; }
+        if (n == DICT_MAX) return -1;
+        key[n] = k;
+        last = n;
+        return n++;
+    }
+};
+
+}  // namespace
+
 template <typename V>
 void DevCsrT<V>::upload(const HostCsr &A, const std::vector<int64_t> &sets_in, hipStream_t s) {
     n_rows = A.n_rows;
@@ -271,13 +312,6 @@ void DevCsrT<V>::upload(const HostCsr &A, const std::vector<int64_t> &sets_in, h
     indptr.alloc(A.indptr.size());
     indices.alloc(std::max<size_t>(A.indices.size(), 1));
     data.alloc(std::max<size_t>(A.data.size(), 1));
-    // interleave (first row, first entry) so that a block reads its extent with one load
-    std::vector<int32_t> info(2 * blocks.size());
-    for (size_t k = 0; k < blocks.size(); ++k) {
-        info[2 * k] = blocks[k];
-        info[2 * k + 1] = A.indptr[blocks[k]];
-    }
-    blk_rows.alloc(info.size());
     indptr.upload(A.indptr.data(), A.indptr.size(), s);
     indices.upload(A.indices.data(), A.indices.size(), s);
     std::vector<V> narrowed;             // float operator: round the fp64 entries once, here
@@ -289,6 +323,113 @@ void DevCsrT<V>::upload(const HostCsr &A, const std::vector<int64_t> &sets_in, h
         vals = narrowed.data();
     }
     data.upload(vals, A.data.size(), s);
+
+    // ---- block dictionaries (common.h "Block-dictionary coding") -----------------------------
+    const int64_t nblk = int64_t(blocks.size()) - 1;          // `blocks` ends with a sentinel row
+    const int mode = compress_mode();
+    std::vector<uint8_t> cc, vc;
+    std::vector<std::vector<int32_t>> cdicts(std::max<int64_t>(nblk, 0));
+    std::vector<std::vector<V>> vdicts(std::max<int64_t>(nblk, 0));
+    if (mode != 0 && nblk > 0 && nnz > 0) {
+        if (mode & 1) cc.assign(size_t(nnz), 0);
+        if (mode & 2) vc.assign(size_t(nnz), 0);
+        auto work = [&](int64_t k0, int64_t k1) {
+            for (int64_t k = k0; k < k1; ++k) {
+                const int64_t r0 = blocks[k], r1 = blocks[k + 1];
+                const int64_t p0 = A.indptr[r0], p1 = A.indptr[r1];
+                if (p1 <= p0 || p1 - p0 > ROWBLK_NNZ) continue;       // empty, or one long row: plain
+                if (mode & 1) {
+                    SmallDict<int32_t> d;
+                    bool ok = true;
+                    for (int64_t r = r0; r < r1 && ok; ++r)
+                        for (int64_t p = A.indptr[r]; p < A.indptr[r + 1]; ++p) {
+                            const int c = d.code(A.indices[p] - int32_t(r));
+                            if (c < 0) { ok = false; break; }
+                            cc[p] = uint8_t(c);
+                        }
+                    if (ok) cdicts[k].assign(d.key, d.key + d.n);
+                }
+                if (mode & 2) {
+                    SmallDict<typename Bits<V>::type> d;
+                    bool ok = true;
+                    for (int64_t p = p0; p < p1; ++p) {
+                        const int c = d.code(Bits<V>::of(vals[p]));
+                        if (c < 0) { ok = false; break; }
+                        vc[p] = uint8_t(c);
+                    }
+                    if (ok) {
+                        vdicts[k].resize(d.n);
+                        std::memcpy(vdicts[k].data(), d.key, size_t(d.n) * sizeof(V));
+                    }
+                }
+            }
+        };
+        const int nthreads = int(std::min<int64_t>(std::max(1u, std::min(16u, std::thread::hardware_concurrency())),
+                                                   std::max<int64_t>(1, nblk / 256)));
+        if (nthreads <= 1) {
+            work(0, nblk);
+        } else {
+            std::vector<std::thread> pool;
+            for (int t = 0; t < nthreads; ++t)
+                pool.emplace_back(work, nblk * t / nthreads, nblk * (t + 1) / nthreads);
+            for (auto &t : pool) t.join();
+        }
+    }
+    // pool the dictionaries: blocks of a stencil operator mostly share one, which then stays in L2
+    std::vector<int32_t> cpool;
+    std::vector<V> vpool;
+    std::vector<int32_t> info(size_t(BLK_INFO_INTS) * blocks.size(), 0);
+    {
+        std::unordered_map<std::string, int32_t> cseen, vseen;
+        const int64_t pool_cap = (int64_t(1) << (31 - DICT_SHIFT)) - DICT_MAX;
+        blocks_ccoded = blocks_vcoded = nnz_ccoded = nnz_vcoded = 0;
+        for (int64_t k = 0; k <= nblk; ++k) {
+            int32_t *rec = info.data() + size_t(BLK_INFO_INTS) * size_t(k);
+            rec[0] = blocks[k];
+            rec[1] = A.indptr[blocks[k]];
+            if (k == nblk) break;
+            const int64_t entries = A.indptr[blocks[k + 1]] - A.indptr[blocks[k]];
+            if (!cdicts[k].empty()) {
+                std::string key(reinterpret_cast<const char *>(cdicts[k].data()), cdicts[k].size() * sizeof(int32_t));
+                auto it = cseen.find(key);
+                if (it == cseen.end() && int64_t(cpool.size()) < pool_cap) {
+                    it = cseen.emplace(std::move(key), int32_t(cpool.size())).first;
+                    cpool.insert(cpool.end(), cdicts[k].begin(), cdicts[k].end());
+                }
+                if (it != cseen.end()) {
+                    rec[2] = (it->second << DICT_SHIFT) | int32_t(cdicts[k].size());
+                    ++blocks_ccoded;
+                    nnz_ccoded += entries;
+                }
+            }
+            if (!vdicts[k].empty()) {
+                std::string key(reinterpret_cast<const char *>(vdicts[k].data()), vdicts[k].size() * sizeof(V));
+                auto it = vseen.find(key);
+                if (it == vseen.end() && int64_t(vpool.size()) < pool_cap) {
+                    it = vseen.emplace(std::move(key), int32_t(vpool.size())).first;
+                    vpool.insert(vpool.end(), vdicts[k].begin(), vdicts[k].end());
+                }
+                if (it != vseen.end()) {
+                    rec[3] = (it->second << DICT_SHIFT) | int32_t(vdicts[k].size());
+                    ++blocks_vcoded;
+                    nnz_vcoded += entries;
+                }
+            }
+        }
+    }
+    if (blocks_ccoded) {
+        ccode.alloc(size_t(nnz));
+        ccode.upload(cc.data(), size_t(nnz), s);
+        cdict.alloc(cpool.size());
+        cdict.upload(cpool.data(), cpool.size(), s);
+    }
+    if (blocks_vcoded) {
+        vcode.alloc(size_t(nnz));
+        vcode.upload(vc.data(), size_t(nnz), s);
+        vdict.alloc(vpool.size());
+        vdict.upload(vpool.data(), vpool.size(), s);
+    }
+    blk_rows.alloc(info.size());
     blk_rows.upload(info.data(), info.size(), s);
     OMG_HIP(hipStreamSynchronize(s));   // host staging vectors may die after return
 }
