@@ -114,7 +114,7 @@ constexpr int ROWBLK_ROWS = 256;      // <= one row per thread
 constexpr int ROWBLK_NNZ = OMG_ROWBLK_NNZ;   // entries staged through LDS per workgroup
 constexpr int DICT_MAX = 64;                 // entries of a block dictionary (power of two)
 constexpr int DICT_SHIFT = 7;                // table word = (pool offset << DICT_SHIFT) | entries
-constexpr int BLK_INFO_INTS = 4;             // ints per row-block table record
+constexpr int BLK_INFO_INTS = 8;             // ints per row-block table record
 
 // V = value type of the stored entries and of the vectors the operator is applied to:
 // double (the reference's precision) or float (BASELINE configs[4]); indices are int32.
@@ -123,8 +123,10 @@ struct DevCsrT {
     int64_t n_rows = 0, n_cols = 0, nnz = 0;
     DevBuf<int32_t> indptr, indices;
     DevBuf<V> data;
-    // Row-block table, 4 ints per block (+ end sentinel): first row, first entry, and the
-    // block's column / value dictionaries as (pool offset << DICT_SHIFT) | entries, 0 = none.
+    // Row-block table, BLK_INFO_INTS ints per block (+ end sentinel): [0] first row, [1] first
+    // entry, [2] / [3] the block's column / value dictionary as (pool offset << DICT_SHIFT) |
+    // entries (0 = none), [4..7] its row-pattern dictionary: entry offset into pidx / pval,
+    // entries, offset into pbeg, patterns (0 = none).
     DevBuf<int32_t> blk_rows;
     // Block-dictionary coding (lossless; DESIGN.md "Device format").  Stencil-like operators
     // repeat a handful of (column - row) offsets and of values inside a row block: such a
@@ -133,11 +135,22 @@ struct DevCsrT {
     // 2 bytes from HBM per entry instead of 4 + sizeof(V).  Blocks that do not fit (irregular
     // sparsity, variable coefficients) read the plain arrays; the choice is per block and
     // separate for columns and values.  The plain arrays above are always present.
+    //
+    // Row patterns go one step further for operators whose ROWS repeat (constant-coefficient
+    // stencils, Galerkin products of them): the block's dictionary holds each distinct row —
+    // its (column - row) offsets and values in stored order — once, and HBM carries one byte
+    // per ROW.  The kernels stream the dictionary (a few hundred bytes, shared between blocks,
+    // L2-resident) into the same LDS image a plain block would fill and walk it per row, so the
+    // summation order, and with it every bit of the result, is unchanged.
     DevBuf<uint8_t> ccode, vcode;      // one byte per stored entry (meaningful in coded blocks)
     DevBuf<int32_t> cdict;             // pool of column-offset dictionaries (shared between blocks)
     DevBuf<V> vdict;                   // pool of value dictionaries
-    int64_t blocks_ccoded = 0, blocks_vcoded = 0;   // blocks using each dictionary (host, stats)
-    int64_t nnz_ccoded = 0, nnz_vcoded = 0;         // their stored entries
+    DevBuf<uint8_t> rcode;             // one byte per row: its pattern (meaningful in pattern blocks)
+    DevBuf<int32_t> pidx, pbeg;        // pattern pools: offsets; per dictionary npat + 1 starts into them
+    DevBuf<V> pval;                    //                values
+    int64_t blocks_ccoded = 0, blocks_vcoded = 0, blocks_pcoded = 0;   // blocks using each coding (host, stats)
+    int64_t nnz_ccoded = 0, nnz_vcoded = 0, nnz_pcoded = 0;            // their stored entries
+    int64_t rows_pcoded = 0;
     std::vector<int64_t> set_blk;      // block offsets of the independent sets (host)
     std::vector<int64_t> sets;         // row offsets of the sets (host)
     int rows_cap = ROWBLK_ROWS;        // most rows a block may hold (> ROWBLK_THREADS: short rows)

@@ -54,6 +54,10 @@ struct KArgs {
     const uint8_t *vcode;      // per entry: index into the block's value dictionary
     const int32_t *cdict;      // dictionary pools (common.h "Block-dictionary coding")
     const V *vdict;
+    const uint8_t *rcode;      // per row: its pattern in the block's row-pattern dictionary
+    const int32_t *pidx;       // row-pattern pools: (column - row) offsets, values, pattern starts
+    const V *pval;
+    const int32_t *pbeg;
     const int32_t *indptr;
     const int32_t *indices;
     const V *data;
@@ -98,11 +102,18 @@ struct RowPre {
     V bv, xv;         // b[r]; x[r] (GS, Jacobi) or y[r] (y += A x)
 };
 
+// pat: the block is row-pattern coded; beg then holds the row's pattern code until
+// row_resolve() turns it into the pattern's extent in the LDS image.
 template <int MODE, typename V>
-__device__ __forceinline__ RowPre<V> row_preload(const KArgs<V> &a, int r) {
+__device__ __forceinline__ RowPre<V> row_preload(const KArgs<V> &a, int r, bool pat = false) {
     RowPre<V> p;
-    p.beg = a.indptr[r];
-    p.end = a.indptr[r + 1];
+    if (pat) {
+        p.beg = a.rcode[r];
+        p.end = 0;
+    } else {
+        p.beg = a.indptr[r];
+        p.end = a.indptr[r + 1];
+    }
     p.bv = V(0);
     p.xv = V(0);
     if constexpr (MODE != ROW_SPMV && MODE != ROW_AXPY) p.bv = a.b[r];
@@ -112,6 +123,13 @@ __device__ __forceinline__ RowPre<V> row_preload(const KArgs<V> &a, int r) {
     p.out = r;
     if constexpr (MODE == ROW_SPMV) { if (a.ymap) p.out = a.ymap[r]; }
     return p;
+}
+
+template <typename V>
+__device__ __forceinline__ void row_resolve(RowPre<V> &p, const int *s_cd) {
+    const int code = p.beg;
+    p.beg = s_cd[code];
+    p.end = s_cd[code + 1];
 }
 
 // Row sums are spelled with an explicit fma everywhere so that the fused sweep+residual
@@ -159,22 +177,31 @@ __device__ void process_block(const KArgs<V> &a, int blk, V *s_val, int *s_idx, 
     // (first row, first entry) of this block and of the next: one round trip instead of
     // block table -> indptr
     const v4i *info = reinterpret_cast<const v4i *>(a.blk_info);
-    const v4i lo = info[blk], hi = info[blk + 1];
+    const v4i lo = info[2 * blk], lp = info[2 * blk + 1], hi = info[2 * blk + 2];
     const int r0 = lo[0], p0 = lo[1], r1 = hi[0], p1 = hi[1];
-    // block dictionaries: (pool offset << DICT_SHIFT) | entries, 0 = this block reads the plain array
+    // per-entry dictionaries: (pool offset << DICT_SHIFT) | entries, 0 = this block reads the plain array
     const int cinfo = lo[2], vinfo = lo[3];
-    const bool crel = cinfo != 0;          // LDS then holds (column - row), not the column
+    // row-pattern dictionary: lp = (entry offset, entries, table offset, patterns), patterns 0 = none
+    const int npat = lp[3];
+    const bool pat = npat != 0;
+    const bool crel = cinfo != 0 || pat;   // LDS then holds (column - row), not the column
     double sq = 0.0;
 
     if (p1 - p0 <= T) {
         int r = r0 + tid / LPR;
         RowPre<V> pre;
-        if (!SHORT && r < r1) pre = row_preload<MODE>(a, r);
+        if (!SHORT && r < r1) pre = row_preload<MODE>(a, r, pat);
         // ---- phase 1: the block's entries into LDS --------------------------------------
         // plain side: streamed from HBM, 16 B per lane per load; coded side: 8 one-byte codes
         // per lane per load, expanded through the block's dictionary (held in LDS)
-        const int base = p0 & ~7;              // 8-entry aligned: 8 B of codes, 32 B of int32, 64 B of fp64
-        const int cnt = p1 - base;
+        // (a pattern block streams its dictionary instead of its own entries: same loops, the
+        // source is the 8-entry aligned pool slice, re-read by every block -> never non-temporal)
+        const int base = pat ? 0 : (p0 & ~7);  // 8-entry aligned: 8 B of codes, 32 B of int32, 64 B of fp64
+        const int cnt = pat ? lp[1] : p1 - base;
+        const int32_t *src_i = pat ? a.pidx + lp[0] : a.indices + base;
+        const V *src_v = pat ? a.pval + lp[0] : a.data + base;
+        const bool ntl = nt && !pat;
+        if (pat && tid <= npat) s_cd[tid] = a.pbeg[lp[2] + tid];
         const int k0 = 8 * tid;
         v2i ccw = {0, 0}, vcw = {0, 0};
         if (cinfo | vinfo) {
@@ -185,19 +212,19 @@ __device__ void process_block(const KArgs<V> &a, int blk, V *s_val, int *s_idx, 
             if (vinfo && k0 < cnt) vcw = *reinterpret_cast<const v2i *>(a.vcode + base + k0);
         }
         if (!cinfo) {
-            const v4i *gi = reinterpret_cast<const v4i *>(a.indices + base);
+            const v4i *gi = reinterpret_cast<const v4i *>(src_i);
             for (int k = 4 * tid; k < cnt; k += 4 * NT) {
                 // matrix entries are read exactly once: non-temporal so that they do not push
                 // the re-used x lines out of L2 / Infinity Cache
-                const v4i v = nt ? __builtin_nontemporal_load(gi + (k >> 2)) : gi[k >> 2];
+                const v4i v = ntl ? __builtin_nontemporal_load(gi + (k >> 2)) : gi[k >> 2];
                 const int s = slot(k);          // k % 4 == 0: the four slots are contiguous
                 s_idx[s] = v[0]; s_idx[s + 1] = v[1]; s_idx[s + 2] = v[2]; s_idx[s + 3] = v[3];
             }
         }
         if (!vinfo) {
-            const vdat *gd = reinterpret_cast<const vdat *>(a.data + base);
+            const vdat *gd = reinterpret_cast<const vdat *>(src_v);
             for (int k = VN * tid; k < cnt; k += VN * NT) {
-                const vdat v = nt ? __builtin_nontemporal_load(gd + (k / VN)) : gd[k / VN];
+                const vdat v = ntl ? __builtin_nontemporal_load(gd + (k / VN)) : gd[k / VN];
                 const int s = slot(k);          // k % VN == 0 and VN <= 4: contiguous slots
 #pragma unroll
                 for (int j = 0; j < VN; ++j) s_val[s + j] = v[j];
@@ -226,6 +253,7 @@ __device__ void process_block(const KArgs<V> &a, int blk, V *s_val, int *s_idx, 
             }
         }
         __syncthreads();
+        if (!SHORT && pat && r < r1) row_resolve(pre, s_cd);
         // ---- phase 2: one thread per row, stored order ---------------------------------
         // (blocks of very short rows — prolongation has one entry per row — hold up to
         // ROWBLK_NNZ rows, so a thread may take several, NT apart: still coalesced)
@@ -337,7 +365,10 @@ __device__ void process_block(const KArgs<V> &a, int blk, V *s_val, int *s_idx, 
                     row_epilogue<MODE>(a, r, pre, sum, diag, sq);
                 }
                 r += NT / LPR;
-                if (r < r1) pre = row_preload<MODE>(a, r);
+                if (r < r1) {
+                    pre = row_preload<MODE>(a, r, pat);
+                    if (pat) row_resolve(pre, s_cd);
+                }
             }
         }
     } else {
@@ -414,7 +445,7 @@ __global__ __launch_bounds__(NT, 6) void rows_kernel(KArgs<V> a, int blk0, int r
     __shared__ V s_val[LDS_SLOTS];
     __shared__ int s_idx[LDS_SLOTS];
     __shared__ double s_red[NT / 64];
-    __shared__ int s_cd[DICT_MAX];
+    __shared__ int s_cd[2 * DICT_MAX];     // column dictionary, or the npat + 1 pattern starts
     __shared__ V s_vd[DICT_MAX];
     const int local = remap == 0 ? int(blockIdx.x)
                     : remap == 1 ? xcd_remap(blockIdx.x, gridDim.x)
@@ -432,7 +463,7 @@ __global__ __launch_bounds__(NT) void rows_serial_kernel(KArgs<V> a, int blk_beg
     __shared__ V s_val[LDS_SLOTS];
     __shared__ int s_idx[LDS_SLOTS];
     __shared__ double s_red[NT / 64];
-    __shared__ int s_cd[DICT_MAX];
+    __shared__ int s_cd[2 * DICT_MAX];
     __shared__ V s_vd[DICT_MAX];
     for (int blk = blk_begin; blk < blk_end; ++blk) {
         process_block<MODE, false, false, 1>(a, blk, s_val, s_idx, s_red, s_cd, s_vd);
@@ -496,6 +527,10 @@ KArgs<V> make_kargs(const DevCsrT<V> &A, const RowArgsT<V> &args) {
     k.vcode = A.vcode.p;
     k.cdict = A.cdict.p;
     k.vdict = A.vdict.p;
+    k.rcode = A.rcode.p;
+    k.pidx = A.pidx.p;
+    k.pval = A.pval.p;
+    k.pbeg = A.pbeg.p;
     k.x = args.x;
     k.b = args.b;
     k.y = args.y;

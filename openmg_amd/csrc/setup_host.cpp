@@ -245,13 +245,14 @@ void make_row_blocks(const std::vector<int32_t> &indptr, const std::vector<int64
 
 namespace {
 
-// OMG_COMPRESS: 0 = plain CSR only, 1 = column dictionaries, 2 = value dictionaries,
-// 3 (default) = both.  Results are bit-identical in every mode (tests/test_gpu_parity.py).
+// OMG_COMPRESS, a bit mask: 1 = per-entry column dictionaries, 2 = per-entry value
+// dictionaries, 4 = whole-row pattern dictionaries; 0 = plain CSR only; default 7.  Results are
+// bit-identical in every mode (tests/test_gpu_parity.py).
 int compress_mode() {
     const char *e = getenv("OMG_COMPRESS");
-    if (!e || !e[0]) return 3;
+    if (!e || !e[0]) return 7;
     const int v = atoi(e);
-    return (v < 0 || v > 3) ? 3 : v;
+    return (v < 0 || v > 7) ? 7 : v;
 }
 
 template <typename V> struct Bits;
@@ -327,17 +328,67 @@ void DevCsrT<V>::upload(const HostCsr &A, const std::vector<int64_t> &sets_in, h
     // ---- block dictionaries (common.h "Block-dictionary coding") -----------------------------
     const int64_t nblk = int64_t(blocks.size()) - 1;          // `blocks` ends with a sentinel row
     const int mode = compress_mode();
-    std::vector<uint8_t> cc, vc;
-    std::vector<std::vector<int32_t>> cdicts(std::max<int64_t>(nblk, 0));
-    std::vector<std::vector<V>> vdicts(std::max<int64_t>(nblk, 0));
+    std::vector<uint8_t> cc, vc, rc;
+    const size_t nb = size_t(std::max<int64_t>(nblk, 0));
+    std::vector<std::vector<int32_t>> cdicts(nb);
+    std::vector<std::vector<V>> vdicts(nb);
+    struct PatDict {
+        std::vector<int32_t> beg, idx;     // beg: npat + 1 offsets into idx / val
+        std::vector<V> val;
+    };
+    std::vector<PatDict> pdicts(nb);
+    // row patterns: not for the several-rows-per-thread operators (prolongation, restriction)
+    const bool try_pat = (mode & 4) && rows_cap <= ROWBLK_THREADS;
     if (mode != 0 && nblk > 0 && nnz > 0) {
         if (mode & 1) cc.assign(size_t(nnz), 0);
         if (mode & 2) vc.assign(size_t(nnz), 0);
+        if (try_pat) rc.assign(size_t(n_rows), 0);
         auto work = [&](int64_t k0, int64_t k1) {
             for (int64_t k = k0; k < k1; ++k) {
                 const int64_t r0 = blocks[k], r1 = blocks[k + 1];
                 const int64_t p0 = A.indptr[r0], p1 = A.indptr[r1];
                 if (p1 <= p0 || p1 - p0 > ROWBLK_NNZ) continue;       // empty, or one long row: plain
+                if (try_pat) {
+                    // whole-row patterns: (length, column - row offsets, values) of every row
+                    PatDict d;
+                    d.beg.push_back(0);
+                    bool ok = true;
+                    int last = -1;
+                    const int64_t budget = (p1 - p0) / 2;             // a dictionary must be a real saving
+                    for (int64_t r = r0; r < r1 && ok; ++r) {
+                        const int64_t q0 = A.indptr[r];
+                        const int len = int(A.indptr[r + 1] - q0);
+                        auto same = [&](int c) {
+                            const int b = d.beg[c];
+                            if (d.beg[c + 1] - b != len) return false;
+                            for (int j = 0; j < len; ++j)
+                                if (d.idx[b + j] != A.indices[q0 + j] - int32_t(r) ||
+                                    Bits<V>::of(d.val[b + j]) != Bits<V>::of(vals[q0 + j]))
+                                    return false;
+                            return true;
+                        };
+                        int code = -1;
+                        const int npat = int(d.beg.size()) - 1;
+                        if (last >= 0 && same(last)) code = last;
+                        for (int c = 0; c < npat && code < 0; ++c)
+                            if (c != last && same(c)) code = c;
+                        if (code < 0) {
+                            if (npat == DICT_MAX || int64_t(d.idx.size()) + len > budget) { ok = false; break; }
+                            for (int j = 0; j < len; ++j) {
+                                d.idx.push_back(A.indices[q0 + j] - int32_t(r));
+                                d.val.push_back(vals[q0 + j]);
+                            }
+                            d.beg.push_back(int32_t(d.idx.size()));
+                            code = npat;
+                        }
+                        rc[r] = uint8_t(code);
+                        last = code;
+                    }
+                    if (ok) {
+                        pdicts[k] = std::move(d);
+                        continue;
+                    }
+                }
                 if (mode & 1) {
                     SmallDict<int32_t> d;
                     bool ok = true;
@@ -376,19 +427,44 @@ void DevCsrT<V>::upload(const HostCsr &A, const std::vector<int64_t> &sets_in, h
         }
     }
     // pool the dictionaries: blocks of a stencil operator mostly share one, which then stays in L2
-    std::vector<int32_t> cpool;
-    std::vector<V> vpool;
+    std::vector<int32_t> cpool, ppool_idx, ppool_beg;
+    std::vector<V> vpool, ppool_val;
     std::vector<int32_t> info(size_t(BLK_INFO_INTS) * blocks.size(), 0);
     {
         std::unordered_map<std::string, int32_t> cseen, vseen;
+        std::unordered_map<std::string, std::pair<int32_t, int32_t>> pseen;    // -> (entry offset, table offset)
         const int64_t pool_cap = (int64_t(1) << (31 - DICT_SHIFT)) - DICT_MAX;
-        blocks_ccoded = blocks_vcoded = nnz_ccoded = nnz_vcoded = 0;
+        blocks_ccoded = blocks_vcoded = nnz_ccoded = nnz_vcoded = blocks_pcoded = rows_pcoded = nnz_pcoded = 0;
         for (int64_t k = 0; k <= nblk; ++k) {
             int32_t *rec = info.data() + size_t(BLK_INFO_INTS) * size_t(k);
             rec[0] = blocks[k];
             rec[1] = A.indptr[blocks[k]];
             if (k == nblk) break;
             const int64_t entries = A.indptr[blocks[k + 1]] - A.indptr[blocks[k]];
+            const PatDict &pd = pdicts[k];
+            if (!pd.idx.empty()) {
+                std::string key(reinterpret_cast<const char *>(pd.beg.data()), pd.beg.size() * sizeof(int32_t));
+                key.append(reinterpret_cast<const char *>(pd.idx.data()), pd.idx.size() * sizeof(int32_t));
+                key.append(reinterpret_cast<const char *>(pd.val.data()), pd.val.size() * sizeof(V));
+                auto it = pseen.find(key);
+                if (it == pseen.end() && int64_t(ppool_idx.size()) < (int64_t(1) << 30)) {
+                    it = pseen.emplace(std::move(key), std::make_pair(int32_t(ppool_idx.size()), int32_t(ppool_beg.size()))).first;
+                    ppool_idx.insert(ppool_idx.end(), pd.idx.begin(), pd.idx.end());
+                    ppool_val.insert(ppool_val.end(), pd.val.begin(), pd.val.end());
+                    while (ppool_idx.size() % 8) { ppool_idx.push_back(0); ppool_val.push_back(V(0)); }   // 16-B vector loads
+                    ppool_beg.insert(ppool_beg.end(), pd.beg.begin(), pd.beg.end());
+                }
+                if (it != pseen.end()) {
+                    rec[4] = it->second.first;
+                    rec[5] = int32_t(pd.idx.size());
+                    rec[6] = it->second.second;
+                    rec[7] = int32_t(pd.beg.size()) - 1;
+                    ++blocks_pcoded;
+                    rows_pcoded += blocks[k + 1] - blocks[k];
+                    nnz_pcoded += entries;
+                    continue;
+                }
+            }
             if (!cdicts[k].empty()) {
                 std::string key(reinterpret_cast<const char *>(cdicts[k].data()), cdicts[k].size() * sizeof(int32_t));
                 auto it = cseen.find(key);
@@ -428,6 +504,16 @@ void DevCsrT<V>::upload(const HostCsr &A, const std::vector<int64_t> &sets_in, h
         vcode.upload(vc.data(), size_t(nnz), s);
         vdict.alloc(vpool.size());
         vdict.upload(vpool.data(), vpool.size(), s);
+    }
+    if (blocks_pcoded) {
+        rcode.alloc(size_t(n_rows));
+        rcode.upload(rc.data(), size_t(n_rows), s);
+        pidx.alloc(ppool_idx.size());
+        pidx.upload(ppool_idx.data(), ppool_idx.size(), s);
+        pval.alloc(ppool_val.size());
+        pval.upload(ppool_val.data(), ppool_val.size(), s);
+        pbeg.alloc(ppool_beg.size());
+        pbeg.upload(ppool_beg.data(), ppool_beg.size(), s);
     }
     blk_rows.alloc(info.size());
     blk_rows.upload(info.data(), info.size(), s);

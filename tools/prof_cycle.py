@@ -20,8 +20,9 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--smoother", default="colour")
     ap.add_argument("--graph", type=int, default=0)
+    ap.add_argument("--dtype", default="float64")
     args = ap.parse_args()
-    h, b, meta = bench.build_problem(args.size, args.grids, args.smoother)
+    h, b, meta = bench.build_problem(args.size, args.grids, args.smoother, args.dtype)
     h.resident_load(b)
     if args.graph:
         h.use_graph(True)
