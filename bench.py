@@ -39,6 +39,13 @@ def residual_bytes(n, nnz, w=8):
     return spmv_bytes(n, nnz, w) + w * n
 
 
+def kernel_name(fmt, mode):
+    """Which kernel walks an operator held like `fmt` (csrc/csr_kernels.hip launch_rows_range)."""
+    if fmt["rows"] and fmt["pattern_rows"] == fmt["rows"] and os.environ.get("OMG_PATTERN_KERNEL", "1") != "0":
+        return "rows_pattern_kernel<%s>" % mode
+    return "rows_kernel<%s>" % mode
+
+
 def build_problem(size, grids, smoother, dtype="float64"):
     import openmg_amd
     from openmg_amd import _hip, operators
@@ -97,6 +104,7 @@ def main():
                     help="precision the levels are stored / computed in (f64 = BASELINE configs[2], the default)")
     ap.add_argument("--graph", type=int, default=0, help="replay the cycle from a hipGraph")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--no-plain", action="store_true", help="skip the plain-CSR (OMG_COMPRESS=0) comparison leg")
     ap.add_argument("--dist", type=int, default=0, help="force the multi-GPU code path even with one rank (debug)")
     ap.add_argument("--watchdog", type=int, default=900, help="multi-GPU: abort the rank after this many seconds")
     ap.add_argument("--overlap", type=int, default=1,
@@ -161,9 +169,13 @@ def main():
     # sits in HBM for the cycle, 20 back-to-back launches in one hipEvent bracket (untimed region).
     spmv_ms = h.spmv_time(20)
     spmv_b = spmv_bytes(meta["n"], meta["nnz"], w)
-    fine_spmv = {"kernel": "rows_kernel<ROW_SPMV> (y = A x, all rows of the fine grid)", "avg_launch_us": round(spmv_ms * 1e3, 2),
+    fmt_all = h.format_info(0, "A")
+    spmv_fmt = fmt_all["format_bytes"] + 2 * w * meta["n"]          # operator in its device format + x read + y written
+    fine_spmv = {"kernel": "y = A x, all rows of the fine grid (%s)" % kernel_name(fmt_all, "ROW_SPMV"),
+                 "avg_launch_us": round(spmv_ms * 1e3, 2),
                  "algorithmic_bytes": spmv_b, "GBps": round(spmv_b / spmv_ms / 1e6, 1),
-                 "frac_of_peak": round(spmv_b / spmv_ms / 1e6 / HBM_PEAK_GBS, 4)}
+                 "frac_of_peak": round(spmv_b / spmv_ms / 1e6 / HBM_PEAK_GBS, 4),
+                 "format_bytes": spmv_fmt, "format_GBps": round(spmv_fmt / spmv_ms / 1e6, 1)}
 
     n, nnz = meta["n"], meta["nnz"]
     launches, ms = timed["residual"]
@@ -179,13 +191,20 @@ def main():
     # covered row, and the whole of x once (the covered rows together reference every unknown)
     res_bytes = (w + 4) * nnz_c + 4 * (rows_c + 1) + 2 * w * rows_c + w * n
     achieved = res_bytes / avg_s / 1e9
+    # ... and the bytes the launch has to move with the operator in its DEVICE format (lossless
+    # block-dictionary recoding of the CSR, DESIGN.md "Device format"): same vectors, fewer
+    # operator bytes.  `achieved` above is the CSR-equivalent rate SURVEY 8(d) defines; the
+    # rate at which HBM is actually driven is format_bytes (or the PMC traffic) over the time.
+    fmt_sets = [h.format_info(0, "A", s) for s in covered]
+    fmt_bytes = sum(f["format_bytes"] for f in fmt_sets) + 2 * w * rows_c + w * n
+    fmt_cov = {k: sum(f[k] for f in fmt_sets) for k in ("rows", "nnz", "blocks", "pattern_rows", "coldict_nnz", "valdict_nnz")}
     # HBM traffic of that launch from the PMC counters cannot be collected from inside this
     # process; it is taken from the committed rocprofv3 pass of the SAME kernel and problem
     # (profiles/, method recorded there) and only when the byte accounting matches exactly.
     traffic, traffic_src = None, None
     try:
         pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_residual.json")))
-        if int(pmc["algorithmic_bytes"]) == int(res_bytes) and w == 8:
+        if int(pmc["algorithmic_bytes"]) == int(res_bytes) and int(pmc.get("format_bytes", -1)) == int(fmt_bytes) and w == 8:
             traffic, traffic_src = pmc["traffic_bytes"], pmc["source"]
     except (OSError, KeyError, ValueError):
         pass
@@ -203,19 +222,74 @@ def main():
         "prolong_add": (w + 4) * n + 4 * (n + 1) + w * n_c + 2 * w * n,   # P entries, indptr, e read, x read + written
         "residual_norm": res_bytes - w * rows_c,                          # as the residual launch, nothing stored
     }
+    # the same launches with the operators in their device format
+    fA = [h.format_info(0, "A", s) for s in range(n_sets)]
+    fR, fP = (h.format_info(0, "R"), h.format_info(0, "P")) if n_c else ({"format_bytes": 0}, {"format_bytes": 0})
+    class_fmt = {
+        "smoother_set_sweep": sum(f["format_bytes"] + 3 * w * f["rows"] for f in fA) / max(n_sets, 1) + w * n / max(n_sets, 1),
+        "residual": fmt_bytes,
+        "restrict": fR["format_bytes"] + w * n + 2 * w * n_c,
+        "prolong_add": fP["format_bytes"] + w * n_c + 2 * w * n,
+        "residual_norm": fmt_bytes - w * rows_c,
+    }
     kernels = {}
     for name, (cnt, tot) in prof.items():
         if cnt:
             us = 1e3 * tot / cnt
             kernels[name] = {"launches_per_cycle": cnt / args.steps, "avg_us": round(us, 2),
                              "algorithmic_bytes": int(class_bytes[name]),
-                             "GBps": round(class_bytes[name] / us / 1e3, 1)}
-    roofline = {"bound": "hbm", "kernel": "rows_kernel<ROW_RESIDUAL> (fine grid r = b - A x)",
+                             "GBps": round(class_bytes[name] / us / 1e3, 1),
+                             "format_bytes": int(class_fmt[name]),
+                             "format_GBps": round(class_fmt[name] / us / 1e3, 1)}
+    roofline = {"bound": "hbm", "kernel": "fine grid r = b - A x (%s)" % kernel_name(fmt_cov, "ROW_RESIDUAL"),
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                 "algorithmic_bytes": res_bytes, "avg_launch_us": round(avg_s * 1e6, 2),
+                "format_bytes": fmt_bytes, "format_GBps": round(fmt_bytes / avg_s / 1e9, 1),
+                "format_frac": round(fmt_bytes / avg_s / 1e9 / HBM_PEAK_GBS, 4),
+                "device_format": {"row_pattern_rows": fmt_cov["pattern_rows"], "rows": fmt_cov["rows"],
+                                  "column_coded_nnz": fmt_cov["coldict_nnz"], "value_coded_nnz": fmt_cov["valdict_nnz"],
+                                  "nnz": fmt_cov["nnz"], "OMG_COMPRESS": os.environ.get("OMG_COMPRESS", "7 (default)")},
                 "rows_covered": rows_c, "nnz_covered": nnz_c, "fused_last_set": h.level_fused(0),
                 "level0_kernels": kernels}
+
+    # The same launch with the operator as PLAIN int32 CSR (OMG_COMPRESS=0): the figure the
+    # north-star target (">= 50 % of the HBM roofline on the fine-grid SpMV") is about.  Second
+    # hierarchy, untimed region, same hipEvent bracketing of the residual launch.
+    plain = None
+    if not args.no_plain and os.environ.get("OMG_COMPRESS", "7") != "0":
+        h.close()
+        os.environ["OMG_COMPRESS"] = "0"
+        try:
+            h2, b2, _ = build_problem(args.size, args.grids, args.smoother, "float64" if w == 8 else "float32")
+        finally:
+            del os.environ["OMG_COMPRESS"]
+        h2.resident_load(b2)
+        for _ in range(args.warmup):
+            h2.resident_cycle(pre, post, want_norm=False)
+        h2.profile_enable(["residual"])
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            h2.resident_cycle(pre, post, want_norm=False)
+        h2.sync()
+        plain_elapsed = time.perf_counter() - t1
+        pl, pms = h2.profile_read()["residual"]
+        h2.profile_enable(False)
+        p_spmv_ms = h2.spmv_time(20)
+        p_us = 1e3 * pms / pl
+        plain = {"what": "operator held as plain int32 CSR (OMG_COMPRESS=0), same problem, untimed region",
+                 "residual_kernel": "rows_kernel<ROW_RESIDUAL>", "avg_launch_us": round(p_us, 2),
+                 "achieved": round(res_bytes / p_us / 1e3, 1), "frac": round(res_bytes / p_us / 1e3 / HBM_PEAK_GBS, 4),
+                 "fine_grid_spmv_us": round(p_spmv_ms * 1e3, 2), "fine_grid_spmv_GBps": round(spmv_b / p_spmv_ms / 1e6, 1),
+                 "fine_grid_spmv_frac": round(spmv_b / p_spmv_ms / 1e6 / HBM_PEAK_GBS, 4),
+                 "vcycles_per_s": round(args.steps / plain_elapsed, 1)}
+        h2.close()
+    roofline["plain_csr"] = plain
+    if fmt_bytes < res_bytes:
+        roofline["note"] = ("frac counts SURVEY 8(d)'s CSR bytes; the operator sits in HBM in a lossless row-pattern / "
+                            "dictionary coding (DESIGN.md 'Device format'), so the launch moves format_bytes, HBM is "
+                            "driven at format_frac of peak, and frac may exceed 1.  plain_csr is the same launch on "
+                            "plain int32 CSR.")
 
     cpu = None
     if not args.no_cpu:

@@ -99,6 +99,16 @@ int omg_hierarchy_level_sets(const omg_hierarchy *h, int level, int64_t *n_sets)
 int omg_hierarchy_level_fused(const omg_hierarchy *h, int level, int *fused);
 /* Rows and stored entries of one smoother set (for byte accounting of per-set launches). */
 int omg_hierarchy_set_info(const omg_hierarchy *h, int level, int set, int64_t *rows, int64_t *nnz);
+/* How an operator of level l sits in HBM (csrc/common.h "Block-dictionary coding": the device
+ * format is a lossless recoding of the caller's CSR, chosen per row block).  op: 0 = A[l],
+ * 1 = R[l], 2 = R[l]^T; set: one smoother set of A[l], or -1 for the whole operator.  out[]:
+ *   0 rows  1 stored entries  2 row blocks
+ *   3 row blocks / 4 rows / 5 entries held as row patterns (one byte per row)
+ *   6 entries with a one-byte column code   7 entries with a one-byte value code
+ *   8 bytes of the operator one launch over these rows reads from HBM in this format
+ *   9 the same for plain int32 CSR: entries * (4 + sizeof value) + 4 * rows                  */
+#define OMG_FORMAT_FIELDS 10
+int omg_hierarchy_format_info(const omg_hierarchy *h, int level, int op, int set, int64_t *out);
 
 /* replaces: openmg.mgCycle(A, b, level, R, parameters, initial) — openmg/__init__.py:151-236.
  * One V-cycle entered at `level` with pre/post = parameters['preIterations'|'postIterations'].

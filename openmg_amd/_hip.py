@@ -65,6 +65,7 @@ SIGNATURES = {
     "omg_hierarchy_level_sets": (_I, [_P, _I, _I64P]),
     "omg_hierarchy_set_info": (_I, [_P, _I, _I, _I64P, _I64P]),
     "omg_hierarchy_level_fused": (_I, [_P, _I, _IP]),
+    "omg_hierarchy_format_info": (_I, [_P, _I, _I, _I, _I64P]),
     "omg_vcycle": (_I, [_P, _I, _P, _P, _I, _I, _DP]),
     "omg_solve": (_I, [_P, _P, _P, _I, _I, _I, _D, _IP, _DP]),
     "omg_resident_load": (_I, [_P, _P, _P]),
@@ -320,6 +321,15 @@ class Hierarchy:
         rows, nnz = ctypes.c_int64(0), ctypes.c_int64(0)
         check(lib().omg_hierarchy_set_info(self._h, level, s, ctypes.byref(rows), ctypes.byref(nnz)))
         return rows.value, nnz.value
+
+    FORMAT_FIELDS = ("rows", "nnz", "blocks", "pattern_blocks", "pattern_rows", "pattern_nnz",
+                     "coldict_nnz", "valdict_nnz", "format_bytes", "csr_bytes")
+
+    def format_info(self, level, op="A", set=-1):
+        """How A / R / P (= R^T) of `level` is held in HBM (omg_hierarchy_format_info)."""
+        out = (ctypes.c_int64 * len(self.FORMAT_FIELDS))()
+        check(lib().omg_hierarchy_format_info(self._h, int(level), {"A": 0, "R": 1, "P": 2}[op], int(set), out))
+        return dict(zip(self.FORMAT_FIELDS, [int(v) for v in out]))
 
     def profile_enable(self, classes=True):
         """True = every class, False = off, or an iterable of class names (PROFILE_NAMES)."""

@@ -151,6 +151,10 @@ struct DevCsrT {
     int64_t blocks_ccoded = 0, blocks_vcoded = 0, blocks_pcoded = 0;   // blocks using each coding (host, stats)
     int64_t nnz_ccoded = 0, nnz_vcoded = 0, nnz_pcoded = 0;            // their stored entries
     int64_t rows_pcoded = 0;
+    std::vector<char> set_pattern;     // per set: 1 when every block of it is row-pattern coded (host)
+    std::vector<int32_t> blk_host;     // host copy of the row-block table (format statistics)
+    // out[OMG_FORMAT_FIELDS] of include/openmg_hip.h for the blocks of set `set` (-1: all)
+    void format_info(int set, int64_t *out) const;
     std::vector<int64_t> set_blk;      // block offsets of the independent sets (host)
     std::vector<int64_t> sets;         // row offsets of the sets (host)
     int rows_cap = ROWBLK_ROWS;        // most rows a block may hold (> ROWBLK_THREADS: short rows)

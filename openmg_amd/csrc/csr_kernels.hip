@@ -472,6 +472,174 @@ __global__ __launch_bounds__(NT) void rows_serial_kernel(KArgs<V> a, int blk_beg
     }
 }
 
+// ---- pure row-pattern launches -------------------------------------------------------------
+// When every row block of a launch is row-pattern coded (common.h), the matrix arrives as one
+// byte per row plus a dictionary that is the same for (nearly) all blocks.  This kernel then
+// skips LDS altogether: one thread per row; the lanes of a wave are grouped by pattern
+// (interior waves: a single group) and each group walks ITS pattern with wave-uniform
+// operands — offsets and values sit in SGPRs, every length test is a scalar branch — so a
+// stored entry costs one address add, one gather of x and one fma.  Entries are taken in
+// stored order with the same fma chain as rows_kernel: identical bits.
+//
+// The dependent memory round trips per block are what bound it, so the dictionary does not
+// wait for the row codes: a dictionary of at most 64 entries is fetched with ONE vector load
+// (lane i holds entry i) next to the codes, b and x_i, and the wave-uniform operands are then
+// picked out of those registers with v_readlane.  (Larger dictionaries use scalar loads.)
+// No LDS image and <= 64 VGPRs: eight workgroups per CU.
+__device__ __forceinline__ int lane_pick(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
+__device__ __forceinline__ float lane_pick(float v, int lane) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+__device__ __forceinline__ double lane_pick(double v, int lane) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+
+// Dictionary access of one wave.  SMALL: the dictionary sits in the lanes of didx / dval / dbeg
+// (uniform operands come out with v_readlane); otherwise it is read with scalar loads.
+template <bool SMALL, typename V>
+struct PatDictRef {
+    const int32_t *__restrict__ pidx;
+    const V *__restrict__ pval;
+    const int32_t *__restrict__ pbeg;
+    int didx, dbeg;
+    V dval;
+    __device__ __forceinline__ int start(int code) const { return SMALL ? lane_pick(dbeg, code) : pbeg[code]; }
+    __device__ __forceinline__ int off(int k) const { return SMALL ? lane_pick(didx, k) : pidx[k]; }
+    __device__ __forceinline__ V val(int k) const { return SMALL ? lane_pick(dval, k) : pval[k]; }
+};
+
+// N consecutive pattern entries starting at k (everything about them is wave-uniform: no
+// clamps, no predicates): operands, then all gathers, then the fma chain in stored order.
+// FUSED and `whole` (the chunk is the entire row): also the relaxed value and the row's
+// residual with it, from the operands still in registers.
+template <int MODE, int N, bool SMALL, typename V>
+__device__ __forceinline__ void pattern_chunk(const PatDictRef<SMALL, V> &d, const V *__restrict__ xrow, int k,
+                                              bool whole, const RowPre<V> &pre, V &sum, V &diag, V &sum2, V &xnew) {
+    constexpr bool FUSED = (MODE == ROW_GS_RES || MODE == ROW_GS_NORM);
+    constexpr bool NEED_DIAG = (MODE == ROW_GS || MODE == ROW_JACOBI || FUSED);
+    int off[N];
+    V val[N], xg[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        off[j] = d.off(k + j);
+        val[j] = d.val(k + j);
+    }
+#pragma unroll
+    for (int j = 0; j < N; ++j) xg[j] = xrow[off[j]];
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        sum = madd(val[j], xg[j], sum);
+        if (NEED_DIAG && off[j] == 0) diag += val[j];
+    }
+    if constexpr (FUSED) {
+        if (whole) {
+            xnew = pre.xv + (pre.bv - sum) / diag;
+#pragma unroll
+            for (int j = 0; j < N; ++j) sum2 = madd(val[j], off[j] == 0 ? xnew : xg[j], sum2);
+        }
+    }
+}
+
+// One wave's rows of a pattern block: lanes grouped by pattern, one group at a time.
+template <int MODE, bool SMALL, typename V>
+__device__ __forceinline__ void pattern_rows(const KArgs<V> &a, int r, bool active, int code, const RowPre<V> &pre,
+                                             const PatDictRef<SMALL, V> &d, V &sum, V &diag, V &sum2, V &xnew) {
+    constexpr bool FUSED = (MODE == ROW_GS_RES || MODE == ROW_GS_NORM);
+    const V *__restrict__ xrow = a.x + r;                     // x[r + offset]
+    unsigned long long todo = __ballot(active);
+    while (todo) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const int ucode = __builtin_amdgcn_readlane(code, leader);      // wave-uniform from here on
+        const bool mine = active && code == ucode;
+        const int pb = d.start(ucode), pe = d.start(ucode + 1);
+        if (mine) {
+            const bool whole = pe - pb <= 8;
+            int k = pb;
+            for (; k + 8 <= pe; k += 8) pattern_chunk<MODE, 8>(d, xrow, k, whole, pre, sum, diag, sum2, xnew);
+            switch (pe - k) {                                 // uniform: one scalar jump
+                case 1: pattern_chunk<MODE, 1>(d, xrow, k, whole, pre, sum, diag, sum2, xnew); break;
+                case 2: pattern_chunk<MODE, 2>(d, xrow, k, whole, pre, sum, diag, sum2, xnew); break;
+                case 3: pattern_chunk<MODE, 3>(d, xrow, k, whole, pre, sum, diag, sum2, xnew); break;
+                case 4: pattern_chunk<MODE, 4>(d, xrow, k, whole, pre, sum, diag, sum2, xnew); break;
+                case 5: pattern_chunk<MODE, 5>(d, xrow, k, whole, pre, sum, diag, sum2, xnew); break;
+                case 6: pattern_chunk<MODE, 6>(d, xrow, k, whole, pre, sum, diag, sum2, xnew); break;
+                case 7: pattern_chunk<MODE, 7>(d, xrow, k, whole, pre, sum, diag, sum2, xnew); break;
+                default: break;
+            }
+            if constexpr (FUSED) {
+                if (!whole) {
+                    // longer rows: relax, then walk the pattern again (rows_kernel's FUSED branch)
+                    xnew = pre.xv + (pre.bv - sum) / diag;
+                    for (int q = pb; q < pe; ++q) {
+                        const int o = d.off(q);
+                        sum2 = madd(d.val(q), o == 0 ? xnew : xrow[o], sum2);
+                    }
+                }
+            }
+        }
+        todo &= ~__ballot(mine);
+    }
+}
+
+// (Variants measured and dropped: several blocks per workgroup with all their operands
+// requested together — no gain; XCD-chunked block mapping — 6 % slower, as for rows_kernel.)
+template <int MODE, typename V>
+__global__ __launch_bounds__(NT, (MODE == ROW_GS_RES || MODE == ROW_GS_NORM) ? 6 : 8)
+void rows_pattern_kernel(KArgs<V> a, int blk0) {
+    constexpr bool FUSED = (MODE == ROW_GS_RES || MODE == ROW_GS_NORM);
+    constexpr bool NEED_NORM = (MODE == ROW_RESNORM || MODE == ROW_NORM_ONLY || MODE == ROW_GS_NORM);
+    __shared__ double s_red[NT / 64];
+    const int blk = blk0 + int(blockIdx.x);
+    const v4i *info = reinterpret_cast<const v4i *>(a.blk_info);
+    const v4i lo = info[2 * blk], lp = info[2 * blk + 1], hi = info[2 * blk + 2];
+    const int r0 = lo[0], r1 = hi[0];
+    const int32_t *__restrict__ pidx = a.pidx + lp[0];       // this block's dictionary
+    const V *__restrict__ pval = a.pval + lp[0];
+    const int32_t *__restrict__ pbeg = a.pbeg + lp[2];
+    const int cnt = lp[1], npat = lp[3];
+    const bool small = cnt <= 64 && npat < 64;                // block-uniform
+    const int r = r0 + int(threadIdx.x);                      // a pattern block has <= NT rows
+    const bool active = r < r1;
+    const int lane = int(threadIdx.x) & 63;
+    double sq = 0.0;
+    RowPre<V> pre;
+    int code = 0, didx = 0, dbeg = 0;
+    V dval = V(0);
+    if (small) {                                              // with the codes, not after them
+        didx = pidx[min(lane, cnt - 1)];
+        dval = pval[min(lane, cnt - 1)];
+        dbeg = pbeg[min(lane, npat)];
+    }
+    if (active) {
+        pre = row_preload<MODE>(a, r, true);
+        code = pre.beg;
+    }
+    V sum = V(0), diag = V(0), sum2 = V(0), xnew = V(0);
+    if (small) {
+        const PatDictRef<true, V> d{pidx, pval, pbeg, didx, dbeg, dval};
+        pattern_rows<MODE, true>(a, r, active, code, pre, d, sum, diag, sum2, xnew);
+    } else {
+        const PatDictRef<false, V> d{pidx, pval, pbeg, didx, dbeg, dval};
+        pattern_rows<MODE, false>(a, r, active, code, pre, d, sum, diag, sum2, xnew);
+    }
+    if (active) {
+        if constexpr (FUSED) {
+            const V res = pre.bv - sum2;
+            a.y[r] = xnew;
+            if constexpr (MODE == ROW_GS_RES) a.zero[r] = res;
+            else sq += double(res) * double(res);
+        } else {
+            row_epilogue<MODE>(a, r, pre, sum, diag, sq);
+        }
+    }
+    if constexpr (NEED_NORM) {
+        const double tot = block_sum(sq, s_red);
+        if (threadIdx.x == 0) a.partials[blk] = tot;
+    }
+}
+
 // Tuning switches (speed only): OMG_XCD_REMAP=1 enables the XCD-chunked block mapping
 // (measured slower than the hardware's round-robin on the 256^3 stencil: 390 vs 374 us for the
 // residual), OMG_NT_LOADS=0 disables the non-temporal matrix loads (measured 3-4 % slower).
@@ -486,8 +654,14 @@ int launch_flags() {
 }
 
 template <int MODE, typename V>
-void launch_mode(const DevCsrT<V> &A, int64_t blk0, int64_t nblk, const KArgs<V> &k, hipStream_t s) {
+void launch_mode(const DevCsrT<V> &A, int64_t blk0, int64_t nblk, const KArgs<V> &k, bool all_pattern,
+                 hipStream_t s) {
     if (nblk <= 0) return;
+    if (all_pattern) {
+        hipLaunchKernelGGL((rows_pattern_kernel<MODE, V>), dim3((unsigned)nblk), dim3(NT), 0, s, k, (int)blk0);
+        OMG_HIP(hipGetLastError());
+        return;
+    }
     const int flags = launch_flags();
     static const int group = [] { const char *e = getenv("OMG_XCD_GROUP"); return e ? atoi(e) : 0; }();
     const int remap = (nblk < 64) ? 0 : (group > 1 ? group : (flags & 1));
@@ -557,16 +731,22 @@ void launch_rows_range(const DevCsrT<V> &A, int mode, int set_begin, int set_end
                 "launch_rows: set range out of bounds");
     const int64_t blk0 = A.set_blk[set_begin];
     const int64_t nblk = A.set_blk[set_end] - blk0;
+    // every block of the range row-pattern coded -> the LDS-free kernel (OMG_PATTERN_KERNEL=0:
+    // the general kernel, which walks the same dictionaries through LDS; identical bits)
+    bool ap = !A.set_pattern.empty() && set_end > set_begin;
+    if (ap) { const char *e = getenv("OMG_PATTERN_KERNEL"); ap = !(e && e[0] == '0'); }
+    for (int q = set_begin; ap && q < set_end; ++q) ap = A.set_pattern[q] != 0;
     switch (mode) {
-        case ROW_GS_RES: launch_mode<ROW_GS_RES>(A, blk0, nblk, k, s); break;
-        case ROW_GS_NORM: launch_mode<ROW_GS_NORM>(A, blk0, nblk, k, s); break;
-        case ROW_SPMV: launch_mode<ROW_SPMV>(A, blk0, nblk, k, s); break;
-        case ROW_RESIDUAL: launch_mode<ROW_RESIDUAL>(A, blk0, nblk, k, s); break;
-        case ROW_RESNORM: launch_mode<ROW_RESNORM>(A, blk0, nblk, k, s); break;
-        case ROW_NORM_ONLY: launch_mode<ROW_NORM_ONLY>(A, blk0, nblk, k, s); break;
-        case ROW_GS: launch_mode<ROW_GS>(A, blk0, nblk, k, s); break;
-        case ROW_JACOBI: launch_mode<ROW_JACOBI>(A, blk0, nblk, k, s); break;
-        case ROW_AXPY: launch_mode<ROW_AXPY>(A, blk0, nblk, k, s); break;
+
+        case ROW_GS_RES: launch_mode<ROW_GS_RES>(A, blk0, nblk, k, ap, s); break;
+        case ROW_GS_NORM: launch_mode<ROW_GS_NORM>(A, blk0, nblk, k, ap, s); break;
+        case ROW_SPMV: launch_mode<ROW_SPMV>(A, blk0, nblk, k, ap, s); break;
+        case ROW_RESIDUAL: launch_mode<ROW_RESIDUAL>(A, blk0, nblk, k, ap, s); break;
+        case ROW_RESNORM: launch_mode<ROW_RESNORM>(A, blk0, nblk, k, ap, s); break;
+        case ROW_NORM_ONLY: launch_mode<ROW_NORM_ONLY>(A, blk0, nblk, k, ap, s); break;
+        case ROW_GS: launch_mode<ROW_GS>(A, blk0, nblk, k, ap, s); break;
+        case ROW_JACOBI: launch_mode<ROW_JACOBI>(A, blk0, nblk, k, ap, s); break;
+        case ROW_AXPY: launch_mode<ROW_AXPY>(A, blk0, nblk, k, ap, s); break;
         default: throw Error(OMG_ERR_INVALID, "launch_rows: unknown mode");
     }
 }

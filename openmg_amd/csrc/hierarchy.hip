@@ -656,6 +656,18 @@ int omg_hierarchy_set_info(const omg_hierarchy *h, int level, int set, int64_t *
     });
 }
 
+int omg_hierarchy_format_info(const omg_hierarchy *h, int level, int op, int set, int64_t *out) {
+    return guarded([&] {
+        with(h, [&](auto *hh) {
+            check_level(hh, level);
+            OMG_REQUIRE(out && op >= 0 && op <= 2, "null / unknown operator");
+            OMG_REQUIRE(op == 0 || level + 1 < (int)hh->lv.size(), "the coarsest level has no restriction");
+            const auto &L = hh->lv[level];
+            (op == 0 ? L.A : op == 1 ? L.R : L.P).format_info(set, out);
+        });
+    });
+}
+
 int omg_vcycle(omg_hierarchy *h, int level, const double *b, double *x, int pre, int post,
                double *norm) {
     return guarded([&] {

@@ -505,6 +505,15 @@ void DevCsrT<V>::upload(const HostCsr &A, const std::vector<int64_t> &sets_in, h
         vdict.alloc(vpool.size());
         vdict.upload(vpool.data(), vpool.size(), s);
     }
+    // sets made of pattern blocks only run the LDS-free kernel (one row per thread: LPR 1)
+    set_pattern.assign(sets.size() - 1, 0);
+    if (blocks_pcoded && lanes_per_row == 1 && rows_cap <= ROWBLK_THREADS)
+        for (size_t q = 0; q + 1 < sets.size(); ++q) {
+            bool all = set_blk[q + 1] > set_blk[q];
+            for (int64_t k = set_blk[q]; all && k < set_blk[q + 1]; ++k)
+                all = info[size_t(BLK_INFO_INTS) * size_t(k) + 7] != 0;
+            set_pattern[q] = all ? 1 : 0;
+        }
     if (blocks_pcoded) {
         rcode.alloc(size_t(n_rows));
         rcode.upload(rc.data(), size_t(n_rows), s);
@@ -518,6 +527,34 @@ void DevCsrT<V>::upload(const HostCsr &A, const std::vector<int64_t> &sets_in, h
     blk_rows.alloc(info.size());
     blk_rows.upload(info.data(), info.size(), s);
     OMG_HIP(hipStreamSynchronize(s));   // host staging vectors may die after return
+    blk_host = std::move(info);
+}
+
+template <typename V>
+void DevCsrT<V>::format_info(int set, int64_t *out) const {
+    for (int i = 0; i < OMG_FORMAT_FIELDS; ++i) out[i] = 0;
+    OMG_REQUIRE(set >= -1 && (set < 0 || size_t(set) < n_sets()), "format_info: set out of range");
+    const int64_t k0 = set < 0 ? 0 : set_blk[set], k1 = set < 0 ? n_blocks() : set_blk[set + 1];
+    const int64_t w = int64_t(sizeof(V));
+    for (int64_t k = k0; k < k1; ++k) {
+        const int32_t *rec = blk_host.data() + size_t(BLK_INFO_INTS) * size_t(k);
+        const int64_t rows = rec[BLK_INFO_INTS] - rec[0], ent = rec[BLK_INFO_INTS + 1] - rec[1];
+        out[0] += rows;
+        out[1] += ent;
+        out[2] += 1;
+        out[8] += 4 * BLK_INFO_INTS;                              // the block's table record
+        if (rec[7]) {                                             // row patterns: a byte per row
+            out[3] += 1;
+            out[4] += rows;
+            out[5] += ent;
+            out[8] += rows;
+        } else {
+            out[8] += 4 * rows;                                   // row pointers
+            if (rec[2]) { out[6] += ent; out[8] += ent; } else out[8] += 4 * ent;
+            if (rec[3]) { out[7] += ent; out[8] += ent; } else out[8] += w * ent;
+        }
+    }
+    out[9] = out[1] * (4 + w) + 4 * out[0];
 }
 
 template struct DevCsrT<double>;

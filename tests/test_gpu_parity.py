@@ -609,3 +609,97 @@ def test_converged_regime_tracks_the_oracle():
     for k, (g, o) in enumerate(zip(norms, norms_o)):
         assert abs(g - o) <= 1e-10 * o + 1e-14 * bnorm, (k, g, o)
     np.testing.assert_allclose(x, xo, rtol=1e-10, atol=1e-12)
+
+
+# ----------------------------------------------------------- device format (lossless recoding) --
+def _variable_coefficient_7pt(shape, rng):
+    """-div(k grad u) on a box, k random per cell face: the 7-point sparsity with no two equal values."""
+    n = int(np.prod(shape))
+    idx = np.arange(n).reshape(shape)
+    rows, cols, vals = [], [], []
+    diag = np.zeros(n)
+    for ax in range(3):
+        lo = np.take(idx, np.arange(shape[ax] - 1), axis=ax).ravel()
+        hi = np.take(idx, np.arange(1, shape[ax]), axis=ax).ravel()
+        k = rng.random(lo.size) + 0.5
+        rows += [lo, hi]
+        cols += [hi, lo]
+        vals += [-k, -k]
+        np.add.at(diag, lo, k)
+        np.add.at(diag, hi, k)
+    rows.append(np.arange(n)); cols.append(np.arange(n)); vals.append(diag + 0.1)
+    return sp.csr_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(n, n))
+
+
+@pytest.mark.parametrize("case", ["poisson7", "poisson7_lex", "galerkin_golden", "variable7", "stencil27", "irregular",
+                                  "poisson7_f32", "jacobi2d"])
+def test_device_format_modes_are_bit_identical(monkeypatch, golden, case):
+    """The device format (csrc/common.h: row patterns, per-entry column / value dictionaries,
+    plain CSR; OMG_COMPRESS bit mask) and the kernel that walks it (OMG_PATTERN_KERNEL) are
+    speed choices only: every combination must give the same bits as plain CSR."""
+    rng = np.random.default_rng(77)
+    dtype, smoother = "float64", "colour"
+    if case in ("poisson7", "poisson7_lex", "poisson7_f32"):
+        shape = (24, 20, 28)
+        A0 = operators.stencil_poisson(shape)
+        R = operators.restrictionList(shape, 1, 4)
+        A = operators.coeffecientList(A0, R)
+        smoother = "gs" if case == "poisson7_lex" else "colour"
+        dtype = "float32" if case == "poisson7_f32" else "float64"
+    elif case == "galerkin_golden":
+        d = golden("g3_poisson3d_16")
+        A = [csr_from(d, "A%d" % l) for l in range(3)]
+        R = [csr_from(d, "R%d" % l) for l in range(2)]
+    elif case == "variable7":
+        shape = (20, 16, 24)
+        A0 = _variable_coefficient_7pt(shape, rng)
+        R = operators.restrictionList(shape, 0, 4)
+        A = operators.coeffecientList(A0, R)
+    elif case == "stencil27":
+        n1 = 16
+        T = sp.diags([np.ones(n1 - 1), np.ones(n1), np.ones(n1 - 1)], [-1, 0, 1])
+        A0 = sp.csr_matrix(-sp.kron(sp.kron(T, T), T) + sp.diags(np.full(n1 ** 3, 28.0)))
+        R = operators.restrictionList((n1,) * 3, 0, 4)
+        A = operators.coeffecientList(A0, R)
+    elif case == "jacobi2d":
+        shape = (64, 64)
+        A0 = operators.stencil_poisson(shape)
+        R = operators.restrictionList(shape, 1, 4)
+        A = operators.coeffecientList(A0, R)
+        smoother = "jacobi"
+    else:
+        A0, R0 = irregular_problem(rng)
+        A, R = [A0, sp.csr_matrix(R0 @ A0 @ R0.T)], [R0]
+    b = A[0] @ rng.random(A[0].shape[0])
+    runs = {}
+    for mode, pk in (("0", "1"), ("1", "1"), ("2", "1"), ("3", "1"), ("4", "1"), ("4", "0"), ("7", "1"), ("7", "0")):
+        monkeypatch.setenv("OMG_COMPRESS", mode)
+        monkeypatch.setenv("OMG_PATTERN_KERNEL", pk)
+        with _hip.Hierarchy(A, R, smoother=smoother, dtype=dtype) as h:
+            info = h.format_info(0)
+            h.resident_load(b)
+            norms = [h.resident_cycle(2, 1) for _ in range(3)]
+            x = h.resident_fetch()
+            # the single-operation entry points go through the same operators
+            r, nr = h.residual(0, b, x, want_norm=True)
+            rc = h.restrict(0, r)
+            xp = h.prolong_add(0, rc, x)
+        runs[(mode, pk)] = (norms, x, r, nr, rc, xp, info)
+    base = runs[("0", "1")]
+    w = 4 if dtype == "float32" else 8
+    assert base[6]["pattern_rows"] == 0 and base[6]["coldict_nnz"] == 0 and base[6]["valdict_nnz"] == 0
+    assert base[6]["format_bytes"] == base[6]["csr_bytes"] + 32 * base[6]["blocks"]
+    assert base[6]["csr_bytes"] == A[0].nnz * (4 + w) + 4 * A[0].shape[0]
+    for key, run in runs.items():
+        assert run[0] == base[0], key
+        for got, want in zip(run[1:6], base[1:6]):
+            assert np.array_equal(got, want), key
+    full = runs[("7", "1")][6]
+    if case in ("poisson7", "poisson7_f32", "stencil27", "jacobi2d", "galerkin_golden"):
+        assert full["pattern_rows"] == full["rows"]              # constant stencils: a byte per row
+        assert full["format_bytes"] < 0.2 * full["csr_bytes"]
+    if case == "variable7":
+        assert full["pattern_rows"] == 0 and full["valdict_nnz"] == 0
+        assert full["coldict_nnz"] == full["nnz"]                # offsets repeat, values do not
+    if case == "irregular":
+        assert full["pattern_rows"] == 0 and full["coldict_nnz"] < full["nnz"]

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Hardware-counter passes over the V-cycle's row kernels, one rocprofv3 run per counter set
 # (counters of different blocks cannot all be collected at once).  Run on the GPU box:
-#     bash tools/pmc_passes.sh gpurun_out/pmc [prof_cycle.py arguments]
+#     [PASSES="1 7 8"] bash tools/pmc_passes.sh gpurun_out/pmc [prof_cycle.py arguments]
 # --kernel-include-regex keeps the 16k tiny Gauss-Jordan dispatches of the setup out of the
 # collection (they make it take minutes); every pass has its own timeout.
 out=${1:-gpurun_out/pmc}; shift
@@ -12,7 +12,8 @@ i=0
 while read -r set; do
   [ -z "$set" ] && continue
   i=$((i+1))
-  timeout 240 rocprofv3 --pmc $set --kernel-include-regex "rows_kernel" --output-format csv \
+  if [ -n "$PASSES" ] && ! echo " $PASSES " | grep -q " $i "; then continue; fi
+  timeout 240 rocprofv3 --pmc $set --kernel-include-regex "rows_(pattern_)?kernel" --output-format csv \
       -d "$root/$out/p$i" -- python3 "$root/tools/prof_cycle.py" --steps 2 "$@" > "$root/$out/p$i.log" 2>&1
   echo "pass $i ($set): rc=$?"
 done <<'SETS'

@@ -23,12 +23,16 @@ def main():
     for path in sorted(glob.glob(os.path.join(root, "p*", "**", "*counter_collection.csv"), recursive=True)):
         for r in csv.DictReader(open(path)):
             m = re.search(r"rows_kernel<(\d+), (true|false), (true|false), (\d+), (\w+)>", r["Kernel_Name"])
-            if not m:
+            mp = re.search(r"rows_pattern_kernel<(\d+), (\w+)>", r["Kernel_Name"])
+            if not m and not mp:
                 continue
             blocks = int(r["Grid_Size"]) // 256
             if blocks < min_blocks:
                 continue
-            key = (MODES.get(int(m.group(1)), m.group(1)), m.group(5), "short" if m.group(3) == "true" else "lpr" + m.group(4), blocks)
+            if mp:
+                key = (MODES.get(int(mp.group(1)), mp.group(1)), mp.group(2), "pattern", blocks)
+            else:
+                key = (MODES.get(int(m.group(1)), m.group(1)), m.group(5), "short" if m.group(3) == "true" else "lpr" + m.group(4), blocks)
             table[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
             if "Start_Timestamp" in r:
                 dur[key].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
