@@ -126,7 +126,8 @@ struct DevCsrT {
     // Row-block table, BLK_INFO_INTS ints per block (+ end sentinel): [0] first row, [1] first
     // entry, [2] / [3] the block's column / value dictionary as (pool offset << DICT_SHIFT) |
     // entries (0 = none), [4..7] its row-pattern dictionary: entry offset into pidx / pval,
-    // entries, offset into pbeg, patterns (0 = none).
+    // entries, offset into pbeg, patterns (0 = none; [6] is then 1 when every row of the
+    // block holds exactly one entry, which lets the kernels skip the row pointers).
     DevBuf<int32_t> blk_rows;
     // Block-dictionary coding (lossless; DESIGN.md "Device format").  Stencil-like operators
     // repeat a handful of (column - row) offsets and of values inside a row block: such a

@@ -102,14 +102,18 @@ struct RowPre {
     V bv, xv;         // b[r]; x[r] (GS, Jacobi) or y[r] (y += A x)
 };
 
-// pat: the block is row-pattern coded; beg then holds the row's pattern code until
-// row_resolve() turns it into the pattern's extent in the LDS image.
+// extent: where the row's entries are — EXT_ROWPTR: indptr; EXT_PATTERN: the block is
+// row-pattern coded, beg holds the row's pattern code until row_resolve() turns it into the
+// pattern's extent in the LDS image; EXT_NONE: the caller knows (one entry per row).
+enum : int { EXT_ROWPTR = 0, EXT_PATTERN = 1, EXT_NONE = 2 };
 template <int MODE, typename V>
-__device__ __forceinline__ RowPre<V> row_preload(const KArgs<V> &a, int r, bool pat = false) {
+__device__ __forceinline__ RowPre<V> row_preload(const KArgs<V> &a, int r, int extent = EXT_ROWPTR) {
     RowPre<V> p;
-    if (pat) {
+    if (extent == EXT_PATTERN) {
         p.beg = a.rcode[r];
         p.end = 0;
+    } else if (extent == EXT_NONE) {
+        p.beg = p.end = 0;
     } else {
         p.beg = a.indptr[r];
         p.end = a.indptr[r + 1];
@@ -185,23 +189,32 @@ __device__ void process_block(const KArgs<V> &a, int blk, V *s_val, int *s_idx, 
     const int npat = lp[3];
     const bool pat = npat != 0;
     const bool crel = cinfo != 0 || pat;   // LDS then holds (column - row), not the column
+    // plain / per-entry coded block whose rows all hold exactly one entry (prolongation):
+    // entry p0 + (row - r0), the row pointers are not read
+    const bool unit = SHORT && !pat && lp[2] == 1;
     double sq = 0.0;
 
     if (p1 - p0 <= T) {
         int r = r0 + tid / LPR;
         RowPre<V> pre;
-        if (!SHORT && r < r1) pre = row_preload<MODE>(a, r, pat);
+        if (!SHORT && r < r1) pre = row_preload<MODE>(a, r, pat ? EXT_PATTERN : EXT_ROWPTR);
         // ---- phase 1: the block's entries into LDS --------------------------------------
         // plain side: streamed from HBM, 16 B per lane per load; coded side: 8 one-byte codes
         // per lane per load, expanded through the block's dictionary (held in LDS)
-        // (a pattern block streams its dictionary instead of its own entries: same loops, the
-        // source is the 8-entry aligned pool slice, re-read by every block -> never non-temporal)
+        // (a pattern block copies its dictionary — a few hundred bytes, shared between blocks,
+        // L2-resident — instead of streaming entries of its own)
         const int base = pat ? 0 : (p0 & ~7);  // 8-entry aligned: 8 B of codes, 32 B of int32, 64 B of fp64
         const int cnt = pat ? lp[1] : p1 - base;
-        const int32_t *src_i = pat ? a.pidx + lp[0] : a.indices + base;
-        const V *src_v = pat ? a.pval + lp[0] : a.data + base;
-        const bool ntl = nt && !pat;
-        if (pat && tid <= npat) s_cd[tid] = a.pbeg[lp[2] + tid];
+        if (pat) {
+            if (tid <= npat) s_cd[tid] = a.pbeg[lp[2] + tid];
+            const int32_t *di = a.pidx + lp[0];
+            const V *dv = a.pval + lp[0];
+            for (int k = tid; k < cnt; k += NT) {
+                const int s = slot(k);
+                s_idx[s] = di[k];
+                s_val[s] = dv[k];
+            }
+        }
         const int k0 = 8 * tid;
         v2i ccw = {0, 0}, vcw = {0, 0};
         if (cinfo | vinfo) {
@@ -211,20 +224,20 @@ __device__ void process_block(const KArgs<V> &a, int blk, V *s_val, int *s_idx, 
             if (cinfo && k0 < cnt) ccw = *reinterpret_cast<const v2i *>(a.ccode + base + k0);
             if (vinfo && k0 < cnt) vcw = *reinterpret_cast<const v2i *>(a.vcode + base + k0);
         }
-        if (!cinfo) {
-            const v4i *gi = reinterpret_cast<const v4i *>(src_i);
+        if (!cinfo && !pat) {
+            const v4i *gi = reinterpret_cast<const v4i *>(a.indices + base);
             for (int k = 4 * tid; k < cnt; k += 4 * NT) {
                 // matrix entries are read exactly once: non-temporal so that they do not push
                 // the re-used x lines out of L2 / Infinity Cache
-                const v4i v = ntl ? __builtin_nontemporal_load(gi + (k >> 2)) : gi[k >> 2];
+                const v4i v = nt ? __builtin_nontemporal_load(gi + (k >> 2)) : gi[k >> 2];
                 const int s = slot(k);          // k % 4 == 0: the four slots are contiguous
                 s_idx[s] = v[0]; s_idx[s + 1] = v[1]; s_idx[s + 2] = v[2]; s_idx[s + 3] = v[3];
             }
         }
-        if (!vinfo) {
-            const vdat *gd = reinterpret_cast<const vdat *>(src_v);
+        if (!vinfo && !pat) {
+            const vdat *gd = reinterpret_cast<const vdat *>(a.data + base);
             for (int k = VN * tid; k < cnt; k += VN * NT) {
-                const vdat v = ntl ? __builtin_nontemporal_load(gd + (k / VN)) : gd[k / VN];
+                const vdat v = nt ? __builtin_nontemporal_load(gd + (k / VN)) : gd[k / VN];
                 const int s = slot(k);          // k % VN == 0 and VN <= 4: contiguous slots
 #pragma unroll
                 for (int j = 0; j < VN; ++j) s_val[s + j] = v[j];
@@ -267,7 +280,13 @@ __device__ void process_block(const KArgs<V> &a, int blk, V *s_val, int *s_idx, 
                 for (int u = 0; u < U; ++u) {
                     const int ru = rb + u * NT;
                     q[u].beg = q[u].end = 0;
-                    if (ru < r1) q[u] = row_preload<MODE>(a, ru);
+                    if (ru < r1) {
+                        q[u] = row_preload<MODE>(a, ru, unit ? EXT_NONE : EXT_ROWPTR);
+                        if (unit) {                           // one entry per row: no row pointers read
+                            q[u].beg = p0 + (ru - r0);
+                            q[u].end = q[u].beg + 1;
+                        }
+                    }
                 }
 #pragma unroll
                 for (int u = 0; u < U; ++u) {           // first entry of every row, batched
@@ -366,7 +385,7 @@ __device__ void process_block(const KArgs<V> &a, int blk, V *s_val, int *s_idx, 
                 }
                 r += NT / LPR;
                 if (r < r1) {
-                    pre = row_preload<MODE>(a, r, pat);
+                    pre = row_preload<MODE>(a, r, pat ? EXT_PATTERN : EXT_ROWPTR);
                     if (pat) row_resolve(pre, s_cd);
                 }
             }
@@ -586,7 +605,7 @@ __device__ __forceinline__ void pattern_rows(const KArgs<V> &a, int r, bool acti
 // (Variants measured and dropped: several blocks per workgroup with all their operands
 // requested together — no gain; XCD-chunked block mapping — 6 % slower, as for rows_kernel.)
 template <int MODE, typename V>
-__global__ __launch_bounds__(NT, (MODE == ROW_GS_RES || MODE == ROW_GS_NORM) ? 6 : 8)
+__global__ __launch_bounds__(NT, (MODE == ROW_GS_RES || MODE == ROW_GS_NORM) ? 6 : (MODE == ROW_GS || MODE == ROW_JACOBI) ? 7 : 8)
 void rows_pattern_kernel(KArgs<V> a, int blk0) {
     constexpr bool FUSED = (MODE == ROW_GS_RES || MODE == ROW_GS_NORM);
     constexpr bool NEED_NORM = (MODE == ROW_RESNORM || MODE == ROW_NORM_ONLY || MODE == ROW_GS_NORM);
@@ -613,7 +632,7 @@ void rows_pattern_kernel(KArgs<V> a, int blk0) {
         dbeg = pbeg[min(lane, npat)];
     }
     if (active) {
-        pre = row_preload<MODE>(a, r, true);
+        pre = row_preload<MODE>(a, r, EXT_PATTERN);
         code = pre.beg;
     }
     V sum = V(0), diag = V(0), sum2 = V(0), xnew = V(0);

@@ -465,6 +465,11 @@ void DevCsrT<V>::upload(const HostCsr &A, const std::vector<int64_t> &sets_in, h
                     continue;
                 }
             }
+            {   // exactly one entry in every row (prolongation): the kernels then skip the row pointers
+                bool unit = entries == blocks[k + 1] - blocks[k];
+                for (int64_t r = blocks[k]; unit && r < blocks[k + 1]; ++r) unit = A.indptr[r + 1] - A.indptr[r] == 1;
+                rec[6] = unit ? 1 : 0;
+            }
             if (!cdicts[k].empty()) {
                 std::string key(reinterpret_cast<const char *>(cdicts[k].data()), cdicts[k].size() * sizeof(int32_t));
                 auto it = cseen.find(key);
@@ -549,7 +554,7 @@ void DevCsrT<V>::format_info(int set, int64_t *out) const {
             out[5] += ent;
             out[8] += rows;
         } else {
-            out[8] += 4 * rows;                                   // row pointers
+            if (!(rec[6] == 1 && rows_cap > ROWBLK_THREADS)) out[8] += 4 * rows;   // row pointers (not read for one-entry rows)
             if (rec[2]) { out[6] += ent; out[8] += ent; } else out[8] += 4 * ent;
             if (rec[3]) { out[7] += ent; out[8] += ent; } else out[8] += w * ent;
         }
