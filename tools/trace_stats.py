@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""rocprofv3 --kernel-trace CSV -> calls / avg / min / max duration per (kernel, grid size).
+
+    python tools/trace_stats.py <kernel_trace.csv>
+
+rocprofv3's own --stats table averages a kernel over ALL its launches; the row kernels run on
+every level of the hierarchy, so the fine-grid launch bench.py times is the one with the
+largest grid (32768 workgroups for a colour of 256^3)."""
+import collections
+import csv
+import re
+import sys
+
+MODES = {0: "spmv", 1: "residual", 2: "resnorm", 3: "gs", 4: "jacobi", 5: "axpy", 6: "norm_only", 7: "gs+res", 8: "gs+norm"}
+
+
+def short(name):
+    m = re.search(r"rows_pattern_kernel<(\d+), (\w+)>", name)
+    if m:
+        return "rows_pattern_kernel<%s, %s>" % (MODES[int(m.group(1))], m.group(2))
+    m = re.search(r"rows_kernel<(\d+), (true|false), (true|false), (\d+), (\w+)>", name)
+    if m:
+        return "rows_kernel<%s, nt=%s, %s, %s>" % (MODES[int(m.group(1))], m.group(2)[0],
+                                                   "short" if m.group(3) == "true" else "lpr" + m.group(4), m.group(5))
+    m = re.search(r"(\w+_kernel|__amd\w+)", name)
+    return m.group(1) if m else name[:40]
+
+
+def main():
+    agg = collections.defaultdict(list)
+    for r in csv.DictReader(open(sys.argv[1])):
+        wg = max(int(r.get("Workgroup_Size_X", 256) or 256), 1)
+        agg[(short(r["Kernel_Name"]), int(r["Grid_Size_X"]) // wg)].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+    print("%-52s %9s %7s %10s %10s %10s" % ("kernel", "wgs", "calls", "avg us", "min us", "max us"))
+    for (name, wgs), v in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
+        if "eliminate" in name or "pivot" in name or "column_kernel" in name or "swap_scale" in name:
+            wgs = -1
+        print("%-52s %9d %7d %10.2f %10.2f %10.2f" % (name, wgs, len(v), sum(v) / len(v), min(v), max(v)))
+
+
+if __name__ == "__main__":
+    main()
