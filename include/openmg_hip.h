@@ -109,6 +109,11 @@ int omg_hierarchy_set_info(const omg_hierarchy *h, int level, int set, int64_t *
  *   9 the same for plain int32 CSR: entries * (4 + sizeof value) + 4 * rows                  */
 #define OMG_FORMAT_FIELDS 10
 int omg_hierarchy_format_info(const omg_hierarchy *h, int level, int op, int set, int64_t *out);
+/* Host-only check of that recoding (needs no GPU): codes the operator exactly as an upload
+ * would (one smoother set, dtype as in omg_hierarchy_create_ex), decodes it the way the kernels
+ * do and compares every column and every value bit with the input; OMG_ERR_INVALID on any
+ * difference.  out[] as above.                                                             */
+int omg_format_selftest(const omg_csr *A, int dtype, int64_t *out);
 
 /* replaces: openmg.mgCycle(A, b, level, R, parameters, initial) — openmg/__init__.py:151-236.
  * One V-cycle entered at `level` with pre/post = parameters['preIterations'|'postIterations'].

@@ -66,6 +66,7 @@ SIGNATURES = {
     "omg_hierarchy_set_info": (_I, [_P, _I, _I, _I64P, _I64P]),
     "omg_hierarchy_level_fused": (_I, [_P, _I, _IP]),
     "omg_hierarchy_format_info": (_I, [_P, _I, _I, _I, _I64P]),
+    "omg_format_selftest": (_I, [_CSR, _I, _I64P]),
     "omg_vcycle": (_I, [_P, _I, _P, _P, _I, _I, _DP]),
     "omg_solve": (_I, [_P, _P, _P, _I, _I, _I, _D, _IP, _DP]),
     "omg_resident_load": (_I, [_P, _P, _P]),
@@ -388,6 +389,16 @@ class Hierarchy:
 
 
 # ---- standalone ------------------------------------------------------------------------
+def format_selftest(A, dtype="float64"):
+    """Code A into the device format on the host, decode, compare bit for bit (no GPU needed);
+    returns the format statistics (Hierarchy.FORMAT_FIELDS).  Raises HipError on a mismatch."""
+    A = as_csr(A)
+    out = (ctypes.c_int64 * len(Hierarchy.FORMAT_FIELDS))()
+    v = csr_view(A)
+    check(lib().omg_format_selftest(ctypes.byref(v), dtype_code(dtype), out))
+    return dict(zip(Hierarchy.FORMAT_FIELDS, [int(x) for x in out]))
+
+
 def spmv(A, x):
     A = as_csr(A)
     x = vec(x, A.shape[1])

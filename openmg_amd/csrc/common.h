@@ -116,6 +116,26 @@ constexpr int DICT_MAX = 64;                 // entries of a block dictionary (p
 constexpr int DICT_SHIFT = 7;                // table word = (pool offset << DICT_SHIFT) | entries
 constexpr int BLK_INFO_INTS = 8;             // ints per row-block table record
 
+// Host image of the device format of one operator (setup_host.cpp:encode_csr): row-block
+// table, code arrays and dictionary pools exactly as they are uploaded.
+template <typename V>
+struct HostFormat {
+    std::vector<int64_t> sets, set_blk, set_nnz;
+    std::vector<char> set_pattern;
+    int rows_cap = 256, lanes_per_row = 1;
+    std::vector<V> narrowed;                    // float operators: the entries rounded once
+    std::vector<uint8_t> cc, vc, rc;            // per-entry column / value codes, per-row pattern codes
+    std::vector<int32_t> cpool, ppool_idx, ppool_beg, info;
+    std::vector<V> vpool, ppool_val;
+    int64_t blocks_ccoded = 0, blocks_vcoded = 0, blocks_pcoded = 0;
+    int64_t nnz_ccoded = 0, nnz_vcoded = 0, nnz_pcoded = 0, rows_pcoded = 0;
+};
+template <typename V>
+HostFormat<V> encode_csr(const HostCsr &A, const std::vector<int64_t> &sets);
+// encode -> decode -> compare bit for bit (throws on a mismatch); out: OMG_FORMAT_FIELDS statistics
+template <typename V>
+void format_selftest(const omg_csr &A, int64_t *out);
+
 // V = value type of the stored entries and of the vectors the operator is applied to:
 // double (the reference's precision) or float (BASELINE configs[4]); indices are int32.
 template <typename V>

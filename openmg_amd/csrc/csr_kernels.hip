@@ -606,7 +606,7 @@ __device__ __forceinline__ void pattern_rows(const KArgs<V> &a, int r, bool acti
 // requested together — no gain; XCD-chunked block mapping — 6 % slower, as for rows_kernel.)
 template <int MODE, typename V>
 __global__ __launch_bounds__(NT, (MODE == ROW_GS_RES || MODE == ROW_GS_NORM) ? 6 : (MODE == ROW_GS || MODE == ROW_JACOBI) ? 7 : 8)
-void rows_pattern_kernel(KArgs<V> a, int blk0) {
+void rows_pattern_kernel(KArgs<V> a, int blk0, int force_scalar) {
     constexpr bool FUSED = (MODE == ROW_GS_RES || MODE == ROW_GS_NORM);
     constexpr bool NEED_NORM = (MODE == ROW_RESNORM || MODE == ROW_NORM_ONLY || MODE == ROW_GS_NORM);
     __shared__ double s_red[NT / 64];
@@ -618,7 +618,7 @@ void rows_pattern_kernel(KArgs<V> a, int blk0) {
     const V *__restrict__ pval = a.pval + lp[0];
     const int32_t *__restrict__ pbeg = a.pbeg + lp[2];
     const int cnt = lp[1], npat = lp[3];
-    const bool small = cnt <= 64 && npat < 64;                // block-uniform
+    const bool small = cnt <= 64 && npat < 64 && !force_scalar;   // block-uniform
     const int r = r0 + int(threadIdx.x);                      // a pattern block has <= NT rows
     const bool active = r < r1;
     const int lane = int(threadIdx.x) & 63;
@@ -677,7 +677,10 @@ void launch_mode(const DevCsrT<V> &A, int64_t blk0, int64_t nblk, const KArgs<V>
                  hipStream_t s) {
     if (nblk <= 0) return;
     if (all_pattern) {
-        hipLaunchKernelGGL((rows_pattern_kernel<MODE, V>), dim3((unsigned)nblk), dim3(NT), 0, s, k, (int)blk0);
+        // OMG_PATTERN_SMALL=0 (tests): always read the dictionary with scalar loads
+        const char *e = getenv("OMG_PATTERN_SMALL");
+        hipLaunchKernelGGL((rows_pattern_kernel<MODE, V>), dim3((unsigned)nblk), dim3(NT), 0, s, k, (int)blk0,
+                           (e && e[0] == '0') ? 1 : 0);
         OMG_HIP(hipGetLastError());
         return;
     }

@@ -668,6 +668,16 @@ int omg_hierarchy_format_info(const omg_hierarchy *h, int level, int op, int set
     });
 }
 
+int omg_format_selftest(const omg_csr *A, int dtype, int64_t *out) {
+    return guarded([&] {
+        OMG_REQUIRE(A && out, "null argument");
+        OMG_REQUIRE(dtype == OMG_DTYPE_F64 || dtype == OMG_DTYPE_F32, "unknown dtype");
+        validate_csr(*A, "A");
+        if (dtype == OMG_DTYPE_F32) format_selftest<float>(*A, out);
+        else format_selftest<double>(*A, out);
+    });
+}
+
 int omg_vcycle(omg_hierarchy *h, int level, const double *b, double *x, int pre, int post,
                double *norm) {
     return guarded([&] {

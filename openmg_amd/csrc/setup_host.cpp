@@ -284,10 +284,15 @@ struct SmallDict {
 }  // namespace
 
 template <typename V>
-void DevCsrT<V>::upload(const HostCsr &A, const std::vector<int64_t> &sets_in, hipStream_t s) {
-    n_rows = A.n_rows;
-    n_cols = A.n_cols;
-    nnz = A.nnz;
+HostFormat<V> encode_csr(const HostCsr &A, const std::vector<int64_t> &sets_in) {
+    HostFormat<V> F;
+    auto &sets = F.sets;
+    auto &set_blk = F.set_blk;
+    auto &set_nnz = F.set_nnz;
+    auto &set_pattern = F.set_pattern;
+    int &rows_cap = F.rows_cap;
+    int &lanes_per_row = F.lanes_per_row;
+    const int64_t n_rows = A.n_rows, nnz = A.nnz;
     sets = sets_in;
     if (sets.empty()) sets = {0, n_rows};
     std::vector<int32_t> blocks;
@@ -310,25 +315,17 @@ void DevCsrT<V>::upload(const HostCsr &A, const std::vector<int64_t> &sets_in, h
     set_nnz.assign(sets.size() - 1, 0);
     for (size_t k = 0; k + 1 < sets.size(); ++k) set_nnz[k] = A.indptr[sets[k + 1]] - A.indptr[sets[k]];
     make_row_blocks(A.indptr, sets, max_rows, ROWBLK_NNZ, blocks, set_blk);
-    indptr.alloc(A.indptr.size());
-    indices.alloc(std::max<size_t>(A.indices.size(), 1));
-    data.alloc(std::max<size_t>(A.data.size(), 1));
-    indptr.upload(A.indptr.data(), A.indptr.size(), s);
-    indices.upload(A.indices.data(), A.indices.size(), s);
-    std::vector<V> narrowed;             // float operator: round the fp64 entries once, here
+    // float operator: round the fp64 entries once, here
+    if constexpr (!std::is_same<V, double>::value) F.narrowed.assign(A.data.begin(), A.data.end());
     const V *vals;
-    if constexpr (std::is_same<V, double>::value) {
-        vals = A.data.data();
-    } else {
-        narrowed.assign(A.data.begin(), A.data.end());
-        vals = narrowed.data();
-    }
-    data.upload(vals, A.data.size(), s);
-
+    if constexpr (std::is_same<V, double>::value) vals = A.data.data();
+    else vals = F.narrowed.data();
     // ---- block dictionaries (common.h "Block-dictionary coding") -----------------------------
     const int64_t nblk = int64_t(blocks.size()) - 1;          // `blocks` ends with a sentinel row
     const int mode = compress_mode();
-    std::vector<uint8_t> cc, vc, rc;
+    auto &cc = F.cc;
+    auto &vc = F.vc;
+    auto &rc = F.rc;
     const size_t nb = size_t(std::max<int64_t>(nblk, 0));
     std::vector<std::vector<int32_t>> cdicts(nb);
     std::vector<std::vector<V>> vdicts(nb);
@@ -427,14 +424,17 @@ void DevCsrT<V>::upload(const HostCsr &A, const std::vector<int64_t> &sets_in, h
         }
     }
     // pool the dictionaries: blocks of a stencil operator mostly share one, which then stays in L2
-    std::vector<int32_t> cpool, ppool_idx, ppool_beg;
-    std::vector<V> vpool, ppool_val;
-    std::vector<int32_t> info(size_t(BLK_INFO_INTS) * blocks.size(), 0);
+    auto &cpool = F.cpool;
+    auto &ppool_idx = F.ppool_idx;
+    auto &ppool_beg = F.ppool_beg;
+    auto &vpool = F.vpool;
+    auto &ppool_val = F.ppool_val;
+    auto &info = F.info;
+    info.assign(size_t(BLK_INFO_INTS) * blocks.size(), 0);
     {
         std::unordered_map<std::string, int32_t> cseen, vseen;
         std::unordered_map<std::string, std::pair<int32_t, int32_t>> pseen;    // -> (entry offset, table offset)
         const int64_t pool_cap = (int64_t(1) << (31 - DICT_SHIFT)) - DICT_MAX;
-        blocks_ccoded = blocks_vcoded = nnz_ccoded = nnz_vcoded = blocks_pcoded = rows_pcoded = nnz_pcoded = 0;
         for (int64_t k = 0; k <= nblk; ++k) {
             int32_t *rec = info.data() + size_t(BLK_INFO_INTS) * size_t(k);
             rec[0] = blocks[k];
@@ -459,9 +459,9 @@ void DevCsrT<V>::upload(const HostCsr &A, const std::vector<int64_t> &sets_in, h
                     rec[5] = int32_t(pd.idx.size());
                     rec[6] = it->second.second;
                     rec[7] = int32_t(pd.beg.size()) - 1;
-                    ++blocks_pcoded;
-                    rows_pcoded += blocks[k + 1] - blocks[k];
-                    nnz_pcoded += entries;
+                    ++F.blocks_pcoded;
+                    F.rows_pcoded += blocks[k + 1] - blocks[k];
+                    F.nnz_pcoded += entries;
                     continue;
                 }
             }
@@ -479,8 +479,8 @@ void DevCsrT<V>::upload(const HostCsr &A, const std::vector<int64_t> &sets_in, h
                 }
                 if (it != cseen.end()) {
                     rec[2] = (it->second << DICT_SHIFT) | int32_t(cdicts[k].size());
-                    ++blocks_ccoded;
-                    nnz_ccoded += entries;
+                    ++F.blocks_ccoded;
+                    F.nnz_ccoded += entries;
                 }
             }
             if (!vdicts[k].empty()) {
@@ -492,57 +492,110 @@ void DevCsrT<V>::upload(const HostCsr &A, const std::vector<int64_t> &sets_in, h
                 }
                 if (it != vseen.end()) {
                     rec[3] = (it->second << DICT_SHIFT) | int32_t(vdicts[k].size());
-                    ++blocks_vcoded;
-                    nnz_vcoded += entries;
+                    ++F.blocks_vcoded;
+                    F.nnz_vcoded += entries;
                 }
             }
         }
     }
-    if (blocks_ccoded) {
-        ccode.alloc(size_t(nnz));
-        ccode.upload(cc.data(), size_t(nnz), s);
-        cdict.alloc(cpool.size());
-        cdict.upload(cpool.data(), cpool.size(), s);
-    }
-    if (blocks_vcoded) {
-        vcode.alloc(size_t(nnz));
-        vcode.upload(vc.data(), size_t(nnz), s);
-        vdict.alloc(vpool.size());
-        vdict.upload(vpool.data(), vpool.size(), s);
-    }
     // sets made of pattern blocks only run the LDS-free kernel (one row per thread: LPR 1)
     set_pattern.assign(sets.size() - 1, 0);
-    if (blocks_pcoded && lanes_per_row == 1 && rows_cap <= ROWBLK_THREADS)
+    if (F.blocks_pcoded && lanes_per_row == 1 && rows_cap <= ROWBLK_THREADS)
         for (size_t q = 0; q + 1 < sets.size(); ++q) {
             bool all = set_blk[q + 1] > set_blk[q];
             for (int64_t k = set_blk[q]; all && k < set_blk[q + 1]; ++k)
                 all = info[size_t(BLK_INFO_INTS) * size_t(k) + 7] != 0;
             set_pattern[q] = all ? 1 : 0;
         }
-    if (blocks_pcoded) {
-        rcode.alloc(size_t(n_rows));
-        rcode.upload(rc.data(), size_t(n_rows), s);
-        pidx.alloc(ppool_idx.size());
-        pidx.upload(ppool_idx.data(), ppool_idx.size(), s);
-        pval.alloc(ppool_val.size());
-        pval.upload(ppool_val.data(), ppool_val.size(), s);
-        pbeg.alloc(ppool_beg.size());
-        pbeg.upload(ppool_beg.data(), ppool_beg.size(), s);
-    }
-    blk_rows.alloc(info.size());
-    blk_rows.upload(info.data(), info.size(), s);
-    OMG_HIP(hipStreamSynchronize(s));   // host staging vectors may die after return
-    blk_host = std::move(info);
+    return F;
 }
 
 template <typename V>
-void DevCsrT<V>::format_info(int set, int64_t *out) const {
+void DevCsrT<V>::upload(const HostCsr &A, const std::vector<int64_t> &sets_in, hipStream_t s) {
+    HostFormat<V> F = encode_csr<V>(A, sets_in);             // host only (setup_host.cpp)
+    n_rows = A.n_rows;
+    n_cols = A.n_cols;
+    nnz = A.nnz;
+    sets = std::move(F.sets);
+    set_blk = std::move(F.set_blk);
+    set_nnz = std::move(F.set_nnz);
+    set_pattern = std::move(F.set_pattern);
+    rows_cap = F.rows_cap;
+    lanes_per_row = F.lanes_per_row;
+    blocks_ccoded = F.blocks_ccoded; blocks_vcoded = F.blocks_vcoded; blocks_pcoded = F.blocks_pcoded;
+    nnz_ccoded = F.nnz_ccoded; nnz_vcoded = F.nnz_vcoded; nnz_pcoded = F.nnz_pcoded;
+    rows_pcoded = F.rows_pcoded;
+    indptr.alloc(A.indptr.size());
+    indices.alloc(std::max<size_t>(A.indices.size(), 1));
+    data.alloc(std::max<size_t>(A.data.size(), 1));
+    indptr.upload(A.indptr.data(), A.indptr.size(), s);
+    indices.upload(A.indices.data(), A.indices.size(), s);
+    if constexpr (std::is_same<V, double>::value) data.upload(A.data.data(), A.data.size(), s);
+    else data.upload(F.narrowed.data(), F.narrowed.size(), s);
+    auto put = [&](auto &dev, const auto &host) {
+        dev.alloc(host.size());
+        dev.upload(host.data(), host.size(), s);
+    };
+    if (blocks_ccoded) { put(ccode, F.cc); put(cdict, F.cpool); }
+    if (blocks_vcoded) { put(vcode, F.vc); put(vdict, F.vpool); }
+    if (blocks_pcoded) { put(rcode, F.rc); put(pidx, F.ppool_idx); put(pval, F.ppool_val); put(pbeg, F.ppool_beg); }
+    put(blk_rows, F.info);
+    OMG_HIP(hipStreamSynchronize(s));   // host staging vectors may die after return
+    blk_host = std::move(F.info);
+}
+
+// The (column, value) of every stored entry rebuilt from the coded form the way the kernels do
+// it (csr_kernels.hip process_block / pattern_rows).  Self-test and documentation of the format.
+template <typename V>
+void decode_format(const HostFormat<V> &F, const HostCsr &A, std::vector<int32_t> &cols, std::vector<V> &vals) {
+    cols.assign(size_t(A.nnz), -1);
+    vals.assign(size_t(A.nnz), V(0));
+    const int64_t nblk = int64_t(F.info.size() / BLK_INFO_INTS) - 1;
+    for (int64_t k = 0; k < nblk; ++k) {
+        const int32_t *rec = F.info.data() + size_t(BLK_INFO_INTS) * size_t(k);
+        const int64_t r0 = rec[0], r1 = rec[BLK_INFO_INTS];
+        if (rec[7]) {
+            const int32_t *beg = F.ppool_beg.data() + rec[6];
+            for (int64_t r = r0; r < r1; ++r) {
+                const int code = F.rc[r];
+                OMG_REQUIRE(code < rec[7], "decode: pattern code out of range");
+                const int pb = beg[code], pe = beg[code + 1];
+                OMG_REQUIRE(pe - pb == A.indptr[r + 1] - A.indptr[r], "decode: pattern length differs from the row's");
+                OMG_REQUIRE(pe <= rec[5], "decode: pattern runs past its dictionary");
+                for (int j = 0; j < pe - pb; ++j) {
+                    cols[A.indptr[r] + j] = F.ppool_idx[rec[4] + pb + j] + int32_t(r);
+                    vals[A.indptr[r] + j] = F.ppool_val[rec[4] + pb + j];
+                }
+            }
+            continue;
+        }
+        const int ncd = rec[2] & (2 * DICT_MAX - 1), nvd = rec[3] & (2 * DICT_MAX - 1);
+        for (int64_t r = r0; r < r1; ++r)
+            for (int64_t p = A.indptr[r]; p < A.indptr[r + 1]; ++p) {
+                if (rec[2]) {
+                    OMG_REQUIRE(F.cc[p] < ncd, "decode: column code out of range");
+                    cols[p] = F.cpool[(rec[2] >> DICT_SHIFT) + F.cc[p]] + int32_t(r);
+                } else {
+                    cols[p] = A.indices[p];
+                }
+                if (rec[3]) {
+                    OMG_REQUIRE(F.vc[p] < nvd, "decode: value code out of range");
+                    vals[p] = F.vpool[(rec[3] >> DICT_SHIFT) + F.vc[p]];
+                } else {
+                    vals[p] = std::is_same<V, double>::value ? V(A.data[p]) : F.narrowed[p];
+                }
+            }
+    }
+}
+
+void format_stats(const std::vector<int32_t> &info, const std::vector<int64_t> &set_blk, int rows_cap, int64_t w,
+                  int set, int64_t *out) {
     for (int i = 0; i < OMG_FORMAT_FIELDS; ++i) out[i] = 0;
-    OMG_REQUIRE(set >= -1 && (set < 0 || size_t(set) < n_sets()), "format_info: set out of range");
-    const int64_t k0 = set < 0 ? 0 : set_blk[set], k1 = set < 0 ? n_blocks() : set_blk[set + 1];
-    const int64_t w = int64_t(sizeof(V));
+    const int64_t n_sets = set_blk.empty() ? 0 : int64_t(set_blk.size()) - 1;
+    OMG_REQUIRE(set >= -1 && set < n_sets, "format_info: set out of range");
+    const int64_t k0 = set < 0 ? 0 : set_blk[set], k1 = set < 0 ? (n_sets ? set_blk.back() : 0) : set_blk[set + 1];
     for (int64_t k = k0; k < k1; ++k) {
-        const int32_t *rec = blk_host.data() + size_t(BLK_INFO_INTS) * size_t(k);
+        const int32_t *rec = info.data() + size_t(BLK_INFO_INTS) * size_t(k);
         const int64_t rows = rec[BLK_INFO_INTS] - rec[0], ent = rec[BLK_INFO_INTS + 1] - rec[1];
         out[0] += rows;
         out[1] += ent;
@@ -562,6 +615,31 @@ void DevCsrT<V>::format_info(int set, int64_t *out) const {
     out[9] = out[1] * (4 + w) + 4 * out[0];
 }
 
+template <typename V>
+void DevCsrT<V>::format_info(int set, int64_t *out) const {
+    format_stats(blk_host, set_blk, rows_cap, int64_t(sizeof(V)), set, out);
+}
+
+// Encode, decode, compare bit for bit; no device involved.
+template <typename V>
+void format_selftest(const omg_csr &A, int64_t *out) {
+    HostCsr H = permute_csr(A, nullptr, nullptr);
+    HostFormat<V> F = encode_csr<V>(H, {});
+    std::vector<int32_t> cols;
+    std::vector<V> vals;
+    decode_format(F, H, cols, vals);
+    for (int64_t p = 0; p < H.nnz; ++p) {
+        const V want = V(H.data[p]);
+        OMG_REQUIRE(cols[p] == H.indices[p], "format self-test: column of entry " + std::to_string(p) + " not reproduced");
+        OMG_REQUIRE(Bits<V>::of(vals[p]) == Bits<V>::of(want), "format self-test: value of entry " + std::to_string(p) + " not reproduced");
+    }
+    format_stats(F.info, F.set_blk, F.rows_cap, int64_t(sizeof(V)), -1, out);
+}
+
+template HostFormat<double> encode_csr<double>(const HostCsr &, const std::vector<int64_t> &);
+template HostFormat<float> encode_csr<float>(const HostCsr &, const std::vector<int64_t> &);
+template void format_selftest<double>(const omg_csr &, int64_t *);
+template void format_selftest<float>(const omg_csr &, int64_t *);
 template struct DevCsrT<double>;
 template struct DevCsrT<float>;
 

@@ -4,9 +4,11 @@ import doctest
 
 import numpy as np
 import pytest
+import scipy.sparse as sp
 
 import openmg_amd
 from openmg_amd import _hip, operators, tools
+from oracle import mg_oracle as orc
 
 
 def test_generators_match_reference_fixtures(golden):
@@ -75,3 +77,64 @@ def test_drop_in_alias_package():
     assert openmg.mgSolve is openmg_amd.mgSolve and openmg.mg_cycle is openmg_amd.mgCycle
     assert ops is openmg_amd.operators and openmg.tools is openmg_amd.tools
     assert openmg.defaults is openmg_amd.defaults
+
+
+# ------------------------------------------------ device format: host-side coder (no GPU) --
+def _shuffled_rows(A, rng):
+    A = sp.csr_matrix(A)
+    for i in range(A.shape[0]):
+        s, e = A.indptr[i], A.indptr[i + 1]
+        q = rng.permutation(e - s)
+        A.indices[s:e] = A.indices[s:e][q]
+        A.data[s:e] = A.data[s:e][q]
+    A.has_sorted_indices = False
+    return A
+
+
+def test_device_format_is_lossless_and_picks_the_expected_coding(monkeypatch):
+    """csrc/setup_host.cpp:encode_csr codes every row block as row patterns, per-entry
+    dictionaries or plain CSR; omg_format_selftest decodes the result like the kernels do and
+    compares every column and value bit with the input.  Runs on the host."""
+    rng = np.random.default_rng(5)
+    n1 = 12
+    T = sp.diags([np.ones(n1 - 1), np.ones(n1), np.ones(n1 - 1)], [-1, 0, 1])
+    stencil27 = sp.csr_matrix(-sp.kron(sp.kron(T, T), T) + sp.diags(np.full(n1 ** 3, 28.0)))
+    poisson = orc.stencil_poisson((20, 16, 24))
+    variable = sp.csr_matrix(poisson.multiply(sp.csr_matrix((rng.random(poisson.nnz) + 0.5, poisson.indices, poisson.indptr),
+                                                           shape=poisson.shape)))
+    irregular = sp.random(3000, 3000, density=0.004, random_state=np.random.RandomState(3), format="csr") \
+        + sp.diags(np.arange(1.0, 3001.0))
+    irregular = _shuffled_rows(irregular, rng)
+    long_row = sp.lil_matrix((500, 3000))
+    long_row[7, :] = rng.standard_normal(3000)                   # > ROWBLK_NNZ entries: a block of its own
+    long_row[8, 3] = -0.0                                        # the sign of a zero is a bit too
+    long_row[9, 5] = np.nan
+    long_row = sp.csr_matrix(long_row)
+    R = orc.restriction((16, 16, 16))
+    empty = sp.csr_matrix((40, 40))
+    for mode in ("7", "3", "4", "2", "1", "0"):
+        monkeypatch.setenv("OMG_COMPRESS", mode)
+        for dtype, w in (("float64", 8), ("float32", 4)):
+            got = {name: _hip.format_selftest(M, dtype) for name, M in
+                   (("poisson", poisson), ("stencil27", stencil27), ("variable", variable), ("irregular", irregular),
+                    ("long_row", long_row), ("R", R), ("P", sp.csr_matrix(R.T)), ("empty", empty))}
+            for name, f in got.items():
+                assert f["csr_bytes"] == f["nnz"] * (4 + w) + 4 * f["rows"], (name, mode)
+            if mode == "0":
+                for name, f in got.items():
+                    assert f["pattern_rows"] == f["coldict_nnz"] == f["valdict_nnz"] == 0
+                    assert f["format_bytes"] == f["csr_bytes"] + 32 * f["blocks"] - (4 * f["rows"] if name == "P" else 0)
+            if mode == "7":
+                assert got["poisson"]["pattern_rows"] == got["poisson"]["rows"]
+                assert got["stencil27"]["pattern_rows"] == got["stencil27"]["rows"]
+                assert got["poisson"]["format_bytes"] < 0.2 * got["poisson"]["csr_bytes"]
+                assert got["variable"]["pattern_rows"] == 0 and got["variable"]["valdict_nnz"] == 0
+                assert got["variable"]["coldict_nnz"] == got["variable"]["nnz"]
+                assert got["irregular"]["pattern_rows"] == 0
+                assert got["R"]["valdict_nnz"] + got["R"]["pattern_nnz"] == got["R"]["nnz"]      # all entries 0.125
+                assert got["P"]["valdict_nnz"] == got["P"]["nnz"] and got["P"]["pattern_rows"] == 0
+                assert got["empty"]["nnz"] == 0
+    with pytest.raises(_hip.HipError):                          # a bad dtype is an argument error, not a crash
+        out = (_hip.ctypes.c_int64 * 10)()
+        v = _hip.csr_view(_hip.as_csr(poisson))
+        _hip.check(_hip.lib().omg_format_selftest(_hip.ctypes.byref(v), 9, out))
