@@ -114,6 +114,7 @@ constexpr int ROWBLK_ROWS = 256;      // <= one row per thread
 constexpr int ROWBLK_NNZ = OMG_ROWBLK_NNZ;   // entries staged through LDS per workgroup
 constexpr int DICT_MAX = 64;                 // entries of a block dictionary (power of two)
 constexpr int DICT_SHIFT = 7;                // table word = (pool offset << DICT_SHIFT) | entries
+constexpr int MIN_CODED_ENTRIES = 64;         // smaller blocks stay plain CSR
 constexpr int BLK_INFO_INTS = 8;             // ints per row-block table record
 
 // Host image of the device format of one operator (setup_host.cpp:encode_csr): row-block

@@ -503,7 +503,9 @@ __global__ __launch_bounds__(NT) void rows_serial_kernel(KArgs<V> a, int blk_beg
 // The dependent memory round trips per block are what bound it, so the dictionary does not
 // wait for the row codes: a dictionary of at most 64 entries is fetched with ONE vector load
 // (lane i holds entry i) next to the codes, b and x_i, and the wave-uniform operands are then
-// picked out of those registers with v_readlane.  (Larger dictionaries use scalar loads.)
+// picked out of those registers with v_readlane.  (Blocks with larger dictionaries — e.g. the
+// hyperplane sets of a lexicographic ordering — go through rows_kernel's LDS image: a
+// scalar-load variant of this kernel was measured at half its speed.)
 // No LDS image and <= 64 VGPRs: eight workgroups per CU.
 __device__ __forceinline__ int lane_pick(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
 __device__ __forceinline__ float lane_pick(float v, int lane) {
@@ -515,26 +517,24 @@ __device__ __forceinline__ double lane_pick(double v, int lane) {
     return __hiloint2double(hi, lo);
 }
 
-// Dictionary access of one wave.  SMALL: the dictionary sits in the lanes of didx / dval / dbeg
-// (uniform operands come out with v_readlane); otherwise it is read with scalar loads.
-template <bool SMALL, typename V>
+// Dictionary of one wave's block: lane i of didx / dval holds entry i, lane c of dbeg the start
+// of pattern c (a pattern-kernel block has at most 64 entries in at most 63 patterns); the
+// wave-uniform operands come out with v_readlane.
+template <typename V>
 struct PatDictRef {
-    const int32_t *__restrict__ pidx;
-    const V *__restrict__ pval;
-    const int32_t *__restrict__ pbeg;
     int didx, dbeg;
     V dval;
-    __device__ __forceinline__ int start(int code) const { return SMALL ? lane_pick(dbeg, code) : pbeg[code]; }
-    __device__ __forceinline__ int off(int k) const { return SMALL ? lane_pick(didx, k) : pidx[k]; }
-    __device__ __forceinline__ V val(int k) const { return SMALL ? lane_pick(dval, k) : pval[k]; }
+    __device__ __forceinline__ int start(int code) const { return lane_pick(dbeg, code); }
+    __device__ __forceinline__ int off(int k) const { return lane_pick(didx, k); }
+    __device__ __forceinline__ V val(int k) const { return lane_pick(dval, k); }
 };
 
 // N consecutive pattern entries starting at k (everything about them is wave-uniform: no
 // clamps, no predicates): operands, then all gathers, then the fma chain in stored order.
 // FUSED and `whole` (the chunk is the entire row): also the relaxed value and the row's
 // residual with it, from the operands still in registers.
-template <int MODE, int N, bool SMALL, typename V>
-__device__ __forceinline__ void pattern_chunk(const PatDictRef<SMALL, V> &d, const V *__restrict__ xrow, int k,
+template <int MODE, int N, typename V>
+__device__ __forceinline__ void pattern_chunk(const PatDictRef<V> &d, const V *__restrict__ xrow, int k,
                                               bool whole, const RowPre<V> &pre, V &sum, V &diag, V &sum2, V &xnew) {
     constexpr bool FUSED = (MODE == ROW_GS_RES || MODE == ROW_GS_NORM);
     constexpr bool NEED_DIAG = (MODE == ROW_GS || MODE == ROW_JACOBI || FUSED);
@@ -562,9 +562,9 @@ __device__ __forceinline__ void pattern_chunk(const PatDictRef<SMALL, V> &d, con
 }
 
 // One wave's rows of a pattern block: lanes grouped by pattern, one group at a time.
-template <int MODE, bool SMALL, typename V>
+template <int MODE, typename V>
 __device__ __forceinline__ void pattern_rows(const KArgs<V> &a, int r, bool active, int code, const RowPre<V> &pre,
-                                             const PatDictRef<SMALL, V> &d, V &sum, V &diag, V &sum2, V &xnew) {
+                                             const PatDictRef<V> &d, V &sum, V &diag, V &sum2, V &xnew) {
     constexpr bool FUSED = (MODE == ROW_GS_RES || MODE == ROW_GS_NORM);
     const V *__restrict__ xrow = a.x + r;                     // x[r + offset]
     unsigned long long todo = __ballot(active);
@@ -606,7 +606,7 @@ __device__ __forceinline__ void pattern_rows(const KArgs<V> &a, int r, bool acti
 // requested together — no gain; XCD-chunked block mapping — 6 % slower, as for rows_kernel.)
 template <int MODE, typename V>
 __global__ __launch_bounds__(NT, (MODE == ROW_GS_RES || MODE == ROW_GS_NORM) ? 6 : (MODE == ROW_GS || MODE == ROW_JACOBI) ? 7 : 8)
-void rows_pattern_kernel(KArgs<V> a, int blk0, int force_scalar) {
+void rows_pattern_kernel(KArgs<V> a, int blk0) {
     constexpr bool FUSED = (MODE == ROW_GS_RES || MODE == ROW_GS_NORM);
     constexpr bool NEED_NORM = (MODE == ROW_RESNORM || MODE == ROW_NORM_ONLY || MODE == ROW_GS_NORM);
     __shared__ double s_red[NT / 64];
@@ -617,32 +617,21 @@ void rows_pattern_kernel(KArgs<V> a, int blk0, int force_scalar) {
     const int32_t *__restrict__ pidx = a.pidx + lp[0];       // this block's dictionary
     const V *__restrict__ pval = a.pval + lp[0];
     const int32_t *__restrict__ pbeg = a.pbeg + lp[2];
-    const int cnt = lp[1], npat = lp[3];
-    const bool small = cnt <= 64 && npat < 64 && !force_scalar;   // block-uniform
+    const int cnt = lp[1], npat = lp[3];                      // cnt <= 64, npat <= 63 (setup: set_pattern)
     const int r = r0 + int(threadIdx.x);                      // a pattern block has <= NT rows
     const bool active = r < r1;
     const int lane = int(threadIdx.x) & 63;
     double sq = 0.0;
     RowPre<V> pre;
-    int code = 0, didx = 0, dbeg = 0;
-    V dval = V(0);
-    if (small) {                                              // with the codes, not after them
-        didx = pidx[min(lane, cnt - 1)];
-        dval = pval[min(lane, cnt - 1)];
-        dbeg = pbeg[min(lane, npat)];
-    }
+    int code = 0;
+    // the dictionary with the codes, not after them
+    const PatDictRef<V> d{pidx[min(lane, cnt - 1)], pbeg[min(lane, npat)], pval[min(lane, cnt - 1)]};
     if (active) {
         pre = row_preload<MODE>(a, r, EXT_PATTERN);
         code = pre.beg;
     }
     V sum = V(0), diag = V(0), sum2 = V(0), xnew = V(0);
-    if (small) {
-        const PatDictRef<true, V> d{pidx, pval, pbeg, didx, dbeg, dval};
-        pattern_rows<MODE, true>(a, r, active, code, pre, d, sum, diag, sum2, xnew);
-    } else {
-        const PatDictRef<false, V> d{pidx, pval, pbeg, didx, dbeg, dval};
-        pattern_rows<MODE, false>(a, r, active, code, pre, d, sum, diag, sum2, xnew);
-    }
+    pattern_rows<MODE>(a, r, active, code, pre, d, sum, diag, sum2, xnew);
     if (active) {
         if constexpr (FUSED) {
             const V res = pre.bv - sum2;
@@ -677,10 +666,7 @@ void launch_mode(const DevCsrT<V> &A, int64_t blk0, int64_t nblk, const KArgs<V>
                  hipStream_t s) {
     if (nblk <= 0) return;
     if (all_pattern) {
-        // OMG_PATTERN_SMALL=0 (tests): always read the dictionary with scalar loads
-        const char *e = getenv("OMG_PATTERN_SMALL");
-        hipLaunchKernelGGL((rows_pattern_kernel<MODE, V>), dim3((unsigned)nblk), dim3(NT), 0, s, k, (int)blk0,
-                           (e && e[0] == '0') ? 1 : 0);
+        hipLaunchKernelGGL((rows_pattern_kernel<MODE, V>), dim3((unsigned)nblk), dim3(NT), 0, s, k, (int)blk0);
         OMG_HIP(hipGetLastError());
         return;
     }

@@ -155,3 +155,69 @@ def stencil_poisson(shape):
     out = sp.csr_matrix((data, indices, indptr.astype(np.int32)), shape=(N, N))
     out.has_sorted_indices = True
     return out
+
+
+def stencil27_variable(shape, seed=0):
+    """Symmetric positive definite 27-point operator with VARIABLE coefficients on a 3-D box
+    (BASELINE.json configs[4]'s synthetic input; NOT in the reference): every pair of grid
+    points that differ by at most one step along each axis is coupled by -k, k uniform in
+    [0.5, 1.5) / (squared distance of the pair), and the diagonal is the sum of a point's
+    couplings + 0.1.  C-order numbering, sorted CSR with int32 indices, assembled directly in
+    CSR (the 256^3 operator has 450 M entries)."""
+    shape = tuple(int(s) for s in shape)
+    if len(shape) != 3:
+        raise ValueError("stencil27_variable needs a 3-D shape")
+    N = int(np.prod(shape))
+    strides = (shape[1] * shape[2], shape[2], 1)
+    cz, cy, cx = np.unravel_index(np.arange(N, dtype=np.int64), shape)
+    coords = (cz, cy, cx)
+    dirs = [(dz, dy, dx) for dz in (-1, 0, 1) for dy in (-1, 0, 1) for dx in (-1, 0, 1)]   # ascending column offset
+    def valid_of(d):
+        v = np.ones(N, dtype=bool)
+        for ax in range(3):
+            if d[ax] < 0:
+                v &= coords[ax] > 0
+            elif d[ax] > 0:
+                v &= coords[ax] < shape[ax] - 1
+        return v
+    valid = [valid_of(d) for d in dirs]
+    counts = np.zeros(N, dtype=np.int64)
+    for v in valid:
+        counts += v
+    indptr = np.zeros(N + 1, dtype=np.int64)
+    np.cumsum(counts, out=indptr[1:])
+    nnz = int(indptr[-1])
+    indices = np.empty(nnz, dtype=np.int32)
+    data = np.empty(nnz, dtype=np.float64)
+    cursor = indptr[:-1].copy()
+    rows = np.arange(N, dtype=np.int64)
+    diag_pos = None
+    diag = np.full(N, 0.1)
+    rng = np.random.default_rng(seed)
+    # the coupling of a pair (i, i + d), d "positive", is drawn once and used for both (i, j) and (j, i)
+    pair_k = {}
+    for d in dirs:
+        if d > (0, 0, 0):
+            v = valid_of(d)
+            k = np.zeros(N)
+            k[v] = (rng.random(int(v.sum())) + 0.5) / float(d[0] ** 2 + d[1] ** 2 + d[2] ** 2)
+            pair_k[d] = k
+    for d, v in zip(dirs, valid):
+        off = d[0] * strides[0] + d[1] * strides[1] + d[2] * strides[2]
+        pos = cursor[v]
+        indices[pos] = (rows[v] + off).astype(np.int32)
+        if d == (0, 0, 0):
+            diag_pos = pos
+        else:
+            if d > (0, 0, 0):
+                kv = pair_k[d][v]                              # stored at the lower point of the pair
+            else:
+                nd = (-d[0], -d[1], -d[2])
+                kv = pair_k[nd][rows[v] + off]                 # the neighbour is the lower point
+            data[pos] = -kv
+            diag[v] += kv
+        cursor += v
+    data[diag_pos] = diag
+    out = sp.csr_matrix((data, indices, indptr.astype(np.int32)), shape=(N, N))
+    out.has_sorted_indices = True
+    return out

@@ -672,12 +672,10 @@ def test_device_format_modes_are_bit_identical(monkeypatch, golden, case):
         A, R = [A0, sp.csr_matrix(R0 @ A0 @ R0.T)], [R0]
     b = A[0] @ rng.random(A[0].shape[0])
     runs = {}
-    # pk: "1" rows_pattern_kernel (dictionary in lanes), "s" the same with scalar dictionary loads,
-    # "0" rows_kernel walking the dictionaries through LDS
-    for mode, pk in (("0", "1"), ("1", "1"), ("2", "1"), ("3", "1"), ("4", "1"), ("4", "0"), ("7", "1"), ("7", "s"), ("7", "0")):
+    # pk: "1" rows_pattern_kernel where the dictionaries fit a wave, "0" rows_kernel walking them through LDS
+    for mode, pk in (("0", "1"), ("1", "1"), ("2", "1"), ("3", "1"), ("4", "1"), ("4", "0"), ("7", "1"), ("7", "0")):
         monkeypatch.setenv("OMG_COMPRESS", mode)
-        monkeypatch.setenv("OMG_PATTERN_KERNEL", "0" if pk == "0" else "1")
-        monkeypatch.setenv("OMG_PATTERN_SMALL", "0" if pk == "s" else "1")
+        monkeypatch.setenv("OMG_PATTERN_KERNEL", pk)
         with _hip.Hierarchy(A, R, smoother=smoother, dtype=dtype) as h:
             info = h.format_info(0)
             h.resident_load(b)
