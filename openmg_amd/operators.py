@@ -157,21 +157,47 @@ def stencil_poisson(shape):
     return out
 
 
-def stencil27_variable(shape, seed=0):
-    """Symmetric positive definite 27-point operator with VARIABLE coefficients on a 3-D box
-    (BASELINE.json configs[4]'s synthetic input; NOT in the reference): every pair of grid
-    points that differ by at most one step along each axis is coupled by -k, k uniform in
-    [0.5, 1.5) / (squared distance of the pair), and the diagonal is the sum of a point's
-    couplings + 0.1.  C-order numbering, sorted CSR with int32 indices, assembled directly in
-    CSR (the 256^3 operator has 450 M entries)."""
+def _q1_element_stiffness():
+    """8 x 8 stiffness matrix of the trilinear (Q1) element on the unit cube for -div(grad u),
+    local nodes numbered (dz, dy, dx) in C order; 2-point Gauss quadrature is exact here."""
+    g = np.array([0.5 - 0.5 / np.sqrt(3.0), 0.5 + 0.5 / np.sqrt(3.0)])
+    corners = [(dz, dy, dx) for dz in (0, 1) for dy in (0, 1) for dx in (0, 1)]
+    K = np.zeros((8, 8))
+    for z in g:
+        for y in g:
+            for x in g:
+                grads = []
+                for (cz, cy, cx) in corners:
+                    fz, fy, fx = (z if cz else 1 - z), (y if cy else 1 - y), (x if cx else 1 - x)
+                    sz, sy, sx = (1.0 if cz else -1.0), (1.0 if cy else -1.0), (1.0 if cx else -1.0)
+                    grads.append((sz * fy * fx, fz * sy * fx, fz * fy * sx))
+                G = np.array(grads)
+                K += G @ G.T / 8.0
+    return K, corners
+
+
+def stencil27_variable(shape, seed=2024):
+    """27-point variable-coefficient operator of BASELINE.json configs[4] as SURVEY.md 8(d)
+    specifies it (NOT in the reference): Q1 finite-element stiffness of -div(kappa grad u) on a
+    box of unit cells whose unknowns are the interior nodes `shape` (homogeneous Dirichlet
+    boundary), kappa = exp(U(-1, 1) ln 10) per cell from default_rng(seed).  Symmetric positive
+    definite.  C-order numbering, sorted CSR with int32 indices, all 27 couplings of a node
+    stored (the six along the axes cancel to ~0 only where kappa is locally constant),
+    assembled directly in CSR (the 256^3 operator has 450 M entries)."""
     shape = tuple(int(s) for s in shape)
     if len(shape) != 3:
         raise ValueError("stencil27_variable needs a 3-D shape")
     N = int(np.prod(shape))
     strides = (shape[1] * shape[2], shape[2], 1)
+    K, corners = _q1_element_stiffness()
+    rng = np.random.default_rng(seed)
+    # one cell per (node, node + 1) interval including the two boundary layers: (n + 1)^3 cells;
+    # cell c spans nodes c - 1 .. c along each axis (node -1 and node n are the Dirichlet boundary)
+    kappa = np.exp(rng.uniform(-1.0, 1.0, size=tuple(s + 1 for s in shape)) * np.log(10.0))
     cz, cy, cx = np.unravel_index(np.arange(N, dtype=np.int64), shape)
     coords = (cz, cy, cx)
     dirs = [(dz, dy, dx) for dz in (-1, 0, 1) for dy in (-1, 0, 1) for dx in (-1, 0, 1)]   # ascending column offset
+
     def valid_of(d):
         v = np.ones(N, dtype=bool)
         for ax in range(3):
@@ -191,33 +217,22 @@ def stencil27_variable(shape, seed=0):
     data = np.empty(nnz, dtype=np.float64)
     cursor = indptr[:-1].copy()
     rows = np.arange(N, dtype=np.int64)
-    diag_pos = None
-    diag = np.full(N, 0.1)
-    rng = np.random.default_rng(seed)
-    # the coupling of a pair (i, i + d), d "positive", is drawn once and used for both (i, j) and (j, i)
-    pair_k = {}
-    for d in dirs:
-        if d > (0, 0, 0):
-            v = valid_of(d)
-            k = np.zeros(N)
-            k[v] = (rng.random(int(v.sum())) + 0.5) / float(d[0] ** 2 + d[1] ** 2 + d[2] ** 2)
-            pair_k[d] = k
     for d, v in zip(dirs, valid):
         off = d[0] * strides[0] + d[1] * strides[1] + d[2] * strides[2]
+        # A[i, i + d] = sum over the cells that contain both nodes: local node a of the cell is i,
+        # local node a + d is i + d; the cell's origin node is i - a, i.e. cell index i - a + 1
+        val = np.zeros(int(v.sum()))
+        pz, py, px = cz[v], cy[v], cx[v]
+        for ia, a in enumerate(corners):
+            b = (a[0] + d[0], a[1] + d[1], a[2] + d[2])
+            if min(b) < 0 or max(b) > 1:
+                continue
+            ib = corners.index(b)
+            val += kappa[pz - a[0] + 1, py - a[1] + 1, px - a[2] + 1] * K[ia, ib]
         pos = cursor[v]
         indices[pos] = (rows[v] + off).astype(np.int32)
-        if d == (0, 0, 0):
-            diag_pos = pos
-        else:
-            if d > (0, 0, 0):
-                kv = pair_k[d][v]                              # stored at the lower point of the pair
-            else:
-                nd = (-d[0], -d[1], -d[2])
-                kv = pair_k[nd][rows[v] + off]                 # the neighbour is the lower point
-            data[pos] = -kv
-            diag[v] += kv
+        data[pos] = val
         cursor += v
-    data[diag_pos] = diag
     out = sp.csr_matrix((data, indices, indptr.astype(np.int32)), shape=(N, N))
     out.has_sorted_indices = True
     return out

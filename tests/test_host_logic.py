@@ -138,3 +138,32 @@ def test_device_format_is_lossless_and_picks_the_expected_coding(monkeypatch):
         out = (_hip.ctypes.c_int64 * 10)()
         v = _hip.csr_view(_hip.as_csr(poisson))
         _hip.check(_hip.lib().omg_format_selftest(_hip.ctypes.byref(v), 9, out))
+
+
+def test_stencil27_variable_is_the_q1_stiffness_survey_8d_specifies():
+    """configs[4]'s input: assembled directly in CSR; compared here with a cell-by-cell
+    assembly of kappa_c * K_e over all cells touching an interior node."""
+    K, corners = operators._q1_element_stiffness()
+    np.testing.assert_allclose(K[0] * 12, [4, 0, 0, -1, 0, -1, -1, -1], atol=1e-12)
+    np.testing.assert_allclose(K.sum(axis=1), 0, atol=1e-12)
+    shape = (4, 3, 5)
+    N = int(np.prod(shape))
+    kappa = np.exp(np.random.default_rng(2024).uniform(-1, 1, size=tuple(s + 1 for s in shape)) * np.log(10))
+    want = np.zeros((N, N))
+    flat = lambda p: (p[0] * shape[1] + p[1]) * shape[2] + p[2]
+    inside = lambda p: all(0 <= p[k] < shape[k] for k in range(3))
+    for c in np.ndindex(*kappa.shape):
+        nodes = [(c[0] - 1 + a[0], c[1] - 1 + a[1], c[2] - 1 + a[2]) for a in corners]
+        for ia, na in enumerate(nodes):
+            for ib, nb in enumerate(nodes):
+                if inside(na) and inside(nb):
+                    want[flat(na), flat(nb)] += kappa[c] * K[ia, ib]
+    A = operators.stencil27_variable(shape)
+    np.testing.assert_allclose(A.toarray(), want, rtol=0, atol=1e-13)
+    assert A.has_sorted_indices and A.indices.dtype == np.int32
+    assert abs(A - A.T).max() == 0
+    assert np.linalg.eigvalsh(A.toarray()).min() > 0
+    B = operators.stencil27_variable((9, 8, 10))
+    assert np.bincount(np.diff(B.indptr))[27] == 7 * 6 * 8          # interior nodes hold all 27 couplings
+    with pytest.raises(ValueError):
+        operators.stencil27_variable((8, 8))

@@ -28,7 +28,7 @@ def main():
     shape = (args.size,) * 3
     w = 4 if args.dtype == "float32" else 8
     t = time.perf_counter()
-    A0 = operators.stencil27_variable(shape, seed=1)
+    A0 = operators.stencil27_variable(shape)                  # Q1 stiffness, kappa per cell, default_rng(2024)
     t_gen = time.perf_counter() - t
     b = A0 @ np.random.default_rng(2).random(A0.shape[0])
     t = time.perf_counter()
