@@ -102,6 +102,8 @@ def main():
     ap.add_argument("--smoother", default="colour")
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"],
                     help="precision the levels are stored / computed in (f64 = BASELINE configs[2], the default)")
+    ap.add_argument("--stencil", default="7pt", choices=["7pt", "27var"],
+                    help="multi-GPU leg only: 27var = BASELINE configs[4]'s 27-point variable-coefficient operator")
     ap.add_argument("--graph", type=int, default=0, help="replay the cycle from a hipGraph")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-plain", action="store_true", help="skip the plain-CSR (OMG_COMPRESS=0) comparison leg")

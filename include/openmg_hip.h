@@ -248,6 +248,11 @@ typedef struct omg_dist_group omg_dist_group;
 int omg_dist_create(int rank, int n_ranks, int n_levels, const omg_dist_level *levels,
                     const omg_csr *coarse_global, const int64_t *coarse_counts,
                     int smoother, double omega, omg_dist **out);
+/* Same with the levels stored / computed in `dtype` (OMG_DTYPE_F64 is omg_dist_create); halo
+ * messages and the coarse all-gather then travel in that type.  Host vectors stay double.  */
+int omg_dist_create_ex(int rank, int n_ranks, int n_levels, const omg_dist_level *levels,
+                       const omg_csr *coarse_global, const int64_t *coarse_counts,
+                       int smoother, double omega, int dtype, omg_dist **out);
 int omg_dist_destroy(omg_dist *d);
 /* Replicated tail: below the last distributed level every rank runs `tail` — an ordinary
  * omg_hierarchy whose finest operator is the WHOLE operator of that level — on the gathered
@@ -266,6 +271,11 @@ int omg_dist_fetch(omg_dist *d, double *x_local);
 /* One V-cycle over all ranks (collective: every rank calls it).  *norm (nullable) = the
  * GLOBAL ||b - A x||_2 (openmg/__init__.py:227).                                          */
 int omg_dist_cycle(omg_dist *d, int pre, int post, double *norm);
+/* Per-GPU measurement helpers of a multi-GPU run: `reps` launches of y = A_0 x over this rank's
+ * rows in one hipEvent bracket (average ms per launch), and omg_hierarchy_format_info for this
+ * rank's operators.                                                                          */
+int omg_dist_spmv_time(omg_dist *d, int reps, double *avg_ms);
+int omg_dist_format_info(omg_dist *d, int level, int op, int set, int64_t *out);
 /* Loopback group: ALL ranks of a decomposition inside one process on one GPU, halos moved by
  * device-to-device copies.  Same schedule as omg_dist_cycle; used to verify the distributed
  * algorithm where only one GPU is available.                                               */

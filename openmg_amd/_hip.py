@@ -91,6 +91,7 @@ SIGNATURES = {
     "omg_csr_result_free": (_I, [_P]),
     "omg_restriction": (_I, [_I, _I64P, _P, _P, _P, _I64P, _I64P]),
     "omg_dist_create": (_I, [_I, _I, _I, _P, _CSR, _I64P, _I, _D, _PP]),
+    "omg_dist_create_ex": (_I, [_I, _I, _I, _P, _CSR, _I64P, _I, _D, _I, _PP]),
     "omg_dist_destroy": (_I, [_P]),
     "omg_dist_set_tail": (_I, [_P, _P]),
     "omg_hierarchy_cycle_dev": (_I, [_P, _P, _P, _I, _I, _P]),
@@ -101,6 +102,8 @@ SIGNATURES = {
     "omg_dist_load": (_I, [_P, _P, _P]),
     "omg_dist_fetch": (_I, [_P, _P]),
     "omg_dist_cycle": (_I, [_P, _I, _I, _DP]),
+    "omg_dist_spmv_time": (_I, [_P, _I, _DP]),
+    "omg_dist_format_info": (_I, [_P, _I, _I, _I, _I64P]),
     "omg_dist_group_create": (_I, [_I, _PP, _PP]),
     "omg_dist_group_destroy": (_I, [_P]),
     "omg_dist_group_cycle": (_I, [_P, _I, _I, _DP]),

@@ -4,7 +4,7 @@ import ctypes
 import numpy as np
 import scipy.sparse as sp
 
-from ._hip import DistLevelView, as_csr, check, csr_view, lib, smoother_code, vec
+from ._hip import DistLevelView, as_csr, check, csr_view, dtype_code, lib, smoother_code, vec
 
 
 def set_device(device):
@@ -24,9 +24,10 @@ class DistRank:
     peers, send_off, send_idx, recv_off."""
 
     def __init__(self, rank, n_ranks, levels, coarse_global, coarse_counts, smoother="colour", omega=1.0,
-                 tail=None):
+                 tail=None, dtype="float64"):
         """coarse_global: the whole operator of the last distributed level (direct solve), or None
-        when `tail` — a _hip.Hierarchy over the levels below it — does that job."""
+        when `tail` — a _hip.Hierarchy over the levels below it — does that job.  dtype: precision
+        of the levels on the device (and of the halo messages); host vectors are float64."""
         self.rank, self.n_ranks = int(rank), int(n_ranks)
         self._tail = tail
         keep = []
@@ -63,10 +64,12 @@ class DistRank:
         gv = None if G is None else csr_view(G)
         counts = (ctypes.c_int64 * self.n_ranks)(*[int(c) for c in coarse_counts])
         self.n_local = levels[0]["A"].shape[0]
+        self.n_halo = int(levels[0]["n_halo"])
+        self.nnz_local = int(levels[0]["A"].nnz)
         h = ctypes.c_void_p()
-        check(lib().omg_dist_create(self.rank, self.n_ranks, len(levels), views,
-                                    None if gv is None else ctypes.byref(gv), counts,
-                                    smoother_code(smoother), float(omega), ctypes.byref(h)))
+        check(lib().omg_dist_create_ex(self.rank, self.n_ranks, len(levels), views,
+                                       None if gv is None else ctypes.byref(gv), counts,
+                                       smoother_code(smoother), float(omega), dtype_code(dtype), ctypes.byref(h)))
         self._h = h
         if tail is not None:
             check(lib().omg_dist_set_tail(self._h, tail._h))
@@ -112,6 +115,19 @@ class DistRank:
             return norm.value
         check(lib().omg_dist_cycle(self._h, int(pre), int(post), None))
         return None
+
+
+    def spmv_time(self, reps=20):
+        """Average milliseconds of y = A_0 x over this rank's rows (omg_dist_spmv_time)."""
+        ms = ctypes.c_double(0.0)
+        check(lib().omg_dist_spmv_time(self._h, int(reps), ctypes.byref(ms)))
+        return ms.value
+
+    def format_info(self, level, op="A", set=-1):
+        from ._hip import Hierarchy
+        out = (ctypes.c_int64 * len(Hierarchy.FORMAT_FIELDS))()
+        check(lib().omg_dist_format_info(self._h, int(level), {"A": 0, "R": 1, "P": 2}[op], int(set), out))
+        return dict(zip(Hierarchy.FORMAT_FIELDS, [int(v) for v in out]))
 
 
 class DistGroup:

@@ -477,7 +477,7 @@ __global__ __launch_bounds__(NT, 6) void rows_kernel(KArgs<V> a, int blk0, int r
 // sweep of a 1-D operator is n single-row sets, and the first/last hyperplanes of a 3-D
 // grid are tiny too.  Stores of set s are visible to set s+1 through the barrier's
 // workgroup-scope fence (same CU, same L1).
-template <int MODE, typename V>
+template <int MODE, int LPR, typename V>
 __global__ __launch_bounds__(NT) void rows_serial_kernel(KArgs<V> a, int blk_begin, int blk_end) {
     __shared__ V s_val[LDS_SLOTS];
     __shared__ int s_idx[LDS_SLOTS];
@@ -485,7 +485,7 @@ __global__ __launch_bounds__(NT) void rows_serial_kernel(KArgs<V> a, int blk_beg
     __shared__ int s_cd[2 * DICT_MAX];
     __shared__ V s_vd[DICT_MAX];
     for (int blk = blk_begin; blk < blk_end; ++blk) {
-        process_block<MODE, false, false, 1>(a, blk, s_val, s_idx, s_red, s_cd, s_vd);
+        process_block<MODE, false, false, LPR>(a, blk, s_val, s_idx, s_red, s_cd, s_vd);
         __threadfence_block();
         __syncthreads();
     }
@@ -768,7 +768,10 @@ void launch_gs_serial(const DevCsrT<V> &A, int set_begin, int set_end, const Row
     k.ymap = nullptr;
     const int b0 = (int)A.set_blk[set_begin], b1 = (int)A.set_blk[set_end];
     if (b1 <= b0) return;
-    hipLaunchKernelGGL((rows_serial_kernel<ROW_GS, V>), dim3(1), dim3(NT), 0, s, k, b0, b1);
+    // the same lanes-per-row association as launch_rows uses for this operator: a row's sum
+    // must not depend on which of the two kernels relaxes it
+    if (A.lanes_per_row == 4) hipLaunchKernelGGL((rows_serial_kernel<ROW_GS, 4, V>), dim3(1), dim3(NT), 0, s, k, b0, b1);
+    else hipLaunchKernelGGL((rows_serial_kernel<ROW_GS, 1, V>), dim3(1), dim3(NT), 0, s, k, b0, b1);
     OMG_HIP(hipGetLastError());
 }
 

@@ -23,6 +23,7 @@
 #include <cmath>
 #include <cstring>
 #include <memory>
+#include <type_traits>
 
 #include "common.h"
 
@@ -77,19 +78,21 @@ Rccl g_rccl;
             throw omg::Error(OMG_ERR_HIP, std::string(#call) + ": " + g_rccl.GetErrorString(r_)); \
     } while (0)
 
+template <typename V>
 struct DLevel {
     int64_t n_loc = 0, n_halo = 0;
-    DevCsr A, R, P;
+    DevCsrT<V> A, R, P;
     Ordering ord;
     DevBuf<int32_t> perm;
     DevBuf<int32_t> r_out;                     // restriction row -> slot in the next level's ordering
-    DevBuf<double> x, tmp, b, r, partials, nat;
-    double *xp = nullptr, *tp = nullptr;
+    DevBuf<V> x, tmp, b, r;
+    DevBuf<double> partials, nat;              // block sums of squares; double staging for host I/O
+    V *xp = nullptr, *tp = nullptr;
     // halo plan
     std::vector<int> peers;
     std::vector<int64_t> send_off, recv_off;   // per peer, size peers + 1
     DevBuf<int32_t> send_idx;                  // rows (this level's ordering) to send, all peers
-    DevBuf<double> send_buf;
+    DevBuf<V> send_buf;
     int set_group = 1;                         // 2: sets are (boundary, interior) pairs
     std::vector<int> entry_group;              // per plan entry: colour it carries, -1 = any
     std::vector<int64_t> send_start;           // per entry: first row in x if contiguous, else -1
@@ -97,21 +100,25 @@ struct DLevel {
 
 __global__ void sqrt_kernel(double *v) { *v = sqrt(*v); }
 
-}  // namespace
-}  // namespace omg
+template <typename V> struct NcclType;
+template <> struct NcclType<double> { static constexpr ncclDataType_t value = ncclDouble; };
+template <> struct NcclType<float> { static constexpr ncclDataType_t value = ncclFloat; };
 
-using namespace omg;
-
-struct omg_dist {
+// One rank's slab, levels stored and computed in V (double: the reference's precision; float:
+// BASELINE configs[4] — halo messages are then half the bytes too).
+template <typename V>
+struct Dist {
+    using value_type = V;
     int rank = 0, n_ranks = 1;
-    std::vector<DLevel> lv;
+    std::vector<DLevel<V>> lv;
     int smoother = OMG_SMOOTH_GS_COLOUR;
     double omega = 1.0;
     hipStream_t own = nullptr, stream = nullptr;
     // coarsest level: replicated inverse, gathered right-hand side
     int64_t n_coarse = 0, coarse_lo = 0;
     std::vector<int64_t> coarse_counts;        // rows per rank at the coarsest level
-    DevBuf<double> coarse_inv, coarse_rhs, coarse_sol;
+    DevBuf<V> coarse_inv, coarse_rhs, coarse_sol;
+    DevBuf<double> tail_rhs, tail_sol;         // the tail hierarchy's device boundary is double
     // Optional replicated TAIL: instead of one direct solve, every rank runs the levels below
     // the last distributed one as an ordinary single-GPU hierarchy on the gathered right-hand
     // side (no communication down there; the coarse levels of a slab decomposition are pure
@@ -126,7 +133,10 @@ struct omg_dist {
     bool halo_dirty = true;
     bool loaded = false;
 
-    ~omg_dist() {
+    Dist() = default;
+    Dist(const Dist &) = delete;
+    Dist &operator=(const Dist &) = delete;
+    ~Dist() {
         if (comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(comm);
         if (ev_go) (void)hipEventDestroy(ev_go);
         if (ev_done) (void)hipEventDestroy(ev_done);
@@ -135,22 +145,28 @@ struct omg_dist {
     }
 };
 
+}  // namespace
+}  // namespace omg
+
+using namespace omg;
+
+struct omg_dist {
+    std::unique_ptr<omg::Dist<double>> d;
+    std::unique_ptr<omg::Dist<float>> f;
+};
+
 struct omg_dist_group {
-    std::vector<omg_dist *> ranks;             // borrowed; all on one device, one shared stream
+    std::vector<omg_dist *> ranks;             // borrowed; all on one device, one shared stream, one dtype
 };
 
 namespace omg {
 namespace {
 
-using D = omg_dist;
-
-omg_csr view(const HostCsr &A) {
-    return omg_csr{A.n_rows, A.n_cols, A.nnz, A.indptr.data(), A.indices.data(), A.data.data()};
-}
-
-std::unique_ptr<D> create(int rank, int n_ranks, int n_levels, const omg_dist_level *lv,
-                          const omg_csr *coarse_global, const int64_t *coarse_counts, int smoother,
-                          double omega) {
+template <typename V>
+std::unique_ptr<Dist<V>> create(int rank, int n_ranks, int n_levels, const omg_dist_level *lv,
+                                const omg_csr *coarse_global, const int64_t *coarse_counts, int smoother,
+                                double omega) {
+    using D = Dist<V>;
     OMG_REQUIRE(n_ranks >= 1 && rank >= 0 && rank < n_ranks, "bad rank / n_ranks");
     OMG_REQUIRE(n_levels >= 1 && lv && coarse_counts, "null argument");
     require_device();
@@ -168,7 +184,7 @@ std::unique_ptr<D> create(int rank, int n_ranks, int n_levels, const omg_dist_le
     d->sumsq.alloc(1);
     for (int l = 0; l < n_levels; ++l) {
         const omg_dist_level &in = lv[l];
-        DLevel &L = d->lv[l];
+        DLevel<V> &L = d->lv[l];
         validate_csr(in.A, ("A[" + std::to_string(l) + "]").c_str());
         L.n_loc = in.A.n_rows;
         L.n_halo = in.n_halo;
@@ -179,14 +195,15 @@ std::unique_ptr<D> create(int rank, int n_ranks, int n_levels, const omg_dist_le
     }
     for (int l = 0; l < n_levels; ++l) {
         const omg_dist_level &in = lv[l];
-        DLevel &L = d->lv[l];
+        DLevel<V> &L = d->lv[l];
         const bool last = l + 1 == n_levels;
         const bool id = L.ord.identity;
         {
             HostCsr Ap = permute_csr(in.A, id ? nullptr : L.ord.perm.data(), id ? nullptr : L.ord.inv.data(), L.n_loc);
             L.A.upload(Ap, L.ord.sets, d->stream);
         }
-        if (!id) { L.perm.alloc(L.n_loc); L.perm.upload(L.ord.perm.data(), L.n_loc, d->stream); L.nat.alloc(L.n_loc); }
+        if (!id) { L.perm.alloc(L.n_loc); L.perm.upload(L.ord.perm.data(), L.n_loc, d->stream); }
+        if (l == 0) L.nat.alloc(std::max<int64_t>(L.n_loc, 1));
         if (!last) {
             // smoothed level: every owned row needs a diagonal
             for (int64_t i = 0; i < L.n_loc; ++i) {
@@ -195,7 +212,7 @@ std::unique_ptr<D> create(int rank, int n_ranks, int n_levels, const omg_dist_le
                 if (!have) throw Error(OMG_ERR_NO_DIAGONAL, "level " + std::to_string(l) + ": local row " + std::to_string(i) + " has no diagonal entry");
             }
             validate_csr(in.R, ("R[" + std::to_string(l) + "]").c_str());
-            const DLevel &C = d->lv[l + 1];
+            const DLevel<V> &C = d->lv[l + 1];
             OMG_REQUIRE(in.R.n_rows == C.n_loc && in.R.n_cols == L.n_loc,
                         "R[l] must be (coarse owned rows) x (fine owned rows): slabs must be cut on aggregate boundaries");
             HostCsr Rp = permute_csr(in.R, C.ord.identity ? nullptr : C.ord.perm.data(), id ? nullptr : L.ord.inv.data());
@@ -268,21 +285,34 @@ std::unique_ptr<D> create(int rank, int n_ranks, int n_levels, const omg_dist_le
             validate_csr(*coarse_global, "coarse_global");
             OMG_REQUIRE(coarse_global->n_rows == coarse_global->n_cols && coarse_global->n_rows == tot,
                         "coarse operator must be square and match the coarse row counts");
-            DevCsr G;
+            DevCsr G;                            // inverted in double whatever V is
             HostCsr Gh = permute_csr(*coarse_global, nullptr, nullptr);
             G.upload(Gh, {}, d->stream);
-            d->coarse_inv.alloc(std::max<size_t>(size_t(d->n_coarse) * size_t(d->n_coarse), 1));
-            dense_inverse_from_csr(G, d->coarse_inv.p, d->stream);
+            const size_t nn = std::max<size_t>(size_t(d->n_coarse) * size_t(d->n_coarse), 1);
+            d->coarse_inv.alloc(nn);
+            if constexpr (std::is_same<V, double>::value) {
+                dense_inverse_from_csr(G, d->coarse_inv.p, d->stream);
+            } else {
+                DevBuf<double> inv64(nn);
+                dense_inverse_from_csr(G, inv64.p, d->stream);
+                launch_gather<double, V>(inv64.p, nullptr, d->coarse_inv.p, int64_t(size_t(d->n_coarse) * size_t(d->n_coarse)), d->stream);
+                OMG_HIP(hipStreamSynchronize(d->stream));
+            }
         }
         d->coarse_rhs.alloc(std::max<int64_t>(d->n_coarse, 1));
         d->coarse_sol.alloc(std::max<int64_t>(d->n_coarse, 1));
+        d->tail_rhs.alloc(std::max<int64_t>(d->n_coarse, 1));
+        d->tail_sol.alloc(std::max<int64_t>(d->n_coarse, 1));
     }
     OMG_HIP(hipStreamSynchronize(d->stream));
     return d;
 }
 
 // ---- the SPMD schedule over the ranks that live in this process ------------------------------
+template <typename V>
 struct Runner {
+    using D = Dist<V>;
+    using RowArgs = RowArgsT<V>;
     std::vector<D *> rs;
     bool rccl;     // true: exactly one local rank, peers reached through RCCL
 
@@ -308,7 +338,7 @@ struct Runner {
     }
     bool on_comm_stream(int l) const {
         if (!rccl && !force_overlap()) return false;
-        const DLevel &L = rs[0]->lv[l];
+        const DLevel<V> &L = rs[0]->lv[l];
         return L.set_group == 2 && !L.peers.empty() && L.n_loc >= overlap_min_rows();
     }
     hipStream_t comm_stream_of(D *d) const { return rccl ? d->cstream : rs[0]->cstream; }
@@ -327,7 +357,7 @@ struct Runner {
     }
 
     void pack(D *d, int l) {
-        DLevel &L = d->lv[l];
+        DLevel<V> &L = d->lv[l];
         const int64_t n = L.peers.empty() ? 0 : L.send_off.back();
         if (n) launch_gather(L.xp, L.send_idx.p, L.send_buf.p, n, cs(d, l));
     }
@@ -347,20 +377,20 @@ struct Runner {
         for (D *d : rs) comm_end(d, l);
     }
 
-    static bool selected(const DLevel &L, size_t e, int group) {
+    static bool selected(const DLevel<V> &L, size_t e, int group) {
         return group < 0 || L.entry_group[e] < 0 || L.entry_group[e] == group;
     }
 
     // Where entry e of level L is sent from: straight out of x when its rows are one run of
     // the ordering, the packed copy otherwise.
-    static const double *send_ptr(const DLevel &L, size_t e) {
+    static const V *send_ptr(const DLevel<V> &L, size_t e) {
         return L.send_start[e] >= 0 ? L.xp + L.send_start[e] : L.send_buf.p + L.send_off[e];
     }
 
     void exchange_start(int l, int group = -1) {
         for (D *d : rs) comm_begin(d, l);
         for (D *d : rs) {                        // pack only what cannot be sent in place
-            DLevel &L = d->lv[l];
+            DLevel<V> &L = d->lv[l];
             bool need = false;
             for (size_t e = 0; e < L.peers.size(); ++e)
                 need = need || (selected(L, e, group) && L.send_start[e] < 0 && L.send_off[e + 1] > L.send_off[e]);
@@ -368,24 +398,24 @@ struct Runner {
         }
         if (rccl) {
             D *d = rs[0];
-            DLevel &L = d->lv[l];
+            DLevel<V> &L = d->lv[l];
             if (L.peers.empty()) return;
             hipStream_t s = cs(d, l);
             OMG_NCCL(g_rccl.GroupStart());
             for (size_t k = 0; k < L.peers.size(); ++k) {
                 if (!selected(L, k, group)) continue;
                 const int64_t ns = L.send_off[k + 1] - L.send_off[k], nr = L.recv_off[k + 1] - L.recv_off[k];
-                if (ns) OMG_NCCL(g_rccl.Send(send_ptr(L, k), (size_t)ns, ncclDouble, L.peers[k], d->comm, s));
-                if (nr) OMG_NCCL(g_rccl.Recv(L.xp + L.n_loc + L.recv_off[k], (size_t)nr, ncclDouble, L.peers[k], d->comm, s));
+                if (ns) OMG_NCCL(g_rccl.Send(send_ptr(L, k), (size_t)ns, NcclType<V>::value, L.peers[k], d->comm, s));
+                if (nr) OMG_NCCL(g_rccl.Recv(L.xp + L.n_loc + L.recv_off[k], (size_t)nr, NcclType<V>::value, L.peers[k], d->comm, s));
             }
             OMG_NCCL(g_rccl.GroupEnd());
         } else {
             for (D *d : rs) {
-                DLevel &L = d->lv[l];
+                DLevel<V> &L = d->lv[l];
                 for (size_t k = 0; k < L.peers.size(); ++k) {
                     if (!selected(L, k, group)) continue;
                     D *p = find(L.peers[k]);
-                    DLevel &PL = p->lv[l];
+                    DLevel<V> &PL = p->lv[l];
                     // the peer's entry towards this rank with the same group tag
                     size_t j = 0;
                     while (j < PL.peers.size() && !(PL.peers[j] == d->rank && PL.entry_group[j] == L.entry_group[k])) ++j;
@@ -393,7 +423,7 @@ struct Runner {
                     const int64_t nr = L.recv_off[k + 1] - L.recv_off[k];
                     OMG_REQUIRE(nr == PL.send_off[j + 1] - PL.send_off[j], "send/recv counts differ");
                     if (nr) OMG_HIP(hipMemcpyAsync(L.xp + L.n_loc + L.recv_off[k], send_ptr(PL, j),
-                                                   nr * sizeof(double), hipMemcpyDeviceToDevice, cs(d, l)));
+                                                   nr * sizeof(V), hipMemcpyDeviceToDevice, cs(d, l)));
                 }
             }
         }
@@ -408,7 +438,7 @@ struct Runner {
         for (int it = 0; it < iterations; ++it) {
             if (rs[0]->smoother == OMG_SMOOTH_JACOBI) {
                 for (D *d : rs) {
-                    DLevel &L = d->lv[l];
+                    DLevel<V> &L = d->lv[l];
                     RowArgs a;
                     a.x = L.xp; a.b = L.b.p; a.y = L.tp; a.omega = d->omega;
                     launch_rows(L.A, ROW_JACOBI, -1, a, d->stream);
@@ -423,7 +453,7 @@ struct Runner {
                                 "ranks disagree on the smoother sets of a level");
                 auto sweep_set = [&](int s, bool last_group) {
                     for (D *d : rs) {
-                        DLevel &L = d->lv[l];
+                        DLevel<V> &L = d->lv[l];
                         RowArgs a;
                         a.x = L.xp; a.b = L.b.p; a.y = L.xp;
                         if (fuse && it + 1 == iterations && last_group) {
@@ -454,19 +484,19 @@ struct Runner {
         // inverse — or runs the replicated tail hierarchy and keeps its slice of the result
         if (rccl) {
             D *d = rs[0];
-            DLevel &L = d->lv.back();
+            DLevel<V> &L = d->lv.back();
             bool equal = true;
             for (int64_t c : d->coarse_counts) equal = equal && c == d->coarse_counts[0];
             if (d->n_ranks == 1) {
-                OMG_HIP(hipMemcpyAsync(d->coarse_rhs.p, L.b.p, L.n_loc * sizeof(double), hipMemcpyDeviceToDevice, d->stream));
+                OMG_HIP(hipMemcpyAsync(d->coarse_rhs.p, L.b.p, L.n_loc * sizeof(V), hipMemcpyDeviceToDevice, d->stream));
             } else if (equal) {
-                OMG_NCCL(g_rccl.AllGather(L.b.p, d->coarse_rhs.p, (size_t)L.n_loc, ncclDouble, d->comm, d->stream));
+                OMG_NCCL(g_rccl.AllGather(L.b.p, d->coarse_rhs.p, (size_t)L.n_loc, NcclType<V>::value, d->comm, d->stream));
             } else {
                 OMG_NCCL(g_rccl.GroupStart());
                 int64_t off = 0;
                 for (int q = 0; q < d->n_ranks; ++q) {
-                    if (L.n_loc) OMG_NCCL(g_rccl.Send(L.b.p, (size_t)L.n_loc, ncclDouble, q, d->comm, d->stream));
-                    if (d->coarse_counts[q]) OMG_NCCL(g_rccl.Recv(d->coarse_rhs.p + off, (size_t)d->coarse_counts[q], ncclDouble, q, d->comm, d->stream));
+                    if (L.n_loc) OMG_NCCL(g_rccl.Send(L.b.p, (size_t)L.n_loc, NcclType<V>::value, q, d->comm, d->stream));
+                    if (d->coarse_counts[q]) OMG_NCCL(g_rccl.Recv(d->coarse_rhs.p + off, (size_t)d->coarse_counts[q], NcclType<V>::value, q, d->comm, d->stream));
                     off += d->coarse_counts[q];
                 }
                 OMG_NCCL(g_rccl.GroupEnd());
@@ -474,22 +504,32 @@ struct Runner {
         } else {
             for (D *d : rs)
                 for (D *p : rs) {
-                    DLevel &PL = p->lv.back();
-                    if (PL.n_loc) OMG_HIP(hipMemcpyAsync(d->coarse_rhs.p + p->coarse_lo, PL.b.p, PL.n_loc * sizeof(double),
+                    DLevel<V> &PL = p->lv.back();
+                    if (PL.n_loc) OMG_HIP(hipMemcpyAsync(d->coarse_rhs.p + p->coarse_lo, PL.b.p, PL.n_loc * sizeof(V),
                                                          hipMemcpyDeviceToDevice, d->stream));
                 }
         }
         for (D *d : rs) {
-            DLevel &L = d->lv.back();
+            DLevel<V> &L = d->lv.back();
             if (d->tail) {
-                const int rc = omg_hierarchy_cycle_dev(d->tail, d->coarse_rhs.p, d->coarse_sol.p, pre, post, d->stream);
+                // the tail's device boundary is double (it converts to its own dtype inside)
+                const double *rhs64;
+                double *sol64;
+                if constexpr (std::is_same<V, double>::value) {
+                    rhs64 = d->coarse_rhs.p;
+                    sol64 = d->coarse_sol.p;
+                } else {
+                    launch_gather<V, double>(d->coarse_rhs.p, nullptr, d->tail_rhs.p, d->n_coarse, d->stream);
+                    rhs64 = d->tail_rhs.p;
+                    sol64 = d->tail_sol.p;
+                }
+                const int rc = omg_hierarchy_cycle_dev(d->tail, rhs64, sol64, pre, post, d->stream);
                 if (rc != OMG_OK) throw Error(rc, std::string("tail hierarchy: ") + omg_last_error());
-                if (L.n_loc) OMG_HIP(hipMemcpyAsync(L.xp, d->coarse_sol.p + d->coarse_lo, L.n_loc * sizeof(double),
-                                                    hipMemcpyDeviceToDevice, d->stream));
+                if (L.n_loc) launch_gather<double, V>(sol64 + d->coarse_lo, nullptr, L.xp, L.n_loc, d->stream);
             } else {
                 OMG_REQUIRE(d->coarse_inv.p != nullptr, "no coarse solver: pass coarse_global or call omg_dist_set_tail");
-                launch_dense_gemv_rows(d->coarse_inv.p + d->coarse_lo * d->n_coarse, d->coarse_rhs.p, L.xp, L.n_loc,
-                                       d->n_coarse, d->stream);
+                launch_dense_gemv_rows<V>(d->coarse_inv.p + d->coarse_lo * d->n_coarse, d->coarse_rhs.p, L.xp, L.n_loc,
+                                          d->n_coarse, d->stream);
             }
         }
     }
@@ -499,8 +539,8 @@ struct Runner {
         if (l >= last) { coarse(pre, post); return false; }
         const bool res_done = smooth(l, pre, 1);
         for (D *d : rs) {
-            DLevel &L = d->lv[l];
-            DLevel &C = d->lv[l + 1];
+            DLevel<V> &L = d->lv[l];
+            DLevel<V> &C = d->lv[l + 1];
             RowArgs a;
             a.x = L.xp; a.b = L.b.p; a.y = L.r.p;
             const int ns = (int)L.A.n_sets();
@@ -509,14 +549,14 @@ struct Runner {
             q.x = L.r.p; q.y = C.b.p; q.zero = (l + 1 < last) ? C.xp : nullptr; q.ymap = L.r_out.p;
             launch_rows(L.R, ROW_SPMV, -1, q, d->stream);
             if (l + 1 < last && C.n_halo)
-                OMG_HIP(hipMemsetAsync(C.xp + C.n_loc, 0, C.n_halo * sizeof(double), d->stream));
+                OMG_HIP(hipMemsetAsync(C.xp + C.n_loc, 0, C.n_halo * sizeof(V), d->stream));
         }
         cycle(l + 1, pre, post);
         // x_l += R^T x_{l+1} (:214, :220/:224), then everybody needs the corrected boundary values
         auto prolong_sets = [&](int first, int step) {
             for (D *d : rs) {
-                DLevel &L = d->lv[l];
-                DLevel &C = d->lv[l + 1];
+                DLevel<V> &L = d->lv[l];
+                DLevel<V> &C = d->lv[l + 1];
                 RowArgs a;
                 a.x = C.xp; a.y = L.xp;
                 if (step == 0) { launch_rows(L.P, ROW_AXPY, -1, a, d->stream); continue; }
@@ -541,7 +581,7 @@ struct Runner {
         const bool single = rs[0]->lv.size() == 1;
         for (D *d : rs) {
             if (single) { OMG_HIP(hipMemsetAsync(d->sumsq.p, 0, sizeof(double), d->stream)); continue; }
-            DLevel &L = d->lv[0];
+            DLevel<V> &L = d->lv[0];
             RowArgs a;
             a.x = L.xp; a.b = L.b.p; a.partials = L.partials.p;
             const int ns = (int)L.A.n_sets();
@@ -600,51 +640,75 @@ int guarded(F &&f) {
     }
 }
 
+// Runs f(Dist<V> *) on whichever instantiation the handle holds.
+template <typename F>
+void with(omg_dist *d, F &&f) {
+    OMG_REQUIRE(d != nullptr && (d->d || d->f), "null handle");
+    if (d->f) f(d->f.get());
+    else f(d->d.get());
+}
+
+template <typename HP>
+using value_of = typename std::remove_pointer<HP>::type::value_type;
+
 }  // namespace
 }  // namespace omg
 
 extern "C" {
 
-int omg_dist_create(int rank, int n_ranks, int n_levels, const omg_dist_level *levels,
-                    const omg_csr *coarse_global, const int64_t *coarse_counts, int smoother,
-                    double omega, omg_dist **out) {
+int omg_dist_create_ex(int rank, int n_ranks, int n_levels, const omg_dist_level *levels,
+                       const omg_csr *coarse_global, const int64_t *coarse_counts, int smoother,
+                       double omega, int dtype, omg_dist **out) {
     return guarded([&] {
         OMG_REQUIRE(out, "out is null");
         *out = nullptr;
-        *out = create(rank, n_ranks, n_levels, levels, coarse_global, coarse_counts, smoother, omega).release();
+        OMG_REQUIRE(dtype == OMG_DTYPE_F64 || dtype == OMG_DTYPE_F32, "unknown dtype");
+        std::unique_ptr<omg_dist> h(new omg_dist);
+        if (dtype == OMG_DTYPE_F32) h->f = create<float>(rank, n_ranks, n_levels, levels, coarse_global, coarse_counts, smoother, omega);
+        else h->d = create<double>(rank, n_ranks, n_levels, levels, coarse_global, coarse_counts, smoother, omega);
+        *out = h.release();
     });
+}
+
+int omg_dist_create(int rank, int n_ranks, int n_levels, const omg_dist_level *levels,
+                    const omg_csr *coarse_global, const int64_t *coarse_counts, int smoother,
+                    double omega, omg_dist **out) {
+    return omg_dist_create_ex(rank, n_ranks, n_levels, levels, coarse_global, coarse_counts, smoother, omega,
+                              OMG_DTYPE_F64, out);
 }
 
 int omg_dist_destroy(omg_dist *d) {
     return guarded([&] {
         if (!d) return;
-        (void)hipStreamSynchronize(d->stream);
+        if (d->d || d->f) with(d, [&](auto *dd) { (void)hipStreamSynchronize(dd->stream); });
         delete d;
     });
 }
 
 int omg_dist_set_stream(omg_dist *d, void *hip_stream) {
     return guarded([&] {
-        OMG_REQUIRE(d, "null handle");
-        OMG_HIP(hipStreamSynchronize(d->stream));
-        d->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : d->own;
+        with(d, [&](auto *dd) {
+            OMG_HIP(hipStreamSynchronize(dd->stream));
+            dd->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : dd->own;
+        });
     });
 }
 
 int omg_dist_set_tail(omg_dist *d, omg_hierarchy *tail) {
     return guarded([&] {
-        OMG_REQUIRE(d, "null handle");
-        if (tail) {
-            int64_t n = 0;
-            OMG_REQUIRE(omg_hierarchy_level_rows(tail, 0, &n) == OMG_OK && n == d->n_coarse,
-                        "tail hierarchy's finest level must have as many rows as the last distributed level has in total");
-        }
-        d->tail = tail;
+        with(d, [&](auto *dd) {
+            if (tail) {
+                int64_t n = 0;
+                OMG_REQUIRE(omg_hierarchy_level_rows(tail, 0, &n) == OMG_OK && n == dd->n_coarse,
+                            "tail hierarchy's finest level must have as many rows as the last distributed level has in total");
+            }
+            dd->tail = tail;
+        });
     });
 }
 
 int omg_dist_sync(omg_dist *d) {
-    return guarded([&] { OMG_REQUIRE(d, "null handle"); OMG_HIP(hipStreamSynchronize(d->stream)); });
+    return guarded([&] { with(d, [&](auto *dd) { OMG_HIP(hipStreamSynchronize(dd->stream)); }); });
 }
 
 int omg_rccl_unique_id(void *out128) {
@@ -659,57 +723,110 @@ int omg_rccl_unique_id(void *out128) {
 
 int omg_dist_connect(omg_dist *d, const void *unique_id128) {
     return guarded([&] {
-        OMG_REQUIRE(d && unique_id128, "null argument");
-        g_rccl.load();
-        ncclUniqueId id;
-        std::memcpy(&id, unique_id128, sizeof(id));
-        OMG_NCCL(g_rccl.CommInitRank(&d->comm, d->n_ranks, id, d->rank));
+        OMG_REQUIRE(unique_id128, "null argument");
+        with(d, [&](auto *dd) {
+            g_rccl.load();
+            ncclUniqueId id;
+            std::memcpy(&id, unique_id128, sizeof(id));
+            OMG_NCCL(g_rccl.CommInitRank(&dd->comm, dd->n_ranks, id, dd->rank));
+        });
     });
 }
 
 int omg_dist_load(omg_dist *d, const double *b_local, const double *x0_local) {
     return guarded([&] {
-        OMG_REQUIRE(d && b_local, "null argument");
-        DLevel &L = d->lv[0];
-        auto put = [&](const double *host, double *dst) {
-            if (L.ord.identity) {
-                OMG_HIP(hipMemcpyAsync(dst, host, L.n_loc * sizeof(double), hipMemcpyHostToDevice, d->stream));
-            } else {
-                L.nat.upload(host, L.n_loc, d->stream);
-                launch_gather(L.nat.p, L.perm.p, dst, L.n_loc, d->stream);
-            }
-        };
-        put(b_local, L.b.p);
-        if (x0_local) put(x0_local, L.xp);
-        else OMG_HIP(hipMemsetAsync(L.xp, 0, (L.n_loc + L.n_halo) * sizeof(double), d->stream));
-        OMG_HIP(hipStreamSynchronize(d->stream));
-        d->halo_dirty = x0_local != nullptr;
-        d->loaded = true;
+        OMG_REQUIRE(b_local, "null argument");
+        with(d, [&](auto *dd) {
+            using V = value_of<decltype(dd)>;
+            auto &L = dd->lv[0];
+            auto put = [&](const double *host, V *dst) {
+                if (std::is_same<V, double>::value && L.ord.identity) {
+                    OMG_HIP(hipMemcpyAsync(dst, host, L.n_loc * sizeof(double), hipMemcpyHostToDevice, dd->stream));
+                } else {                                       // permute and / or narrow on the device
+                    L.nat.upload(host, L.n_loc, dd->stream);
+                    launch_gather<double, V>(L.nat.p, L.ord.identity ? nullptr : L.perm.p, dst, L.n_loc, dd->stream);
+                }
+            };
+            put(b_local, L.b.p);
+            if (x0_local) put(x0_local, L.xp);
+            else OMG_HIP(hipMemsetAsync(L.xp, 0, (L.n_loc + L.n_halo) * sizeof(V), dd->stream));
+            OMG_HIP(hipStreamSynchronize(dd->stream));
+            dd->halo_dirty = x0_local != nullptr;
+            dd->loaded = true;
+        });
     });
 }
 
 int omg_dist_fetch(omg_dist *d, double *x_local) {
     return guarded([&] {
-        OMG_REQUIRE(d && x_local && d->loaded, "null argument / nothing loaded");
-        DLevel &L = d->lv[0];
-        if (L.ord.identity) {
-            OMG_HIP(hipMemcpyAsync(x_local, L.xp, L.n_loc * sizeof(double), hipMemcpyDeviceToHost, d->stream));
-        } else {
-            launch_scatter(L.xp, L.perm.p, L.nat.p, L.n_loc, d->stream);
-            L.nat.download(x_local, L.n_loc, d->stream);
-        }
-        OMG_HIP(hipStreamSynchronize(d->stream));
+        OMG_REQUIRE(x_local, "null argument");
+        with(d, [&](auto *dd) {
+            using V = value_of<decltype(dd)>;
+            OMG_REQUIRE(dd->loaded, "nothing loaded");
+            auto &L = dd->lv[0];
+            if (std::is_same<V, double>::value && L.ord.identity) {
+                OMG_HIP(hipMemcpyAsync(x_local, L.xp, L.n_loc * sizeof(double), hipMemcpyDeviceToHost, dd->stream));
+            } else {
+                launch_scatter<V, double>(L.xp, L.ord.identity ? nullptr : L.perm.p, L.nat.p, L.n_loc, dd->stream);
+                L.nat.download(x_local, L.n_loc, dd->stream);
+            }
+            OMG_HIP(hipStreamSynchronize(dd->stream));
+        });
     });
 }
 
 int omg_dist_cycle(omg_dist *d, int pre, int post, double *norm) {
     return guarded([&] {
-        OMG_REQUIRE(d && pre >= 0 && post >= 0, "bad argument");
-        OMG_REQUIRE(d->n_ranks == 1 || d->comm, "omg_dist_connect has not been called");
-        Runner r;
-        r.rs = {d};
-        r.rccl = true;
-        r.run(pre, post, norm);
+        OMG_REQUIRE(pre >= 0 && post >= 0, "bad argument");
+        with(d, [&](auto *dd) {
+            using V = value_of<decltype(dd)>;
+            OMG_REQUIRE(dd->n_ranks == 1 || dd->comm, "omg_dist_connect has not been called");
+            Runner<V> r;
+            r.rs = {dd};
+            r.rccl = true;
+            r.run(pre, post, norm);
+        });
+    });
+}
+
+// Plain y = A_0 x over this rank's rows (x: the resident iterate with its halo, y: the residual
+// buffer), `reps` launches in one hipEvent bracket on the rank's stream: the per-GPU fine-grid
+// SpMV rate of a multi-GPU run.
+int omg_dist_spmv_time(omg_dist *d, int reps, double *avg_ms) {
+    return guarded([&] {
+        OMG_REQUIRE(reps > 0 && avg_ms, "bad argument");
+        with(d, [&](auto *dd) {
+            using V = value_of<decltype(dd)>;
+            OMG_REQUIRE(dd->loaded && dd->lv.size() > 1, "nothing loaded / single level");
+            auto &L = dd->lv[0];
+            RowArgsT<V> a;
+            a.x = L.xp; a.y = L.r.p;
+            launch_rows(L.A, ROW_SPMV, -1, a, dd->stream);
+            hipEvent_t e0, e1;
+            OMG_HIP(hipEventCreate(&e0));
+            OMG_HIP(hipEventCreate(&e1));
+            OMG_HIP(hipEventRecord(e0, dd->stream));
+            for (int i = 0; i < reps; ++i) launch_rows(L.A, ROW_SPMV, -1, a, dd->stream);
+            OMG_HIP(hipEventRecord(e1, dd->stream));
+            OMG_HIP(hipEventSynchronize(e1));
+            float ms = 0.f;
+            OMG_HIP(hipEventElapsedTime(&ms, e0, e1));
+            (void)hipEventDestroy(e0);
+            (void)hipEventDestroy(e1);
+            *avg_ms = double(ms) / reps;
+        });
+    });
+}
+
+int omg_dist_format_info(omg_dist *d, int level, int op, int set, int64_t *out) {
+    return guarded([&] {
+        OMG_REQUIRE(out && op >= 0 && op <= 2, "null / unknown operator");
+        with(d, [&](auto *dd) {
+            OMG_REQUIRE(level >= 0 && level < (int)dd->lv.size(), "level out of range");
+            OMG_REQUIRE(op == 0 || level + 1 < (int)dd->lv.size(), "the last level has no restriction");
+            const auto &L = dd->lv[level];
+            (op == 0 ? L.A : op == 1 ? L.R : L.P).format_info(set, out);
+        });
     });
 }
 
@@ -718,11 +835,16 @@ int omg_dist_group_create(int n, omg_dist **ranks, omg_dist_group **out) {
         OMG_REQUIRE(n >= 1 && ranks && out, "bad argument");
         std::unique_ptr<omg_dist_group> g(new omg_dist_group);
         for (int i = 0; i < n; ++i) {
-            OMG_REQUIRE(ranks[i] && ranks[i]->n_ranks == n, "group must hold every rank of the decomposition");
+            OMG_REQUIRE(ranks[i] && (ranks[i]->d || ranks[i]->f), "null rank");
+            OMG_REQUIRE(bool(ranks[i]->f) == bool(ranks[0]->f), "all ranks of a group must have one dtype");
+            with(ranks[i], [&](auto *dd) { OMG_REQUIRE(dd->n_ranks == n, "group must hold every rank of the decomposition"); });
             g->ranks.push_back(ranks[i]);
         }
         // one shared stream: the loopback exchange relies on in-order execution
-        for (omg_dist *d : g->ranks) { OMG_HIP(hipStreamSynchronize(d->stream)); d->stream = g->ranks[0]->own; }
+        hipStream_t shared = nullptr;
+        with(g->ranks[0], [&](auto *dd) { shared = dd->own; });
+        for (omg_dist *d : g->ranks)
+            with(d, [&](auto *dd) { OMG_HIP(hipStreamSynchronize(dd->stream)); dd->stream = shared; });
         *out = g.release();
     });
 }
@@ -734,11 +856,17 @@ int omg_dist_group_destroy(omg_dist_group *g) {
 
 int omg_dist_group_cycle(omg_dist_group *g, int pre, int post, double *norm) {
     return guarded([&] {
-        OMG_REQUIRE(g && pre >= 0 && post >= 0, "bad argument");
-        Runner r;
-        r.rs = g->ranks;
-        r.rccl = false;
-        r.run(pre, post, norm);
+        OMG_REQUIRE(g && !g->ranks.empty() && pre >= 0 && post >= 0, "bad argument");
+        with(g->ranks[0], [&](auto *first) {
+            using V = value_of<decltype(first)>;
+            Runner<V> r;
+            for (omg_dist *d : g->ranks) {
+                if constexpr (std::is_same<V, double>::value) r.rs.push_back(d->d.get());
+                else r.rs.push_back(d->f.get());
+            }
+            r.rccl = false;
+            r.run(pre, post, norm);
+        });
     });
 }
 

@@ -99,6 +99,14 @@ def stencil_rows(shape, row_lo, row_hi):
     return sp.csr_matrix((data, indices, indptr), shape=(rows.size, N))
 
 
+def stencil27_variable_rows(shape, row_lo, row_hi, seed=2024):
+    """Rows [row_lo, row_hi) of operators.stencil27_variable(shape, seed) with GLOBAL column
+    indices.  Every rank draws the whole kappa field from the same seed (it is one double per
+    cell) and assembles only its rows."""
+    from . import operators
+    return operators.stencil27_variable(shape, seed, rows=(int(row_lo), int(row_hi)))
+
+
 def restriction_rows(shape, row_lo, row_hi):
     """Rows [row_lo, row_hi) of operators.restriction(shape) (openmg/operators.py:15-89) with
     GLOBAL column indices; even extents only (SlabPartition checks that)."""
@@ -123,18 +131,27 @@ def restriction_rows(shape, row_lo, row_hi):
     return sp.csr_matrix((data, cols, indptr), shape=(r.size, N))
 
 
-def set_keys(shape, rows, smoother):
+def set_keys(shape, rows, smoother, colouring="parity"):
     """Smoother set of each global row of a grid-stencil operator, the same on every rank.
-    'colour': parity of the coordinate sum (red-black; what the single-GPU greedy colouring gives
-    on 3/5/7-point stencils).  'gs': hyperplane index i0+i1+... — the level schedule of the
-    lexicographic sweep on such stencils.  'jacobi': one set."""
+    'colour': with colouring 'parity' the parity of the coordinate sum (red-black; what the
+    single-GPU greedy colouring gives on 3/5/7-point stencils), with 'octant' the bits
+    (c0 % 2, c1 % 2, ...) most significant first — 2^dim colours, what the greedy colouring
+    gives on 9/27-point stencils.  'gs': hyperplane index i0+i1+... — the level schedule of the
+    lexicographic sweep on 3/5/7-point stencils.  'jacobi': one set."""
     if smoother in ("jacobi",):
         return None, 0
     coords = np.unravel_index(np.asarray(rows, dtype=np.int64), shape)
     total = np.zeros(np.size(rows), dtype=np.int64)
     for c in coords:
         total += c
+    if smoother == "colour" and colouring == "octant":
+        key = np.zeros(np.size(rows), dtype=np.int64)
+        for c in coords:
+            key = 2 * key + c % 2
+        return key.astype(np.int32), 2 ** len(shape)
     if smoother == "colour":
+        if colouring != "parity":
+            raise ValueError("unknown colouring %r" % (colouring,))
         return (total % 2).astype(np.int32), 2
     if smoother == "gs":
         return total.astype(np.int32), int(sum(shape) - len(shape) + 1)
@@ -222,8 +239,11 @@ class RankSetup:
 
     `spgemm(X, Y)` does the two Galerkin products (default: the device SpGEMM)."""
 
-    def __init__(self, part, rank, A0_rows, smoother="colour", spgemm=None, overlap=True):
+    def __init__(self, part, rank, A0_rows, smoother="colour", spgemm=None, overlap=True, colouring="parity"):
+        """colouring: 'parity' (3/5/7-point stencils) or 'octant' (9/27-point), see set_keys; it
+        must be a valid colouring of every level's operator on every rank (checked)."""
         self.part, self.rank, self.smoother, self.overlap = part, int(rank), smoother, bool(overlap)
+        self.colouring = colouring
         if spgemm is None:
             from . import _hip
             spgemm = _hip.spgemm
@@ -245,13 +265,13 @@ class RankSetup:
         # values change, so only they are sent (half the bytes for red-black)
         group_of = None
         if not last and self.smoother == "colour":
-            group_of = lambda gids: set_keys(part.shapes[l], gids, "colour")[0]
+            group_of = lambda gids: set_keys(part.shapes[l], gids, "colour", self.colouring)[0]
         A_loc, halo, halo_groups = compress_columns(self._A_glob, lo, hi, part.bounds(l), group_of)
         lv = {"A": A_loc, "R": None, "n_halo": int(halo.size), "keys": None, "n_sets": 0}
         if not last:
-            keys, n_sets = set_keys(part.shapes[l], np.arange(lo, hi), self.smoother)
+            keys, n_sets = set_keys(part.shapes[l], np.arange(lo, hi), self.smoother, self.colouring)
             if keys is not None:
-                self._check_keys(A_loc, keys, set_keys(part.shapes[l], halo, self.smoother)[0], hi - lo)
+                self._check_keys(A_loc, keys, set_keys(part.shapes[l], halo, self.smoother, self.colouring)[0], hi - lo)
             lv["set_group"] = 1
             min_rows = int(os.environ.get("OMG_OVERLAP_MIN_ROWS", 1 << 19))   # same rule as csrc/dist.hip
             if keys is not None and self.smoother == "colour" and self.overlap and hi - lo >= min_rows:
@@ -283,10 +303,19 @@ class RankSetup:
             R_ext = restriction_rows(part.shapes[l], c_lo, c_hi)
             R_ext = sp.csr_matrix((R_ext.data, R_ext.indices - f_lo, R_ext.indptr), shape=(c_hi - c_lo, f_hi - f_lo))
             Rt_ext = sp.csr_matrix(R_ext.T)                  # (fine rows f_lo..f_hi) x (coarse rows c_lo..c_hi)
-            Z = sp.csr_matrix(Rt_ext[ext - f_lo])
+            # The products run with the fine unknowns numbered in GLOBAL order (lower halo, owned,
+            # upper halo), not [owned | halo]: SpGEMM adds the terms of an output entry in the
+            # column order of its left factor's row, and only this numbering makes that order —
+            # and with it every rounding of a variable-coefficient coarse operator — the one of
+            # the global product R A R^T, whatever the number of ranks.
+            ext_sorted = np.sort(ext)
+            to_sorted = np.searchsorted(ext_sorted, ext)
+            A_sorted = sp.csr_matrix((A_loc.data, to_sorted[A_loc.indices].astype(np.int32), A_loc.indptr),
+                                     shape=(hi - lo, ext.size))
+            Z = sp.csr_matrix(Rt_ext[ext_sorted - f_lo])
             if (np.diff(Z.indptr) == 0).any():
                 raise ValueError("level %d: a halo unknown's aggregate lies outside the neighbouring planes" % l)
-            RA = self.spgemm(R_loc, A_loc)
+            RA = self.spgemm(R_loc, A_sorted)
             An = sp.csr_matrix(self.spgemm(RA, Z))
             self._A_next = sp.csr_matrix((An.data, An.indices.astype(np.int64) + c_lo, An.indptr),
                                          shape=(chi - clo, part.n_rows(l + 1)))
@@ -319,10 +348,10 @@ class RankSetup:
         off = col != row
         if (all_keys[col[off]] == keys[row[off]]).any():
             raise ValueError("the coordinate-based smoother sets are not independent for this operator "
-                             "(the distributed path supports 3/5/7-point grid stencils)")
+                             "(colouring='parity' fits 3/5/7-point grid stencils, 'octant' 9/27-point ones)")
 
 
-def make_tail(coarse_global, shape, n_grids, smoother="colour", omega=1.0):
+def make_tail(coarse_global, shape, n_grids, smoother="colour", omega=1.0, dtype="float64"):
     """Replicated tail: an ordinary single-GPU hierarchy over the levels BELOW the last
     distributed one.  `coarse_global` is the whole operator of that level (shape `shape`),
     `n_grids` how many grids the tail has (1 = direct solve only).  Every rank builds the same
@@ -332,7 +361,7 @@ def make_tail(coarse_global, shape, n_grids, smoother="colour", omega=1.0):
     shapes = [tuple(s // 2 ** l for s in shape) for l in range(n_grids)]
     R = [operators.restriction(shapes[l]) for l in range(n_grids - 1)]
     A = operators.coeffecientList(sp.csr_matrix(coarse_global), R)
-    return _hip.Hierarchy(A, R, smoother=smoother, omega=omega)
+    return _hip.Hierarchy(A, R, smoother=smoother, omega=omega, dtype=dtype)
 
 
 def assemble_coarse(rows_per_rank):
@@ -341,10 +370,10 @@ def assemble_coarse(rows_per_rank):
     return G
 
 
-def build_all_ranks(part, A0_rows_of, smoother="colour", spgemm=None, overlap=True):
+def build_all_ranks(part, A0_rows_of, smoother="colour", spgemm=None, overlap=True, colouring="parity"):
     """In-process construction of EVERY rank (loopback groups, tests).  A0_rows_of(rank) gives
     that rank's fine rows.  Returns (levels_per_rank, coarse_global, coarse_counts)."""
-    setups = [RankSetup(part, q, A0_rows_of(q), smoother=smoother, spgemm=spgemm, overlap=overlap)
+    setups = [RankSetup(part, q, A0_rows_of(q), smoother=smoother, spgemm=spgemm, overlap=overlap, colouring=colouring)
               for q in range(part.n_ranks)]
     for l in range(part.n_grids):
         halos = [s.begin_level(l) for s in setups]
@@ -356,10 +385,11 @@ def build_all_ranks(part, A0_rows_of, smoother="colour", spgemm=None, overlap=Tr
     return [s.levels for s in setups], coarse, counts
 
 
-def build_this_rank(part, rank, A0_rows, all_gather, smoother="colour", spgemm=None, overlap=True):
+def build_this_rank(part, rank, A0_rows, all_gather, smoother="colour", spgemm=None, overlap=True,
+                    colouring="parity"):
     """SPMD construction: `all_gather(obj)` returns the list of every rank's obj (e.g.
     torch.distributed.all_gather_object).  Returns (levels, coarse_global, coarse_counts)."""
-    s = RankSetup(part, rank, A0_rows, smoother=smoother, spgemm=spgemm, overlap=overlap)
+    s = RankSetup(part, rank, A0_rows, smoother=smoother, spgemm=spgemm, overlap=overlap, colouring=colouring)
     for l in range(part.n_grids):
         halo = s.begin_level(l)
         s.finish_level(l, all_gather(halo))

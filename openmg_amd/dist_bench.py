@@ -58,16 +58,23 @@ def main(args):
     n_dist = max(2, min(args.dist_grids, grids))
     part = dist.SlabPartition(shape, world, n_dist)
     lo, hi = part.rows(0, rank)
-    A_rows = dist.stencil_rows(shape, lo, hi)
+    w = 8 if args.dtype == "f64" else 4
+    np_dtype = "float64" if w == 8 else "float32"
+    if args.stencil == "27var":                               # BASELINE configs[4]
+        A_rows = dist.stencil27_variable_rows(shape, lo, hi)
+        colouring = "octant"
+    else:
+        A_rows = dist.stencil_rows(shape, lo, hi)
+        colouring = "parity"
     u = np.random.default_rng(12345).random(part.n_rows(0))
     b_loc = A_rows @ u
     del u
     levels, coarse, counts = dist.build_this_rank(part, rank, A_rows, all_gather, smoother=args.smoother,
-                                                  overlap=bool(args.overlap))
+                                                  overlap=bool(args.overlap), colouring=colouring)
     nnz_loc, n_loc = A_rows.nnz, hi - lo
     del A_rows
-    tail = dist.make_tail(coarse, part.shapes[-1], grids - n_dist + 1, smoother=args.smoother)
-    r = _hip_dist.DistRank(rank, world, levels, None, counts, smoother=args.smoother, tail=tail)
+    tail = dist.make_tail(coarse, part.shapes[-1], grids - n_dist + 1, smoother=args.smoother, dtype=np_dtype)
+    r = _hip_dist.DistRank(rank, world, levels, None, counts, smoother=args.smoother, tail=tail, dtype=np_dtype)
     ident = [_hip_dist.rccl_unique_id() if rank == 0 else None]
     td.broadcast_object_list(ident, src=0)
     r.connect(ident[0])
@@ -91,27 +98,44 @@ def main(args):
     td.all_reduce(t, op=td.ReduceOp.MAX)
     elapsed = float(t[0])
     norm = r.cycle(pre, post, want_norm=True)
+    # rank 0's fine-grid SpMV over its own rows (untimed region, hipEvents on the rank's stream)
+    spmv_ms = r.spmv_time(20)
+    fmt = r.format_info(0, "A")
 
     if rank == 0:
         n_glob = part.n_rows(0)
         equiv = n_glob / float(256 ** 3)
         out = {
-            "metric": "V-cycles/sec (256^3-unknown equivalents), 3-D 7-point Poisson, weak scaling",
+            "metric": "V-cycles/sec (256^3-unknown equivalents), 3-D %s, weak scaling"
+                      % ("7-point Poisson" if args.stencil != "27var" else "27-point variable-coefficient Poisson"),
             "value": round(args.steps / elapsed * equiv, 3),
             "unit": "256^3-equivalent V-cycles/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "3-D 7-point Poisson %s, %d-grid V(1,1) cycle, %s Gauss-Seidel, fp64, int32 CSR, "
+            "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": "3-D %s %s, %d-grid V(1,1) cycle, %s Gauss-Seidel, %s, int32 CSR, "
                                    "1-D slabs over %d GPUs, RCCL halo exchange"
-                                   % ("x".join(map(str, shape)), grids,
-                                      "red-black" if args.smoother == "colour" else args.smoother, world),
+                                   % ("7-point Poisson" if args.stencil != "27var" else "27-point variable-coefficient Poisson (Q1 stiffness)",
+                                      "x".join(map(str, shape)), grids,
+                                      ("red-black" if colouring == "parity" else "8-colour") if args.smoother == "colour" else args.smoother,
+                                      "fp64" if w == 8 else "fp32", world),
                        "unknowns": n_glob, "unknowns_per_gpu": n_loc, "nnz_per_gpu": nnz_loc, "grids": grids,
                        "distributed_grids": n_dist - 1, "replicated_tail_grids": grids - n_dist + 1,
                        "pre": pre, "post": post, "cycles_per_s": round(args.steps / elapsed, 3),
                        "final_residual_norm": norm, "setup_s": round(setup_s, 2)},
-            "roofline": None, "cpu_baseline": None,
+            # rank 0's y = A x over its own rows; `achieved` counts SURVEY 8(d)'s CSR bytes, the
+            # operator sits in HBM in the lossless block recoding of DESIGN.md section 4
+            "roofline": {"bound": "hbm", "kernel": "y = A_local x on rank 0 (all local rows; x incl. halo)",
+                         "achieved": round(((w + 4) * nnz_loc + 4 * (n_loc + 1) + 2 * w * n_loc) / spmv_ms / 1e6, 1),
+                         "peak": 8000.0, "unit": "GB/s",
+                         "frac": round(((w + 4) * nnz_loc + 4 * (n_loc + 1) + 2 * w * n_loc) / spmv_ms / 1e6 / 8000.0, 4),
+                         "traffic": None, "avg_launch_us": round(1e3 * spmv_ms, 2),
+                         "algorithmic_bytes": (w + 4) * nnz_loc + 4 * (n_loc + 1) + 2 * w * n_loc,
+                         "format_bytes": fmt["format_bytes"] + 2 * w * n_loc,
+                         "format_frac": round((fmt["format_bytes"] + 2 * w * n_loc) / spmv_ms / 1e6 / 8000.0, 4),
+                         "device_format": {k: fmt[k] for k in ("rows", "nnz", "pattern_rows", "coldict_nnz", "valdict_nnz")}},
+            "cpu_baseline": None,
         }
         # RCCL (NCCL_DEBUG=VERSION) and gloo write banners through C stdio; push them out first
         # so that the JSON line is the LAST line of stdout

@@ -176,14 +176,15 @@ def _q1_element_stiffness():
     return K, corners
 
 
-def stencil27_variable(shape, seed=2024):
+def stencil27_variable(shape, seed=2024, rows=None):
     """27-point variable-coefficient operator of BASELINE.json configs[4] as SURVEY.md 8(d)
     specifies it (NOT in the reference): Q1 finite-element stiffness of -div(kappa grad u) on a
     box of unit cells whose unknowns are the interior nodes `shape` (homogeneous Dirichlet
     boundary), kappa = exp(U(-1, 1) ln 10) per cell from default_rng(seed).  Symmetric positive
     definite.  C-order numbering, sorted CSR with int32 indices, all 27 couplings of a node
     stored (the six along the axes cancel to ~0 only where kappa is locally constant),
-    assembled directly in CSR (the 256^3 operator has 450 M entries)."""
+    assembled directly in CSR (the 256^3 operator has 450 M entries).  rows=(lo, hi): only those
+    rows, as a (hi - lo) x N matrix with global columns (one slab of a distributed run)."""
     shape = tuple(int(s) for s in shape)
     if len(shape) != 3:
         raise ValueError("stencil27_variable needs a 3-D shape")
@@ -194,12 +195,14 @@ def stencil27_variable(shape, seed=2024):
     # one cell per (node, node + 1) interval including the two boundary layers: (n + 1)^3 cells;
     # cell c spans nodes c - 1 .. c along each axis (node -1 and node n are the Dirichlet boundary)
     kappa = np.exp(rng.uniform(-1.0, 1.0, size=tuple(s + 1 for s in shape)) * np.log(10.0))
-    cz, cy, cx = np.unravel_index(np.arange(N, dtype=np.int64), shape)
+    row_lo, row_hi = (0, N) if rows is None else (int(rows[0]), int(rows[1]))
+    M = row_hi - row_lo
+    cz, cy, cx = np.unravel_index(np.arange(row_lo, row_hi, dtype=np.int64), shape)
     coords = (cz, cy, cx)
     dirs = [(dz, dy, dx) for dz in (-1, 0, 1) for dy in (-1, 0, 1) for dx in (-1, 0, 1)]   # ascending column offset
 
     def valid_of(d):
-        v = np.ones(N, dtype=bool)
+        v = np.ones(M, dtype=bool)
         for ax in range(3):
             if d[ax] < 0:
                 v &= coords[ax] > 0
@@ -207,16 +210,16 @@ def stencil27_variable(shape, seed=2024):
                 v &= coords[ax] < shape[ax] - 1
         return v
     valid = [valid_of(d) for d in dirs]
-    counts = np.zeros(N, dtype=np.int64)
+    counts = np.zeros(M, dtype=np.int64)
     for v in valid:
         counts += v
-    indptr = np.zeros(N + 1, dtype=np.int64)
+    indptr = np.zeros(M + 1, dtype=np.int64)
     np.cumsum(counts, out=indptr[1:])
     nnz = int(indptr[-1])
     indices = np.empty(nnz, dtype=np.int32)
     data = np.empty(nnz, dtype=np.float64)
     cursor = indptr[:-1].copy()
-    rows = np.arange(N, dtype=np.int64)
+    gid = np.arange(row_lo, row_hi, dtype=np.int64)
     for d, v in zip(dirs, valid):
         off = d[0] * strides[0] + d[1] * strides[1] + d[2] * strides[2]
         # A[i, i + d] = sum over the cells that contain both nodes: local node a of the cell is i,
@@ -230,9 +233,9 @@ def stencil27_variable(shape, seed=2024):
             ib = corners.index(b)
             val += kappa[pz - a[0] + 1, py - a[1] + 1, px - a[2] + 1] * K[ia, ib]
         pos = cursor[v]
-        indices[pos] = (rows[v] + off).astype(np.int32)
+        indices[pos] = (gid[v] + off).astype(np.int32)
         data[pos] = val
         cursor += v
-    out = sp.csr_matrix((data, indices, indptr.astype(np.int32)), shape=(N, N))
+    out = sp.csr_matrix((data, indices, indptr.astype(np.int32)), shape=(M, N))
     out.has_sorted_indices = True
     return out

@@ -197,3 +197,69 @@ def test_default_thresholds_at_realistic_slab_size(monkeypatch):
         group.close()
     assert np.array_equal(xd, x1)
     np.testing.assert_allclose(nd, n1, rtol=1e-13)
+
+
+# ------------------------------------------------------------- fp32 levels, 27-point operators --
+def _single(A0, shape, grids, b, cycles, dtype):
+    R = [operators.restriction(tuple(s // 2 ** l for s in shape)) for l in range(grids - 1)]
+    A = operators.coeffecientList(A0, R)
+    with _hip.Hierarchy(A, R, smoother="colour", dtype=dtype) as h:
+        sets = h.level_sets(0)
+        h.resident_load(b)
+        norms = [h.resident_cycle(1, 1) for _ in range(cycles)]
+        return h.resident_fetch(), norms, sets
+
+
+def _loopback(rows_of, shape, grids, n_ranks, b, cycles, dtype, colouring="parity", n_dist=None):
+    n_dist = grids if n_dist is None else n_dist
+    part = dist.SlabPartition(shape, n_ranks, n_dist)
+    levels, coarse, counts = dist.build_all_ranks(part, lambda q: rows_of(*part.rows(0, q)), smoother="colour",
+                                                  colouring=colouring)
+    tail = lambda: None if n_dist == grids else dist.make_tail(coarse, part.shapes[-1], grids - n_dist + 1, dtype=dtype)
+    ranks = [_hip_dist.DistRank(q, n_ranks, levels[q], coarse if n_dist == grids else None, counts, smoother="colour",
+                                tail=tail(), dtype=dtype) for q in range(n_ranks)]
+    group = _hip_dist.DistGroup(ranks)
+    try:
+        for q, r in enumerate(ranks):
+            r.load(b[slice(*part.rows(0, q))])
+        norms = [group.cycle(1, 1) for _ in range(cycles)]
+        x = np.concatenate([r.fetch() for r in ranks])
+    finally:
+        group.close()
+    return x, norms
+
+
+@pytest.mark.parametrize("n_ranks,n_dist", [(2, 3), (4, 2)])
+def test_fp32_slabs_give_the_single_gpu_fp32_iterate(n_ranks, n_dist):
+    """omg_dist_create_ex(OMG_DTYPE_F32): levels, halo messages and the coarse all-gather in
+    float.  Rows of a colour are uncoupled, so the fp32 iterate is bit-identical to the
+    single-GPU fp32 hierarchy whatever the number of slabs, with a direct coarse solve and with
+    a replicated fp32 tail."""
+    shape, grids = (32, 32, 32), 3
+    A0 = operators.stencil_poisson(shape)
+    b = A0 @ np.random.default_rng(31).random(A0.shape[0])
+    x1, n1, _ = _single(A0, shape, grids, b, 3, "float32")
+    x64, _, _ = _single(A0, shape, grids, b, 3, "float64")
+    xd, nd = _loopback(lambda lo, hi: dist.stencil_rows(shape, lo, hi), shape, grids, n_ranks, b, 3, "float32", n_dist=n_dist)
+    assert np.array_equal(xd, x1)
+    assert not np.array_equal(xd, x64)                       # it really ran in float
+    np.testing.assert_allclose(nd, n1, rtol=1e-6)            # norm: fp32 residuals, double sums in another grouping
+
+
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+def test_27_point_variable_coefficient_slabs(dtype):
+    """configs[4]'s operator over slabs: 8 colours by coordinate octant (what the single-GPU
+    greedy colouring finds on a 27-point stencil, in the same order), one halo message per
+    (neighbour, colour), Galerkin products from the rank's own rows.  Bit-identical to one GPU."""
+    shape, grids = (16, 16, 16), 3
+    A0 = operators.stencil27_variable(shape)
+    b = A0 @ np.random.default_rng(32).random(A0.shape[0])
+    x1, n1, sets = _single(A0, shape, grids, b, 3, dtype)
+    assert sets == 8
+    for n_ranks in (2, 4):
+        xd, nd = _loopback(lambda lo, hi: dist.stencil27_variable_rows(shape, lo, hi), shape, grids, n_ranks, b, 3, dtype,
+                           colouring="octant")
+        assert np.array_equal(xd, x1), n_ranks
+        np.testing.assert_allclose(nd, n1, rtol=1e-13 if dtype == "float64" else 1e-6)
+    with pytest.raises(ValueError):                          # red-black is not a colouring of a 27-point operator
+        _loopback(lambda lo, hi: dist.stencil27_variable_rows(shape, lo, hi), shape, grids, 2, b, 1, dtype)
