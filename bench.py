@@ -227,11 +227,13 @@ def main():
     # the same launches with the operators in their device format
     fA = [h.format_info(0, "A", s) for s in range(n_sets)]
     fR, fP = (h.format_info(0, "R"), h.format_info(0, "P")) if n_c else ({"format_bytes": 0}, {"format_bytes": 0})
+    scatter = bool(n_c) and h.level_flags(0)["scatter_prolong"]
     class_fmt = {
         "smoother_set_sweep": sum(f["format_bytes"] + 3 * w * f["rows"] for f in fA) / max(n_sets, 1) + w * n / max(n_sets, 1),
         "residual": fmt_bytes,
         "restrict": fR["format_bytes"] + w * n + 2 * w * n_c,
-        "prolong_add": fP["format_bytes"] + w * n_c + 2 * w * n,
+        # prolongation: a pass over P = R^T, or (aggregation R, row-pattern coded) a scatter over R's rows
+        "prolong_add": (fR["format_bytes"] if scatter else fP["format_bytes"]) + w * n_c + 2 * w * n,
         "residual_norm": fmt_bytes - w * rows_c,
     }
     kernels = {}

@@ -97,6 +97,12 @@ int omg_hierarchy_level_sets(const omg_hierarchy *h, int level, int64_t *n_sets)
  * norm share (ROW_GS_RES / ROW_GS_NORM in csrc/common.h), so that the residual and norm
  * launches cover only the other sets.  Bit-identical results either way.                  */
 int omg_hierarchy_level_fused(const omg_hierarchy *h, int level, int *fused);
+/* Schedule choices of a level as a bit mask: 1 = fused last set (as above); 2 = prolongation
+ * runs as a scatter over the restriction's row patterns (csrc/common.h ROW_SCATTER) instead of
+ * a pass over the explicit transpose.  Bit-identical results either way.                   */
+#define OMG_LEVEL_FUSED_LAST_SET   1
+#define OMG_LEVEL_SCATTER_PROLONG  2
+int omg_hierarchy_level_flags(const omg_hierarchy *h, int level, int *flags);
 /* Rows and stored entries of one smoother set (for byte accounting of per-set launches). */
 int omg_hierarchy_set_info(const omg_hierarchy *h, int level, int set, int64_t *rows, int64_t *nnz);
 /* How an operator of level l sits in HBM (csrc/common.h "Block-dictionary coding": the device

@@ -65,6 +65,7 @@ SIGNATURES = {
     "omg_hierarchy_level_sets": (_I, [_P, _I, _I64P]),
     "omg_hierarchy_set_info": (_I, [_P, _I, _I, _I64P, _I64P]),
     "omg_hierarchy_level_fused": (_I, [_P, _I, _IP]),
+    "omg_hierarchy_level_flags": (_I, [_P, _I, _IP]),
     "omg_hierarchy_format_info": (_I, [_P, _I, _I, _I, _I64P]),
     "omg_format_selftest": (_I, [_CSR, _I, _I64P]),
     "omg_vcycle": (_I, [_P, _I, _P, _P, _I, _I, _DP]),
@@ -319,6 +320,12 @@ class Hierarchy:
         v = ctypes.c_int(0)
         check(lib().omg_hierarchy_level_fused(self._h, level, ctypes.byref(v)))
         return bool(v.value)
+
+    def level_flags(self, level):
+        """dict(fused_last_set=bool, scatter_prolong=bool) of a smoothed level."""
+        f = ctypes.c_int(0)
+        check(lib().omg_hierarchy_level_flags(self._h, int(level), ctypes.byref(f)))
+        return {"fused_last_set": bool(f.value & 1), "scatter_prolong": bool(f.value & 2)}
 
     def set_info(self, level, s):
         """(rows, stored entries) of smoother set `s` of a level."""

@@ -184,6 +184,11 @@ struct DevCsrT {
     int lanes_per_row = 1;             // 4 for operators with long rows (avg > 16 entries)
     void upload(const HostCsr &A, const std::vector<int64_t> &sets, hipStream_t s);   // converts to V
     size_t n_sets() const { return sets.empty() ? 0 : sets.size() - 1; }
+    bool all_pattern() const {         // every set runs rows_pattern_kernel
+        if (set_pattern.empty()) return false;
+        for (char c : set_pattern) if (!c) return false;
+        return true;
+    }
     int64_t n_blocks() const { return set_blk.empty() ? 0 : set_blk.back(); }
 };
 using DevCsr = DevCsrT<double>;
@@ -205,6 +210,11 @@ enum RowMode : int {
     // only has to visit the rows of the other sets.
     ROW_GS_RES = 7,     // ... residual stored to `zero`-slot pointer aux
     ROW_GS_NORM = 8,    // ... residual squared into the block partials
+    // y[col] += a_rc * x[row] for every stored entry: the TRANSPOSE applied from the rows of
+    // the operator — prolongation straight from the restriction's row patterns, no explicit
+    // R^T.  Only for operators whose columns each hold at most one entry (aggregation: no two
+    // rows write the same y) and whose blocks are all pattern coded (rows_pattern_kernel).
+    ROW_SCATTER = 9,
 };
 
 template <typename V>

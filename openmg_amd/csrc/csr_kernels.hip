@@ -120,12 +120,13 @@ __device__ __forceinline__ RowPre<V> row_preload(const KArgs<V> &a, int r, int e
     }
     p.bv = V(0);
     p.xv = V(0);
-    if constexpr (MODE != ROW_SPMV && MODE != ROW_AXPY) p.bv = a.b[r];
+    if constexpr (MODE != ROW_SPMV && MODE != ROW_AXPY && MODE != ROW_SCATTER) p.bv = a.b[r];
     if constexpr (MODE == ROW_GS || MODE == ROW_JACOBI || MODE == ROW_GS_RES || MODE == ROW_GS_NORM)
         p.xv = a.x[r];
     if constexpr (MODE == ROW_AXPY) p.xv = a.y[r];
     p.out = r;
     if constexpr (MODE == ROW_SPMV) { if (a.ymap) p.out = a.ymap[r]; }
+    if constexpr (MODE == ROW_SCATTER) p.xv = a.x[a.ymap ? a.ymap[r] : r];     // the row's multiplier
     return p;
 }
 
@@ -545,6 +546,16 @@ __device__ __forceinline__ void pattern_chunk(const PatDictRef<V> &d, const V *_
         off[j] = d.off(k + j);
         val[j] = d.val(k + j);
     }
+    if constexpr (MODE == ROW_SCATTER) {
+        // y[r + off] += val * x_row: product rounded, then added — the two roundings of
+        // ROW_AXPY over the explicit transpose (y + fma(val, x, 0)), so the same bits
+        V *__restrict__ ycol = const_cast<V *>(xrow);         // xrow = y + r here (pattern_rows)
+#pragma unroll
+        for (int j = 0; j < N; ++j) xg[j] = ycol[off[j]];
+#pragma unroll
+        for (int j = 0; j < N; ++j) ycol[off[j]] = xg[j] + madd(val[j], pre.xv, V(0));
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < N; ++j) xg[j] = xrow[off[j]];
 #pragma unroll
@@ -566,7 +577,8 @@ template <int MODE, typename V>
 __device__ __forceinline__ void pattern_rows(const KArgs<V> &a, int r, bool active, int code, const RowPre<V> &pre,
                                              const PatDictRef<V> &d, V &sum, V &diag, V &sum2, V &xnew) {
     constexpr bool FUSED = (MODE == ROW_GS_RES || MODE == ROW_GS_NORM);
-    const V *__restrict__ xrow = a.x + r;                     // x[r + offset]
+    // x[r + offset]; ROW_SCATTER walks (and updates) y there instead
+    const V *__restrict__ xrow = (MODE == ROW_SCATTER ? a.y : a.x) + r;
     unsigned long long todo = __ballot(active);
     while (todo) {
         const int leader = __ffsll((long long)todo) - 1;
@@ -638,7 +650,7 @@ void rows_pattern_kernel(KArgs<V> a, int blk0) {
             a.y[r] = xnew;
             if constexpr (MODE == ROW_GS_RES) a.zero[r] = res;
             else sq += double(res) * double(res);
-        } else {
+        } else if constexpr (MODE != ROW_SCATTER) {
             row_epilogue<MODE>(a, r, pre, sum, diag, sq);
         }
     }
@@ -744,6 +756,16 @@ void launch_rows_range(const DevCsrT<V> &A, int mode, int set_begin, int set_end
     bool ap = !A.set_pattern.empty() && set_end > set_begin;
     if (ap) { const char *e = getenv("OMG_PATTERN_KERNEL"); ap = !(e && e[0] == '0'); }
     for (int q = set_begin; ap && q < set_end; ++q) ap = A.set_pattern[q] != 0;
+    if (mode == ROW_SCATTER) {                 // exists in the pattern kernel only (common.h)
+        bool all = !A.set_pattern.empty() && set_end > set_begin;
+        for (int q = set_begin; all && q < set_end; ++q) all = A.set_pattern[q] != 0;
+        OMG_REQUIRE(all, "ROW_SCATTER needs an operator whose blocks are all row-pattern coded");
+        if (nblk > 0) {
+            hipLaunchKernelGGL((rows_pattern_kernel<ROW_SCATTER, V>), dim3((unsigned)nblk), dim3(NT), 0, s, k, (int)blk0);
+            OMG_HIP(hipGetLastError());
+        }
+        return;
+    }
     switch (mode) {
 
         case ROW_GS_RES: launch_mode<ROW_GS_RES>(A, blk0, nblk, k, ap, s); break;

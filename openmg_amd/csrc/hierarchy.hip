@@ -49,6 +49,10 @@ struct Level {
     DevBuf<double> nat;       // natural-order (double) staging for host I/O at this level
     V *xp = nullptr, *tp = nullptr;   // current iterate / Jacobi scratch (swap)
     std::vector<SweepStep> plan;
+    // prolongation as a scatter over R's row patterns (ROW_SCATTER) instead of a pass over the
+    // explicit transpose P: possible when no two rows of R share a column (aggregation) and R
+    // is row-pattern coded; reads 1 byte per COARSE row instead of ~9 per fine row
+    bool scatter_prolong = false;
 };
 
 struct ProfEvent {
@@ -249,7 +253,12 @@ void prolong_add_level(Hier<V> *h, int l, const V *coarse, V *fine) {
     Prof<V> p(h, l, 3);
     RowArgsT<V> a;
     a.x = coarse; a.y = fine;
-    launch_rows(L.P, ROW_AXPY, -1, a, h->stream);
+    if (L.scatter_prolong) {
+        a.ymap = L.r_out.p;                   // R's rows are in natural coarse order (create())
+        launch_rows(L.R, ROW_SCATTER, -1, a, h->stream);
+    } else {
+        launch_rows(L.P, ROW_AXPY, -1, a, h->stream);
+    }
 }
 
 template <typename V>
@@ -474,6 +483,8 @@ std::unique_ptr<Hier<V>> create(int n_levels, const omg_csr *A, const omg_csr *R
             HostCsr Rp = permute_csr(R[l], co.identity ? nullptr : co.perm.data(), id ? nullptr : L.ord.inv.data());
             HostCsr Pt = transpose_csr(Rp);
             L.P.upload(Pt, {}, h->stream);
+            const HostCsr *r_used = &Rp;
+            HostCsr Rn;
             if (co.identity) {
                 L.R.upload(Rp, {}, h->stream);
             } else {
@@ -483,11 +494,24 @@ std::unique_ptr<Hier<V>> create(int n_levels, const omg_csr *A, const omg_csr *R
                 // gathers).  In the coarse COLOUR order consecutive rows are every other
                 // aggregate and each gather used half of every cache line (measured: 480 MB
                 // read for 343 MB algorithmic).
-                HostCsr Rn = permute_csr(R[l], nullptr, id ? nullptr : L.ord.inv.data());
+                Rn = permute_csr(R[l], nullptr, id ? nullptr : L.ord.inv.data());
+                r_used = &Rn;
                 L.R.upload(Rn, {}, h->stream);
                 L.r_out.alloc(co.inv.size());
                 L.r_out.upload(co.inv.data(), co.inv.size(), h->stream);
                 OMG_HIP(hipStreamSynchronize(h->stream));
+            }
+            {   // OMG_PROLONG_SCATTER=0: always the explicit transpose (identical bits, tested)
+                const char *e = getenv("OMG_PROLONG_SCATTER");
+                bool ok = !(e && e[0] == '0') && L.R.all_pattern();
+                if (ok) {
+                    std::vector<char> seen(size_t(L.n), 0);
+                    for (int32_t c : r_used->indices) {
+                        if (seen[c]) { ok = false; break; }
+                        seen[c] = 1;
+                    }
+                }
+                L.scatter_prolong = ok;
             }
             L.r.alloc(L.n);
             if (smoother == OMG_SMOOTH_JACOBI) L.tmp.alloc(L.n);
@@ -640,6 +664,18 @@ int omg_hierarchy_level_fused(const omg_hierarchy *h, int level, int *fused) {
             check_level(hh, level);
             OMG_REQUIRE(fused, "null");
             *fused = (level + 1 < (int)hh->lv.size() && can_fuse(hh, hh->lv[level])) ? 1 : 0;
+        });
+    });
+}
+
+int omg_hierarchy_level_flags(const omg_hierarchy *h, int level, int *flags) {
+    return guarded([&] {
+        with(h, [&](auto *hh) {
+            check_level(hh, level);
+            OMG_REQUIRE(flags, "null");
+            const bool smoothed = level + 1 < (int)hh->lv.size();
+            *flags = ((smoothed && can_fuse(hh, hh->lv[level])) ? OMG_LEVEL_FUSED_LAST_SET : 0) |
+                     ((smoothed && hh->lv[level].scatter_prolong) ? OMG_LEVEL_SCATTER_PROLONG : 0);
         });
     });
 }

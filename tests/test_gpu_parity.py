@@ -704,3 +704,39 @@ def test_device_format_modes_are_bit_identical(monkeypatch, golden, case):
         assert full["coldict_nnz"] == full["nnz"]                # offsets repeat, values do not
     if case == "irregular":
         assert full["pattern_rows"] == 0 and full["coldict_nnz"] < full["nnz"]
+
+
+def test_prolongation_as_a_scatter_over_restriction_rows_is_bit_identical(monkeypatch):
+    """ROW_SCATTER: x += R^T e applied from R's row patterns (aggregation: every fine unknown
+    has one parent) instead of from the explicit transpose; OMG_PROLONG_SCATTER=0 switches it
+    off.  Same two roundings per entry -> same bits, in both precisions; an R whose rows share
+    columns (linear interpolation) keeps the transpose."""
+    shape = (128, 128, 128)       # long grid lines: R's blocks then hold a handful of row patterns
+    A0 = operators.stencil_poisson(shape)
+    R = operators.restrictionList(shape, 2, 4)
+    A = operators.coeffecientList(A0, R)
+    rng = np.random.default_rng(90)
+    b = A0 @ rng.random(A0.shape[0])
+    e0, x0 = rng.random(R[0].shape[0]), rng.random(A0.shape[0])
+    for dtype in ("float64", "float32"):
+        out = {}
+        for sw in ("0", "1"):
+            monkeypatch.setenv("OMG_PROLONG_SCATTER", sw)
+            with _hip.Hierarchy(A, R, smoother="colour", dtype=dtype) as h:
+                assert h.level_flags(0)["scatter_prolong"] == (sw == "1")
+                p = h.prolong_add(0, e0, x0)
+                h.resident_load(b)
+                norms = [h.resident_cycle(1, 1) for _ in range(3)]
+                out[sw] = (p, norms, h.resident_fetch())
+        assert np.array_equal(out["0"][0], out["1"][0])
+        assert out["0"][1] == out["1"][1] and np.array_equal(out["0"][2], out["1"][2])
+    monkeypatch.setenv("OMG_PROLONG_SCATTER", "1")
+    # overlapping aggregates: columns shared between rows -> no scatter
+    n = 600
+    Rl = sp.diags([0.25 * np.ones(n - 1), 0.5 * np.ones(n), 0.25 * np.ones(n - 1)], [-1, 0, 1], format="csr")[::2]
+    Al = sp.diags([-np.ones(n - 1), 2.5 * np.ones(n), -np.ones(n - 1)], [-1, 0, 1], format="csr")
+    Ac = sp.csr_matrix(Rl @ Al @ Rl.T)
+    with _hip.Hierarchy([Al, Ac], [sp.csr_matrix(Rl)], smoother="colour") as h:
+        assert not h.level_flags(0)["scatter_prolong"]
+        e, x = rng.random(Rl.shape[0]), rng.random(n)
+        np.testing.assert_allclose(h.prolong_add(0, e, x), x + Rl.T @ e, **OP)

@@ -167,3 +167,33 @@ def test_stencil27_variable_is_the_q1_stiffness_survey_8d_specifies():
     assert np.bincount(np.diff(B.indptr))[27] == 7 * 6 * 8          # interior nodes hold all 27 couplings
     with pytest.raises(ValueError):
         operators.stencil27_variable((8, 8))
+
+
+def test_device_format_selftest_property():
+    """Random structure: banded / repeated-value / random matrices with empty rows, duplicate
+    columns and unsorted rows survive the coder bit for bit in both precisions."""
+    from hypothesis import given, settings, strategies as st
+
+    @settings(max_examples=40, deadline=None)
+    @given(n=st.integers(1, 700), m=st.integers(1, 700), kind=st.sampled_from(["banded", "few_values", "random", "dup"]),
+           seed=st.integers(0, 2 ** 31 - 1), dtype=st.sampled_from(["float64", "float32"]))
+    def run(n, m, kind, seed, dtype):
+        rng = np.random.default_rng(seed)
+        if kind == "banded":
+            offs = sorted(set(int(o) for o in rng.integers(-min(n, m) + 1, min(n, m), size=5)))
+            M = sp.diags([rng.choice([-1.0, 2.0, 0.5], size=1)[0] * np.ones(min(n, m))] * len(offs), offs, shape=(n, m), format="csr")
+        elif kind == "few_values":
+            M = sp.random(n, m, density=0.05, random_state=np.random.RandomState(seed % (2 ** 31)), format="csr")
+            M.data = rng.choice([1.0, -1.0, 0.125, 3.0], size=M.nnz)
+        elif kind == "random":
+            M = sp.random(n, m, density=0.03, random_state=np.random.RandomState(seed % (2 ** 31)), format="csr")
+        else:                                                    # duplicate column entries inside rows, unsorted
+            k = int(rng.integers(0, 4 * n + 1))
+            rows = np.sort(rng.integers(0, n, size=k))
+            cols = rng.integers(0, m, size=k)
+            indptr = np.searchsorted(rows, np.arange(n + 1)).astype(np.int32)
+            M = sp.csr_matrix((rng.standard_normal(k), cols.astype(np.int32), indptr), shape=(n, m))
+        info = _hip.format_selftest(M, dtype)                    # raises on any mismatch
+        assert info["rows"] == n and info["nnz"] == M.nnz
+
+    run()
