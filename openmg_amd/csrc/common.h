@@ -114,6 +114,13 @@ constexpr int ROWBLK_ROWS = 256;      // <= one row per thread
 constexpr int ROWBLK_NNZ = OMG_ROWBLK_NNZ;   // entries staged through LDS per workgroup
 constexpr int DICT_MAX = 64;                 // entries of a block dictionary (power of two)
 constexpr int DICT_SHIFT = 7;                // table word = (pool offset << DICT_SHIFT) | entries
+// How a row's sum is associated — a property of the ROW, so that every kernel, partition and
+// rank count gives the same bits: rows of at most ASSOC_LEN stored entries are one fma chain in
+// stored order (the reference's order, openmg/solvers.py:63-65); longer rows are four chains —
+// chain q takes entries q, q+4, q+8, ... in stored order — added as ((s0 + s1) + s2) + s3.
+// (Four lanes can then share a long row, and a single thread keeps four fmas in flight.)
+constexpr int ASSOC_LEN = 16;
+constexpr int PAT_LANE_ENTRIES = 128;         // pattern-kernel dictionary: entries held in the lanes of a wave (2 registers)
 constexpr int MIN_CODED_ENTRIES = 64;         // smaller blocks stay plain CSR
 constexpr int BLK_INFO_INTS = 8;             // ints per row-block table record
 
@@ -122,14 +129,17 @@ constexpr int BLK_INFO_INTS = 8;             // ints per row-block table record
 template <typename V>
 struct HostFormat {
     std::vector<int64_t> sets, set_blk, set_nnz;
+    std::vector<int32_t> set_maxlen;
     std::vector<char> set_pattern;
     int rows_cap = 256, lanes_per_row = 1;
     std::vector<V> narrowed;                    // float operators: the entries rounded once
     std::vector<uint8_t> cc, vc, rc;            // per-entry column / value codes, per-row pattern codes
     std::vector<int32_t> cpool, ppool_idx, ppool_beg, info;
     std::vector<V> vpool, ppool_val;
-    int64_t blocks_ccoded = 0, blocks_vcoded = 0, blocks_pcoded = 0;
-    int64_t nnz_ccoded = 0, nnz_vcoded = 0, nnz_pcoded = 0, rows_pcoded = 0;
+    std::vector<V> vell;                        // block-transposed values of the offset-pattern blocks
+    int64_t blocks_ccoded = 0, blocks_vcoded = 0, blocks_pcoded = 0, blocks_ell = 0;
+    int64_t nnz_ccoded = 0, nnz_vcoded = 0, nnz_pcoded = 0, rows_pcoded = 0, nnz_ell = 0;
+    bool wide_failed = false;                   // encode_csr's 256-row attempt for long-row operators did not qualify
 };
 template <typename V>
 HostFormat<V> encode_csr(const HostCsr &A, const std::vector<int64_t> &sets);
@@ -164,16 +174,28 @@ struct DevCsrT {
     // per ROW.  The kernels stream the dictionary (a few hundred bytes, shared between blocks,
     // L2-resident) into the same LDS image a plain block would fill and walk it per row, so the
     // summation order, and with it every bit of the result, is unchanged.
+    //
+    // Variable coefficients repeat the OFFSETS of their rows but not the values.  Where a whole
+    // smoother set can run the LDS-free pattern kernel, such a block keeps offset-only patterns
+    // (one byte per row) and its values move to `vell`, transposed inside the block: entry j of
+    // every row side by side, so that the one-thread-per-row kernel reads them coalesced
+    // (record word [2] = offset into vell + 1, [3] = the block's longest row).  sizeof(V) bytes
+    // per entry instead of sizeof(V) + 1 (+ padding for the shorter boundary rows).
     DevBuf<uint8_t> ccode, vcode;      // one byte per stored entry (meaningful in coded blocks)
     DevBuf<int32_t> cdict;             // pool of column-offset dictionaries (shared between blocks)
     DevBuf<V> vdict;                   // pool of value dictionaries
     DevBuf<uint8_t> rcode;             // one byte per row: its pattern (meaningful in pattern blocks)
     DevBuf<int32_t> pidx, pbeg;        // pattern pools: offsets; per dictionary npat + 1 starts into them
     DevBuf<V> pval;                    //                values
+    DevBuf<V> vell;                    // block-transposed values of offset-pattern blocks
+    int64_t blocks_ell = 0, nnz_ell = 0;
     int64_t blocks_ccoded = 0, blocks_vcoded = 0, blocks_pcoded = 0;   // blocks using each coding (host, stats)
     int64_t nnz_ccoded = 0, nnz_vcoded = 0, nnz_pcoded = 0;            // their stored entries
     int64_t rows_pcoded = 0;
-    std::vector<char> set_pattern;     // per set: 1 when every block of it is row-pattern coded (host)
+    // per set (host): 0 = rows_kernel; 1 = every block is row-pattern coded with a wave-sized
+    // dictionary: rows_pattern_kernel (OMG_PATTERN_KERNEL=0 may still choose rows_kernel); 2 = the
+    // same, and rows_kernel could not run it (values in vell, or 256-row blocks of long rows)
+    std::vector<char> set_pattern;
     std::vector<int32_t> blk_host;     // host copy of the row-block table (format statistics)
     // out[OMG_FORMAT_FIELDS] of include/openmg_hip.h for the blocks of set `set` (-1: all)
     void format_info(int set, int64_t *out) const;
@@ -181,6 +203,7 @@ struct DevCsrT {
     std::vector<int64_t> sets;         // row offsets of the sets (host)
     int rows_cap = ROWBLK_ROWS;        // most rows a block may hold (> ROWBLK_THREADS: short rows)
     std::vector<int64_t> set_nnz;      // stored entries of each set (host)
+    std::vector<int32_t> set_maxlen;   // longest row of each set (host): > ASSOC_LEN picks the four-chain kernels
     int lanes_per_row = 1;             // 4 for operators with long rows (avg > 16 entries)
     void upload(const HostCsr &A, const std::vector<int64_t> &sets, hipStream_t s);   // converts to V
     size_t n_sets() const { return sets.empty() ? 0 : sets.size() - 1; }

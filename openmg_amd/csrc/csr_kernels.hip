@@ -58,6 +58,7 @@ struct KArgs {
     const int32_t *pidx;       // row-pattern pools: (column - row) offsets, values, pattern starts
     const V *pval;
     const int32_t *pbeg;
+    const V *vell;             // block-transposed values of offset-pattern blocks
     const int32_t *indptr;
     const int32_t *indices;
     const V *data;
@@ -142,6 +143,38 @@ __device__ __forceinline__ void row_resolve(RowPre<V> &p, const int *s_cd) {
 __device__ __forceinline__ double madd(double v, double x, double acc) { return fma(v, x, acc); }
 __device__ __forceinline__ float madd(float v, float x, float acc) { return fmaf(v, x, acc); }
 
+// Row-sum association (common.h ASSOC_LEN).  four: the row is long — entry e (counted from the
+// row's first) goes to chain e & 3; callers pass e's low bits as a compile-time j.
+template <typename V>
+struct Chains {
+    V s0 = V(0), s1 = V(0), s2 = V(0), s3 = V(0);
+    __device__ __forceinline__ void fma_at(int j, bool four, V v, V x) {
+        if (four) {
+            switch (j & 3) {
+                case 0: s0 = madd(v, x, s0); break;
+                case 1: s1 = madd(v, x, s1); break;
+                case 2: s2 = madd(v, x, s2); break;
+                default: s3 = madd(v, x, s3); break;
+            }
+        } else {
+            s0 = madd(v, x, s0);
+        }
+    }
+    __device__ __forceinline__ void add_at(int j, bool four, V v) {
+        if (four) {
+            switch (j & 3) {
+                case 0: s0 += v; break;
+                case 1: s1 += v; break;
+                case 2: s2 += v; break;
+                default: s3 += v; break;
+            }
+        } else {
+            s0 += v;
+        }
+    }
+    __device__ __forceinline__ V total(bool four) const { return four ? ((s0 + s1) + s2) + s3 : s0; }
+};
+
 template <int MODE, typename V>
 __device__ __forceinline__ void row_epilogue(const KArgs<V> &a, int r, const RowPre<V> &p, V sum,
                                              V diag, double &sq) {
@@ -170,7 +203,9 @@ __device__ __forceinline__ void row_epilogue(const KArgs<V> &a, int r, const Row
 // SHORT selects the phase-2 variant for operators whose rows are so short (prolongation:
 // one entry per row) that a block holds several rows per thread: the rows of a thread are
 // then processed eight at a time with all their loads in flight together.
-template <int MODE, bool nt, bool SHORT, int LPR, typename V>
+// LONG: the launch may hold rows of more than ASSOC_LEN entries (host: set_maxlen); only then does a
+// one-thread-per-row instantiation carry the four accumulators of a long row (registers).
+template <int MODE, bool nt, bool SHORT, int LPR, bool LONG, typename V>
 __device__ void process_block(const KArgs<V> &a, int blk, V *s_val, int *s_idx, double *s_red, int *s_cd,
                               V *s_vd) {
     constexpr bool FUSED = (MODE == ROW_GS_RES || MODE == ROW_GS_NORM);
@@ -303,78 +338,115 @@ __device__ void process_block(const KArgs<V> &a, int blk, V *s_val, int *s_idx, 
                     const int ru = rb + u * NT;
                     if (ru >= r1) continue;
                     sum[u] = (q[u].beg < q[u].end) ? madd(v0[u], x0[u], V(0)) : V(0);
-                    for (int k = q[u].beg + 1 - base; k < q[u].end - base; ++k) {   // rest, stored order
-                        const int sl = slot(k);
-                        sum[u] = madd(s_val[sl], a.x[s_idx[sl] + (crel ? ru : 0)], sum[u]);
+                    if (q[u].end - q[u].beg <= ASSOC_LEN) {
+                        for (int k = q[u].beg + 1 - base; k < q[u].end - base; ++k) {   // rest, stored order
+                            const int sl = slot(k);
+                            sum[u] = madd(s_val[sl], a.x[s_idx[sl] + (crel ? ru : 0)], sum[u]);
+                        }
+                    } else {
+                        // a long row among the short ones: four chains (common.h ASSOC_LEN); the
+                        // batched first entry started chain 0
+                        V ch[4] = {sum[u], V(0), V(0), V(0)};
+#pragma unroll
+                        for (int t = 0; t < 4; ++t)
+                            for (int k = q[u].beg - base + (t == 0 ? 4 : t); k < q[u].end - base; k += 4) {
+                                const int sl = slot(k);
+                                ch[t] = madd(s_val[sl], a.x[s_idx[sl] + (crel ? ru : 0)], ch[t]);
+                            }
+                        sum[u] = ((ch[0] + ch[1]) + ch[2]) + ch[3];
                     }
                     double unused = 0.0;
                     row_epilogue<MODE>(a, ru, q[u], sum[u], V(0), unused);
                 }
             }
         } else {
-            // LPR lanes share a row (LPR = 1: one thread per row, strictly stored order).  With
-            // LPR = 4 — operators with long rows, e.g. 27-point stencils, where one thread per
-            // row would leave most of the workgroup idle — lane q of a row's quad takes entries
-            // q, q+4, q+8, ... in stored order and the four partial sums are added in lane
-            // order: a fixed, run-to-run reproducible association, the same in every mode.
+            // LPR lanes share a row.  The association of a row's sum is fixed by its length
+            // (common.h ASSOC_LEN), not by LPR: a row of <= 16 entries is ONE chain in stored
+            // order (LPR = 4: the quad's first lane walks it alone), a longer row FOUR chains —
+            // chain q takes entries q, q+4, ... — which with LPR = 4 are the quad's four lanes
+            // and with LPR = 1 four accumulators of the row's thread; added as ((s0+s1)+s2)+s3.
             const int sub = tid % LPR;
             const int lane0 = (threadIdx.x & 63) & ~(LPR - 1);     // first lane of the quad
-            auto quad_sum = [&](V p) {
-                if constexpr (LPR == 1) return p;
-                V t = __shfl(p, lane0, 64);
-#pragma unroll
-                for (int q = 1; q < LPR; ++q) t += __shfl(p, lane0 + q, 64);
-                return t;
-            };
             while (r < r1) {
                 const int beg = pre.beg - base, end = pre.end - base;
                 const int radd = crel ? r : 0;
-                V sum = V(0), diag = V(0);
+                const bool four = end - beg > ASSOC_LEN;
+                const bool four_here = LPR == 1 && LONG && four;  // the four chains live in this thread
+                const int step = (LPR == 4 && four) ? 4 : 1;
+                const int first = (LPR == 4 && four) ? sub : 0;
+                const bool live = LPR == 1 || four || sub == 0;
+                // a quad's partial sums -> the row's sum, in lane order (or lane 0's chain alone)
+                auto fold = [&](const Chains<V> &ch) {
+                    if constexpr (LPR == 1) {
+                        return ch.total(four);
+                    } else {
+                        V t = __shfl(ch.s0, lane0, 64);
+                        if (four) {
+#pragma unroll
+                            for (int q = 1; q < LPR; ++q) t += __shfl(ch.s0, lane0 + q, 64);
+                        }
+                        return t;
+                    }
+                };
+                Chains<V> acc, dacc;
                 int c[8];
                 V v[8], xv[8];
-                for (int k = beg + sub; k < end; k += 8 * LPR) {
+                if (live) {
+                    for (int k = beg + first; k < end; k += 8 * step) {   // (k - beg - first) % (8 step) == 0
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const int kk = min(k + j * LPR, end - 1);
-                        const int s = slot(kk);
-                        c[j] = s_idx[s] + radd;
-                        v[j] = s_val[s];
-                    }
+                        for (int j = 0; j < 8; ++j) {
+                            const int kk = min(k + j * step, end - 1);
+                            const int s = slot(kk);
+                            c[j] = s_idx[s] + radd;
+                            v[j] = s_val[s];
+                        }
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) xv[j] = a.x[c[j]];
+                        for (int j = 0; j < 8; ++j) xv[j] = a.x[c[j]];
+                        if (four_here) {
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        if (k + j * LPR < end) {
-                            sum = madd(v[j], xv[j], sum);
-                            if (NEED_DIAG && c[j] == r) diag += v[j];
+                            for (int j = 0; j < 8; ++j)
+                                if (k + j * step < end) {
+                                    acc.fma_at(j, true, v[j], xv[j]);
+                                    if (NEED_DIAG && c[j] == r) dacc.add_at(j, true, v[j]);
+                                }
+                        } else {
+#pragma unroll
+                            for (int j = 0; j < 8; ++j)
+                                if (k + j * step < end) {
+                                    acc.s0 = madd(v[j], xv[j], acc.s0);
+                                    if (NEED_DIAG && c[j] == r) dacc.s0 += v[j];
+                                }
                         }
                     }
                 }
-                sum = quad_sum(sum);
-                if constexpr (NEED_DIAG) diag = quad_sum(diag);
+                const V sum = fold(acc);
+                V diag = V(0);
+                if constexpr (NEED_DIAG) diag = fold(dacc);
                 if constexpr (FUSED) {
                     // relax the row, then its residual with the NEW x_i: same entries, same
-                    // order, same fma chain as ROW_RESIDUAL would run on the updated vector
+                    // chains as ROW_RESIDUAL would run on the updated vector
                     const V xnew = pre.xv + (pre.bv - sum) / diag;
-                    V sum2 = V(0);
-                    if (end - beg <= 8 * LPR) {      // the row's entries are still in registers
+                    Chains<V> acc2;
+                    if (live) {
+                        if (end - beg <= 8 * step) {      // the lane's entries are still in registers: one chain here
 #pragma unroll
-                        for (int j = 0; j < 8; ++j)
-                            if (beg + sub + j * LPR < end) sum2 = madd(v[j], c[j] == r ? xnew : xv[j], sum2);
-                    } else {
-                        for (int k = beg + sub; k < end; k += 8 * LPR) {
+                            for (int j = 0; j < 8; ++j)
+                                if (beg + first + j * step < end) acc2.s0 = madd(v[j], c[j] == r ? xnew : xv[j], acc2.s0);
+                        } else {
+                            for (int k = beg + first; k < end; k += 8 * step) {
 #pragma unroll
-                            for (int j = 0; j < 8; ++j) {
-                                const int kk = k + j * LPR;
-                                if (kk < end) {
-                                    const int s = slot(kk);
-                                    const int cc = s_idx[s] + radd;
-                                    sum2 = madd(s_val[s], cc == r ? xnew : a.x[cc], sum2);
+                                for (int j = 0; j < 8; ++j) {
+                                    const int kk = k + j * step;
+                                    if (kk < end) {
+                                        const int s = slot(kk);
+                                        const int cc = s_idx[s] + radd;
+                                        acc2.fma_at(j, four_here, s_val[s], cc == r ? xnew : a.x[cc]);
+                                    }
                                 }
                             }
                         }
                     }
-                    sum2 = quad_sum(sum2);
+                    const V sum2 = fold(acc2);
                     const V res = pre.bv - sum2;
                     if (sub == 0) {
                         a.y[r] = xnew;
@@ -460,7 +532,7 @@ __device__ __forceinline__ int xcd_remap_grouped(int b, int n, int G) {
 
 // (NT, 6): six workgroups per CU is what the 25 KB fp64 LDS image allows; keep every variant
 // within 80 VGPRs so that registers do not cut that to five (the fused sweeps wanted 82-94).
-template <int MODE, bool NTL, bool SHORT, int LPR, typename V>
+template <int MODE, bool NTL, bool SHORT, int LPR, bool LONG, typename V>
 __global__ __launch_bounds__(NT, 6) void rows_kernel(KArgs<V> a, int blk0, int remap) {
     __shared__ V s_val[LDS_SLOTS];
     __shared__ int s_idx[LDS_SLOTS];
@@ -470,7 +542,7 @@ __global__ __launch_bounds__(NT, 6) void rows_kernel(KArgs<V> a, int blk0, int r
     const int local = remap == 0 ? int(blockIdx.x)
                     : remap == 1 ? xcd_remap(blockIdx.x, gridDim.x)
                                  : xcd_remap_grouped(blockIdx.x, gridDim.x, remap);
-    process_block<MODE, NTL, SHORT, LPR>(a, blk0 + local, s_val, s_idx, s_red, s_cd, s_vd);
+    process_block<MODE, NTL, SHORT, LPR, LONG>(a, blk0 + local, s_val, s_idx, s_red, s_cd, s_vd);
 }
 
 // A run of consecutive tiny sets (one row block each), executed back to back by ONE
@@ -478,7 +550,7 @@ __global__ __launch_bounds__(NT, 6) void rows_kernel(KArgs<V> a, int blk0, int r
 // sweep of a 1-D operator is n single-row sets, and the first/last hyperplanes of a 3-D
 // grid are tiny too.  Stores of set s are visible to set s+1 through the barrier's
 // workgroup-scope fence (same CU, same L1).
-template <int MODE, int LPR, typename V>
+template <int MODE, int LPR, bool LONG, typename V>
 __global__ __launch_bounds__(NT) void rows_serial_kernel(KArgs<V> a, int blk_begin, int blk_end) {
     __shared__ V s_val[LDS_SLOTS];
     __shared__ int s_idx[LDS_SLOTS];
@@ -486,7 +558,7 @@ __global__ __launch_bounds__(NT) void rows_serial_kernel(KArgs<V> a, int blk_beg
     __shared__ int s_cd[2 * DICT_MAX];
     __shared__ V s_vd[DICT_MAX];
     for (int blk = blk_begin; blk < blk_end; ++blk) {
-        process_block<MODE, false, false, LPR>(a, blk, s_val, s_idx, s_red, s_cd, s_vd);
+        process_block<MODE, false, false, LPR, LONG>(a, blk, s_val, s_idx, s_red, s_cd, s_vd);
         __threadfence_block();
         __syncthreads();
     }
@@ -518,33 +590,50 @@ __device__ __forceinline__ double lane_pick(double v, int lane) {
     return __hiloint2double(hi, lo);
 }
 
-// Dictionary of one wave's block: lane i of didx / dval holds entry i, lane c of dbeg the start
-// of pattern c (a pattern-kernel block has at most 64 entries in at most 63 patterns); the
-// wave-uniform operands come out with v_readlane.
-template <typename V>
+// Dictionary of one wave's block: lane i of didx[h] / dval[h] holds entry 64 h + i, lane c of
+// dbeg the start of pattern c (a pattern-kernel block has at most PAT_LANE_ENTRIES entries in at
+// most 63 patterns); the wave-uniform operands come out with v_readlane.  ell != NULL: the block
+// keeps offset patterns only and its values sit transposed in the ELL array — entry j of row i
+// of the block at ell[j * rows + i], read coalesced by the one-thread-per-row kernel.
+template <bool BIG, typename V>
 struct PatDictRef {
-    int didx, dbeg;
-    V dval;
+    int didx[2], dbeg;
+    V dval[2];
+    const V *__restrict__ ell;     // + row in block
+    int rows;                      // rows of the block (ELL stride)
+    // BIG: more than 64 entries, the second register is in use (block-uniform; a template
+    // parameter so that the common small dictionary pays no test per operand)
     __device__ __forceinline__ int start(int code) const { return lane_pick(dbeg, code); }
-    __device__ __forceinline__ int off(int k) const { return lane_pick(didx, k); }
-    __device__ __forceinline__ V val(int k) const { return lane_pick(dval, k); }
+    __device__ __forceinline__ int off(int k) const {
+        if (!BIG) return lane_pick(didx[0], k);
+        return k < 64 ? lane_pick(didx[0], k) : lane_pick(didx[1], k - 64);
+    }
+    __device__ __forceinline__ V val(int k) const {
+        if (!BIG) return lane_pick(dval[0], k);
+        return k < 64 ? lane_pick(dval[0], k) : lane_pick(dval[1], k - 64);
+    }
 };
 
 // N consecutive pattern entries starting at k (everything about them is wave-uniform: no
 // clamps, no predicates): operands, then all gathers, then the fma chain in stored order.
 // FUSED and `whole` (the chunk is the entire row): also the relaxed value and the row's
 // residual with it, from the operands still in registers.
-template <int MODE, int N, typename V>
-__device__ __forceinline__ void pattern_chunk(const PatDictRef<V> &d, const V *__restrict__ xrow, int k,
-                                              bool whole, const RowPre<V> &pre, V &sum, V &diag, V &sum2, V &xnew) {
+template <int MODE, int N, bool BIG, typename V>
+__device__ __forceinline__ void pattern_chunk(const PatDictRef<BIG, V> &d, const V *__restrict__ xrow, int k, int pb,
+                                              bool whole, bool four, const RowPre<V> &pre, Chains<V> &acc,
+                                              Chains<V> &dacc, V &sum2, V &xnew) {
     constexpr bool FUSED = (MODE == ROW_GS_RES || MODE == ROW_GS_NORM);
     constexpr bool NEED_DIAG = (MODE == ROW_GS || MODE == ROW_JACOBI || FUSED);
     int off[N];
     V val[N], xg[N];
 #pragma unroll
-    for (int j = 0; j < N; ++j) {
-        off[j] = d.off(k + j);
-        val[j] = d.val(k + j);
+    for (int j = 0; j < N; ++j) off[j] = d.off(k + j);
+    if (d.ell) {                                              // block-uniform
+#pragma unroll
+        for (int j = 0; j < N; ++j) val[j] = d.ell[(k - pb + j) * d.rows];
+    } else {
+#pragma unroll
+        for (int j = 0; j < N; ++j) val[j] = d.val(k + j);
     }
     if constexpr (MODE == ROW_SCATTER) {
         // y[r + off] += val * x_row: product rounded, then added — the two roundings of
@@ -559,13 +648,13 @@ __device__ __forceinline__ void pattern_chunk(const PatDictRef<V> &d, const V *_
 #pragma unroll
     for (int j = 0; j < N; ++j) xg[j] = xrow[off[j]];
 #pragma unroll
-    for (int j = 0; j < N; ++j) {
-        sum = madd(val[j], xg[j], sum);
-        if (NEED_DIAG && off[j] == 0) diag += val[j];
+    for (int j = 0; j < N; ++j) {                             // (k - pb) % 8 == 0: entry k + j feeds chain j & 3
+        acc.fma_at(j, four, val[j], xg[j]);
+        if (NEED_DIAG && off[j] == 0) dacc.add_at(j, four, val[j]);
     }
     if constexpr (FUSED) {
-        if (whole) {
-            xnew = pre.xv + (pre.bv - sum) / diag;
+        if (whole) {                                          // <= 8 entries: one chain
+            xnew = pre.xv + (pre.bv - acc.s0) / dacc.s0;
 #pragma unroll
             for (int j = 0; j < N; ++j) sum2 = madd(val[j], off[j] == 0 ? xnew : xg[j], sum2);
         }
@@ -573,9 +662,9 @@ __device__ __forceinline__ void pattern_chunk(const PatDictRef<V> &d, const V *_
 }
 
 // One wave's rows of a pattern block: lanes grouped by pattern, one group at a time.
-template <int MODE, typename V>
+template <int MODE, bool LONG, bool BIG, typename V>
 __device__ __forceinline__ void pattern_rows(const KArgs<V> &a, int r, bool active, int code, const RowPre<V> &pre,
-                                             const PatDictRef<V> &d, V &sum, V &diag, V &sum2, V &xnew) {
+                                             const PatDictRef<BIG, V> &d, V &sum, V &diag, V &sum2, V &xnew) {
     constexpr bool FUSED = (MODE == ROW_GS_RES || MODE == ROW_GS_NORM);
     // x[r + offset]; ROW_SCATTER walks (and updates) y there instead
     const V *__restrict__ xrow = (MODE == ROW_SCATTER ? a.y : a.x) + r;
@@ -587,26 +676,41 @@ __device__ __forceinline__ void pattern_rows(const KArgs<V> &a, int r, bool acti
         const int pb = d.start(ucode), pe = d.start(ucode + 1);
         if (mine) {
             const bool whole = pe - pb <= 8;
+            // common.h: long rows sum as four chains (LONG: the launch holds such rows at all;
+            // the lean instantiation keeps a single accumulator)
+            const bool four = LONG && pe - pb > ASSOC_LEN;
+            Chains<V> acc, dacc;
             int k = pb;
-            for (; k + 8 <= pe; k += 8) pattern_chunk<MODE, 8>(d, xrow, k, whole, pre, sum, diag, sum2, xnew);
+            for (; k + 8 <= pe; k += 8) pattern_chunk<MODE, 8>(d, xrow, k, pb, whole, four, pre, acc, dacc, sum2, xnew);
             switch (pe - k) {                                 // uniform: one scalar jump
-                case 1: pattern_chunk<MODE, 1>(d, xrow, k, whole, pre, sum, diag, sum2, xnew); break;
-                case 2: pattern_chunk<MODE, 2>(d, xrow, k, whole, pre, sum, diag, sum2, xnew); break;
-                case 3: pattern_chunk<MODE, 3>(d, xrow, k, whole, pre, sum, diag, sum2, xnew); break;
-                case 4: pattern_chunk<MODE, 4>(d, xrow, k, whole, pre, sum, diag, sum2, xnew); break;
-                case 5: pattern_chunk<MODE, 5>(d, xrow, k, whole, pre, sum, diag, sum2, xnew); break;
-                case 6: pattern_chunk<MODE, 6>(d, xrow, k, whole, pre, sum, diag, sum2, xnew); break;
-                case 7: pattern_chunk<MODE, 7>(d, xrow, k, whole, pre, sum, diag, sum2, xnew); break;
+                case 1: pattern_chunk<MODE, 1>(d, xrow, k, pb, whole, four, pre, acc, dacc, sum2, xnew); break;
+                case 2: pattern_chunk<MODE, 2>(d, xrow, k, pb, whole, four, pre, acc, dacc, sum2, xnew); break;
+                case 3: pattern_chunk<MODE, 3>(d, xrow, k, pb, whole, four, pre, acc, dacc, sum2, xnew); break;
+                case 4: pattern_chunk<MODE, 4>(d, xrow, k, pb, whole, four, pre, acc, dacc, sum2, xnew); break;
+                case 5: pattern_chunk<MODE, 5>(d, xrow, k, pb, whole, four, pre, acc, dacc, sum2, xnew); break;
+                case 6: pattern_chunk<MODE, 6>(d, xrow, k, pb, whole, four, pre, acc, dacc, sum2, xnew); break;
+                case 7: pattern_chunk<MODE, 7>(d, xrow, k, pb, whole, four, pre, acc, dacc, sum2, xnew); break;
                 default: break;
             }
+            sum = acc.total(four);
+            diag = dacc.total(four);
             if constexpr (FUSED) {
                 if (!whole) {
-                    // longer rows: relax, then walk the pattern again (rows_kernel's FUSED branch)
+                    // longer rows: relax, then walk the pattern again (rows_kernel's FUSED branch),
+                    // chain by chain
                     xnew = pre.xv + (pre.bv - sum) / diag;
-                    for (int q = pb; q < pe; ++q) {
-                        const int o = d.off(q);
-                        sum2 = madd(d.val(q), o == 0 ? xnew : xrow[o], sum2);
+                    V ch[4] = {V(0), V(0), V(0), V(0)};
+                    const int nch = four ? 4 : 1;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        if (t >= nch) break;
+                        for (int q = pb + t; q < pe; q += nch) {
+                            const int o = d.off(q);
+                            const V v = d.ell ? d.ell[(q - pb) * d.rows] : d.val(q);
+                            ch[t] = madd(v, o == 0 ? xnew : xrow[o], ch[t]);
+                        }
                     }
+                    sum2 = four ? ((ch[0] + ch[1]) + ch[2]) + ch[3] : ch[0];
                 }
             }
         }
@@ -616,8 +720,9 @@ __device__ __forceinline__ void pattern_rows(const KArgs<V> &a, int r, bool acti
 
 // (Variants measured and dropped: several blocks per workgroup with all their operands
 // requested together — no gain; XCD-chunked block mapping — 6 % slower, as for rows_kernel.)
-template <int MODE, typename V>
-__global__ __launch_bounds__(NT, (MODE == ROW_GS_RES || MODE == ROW_GS_NORM) ? 6 : (MODE == ROW_GS || MODE == ROW_JACOBI) ? 7 : 8)
+template <int MODE, bool LONG, typename V>
+__global__ __launch_bounds__(NT, (MODE == ROW_GS_RES || MODE == ROW_GS_NORM) ? (LONG ? 4 : 6)
+                                                                              : (MODE == ROW_GS || MODE == ROW_JACOBI) ? 7 : 8)
 void rows_pattern_kernel(KArgs<V> a, int blk0) {
     constexpr bool FUSED = (MODE == ROW_GS_RES || MODE == ROW_GS_NORM);
     constexpr bool NEED_NORM = (MODE == ROW_RESNORM || MODE == ROW_NORM_ONLY || MODE == ROW_GS_NORM);
@@ -629,7 +734,7 @@ void rows_pattern_kernel(KArgs<V> a, int blk0) {
     const int32_t *__restrict__ pidx = a.pidx + lp[0];       // this block's dictionary
     const V *__restrict__ pval = a.pval + lp[0];
     const int32_t *__restrict__ pbeg = a.pbeg + lp[2];
-    const int cnt = lp[1], npat = lp[3];                      // cnt <= 64, npat <= 63 (setup: set_pattern)
+    const int cnt = lp[1], npat = lp[3];                      // cnt <= PAT_LANE_ENTRIES, npat <= 63 (setup: set_pattern)
     const int r = r0 + int(threadIdx.x);                      // a pattern block has <= NT rows
     const bool active = r < r1;
     const int lane = int(threadIdx.x) & 63;
@@ -637,13 +742,28 @@ void rows_pattern_kernel(KArgs<V> a, int blk0) {
     RowPre<V> pre;
     int code = 0;
     // the dictionary with the codes, not after them
-    const PatDictRef<V> d{pidx[min(lane, cnt - 1)], pbeg[min(lane, npat)], pval[min(lane, cnt - 1)]};
+    const V *ell = lo[2] ? a.vell + (lo[2] - 1) + int(threadIdx.x) : nullptr;      // offset patterns, values in the ELL array
+    const int didx0 = pidx[min(lane, cnt - 1)];
+    const int dbeg = pbeg[min(lane, npat)];
+    V dval0 = V(0);
+    if (!ell) dval0 = pval[min(lane, cnt - 1)];
     if (active) {
         pre = row_preload<MODE>(a, r, EXT_PATTERN);
         code = pre.beg;
     }
     V sum = V(0), diag = V(0), sum2 = V(0), xnew = V(0);
-    pattern_rows<MODE>(a, r, active, code, pre, d, sum, diag, sum2, xnew);
+    if (cnt > 64) {                                           // block-uniform: second dictionary register
+        PatDictRef<true, V> d;
+        d.didx[0] = didx0; d.dbeg = dbeg; d.dval[0] = dval0; d.ell = ell; d.rows = r1 - r0;
+        d.didx[1] = pidx[min(64 + lane, cnt - 1)];
+        d.dval[1] = ell ? V(0) : pval[min(64 + lane, cnt - 1)];
+        pattern_rows<MODE, LONG>(a, r, active, code, pre, d, sum, diag, sum2, xnew);
+    } else {
+        PatDictRef<false, V> d;
+        d.didx[0] = didx0; d.dbeg = dbeg; d.dval[0] = dval0; d.ell = ell; d.rows = r1 - r0;
+        d.didx[1] = 0; d.dval[1] = V(0);
+        pattern_rows<MODE, LONG>(a, r, active, code, pre, d, sum, diag, sum2, xnew);
+    }
     if (active) {
         if constexpr (FUSED) {
             const V res = pre.bv - sum2;
@@ -675,10 +795,11 @@ int launch_flags() {
 
 template <int MODE, typename V>
 void launch_mode(const DevCsrT<V> &A, int64_t blk0, int64_t nblk, const KArgs<V> &k, bool all_pattern,
-                 hipStream_t s) {
+                 bool long_rows, hipStream_t s) {
     if (nblk <= 0) return;
     if (all_pattern) {
-        hipLaunchKernelGGL((rows_pattern_kernel<MODE, V>), dim3((unsigned)nblk), dim3(NT), 0, s, k, (int)blk0);
+        if (long_rows) hipLaunchKernelGGL((rows_pattern_kernel<MODE, true, V>), dim3((unsigned)nblk), dim3(NT), 0, s, k, (int)blk0);
+        else hipLaunchKernelGGL((rows_pattern_kernel<MODE, false, V>), dim3((unsigned)nblk), dim3(NT), 0, s, k, (int)blk0);
         OMG_HIP(hipGetLastError());
         return;
     }
@@ -693,20 +814,25 @@ void launch_mode(const DevCsrT<V> &A, int64_t blk0, int64_t nblk, const KArgs<V>
     const dim3 grid((unsigned)nblk), block(NT);
     if constexpr (HAS_SHORT) {
         if (A.rows_cap > NT) {
-            if (ntl) hipLaunchKernelGGL((rows_kernel<MODE, true, true, 1, V>), grid, block, 0, s, k, (int)blk0, remap);
-            else hipLaunchKernelGGL((rows_kernel<MODE, false, true, 1, V>), grid, block, 0, s, k, (int)blk0, remap);
+            if (ntl) hipLaunchKernelGGL((rows_kernel<MODE, true, true, 1, true, V>), grid, block, 0, s, k, (int)blk0, remap);
+            else hipLaunchKernelGGL((rows_kernel<MODE, false, true, 1, true, V>), grid, block, 0, s, k, (int)blk0, remap);
             OMG_HIP(hipGetLastError());
             return;
         }
     }
     if (A.lanes_per_row == 4) {       // long rows: four lanes per row
-        if (ntl) hipLaunchKernelGGL((rows_kernel<MODE, true, false, 4, V>), grid, block, 0, s, k, (int)blk0, remap);
-        else hipLaunchKernelGGL((rows_kernel<MODE, false, false, 4, V>), grid, block, 0, s, k, (int)blk0, remap);
+        if (ntl) hipLaunchKernelGGL((rows_kernel<MODE, true, false, 4, true, V>), grid, block, 0, s, k, (int)blk0, remap);
+        else hipLaunchKernelGGL((rows_kernel<MODE, false, false, 4, true, V>), grid, block, 0, s, k, (int)blk0, remap);
         OMG_HIP(hipGetLastError());
         return;
     }
-    if (ntl) hipLaunchKernelGGL((rows_kernel<MODE, true, false, 1, V>), grid, block, 0, s, k, (int)blk0, remap);
-    else hipLaunchKernelGGL((rows_kernel<MODE, false, false, 1, V>), grid, block, 0, s, k, (int)blk0, remap);
+    if (long_rows) {
+        if (ntl) hipLaunchKernelGGL((rows_kernel<MODE, true, false, 1, true, V>), grid, block, 0, s, k, (int)blk0, remap);
+        else hipLaunchKernelGGL((rows_kernel<MODE, false, false, 1, true, V>), grid, block, 0, s, k, (int)blk0, remap);
+    } else {
+        if (ntl) hipLaunchKernelGGL((rows_kernel<MODE, true, false, 1, false, V>), grid, block, 0, s, k, (int)blk0, remap);
+        else hipLaunchKernelGGL((rows_kernel<MODE, false, false, 1, false, V>), grid, block, 0, s, k, (int)blk0, remap);
+    }
     OMG_HIP(hipGetLastError());
 }
 
@@ -725,6 +851,7 @@ KArgs<V> make_kargs(const DevCsrT<V> &A, const RowArgsT<V> &args) {
     k.pidx = A.pidx.p;
     k.pval = A.pval.p;
     k.pbeg = A.pbeg.p;
+    k.vell = A.vell.p;
     k.x = args.x;
     k.b = args.b;
     k.y = args.y;
@@ -743,41 +870,65 @@ void launch_rows(const DevCsrT<V> &A, int mode, int set, const RowArgsT<V> &args
     else launch_rows_range(A, mode, set, set + 1, args, s);
 }
 
+namespace {
+
+// [set_begin, set_end): all sets go to the same kernel (pattern: rows_pattern_kernel)
 template <typename V>
-void launch_rows_range(const DevCsrT<V> &A, int mode, int set_begin, int set_end, const RowArgsT<V> &args,
-                       hipStream_t s) {
+void launch_rows_uniform(const DevCsrT<V> &A, int mode, int set_begin, int set_end, bool pattern,
+                         const RowArgsT<V> &args, hipStream_t s) {
     const KArgs<V> k = make_kargs(A, args);
-    OMG_REQUIRE(set_begin >= 0 && set_begin <= set_end && size_t(set_end) <= A.n_sets(),
-                "launch_rows: set range out of bounds");
     const int64_t blk0 = A.set_blk[set_begin];
     const int64_t nblk = A.set_blk[set_end] - blk0;
-    // every block of the range row-pattern coded -> the LDS-free kernel (OMG_PATTERN_KERNEL=0:
-    // the general kernel, which walks the same dictionaries through LDS; identical bits)
-    bool ap = !A.set_pattern.empty() && set_end > set_begin;
-    if (ap) { const char *e = getenv("OMG_PATTERN_KERNEL"); ap = !(e && e[0] == '0'); }
-    for (int q = set_begin; ap && q < set_end; ++q) ap = A.set_pattern[q] != 0;
     if (mode == ROW_SCATTER) {                 // exists in the pattern kernel only (common.h)
-        bool all = !A.set_pattern.empty() && set_end > set_begin;
-        for (int q = set_begin; all && q < set_end; ++q) all = A.set_pattern[q] != 0;
-        OMG_REQUIRE(all, "ROW_SCATTER needs an operator whose blocks are all row-pattern coded");
+        OMG_REQUIRE(pattern, "ROW_SCATTER needs an operator whose blocks are all row-pattern coded");
         if (nblk > 0) {
-            hipLaunchKernelGGL((rows_pattern_kernel<ROW_SCATTER, V>), dim3((unsigned)nblk), dim3(NT), 0, s, k, (int)blk0);
+            hipLaunchKernelGGL((rows_pattern_kernel<ROW_SCATTER, false, V>), dim3((unsigned)nblk), dim3(NT), 0, s, k, (int)blk0);
             OMG_HIP(hipGetLastError());
         }
         return;
     }
+    const bool ap = pattern;
+    bool long_rows = false;                    // any row of the range summed as four chains (common.h ASSOC_LEN)
+    for (int q = set_begin; q < set_end; ++q) long_rows = long_rows || A.set_maxlen.empty() || A.set_maxlen[q] > ASSOC_LEN;
     switch (mode) {
-
-        case ROW_GS_RES: launch_mode<ROW_GS_RES>(A, blk0, nblk, k, ap, s); break;
-        case ROW_GS_NORM: launch_mode<ROW_GS_NORM>(A, blk0, nblk, k, ap, s); break;
-        case ROW_SPMV: launch_mode<ROW_SPMV>(A, blk0, nblk, k, ap, s); break;
-        case ROW_RESIDUAL: launch_mode<ROW_RESIDUAL>(A, blk0, nblk, k, ap, s); break;
-        case ROW_RESNORM: launch_mode<ROW_RESNORM>(A, blk0, nblk, k, ap, s); break;
-        case ROW_NORM_ONLY: launch_mode<ROW_NORM_ONLY>(A, blk0, nblk, k, ap, s); break;
-        case ROW_GS: launch_mode<ROW_GS>(A, blk0, nblk, k, ap, s); break;
-        case ROW_JACOBI: launch_mode<ROW_JACOBI>(A, blk0, nblk, k, ap, s); break;
-        case ROW_AXPY: launch_mode<ROW_AXPY>(A, blk0, nblk, k, ap, s); break;
+        case ROW_GS_RES: launch_mode<ROW_GS_RES>(A, blk0, nblk, k, ap, long_rows, s); break;
+        case ROW_GS_NORM: launch_mode<ROW_GS_NORM>(A, blk0, nblk, k, ap, long_rows, s); break;
+        case ROW_SPMV: launch_mode<ROW_SPMV>(A, blk0, nblk, k, ap, long_rows, s); break;
+        case ROW_RESIDUAL: launch_mode<ROW_RESIDUAL>(A, blk0, nblk, k, ap, long_rows, s); break;
+        case ROW_RESNORM: launch_mode<ROW_RESNORM>(A, blk0, nblk, k, ap, long_rows, s); break;
+        case ROW_NORM_ONLY: launch_mode<ROW_NORM_ONLY>(A, blk0, nblk, k, ap, long_rows, s); break;
+        case ROW_GS: launch_mode<ROW_GS>(A, blk0, nblk, k, ap, long_rows, s); break;
+        case ROW_JACOBI: launch_mode<ROW_JACOBI>(A, blk0, nblk, k, ap, long_rows, s); break;
+        case ROW_AXPY: launch_mode<ROW_AXPY>(A, blk0, nblk, k, ap, long_rows, s); break;
         default: throw Error(OMG_ERR_INVALID, "launch_rows: unknown mode");
+    }
+}
+
+}  // namespace
+
+template <typename V>
+void launch_rows_range(const DevCsrT<V> &A, int mode, int set_begin, int set_end, const RowArgsT<V> &args,
+                       hipStream_t s) {
+    OMG_REQUIRE(set_begin >= 0 && set_begin <= set_end && size_t(set_end) <= A.n_sets(),
+                "launch_rows: set range out of bounds");
+    if (set_begin == set_end) return;
+    // Which kernel a set runs (common.h set_pattern): 2 = the LDS-free pattern kernel, always;
+    // 1 = the pattern kernel unless OMG_PATTERN_KERNEL=0 asks for rows_kernel's walk of the same
+    // dictionaries through LDS (identical bits); 0 = rows_kernel.  Consecutive sets with the same
+    // answer share a launch.
+    const char *e = getenv("OMG_PATTERN_KERNEL");
+    const bool prefer = !(e && e[0] == '0');
+    auto pattern_of = [&](int q) {
+        const int v = A.set_pattern.empty() ? 0 : A.set_pattern[q];
+        return v == 2 || (v == 1 && (prefer || mode == ROW_SCATTER));     // the scatter exists in the pattern kernel only
+    };
+    int q0 = set_begin;
+    while (q0 < set_end) {
+        const bool pat = pattern_of(q0);
+        int q1 = q0 + 1;
+        while (q1 < set_end && pattern_of(q1) == pat) ++q1;
+        launch_rows_uniform(A, mode, q0, q1, pat, args, s);
+        q0 = q1;
     }
 }
 
@@ -790,10 +941,20 @@ void launch_gs_serial(const DevCsrT<V> &A, int set_begin, int set_end, const Row
     k.ymap = nullptr;
     const int b0 = (int)A.set_blk[set_begin], b1 = (int)A.set_blk[set_end];
     if (b1 <= b0) return;
+    // the serial kernel walks rows_kernel's LDS image: sets that only the pattern kernel can run
+    // are launched one by one instead
+    for (int q = set_begin; q < set_end; ++q)
+        if (!A.set_pattern.empty() && A.set_pattern[q] == 2) {
+            for (int t = set_begin; t < set_end; ++t) launch_rows_range(A, ROW_GS, t, t + 1, args, s);
+            return;
+        }
     // the same lanes-per-row association as launch_rows uses for this operator: a row's sum
     // must not depend on which of the two kernels relaxes it
-    if (A.lanes_per_row == 4) hipLaunchKernelGGL((rows_serial_kernel<ROW_GS, 4, V>), dim3(1), dim3(NT), 0, s, k, b0, b1);
-    else hipLaunchKernelGGL((rows_serial_kernel<ROW_GS, 1, V>), dim3(1), dim3(NT), 0, s, k, b0, b1);
+    bool long_rows = false;
+    for (int q = set_begin; q < set_end; ++q) long_rows = long_rows || A.set_maxlen.empty() || A.set_maxlen[q] > ASSOC_LEN;
+    if (A.lanes_per_row == 4) hipLaunchKernelGGL((rows_serial_kernel<ROW_GS, 4, true, V>), dim3(1), dim3(NT), 0, s, k, b0, b1);
+    else if (long_rows) hipLaunchKernelGGL((rows_serial_kernel<ROW_GS, 1, true, V>), dim3(1), dim3(NT), 0, s, k, b0, b1);
+    else hipLaunchKernelGGL((rows_serial_kernel<ROW_GS, 1, false, V>), dim3(1), dim3(NT), 0, s, k, b0, b1);
     OMG_HIP(hipGetLastError());
 }
 

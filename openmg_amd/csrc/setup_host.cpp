@@ -246,13 +246,14 @@ void make_row_blocks(const std::vector<int32_t> &indptr, const std::vector<int64
 namespace {
 
 // OMG_COMPRESS, a bit mask: 1 = per-entry column dictionaries, 2 = per-entry value
-// dictionaries, 4 = whole-row pattern dictionaries; 0 = plain CSR only; default 7.  Results are
+// dictionaries, 4 = whole-row pattern dictionaries, 8 = offset patterns with the values in a
+// block-transposed (ELL) array (needs 4); 0 = plain CSR only; default 15.  Results are
 // bit-identical in every mode (tests/test_gpu_parity.py).
 int compress_mode() {
     const char *e = getenv("OMG_COMPRESS");
-    if (!e || !e[0]) return 7;
+    if (!e || !e[0]) return 15;
     const int v = atoi(e);
-    return (v < 0 || v > 7) ? 7 : v;
+    return (v < 0 || v > 15) ? 15 : v;
 }
 
 template <typename V> struct Bits;
@@ -283,112 +284,106 @@ struct SmallDict {
 
 }  // namespace
 
+namespace {
+
+// One attempt at coding A with a given row-block partition (see encode_csr).
 template <typename V>
-HostFormat<V> encode_csr(const HostCsr &A, const std::vector<int64_t> &sets_in) {
+HostFormat<V> encode_with(const HostCsr &A, const std::vector<int64_t> &sets_in, int max_rows, int max_nnz,
+                          int lanes, int mode) {
     HostFormat<V> F;
     auto &sets = F.sets;
     auto &set_blk = F.set_blk;
-    auto &set_nnz = F.set_nnz;
-    auto &set_pattern = F.set_pattern;
-    int &rows_cap = F.rows_cap;
-    int &lanes_per_row = F.lanes_per_row;
     const int64_t n_rows = A.n_rows, nnz = A.nnz;
     sets = sets_in;
     if (sets.empty()) sets = {0, n_rows};
+    F.rows_cap = max_rows;
+    F.lanes_per_row = lanes;
     std::vector<int32_t> blocks;
-    // One row per thread for stencil-like rows; for very short rows (prolongation: one entry
-    // per row) let a block take as many rows as fit its LDS budget so that each workgroup
-    // still moves tens of KB.
-    int max_rows = ROWBLK_ROWS;
-    if (n_rows > 0) {
-        const double avg = double(nnz) / double(n_rows);
-        while (max_rows < ROWBLK_NNZ && avg * (2 * max_rows) <= ROWBLK_NNZ) max_rows *= 2;
-        // long rows (27-point stencils ...): one thread per row would leave most of the
-        // workgroup idle in the row phase, so four lanes share a row and a block holds at
-        // most ROWBLK_THREADS / 4 rows per pass
-        const char *e = getenv("OMG_LANES_PER_ROW");
-        lanes_per_row = e ? atoi(e) : (avg > 16.0 ? 4 : 1);
-        if (lanes_per_row != 4) lanes_per_row = 1;
-        if (lanes_per_row == 4) max_rows = ROWBLK_THREADS / 4;
-    }
-    rows_cap = max_rows;
-    set_nnz.assign(sets.size() - 1, 0);
-    for (size_t k = 0; k + 1 < sets.size(); ++k) set_nnz[k] = A.indptr[sets[k + 1]] - A.indptr[sets[k]];
-    make_row_blocks(A.indptr, sets, max_rows, ROWBLK_NNZ, blocks, set_blk);
+    F.set_nnz.assign(sets.size() - 1, 0);
+    for (size_t k = 0; k + 1 < sets.size(); ++k) F.set_nnz[k] = A.indptr[sets[k + 1]] - A.indptr[sets[k]];
+    F.set_maxlen.assign(sets.size() - 1, 0);
+    for (size_t k = 0; k + 1 < sets.size(); ++k)
+        for (int64_t r = sets[k]; r < sets[k + 1]; ++r)
+            F.set_maxlen[k] = std::max<int32_t>(F.set_maxlen[k], A.indptr[r + 1] - A.indptr[r]);
+    make_row_blocks(A.indptr, sets, max_rows, max_nnz, blocks, set_blk);
     // float operator: round the fp64 entries once, here
     if constexpr (!std::is_same<V, double>::value) F.narrowed.assign(A.data.begin(), A.data.end());
     const V *vals;
     if constexpr (std::is_same<V, double>::value) vals = A.data.data();
     else vals = F.narrowed.data();
-    // ---- block dictionaries (common.h "Block-dictionary coding") -----------------------------
+
+    // ---- phase A (parallel over blocks): what each block COULD be coded as -----------------------
     const int64_t nblk = int64_t(blocks.size()) - 1;          // `blocks` ends with a sentinel row
-    const int mode = compress_mode();
     auto &cc = F.cc;
     auto &vc = F.vc;
     auto &rc = F.rc;
     const size_t nb = size_t(std::max<int64_t>(nblk, 0));
-    std::vector<std::vector<int32_t>> cdicts(nb);
-    std::vector<std::vector<V>> vdicts(nb);
     struct PatDict {
         std::vector<int32_t> beg, idx;     // beg: npat + 1 offsets into idx / val
-        std::vector<V> val;
+        std::vector<V> val;                // empty: offsets only (values go to the ELL array)
+        int maxlen = 0;
+        bool wave_sized() const { return !idx.empty() && int(beg.size()) - 1 < 64 && int(idx.size()) <= PAT_LANE_ENTRIES; }
     };
-    std::vector<PatDict> pdicts(nb);
+    std::vector<PatDict> pfull(nb), pcols(nb);
+    std::vector<std::vector<int32_t>> cdicts(nb);
+    std::vector<std::vector<V>> vdicts(nb);
     // row patterns: not for the several-rows-per-thread operators (prolongation, restriction)
-    const bool try_pat = (mode & 4) && rows_cap <= ROWBLK_THREADS;
+    const bool try_pat = (mode & 4) && max_rows <= ROWBLK_THREADS;
+    const bool try_ell = try_pat && (mode & 8) && lanes == 1;
     if (mode != 0 && nblk > 0 && nnz > 0) {
         if (mode & 1) cc.assign(size_t(nnz), 0);
         if (mode & 2) vc.assign(size_t(nnz), 0);
         if (try_pat) rc.assign(size_t(n_rows), 0);
+        // rows of [r0, r1) as patterns of (column - row) offsets, with their values (full) or without
+        auto patterns = [&](int64_t r0, int64_t r1, bool with_values, int64_t budget, PatDict &out) {
+            PatDict d;
+            d.beg.push_back(0);
+            int last = -1;
+            for (int64_t r = r0; r < r1; ++r) {
+                const int64_t q0 = A.indptr[r];
+                const int len = int(A.indptr[r + 1] - q0);
+                auto same = [&](int c) {
+                    const int b = d.beg[c];
+                    if (d.beg[c + 1] - b != len) return false;
+                    for (int j = 0; j < len; ++j) {
+                        if (d.idx[b + j] != A.indices[q0 + j] - int32_t(r)) return false;
+                        if (with_values && Bits<V>::of(d.val[b + j]) != Bits<V>::of(vals[q0 + j])) return false;
+                    }
+                    return true;
+                };
+                int code = -1;
+                const int npat = int(d.beg.size()) - 1;
+                if (last >= 0 && same(last)) code = last;
+                for (int c = 0; c < npat && code < 0; ++c)
+                    if (c != last && same(c)) code = c;
+                if (code < 0) {
+                    if (npat == DICT_MAX || int64_t(d.idx.size()) + len > budget) return false;
+                    for (int j = 0; j < len; ++j) {
+                        d.idx.push_back(A.indices[q0 + j] - int32_t(r));
+                        if (with_values) d.val.push_back(vals[q0 + j]);
+                    }
+                    d.beg.push_back(int32_t(d.idx.size()));
+                    code = npat;
+                }
+                rc[r] = uint8_t(code);
+                last = code;
+                d.maxlen = std::max(d.maxlen, len);
+            }
+            out = std::move(d);
+            return true;
+        };
         auto work = [&](int64_t k0, int64_t k1) {
             for (int64_t k = k0; k < k1; ++k) {
                 const int64_t r0 = blocks[k], r1 = blocks[k + 1];
                 const int64_t p0 = A.indptr[r0], p1 = A.indptr[r1];
-                if (p1 <= p0 || p1 - p0 > ROWBLK_NNZ) continue;       // empty, or one long row: plain
+                if (p1 <= p0 || p1 - p0 > max_nnz) continue;          // empty, or one long row: plain
                 // a small block is latency, not bytes: a dictionary would only add a round trip
                 // (the single-row sets of a 1-D lexicographic sweep ran 20 % slower coded)
                 if (p1 - p0 < MIN_CODED_ENTRIES) continue;
-                if (try_pat) {
-                    // whole-row patterns: (length, column - row offsets, values) of every row
-                    PatDict d;
-                    d.beg.push_back(0);
-                    bool ok = true;
-                    int last = -1;
-                    const int64_t budget = (p1 - p0) / 2;             // a dictionary must be a real saving
-                    for (int64_t r = r0; r < r1 && ok; ++r) {
-                        const int64_t q0 = A.indptr[r];
-                        const int len = int(A.indptr[r + 1] - q0);
-                        auto same = [&](int c) {
-                            const int b = d.beg[c];
-                            if (d.beg[c + 1] - b != len) return false;
-                            for (int j = 0; j < len; ++j)
-                                if (d.idx[b + j] != A.indices[q0 + j] - int32_t(r) ||
-                                    Bits<V>::of(d.val[b + j]) != Bits<V>::of(vals[q0 + j]))
-                                    return false;
-                            return true;
-                        };
-                        int code = -1;
-                        const int npat = int(d.beg.size()) - 1;
-                        if (last >= 0 && same(last)) code = last;
-                        for (int c = 0; c < npat && code < 0; ++c)
-                            if (c != last && same(c)) code = c;
-                        if (code < 0) {
-                            if (npat == DICT_MAX || int64_t(d.idx.size()) + len > budget) { ok = false; break; }
-                            for (int j = 0; j < len; ++j) {
-                                d.idx.push_back(A.indices[q0 + j] - int32_t(r));
-                                d.val.push_back(vals[q0 + j]);
-                            }
-                            d.beg.push_back(int32_t(d.idx.size()));
-                            code = npat;
-                        }
-                        rc[r] = uint8_t(code);
-                        last = code;
-                    }
-                    if (ok) {
-                        pdicts[k] = std::move(d);
-                        continue;
-                    }
-                }
+                const int64_t budget = (p1 - p0) / 2;                 // a dictionary must be a real saving
+                if (try_pat && patterns(r0, r1, true, budget, pfull[k])) continue;
+                if (try_ell) patterns(r0, r1, false, budget, pcols[k]);
+                if (p1 - p0 > ROWBLK_NNZ) continue;                   // (wide partition: no LDS fallback exists)
                 if (mode & 1) {
                     SmallDict<int32_t> d;
                     bool ok = true;
@@ -426,7 +421,29 @@ HostFormat<V> encode_csr(const HostCsr &A, const std::vector<int64_t> &sets_in) 
             for (auto &t : pool) t.join();
         }
     }
-    // pool the dictionaries: blocks of a stencil operator mostly share one, which then stays in L2
+
+    // ---- phase B: which sets can run the LDS-free pattern kernel; final coding of every block ----
+    // A set runs rows_pattern_kernel when EVERY block of it is a row-pattern block whose
+    // dictionary fits the lanes of a wave (one row per thread: LPR 1).  Only there may a block
+    // keep offset patterns with its values in the ELL array (rows_kernel has no path for it).
+    F.set_pattern.assign(sets.size() - 1, 0);
+    if (lanes == 1 && max_rows <= ROWBLK_THREADS)
+        for (size_t q = 0; q + 1 < sets.size(); ++q) {
+            bool all = set_blk[q + 1] > set_blk[q], ell = false;
+            for (int64_t k = set_blk[q]; all && k < set_blk[q + 1]; ++k) {
+                if (pfull[k].wave_sized()) continue;
+                if (pcols[k].wave_sized()) { ell = true; continue; }
+                all = false;
+            }
+            F.set_pattern[q] = all ? (ell ? 2 : 1) : 0;
+        }
+    if (max_nnz > ROWBLK_NNZ) {
+        // wide partition (encode_csr): usable only if the pattern kernel takes every set
+        bool all = true;
+        for (size_t q = 0; q + 1 < sets.size(); ++q) all = all && (F.set_pattern[q] != 0 || set_blk[q + 1] == set_blk[q]);
+        if (!all) { F.set_pattern.assign(sets.size() - 1, 0); F.wide_failed = true; return F; }
+        for (auto &c : F.set_pattern) c = 2;     // mandatory: these blocks do not fit rows_kernel's LDS image
+    }
     auto &cpool = F.cpool;
     auto &ppool_idx = F.ppool_idx;
     auto &ppool_beg = F.ppool_beg;
@@ -434,42 +451,60 @@ HostFormat<V> encode_csr(const HostCsr &A, const std::vector<int64_t> &sets_in) 
     auto &ppool_val = F.ppool_val;
     auto &info = F.info;
     info.assign(size_t(BLK_INFO_INTS) * blocks.size(), 0);
+    std::vector<int64_t> ell_off(nb, -1);
+    int64_t ell_total = 0;
     {
         std::unordered_map<std::string, int32_t> cseen, vseen;
         std::unordered_map<std::string, std::pair<int32_t, int32_t>> pseen;    // -> (entry offset, table offset)
         const int64_t pool_cap = (int64_t(1) << (31 - DICT_SHIFT)) - DICT_MAX;
+        size_t set_of = 0;
         for (int64_t k = 0; k <= nblk; ++k) {
             int32_t *rec = info.data() + size_t(BLK_INFO_INTS) * size_t(k);
             rec[0] = blocks[k];
             rec[1] = A.indptr[blocks[k]];
             if (k == nblk) break;
+            while (set_of + 1 < set_blk.size() - 1 && k >= set_blk[set_of + 1]) ++set_of;
+            const int64_t rows = blocks[k + 1] - blocks[k];
             const int64_t entries = A.indptr[blocks[k + 1]] - A.indptr[blocks[k]];
-            const PatDict &pd = pdicts[k];
+            const bool use_ell = pfull[k].idx.empty() && !pcols[k].idx.empty() && F.set_pattern[set_of] == 2;
+            const PatDict &pd = use_ell ? pcols[k] : pfull[k];
             if (!pd.idx.empty()) {
+                std::vector<V> padv(pd.idx.size(), V(0));                      // offsets-only dictionaries: zeros
+                const V *dv = pd.val.empty() ? padv.data() : pd.val.data();
                 std::string key(reinterpret_cast<const char *>(pd.beg.data()), pd.beg.size() * sizeof(int32_t));
                 key.append(reinterpret_cast<const char *>(pd.idx.data()), pd.idx.size() * sizeof(int32_t));
-                key.append(reinterpret_cast<const char *>(pd.val.data()), pd.val.size() * sizeof(V));
+                key.append(reinterpret_cast<const char *>(dv), pd.idx.size() * sizeof(V));
                 auto it = pseen.find(key);
                 if (it == pseen.end() && int64_t(ppool_idx.size()) < (int64_t(1) << 30)) {
                     it = pseen.emplace(std::move(key), std::make_pair(int32_t(ppool_idx.size()), int32_t(ppool_beg.size()))).first;
                     ppool_idx.insert(ppool_idx.end(), pd.idx.begin(), pd.idx.end());
-                    ppool_val.insert(ppool_val.end(), pd.val.begin(), pd.val.end());
+                    ppool_val.insert(ppool_val.end(), dv, dv + pd.idx.size());
                     while (ppool_idx.size() % 8) { ppool_idx.push_back(0); ppool_val.push_back(V(0)); }   // 16-B vector loads
                     ppool_beg.insert(ppool_beg.end(), pd.beg.begin(), pd.beg.end());
                 }
-                if (it != pseen.end()) {
-                    rec[4] = it->second.first;
-                    rec[5] = int32_t(pd.idx.size());
-                    rec[6] = it->second.second;
-                    rec[7] = int32_t(pd.beg.size()) - 1;
-                    ++F.blocks_pcoded;
-                    F.rows_pcoded += blocks[k + 1] - blocks[k];
-                    F.nnz_pcoded += entries;
-                    continue;
+                OMG_REQUIRE(it != pseen.end(), "pattern dictionary pool overflow");
+                rec[4] = it->second.first;
+                rec[5] = int32_t(pd.idx.size());
+                rec[6] = it->second.second;
+                rec[7] = int32_t(pd.beg.size()) - 1;
+                ++F.blocks_pcoded;
+                F.rows_pcoded += rows;
+                F.nnz_pcoded += entries;
+                if (use_ell) {
+                    // values of the block transposed: entry j of every row side by side (coalesced)
+                    OMG_REQUIRE(ell_total + rows * pd.maxlen < (int64_t(1) << 31) - 1, "ELL value array exceeds int32 offsets");
+                    ell_off[k] = ell_total;
+                    rec[2] = int32_t(ell_total) + 1;
+                    rec[3] = pd.maxlen;
+                    ell_total += rows * pd.maxlen;
+                    ++F.blocks_ell;
+                    F.nnz_ell += entries;
                 }
+                continue;
             }
+            OMG_REQUIRE(max_nnz <= ROWBLK_NNZ, "a wide row block fell back to the LDS kernels");
             {   // exactly one entry in every row (prolongation): the kernels then skip the row pointers
-                bool unit = entries == blocks[k + 1] - blocks[k];
+                bool unit = entries == rows;
                 for (int64_t r = blocks[k]; unit && r < blocks[k + 1]; ++r) unit = A.indptr[r + 1] - A.indptr[r] == 1;
                 rec[6] = unit ? 1 : 0;
             }
@@ -501,19 +536,59 @@ HostFormat<V> encode_csr(const HostCsr &A, const std::vector<int64_t> &sets_in) 
             }
         }
     }
-    // sets made only of pattern blocks with wave-sized dictionaries run the LDS-free kernel
-    // (one row per thread: LPR 1)
-    set_pattern.assign(sets.size() - 1, 0);
-    if (F.blocks_pcoded && lanes_per_row == 1 && rows_cap <= ROWBLK_THREADS)
-        for (size_t q = 0; q + 1 < sets.size(); ++q) {
-            bool all = set_blk[q + 1] > set_blk[q];
-            for (int64_t k = set_blk[q]; all && k < set_blk[q + 1]; ++k) {
-                const int32_t *rec = info.data() + size_t(BLK_INFO_INTS) * size_t(k);
-                all = rec[7] != 0 && rec[7] < 64 && rec[5] <= 64;      // dictionary fits the lanes of a wave
+    // ---- phase C (parallel): the ELL value array -------------------------------------------------
+    if (ell_total > 0) {
+        F.vell.assign(size_t(ell_total), V(0));
+        auto fill = [&](int64_t k0, int64_t k1) {
+            for (int64_t k = k0; k < k1; ++k) {
+                if (ell_off[k] < 0) continue;
+                const int64_t r0 = blocks[k], rows = blocks[k + 1] - blocks[k];
+                V *dst = F.vell.data() + ell_off[k];
+                for (int64_t r = r0; r < r0 + rows; ++r)
+                    for (int64_t p = A.indptr[r]; p < A.indptr[r + 1]; ++p)
+                        dst[(p - A.indptr[r]) * rows + (r - r0)] = vals[p];
             }
-            set_pattern[q] = all ? 1 : 0;
-        }
+        };
+        const int nthreads = int(std::min<int64_t>(std::max(1u, std::min(16u, std::thread::hardware_concurrency())),
+                                                   std::max<int64_t>(1, nblk / 256)));
+        std::vector<std::thread> pool;
+        for (int t = 0; t < nthreads; ++t) pool.emplace_back(fill, nblk * t / nthreads, nblk * (t + 1) / nthreads);
+        for (auto &t : pool) t.join();
+    }
     return F;
+}
+
+}  // namespace
+
+template <typename V>
+HostFormat<V> encode_csr(const HostCsr &A, const std::vector<int64_t> &sets_in) {
+    int mode = compress_mode();
+    {   // OMG_PATTERN_KERNEL=0 (rows_kernel everywhere): no ELL blocks, rows_kernel cannot read them
+        const char *e = getenv("OMG_PATTERN_KERNEL");
+        if (e && e[0] == '0') mode &= ~8;
+    }
+    // One row per thread for stencil-like rows; for very short rows (prolongation: one entry
+    // per row) let a block take as many rows as fit its LDS budget so that each workgroup
+    // still moves tens of KB.
+    int max_rows = ROWBLK_ROWS, lanes = 1;
+    if (A.n_rows > 0) {
+        const double avg = double(A.nnz) / double(A.n_rows);
+        while (max_rows < ROWBLK_NNZ && avg * (2 * max_rows) <= ROWBLK_NNZ) max_rows *= 2;
+        // long rows (27-point stencils ...): one thread per row would leave most of the
+        // workgroup idle in rows_kernel's row phase, so four lanes share a row and a block holds
+        // at most ROWBLK_THREADS / 4 rows per pass
+        const char *e = getenv("OMG_LANES_PER_ROW");
+        lanes = e ? atoi(e) : (avg > 16.0 ? 4 : 1);
+        if (lanes != 4) lanes = 1;
+        if (lanes == 4) max_rows = ROWBLK_THREADS / 4;
+        // ... unless the LDS-free pattern kernel can take the WHOLE operator: it has no LDS image
+        // to fit, so its blocks are a full 256 rows whatever the row length.  Tried first.
+        if (lanes == 4 && (mode & 4) && !(getenv("OMG_PATTERN_KERNEL") && getenv("OMG_PATTERN_KERNEL")[0] == '0')) {
+            HostFormat<V> W = encode_with<V>(A, sets_in, ROWBLK_THREADS, 1 << 24, 1, mode);
+            if (!W.wide_failed) return W;
+        }
+    }
+    return encode_with<V>(A, sets_in, max_rows, ROWBLK_NNZ, lanes, mode);
 }
 
 template <typename V>
@@ -525,12 +600,14 @@ void DevCsrT<V>::upload(const HostCsr &A, const std::vector<int64_t> &sets_in, h
     sets = std::move(F.sets);
     set_blk = std::move(F.set_blk);
     set_nnz = std::move(F.set_nnz);
+    set_maxlen = std::move(F.set_maxlen);
     set_pattern = std::move(F.set_pattern);
     rows_cap = F.rows_cap;
     lanes_per_row = F.lanes_per_row;
     blocks_ccoded = F.blocks_ccoded; blocks_vcoded = F.blocks_vcoded; blocks_pcoded = F.blocks_pcoded;
     nnz_ccoded = F.nnz_ccoded; nnz_vcoded = F.nnz_vcoded; nnz_pcoded = F.nnz_pcoded;
     rows_pcoded = F.rows_pcoded;
+    blocks_ell = F.blocks_ell; nnz_ell = F.nnz_ell;
     indptr.alloc(A.indptr.size());
     indices.alloc(std::max<size_t>(A.indices.size(), 1));
     data.alloc(std::max<size_t>(A.data.size(), 1));
@@ -545,6 +622,7 @@ void DevCsrT<V>::upload(const HostCsr &A, const std::vector<int64_t> &sets_in, h
     if (blocks_ccoded) { put(ccode, F.cc); put(cdict, F.cpool); }
     if (blocks_vcoded) { put(vcode, F.vc); put(vdict, F.vpool); }
     if (blocks_pcoded) { put(rcode, F.rc); put(pidx, F.ppool_idx); put(pval, F.ppool_val); put(pbeg, F.ppool_beg); }
+    if (!F.vell.empty()) put(vell, F.vell);
     put(blk_rows, F.info);
     OMG_HIP(hipStreamSynchronize(s));   // host staging vectors may die after return
     blk_host = std::move(F.info);
@@ -570,7 +648,12 @@ void decode_format(const HostFormat<V> &F, const HostCsr &A, std::vector<int32_t
                 OMG_REQUIRE(pe <= rec[5], "decode: pattern runs past its dictionary");
                 for (int j = 0; j < pe - pb; ++j) {
                     cols[A.indptr[r] + j] = F.ppool_idx[rec[4] + pb + j] + int32_t(r);
-                    vals[A.indptr[r] + j] = F.ppool_val[rec[4] + pb + j];
+                    if (rec[2]) {                                 // values in the ELL array, entry j of the block's rows side by side
+                        OMG_REQUIRE(j < rec[3], "decode: row longer than the block's ELL width");
+                        vals[A.indptr[r] + j] = F.vell[size_t(rec[2] - 1) + size_t(j) * size_t(r1 - r0) + size_t(r - r0)];
+                    } else {
+                        vals[A.indptr[r] + j] = F.ppool_val[rec[4] + pb + j];
+                    }
                 }
             }
             continue;
@@ -612,6 +695,7 @@ void format_stats(const std::vector<int32_t> &info, const std::vector<int64_t> &
             out[4] += rows;
             out[5] += ent;
             out[8] += rows;
+            if (rec[2]) out[8] += w * rows * rec[3];              // + the block's (padded) ELL values
         } else {
             if (!(rec[6] == 1 && rows_cap > ROWBLK_THREADS)) out[8] += 4 * rows;   // row pointers (not read for one-entry rows)
             if (rec[2]) { out[6] += ent; out[8] += ent; } else out[8] += 4 * ent;

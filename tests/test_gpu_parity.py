@@ -673,7 +673,8 @@ def test_device_format_modes_are_bit_identical(monkeypatch, golden, case):
     b = A[0] @ rng.random(A[0].shape[0])
     runs = {}
     # pk: "1" rows_pattern_kernel where the dictionaries fit a wave, "0" rows_kernel walking them through LDS
-    for mode, pk in (("0", "1"), ("1", "1"), ("2", "1"), ("3", "1"), ("4", "1"), ("4", "0"), ("7", "1"), ("7", "0")):
+    for mode, pk in (("0", "1"), ("1", "1"), ("2", "1"), ("3", "1"), ("4", "1"), ("4", "0"), ("7", "1"), ("7", "0"),
+                     ("15", "1"), ("15", "0"), ("12", "1")):
         monkeypatch.setenv("OMG_COMPRESS", mode)
         monkeypatch.setenv("OMG_PATTERN_KERNEL", pk)
         with _hip.Hierarchy(A, R, smoother=smoother, dtype=dtype) as h:
@@ -692,10 +693,16 @@ def test_device_format_modes_are_bit_identical(monkeypatch, golden, case):
     assert base[6]["format_bytes"] == base[6]["csr_bytes"] + 32 * base[6]["blocks"]
     assert base[6]["csr_bytes"] == A[0].nnz * (4 + w) + 4 * A[0].shape[0]
     for key, run in runs.items():
-        assert run[0] == base[0], key
-        for got, want in zip(run[1:6], base[1:6]):
+        # vectors: to the bit.  Norms are sums over row blocks, and a coding may come with another
+        # block partition (256-row blocks for long rows in the pattern kernel): same terms, other grouping.
+        np.testing.assert_allclose(run[0], base[0], rtol=1e-13, err_msg=str(key))
+        np.testing.assert_allclose(run[3], base[3], rtol=1e-13, err_msg=str(key))
+        for got, want in zip((run[1], run[2], run[4], run[5]), (base[1], base[2], base[4], base[5])):
             assert np.array_equal(got, want), key
     full = runs[("7", "1")][6]
+    if case == "variable7":                                      # offsets repeat, values do not: offset patterns + ELL values
+        ell = runs[("15", "1")][6]
+        assert ell["pattern_rows"] == ell["rows"] and ell["format_bytes"] < 0.75 * ell["csr_bytes"]
     if case in ("poisson7", "poisson7_f32", "stencil27", "jacobi2d", "galerkin_golden"):
         assert full["pattern_rows"] == full["rows"]              # constant stencils: a byte per row
         assert full["format_bytes"] < 0.2 * full["csr_bytes"]
