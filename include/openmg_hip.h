@@ -282,6 +282,9 @@ int omg_dist_cycle(omg_dist *d, int pre, int post, double *norm);
  * rank's operators.                                                                          */
 int omg_dist_spmv_time(omg_dist *d, int reps, double *avg_ms);
 int omg_dist_format_info(omg_dist *d, int level, int op, int set, int64_t *out);
+/* Schedule of a smoothed level of this rank: OMG_LEVEL_SCATTER_PROLONG, 4 = (boundary, interior)
+ * set pairs, 8 = the scatter prolongation is split the same way (boundary aggregates first). */
+int omg_dist_level_flags(omg_dist *d, int level, int *flags);
 /* Loopback group: ALL ranks of a decomposition inside one process on one GPU, halos moved by
  * device-to-device copies.  Same schedule as omg_dist_cycle; used to verify the distributed
  * algorithm where only one GPU is available.                                               */

@@ -123,6 +123,11 @@ class DistRank:
         check(lib().omg_dist_spmv_time(self._h, int(reps), ctypes.byref(ms)))
         return ms.value
 
+    def level_flags(self, level):
+        f = ctypes.c_int(0)
+        check(lib().omg_dist_level_flags(self._h, int(level), ctypes.byref(f)))
+        return {"scatter_prolong": bool(f.value & 2), "paired_sets": bool(f.value & 4), "split_scatter": bool(f.value & 8)}
+
     def format_info(self, level, op="A", set=-1):
         from ._hip import Hierarchy
         out = (ctypes.c_int64 * len(Hierarchy.FORMAT_FIELDS))()

@@ -207,9 +207,10 @@ struct DevCsrT {
     int lanes_per_row = 1;             // 4 for operators with long rows (avg > 16 entries)
     void upload(const HostCsr &A, const std::vector<int64_t> &sets, hipStream_t s);   // converts to V
     size_t n_sets() const { return sets.empty() ? 0 : sets.size() - 1; }
-    bool all_pattern() const {         // every set runs rows_pattern_kernel
+    bool all_pattern() const {         // every (non-empty) set runs rows_pattern_kernel
         if (set_pattern.empty()) return false;
-        for (char c : set_pattern) if (!c) return false;
+        for (size_t q = 0; q < set_pattern.size(); ++q)
+            if (!set_pattern[q] && sets[q + 1] > sets[q]) return false;
         return true;
     }
     int64_t n_blocks() const { return set_blk.empty() ? 0 : set_blk.back(); }

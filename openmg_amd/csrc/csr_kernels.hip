@@ -922,11 +922,13 @@ void launch_rows_range(const DevCsrT<V> &A, int mode, int set_begin, int set_end
         const int v = A.set_pattern.empty() ? 0 : A.set_pattern[q];
         return v == 2 || (v == 1 && (prefer || mode == ROW_SCATTER));     // the scatter exists in the pattern kernel only
     };
+    auto empty = [&](int q) { return A.set_blk[q + 1] == A.set_blk[q]; };
     int q0 = set_begin;
     while (q0 < set_end) {
+        if (empty(q0)) { ++q0; continue; }
         const bool pat = pattern_of(q0);
         int q1 = q0 + 1;
-        while (q1 < set_end && pattern_of(q1) == pat) ++q1;
+        while (q1 < set_end && (empty(q1) || pattern_of(q1) == pat)) ++q1;
         launch_rows_uniform(A, mode, q0, q1, pat, args, s);
         q0 = q1;
     }

@@ -93,6 +93,10 @@ struct DLevel {
     std::vector<int64_t> send_off, recv_off;   // per peer, size peers + 1
     DevBuf<int32_t> send_idx;                  // rows (this level's ordering) to send, all peers
     DevBuf<V> send_buf;
+    // prolongation as a scatter over R's row patterns (csrc/common.h ROW_SCATTER) instead of a
+    // pass over P; with (boundary, interior) set pairs R's rows are then split into [first
+    // coarse planes | interior | last coarse planes] so that the boundary part still goes first
+    bool scatter_prolong = false;
     int set_group = 1;                         // 2: sets are (boundary, interior) pairs
     std::vector<int> entry_group;              // per plan entry: colour it carries, -1 = any
     std::vector<int64_t> send_start;           // per entry: first row in x if contiguous, else -1
@@ -217,16 +221,44 @@ std::unique_ptr<Dist<V>> create(int rank, int n_ranks, int n_levels, const omg_d
                         "R[l] must be (coarse owned rows) x (fine owned rows): slabs must be cut on aggregate boundaries");
             HostCsr Rp = permute_csr(in.R, C.ord.identity ? nullptr : C.ord.perm.data(), id ? nullptr : L.ord.inv.data());
             HostCsr Pt = transpose_csr(Rp);
+            // R's rows as [aggregates holding boundary rows | interior | ... boundary]: possible when
+            // those aggregates are a prefix and a suffix of the natural coarse order (slabs: the
+            // first and last coarse planes); needed only where the fine sets are paired
+            std::vector<int64_t> rsets;
+            bool scatter_ok = true;
+            {
+                const char *e = getenv("OMG_PROLONG_SCATTER");
+                scatter_ok = !(e && e[0] == '0');
+                std::vector<char> seen(size_t(L.n_loc), 0);                // aggregation: no shared columns
+                for (int64_t p = 0; scatter_ok && p < in.R.nnz; ++p) {
+                    const int32_t c = in.R.indices[p];
+                    if (seen[c]) scatter_ok = false;
+                    seen[c] = 1;
+                }
+                if (scatter_ok && in.set_group == 2 && in.keys) {
+                    const int64_t nc = in.R.n_rows;
+                    std::vector<char> bnd(size_t(nc), 0);
+                    for (int64_t j = 0; j < nc; ++j)
+                        for (int32_t p = in.R.indptr[j]; p < in.R.indptr[j + 1]; ++p)
+                            if (in.keys[in.R.indices[p]] % 2 == 0) bnd[j] = 1;   // key = 2 colour + interior
+                    int64_t a = 0, b = nc;
+                    while (a < nc && bnd[a]) ++a;
+                    while (b > a && bnd[b - 1]) --b;
+                    for (int64_t j = a; scatter_ok && j < b; ++j) if (bnd[j]) scatter_ok = false;
+                    if (scatter_ok) rsets = {0, a, b, nc};
+                }
+            }
             if (C.ord.identity) {
-                L.R.upload(Rp, {}, d->stream);
+                L.R.upload(Rp, rsets, d->stream);
             } else {
                 // rows in natural coarse order + output map: dense gathers (see hierarchy.hip)
                 HostCsr Rn = permute_csr(in.R, nullptr, id ? nullptr : L.ord.inv.data());
-                L.R.upload(Rn, {}, d->stream);
+                L.R.upload(Rn, rsets, d->stream);
                 L.r_out.alloc(C.ord.inv.size());
                 L.r_out.upload(C.ord.inv.data(), C.ord.inv.size(), d->stream);
                 OMG_HIP(hipStreamSynchronize(d->stream));
             }
+            L.scatter_prolong = scatter_ok && L.R.all_pattern();
             // prolongation rows carry the fine level's sets: with (boundary, interior) pairs the
             // boundary rows are corrected first and travel while the interior ones are corrected
             L.P.upload(Pt, L.ord.sets, d->stream);
@@ -553,12 +585,25 @@ struct Runner {
         }
         cycle(l + 1, pre, post);
         // x_l += R^T x_{l+1} (:214, :220/:224), then everybody needs the corrected boundary values
+        // step 0: everything; first 0 / 1 with step 2: the boundary / the interior part
         auto prolong_sets = [&](int first, int step) {
             for (D *d : rs) {
                 DLevel<V> &L = d->lv[l];
                 DLevel<V> &C = d->lv[l + 1];
                 RowArgs a;
                 a.x = C.xp; a.y = L.xp;
+                if (L.scatter_prolong) {             // over R's rows: [boundary | interior | boundary] when split
+                    a.ymap = L.r_out.p;
+                    if (step == 0 || L.R.n_sets() != 3) {
+                        if (step == 0 || first == 0) launch_rows(L.R, ROW_SCATTER, -1, a, d->stream);
+                    } else if (first == 0) {
+                        launch_rows(L.R, ROW_SCATTER, 0, a, d->stream);
+                        launch_rows(L.R, ROW_SCATTER, 2, a, d->stream);
+                    } else {
+                        launch_rows(L.R, ROW_SCATTER, 1, a, d->stream);
+                    }
+                    continue;
+                }
                 if (step == 0) { launch_rows(L.P, ROW_AXPY, -1, a, d->stream); continue; }
                 for (int s = first; s < (int)L.P.n_sets(); s += step) launch_rows(L.P, ROW_AXPY, s, a, d->stream);
             }
@@ -814,6 +859,18 @@ int omg_dist_spmv_time(omg_dist *d, int reps, double *avg_ms) {
             (void)hipEventDestroy(e0);
             (void)hipEventDestroy(e1);
             *avg_ms = double(ms) / reps;
+        });
+    });
+}
+
+int omg_dist_level_flags(omg_dist *d, int level, int *flags) {
+    return guarded([&] {
+        OMG_REQUIRE(flags, "null");
+        with(d, [&](auto *dd) {
+            OMG_REQUIRE(level >= 0 && level + 1 < (int)dd->lv.size(), "level out of range (smoothed levels only)");
+            const auto &L = dd->lv[level];
+            *flags = (L.scatter_prolong ? OMG_LEVEL_SCATTER_PROLONG : 0) | (L.set_group == 2 ? 4 : 0) |
+                     (L.scatter_prolong && L.R.n_sets() == 3 ? 8 : 0);
         });
     });
 }

@@ -263,3 +263,31 @@ def test_27_point_variable_coefficient_slabs(dtype):
         np.testing.assert_allclose(nd, n1, rtol=1e-13 if dtype == "float64" else 1e-6)
     with pytest.raises(ValueError):                          # red-black is not a colouring of a 27-point operator
         _loopback(lambda lo, hi: dist.stencil27_variable_rows(shape, lo, hi), shape, grids, 2, b, 1, dtype)
+
+
+def test_split_scatter_prolongation_with_overlap(monkeypatch):
+    """Long grid lines (R's blocks then hold a handful of row patterns): prolongation runs as a
+    scatter over R's rows, split [first coarse planes | interior | last coarse planes] where the
+    fine sets are (boundary, interior) pairs, with the exchange on the second stream beside the
+    interior part.  Same bits as one GPU."""
+    monkeypatch.setenv("OMG_OVERLAP_MIN_ROWS", "0")
+    monkeypatch.setenv("OMG_FORCE_OVERLAP", "1")
+    shape, grids, n_ranks = (256, 8, 256), 3, 2
+    A0 = operators.stencil_poisson(shape)
+    b = A0 @ np.random.default_rng(41).random(A0.shape[0])
+    x1, n1, _ = _single(A0, shape, grids, b, 2, "float64")
+    part = dist.SlabPartition(shape, n_ranks, grids)
+    levels, coarse, counts = dist.build_all_ranks(part, lambda q: dist.stencil_rows(shape, *part.rows(0, q)), smoother="colour")
+    ranks = [_hip_dist.DistRank(q, n_ranks, levels[q], coarse, counts, smoother="colour") for q in range(n_ranks)]
+    flags = ranks[0].level_flags(0)
+    assert flags["paired_sets"] and flags["scatter_prolong"] and flags["split_scatter"], flags
+    group = _hip_dist.DistGroup(ranks)
+    try:
+        for q, r in enumerate(ranks):
+            r.load(b[slice(*part.rows(0, q))])
+        nd = [group.cycle(1, 1) for _ in range(2)]
+        xd = np.concatenate([r.fetch() for r in ranks])
+    finally:
+        group.close()
+    assert np.array_equal(xd, x1)
+    np.testing.assert_allclose(nd, n1, rtol=1e-13)
