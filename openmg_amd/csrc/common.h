@@ -130,7 +130,7 @@ template <typename V>
 struct HostFormat {
     std::vector<int64_t> sets, set_blk, set_nnz;
     std::vector<int32_t> set_maxlen;
-    std::vector<char> set_pattern;
+    std::vector<char> set_pattern, set_ell;
     int rows_cap = 256, lanes_per_row = 1;
     std::vector<V> narrowed;                    // float operators: the entries rounded once
     std::vector<uint8_t> cc, vc, rc;            // per-entry column / value codes, per-row pattern codes
@@ -204,6 +204,7 @@ struct DevCsrT {
     int rows_cap = ROWBLK_ROWS;        // most rows a block may hold (> ROWBLK_THREADS: short rows)
     std::vector<int64_t> set_nnz;      // stored entries of each set (host)
     std::vector<int32_t> set_maxlen;   // longest row of each set (host): > ASSOC_LEN picks the four-chain kernels
+    std::vector<char> set_ell;         // per set: some block keeps its values in vell (host)
     int lanes_per_row = 1;             // 4 for operators with long rows (avg > 16 entries)
     void upload(const HostCsr &A, const std::vector<int64_t> &sets, hipStream_t s);   // converts to V
     size_t n_sets() const { return sets.empty() ? 0 : sets.size() - 1; }

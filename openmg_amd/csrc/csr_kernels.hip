@@ -720,7 +720,8 @@ __device__ __forceinline__ void pattern_rows(const KArgs<V> &a, int r, bool acti
 
 // (Variants measured and dropped: several blocks per workgroup with all their operands
 // requested together — no gain; XCD-chunked block mapping — 6 % slower, as for rows_kernel.)
-template <int MODE, bool LONG, typename V>
+// ELL: the launch may hold blocks whose values sit in the ELL array (host: set_ell)
+template <int MODE, bool LONG, bool ELL, typename V>
 __global__ __launch_bounds__(NT, (MODE == ROW_GS_RES || MODE == ROW_GS_NORM) ? (LONG ? 4 : 6)
                                                                               : (MODE == ROW_GS || MODE == ROW_JACOBI) ? 7 : 8)
 void rows_pattern_kernel(KArgs<V> a, int blk0) {
@@ -742,7 +743,7 @@ void rows_pattern_kernel(KArgs<V> a, int blk0) {
     RowPre<V> pre;
     int code = 0;
     // the dictionary with the codes, not after them
-    const V *ell = lo[2] ? a.vell + (lo[2] - 1) + int(threadIdx.x) : nullptr;      // offset patterns, values in the ELL array
+    const V *ell = (ELL && lo[2]) ? a.vell + (lo[2] - 1) + int(threadIdx.x) : nullptr;   // offset patterns, values in the ELL array
     const int didx0 = pidx[min(lane, cnt - 1)];
     const int dbeg = pbeg[min(lane, npat)];
     V dval0 = V(0);
@@ -795,11 +796,17 @@ int launch_flags() {
 
 template <int MODE, typename V>
 void launch_mode(const DevCsrT<V> &A, int64_t blk0, int64_t nblk, const KArgs<V> &k, bool all_pattern,
-                 bool long_rows, hipStream_t s) {
+                 bool long_rows, bool ell, hipStream_t s) {
     if (nblk <= 0) return;
     if (all_pattern) {
-        if (long_rows) hipLaunchKernelGGL((rows_pattern_kernel<MODE, true, V>), dim3((unsigned)nblk), dim3(NT), 0, s, k, (int)blk0);
-        else hipLaunchKernelGGL((rows_pattern_kernel<MODE, false, V>), dim3((unsigned)nblk), dim3(NT), 0, s, k, (int)blk0);
+        const dim3 g((unsigned)nblk), b(NT);
+        if (ell) {
+            if (long_rows) hipLaunchKernelGGL((rows_pattern_kernel<MODE, true, true, V>), g, b, 0, s, k, (int)blk0);
+            else hipLaunchKernelGGL((rows_pattern_kernel<MODE, false, true, V>), g, b, 0, s, k, (int)blk0);
+        } else {
+            if (long_rows) hipLaunchKernelGGL((rows_pattern_kernel<MODE, true, false, V>), g, b, 0, s, k, (int)blk0);
+            else hipLaunchKernelGGL((rows_pattern_kernel<MODE, false, false, V>), g, b, 0, s, k, (int)blk0);
+        }
         OMG_HIP(hipGetLastError());
         return;
     }
@@ -879,27 +886,33 @@ void launch_rows_uniform(const DevCsrT<V> &A, int mode, int set_begin, int set_e
     const KArgs<V> k = make_kargs(A, args);
     const int64_t blk0 = A.set_blk[set_begin];
     const int64_t nblk = A.set_blk[set_end] - blk0;
+    bool long_rows = false;                    // any row of the range summed as four chains (common.h ASSOC_LEN)
+    bool ell = false;                          // any block of the range keeps its values in the ELL array
+    for (int q = set_begin; q < set_end; ++q) {
+        long_rows = long_rows || A.set_maxlen.empty() || A.set_maxlen[q] > ASSOC_LEN;
+        ell = ell || (!A.set_ell.empty() && A.set_ell[q]);
+    }
     if (mode == ROW_SCATTER) {                 // exists in the pattern kernel only (common.h)
         OMG_REQUIRE(pattern, "ROW_SCATTER needs an operator whose blocks are all row-pattern coded");
         if (nblk > 0) {
-            hipLaunchKernelGGL((rows_pattern_kernel<ROW_SCATTER, false, V>), dim3((unsigned)nblk), dim3(NT), 0, s, k, (int)blk0);
+            const dim3 g((unsigned)nblk), b(NT);
+            if (ell) hipLaunchKernelGGL((rows_pattern_kernel<ROW_SCATTER, false, true, V>), g, b, 0, s, k, (int)blk0);
+            else hipLaunchKernelGGL((rows_pattern_kernel<ROW_SCATTER, false, false, V>), g, b, 0, s, k, (int)blk0);
             OMG_HIP(hipGetLastError());
         }
         return;
     }
     const bool ap = pattern;
-    bool long_rows = false;                    // any row of the range summed as four chains (common.h ASSOC_LEN)
-    for (int q = set_begin; q < set_end; ++q) long_rows = long_rows || A.set_maxlen.empty() || A.set_maxlen[q] > ASSOC_LEN;
     switch (mode) {
-        case ROW_GS_RES: launch_mode<ROW_GS_RES>(A, blk0, nblk, k, ap, long_rows, s); break;
-        case ROW_GS_NORM: launch_mode<ROW_GS_NORM>(A, blk0, nblk, k, ap, long_rows, s); break;
-        case ROW_SPMV: launch_mode<ROW_SPMV>(A, blk0, nblk, k, ap, long_rows, s); break;
-        case ROW_RESIDUAL: launch_mode<ROW_RESIDUAL>(A, blk0, nblk, k, ap, long_rows, s); break;
-        case ROW_RESNORM: launch_mode<ROW_RESNORM>(A, blk0, nblk, k, ap, long_rows, s); break;
-        case ROW_NORM_ONLY: launch_mode<ROW_NORM_ONLY>(A, blk0, nblk, k, ap, long_rows, s); break;
-        case ROW_GS: launch_mode<ROW_GS>(A, blk0, nblk, k, ap, long_rows, s); break;
-        case ROW_JACOBI: launch_mode<ROW_JACOBI>(A, blk0, nblk, k, ap, long_rows, s); break;
-        case ROW_AXPY: launch_mode<ROW_AXPY>(A, blk0, nblk, k, ap, long_rows, s); break;
+        case ROW_GS_RES: launch_mode<ROW_GS_RES>(A, blk0, nblk, k, ap, long_rows, ell, s); break;
+        case ROW_GS_NORM: launch_mode<ROW_GS_NORM>(A, blk0, nblk, k, ap, long_rows, ell, s); break;
+        case ROW_SPMV: launch_mode<ROW_SPMV>(A, blk0, nblk, k, ap, long_rows, ell, s); break;
+        case ROW_RESIDUAL: launch_mode<ROW_RESIDUAL>(A, blk0, nblk, k, ap, long_rows, ell, s); break;
+        case ROW_RESNORM: launch_mode<ROW_RESNORM>(A, blk0, nblk, k, ap, long_rows, ell, s); break;
+        case ROW_NORM_ONLY: launch_mode<ROW_NORM_ONLY>(A, blk0, nblk, k, ap, long_rows, ell, s); break;
+        case ROW_GS: launch_mode<ROW_GS>(A, blk0, nblk, k, ap, long_rows, ell, s); break;
+        case ROW_JACOBI: launch_mode<ROW_JACOBI>(A, blk0, nblk, k, ap, long_rows, ell, s); break;
+        case ROW_AXPY: launch_mode<ROW_AXPY>(A, blk0, nblk, k, ap, long_rows, ell, s); break;
         default: throw Error(OMG_ERR_INVALID, "launch_rows: unknown mode");
     }
 }

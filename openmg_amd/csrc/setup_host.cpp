@@ -427,6 +427,7 @@ HostFormat<V> encode_with(const HostCsr &A, const std::vector<int64_t> &sets_in,
     // dictionary fits the lanes of a wave (one row per thread: LPR 1).  Only there may a block
     // keep offset patterns with its values in the ELL array (rows_kernel has no path for it).
     F.set_pattern.assign(sets.size() - 1, 0);
+    F.set_ell.assign(sets.size() - 1, 0);
     if (lanes == 1 && max_rows <= ROWBLK_THREADS)
         for (size_t q = 0; q + 1 < sets.size(); ++q) {
             bool all = set_blk[q + 1] > set_blk[q], ell = false;
@@ -436,6 +437,7 @@ HostFormat<V> encode_with(const HostCsr &A, const std::vector<int64_t> &sets_in,
                 all = false;
             }
             F.set_pattern[q] = all ? (ell ? 2 : 1) : 0;
+            F.set_ell[q] = (all && ell) ? 1 : 0;
         }
     if (max_nnz > ROWBLK_NNZ) {
         // wide partition (encode_csr): usable only if the pattern kernel takes every set
@@ -601,6 +603,7 @@ void DevCsrT<V>::upload(const HostCsr &A, const std::vector<int64_t> &sets_in, h
     set_blk = std::move(F.set_blk);
     set_nnz = std::move(F.set_nnz);
     set_maxlen = std::move(F.set_maxlen);
+    set_ell = std::move(F.set_ell);
     set_pattern = std::move(F.set_pattern);
     rows_cap = F.rows_cap;
     lanes_per_row = F.lanes_per_row;
