@@ -22,8 +22,8 @@ def main():
     dur = collections.defaultdict(list)
     for path in sorted(glob.glob(os.path.join(root, "p*", "**", "*counter_collection.csv"), recursive=True)):
         for r in csv.DictReader(open(path)):
-            m = re.search(r"rows_kernel<(\d+), (true|false), (true|false), (\d+), (\w+)>", r["Kernel_Name"])
-            mp = re.search(r"rows_pattern_kernel<(\d+), (\w+)>", r["Kernel_Name"])
+            m = re.search(r"rows_kernel<(\d+), (true|false), (true|false), (\d+), (?:true|false), (\w+)>", r["Kernel_Name"])
+            mp = re.search(r"rows_pattern_kernel<(\d+), (?:true|false), (?:true|false), (\w+)>", r["Kernel_Name"])
             if not m and not mp:
                 continue
             blocks = int(r["Grid_Size"]) // 256

@@ -15,10 +15,10 @@ MODES = {0: "spmv", 1: "residual", 2: "resnorm", 3: "gs", 4: "jacobi", 5: "axpy"
 
 
 def short(name):
-    m = re.search(r"rows_pattern_kernel<(\d+), (\w+)>", name)
+    m = re.search(r"rows_pattern_kernel<(\d+), (?:true|false), (?:true|false), (\w+)>", name)
     if m:
         return "rows_pattern_kernel<%s, %s>" % (MODES[int(m.group(1))], m.group(2))
-    m = re.search(r"rows_kernel<(\d+), (true|false), (true|false), (\d+), (\w+)>", name)
+    m = re.search(r"rows_kernel<(\d+), (true|false), (true|false), (\d+), (?:true|false), (\w+)>", name)
     if m:
         return "rows_kernel<%s, nt=%s, %s, %s>" % (MODES[int(m.group(1))], m.group(2)[0],
                                                    "short" if m.group(3) == "true" else "lpr" + m.group(4), m.group(5))
