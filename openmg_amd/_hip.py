@@ -275,8 +275,8 @@ class Hierarchy:
     # -- resident ------------------------------------------------------------------------
     def resident_load(self, b, x0=None):
         b = vec(b, self.sizes[0])
-        x0p = None if x0 is None else vec(x0, self.sizes[0]).ctypes.data
-        check(lib().omg_resident_load(self._h, b.ctypes.data, x0p))
+        x0 = None if x0 is None else vec(x0, self.sizes[0])        # kept alive until the call returns
+        check(lib().omg_resident_load(self._h, b.ctypes.data, None if x0 is None else x0.ctypes.data))
 
     def resident_cycle(self, pre, post, want_norm=True):
         if want_norm:
