@@ -14,7 +14,7 @@ import sys
 def load(path):
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(path)):
-        m = re.search(r"rows_kernel<(\d+), (true|false), (true|false), \d+>", r["Kernel_Name"])
+        m = re.search(r"rows_(?:pattern_)?kernel<(\d+), ", r["Kernel_Name"])
         if not m:
             continue
         key = (int(m.group(1)), int(r["Grid_Size"]) // 256)
