@@ -16,7 +16,11 @@
  *   - vectors are float64;
  *   - every function returns OMG_OK (0) or an OMG_ERR_* code; omg_last_error() gives text;
  *   - there is NO CPU fallback: without a usable GPU every compute call returns
- *     OMG_ERR_NO_DEVICE.
+ *     OMG_ERR_NO_DEVICE;
+ *   - what the device keeps of an operator is a LOSSLESS recoding of the caller's CSR (row
+ *     patterns, dictionaries, block-transposed values; csrc/common.h):
+ *     a storage choice per row block that never changes a result bit
+ *     (omg_hierarchy_format_info reports it, env OMG_COMPRESS=0 turns it off).
  */
 #ifndef OPENMG_HIP_H
 #define OPENMG_HIP_H
