@@ -253,7 +253,7 @@ def main():
                 "format_frac": round(fmt_bytes / avg_s / 1e9 / HBM_PEAK_GBS, 4),
                 "device_format": {"row_pattern_rows": fmt_cov["pattern_rows"], "rows": fmt_cov["rows"],
                                   "column_coded_nnz": fmt_cov["coldict_nnz"], "value_coded_nnz": fmt_cov["valdict_nnz"],
-                                  "nnz": fmt_cov["nnz"], "OMG_COMPRESS": os.environ.get("OMG_COMPRESS", "7 (default)")},
+                                  "nnz": fmt_cov["nnz"], "OMG_COMPRESS": os.environ.get("OMG_COMPRESS", "15 (default)")},
                 "rows_covered": rows_c, "nnz_covered": nnz_c, "fused_last_set": h.level_fused(0),
                 "level0_kernels": kernels}
 
@@ -261,13 +261,17 @@ def main():
     # north-star target (">= 50 % of the HBM roofline on the fine-grid SpMV") is about.  Second
     # hierarchy, untimed region, same hipEvent bracketing of the residual launch.
     plain = None
-    if not args.no_plain and os.environ.get("OMG_COMPRESS", "7") != "0":
+    if not args.no_plain and os.environ.get("OMG_COMPRESS", "15") != "0":
         h.close()
+        keep = os.environ.get("OMG_COMPRESS")
         os.environ["OMG_COMPRESS"] = "0"
         try:
             h2, b2, _ = build_problem(args.size, args.grids, args.smoother, "float64" if w == 8 else "float32")
         finally:
-            del os.environ["OMG_COMPRESS"]
+            if keep is None:
+                del os.environ["OMG_COMPRESS"]
+            else:
+                os.environ["OMG_COMPRESS"] = keep
         h2.resident_load(b2)
         for _ in range(args.warmup):
             h2.resident_cycle(pre, post, want_norm=False)
