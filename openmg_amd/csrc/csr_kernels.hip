@@ -1,17 +1,27 @@
 // CSR row kernels for gfx950 (MI355X).  Bandwidth-bound sparse path: no MFMA.
 //
-// One workgroup (256 threads = 4 wave64) owns one ROW BLOCK: a run of at most 256
-// consecutive rows holding at most ROWBLK_NNZ stored entries (partition made at setup,
-// setup_host.cpp:make_row_blocks).  Two phases:
-//   1. the block's slice of `indices` and `data` is streamed from HBM into LDS with
-//      16-byte-per-lane loads (1 KiB per wave instruction, fully coalesced, each byte of
-//      the matrix is fetched exactly once);
-//   2. one thread per row walks its entries in LDS IN STORED ORDER (the summation order
-//      of openmg/solvers.py:63-65 and of SciPy's csr_matvec), gathering x from global
-//      memory — for stencil-like matrices consecutive lanes touch consecutive x, so
+// The operators sit in HBM in the block-coded form of common.h (plain CSR, per-entry
+// dictionaries, row patterns, offset patterns + ELL values — a lossless recoding chosen per row
+// block at upload).  Two kernels walk it; both take a row's entries in STORED order (the
+// summation order of openmg/solvers.py:63-65 and of SciPy's csr_matvec; rows longer than
+// ASSOC_LEN as four interleaved chains, common.h), so every coding and either kernel give the
+// same bits.
+//
+// rows_kernel — any block.  One workgroup (256 threads = 4 wave64) owns one ROW BLOCK: a run of
+// at most 256 consecutive rows holding at most ROWBLK_NNZ stored entries (partition made at
+// setup, setup_host.cpp:make_row_blocks).  Two phases:
+//   1. an LDS image of the block's (column, value) pairs is built: plain sides are streamed from
+//      HBM with 16-byte-per-lane loads (1 KiB per wave instruction, fully coalesced, each byte
+//      of the matrix fetched exactly once), coded sides are expanded through the block's
+//      dictionary;
+//   2. one thread per row (or four lanes per row) walks its entries in LDS, gathering x from
+//      global memory — for stencil-like matrices consecutive lanes touch consecutive x, so
 //      each gather is itself a coalesced 512-byte access served by L1/L2.
+// rows_pattern_kernel — launches whose blocks are all row-pattern coded with wave-sized
+// dictionaries: no LDS image, one thread per row, the pattern's offsets and values as
+// wave-uniform operands (see the comment at the kernel).
 // The epilogue is selected by MODE (SpMV, residual, residual norm, Gauss-Seidel set
-// sweep, weighted Jacobi, y += A x, and the fused last-set sweeps).
+// sweep, weighted Jacobi, y += A x, the fused last-set sweeps, and the transpose scatter).
 //
 // Everything is a template on the value type V (double: the reference's precision; float:
 // BASELINE configs[4]); indices are int32; norms are accumulated in double for either V.
