@@ -747,3 +747,45 @@ def test_prolongation_as_a_scatter_over_restriction_rows_is_bit_identical(monkey
         assert not h.level_flags(0)["scatter_prolong"]
         e, x = rng.random(Rl.shape[0]), rng.random(n)
         np.testing.assert_allclose(h.prolong_add(0, e, x), x + Rl.T @ e, **OP)
+
+
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+def test_long_rows_pattern_kernel_matches_four_lanes_per_row(monkeypatch, dtype):
+    """27-point variable-coefficient operator with long grid lines: by default every set runs the
+    LDS-free pattern kernel with 256-row blocks, offset patterns and ELL values (one thread per
+    row, four accumulators); with OMG_COMPRESS=0 rows_kernel gives each row four lanes.  The
+    association of a row's sum is fixed by its length (csrc/common.h ASSOC_LEN), so both give
+    the same bits — sweeps, fused last colour, residual, norm."""
+    shape = (4, 6, 256)
+    A0 = operators.stencil27_variable(shape)
+    n = A0.shape[0]
+    pairs = np.arange(n) // 2
+    R = sp.csr_matrix((np.full(n, 0.5), (pairs, np.arange(n))), shape=(n // 2, n))
+    # keep the coarse level small enough for the dense inverse: aggregate 8 more times
+    Rs = [R]
+    while Rs[-1].shape[0] > 1500:
+        m = Rs[-1].shape[0]
+        Rs.append(sp.csr_matrix((np.full(m, 0.5), (np.arange(m) // 2, np.arange(m))), shape=((m + 1) // 2, m)))
+    A = [A0]
+    for Rl in Rs:
+        A.append(sp.csr_matrix(Rl @ A[-1] @ Rl.T))
+    rng = np.random.default_rng(55)
+    b, x0 = A0 @ rng.random(n), rng.random(n)
+    out = {}
+    for mode in ("0", "15"):
+        monkeypatch.setenv("OMG_COMPRESS", mode)
+        with _hip.Hierarchy(A, Rs, smoother="colour", dtype=dtype) as h:
+            info = h.format_info(0)
+            r, nr = h.residual(0, b, x0, want_norm=True)
+            h.resident_load(b, x0)
+            norms = [h.resident_cycle(2, 2) for _ in range(2)]
+            out[mode] = (r, h.resident_fetch(), norms, nr, info, h.level_sets(0))
+    assert out["15"][5] == out["0"][5] >= 8
+    wide, plain = out["15"][4], out["0"][4]
+    assert wide["pattern_rows"] == wide["rows"] and wide["blocks"] * 4 <= plain["blocks"] + 32    # 256-row blocks vs 64-row
+    assert np.array_equal(out["15"][0], out["0"][0])
+    assert np.array_equal(out["15"][1], out["0"][1])
+    np.testing.assert_allclose(out["15"][2], out["0"][2], rtol=1e-13)
+    np.testing.assert_allclose(out["15"][3], out["0"][3], rtol=1e-13)
+    if dtype == "float64":
+        np.testing.assert_allclose(out["0"][0], b - A0 @ x0, rtol=0, atol=1e-12 * (abs(A0).sum(axis=1).max() + np.abs(b).max()))
