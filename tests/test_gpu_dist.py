@@ -291,3 +291,19 @@ def test_split_scatter_prolongation_with_overlap(monkeypatch):
         group.close()
     assert np.array_equal(xd, x1)
     np.testing.assert_allclose(nd, n1, rtol=1e-13)
+
+
+def test_27_point_slabs_with_paired_sets_overlap_and_tail(monkeypatch):
+    """All the schedule options at once on the 8-colour operator: (boundary, interior) set pairs
+    (16 sets), exchanges on the second stream, a replicated fp32 tail below the first level."""
+    monkeypatch.setenv("OMG_OVERLAP_MIN_ROWS", "0")
+    monkeypatch.setenv("OMG_FORCE_OVERLAP", "1")
+    shape, grids = (16, 16, 16), 3
+    A0 = operators.stencil27_variable(shape)
+    b = A0 @ np.random.default_rng(33).random(A0.shape[0])
+    for dtype in ("float64", "float32"):
+        x1, n1, _ = _single(A0, shape, grids, b, 2, dtype)
+        xd, nd = _loopback(lambda lo, hi: dist.stencil27_variable_rows(shape, lo, hi), shape, grids, 2, b, 2, dtype,
+                           colouring="octant", n_dist=2)
+        assert np.array_equal(xd, x1), dtype
+        np.testing.assert_allclose(nd, n1, rtol=1e-13 if dtype == "float64" else 1e-6)
