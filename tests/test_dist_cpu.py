@@ -84,7 +84,7 @@ def _free_port():
     return port
 
 
-def _worker(rank, world, port, shape, grids, smoother, out_dir):
+def _worker(rank, world, port, shape, grids, smoother, out_dir, stencil="7pt"):
     import torch.distributed as td
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -120,9 +120,10 @@ def _worker(rank, world, port, shape, grids, smoother, out_dir):
 
         part = dist.SlabPartition(shape, world, grids)
         lo, hi = part.rows(0, rank)
-        A_rows = dist.stencil_rows(shape, lo, hi)
+        A_rows = dist.stencil_rows(shape, lo, hi) if stencil == "7pt" else dist.stencil27_variable_rows(shape, lo, hi)
         levels, coarse, counts = dist.build_this_rank(part, rank, A_rows, all_gather, smoother=smoother,
-                                                      spgemm=scipy_spgemm)
+                                                      spgemm=scipy_spgemm,
+                                                      colouring="parity" if stencil == "7pt" else "octant")
         u = np.random.default_rng(12345).random(part.n_rows(0))
         b_loc = A_rows @ u
         x_loc, norms = CpuRank(rank, levels, coarse, counts, smoother, Comm(), omega=0.8).run(b_loc, 3, 1, 1)
@@ -145,6 +146,28 @@ def test_two_process_gloo_cycle_matches_single_process_oracle(tmp_path, smoother
     p = {"preIterations": 1, "postIterations": 1, "coarsestLevel": len(R)}
     x = None
     norms = []
+    for _ in range(3):
+        x, info = orc.mg_cycle(A, b, 0, R, p, initial=x, smoother=sm)
+        norms.append(info["norm"])
+    for rank in range(world):
+        d = np.load(os.path.join(str(tmp_path), "rank%d.npz" % rank))
+        np.testing.assert_allclose(d["x"], x[int(d["lo"]):int(d["hi"])], rtol=1e-11, atol=1e-13)
+        np.testing.assert_allclose(d["norms"], norms, rtol=1e-11)
+
+
+def test_two_process_gloo_cycle_27_point_eight_colours(tmp_path):
+    """The 8-colour schedule (one message per neighbour and colour) over real message passing."""
+    import torch.multiprocessing as mp
+    from openmg_amd import operators
+    shape, grids, world = (8, 8, 8), 2, 2
+    mp.spawn(_worker, args=(world, _free_port(), shape, grids, "colour", str(tmp_path), "27var"), nprocs=world, join=True)
+    A0 = operators.stencil27_variable(shape)
+    b = A0 @ np.random.default_rng(12345).random(A0.shape[0])
+    R = orc.restriction_list(shape, grids - 2, 1)
+    A = orc.coefficient_list(A0, R)
+    sm = orc.make_smoother("colour", A)
+    p = {"preIterations": 1, "postIterations": 1, "coarsestLevel": len(R)}
+    x, norms = None, []
     for _ in range(3):
         x, info = orc.mg_cycle(A, b, 0, R, p, initial=x, smoother=sm)
         norms.append(info["norm"])
