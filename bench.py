@@ -8,20 +8,30 @@ correct, post-smooth, residual norm — openmg/__init__.py:151-236) on a synthet
 Poisson problem with b, x and the whole hierarchy already resident in HBM.  The workload at
 N = 1 is BASELINE.json configs[2]: 256^3, 5 grids, red-black Gauss-Seidel, fp64, V(1,1).
 
-Prints ONE JSON line (see README of the task): metric V-cycles/s, plus
-  roofline      the fine-grid residual kernel r = b - A x (the SpMV-class kernel the metric
-                names): algorithmic bytes / average launch time measured with hipEvents on
-                the kernel's own stream inside the timed region, against 8 TB/s;
+N > 1: started by torch.distributed.run (RANK / WORLD_SIZE in the environment) every process is
+one rank; started bare (`python bench.py --gpus N`) the parent launches the N rank processes
+itself (openmg_amd/launch.py) before it touches the GPU, relays rank 0's JSON line and returns
+the worst child exit code.
+
+Prints ONE JSON line: metric V-cycles/s (median of --repeats timed regions of K cycles), plus
+  roofline      the fine-grid residual kernel r = b - A x (the SpMV-class kernel of the metric):
+                bytes the launch has to move, with the operator in the format it has in HBM,
+                / average launch time measured with hipEvents on the kernel's own stream inside
+                the timed regions, against 8 TB/s (frac <= 1 by construction); the rate in
+                SURVEY 8(d)'s plain-CSR bytes is reported beside it as csr_equiv_GBps;
+  csr_path      the same problem with every operator held as plain int32 CSR (OMG_COMPRESS=0),
+                timed with the same loop: V-cycles/s, residual and fine-grid SpMV launches against
+                SURVEY 8(d)'s CSR byte counts;
   cpu_baseline  the CPU oracle's V-cycle timed on this box's host (one core: the oracle's C
                 sweeps and SciPy's CSR kernels are single-threaded) on a bounded sample.
 """
 import argparse
+import hashlib
 import json
 import os
+import statistics
 import sys
 import time
-
-import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
@@ -35,8 +45,15 @@ def spmv_bytes(n, nnz, w=8):
     return nnz * (w + 4) + 4 * (n + 1) + 2 * w * n
 
 
-def residual_bytes(n, nnz, w=8):
-    return spmv_bytes(n, nnz, w) + w * n
+def kernel_source_hash():
+    """Identity of the kernel sources a PMC profile was taken with (profiles/*.json carry it)."""
+    h = hashlib.sha256()
+    src = os.path.join(ROOT, "openmg_amd", "csrc")
+    for name in sorted(os.listdir(src)):
+        if name.endswith((".hip", ".h", ".cpp")):
+            h.update(name.encode())
+            h.update(open(os.path.join(src, name), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def kernel_name(fmt, mode):
@@ -47,7 +64,7 @@ def kernel_name(fmt, mode):
 
 
 def build_problem(size, grids, smoother, dtype="float64"):
-    import openmg_amd
+    import numpy as np
     from openmg_amd import _hip, operators
     shape = (size, size, size)
     A0 = operators.stencil_poisson(shape)
@@ -65,9 +82,10 @@ def cpu_baseline(size, grids, cycles):
     """The CPU oracle (oracle/, a 'port' of the reference's algorithm: the reference itself
     is Python 2 and cannot run here) on a bounded sample: `size`^3, same grids, V(1,1)
     red-black.  Returned in 256^3-equivalent V-cycles/s (work per cycle scales with n)."""
+    import numpy as np
     from oracle import mg_oracle as orc
-    shape = (size, size, size)
     from openmg_amd import operators
+    shape = (size, size, size)
     A0 = operators.stencil_poisson(shape)                       # input generator only
     b = A0 @ np.random.default_rng(12345).random(A0.shape[0])
     R = orc.restriction_list(shape, grids - 2, 8)
@@ -92,11 +110,36 @@ def cpu_baseline(size, grids, cycles):
     return cycles / dt, dt, spmv_bytes(A0.shape[0], A0.nnz) / spmv_s / 1e9
 
 
+def timed_regions(h, sync, steps, warmup, repeats, pre, post, classes=("residual",)):
+    """`warmup` untimed cycles, then `repeats` timed regions of EXACTLY `steps` cycles each,
+    every one bracketed by a device synchronisation on both sides.  Inside the regions the
+    launches of `classes` are bracketed by hipEvents on the hierarchy's own stream (one pair per
+    cycle for 'residual': ~1 % of the cycle).  Returns (elapsed seconds per region, profile)."""
+    for _ in range(warmup):
+        h.resident_cycle(pre, post, want_norm=False)
+    sync()
+    if classes:
+        h.profile_enable(list(classes))
+    times = []
+    for _ in range(repeats):
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            h.resident_cycle(pre, post, want_norm=False)
+        sync()
+        times.append(time.perf_counter() - t0)
+    prof = h.profile_read() if classes else None
+    h.profile_enable(False)
+    return times, prof
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--repeats", type=int, default=5,
+                    help="timed regions of --steps cycles each; value = steps / median region time (BASELINE.md §3)")
     ap.add_argument("--size", type=int, default=256, help="grid extent per axis (default: BASELINE config 3)")
     ap.add_argument("--grids", type=int, default=5)
     ap.add_argument("--smoother", default="colour")
@@ -106,9 +149,9 @@ def main():
                     help="multi-GPU leg only: 27var = BASELINE configs[4]'s 27-point variable-coefficient operator")
     ap.add_argument("--graph", type=int, default=0, help="replay the cycle from a hipGraph")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
-    ap.add_argument("--no-plain", action="store_true", help="skip the plain-CSR (OMG_COMPRESS=0) comparison leg")
+    ap.add_argument("--no-plain", action="store_true", help="skip the plain-CSR (OMG_COMPRESS=0) leg")
     ap.add_argument("--dist", type=int, default=0, help="force the multi-GPU code path even with one rank (debug)")
-    ap.add_argument("--watchdog", type=int, default=900, help="multi-GPU: abort the rank after this many seconds")
+    ap.add_argument("--watchdog", type=int, default=900, help="multi-GPU: abort after this many seconds")
     ap.add_argument("--overlap", type=int, default=1,
                     help="multi-GPU: relax boundary rows first and exchange them while the interior rows run")
     ap.add_argument("--dist-grids", type=int, default=4,
@@ -117,6 +160,12 @@ def main():
     ap.add_argument("--cpu-cycles", type=int, default=16)
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # bare `python bench.py --gpus N`: become the launcher.  Nothing GPU-related has been
+        # imported yet (launch.py imports neither torch nor the HIP library).
+        from openmg_amd import launch
+        return launch.spawn_ranks(args.gpus, [sys.executable, os.path.abspath(__file__)] + sys.argv[1:],
+                                  timeout_s=args.watchdog + 60)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 or world > 1 or args.dist:
         from openmg_amd import dist_bench
@@ -126,36 +175,30 @@ def main():
     from openmg_amd import _hip
     _hip.require_gpu()
     torch.cuda.set_device(0)
+    repeats = max(1, args.repeats)
 
     t_setup = time.perf_counter()
     w = 8 if args.dtype == "f64" else 4
-    h, b, meta = build_problem(args.size, args.grids, args.smoother, "float64" if w == 8 else "float32")
+    np_dtype = "float64" if w == 8 else "float32"
+    h, b, meta = build_problem(args.size, args.grids, args.smoother, np_dtype)
     h.resident_load(b)
     setup_s = time.perf_counter() - t_setup
     pre = post = 1
     if args.graph:
         h.use_graph(True)
-    for _ in range(args.warmup):
-        h.resident_cycle(pre, post, want_norm=False)
-    h.sync()
-    torch.cuda.synchronize()
 
-    # Timed region.  Only the roofline kernel (fine-grid residual, one launch per cycle) is
-    # bracketed by hipEvents here: every event pair opens a ~10 us gap in the stream, so
-    # timing all eight level-0 launches would cost the cycle ~4 %.  (A hipGraph replay cannot
-    # carry the events; with --graph 1 the kernel is timed in the second region below.)
+    def sync():
+        h.sync()
+        torch.cuda.synchronize()
+
+    # Timed regions.  Only the roofline kernel (fine-grid residual, one launch per cycle) is
+    # bracketed by hipEvents there: every event pair opens a gap in the stream, so timing all
+    # eight level-0 launches would cost the cycle ~4 %.  (A hipGraph replay cannot carry the
+    # events; with --graph 1 the kernel is timed in the second region below.)
     in_region = not args.graph
-    if in_region:
-        h.profile_enable(["residual"])
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        h.resident_cycle(pre, post, want_norm=False)
-    h.sync()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    timed = h.profile_read() if in_region else None
-    h.profile_enable(False)
+    times, timed = timed_regions(h, sync, args.steps, args.warmup, repeats, pre, post,
+                                 ("residual",) if in_region else ())
+    elapsed = statistics.median(times)
     norm = h.resident_cycle(pre, post, want_norm=True)          # untimed: read the norm back once
 
     # Second, untimed region: every level-0 kernel class, for the per-kernel table.
@@ -170,16 +213,16 @@ def main():
     # The metric's "fine-grid SpMV GB/s": plain y = A x over the whole level-0 operator as it
     # sits in HBM for the cycle, 20 back-to-back launches in one hipEvent bracket (untimed region).
     spmv_ms = h.spmv_time(20)
-    spmv_b = spmv_bytes(meta["n"], meta["nnz"], w)
+    n, nnz = meta["n"], meta["nnz"]
+    spmv_csr = spmv_bytes(n, nnz, w)
     fmt_all = h.format_info(0, "A")
-    spmv_fmt = fmt_all["format_bytes"] + 2 * w * meta["n"]          # operator in its device format + x read + y written
+    spmv_fmt = fmt_all["format_bytes"] + 2 * w * n              # operator in its device format + x read + y written
     fine_spmv = {"kernel": "y = A x, all rows of the fine grid (%s)" % kernel_name(fmt_all, "ROW_SPMV"),
                  "avg_launch_us": round(spmv_ms * 1e3, 2),
-                 "algorithmic_bytes": spmv_b, "GBps": round(spmv_b / spmv_ms / 1e6, 1),
-                 "frac_of_peak": round(spmv_b / spmv_ms / 1e6 / HBM_PEAK_GBS, 4),
-                 "format_bytes": spmv_fmt, "format_GBps": round(spmv_fmt / spmv_ms / 1e6, 1)}
+                 "bytes_per_launch": spmv_fmt, "achieved": round(spmv_fmt / spmv_ms / 1e6, 1),
+                 "frac": round(spmv_fmt / spmv_ms / 1e6 / HBM_PEAK_GBS, 4),
+                 "csr_equiv_bytes": spmv_csr, "csr_equiv_GBps": round(spmv_csr / spmv_ms / 1e6, 1)}
 
-    n, nnz = meta["n"], meta["nnz"]
     launches, ms = timed["residual"]
     avg_s = (ms / launches) * 1e-3
     # Rows the fine-grid residual launch covers.  With a Gauss-Seidel ordering the last set's
@@ -189,116 +232,110 @@ def main():
     covered = range(n_sets - 1) if h.level_fused(0) else range(n_sets)
     rows_c = sum(h.set_info(0, s)[0] for s in covered)
     nnz_c = sum(h.set_info(0, s)[1] for s in covered)
-    # algorithmic bytes (w = value width): entries w+4 B, row pointers 4 B, b and r w B per
-    # covered row, and the whole of x once (the covered rows together reference every unknown)
-    res_bytes = (w + 4) * nnz_c + 4 * (rows_c + 1) + 2 * w * rows_c + w * n
-    achieved = res_bytes / avg_s / 1e9
-    # ... and the bytes the launch has to move with the operator in its DEVICE format (lossless
-    # block-dictionary recoding of the CSR, DESIGN.md "Device format"): same vectors, fewer
-    # operator bytes.  `achieved` above is the CSR-equivalent rate SURVEY 8(d) defines; the
-    # rate at which HBM is actually driven is format_bytes (or the PMC traffic) over the time.
+    # SURVEY 8(d)'s bytes of that launch on plain CSR (w = value width): entries w+4 B, row
+    # pointers 4 B, b and r w B per covered row, the whole of x once
+    res_csr = (w + 4) * nnz_c + 4 * (rows_c + 1) + 2 * w * rows_c + w * n
+    # ... and the bytes the launch HAS TO MOVE with the operator in its device format (lossless
+    # block recoding): same vectors, the operator as it is stored.  The roofline
+    # fraction is taken on these: a launch cannot be credited with bytes it does not read.
     fmt_sets = [h.format_info(0, "A", s) for s in covered]
-    fmt_bytes = sum(f["format_bytes"] for f in fmt_sets) + 2 * w * rows_c + w * n
+    res_fmt = sum(f["format_bytes"] for f in fmt_sets) + 2 * w * rows_c + w * n
     fmt_cov = {k: sum(f[k] for f in fmt_sets) for k in ("rows", "nnz", "blocks", "pattern_rows", "coldict_nnz", "valdict_nnz")}
-    # HBM traffic of that launch from the PMC counters cannot be collected from inside this
-    # process; it is taken from the committed rocprofv3 pass of the SAME kernel and problem
-    # (profiles/, method recorded there) and only when the byte accounting matches exactly.
+    # HBM traffic from the PMC counters cannot be collected from inside this process.  It is taken
+    # from a committed rocprofv3 pass of the same launch ONLY when that pass was made with the
+    # kernel sources of this build (hash recorded in the profile) on the same problem.
     traffic, traffic_src = None, None
     try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_residual.json")))
-        if int(pmc["algorithmic_bytes"]) == int(res_bytes) and int(pmc.get("format_bytes", -1)) == int(fmt_bytes) and w == 8:
-            traffic, traffic_src = pmc["traffic_bytes"], pmc["source"]
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_residual.json")))
+        if pmc.get("kernel_src_sha") == kernel_source_hash() and int(pmc["bytes_per_launch"]) == int(res_fmt) and w == 8:
+            traffic = pmc["traffic_bytes"]
+            traffic_src = "NOT measured in this run: rocprofv3 --pmc passes of the same build, " + pmc["source"]
     except (OSError, KeyError, ValueError):
         pass
-    # Per-class table of the level-0 launches (second region): average time and algorithmic
-    # bytes of ONE launch -> GB/s.  Smoother launches are per set; with the fused last set two
-    # of the 2*n_sets launches per cycle also write the residual (8 B per covered row more).
+    # Per-class table of the level-0 launches (second region): average time, bytes one launch has
+    # to move in the device format, and the CSR-equivalent rate.
     n_c = meta["level_rows"][1] if len(meta["level_rows"]) > 1 else 0
     set_rows = [h.set_info(0, s)[0] for s in range(n_sets)]
     set_nnz = [h.set_info(0, s)[1] for s in range(n_sets)]
-    avg_set_bytes = sum((w + 4) * z + 4 * (r + 1) + 3 * w * r for r, z in zip(set_rows, set_nnz)) / max(n_sets, 1) + w * n / max(n_sets, 1)
-    class_bytes = {
-        "smoother_set_sweep": avg_set_bytes,
-        "residual": res_bytes,
+    class_csr = {
+        "smoother_set_sweep": sum((w + 4) * z + 4 * (r + 1) + 3 * w * r for r, z in zip(set_rows, set_nnz)) / max(n_sets, 1) + w * n / max(n_sets, 1),
+        "residual": res_csr,
         "restrict": (w + 4) * n + 4 * (n_c + 1) + w * n + 2 * w * n_c,    # R entries, indptr, r read, b_c + cleared x_c written
         "prolong_add": (w + 4) * n + 4 * (n + 1) + w * n_c + 2 * w * n,   # P entries, indptr, e read, x read + written
-        "residual_norm": res_bytes - w * rows_c,                          # as the residual launch, nothing stored
+        "residual_norm": res_csr - w * rows_c,                            # as the residual launch, nothing stored
     }
-    # the same launches with the operators in their device format
     fA = [h.format_info(0, "A", s) for s in range(n_sets)]
     fR, fP = (h.format_info(0, "R"), h.format_info(0, "P")) if n_c else ({"format_bytes": 0}, {"format_bytes": 0})
     scatter = bool(n_c) and h.level_flags(0)["scatter_prolong"]
     class_fmt = {
         "smoother_set_sweep": sum(f["format_bytes"] + 3 * w * f["rows"] for f in fA) / max(n_sets, 1) + w * n / max(n_sets, 1),
-        "residual": fmt_bytes,
+        "residual": res_fmt,
         "restrict": fR["format_bytes"] + w * n + 2 * w * n_c,
         # prolongation: a pass over P = R^T, or (aggregation R, row-pattern coded) a scatter over R's rows
         "prolong_add": (fR["format_bytes"] if scatter else fP["format_bytes"]) + w * n_c + 2 * w * n,
-        "residual_norm": fmt_bytes - w * rows_c,
+        "residual_norm": res_fmt - w * rows_c,
     }
     kernels = {}
     for name, (cnt, tot) in prof.items():
         if cnt:
             us = 1e3 * tot / cnt
             kernels[name] = {"launches_per_cycle": cnt / args.steps, "avg_us": round(us, 2),
-                             "algorithmic_bytes": int(class_bytes[name]),
-                             "GBps": round(class_bytes[name] / us / 1e3, 1),
-                             "format_bytes": int(class_fmt[name]),
-                             "format_GBps": round(class_fmt[name] / us / 1e3, 1)}
+                             "bytes_per_launch": int(class_fmt[name]),
+                             "achieved": round(class_fmt[name] / us / 1e3, 1),
+                             "frac": round(class_fmt[name] / us / 1e3 / HBM_PEAK_GBS, 4),
+                             "csr_equiv_GBps": round(class_csr[name] / us / 1e3, 1)}
+    achieved = res_fmt / avg_s / 1e9
     roofline = {"bound": "hbm", "kernel": "fine grid r = b - A x (%s)" % kernel_name(fmt_cov, "ROW_RESIDUAL"),
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
-                "algorithmic_bytes": res_bytes, "avg_launch_us": round(avg_s * 1e6, 2),
-                "format_bytes": fmt_bytes, "format_GBps": round(fmt_bytes / avg_s / 1e9, 1),
-                "format_frac": round(fmt_bytes / avg_s / 1e9 / HBM_PEAK_GBS, 4),
+                "bytes_per_launch": res_fmt,
+                "bytes_definition": "operator bytes as stored in HBM (device format, DESIGN.md §4) + b and r of the covered rows + x once",
+                "avg_launch_us": round(avg_s * 1e6, 2), "launches_timed": launches,
+                "csr_equiv_bytes": res_csr, "csr_equiv_GBps": round(res_csr / avg_s / 1e9, 1),
                 "device_format": {"row_pattern_rows": fmt_cov["pattern_rows"], "rows": fmt_cov["rows"],
                                   "column_coded_nnz": fmt_cov["coldict_nnz"], "value_coded_nnz": fmt_cov["valdict_nnz"],
                                   "nnz": fmt_cov["nnz"], "OMG_COMPRESS": os.environ.get("OMG_COMPRESS", "15 (default)")},
                 "rows_covered": rows_c, "nnz_covered": nnz_c, "fused_last_set": h.level_fused(0),
                 "level0_kernels": kernels}
 
-    # The same launch with the operator as PLAIN int32 CSR (OMG_COMPRESS=0): the figure the
-    # north-star target (">= 50 % of the HBM roofline on the fine-grid SpMV") is about.  Second
-    # hierarchy, untimed region, same hipEvent bracketing of the residual launch.
-    plain = None
+    # The same problem with every operator as PLAIN int32 CSR (OMG_COMPRESS=0) — what the north
+    # star's "CSR SpMV ... >= 50 % of the HBM roofline on the fine-grid SpMV" describes — timed
+    # with the same loop (same warm-up, steps, repeats, event bracketing).
+    csr_path = None
     if not args.no_plain and os.environ.get("OMG_COMPRESS", "15") != "0":
         h.close()
         keep = os.environ.get("OMG_COMPRESS")
         os.environ["OMG_COMPRESS"] = "0"
         try:
-            h2, b2, _ = build_problem(args.size, args.grids, args.smoother, "float64" if w == 8 else "float32")
+            h2, b2, _ = build_problem(args.size, args.grids, args.smoother, np_dtype)
         finally:
             if keep is None:
                 del os.environ["OMG_COMPRESS"]
             else:
                 os.environ["OMG_COMPRESS"] = keep
         h2.resident_load(b2)
-        for _ in range(args.warmup):
-            h2.resident_cycle(pre, post, want_norm=False)
-        h2.profile_enable(["residual"])
-        t1 = time.perf_counter()
-        for _ in range(args.steps):
-            h2.resident_cycle(pre, post, want_norm=False)
-        h2.sync()
-        plain_elapsed = time.perf_counter() - t1
-        pl, pms = h2.profile_read()["residual"]
-        h2.profile_enable(False)
+
+        def sync2():
+            h2.sync()
+            torch.cuda.synchronize()
+
+        p_times, p_prof = timed_regions(h2, sync2, args.steps, args.warmup, repeats, pre, post, ("residual",))
+        p_elapsed = statistics.median(p_times)
+        pl, pms = p_prof["residual"]
         p_spmv_ms = h2.spmv_time(20)
         p_us = 1e3 * pms / pl
-        plain = {"what": "operator held as plain int32 CSR (OMG_COMPRESS=0), same problem, untimed region",
-                 "residual_kernel": "rows_kernel<ROW_RESIDUAL>", "avg_launch_us": round(p_us, 2),
-                 "achieved": round(res_bytes / p_us / 1e3, 1), "frac": round(res_bytes / p_us / 1e3 / HBM_PEAK_GBS, 4),
-                 "fine_grid_spmv_us": round(p_spmv_ms * 1e3, 2), "fine_grid_spmv_GBps": round(spmv_b / p_spmv_ms / 1e6, 1),
-                 "fine_grid_spmv_frac": round(spmv_b / p_spmv_ms / 1e6 / HBM_PEAK_GBS, 4),
-                 "vcycles_per_s": round(args.steps / plain_elapsed, 1)}
+        csr_path = {"what": "same problem and timed loop, every operator held as plain int32 CSR (OMG_COMPRESS=0)",
+                    "vcycles_per_s": round(args.steps / p_elapsed, 3), "ms_per_step": round(1e3 * p_elapsed / args.steps, 4),
+                    "ms_per_step_all": [round(1e3 * t / args.steps, 4) for t in p_times],
+                    "residual": {"kernel": "rows_kernel<ROW_RESIDUAL>", "avg_launch_us": round(p_us, 2),
+                                 "bytes_per_launch": res_csr, "achieved": round(res_csr / p_us / 1e3, 1),
+                                 "frac": round(res_csr / p_us / 1e3 / HBM_PEAK_GBS, 4)},
+                    "fine_grid_spmv": {"kernel": "rows_kernel<ROW_SPMV>", "avg_launch_us": round(p_spmv_ms * 1e3, 2),
+                                       "bytes_per_launch": spmv_csr, "achieved": round(spmv_csr / p_spmv_ms / 1e6, 1),
+                                       "frac": round(spmv_csr / p_spmv_ms / 1e6 / HBM_PEAK_GBS, 4)}}
         h2.close()
-    roofline["plain_csr"] = plain
-    if fmt_bytes < res_bytes:
-        roofline["note"] = ("frac counts SURVEY 8(d)'s CSR bytes; the operator sits in HBM in a lossless row-pattern / "
-                            "dictionary coding (DESIGN.md 'Device format'), so the launch moves format_bytes, HBM is "
-                            "driven at format_frac of peak, and frac may exceed 1.  plain_csr is the same launch on "
-                            "plain int32 CSR.")
 
+    h.close()
     cpu = None
     if not args.no_cpu:
         rate, dt, cpu_spmv = cpu_baseline(args.cpu_size, args.grids, args.cpu_cycles)
@@ -325,20 +362,22 @@ def main():
         "vs_baseline": None,
         "dtype": args.dtype,
         "data": "synthetic",
+        "value_plain_csr": None if csr_path is None else csr_path["vcycles_per_s"],
         "config": {"workload": "3-D 7-point Poisson %d^3, %d-grid V(1,1) cycle, %s Gauss-Seidel, %s, "
-                               "int32 CSR (BASELINE configs[2]%s)" % (args.size, meta["grids"],
-                                                                      "red-black" if args.smoother == "colour" else args.smoother,
-                                                                      "fp64" if w == 8 else "fp32",
-                                                                      "" if w == 8 else " run in fp32: NOT the headline configuration"),
+                               "int32 CSR at the boundary (BASELINE configs[2]%s); `value`: operators in the lossless "
+                               "device format (row patterns), `value_plain_csr`: the same cycle on plain CSR"
+                               % (args.size, meta["grids"], "red-black" if args.smoother == "colour" else args.smoother,
+                                  "fp64" if w == 8 else "fp32", "" if w == 8 else " run in fp32: NOT the headline configuration"),
                    "unknowns": n, "nnz": nnz, "grids": meta["grids"], "pre": pre, "post": post,
                    "smoother": args.smoother, "hipgraph": bool(args.graph),
+                   "repeats": repeats, "ms_per_step_all": [round(1e3 * t / args.steps, 4) for t in times],
                    "final_residual_norm": norm, "setup_s": round(setup_s, 2)},
         "roofline": roofline,
+        "csr_path": csr_path,
         "fine_grid_spmv": fine_spmv,
         "cpu_baseline": cpu,
     }
     print(json.dumps(out))
-    h.close()
     return 0
 
 

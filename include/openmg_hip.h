@@ -275,6 +275,10 @@ int omg_dist_sync(omg_dist *d);
  * every rank connects.  librccl is dlopen'ed on first use.                                */
 int omg_rccl_unique_id(void *out128);
 int omg_dist_connect(omg_dist *d, const void *unique_id128);
+/* Number of ranks of the RCCL communicator this rank is connected to (ncclCommCount); 0 before
+ * omg_dist_connect.  bench.py prints it (config.rccl_ranks) as evidence that the N-GPU run
+ * really is one N-rank communicator.                                                        */
+int omg_dist_rccl_ranks(omg_dist *d, int *count);
 /* owned part of b and of the initial iterate (NULL = zeros), natural local numbering */
 int omg_dist_load(omg_dist *d, const double *b_local, const double *x0_local);
 int omg_dist_fetch(omg_dist *d, double *x_local);

@@ -55,36 +55,63 @@ def _dtype_of(parameters):
 
 # ---- device hierarchy cache for repeated mgCycle calls ---------------------------------------
 # mgCycle receives the A and R lists on every call (openmg/__init__.py:151); uploading
-# them each time would dominate.  The device copy is keyed on the identity of the list
-# members and of their buffers; clear_cache() drops it (do that after editing a matrix in
-# place).
+# them each time would dominate.  A cache entry holds the device hierarchy TOGETHER WITH strong
+# references to the list members it was built from, so that neither their ids nor their buffer
+# addresses can be recycled for other matrices while the entry lives, and the key carries a
+# checksum of the stored arrays, so that a matrix edited in place (or rebuilt into the same
+# buffers) misses.  Small operators are hashed whole; above _HASH_ALL_BYTES per array the
+# checksum covers the head, the tail and a strided sample — call clear_cache() after editing a
+# few entries of such a matrix in place.
 _cache = {}
 _CACHE_SLOTS = 2
+_HASH_ALL_BYTES = 1 << 25
+_HASH_SAMPLES = 1 << 14
+
+try:
+    from xxhash import xxh64_intdigest as _digest
+except ImportError:                                   # pragma: no cover - xxhash ships with the image
+    import zlib
+
+    def _digest(buf):
+        return zlib.crc32(buf)
+
+
+def _array_checksum(a):
+    a = np.ascontiguousarray(a).reshape(-1)
+    if a.nbytes <= _HASH_ALL_BYTES:
+        return _digest(a.view(np.uint8))
+    step = max(1, a.size // _HASH_SAMPLES)
+    head = _HASH_SAMPLES
+    return (_digest(np.ascontiguousarray(a[:head]).view(np.uint8)), _digest(np.ascontiguousarray(a[-head:]).view(np.uint8)),
+            _digest(np.ascontiguousarray(a[::step]).view(np.uint8)))
 
 
 def _fingerprint(A, R, n_levels, code, omega, dtype):
     def one(M):
         if sp.issparse(M):
-            return (id(M), M.shape, M.nnz, M.data.ctypes.data if M.nnz else 0)
-        return (id(M), np.shape(M))
+            M = M if sp.isspmatrix_csr(M) else sp.csr_matrix(M)
+            return (M.shape, M.nnz, _array_checksum(M.indptr), _array_checksum(M.indices), _array_checksum(M.data))
+        M = np.asarray(M)
+        return (M.shape, _array_checksum(M))
     return (tuple(one(M) for M in A[:n_levels]), tuple(one(M) for M in R[:n_levels - 1]), code, omega, dtype)
 
 
 def _hierarchy_for(A, R, n_levels, code, omega, dtype=_hip.DTYPE_F64):
     key = _fingerprint(A, R, n_levels, code, omega, dtype)
-    h = _cache.get(key)
-    if h is None:
+    entry = _cache.get(key)
+    if entry is None:
         while len(_cache) >= _CACHE_SLOTS:
-            _cache.pop(next(iter(_cache))).close()
-        h = _hip.Hierarchy(list(A[:n_levels]), list(R[:n_levels - 1]), smoother=code, omega=omega, dtype=dtype)
-        _cache[key] = h
-    return h
+            _cache.pop(next(iter(_cache)))[0].close()
+        members = (list(A[:n_levels]), list(R[:n_levels - 1]))
+        h = _hip.Hierarchy(members[0], members[1], smoother=code, omega=omega, dtype=dtype)
+        entry = _cache[key] = (h, members)
+    return entry[0]
 
 
 def clear_cache():
     """Free the device hierarchies kept for repeated mgCycle calls."""
     while _cache:
-        _cache.popitem()[1].close()
+        _cache.popitem()[1][0].close()
 
 
 # ---- the two public drivers ---------------------------------------------------------------

@@ -100,6 +100,7 @@ SIGNATURES = {
     "omg_dist_sync": (_I, [_P]),
     "omg_rccl_unique_id": (_I, [_P]),
     "omg_dist_connect": (_I, [_P, _P]),
+    "omg_dist_rccl_ranks": (_I, [_P, _IP]),
     "omg_dist_load": (_I, [_P, _P, _P]),
     "omg_dist_fetch": (_I, [_P, _P]),
     "omg_dist_cycle": (_I, [_P, _I, _I, _DP]),

@@ -92,6 +92,12 @@ class DistRank:
     def connect(self, unique_id):
         check(lib().omg_dist_connect(self._h, ctypes.c_char_p(unique_id)))
 
+    def rccl_ranks(self):
+        """Ranks of the RCCL communicator this rank joined (0 before connect)."""
+        n = ctypes.c_int(0)
+        check(lib().omg_dist_rccl_ranks(self._h, ctypes.byref(n)))
+        return n.value
+
     def set_stream(self, hip_stream):
         check(lib().omg_dist_set_stream(self._h, ctypes.c_void_p(hip_stream or 0)))
 

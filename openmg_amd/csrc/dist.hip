@@ -36,6 +36,7 @@ struct Rccl {
     decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
     decltype(&ncclCommInitRank) CommInitRank = nullptr;
     decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclCommCount) CommCount = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
     decltype(&ncclGroupStart) GroupStart = nullptr;
     decltype(&ncclGroupEnd) GroupEnd = nullptr;
@@ -60,6 +61,7 @@ struct Rccl {
         sym(GetUniqueId, "ncclGetUniqueId");
         sym(CommInitRank, "ncclCommInitRank");
         sym(CommDestroy, "ncclCommDestroy");
+        sym(CommCount, "ncclCommCount");
         sym(GetErrorString, "ncclGetErrorString");
         sym(GroupStart, "ncclGroupStart");
         sym(GroupEnd, "ncclGroupEnd");
@@ -774,6 +776,16 @@ int omg_dist_connect(omg_dist *d, const void *unique_id128) {
             ncclUniqueId id;
             std::memcpy(&id, unique_id128, sizeof(id));
             OMG_NCCL(g_rccl.CommInitRank(&dd->comm, dd->n_ranks, id, dd->rank));
+        });
+    });
+}
+
+int omg_dist_rccl_ranks(omg_dist *d, int *count) {
+    return guarded([&] {
+        OMG_REQUIRE(count, "null argument");
+        with(d, [&](auto *dd) {
+            *count = 0;
+            if (dd->comm) OMG_NCCL(g_rccl.CommCount(dd->comm, count));
         });
     });
 }

@@ -7,6 +7,7 @@ Six grids (configs[3]) for N >= 2.  `value` is in 256^3-equivalent V-cycles/s = 
 (global unknowns / 256^3), so that it aggregates over GPUs."""
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -16,10 +17,8 @@ SHAPES = {1: (256, 256, 256), 2: (256, 512, 256), 4: (512, 256, 512), 8: (512, 5
 
 
 def main(args):
-    import torch
-    import torch.distributed as td
-    from . import _hip, _hip_dist, dist
-
+    import datetime
+    import threading
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", str(args.gpus)))
     local = int(os.environ.get("LOCAL_RANK", str(rank)))
@@ -27,11 +26,30 @@ def main(args):
     os.environ.setdefault("MASTER_PORT", "29511")
     if world not in SHAPES:
         raise SystemExit("bench.py --gpus must be 1, 2, 4 or 8")
+
+    # A rendezvous or collective that never completes would hang the whole node job: the
+    # watchdog is armed BEFORE anything that can block (init_process_group included) and ends
+    # this rank with a non-zero code.  Nothing is ever re-exec'ed.
+    def _abort():
+        sys.stderr.write("bench.py rank %d: watchdog expired after %d s, aborting\n" % (rank, args.watchdog))
+        sys.stderr.flush()
+        os._exit(3)
+
+    watchdog = threading.Timer(args.watchdog, _abort)
+    watchdog.daemon = True
+    watchdog.start()
+
+    import torch
+    import torch.distributed as td
+    from . import _hip, _hip_dist, dist
+
+    _hip.require_gpu()
     torch.cuda.set_device(local)
     _hip_dist.set_device(local)
     # control plane (ids, barriers, timing max) over gloo; the data plane is RCCL inside
     # libopenmg_hip.so on the rank's HIP stream
-    td.init_process_group("gloo", rank=rank, world_size=world)
+    td.init_process_group("gloo", rank=rank, world_size=world,
+                          timeout=datetime.timedelta(seconds=max(30, min(args.watchdog, 600))))
 
     def all_gather(obj):
         out = [None] * world
@@ -41,17 +59,6 @@ def main(args):
     scale = args.size / 256.0
     shape = tuple(int(s * scale) for s in SHAPES[world])
     grids = args.grids if world == 1 else args.grids + 1
-    # A collective that never completes would hang the whole node job: bail out hard instead.
-    import threading
-
-    def _abort():
-        sys.stderr.write("bench.py rank %d: watchdog expired after %d s, aborting\n" % (rank, args.watchdog))
-        sys.stderr.flush()
-        os._exit(3)
-
-    watchdog = threading.Timer(args.watchdog, _abort)
-    watchdog.daemon = True
-    watchdog.start()
     t_setup = time.perf_counter()
     # levels 0..n_dist-2 are smoothed across ranks; level n_dist-1 and everything below it run
     # replicated on every rank as an ordinary single-GPU hierarchy (dist.make_tail)
@@ -84,25 +91,30 @@ def main(args):
     pre = post = 1
     for _ in range(args.warmup):
         r.cycle(pre, post, want_norm=False)
-    r.sync()
-    torch.cuda.synchronize()
-    td.barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        r.cycle(pre, post, want_norm=False)
-    r.sync()
-    torch.cuda.synchronize()
-    td.barrier()
-    elapsed = time.perf_counter() - t0
-    t = torch.tensor([elapsed], dtype=torch.float64)
-    td.all_reduce(t, op=td.ReduceOp.MAX)
-    elapsed = float(t[0])
+    times = []
+    for _ in range(max(1, getattr(args, "repeats", 1))):
+        r.sync()
+        torch.cuda.synchronize()
+        td.barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            r.cycle(pre, post, want_norm=False)
+        r.sync()
+        torch.cuda.synchronize()
+        td.barrier()
+        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+        td.all_reduce(t, op=td.ReduceOp.MAX)           # the slowest rank's time
+        times.append(float(t[0]))
+    elapsed = statistics.median(times)
     norm = r.cycle(pre, post, want_norm=True)
     # rank 0's fine-grid SpMV over its own rows (untimed region, hipEvents on the rank's stream)
     spmv_ms = r.spmv_time(20)
     fmt = r.format_info(0, "A")
 
+    rccl_ranks = r.rccl_ranks()
     if rank == 0:
+        fmt_bytes = fmt["format_bytes"] + 2 * w * n_loc
+        csr_bytes = (w + 4) * nnz_loc + 4 * (n_loc + 1) + 2 * w * n_loc
         n_glob = part.n_rows(0)
         equiv = n_glob / float(256 ** 3)
         out = {
@@ -122,18 +134,20 @@ def main(args):
                                       "fp64" if w == 8 else "fp32", world),
                        "unknowns": n_glob, "unknowns_per_gpu": n_loc, "nnz_per_gpu": nnz_loc, "grids": grids,
                        "distributed_grids": n_dist - 1, "replicated_tail_grids": grids - n_dist + 1,
+                       "rccl_ranks": rccl_ranks, "repeats": len(times),
+                       "ms_per_step_all": [round(1e3 * t / args.steps, 4) for t in times],
                        "pre": pre, "post": post, "cycles_per_s": round(args.steps / elapsed, 3),
                        "final_residual_norm": norm, "setup_s": round(setup_s, 2)},
-            # rank 0's y = A x over its own rows; `achieved` counts SURVEY 8(d)'s CSR bytes, the
-            # operator sits in HBM in the lossless block recoding of DESIGN.md section 4
+            # rank 0's y = A x over its own rows: bytes the launch has to move with the operator in
+            # its device format over the launch time, frac <= 1 by construction;
+            # the rate in SURVEY 8(d)'s plain-CSR bytes is csr_equiv_GBps
             "roofline": {"bound": "hbm", "kernel": "y = A_local x on rank 0 (all local rows; x incl. halo)",
-                         "achieved": round(((w + 4) * nnz_loc + 4 * (n_loc + 1) + 2 * w * n_loc) / spmv_ms / 1e6, 1),
+                         "achieved": round(fmt_bytes / spmv_ms / 1e6, 1),
                          "peak": 8000.0, "unit": "GB/s",
-                         "frac": round(((w + 4) * nnz_loc + 4 * (n_loc + 1) + 2 * w * n_loc) / spmv_ms / 1e6 / 8000.0, 4),
+                         "frac": round(fmt_bytes / spmv_ms / 1e6 / 8000.0, 4),
                          "traffic": None, "avg_launch_us": round(1e3 * spmv_ms, 2),
-                         "algorithmic_bytes": (w + 4) * nnz_loc + 4 * (n_loc + 1) + 2 * w * n_loc,
-                         "format_bytes": fmt["format_bytes"] + 2 * w * n_loc,
-                         "format_frac": round((fmt["format_bytes"] + 2 * w * n_loc) / spmv_ms / 1e6 / 8000.0, 4),
+                         "bytes_per_launch": fmt_bytes,
+                         "csr_equiv_bytes": csr_bytes, "csr_equiv_GBps": round(csr_bytes / spmv_ms / 1e6, 1),
                          "device_format": {k: fmt[k] for k in ("rows", "nnz", "pattern_rows", "coldict_nnz", "valdict_nnz")}},
             "cpu_baseline": None,
         }

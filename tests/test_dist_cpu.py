@@ -85,51 +85,29 @@ def _free_port():
 
 
 def _worker(rank, world, port, shape, grids, smoother, out_dir, stencil="7pt"):
-    import torch.distributed as td
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    td.init_process_group("gloo", rank=rank, world_size=world)
-    try:
-        import torch
-        from tests.dist_cpu_executor import CpuRank
+    from tests.dist_cpu_worker import run_rank
+    run_rank(rank, world, port, shape, grids, smoother, out_dir, stencil)
 
-        class Comm:
-            def sendrecv(self, sends, recvs):
-                bufs = [torch.empty(n, dtype=torch.float64) for _, n in recvs]
-                ops = [td.P2POp(td.isend, torch.from_numpy(a), p) for p, a in sends]
-                ops += [td.P2POp(td.irecv, t, p) for (p, _), t in zip(recvs, bufs)]
-                if ops:
-                    for r in td.batch_isend_irecv(ops):
-                        r.wait()
-                return [t.numpy() for t in bufs]
 
-            def allgather(self, a):
-                out = [None] * world
-                td.all_gather_object(out, np.asarray(a))
-                return out
+def _oracle_cycles(A0, shape, grids, smoother, cycles=3):
+    b = A0 @ np.random.default_rng(12345).random(A0.shape[0])
+    R = orc.restriction_list(shape, grids - 2, 1)
+    A = orc.coefficient_list(A0, R)
+    assert len(A) == grids
+    sm = orc.make_smoother(smoother, A, omega=0.8)
+    p = {"preIterations": 1, "postIterations": 1, "coarsestLevel": len(R)}
+    x, norms = None, []
+    for _ in range(cycles):
+        x, info = orc.mg_cycle(A, b, 0, R, p, initial=x, smoother=sm)
+        norms.append(info["norm"])
+    return x, norms
 
-            def allreduce_sum(self, v):
-                t = torch.tensor([v], dtype=torch.float64)
-                td.all_reduce(t)
-                return float(t[0])
 
-        def all_gather(obj):
-            out = [None] * world
-            td.all_gather_object(out, obj)
-            return out
-
-        part = dist.SlabPartition(shape, world, grids)
-        lo, hi = part.rows(0, rank)
-        A_rows = dist.stencil_rows(shape, lo, hi) if stencil == "7pt" else dist.stencil27_variable_rows(shape, lo, hi)
-        levels, coarse, counts = dist.build_this_rank(part, rank, A_rows, all_gather, smoother=smoother,
-                                                      spgemm=scipy_spgemm,
-                                                      colouring="parity" if stencil == "7pt" else "octant")
-        u = np.random.default_rng(12345).random(part.n_rows(0))
-        b_loc = A_rows @ u
-        x_loc, norms = CpuRank(rank, levels, coarse, counts, smoother, Comm(), omega=0.8).run(b_loc, 3, 1, 1)
-        np.savez(os.path.join(out_dir, "rank%d.npz" % rank), x=x_loc, norms=np.array(norms), lo=lo, hi=hi)
-    finally:
-        td.destroy_process_group()
+def _check_ranks(out_dir, world, x, norms):
+    for rank in range(world):
+        d = np.load(os.path.join(str(out_dir), "rank%d.npz" % rank))
+        np.testing.assert_allclose(d["x"], x[int(d["lo"]):int(d["hi"])], rtol=1e-11, atol=1e-13)
+        np.testing.assert_allclose(d["norms"], norms, rtol=1e-11)
 
 
 @pytest.mark.parametrize("smoother", ["colour", "gs", "jacobi"])
@@ -137,22 +115,8 @@ def test_two_process_gloo_cycle_matches_single_process_oracle(tmp_path, smoother
     import torch.multiprocessing as mp
     shape, grids, world = (16, 16, 16), 3, 2
     mp.spawn(_worker, args=(world, _free_port(), shape, grids, smoother, str(tmp_path)), nprocs=world, join=True)
-    A0 = orc.stencil_poisson(shape)
-    b = A0 @ np.random.default_rng(12345).random(A0.shape[0])
-    R = orc.restriction_list(shape, grids - 2, 1)
-    A = orc.coefficient_list(A0, R)
-    assert len(A) == grids
-    sm = orc.make_smoother({"colour": "colour", "gs": "gs", "jacobi": "jacobi"}[smoother], A, omega=0.8)
-    p = {"preIterations": 1, "postIterations": 1, "coarsestLevel": len(R)}
-    x = None
-    norms = []
-    for _ in range(3):
-        x, info = orc.mg_cycle(A, b, 0, R, p, initial=x, smoother=sm)
-        norms.append(info["norm"])
-    for rank in range(world):
-        d = np.load(os.path.join(str(tmp_path), "rank%d.npz" % rank))
-        np.testing.assert_allclose(d["x"], x[int(d["lo"]):int(d["hi"])], rtol=1e-11, atol=1e-13)
-        np.testing.assert_allclose(d["norms"], norms, rtol=1e-11)
+    x, norms = _oracle_cycles(orc.stencil_poisson(shape), shape, grids, smoother)
+    _check_ranks(tmp_path, world, x, norms)
 
 
 def test_two_process_gloo_cycle_27_point_eight_colours(tmp_path):
@@ -213,3 +177,63 @@ def test_27_point_variable_coefficient_slabs_on_the_host(n_ranks):
                 if len(lv["peers"]):
                     assert sorted(set(lv["groups"])) == list(range(8))
                     assert len(lv["peers"]) == 8 * len(set(lv["peers"]))
+
+
+# ------------------------------------------------- the bench launcher (openmg_amd/launch.py) --
+def _launch(world, out_dir, extra=(), timeout_s=240.0):
+    import io
+    import sys
+    from openmg_amd import launch
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "dist_cpu_worker.py")
+    out, err = io.StringIO(), io.StringIO()
+    code = launch.spawn_ranks(world, [sys.executable, worker, "--out", str(out_dir)] + list(extra),
+                              timeout_s=timeout_s, out=out, err=err)
+    return code, out.getvalue(), err.getvalue()
+
+
+@pytest.mark.parametrize("world,shape,grids", [(2, (16, 16, 16), 3), (8, (32, 16, 32), 3)])
+def test_launcher_runs_every_rank_and_relays_rank0_json(tmp_path, world, shape, grids):
+    """`python bench.py --gpus N` without torch.distributed.run goes through launch.spawn_ranks:
+    N rank processes with RANK / WORLD_SIZE / MASTER_* set, rank 0's JSON as the last stdout
+    line, exit code 0.  Driven here with the gloo executor of the distributed schedule at world
+    2 and at world 8 (8 slabs of 4 planes: the decomposition of BASELINE configs[3]/[4]), and
+    every rank's iterate is checked against the single-process oracle."""
+    import json
+    code, out, err = _launch(world, tmp_path, ["--shape", ",".join(map(str, shape)), "--grids", str(grids)])
+    assert code == 0, err
+    last = json.loads(out.strip().splitlines()[-1])
+    assert last["world"] == world
+    x, norms = _oracle_cycles(orc.stencil_poisson(shape), shape, grids, "colour")
+    np.testing.assert_allclose(last["norms"], norms, rtol=1e-11)
+    _check_ranks(tmp_path, world, x, norms)
+
+
+def test_launcher_deadline_and_failure_propagation(tmp_path):
+    import time
+    t0 = time.monotonic()
+    code, out, err = _launch(2, tmp_path, ["--mode", "hang"], timeout_s=3.0)
+    assert code == 124 and "deadline" in err and time.monotonic() - t0 < 30
+    t0 = time.monotonic()
+    code, out, err = _launch(3, tmp_path, ["--mode", "fail"], timeout_s=120.0)
+    assert code == 7 and "rank 1 gives up" in err          # worst child code; the peers were ended, not waited for
+    assert time.monotonic() - t0 < 60
+
+
+def test_bench_parent_without_gpu_fails_fast_and_prints_no_result():
+    """bench.py --gpus 2 started bare on a box without GPUs: the parent launches two rank
+    processes, each fails loudly in require_gpu(), the parent returns non-zero within seconds
+    (the round-1 behaviour was a gloo rendezvous hang) and prints no JSON line."""
+    import subprocess
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    t0 = time.monotonic()
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    from openmg_amd import _hip
+    if _hip.device_count() > 0:
+        pytest.skip("a GPU is visible: the no-GPU path cannot be exercised here")
+    assert p.returncode != 0 and time.monotonic() - t0 < 240
+    assert "no MI355X" in p.stderr or "no HIP device" in p.stderr
+    assert not any(line.startswith("{") for line in p.stdout.splitlines())

@@ -197,3 +197,33 @@ def test_device_format_selftest_property():
         assert info["rows"] == n and info["nnz"] == M.nnz
 
     run()
+
+
+def test_mgcycle_cache_key_follows_content_not_object_identity():
+    """the device-hierarchy cache of mgCycle was keyed on id() / buffer
+    addresses, which CPython and malloc recycle once the caller frees its matrices.  The key is
+    a checksum of the stored arrays now: same-shape operators with different values, built in a
+    loop with the previous ones freed, must all get distinct keys; equal content gives an equal
+    key; an in-place edit changes it."""
+    import gc
+    keys = set()
+    R = [sp.csr_matrix((np.full(64, 0.5), (np.arange(64) // 2, np.arange(64))), shape=(32, 64))]
+    A = None
+    for k in range(8):
+        A = None
+        gc.collect()
+        T = sp.diags([-np.ones(63), (2.0 + k) * np.ones(64), -np.ones(63)], [-1, 0, 1], format="csr")
+        A = [T, sp.csr_matrix(R[0] @ T @ R[0].T)]
+        keys.add(openmg_amd._fingerprint(A, R, 2, 0, 1.0, 0))
+    assert len(keys) == 8
+    same = [sp.csr_matrix(M.copy()) for M in A]
+    assert openmg_amd._fingerprint(same, R, 2, 0, 1.0, 0) == openmg_amd._fingerprint(A, R, 2, 0, 1.0, 0)
+    before = openmg_amd._fingerprint(A, R, 2, 0, 1.0, 0)
+    A[0].data[5] += 1.0
+    assert openmg_amd._fingerprint(A, R, 2, 0, 1.0, 0) != before
+    assert openmg_amd._fingerprint(A, R, 2, 1, 1.0, 0) != openmg_amd._fingerprint(A, R, 2, 0, 1.0, 0)
+    # large arrays are sampled (head, tail, stride), never skipped
+    big = np.arange(openmg_amd._HASH_ALL_BYTES // 8 + 1000, dtype=np.float64)
+    c0 = openmg_amd._array_checksum(big)
+    big[-1] = -1.0
+    assert openmg_amd._array_checksum(big) != c0
