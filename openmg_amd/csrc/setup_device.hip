@@ -4,7 +4,8 @@
 // SpGEMM C = X Y is row-wise Gustavson with one thread per row of X.  The products of a row
 // are generated in SciPy's order (k in stored order of X's row, then j in stored order of
 // Y's row k) and accumulated into a per-row list kept sorted by column, so every C(i, j) is
-// summed in exactly the order SciPy's csr_matmat uses and the output has sorted columns.
+// summed in exactly the order SciPy's csr_matmat uses and the output has sorted columns;
+// entries whose sum is exactly zero are dropped, as SciPy drops them.
 // The list lives in a global scratch slice sized by the row's upper bound sum_k nnz(Y_k).
 // Setup runs once per hierarchy; it is latency- not bandwidth-bound and is not on the
 // V-cycle's critical path.
@@ -80,7 +81,13 @@ __global__ void gustavson_rows_kernel(int64_t n, const int32_t *xp, const int32_
                 }
             }
         }
-        row_nnz[i] = cnt;
+        // SciPy's csr_matmat keeps an accumulated entry only `if (sums[head] != 0)`: sums that
+        // cancel to exactly 0.0 are not stored (they would change nnz, add couplings to the
+        // colouring / level schedule and cost bytes)
+        int kept = 0;
+        for (int m = 0; m < cnt; ++m)
+            if (vals[m] != 0.0) { cols[kept] = cols[m]; vals[kept] = vals[m]; ++kept; }
+        row_nnz[i] = kept;
     }
 }
 

@@ -17,8 +17,8 @@ def flexibleMmult(x, y):
     """Product of two 2-D operands, either of which may be sparse (openmg/tools.py:18-26).
 
     matrix @ vector -> device CSR SpMV (the shape of y — (N,) or (N,1) — is preserved, as
-    SciPy's `*` does); matrix @ matrix -> device SpGEMM, returned as CSR when either operand
-    is sparse and as ndarray when both are dense.
+    SciPy's `*` does); matrix @ matrix -> device SpGEMM, returned as CSR when BOTH operands
+    are sparse and as ndarray otherwise (what SciPy's `*` / np.dot return).
     """
     if _is_vector(y):
         out = _hip.spmv(x, np.asarray(y))
@@ -27,9 +27,10 @@ def flexibleMmult(x, y):
         # row vector times matrix
         out = _hip.spmv(sp.csr_matrix(y).T.tocsr(), np.asarray(x))
         return out
-    both_dense = (not sp.issparse(x)) and (not sp.issparse(y))
+    # SciPy's `sparse * dense-2-D` (and dense * sparse) returns a dense array, only sparse *
+    # sparse stays sparse; np.dot of two dense operands is dense too
     prod = _hip.spgemm(x, y)
-    return prod.toarray() if both_dense else prod
+    return prod if (sp.issparse(x) and sp.issparse(y)) else prod.toarray()
 
 
 def getresidual(b, A, x, N):

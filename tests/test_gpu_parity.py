@@ -259,6 +259,37 @@ def test_spgemm_bitwise_against_scipy_order():
     np.testing.assert_allclose(both, X.toarray() @ Y.toarray(), rtol=1e-12, atol=1e-13)
 
 
+def test_spgemm_drops_cancelled_entries_and_dense_operands_give_dense_results():
+    """SciPy's csr_matmat stores an accumulated entry only when it is != 0, so sums
+    that cancel exactly must not appear in the device product either (structure == SciPy's);
+    and `sparse * dense-2-D` is a dense array in SciPy (openmg/tools.py:26), so
+    flexibleMmult returns an ndarray unless BOTH operands are sparse."""
+    X = sp.csr_matrix(np.array([[1.0, -1.0, 0.0], [2.0, 0.0, 1.0], [0.0, 0.0, 0.0], [1.0, 1.0, -2.0]]))
+    Y = sp.csr_matrix(np.array([[1.0, 3.0], [1.0, 0.0], [1.0, 1.5]]))
+    C = _hip.spgemm(X, Y)
+    W = sp.csr_matrix(X @ Y)
+    W.sort_indices()
+    assert W.nnz == 4                                             # (0,0) and (3,0), (3,1) cancel: 1-1, 1+1-2, 3-3
+    assert np.array_equal(C.indptr, W.indptr) and np.array_equal(C.indices, W.indices)
+    assert np.array_equal(C.data, W.data) and not (C.data == 0).any()
+    # Galerkin product with cancellation: a constant vector is in the null space of the graph Laplacian
+    n = 64
+    L = sp.diags([-np.ones(n - 1), 2.0 * np.ones(n), -np.ones(n - 1)], [-1, 0, 1], format="lil")
+    L[0, 0] = L[n - 1, n - 1] = 1.0
+    Rr = sp.csr_matrix(np.ones((1, n)))
+    got = _hip.rap(Rr, sp.csr_matrix(L))
+    assert got.nnz == 0 and sp.csr_matrix((Rr @ sp.csr_matrix(L)) @ Rr.T).nnz == 0
+    rng = np.random.default_rng(17)
+    S = random_csr(40, 30, rng, density=0.2)
+    D = rng.standard_normal((30, 5))
+    out = tools.flexibleMmult(S, D)
+    assert isinstance(out, np.ndarray) and out.shape == (40, 5)
+    np.testing.assert_allclose(out, S @ D, rtol=1e-12, atol=1e-13)
+    out = tools.flexibleMmult(D.T, sp.csr_matrix(S.T))
+    assert isinstance(out, np.ndarray) and out.shape == (5, 40)
+    assert sp.issparse(tools.flexibleMmult(S, sp.csr_matrix(S.T)))
+
+
 # -------------------------------------------------------------------- level operations --
 def test_level_operations_against_oracle(golden):
     d = golden("g3_poisson3d_16")
