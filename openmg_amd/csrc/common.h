@@ -123,6 +123,14 @@ constexpr int ASSOC_LEN = 16;
 constexpr int PAT_LANE_ENTRIES = 128;         // pattern-kernel dictionary: entries held in the lanes of a wave (2 registers)
 constexpr int MIN_CODED_ENTRIES = 64;         // smaller blocks stay plain CSR
 constexpr int BLK_INFO_INTS = 8;             // ints per row-block table record
+// Union walk (rows_union_kernel): when every row pattern of a block is a SUBSEQUENCE of one short
+// sequence of (offset, value) pairs — a stencil's boundary rows drop entries of the interior row,
+// the two parities of a red-black ordering interleave — the block's dictionary also carries that
+// common supersequence (at most UNION_MAX entries, behind its pattern entries) and one bit mask
+// per pattern (behind its pattern starts).  A wave then walks the union ONCE with scalar operands
+// for all its rows, each lane skipping the slots its mask lacks: stored order, hence the bits,
+// unchanged, and no per-pattern grouping of the lanes.
+constexpr int UNION_MAX = 16;
 
 // Host image of the device format of one operator (setup_host.cpp:encode_csr): row-block
 // table, code arrays and dictionary pools exactly as they are uploaded.
@@ -131,6 +139,9 @@ struct HostFormat {
     std::vector<int64_t> sets, set_blk, set_nnz;
     std::vector<int32_t> set_maxlen;
     std::vector<char> set_pattern, set_ell;
+    std::vector<char> set_union;                // per set: every block carries a union (rows_union_kernel can run it)
+    int union_max = 0;                          // longest union of any block
+    int union_blocks = 0;                       // 1: several-rows-per-thread partition (blocks of rows_cap > 256 rows, all with unions)
     int rows_cap = 256, lanes_per_row = 1;
     std::vector<V> narrowed;                    // float operators: the entries rounded once
     std::vector<uint8_t> cc, vc, rc;            // per-entry column / value codes, per-row pattern codes
@@ -140,6 +151,7 @@ struct HostFormat {
     int64_t blocks_ccoded = 0, blocks_vcoded = 0, blocks_pcoded = 0, blocks_ell = 0;
     int64_t nnz_ccoded = 0, nnz_vcoded = 0, nnz_pcoded = 0, rows_pcoded = 0, nnz_ell = 0;
     bool wide_failed = false;                   // encode_csr's 256-row attempt for long-row operators did not qualify
+    bool union_failed = false;                  // encode_csr's several-rows-per-thread attempt (union walk) did not qualify
 };
 template <typename V>
 HostFormat<V> encode_csr(const HostCsr &A, const std::vector<int64_t> &sets);
@@ -159,6 +171,9 @@ struct DevCsrT {
     // entries (0 = none), [4..7] its row-pattern dictionary: entry offset into pidx / pval,
     // entries, offset into pbeg, patterns (0 = none; [6] is then 1 when every row of the
     // block holds exactly one entry, which lets the kernels skip the row pointers).
+    // In a row-pattern block [2] / [3] mean something else: [2] != 0: offset patterns, values in
+    // vell at [2] - 1 and [3] = the block's longest row; [2] == 0: [3] = entries of the block's
+    // UNION (0 = none), which sits at pidx / pval [4] + [5] .. and its masks at pbeg [6] + [7] + 1 ..
     DevBuf<int32_t> blk_rows;
     // Block-dictionary coding (lossless; DESIGN.md "Device format").  Stencil-like operators
     // repeat a handful of (column - row) offsets and of values inside a row block: such a
@@ -205,11 +220,14 @@ struct DevCsrT {
     std::vector<int64_t> set_nnz;      // stored entries of each set (host)
     std::vector<int32_t> set_maxlen;   // longest row of each set (host): > ASSOC_LEN picks the four-chain kernels
     std::vector<char> set_ell;         // per set: some block keeps its values in vell (host)
+    std::vector<char> set_union;       // per set: every block carries a union -> rows_union_kernel (host)
+    int union_max = 0;                 // longest union of any block (picks the kernel instantiation)
+    int union_blocks = 0;              // 1: blocks of rows_cap > 256 rows made for rows_union_kernel (not SHORT rows)
     int lanes_per_row = 1;             // 4 for operators with long rows (avg > 16 entries)
     void upload(const HostCsr &A, const std::vector<int64_t> &sets, hipStream_t s);   // converts to V
     size_t n_sets() const { return sets.empty() ? 0 : sets.size() - 1; }
-    bool all_pattern() const {         // every (non-empty) set runs rows_pattern_kernel
-        if (set_pattern.empty()) return false;
+    bool all_pattern() const {         // every (non-empty) set can run rows_pattern_kernel
+        if (set_pattern.empty() || union_blocks) return false;
         for (size_t q = 0; q < set_pattern.size(); ++q)
             if (!set_pattern[q] && sets[q + 1] > sets[q]) return false;
         return true;

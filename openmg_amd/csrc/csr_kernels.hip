@@ -229,18 +229,19 @@ __device__ void process_block(const KArgs<V> &a, int blk, V *s_val, int *s_idx, 
     const v4i *info = reinterpret_cast<const v4i *>(a.blk_info);
     const v4i lo = info[2 * blk], lp = info[2 * blk + 1], hi = info[2 * blk + 2];
     const int r0 = lo[0], p0 = lo[1], r1 = hi[0], p1 = hi[1];
-    // per-entry dictionaries: (pool offset << DICT_SHIFT) | entries, 0 = this block reads the plain array
-    const int cinfo = lo[2], vinfo = lo[3];
     // row-pattern dictionary: lp = (entry offset, entries, table offset, patterns), patterns 0 = none
     const int npat = lp[3];
     const bool pat = npat != 0;
+    // per-entry dictionaries: (pool offset << DICT_SHIFT) | entries, 0 = this block reads the plain
+    // array (in a pattern block the two words mean something else: common.h)
+    const int cinfo = pat ? 0 : lo[2], vinfo = pat ? 0 : lo[3];
     const bool crel = cinfo != 0 || pat;   // LDS then holds (column - row), not the column
     // plain / per-entry coded block whose rows all hold exactly one entry (prolongation):
     // entry p0 + (row - r0), the row pointers are not read
     const bool unit = SHORT && !pat && lp[2] == 1;
     double sq = 0.0;
 
-    if (p1 - p0 <= T) {
+    if (pat || p1 - p0 <= T) {             // (a pattern block stages its dictionary, not its entries)
         int r = r0 + tid / LPR;
         RowPre<V> pre;
         if (!SHORT && r < r1) pre = row_preload<MODE>(a, r, pat ? EXT_PATTERN : EXT_ROWPTR);
@@ -791,6 +792,150 @@ void rows_pattern_kernel(KArgs<V> a, int blk0) {
     }
 }
 
+// ---- union walk: several rows per thread, one pass per wave ----------------------------------
+// Blocks whose dictionary carries a UNION (common.h UNION_MAX: every row pattern of the block is a
+// subsequence of one short sequence of (offset, value) pairs, e.g. a stencil's boundary rows and
+// the two parities of a red-black ordering).  One workgroup = one block of up to U x 256 rows, a
+// thread owns rows r0 + tid + 256 u.  The dependent memory round trips per wave are what bounds
+// the one-row-per-thread kernel above (block record -> codes -> gathers, with the lanes taken one
+// pattern group at a time); here a wave
+//   1. reads the block record and the union (offsets, values: lane j holds slot j; masks: lane c
+//      holds pattern c) — shared by all blocks of a launch, L2-resident;
+//   2. requests, for ALL its rows at once, the row code, b, x_i, then — masks looked up with one
+//      ds_bpermute per row — the gathers of every union slot a row owns: x[r + off_j] through a
+//      buffer descriptor (32-bit offset r + off_j in one VALU add, no 64-bit address arithmetic),
+//      U x (entries + 2) loads in flight per lane and no grouping of the lanes by pattern;
+//   3. walks the union once with SCALAR operands (v_readlane), each lane skipping the slots its
+//      pattern's mask lacks: the row's entries in stored order, one fma chain — the bits of
+//      rows_kernel / rows_pattern_kernel (rows here hold at most UNION_MAX <= ASSOC_LEN entries).
+typedef unsigned v2u __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ double buffer_gather(__amdgpu_buffer_rsrc_t rs, int byte_off, double) {
+    return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs, byte_off, 0, 0));
+}
+__device__ __forceinline__ float buffer_gather(__amdgpu_buffer_rsrc_t rs, int byte_off, float) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, byte_off, 0, 0));
+}
+
+template <int MODE, int U, int UMAX, typename V>
+__global__ __launch_bounds__(NT) void rows_union_kernel(KArgs<V> a, int blk0, unsigned x_bytes) {
+    constexpr bool FUSED = (MODE == ROW_GS_RES || MODE == ROW_GS_NORM);
+    constexpr bool NEED_DIAG = (MODE == ROW_GS || MODE == ROW_JACOBI || FUSED);
+    constexpr bool NEED_NORM = (MODE == ROW_RESNORM || MODE == ROW_NORM_ONLY || MODE == ROW_GS_NORM);
+    __shared__ double s_red[NT / 64];
+    const int blk = blk0 + int(blockIdx.x);
+    const v4i *info = reinterpret_cast<const v4i *>(a.blk_info);
+    const v4i lo = info[2 * blk], lp = info[2 * blk + 1], hi = info[2 * blk + 2];
+    const int r0 = lo[0], r1 = hi[0];
+    const int ul = lo[3];                                       // 1 <= ul <= UMAX (host: set_union, union_max)
+    const int cnt = lp[1], npat = lp[3];
+    const int32_t *__restrict__ uidx = a.pidx + lp[0] + cnt;    // the union sits behind the pattern entries
+    const V *__restrict__ uval = a.pval + lp[0] + cnt;
+    const int32_t *__restrict__ pmask = a.pbeg + lp[2] + npat + 1;   // the masks behind the pattern starts
+    const int lane = int(threadIdx.x) & 63;
+    const int uo = uidx[min(lane, ul - 1)];
+    const V uv = uval[min(lane, ul - 1)];
+    const int mk = pmask[min(lane, npat - 1)];
+    // the gathered vector as a buffer: out-of-range offsets (negative ones wrap to huge) read 0
+    const __amdgpu_buffer_rsrc_t xs = __builtin_amdgcn_make_buffer_rsrc(const_cast<V *>(a.x), 0, x_bytes, 0x00020000);
+
+    int row[U], code[U];
+    bool act[U];
+    RowPre<V> pre[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        row[u] = r0 + int(threadIdx.x) + u * NT;
+        act[u] = row[u] < r1;
+        code[u] = 0;
+        pre[u].beg = pre[u].end = 0; pre[u].out = row[u]; pre[u].bv = V(0); pre[u].xv = V(0);
+        if (act[u]) {
+            pre[u] = row_preload<MODE>(a, row[u], EXT_PATTERN);
+            code[u] = pre[u].beg;
+        }
+    }
+    // the pattern masks: lane c holds pattern c's.  ds_bpermute outside any divergent branch — an
+    // inactive SOURCE lane would read as 0 (a block's last wave may have fewer live rows than
+    // the block has patterns)
+    int mask[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int m = __builtin_amdgcn_ds_bpermute(code[u] << 2, mk);
+        mask[u] = act[u] ? m : 0;
+    }
+    // gathers of every slot a row owns, all rows of the thread, before any is used.  (Requesting
+    // every union slot for every lane without waiting for the masks — offsets that leave the
+    // vector read 0 by the descriptor's range check — shortens the dependent chain by one round
+    // trip but moves more bytes through the vector L1, which is what these launches are short
+    // of: measured 3-8 % slower at 256^3.)
+    V xg[U][UMAX];
+#pragma unroll
+    for (int j = 0; j < UMAX; ++j) {
+        if (j < ul) {                                           // block-uniform
+            const int oj = __builtin_amdgcn_readlane(uo, j);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                xg[u][j] = V(0);
+                if ((mask[u] >> j) & 1) xg[u][j] = buffer_gather(xs, (row[u] + oj) * int(sizeof(V)), V(0));
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < U; ++u) xg[u][j] = V(0);
+        }
+    }
+    V sum[U], diag[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) { sum[u] = V(0); diag[u] = V(0); }
+#pragma unroll
+    for (int j = 0; j < UMAX; ++j) {
+        if (j < ul) {
+            const V vj = lane_pick(uv, j);
+            const int oj = __builtin_amdgcn_readlane(uo, j);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const bool on = (mask[u] >> j) & 1;
+                sum[u] = on ? madd(vj, xg[u][j], sum[u]) : sum[u];
+                if (NEED_DIAG && oj == 0) diag[u] = on ? diag[u] + vj : diag[u];
+            }
+        }
+    }
+    double sq = 0.0;
+    if constexpr (FUSED) {
+        // relax, then the row's residual with the NEW x_i from the operands still in registers:
+        // the same chain ROW_RESIDUAL would run on the updated vector
+        V xnew[U], sum2[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) { xnew[u] = pre[u].xv + (pre[u].bv - sum[u]) / diag[u]; sum2[u] = V(0); }
+#pragma unroll
+        for (int j = 0; j < UMAX; ++j) {
+            if (j < ul) {
+                const V vj = lane_pick(uv, j);
+                const int oj = __builtin_amdgcn_readlane(uo, j);
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const bool on = (mask[u] >> j) & 1;
+                    const V xj = oj == 0 ? xnew[u] : xg[u][j];
+                    sum2[u] = on ? madd(vj, xj, sum2[u]) : sum2[u];
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (act[u]) {
+                const V res = pre[u].bv - sum2[u];
+                a.y[row[u]] = xnew[u];
+                if constexpr (MODE == ROW_GS_RES) a.zero[row[u]] = res;
+                else sq += double(res) * double(res);
+            }
+    } else {
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (act[u]) row_epilogue<MODE>(a, row[u], pre[u], sum[u], diag[u], sq);
+    }
+    if constexpr (NEED_NORM) {
+        const double tot = block_sum(sq, s_red);
+        if (threadIdx.x == 0) a.partials[blk] = tot;
+    }
+}
+
 // Tuning switches (speed only): OMG_XCD_REMAP=1 enables the XCD-chunked block mapping
 // (measured slower than the hardware's round-robin on the 256^3 stencil: 390 vs 374 us for the
 // residual), OMG_NT_LOADS=0 disables the non-temporal matrix loads (measured 3-4 % slower).
@@ -804,11 +949,32 @@ int launch_flags() {
     return v;
 }
 
+template <int MODE, int U, typename V>
+void launch_union(const DevCsrT<V> &A, int64_t blk0, int64_t nblk, const KArgs<V> &k, hipStream_t s) {
+    const dim3 g((unsigned)nblk), b(NT);
+    const unsigned x_bytes = unsigned(size_t(A.n_cols) * sizeof(V));
+    if (A.union_max <= 10) hipLaunchKernelGGL((rows_union_kernel<MODE, U, 10, V>), g, b, 0, s, k, (int)blk0, x_bytes);
+    else hipLaunchKernelGGL((rows_union_kernel<MODE, U, UNION_MAX, V>), g, b, 0, s, k, (int)blk0, x_bytes);
+    OMG_HIP(hipGetLastError());
+}
+
+// kind: 0 rows_kernel, 1 rows_pattern_kernel, 2 rows_union_kernel
 template <int MODE, typename V>
-void launch_mode(const DevCsrT<V> &A, int64_t blk0, int64_t nblk, const KArgs<V> &k, bool all_pattern,
+void launch_mode(const DevCsrT<V> &A, int64_t blk0, int64_t nblk, const KArgs<V> &k, int kind,
                  bool long_rows, bool ell, hipStream_t s) {
     if (nblk <= 0) return;
+    if (kind == 2) {
+        if constexpr (MODE != ROW_SCATTER) {
+            const int u = (A.rows_cap + NT - 1) / NT;
+            if (u <= 1) launch_union<MODE, 1>(A, blk0, nblk, k, s);
+            else if (u == 2) launch_union<MODE, 2>(A, blk0, nblk, k, s);
+            else launch_union<MODE, 4>(A, blk0, nblk, k, s);
+        }
+        return;
+    }
+    const bool all_pattern = kind == 1;
     if (all_pattern) {
+        OMG_REQUIRE(A.rows_cap <= NT, "rows_pattern_kernel cannot run blocks of more than 256 rows");
         const dim3 g((unsigned)nblk), b(NT);
         if (ell) {
             if (long_rows) hipLaunchKernelGGL((rows_pattern_kernel<MODE, true, true, V>), g, b, 0, s, k, (int)blk0);
@@ -830,7 +996,7 @@ void launch_mode(const DevCsrT<V> &A, int64_t blk0, int64_t nblk, const KArgs<V>
     constexpr bool HAS_SHORT = (MODE == ROW_SPMV || MODE == ROW_AXPY || MODE == ROW_RESIDUAL);
     const dim3 grid((unsigned)nblk), block(NT);
     if constexpr (HAS_SHORT) {
-        if (A.rows_cap > NT) {
+        if (A.rows_cap > NT && A.union_blocks == 0) {
             if (ntl) hipLaunchKernelGGL((rows_kernel<MODE, true, true, 1, true, V>), grid, block, 0, s, k, (int)blk0, remap);
             else hipLaunchKernelGGL((rows_kernel<MODE, false, true, 1, true, V>), grid, block, 0, s, k, (int)blk0, remap);
             OMG_HIP(hipGetLastError());
@@ -889,9 +1055,10 @@ void launch_rows(const DevCsrT<V> &A, int mode, int set, const RowArgsT<V> &args
 
 namespace {
 
-// [set_begin, set_end): all sets go to the same kernel (pattern: rows_pattern_kernel)
+// [set_begin, set_end): all sets go to the same kernel (kind: 0 rows_kernel, 1 rows_pattern_kernel,
+// 2 rows_union_kernel)
 template <typename V>
-void launch_rows_uniform(const DevCsrT<V> &A, int mode, int set_begin, int set_end, bool pattern,
+void launch_rows_uniform(const DevCsrT<V> &A, int mode, int set_begin, int set_end, int kind,
                          const RowArgsT<V> &args, hipStream_t s) {
     const KArgs<V> k = make_kargs(A, args);
     const int64_t blk0 = A.set_blk[set_begin];
@@ -903,7 +1070,7 @@ void launch_rows_uniform(const DevCsrT<V> &A, int mode, int set_begin, int set_e
         ell = ell || (!A.set_ell.empty() && A.set_ell[q]);
     }
     if (mode == ROW_SCATTER) {                 // exists in the pattern kernel only (common.h)
-        OMG_REQUIRE(pattern, "ROW_SCATTER needs an operator whose blocks are all row-pattern coded");
+        OMG_REQUIRE(kind == 1 && A.rows_cap <= NT, "ROW_SCATTER needs an operator whose blocks are all row-pattern coded");
         if (nblk > 0) {
             const dim3 g((unsigned)nblk), b(NT);
             if (ell) hipLaunchKernelGGL((rows_pattern_kernel<ROW_SCATTER, false, true, V>), g, b, 0, s, k, (int)blk0);
@@ -912,17 +1079,16 @@ void launch_rows_uniform(const DevCsrT<V> &A, int mode, int set_begin, int set_e
         }
         return;
     }
-    const bool ap = pattern;
     switch (mode) {
-        case ROW_GS_RES: launch_mode<ROW_GS_RES>(A, blk0, nblk, k, ap, long_rows, ell, s); break;
-        case ROW_GS_NORM: launch_mode<ROW_GS_NORM>(A, blk0, nblk, k, ap, long_rows, ell, s); break;
-        case ROW_SPMV: launch_mode<ROW_SPMV>(A, blk0, nblk, k, ap, long_rows, ell, s); break;
-        case ROW_RESIDUAL: launch_mode<ROW_RESIDUAL>(A, blk0, nblk, k, ap, long_rows, ell, s); break;
-        case ROW_RESNORM: launch_mode<ROW_RESNORM>(A, blk0, nblk, k, ap, long_rows, ell, s); break;
-        case ROW_NORM_ONLY: launch_mode<ROW_NORM_ONLY>(A, blk0, nblk, k, ap, long_rows, ell, s); break;
-        case ROW_GS: launch_mode<ROW_GS>(A, blk0, nblk, k, ap, long_rows, ell, s); break;
-        case ROW_JACOBI: launch_mode<ROW_JACOBI>(A, blk0, nblk, k, ap, long_rows, ell, s); break;
-        case ROW_AXPY: launch_mode<ROW_AXPY>(A, blk0, nblk, k, ap, long_rows, ell, s); break;
+        case ROW_GS_RES: launch_mode<ROW_GS_RES>(A, blk0, nblk, k, kind, long_rows, ell, s); break;
+        case ROW_GS_NORM: launch_mode<ROW_GS_NORM>(A, blk0, nblk, k, kind, long_rows, ell, s); break;
+        case ROW_SPMV: launch_mode<ROW_SPMV>(A, blk0, nblk, k, kind, long_rows, ell, s); break;
+        case ROW_RESIDUAL: launch_mode<ROW_RESIDUAL>(A, blk0, nblk, k, kind, long_rows, ell, s); break;
+        case ROW_RESNORM: launch_mode<ROW_RESNORM>(A, blk0, nblk, k, kind, long_rows, ell, s); break;
+        case ROW_NORM_ONLY: launch_mode<ROW_NORM_ONLY>(A, blk0, nblk, k, kind, long_rows, ell, s); break;
+        case ROW_GS: launch_mode<ROW_GS>(A, blk0, nblk, k, kind, long_rows, ell, s); break;
+        case ROW_JACOBI: launch_mode<ROW_JACOBI>(A, blk0, nblk, k, kind, long_rows, ell, s); break;
+        case ROW_AXPY: launch_mode<ROW_AXPY>(A, blk0, nblk, k, kind, long_rows, ell, s); break;
         default: throw Error(OMG_ERR_INVALID, "launch_rows: unknown mode");
     }
 }
@@ -935,24 +1101,29 @@ void launch_rows_range(const DevCsrT<V> &A, int mode, int set_begin, int set_end
     OMG_REQUIRE(set_begin >= 0 && set_begin <= set_end && size_t(set_end) <= A.n_sets(),
                 "launch_rows: set range out of bounds");
     if (set_begin == set_end) return;
-    // Which kernel a set runs (common.h set_pattern): 2 = the LDS-free pattern kernel, always;
-    // 1 = the pattern kernel unless OMG_PATTERN_KERNEL=0 asks for rows_kernel's walk of the same
-    // dictionaries through LDS (identical bits); 0 = rows_kernel.  Consecutive sets with the same
-    // answer share a launch.
+    // Which kernel a set runs: rows_union_kernel where every block carries a union (common.h
+    // set_union; OMG_UNION_KERNEL=0 clears it at upload); else by set_pattern: 2 = the LDS-free
+    // pattern kernel, always; 1 = the pattern kernel unless OMG_PATTERN_KERNEL=0 asks for
+    // rows_kernel's walk of the same dictionaries through LDS (identical bits); 0 = rows_kernel.
+    // Consecutive sets with the same answer share a launch.
     const char *e = getenv("OMG_PATTERN_KERNEL");
     const bool prefer = !(e && e[0] == '0');
-    auto pattern_of = [&](int q) {
+    const bool x_fits = size_t(A.n_cols) * sizeof(V) < (size_t(1) << 31);       // 32-bit buffer offsets
+    auto kind_of = [&](int q) {
+        // (square operators only: restriction / prolongation rows measured faster in the pattern kernel)
+        if (mode != ROW_SCATTER && x_fits && A.n_rows == A.n_cols && !A.set_union.empty() && A.set_union[q]) return 2;
         const int v = A.set_pattern.empty() ? 0 : A.set_pattern[q];
-        return v == 2 || (v == 1 && (prefer || mode == ROW_SCATTER));     // the scatter exists in the pattern kernel only
+        if (A.rows_cap > NT && A.union_blocks) return 0;                        // big pattern blocks: rows_kernel walks them
+        return (v == 2 || (v == 1 && (prefer || mode == ROW_SCATTER))) ? 1 : 0;   // the scatter exists in the pattern kernel only
     };
     auto empty = [&](int q) { return A.set_blk[q + 1] == A.set_blk[q]; };
     int q0 = set_begin;
     while (q0 < set_end) {
         if (empty(q0)) { ++q0; continue; }
-        const bool pat = pattern_of(q0);
+        const int kind = kind_of(q0);
         int q1 = q0 + 1;
-        while (q1 < set_end && (empty(q1) || pattern_of(q1) == pat)) ++q1;
-        launch_rows_uniform(A, mode, q0, q1, pat, args, s);
+        while (q1 < set_end && (empty(q1) || kind_of(q1) == kind)) ++q1;
+        launch_rows_uniform(A, mode, q0, q1, kind, args, s);
         q0 = q1;
     }
 }

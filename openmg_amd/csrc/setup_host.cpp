@@ -256,6 +256,17 @@ int compress_mode() {
     return (v < 0 || v > 15) ? 15 : v;
 }
 
+// rows per thread of the union walk (csr_kernels.hip rows_union_kernel): 0 = kernel off
+int union_rows() {
+    const char *k = getenv("OMG_UNION_KERNEL");
+    if (k && k[0] == '0') return 0;
+    const char *p = getenv("OMG_PATTERN_KERNEL");            // rows_kernel everywhere: standard blocks
+    if (p && p[0] == '0') return 0;
+    const char *e = getenv("OMG_UNION_ROWS");
+    const int v = e ? atoi(e) : 2;          // measured at 256^3 (7-point, red-black): 2 > 4 > 1
+    return v >= 4 ? 4 : v >= 2 ? 2 : 1;
+}
+
 template <typename V> struct Bits;
 template <> struct Bits<double> {
     typedef uint64_t type;
@@ -289,7 +300,7 @@ namespace {
 // One attempt at coding A with a given row-block partition (see encode_csr).
 template <typename V>
 HostFormat<V> encode_with(const HostCsr &A, const std::vector<int64_t> &sets_in, int max_rows, int max_nnz,
-                          int lanes, int mode) {
+                          int lanes, int mode, bool need_union = false) {
     HostFormat<V> F;
     auto &sets = F.sets;
     auto &set_blk = F.set_blk;
@@ -322,13 +333,63 @@ HostFormat<V> encode_with(const HostCsr &A, const std::vector<int64_t> &sets_in,
         std::vector<int32_t> beg, idx;     // beg: npat + 1 offsets into idx / val
         std::vector<V> val;                // empty: offsets only (values go to the ELL array)
         int maxlen = 0;
+        // union walk (common.h UNION_MAX): a common supersequence of all patterns and, per pattern,
+        // the mask of the union slots it occupies; uidx empty = none
+        std::vector<int32_t> uidx, umask;
+        std::vector<V> uval;
         bool wave_sized() const { return !idx.empty() && int(beg.size()) - 1 < 64 && int(idx.size()) <= PAT_LANE_ENTRIES; }
+        // Shortest common supersequence, pattern by pattern (each pattern stays a subsequence of the
+        // growing union because the union only ever gains entries); gives up beyond UNION_MAX.
+        void make_union() {
+            uidx.clear(); uval.clear(); umask.clear();
+            if (idx.empty() || val.size() != idx.size()) return;
+            const int npat = int(beg.size()) - 1;
+            if (npat > 64) return;
+            auto eq = [&](int ui, int pi) { return uidx[ui] == idx[pi] && Bits<V>::of(uval[ui]) == Bits<V>::of(val[pi]); };
+            // start from the longest pattern: most others are subsequences of it
+            int longest = 0;
+            for (int c = 1; c < npat; ++c) if (beg[c + 1] - beg[c] > beg[longest + 1] - beg[longest]) longest = c;
+            uidx.assign(idx.begin() + beg[longest], idx.begin() + beg[longest + 1]);
+            uval.assign(val.begin() + beg[longest], val.begin() + beg[longest + 1]);
+            for (int c = 0; c < npat; ++c) {
+                const int pb = beg[c], len = beg[c + 1] - beg[c], ul = int(uidx.size());
+                int k = 0;
+                for (int i = 0; i < ul && k < len; ++i) if (eq(i, pb + k)) ++k;
+                if (k == len) continue;                              // already a subsequence
+                // LCS table, then merge
+                std::vector<int> L(size_t(ul + 1) * size_t(len + 1), 0);
+                auto at = [&](int i, int j) -> int & { return L[size_t(i) * size_t(len + 1) + size_t(j)]; };
+                for (int i = ul - 1; i >= 0; --i)
+                    for (int j = len - 1; j >= 0; --j)
+                        at(i, j) = eq(i, pb + j) ? at(i + 1, j + 1) + 1 : std::max(at(i + 1, j), at(i, j + 1));
+                std::vector<int32_t> ni;
+                std::vector<V> nv;
+                int i = 0, j = 0;
+                while (i < ul || j < len) {
+                    if (i < ul && j < len && eq(i, pb + j)) { ni.push_back(uidx[i]); nv.push_back(uval[i]); ++i; ++j; }
+                    else if (j == len || (i < ul && at(i + 1, j) >= at(i, j + 1))) { ni.push_back(uidx[i]); nv.push_back(uval[i]); ++i; }
+                    else { ni.push_back(idx[pb + j]); nv.push_back(val[pb + j]); ++j; }
+                }
+                if (int(ni.size()) > UNION_MAX) { uidx.clear(); uval.clear(); return; }
+                uidx.swap(ni);
+                uval.swap(nv);
+            }
+            if (int(uidx.size()) > UNION_MAX) { uidx.clear(); uval.clear(); return; }
+            umask.assign(size_t(npat), 0);
+            for (int c = 0; c < npat; ++c) {
+                const int pb = beg[c], len = beg[c + 1] - beg[c];
+                int k = 0;
+                for (int i = 0; i < int(uidx.size()) && k < len; ++i)
+                    if (eq(i, pb + k)) { umask[c] |= int32_t(1) << i; ++k; }
+                if (k != len) { uidx.clear(); uval.clear(); umask.clear(); return; }   // cannot happen
+            }
+        }
     };
     std::vector<PatDict> pfull(nb), pcols(nb);
     std::vector<std::vector<int32_t>> cdicts(nb);
     std::vector<std::vector<V>> vdicts(nb);
     // row patterns: not for the several-rows-per-thread operators (prolongation, restriction)
-    const bool try_pat = (mode & 4) && max_rows <= ROWBLK_THREADS;
+    const bool try_pat = (mode & 4) && (max_rows <= ROWBLK_THREADS || need_union);
     const bool try_ell = try_pat && (mode & 8) && lanes == 1;
     if (mode != 0 && nblk > 0 && nnz > 0) {
         if (mode & 1) cc.assign(size_t(nnz), 0);
@@ -381,7 +442,7 @@ HostFormat<V> encode_with(const HostCsr &A, const std::vector<int64_t> &sets_in,
                 // (the single-row sets of a 1-D lexicographic sweep ran 20 % slower coded)
                 if (p1 - p0 < MIN_CODED_ENTRIES) continue;
                 const int64_t budget = (p1 - p0) / 2;                 // a dictionary must be a real saving
-                if (try_pat && patterns(r0, r1, true, budget, pfull[k])) continue;
+                if (try_pat && patterns(r0, r1, true, budget, pfull[k])) { pfull[k].make_union(); continue; }
                 if (try_ell) patterns(r0, r1, false, budget, pcols[k]);
                 if (p1 - p0 > ROWBLK_NNZ) continue;                   // (wide partition: no LDS fallback exists)
                 if (mode & 1) {
@@ -439,7 +500,25 @@ HostFormat<V> encode_with(const HostCsr &A, const std::vector<int64_t> &sets_in,
             F.set_pattern[q] = all ? (ell ? 2 : 1) : 0;
             F.set_ell[q] = (all && ell) ? 1 : 0;
         }
-    if (max_nnz > ROWBLK_NNZ) {
+    // union walk: every block of the set is a full (offsets + values) pattern block with a union
+    F.set_union.assign(sets.size() - 1, 0);
+    for (size_t q = 0; q + 1 < sets.size(); ++q) {
+        bool all = set_blk[q + 1] > set_blk[q];
+        for (int64_t k = set_blk[q]; all && k < set_blk[q + 1]; ++k) {
+            all = !pfull[k].uidx.empty() && int(pfull[k].beg.size()) - 1 <= 64;
+            if (all) F.union_max = std::max(F.union_max, int(pfull[k].uidx.size()));
+        }
+        F.set_union[q] = all ? 1 : 0;
+    }
+    if (need_union) {
+        // several-rows-per-thread partition (encode_csr): blocks of more than ROWBLK_THREADS rows,
+        // which only rows_union_kernel (and rows_kernel's walk of the dictionary) can run
+        bool all = true;
+        for (size_t q = 0; q + 1 < sets.size(); ++q) all = all && (F.set_union[q] != 0 || set_blk[q + 1] == set_blk[q]);
+        if (!all) { F.union_failed = true; return F; }
+        for (size_t q = 0; q + 1 < sets.size(); ++q) F.set_pattern[q] = 1;
+        F.union_blocks = 1;
+    } else if (max_nnz > ROWBLK_NNZ) {
         // wide partition (encode_csr): usable only if the pattern kernel takes every set
         bool all = true;
         for (size_t q = 0; q + 1 < sets.size(); ++q) all = all && (F.set_pattern[q] != 0 || set_blk[q + 1] == set_blk[q]);
@@ -473,7 +552,8 @@ HostFormat<V> encode_with(const HostCsr &A, const std::vector<int64_t> &sets_in,
             if (!pd.idx.empty()) {
                 std::vector<V> padv(pd.idx.size(), V(0));                      // offsets-only dictionaries: zeros
                 const V *dv = pd.val.empty() ? padv.data() : pd.val.data();
-                std::string key(reinterpret_cast<const char *>(pd.beg.data()), pd.beg.size() * sizeof(int32_t));
+                std::string key(use_ell ? "E" : "F");               // an offsets-only dictionary carries no union behind it
+                key.append(reinterpret_cast<const char *>(pd.beg.data()), pd.beg.size() * sizeof(int32_t));
                 key.append(reinterpret_cast<const char *>(pd.idx.data()), pd.idx.size() * sizeof(int32_t));
                 key.append(reinterpret_cast<const char *>(dv), pd.idx.size() * sizeof(V));
                 auto it = pseen.find(key);
@@ -481,14 +561,20 @@ HostFormat<V> encode_with(const HostCsr &A, const std::vector<int64_t> &sets_in,
                     it = pseen.emplace(std::move(key), std::make_pair(int32_t(ppool_idx.size()), int32_t(ppool_beg.size()))).first;
                     ppool_idx.insert(ppool_idx.end(), pd.idx.begin(), pd.idx.end());
                     ppool_val.insert(ppool_val.end(), dv, dv + pd.idx.size());
+                    if (!use_ell && !pd.uidx.empty()) {                        // the union, then (below) its masks
+                        ppool_idx.insert(ppool_idx.end(), pd.uidx.begin(), pd.uidx.end());
+                        ppool_val.insert(ppool_val.end(), pd.uval.begin(), pd.uval.end());
+                    }
                     while (ppool_idx.size() % 8) { ppool_idx.push_back(0); ppool_val.push_back(V(0)); }   // 16-B vector loads
                     ppool_beg.insert(ppool_beg.end(), pd.beg.begin(), pd.beg.end());
+                    if (!use_ell && !pd.uidx.empty()) ppool_beg.insert(ppool_beg.end(), pd.umask.begin(), pd.umask.end());
                 }
                 OMG_REQUIRE(it != pseen.end(), "pattern dictionary pool overflow");
                 rec[4] = it->second.first;
                 rec[5] = int32_t(pd.idx.size());
                 rec[6] = it->second.second;
                 rec[7] = int32_t(pd.beg.size()) - 1;
+                if (!use_ell) rec[3] = int32_t(pd.uidx.size());                 // union entries (0: none)
                 ++F.blocks_pcoded;
                 F.rows_pcoded += rows;
                 F.nnz_pcoded += entries;
@@ -589,6 +675,16 @@ HostFormat<V> encode_csr(const HostCsr &A, const std::vector<int64_t> &sets_in) 
             HostFormat<V> W = encode_with<V>(A, sets_in, ROWBLK_THREADS, 1 << 24, 1, mode);
             if (!W.wide_failed) return W;
         }
+        // Short-row square operators (the smoothed A_l of stencil problems) whose blocks all carry a
+        // union: blocks of U x 256 rows, U rows per thread in rows_union_kernel (all gathers of a
+        // thread's rows in flight together).  Tried first; OMG_UNION_ROWS = 1, 2 or 4 (default 2),
+        // OMG_UNION_KERNEL=0 switches the union walk off altogether.
+        const int urows = union_rows();
+        if (lanes == 1 && max_rows == ROWBLK_ROWS && urows > 1 && (mode & 4) && A.n_rows == A.n_cols &&
+            A.n_rows >= int64_t(4) * urows * ROWBLK_THREADS) {
+            HostFormat<V> W = encode_with<V>(A, sets_in, urows * ROWBLK_THREADS, 1 << 24, 1, mode, true);
+            if (!W.union_failed) return W;
+        }
     }
     return encode_with<V>(A, sets_in, max_rows, ROWBLK_NNZ, lanes, mode);
 }
@@ -604,6 +700,10 @@ void DevCsrT<V>::upload(const HostCsr &A, const std::vector<int64_t> &sets_in, h
     set_nnz = std::move(F.set_nnz);
     set_maxlen = std::move(F.set_maxlen);
     set_ell = std::move(F.set_ell);
+    set_union = std::move(F.set_union);
+    if (union_rows() == 0) set_union.assign(set_union.size(), 0);
+    union_max = F.union_max;
+    union_blocks = F.union_blocks;
     set_pattern = std::move(F.set_pattern);
     rows_cap = F.rows_cap;
     lanes_per_row = F.lanes_per_row;
@@ -649,6 +749,24 @@ void decode_format(const HostFormat<V> &F, const HostCsr &A, std::vector<int32_t
                 const int pb = beg[code], pe = beg[code + 1];
                 OMG_REQUIRE(pe - pb == A.indptr[r + 1] - A.indptr[r], "decode: pattern length differs from the row's");
                 OMG_REQUIRE(pe <= rec[5], "decode: pattern runs past its dictionary");
+                if (!rec[2] && rec[3]) {
+                    // union walk (rows_union_kernel): the slots of the block's union that the
+                    // pattern's mask selects, in order, must be exactly the row's entries
+                    const int ul = rec[3];
+                    OMG_REQUIRE(ul <= UNION_MAX, "decode: union longer than UNION_MAX");
+                    const int32_t *ui = F.ppool_idx.data() + rec[4] + rec[5];
+                    const V *uv = F.ppool_val.data() + rec[4] + rec[5];
+                    const int32_t mask = F.ppool_beg[rec[6] + rec[7] + 1 + code];
+                    int j = 0;
+                    for (int sl = 0; sl < ul; ++sl) {
+                        if (!((mask >> sl) & 1)) continue;
+                        OMG_REQUIRE(j < pe - pb && ui[sl] == F.ppool_idx[rec[4] + pb + j] &&
+                                        Bits<V>::of(uv[sl]) == Bits<V>::of(F.ppool_val[rec[4] + pb + j]),
+                                    "decode: union slot differs from the pattern entry");
+                        ++j;
+                    }
+                    OMG_REQUIRE(j == pe - pb && (mask >> ul) == 0, "decode: mask does not cover the pattern");
+                }
                 for (int j = 0; j < pe - pb; ++j) {
                     cols[A.indptr[r] + j] = F.ppool_idx[rec[4] + pb + j] + int32_t(r);
                     if (rec[2]) {                                 // values in the ELL array, entry j of the block's rows side by side

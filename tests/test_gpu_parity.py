@@ -269,7 +269,7 @@ def test_spgemm_drops_cancelled_entries_and_dense_operands_give_dense_results():
     C = _hip.spgemm(X, Y)
     W = sp.csr_matrix(X @ Y)
     W.sort_indices()
-    assert W.nnz == 4                                             # (0,0) and (3,0), (3,1) cancel: 1-1, 1+1-2, 3-3
+    assert W.nnz == 3                                             # (0,0), (3,0) and (3,1) cancel: 1-1, 1+1-2, 3-3
     assert np.array_equal(C.indptr, W.indptr) and np.array_equal(C.indices, W.indices)
     assert np.array_equal(C.data, W.data) and not (C.data == 0).any()
     # Galerkin product with cancellation: a constant vector is in the null space of the graph Laplacian
@@ -704,10 +704,14 @@ def test_device_format_modes_are_bit_identical(monkeypatch, golden, case):
     b = A[0] @ rng.random(A[0].shape[0])
     runs = {}
     # pk: "1" rows_pattern_kernel where the dictionaries fit a wave, "0" rows_kernel walking them through LDS
-    for mode, pk in (("0", "1"), ("1", "1"), ("2", "1"), ("3", "1"), ("4", "1"), ("4", "0"), ("7", "1"), ("7", "0"),
-                     ("15", "1"), ("15", "0"), ("12", "1")):
+    # ur: rows per thread of the union walk (rows_union_kernel, blocks of ur x 256 rows); "0" = that kernel off
+    for mode, pk, ur in (("0", "1", "4"), ("1", "1", "4"), ("2", "1", "4"), ("3", "1", "4"), ("4", "1", "0"), ("4", "0", "4"),
+                         ("7", "1", "0"), ("7", "0", "4"), ("15", "1", "0"), ("15", "0", "4"), ("12", "1", "0"),
+                         ("4", "1", "1"), ("15", "1", "1"), ("15", "1", "2"), ("15", "1", "4"), ("7", "1", "4")):
         monkeypatch.setenv("OMG_COMPRESS", mode)
         monkeypatch.setenv("OMG_PATTERN_KERNEL", pk)
+        monkeypatch.setenv("OMG_UNION_KERNEL", "0" if ur == "0" else "1")
+        monkeypatch.setenv("OMG_UNION_ROWS", ur if ur != "0" else "1")
         with _hip.Hierarchy(A, R, smoother=smoother, dtype=dtype) as h:
             info = h.format_info(0)
             h.resident_load(b)
@@ -717,8 +721,8 @@ def test_device_format_modes_are_bit_identical(monkeypatch, golden, case):
             r, nr = h.residual(0, b, x, want_norm=True)
             rc = h.restrict(0, r)
             xp = h.prolong_add(0, rc, x)
-        runs[(mode, pk)] = (norms, x, r, nr, rc, xp, info)
-    base = runs[("0", "1")]
+        runs[(mode, pk, ur)] = (norms, x, r, nr, rc, xp, info)
+    base = runs[("0", "1", "4")]
     w = 4 if dtype == "float32" else 8
     assert base[6]["pattern_rows"] == 0 and base[6]["coldict_nnz"] == 0 and base[6]["valdict_nnz"] == 0
     assert base[6]["format_bytes"] == base[6]["csr_bytes"] + 32 * base[6]["blocks"]
@@ -730,9 +734,13 @@ def test_device_format_modes_are_bit_identical(monkeypatch, golden, case):
         np.testing.assert_allclose(run[3], base[3], rtol=1e-13, err_msg=str(key))
         for got, want in zip((run[1], run[2], run[4], run[5]), (base[1], base[2], base[4], base[5])):
             assert np.array_equal(got, want), key
-    full = runs[("7", "1")][6]
+    full = runs[("7", "1", "0")][6]
+    if case in ("poisson7", "poisson7_f32", "jacobi2d"):
+        # constant stencils, short rows: every block carries a union -> blocks of 4 x 256 rows
+        wide, std = runs[("15", "1", "4")][6], runs[("15", "1", "1")][6]
+        assert wide["pattern_rows"] == wide["rows"] and wide["blocks"] < std["blocks"]
     if case == "variable7":                                      # offsets repeat, values do not: offset patterns + ELL values
-        ell = runs[("15", "1")][6]
+        ell = runs[("15", "1", "0")][6]
         assert ell["pattern_rows"] == ell["rows"] and ell["format_bytes"] < 0.75 * ell["csr_bytes"]
     if case in ("poisson7", "poisson7_f32", "stencil27", "jacobi2d", "galerkin_golden"):
         assert full["pattern_rows"] == full["rows"]              # constant stencils: a byte per row
