@@ -179,6 +179,11 @@ int omg_level_restrict(omg_hierarchy *h, int level, const double *fine, double *
 int omg_level_prolong_add(omg_hierarchy *h, int level, const double *coarse, double *fine_inout);
 /* replaces: solvers.coarseSolve(A[-1], b) — openmg/solvers.py:16-26. */
 int omg_coarse_solve(omg_hierarchy *h, const double *b, double *x);
+/* How the coarsest operator is factored (the reference re-runs SuperLU on every cycle,
+ * openmg/solvers.py:23; here once at setup): out[0] = interior blocks P (1 = explicit dense
+ * inverse; > 1 = substructuring along the band into P blocks and P - 1 separators), out[1] =
+ * unknowns, out[2] = half-bandwidth, out[3] = device bytes one solve reads.                  */
+int omg_hierarchy_coarse_info(const omg_hierarchy *h, int64_t *out4);
 
 /* ---- standalone operations ----------------------------------------------------------- */
 /* replaces: tools.flexibleMmult(A, x) for sparse A, dense vector x — openmg/tools.py:26. */

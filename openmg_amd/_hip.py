@@ -82,6 +82,7 @@ SIGNATURES = {
     "omg_level_restrict": (_I, [_P, _I, _P, _P]),
     "omg_level_prolong_add": (_I, [_P, _I, _P, _P]),
     "omg_coarse_solve": (_I, [_P, _P, _P]),
+    "omg_hierarchy_coarse_info": (_I, [_P, _I64P]),
     "omg_spmv": (_I, [_CSR, _P, _P]),
     "omg_residual": (_I, [_CSR, _P, _P, _P, _DP]),
     "omg_gauss_seidel": (_I, [_CSR, _P, _P, _I, _D, _I, _D, _IP]),
@@ -392,6 +393,13 @@ class Hierarchy:
         out = vec(fine, self.sizes[level], copy=True)
         check(lib().omg_level_prolong_add(self._h, level, coarse.ctypes.data, out.ctypes.data))
         return out
+
+    def coarse_info(self):
+        """dict(blocks, n, half_bandwidth, bytes_per_solve) of the coarsest level's direct solver:
+        blocks == 1 is the explicit inverse, > 1 substructuring along the band."""
+        out = (ctypes.c_int64 * 4)()
+        check(lib().omg_hierarchy_coarse_info(self._h, out))
+        return {"blocks": int(out[0]), "n": int(out[1]), "half_bandwidth": int(out[2]), "bytes_per_solve": int(out[3])}
 
     def coarse_solve(self, b):
         b = vec(b, self.sizes[-1])

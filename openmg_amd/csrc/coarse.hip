@@ -1,0 +1,377 @@
+// Coarsest-level direct solve: explicit inverse, or substructuring along the band (common.h
+// CoarseSolver).  The reference re-factorises with SuperLU on every cycle
+// (openmg/solvers.py:23); here the factors are built once at setup.
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <type_traits>
+
+#include "common.h"
+
+namespace omg {
+namespace {
+
+constexpr int64_t LDS_DOUBLES = 6144;      // 48 KB: g and the longest interior block must fit (as V)
+
+int grid1d(int64_t n, int cap = 65536) {
+    int64_t g = (n + 255) / 256;
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+__device__ __forceinline__ double wsum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ float wsum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+// T[i, c] = sum_r B[i, r] Aig[r, c] for the interior block: thread (i, c) walks column c of the
+// coupling block (given column-wise: cptr / cidx / cval, rows local to the block).
+__global__ void couple_kernel(const double *B, int64_t m, const int32_t *cptr, const int32_t *cidx,
+                              const double *cval, int64_t g, double *T) {
+    const int64_t tot = m * g;
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < tot; t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t i = t / g, c = t % g;
+        double acc = 0.0;
+        for (int32_t p = cptr[c]; p < cptr[c + 1]; ++p) acc += B[i * m + cidx[p]] * cval[p];
+        T[t] = acc;
+    }
+}
+
+// S[q, c] -= sum_i Agi[q, i] T[i, c]: rows of A_GI restricted to this block (CSR, columns local)
+// (S: leading dimension ld — the left half of the augmented matrix its inversion works on)
+__global__ void schur_kernel(const int32_t *rptr, const int32_t *ridx, const double *rval, int64_t g,
+                             const double *T, double *S, int64_t ld) {
+    const int64_t tot = g * g;
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < tot; t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t q = t / g, c = t % g;
+        double acc = 0.0;
+        for (int32_t p = rptr[q]; p < rptr[q + 1]; ++p) acc += rval[p] * T[int64_t(ridx[p]) * g + c];
+        if (acc != 0.0) S[q * ld + c] -= acc;
+    }
+}
+
+template <typename V>
+__global__ void narrow_kernel(const double *src, V *dst, int64_t n) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        dst[i] = V(src[i]);
+}
+
+// ---- the solve ---------------------------------------------------------------------------
+// y_k = B_k b_I_k: one wave per interior row, four rows of one block per workgroup.
+template <typename V>
+__global__ __launch_bounds__(256) void interior_solve_kernel(const V *__restrict__ binv, const int64_t *__restrict__ binv_off,
+                                                             const int64_t *__restrict__ blk_off,
+                                                             const int32_t *__restrict__ wg_blk, const int32_t *__restrict__ wg_row,
+                                                             const int32_t *__restrict__ perm, const V *__restrict__ b,
+                                                             V *__restrict__ y) {
+    const int k = wg_blk[blockIdx.x];
+    const int64_t o = blk_off[k], m = blk_off[k + 1] - o;
+    const int64_t i = wg_row[blockIdx.x] + (threadIdx.x >> 6);
+    if (i >= m) return;
+    const int lane = threadIdx.x & 63;
+    const V *row = binv + binv_off[k] + i * m;
+    V acc = V(0);
+    for (int64_t j = lane; j < m; j += 64) acc += row[j] * b[perm[o + j]];
+    acc = wsum(acc);
+    if (lane == 0) y[o + i] = acc;
+}
+
+// x_G = S^-1 (b_G - A_GI y): the right-hand side is formed in LDS by the whole workgroup, then
+// one wave per row of S^-1.  Also leaves x_G in xg (permuted) for the back substitution.
+template <typename V>
+__global__ __launch_bounds__(256) void separator_solve_kernel(const V *__restrict__ sinv, int64_t g, int64_t n_int,
+                                                              const int32_t *__restrict__ gptr, const int32_t *__restrict__ gidx,
+                                                              const V *__restrict__ gval, const int32_t *__restrict__ perm,
+                                                              const V *__restrict__ b, const V *__restrict__ y,
+                                                              V *__restrict__ xg, V *__restrict__ x) {
+    extern __shared__ unsigned char s_raw[];
+    V *s_rhs = reinterpret_cast<V *>(s_raw);
+    for (int64_t q = threadIdx.x; q < g; q += 256) {
+        V acc = V(0);
+        for (int32_t p = gptr[q]; p < gptr[q + 1]; ++p) acc += gval[p] * y[gidx[p]];
+        s_rhs[q] = b[perm[n_int + q]] - acc;
+    }
+    __syncthreads();
+    const int64_t q = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (q >= g) return;
+    const int lane = threadIdx.x & 63;
+    const V *row = sinv + q * g;
+    V acc = V(0);
+    for (int64_t c = lane; c < g; c += 64) acc += row[c] * s_rhs[c];
+    acc = wsum(acc);
+    if (lane == 0) { xg[q] = acc; x[perm[n_int + q]] = acc; }
+}
+
+// x_I_k = y_k - B_k t, t = A_I_kG x_G: t is nonzero only within w of the block's ends, so only
+// those columns of B_k are read.  t is formed in LDS by the whole workgroup.
+template <typename V>
+__global__ __launch_bounds__(256) void interior_correct_kernel(const V *__restrict__ binv, const int64_t *__restrict__ binv_off,
+                                                               const int64_t *__restrict__ blk_off,
+                                                               const int32_t *__restrict__ wg_blk, const int32_t *__restrict__ wg_row,
+                                                               const int32_t *__restrict__ iptr, const int32_t *__restrict__ iidx,
+                                                               const V *__restrict__ ival, const V *__restrict__ xg,
+                                                               const int32_t *__restrict__ perm, const V *__restrict__ y,
+                                                               int64_t w, V *__restrict__ x) {
+    extern __shared__ unsigned char s_raw[];
+    V *s_t = reinterpret_cast<V *>(s_raw);          // 2 w entries: the first w and the last w rows of the block
+    const int k = wg_blk[blockIdx.x];
+    const int64_t o = blk_off[k], m = blk_off[k + 1] - o;
+    const int64_t head = min(w, m), tail0 = max(head, m - w);       // columns [0, head) and [tail0, m)
+    const int64_t nt = head + (m - tail0);
+    for (int64_t c = threadIdx.x; c < nt; c += 256) {
+        const int64_t j = c < head ? c : tail0 + (c - head);
+        V acc = V(0);
+        for (int32_t p = iptr[o + j]; p < iptr[o + j + 1]; ++p) acc += ival[p] * xg[iidx[p]];
+        s_t[c] = acc;
+    }
+    __syncthreads();
+    const int64_t i = wg_row[blockIdx.x] + (threadIdx.x >> 6);
+    if (i >= m) return;
+    const int lane = threadIdx.x & 63;
+    const V *row = binv + binv_off[k] + i * m;
+    V acc = V(0);
+    for (int64_t c = lane; c < nt; c += 64) {
+        const int64_t j = c < head ? c : tail0 + (c - head);
+        acc += row[j] * s_t[c];
+    }
+    acc = wsum(acc);
+    if (lane == 0) x[perm[o + i]] = y[o + i] - acc;
+}
+
+struct HostSub {            // small host CSR / CSC piece
+    std::vector<int32_t> ptr, idx;
+    std::vector<double> val;
+};
+
+template <typename T>
+void put(DevBuf<T> &d, const std::vector<T> &h, hipStream_t s) {
+    d.alloc(std::max<size_t>(h.size(), 1));
+    d.upload(h.data(), h.size(), s);
+}
+
+template <typename V>
+void put_values(DevBuf<V> &d, const std::vector<double> &h, hipStream_t s, std::vector<V> &keep) {
+    keep.assign(h.begin(), h.end());
+    d.alloc(std::max<size_t>(keep.size(), 1));
+    d.upload(keep.data(), keep.size(), s);
+}
+
+}  // namespace
+
+template <typename V>
+void CoarseSolver<V>::build(const HostCsr &A, hipStream_t s) {
+    OMG_REQUIRE(A.n_rows == A.n_cols, "coarse operator must be square");
+    n = A.n_rows;
+    if (n == 0) return;
+    // half-bandwidth
+    int64_t band = 0;
+    for (int64_t i = 0; i < n; ++i)
+        for (int32_t p = A.indptr[i]; p < A.indptr[i + 1]; ++p) band = std::max<int64_t>(band, std::llabs(int64_t(A.indices[p]) - i));
+    w = std::max<int64_t>(band, 1);
+    // number of interior blocks: least stored bytes subject to the LDS limits of the solve kernels
+    const int64_t lds_cap = LDS_DOUBLES * int64_t(sizeof(double) / sizeof(V));      // elements of V in 48 KB
+    P = 1;
+    {
+        const char *e = getenv("OMG_COARSE_BLOCKS");         // 1 forces the explicit inverse
+        const int forced = e ? atoi(e) : 0;
+        // Measured at 256^3 / 5 grids (n = 4096, w = 256): the inverse's one 134 MB mat-vec takes
+        // 26 us, the three dependent launches of the substructured solve 39 us although they read
+        // 40 MB — so substructuring is for operators whose inverse would not even fit the 256 MiB
+        // Infinity Cache (n > 5792 in double): 128^2 5-point, 0.5 ms -> 0.05 ms per solve.
+        const bool big = double(n) * double(n) * sizeof(V) > double(size_t(256) << 20);
+        double best = double(n) * double(n);
+        if (forced > 1 || (forced == 0 && big))
+            for (int q = 2; q <= 64; ++q) {
+                const int64_t gq = int64_t(q - 1) * w;
+                if (gq >= n || gq > lds_cap || 2 * w > lds_cap) break;
+                const int64_t mq = (n - gq + q - 1) / q;
+                if (mq < 2 * w) break;                        // blocks shorter than their couplings: no gain
+                const double cost = double(q) * double(mq) * double(mq) + double(gq) * double(gq);
+                if ((forced == q) || (forced == 0 && cost < best)) { best = cost; P = q; }
+                if (forced == q) break;
+            }
+    }
+    std::vector<int32_t> plain_ptr(A.indptr.begin(), A.indptr.end());
+    DevBuf<int32_t> d_ptr, d_idx;
+    DevBuf<double> d_val;
+    put(d_ptr, plain_ptr, s);
+    put(d_idx, A.indices, s);
+    put(d_val, A.data, s);
+    if (P == 1) {
+        if (n > 16384)
+            throw Error(OMG_ERR_UNSUPPORTED, "coarsest level has " + std::to_string(n) + " unknowns and a half-bandwidth of " +
+                                                 std::to_string(band) + ": neither the explicit inverse (n <= 16384) nor "
+                                                 "substructuring along the band applies — use more gridLevels");
+        std::vector<int32_t> ident((size_t)(n));
+        for (int64_t i = 0; i < n; ++i) ident[i] = int32_t(i);
+        DevBuf<int32_t> d_map;
+        put(d_map, ident, s);
+        DevBuf<double> W((size_t)(n) * (size_t)(2 * n)), inv64((size_t)(n) * (size_t)(n));
+        fill_augmented_from_csr(d_ptr.p, d_idx.p, d_val.p, n, d_map.p, d_map.p, n, W.p, s);
+        gauss_jordan_inverse(W.p, n, inv64.p, s);
+        inv.alloc((size_t)(n) * (size_t)(n));
+        hipLaunchKernelGGL((narrow_kernel<V>), dim3(grid1d(n * n)), dim3(256), 0, s, inv64.p, inv.p, n * n);
+        OMG_HIP(hipStreamSynchronize(s));
+        bytes = (size_t)(n) * (size_t)(n) * sizeof(V);
+        return;
+    }
+    // ---- partition: [I_0][G_0][I_1][G_1] ... [I_{P-1}] in the original numbering -------------
+    g = int64_t(P - 1) * w;
+    n_int = n - g;
+    std::vector<int64_t> h_off((size_t)(P) + 1, 0), h_boff((size_t)(P) + 1, 0), start((size_t)(P), 0);
+    std::vector<int32_t> h_perm((size_t)(n)), to_int((size_t)(n), -1), to_gam((size_t)(n), -1), blk_of((size_t)(n), -1);
+    {
+        int64_t pos = 0;
+        for (int k = 0; k < P; ++k) {
+            const int64_t m = n_int / P + (k < n_int % P ? 1 : 0);
+            start[k] = pos;
+            h_off[k + 1] = h_off[k] + m;
+            h_boff[k + 1] = h_boff[k] + m * m;
+            for (int64_t j = 0; j < m; ++j) {
+                h_perm[h_off[k] + j] = int32_t(pos + j);
+                to_int[pos + j] = int32_t(h_off[k] + j);
+                blk_of[pos + j] = k;
+            }
+            pos += m;
+            if (k + 1 < P)
+                for (int64_t j = 0; j < w; ++j) {
+                    h_perm[n_int + int64_t(k) * w + j] = int32_t(pos + j);
+                    to_gam[pos + j] = int32_t(int64_t(k) * w + j);
+                }
+            pos += (k + 1 < P) ? w : 0;
+        }
+    }
+    // sparse couplings (host): A_GI by rows (columns permuted interior), A_IG by rows (columns
+    // Gamma-local); per block: A_IG column-wise with block-local rows, A_GI rows with block-local columns
+    HostSub gi, ig;
+    gi.ptr.assign((size_t)(g) + 1, 0);
+    ig.ptr.assign((size_t)(n_int) + 1, 0);
+    std::vector<HostSub> col_k((size_t)(P)), row_k((size_t)(P));
+    for (int k = 0; k < P; ++k) { col_k[k].ptr.assign((size_t)(g) + 1, 0); row_k[k].ptr.assign((size_t)(g) + 1, 0); }
+    for (int64_t q = 0; q < g; ++q) {
+        const int64_t i = h_perm[n_int + q];
+        for (int32_t p = A.indptr[i]; p < A.indptr[i + 1]; ++p) {
+            const int32_t c = A.indices[p];
+            if (to_int[c] >= 0) {
+                gi.idx.push_back(to_int[c]);
+                gi.val.push_back(A.data[p]);
+                HostSub &rk = row_k[blk_of[c]];
+                rk.idx.push_back(int32_t(to_int[c] - h_off[blk_of[c]]));
+                rk.val.push_back(A.data[p]);
+                rk.ptr[q + 1]++;
+            }
+        }
+        gi.ptr[q + 1] = int32_t(gi.idx.size());
+    }
+    for (int k = 0; k < P; ++k)
+        for (int64_t q = 0; q < g; ++q) row_k[k].ptr[q + 1] += row_k[k].ptr[q];
+    {
+        std::vector<std::vector<std::pair<int32_t, double>>> cols((size_t)(g));
+        for (int64_t r = 0; r < n_int; ++r) {
+            const int64_t i = h_perm[r];
+            for (int32_t p = A.indptr[i]; p < A.indptr[i + 1]; ++p) {
+                const int32_t c = A.indices[p];
+                if (to_gam[c] >= 0) {
+                    ig.idx.push_back(to_gam[c]);
+                    ig.val.push_back(A.data[p]);
+                    OMG_REQUIRE(blk_of[i] >= 0, "coarse solve: partition error");
+                }
+            }
+            ig.ptr[r + 1] = int32_t(ig.idx.size());
+        }
+        for (int k = 0; k < P; ++k) {
+            for (auto &c : cols) c.clear();
+            for (int64_t r = h_off[k]; r < h_off[k + 1]; ++r)
+                for (int32_t p = ig.ptr[r]; p < ig.ptr[r + 1]; ++p) cols[ig.idx[p]].emplace_back(int32_t(r - h_off[k]), ig.val[p]);
+            HostSub &ck = col_k[k];
+            for (int64_t c = 0; c < g; ++c) {
+                for (auto &e : cols[c]) { ck.idx.push_back(e.first); ck.val.push_back(e.second); }
+                ck.ptr[c + 1] = int32_t(ck.idx.size());
+            }
+        }
+    }
+    // ---- device: B_k, Schur complement, its inverse ----------------------------------------
+    DevBuf<int32_t> d_toint, d_togam;
+    put(d_toint, to_int, s);
+    put(d_togam, to_gam, s);
+    DevBuf<double> b64((size_t)(h_boff[P])), S((size_t)(g) * (size_t)(g) * 2), sinv64((size_t)(g) * (size_t)(g));
+    // S starts as A_GG (built as the left half of an augmented [A_GG | I], reused for its inversion)
+    fill_augmented_from_csr(d_ptr.p, d_idx.p, d_val.p, n, d_togam.p, d_togam.p, g, S.p, s);
+    int64_t m_max = 0;
+    for (int k = 0; k < P; ++k) m_max = std::max(m_max, h_off[k + 1] - h_off[k]);
+    DevBuf<double> W((size_t)(m_max) * (size_t)(2 * m_max)), T((size_t)(m_max) * (size_t)(g));
+    std::vector<int32_t> rmap((size_t)(n));
+    DevBuf<int32_t> d_rmap((size_t)(n)), c_ptr, c_idx, r_ptr, r_idx;
+    DevBuf<double> c_val, r_val;
+    for (int k = 0; k < P; ++k) {
+        const int64_t m = h_off[k + 1] - h_off[k];
+        for (int64_t i = 0; i < n; ++i) rmap[i] = (blk_of[i] == k) ? int32_t(to_int[i] - h_off[k]) : -1;
+        d_rmap.upload(rmap.data(), (size_t)(n), s);
+        OMG_HIP(hipStreamSynchronize(s));
+        fill_augmented_from_csr(d_ptr.p, d_idx.p, d_val.p, n, d_rmap.p, d_rmap.p, m, W.p, s);
+        gauss_jordan_inverse(W.p, m, b64.p + h_boff[k], s);
+        put(c_ptr, col_k[k].ptr, s); put(c_idx, col_k[k].idx, s); put(c_val, col_k[k].val, s);
+        put(r_ptr, row_k[k].ptr, s); put(r_idx, row_k[k].idx, s); put(r_val, row_k[k].val, s);
+        hipLaunchKernelGGL(couple_kernel, dim3(grid1d(m * g)), dim3(256), 0, s, b64.p + h_boff[k], m, c_ptr.p, c_idx.p,
+                           c_val.p, g, T.p);
+        // S -= A_GI_k T
+        hipLaunchKernelGGL(schur_kernel, dim3(grid1d(g * g)), dim3(256), 0, s, r_ptr.p, r_idx.p, r_val.p, g, T.p, S.p, 2 * g);
+        OMG_HIP(hipGetLastError());
+        OMG_HIP(hipStreamSynchronize(s));          // host staging of this block may be reused
+    }
+    gauss_jordan_inverse(S.p, g, sinv64.p, s);
+    // ---- stored factors (V) ----------------------------------------------------------------
+    binv.alloc((size_t)(h_boff[P]));
+    sinv.alloc((size_t)(g) * (size_t)(g));
+    hipLaunchKernelGGL((narrow_kernel<V>), dim3(grid1d(h_boff[P])), dim3(256), 0, s, b64.p, binv.p, h_boff[P]);
+    hipLaunchKernelGGL((narrow_kernel<V>), dim3(grid1d(g * g)), dim3(256), 0, s, sinv64.p, sinv.p, g * g);
+    put(blk_off, h_off, s);
+    put(binv_off, h_boff, s);
+    put(perm, h_perm, s);
+    std::vector<int32_t> h_wblk, h_wrow;
+    for (int k = 0; k < P; ++k)
+        for (int64_t r = 0; r < h_off[k + 1] - h_off[k]; r += 4) { h_wblk.push_back(k); h_wrow.push_back(int32_t(r)); }
+    n_wg = int64_t(h_wblk.size());
+    put(wg_blk, h_wblk, s);
+    put(wg_row, h_wrow, s);
+    std::vector<V> keep1, keep2;
+    put(gi_ptr, gi.ptr, s); put(gi_idx, gi.idx, s); put_values(gi_val, gi.val, s, keep1);
+    put(ig_ptr, ig.ptr, s); put(ig_idx, ig.idx, s); put_values(ig_val, ig.val, s, keep2);
+    y.alloc((size_t)(n_int));
+    xg.alloc((size_t)(g));
+    OMG_HIP(hipStreamSynchronize(s));
+    size_t corr = 0;
+    for (int k = 0; k < P; ++k) {
+        const int64_t m = h_off[k + 1] - h_off[k];
+        corr += (size_t)(m) * (size_t)(std::min<int64_t>(2 * w, m));
+    }
+    bytes = ((size_t)(h_boff[P]) + (size_t)(g) * (size_t)(g) + corr) * sizeof(V);
+}
+
+template <typename V>
+void CoarseSolver<V>::solve(const V *b, V *x, hipStream_t s) const {
+    if (n == 0) return;
+    if (P == 1) {
+        launch_dense_gemv<V>(inv.p, b, x, n, s);
+        return;
+    }
+    hipLaunchKernelGGL((interior_solve_kernel<V>), dim3((unsigned)n_wg), dim3(256), 0, s, binv.p, binv_off.p, blk_off.p,
+                       wg_blk.p, wg_row.p, perm.p, b, y.p);
+    hipLaunchKernelGGL((separator_solve_kernel<V>), dim3((unsigned)((g + 3) / 4)), dim3(256), (size_t)(g) * sizeof(V), s,
+                       sinv.p, g, n_int, gi_ptr.p, gi_idx.p, gi_val.p, perm.p, b, y.p, xg.p, x);
+    hipLaunchKernelGGL((interior_correct_kernel<V>), dim3((unsigned)n_wg), dim3(256), (size_t)(2 * w) * sizeof(V), s, binv.p,
+                       binv_off.p, blk_off.p, wg_blk.p, wg_row.p, ig_ptr.p, ig_idx.p, ig_val.p, xg.p, perm.p, y.p, w, x);
+    OMG_HIP(hipGetLastError());
+}
+
+template struct CoarseSolver<double>;
+template struct CoarseSolver<float>;
+
+}  // namespace omg

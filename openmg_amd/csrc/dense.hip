@@ -30,6 +30,21 @@ __global__ void csr_scatter_dense_kernel(const int32_t *indptr, const int32_t *i
             atomicAdd(&W[r * ld + indices[p]], data[p]);   // duplicates add, like A[i, j] in SciPy
 }
 
+// The same for a sub-block: entry (r, c) goes to W[rmap[r] * ld + cmap[c]] when both maps are >= 0.
+__global__ void csr_scatter_sub_kernel(const int32_t *indptr, const int32_t *indices, const double *data,
+                                       int64_t n_rows, const int32_t *rmap, const int32_t *cmap, double *W,
+                                       int64_t ld) {
+    for (int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r < n_rows;
+         r += (int64_t)gridDim.x * blockDim.x) {
+        const int32_t lr = rmap[r];
+        if (lr < 0) continue;
+        for (int32_t p = indptr[r]; p < indptr[r + 1]; ++p) {
+            const int32_t lc = cmap[indices[p]];
+            if (lc >= 0) atomicAdd(&W[int64_t(lr) * ld + lc], data[p]);
+        }
+    }
+}
+
 // argmax_{i >= k} |W[i, k]|  ->  piv[0] = row, flag set when the column is exactly zero.
 __global__ __launch_bounds__(1024) void pivot_kernel(const double *W, int64_t n, int64_t ld,
                                                      int64_t k, int *piv, int *singular) {
@@ -119,6 +134,41 @@ int grid1d(int64_t n) {
 
 }  // namespace
 
+// Gauss-Jordan with partial pivoting on a prepared augmented matrix W = [M | I] (row-major
+// n x 2n, destroyed); the inverse goes to Minv (n*n doubles).  ~4 n dependent launches.
+void gauss_jordan_inverse(double *W, int64_t n, double *Minv, hipStream_t s) {
+    if (n == 0) return;
+    const int64_t ld = 2 * n;
+    DevBuf<double> colk(n);
+    DevBuf<int> piv(2);
+    piv.zero(s);
+    int *singular = piv.p + 1;
+    const dim3 egrid((unsigned)((ld + 255) / 256), (unsigned)std::min<int64_t>(n, 64));
+    for (int64_t k = 0; k < n; ++k) {
+        hipLaunchKernelGGL(pivot_kernel, dim3(1), dim3(1024), 0, s, W, n, ld, k, piv.p, singular);
+        hipLaunchKernelGGL(column_kernel, dim3(grid1d(n)), dim3(256), 0, s, W, n, ld, k, piv.p, colk.p);
+        hipLaunchKernelGGL(swap_scale_kernel, dim3(grid1d(ld)), dim3(256), 0, s, W, ld, k, piv.p, colk.p);
+        hipLaunchKernelGGL(eliminate_kernel, egrid, dim3(256), 0, s, W, n, ld, k, colk.p);
+    }
+    OMG_HIP(hipGetLastError());
+    hipLaunchKernelGGL(extract_inverse_kernel, dim3(grid1d(n * n)), dim3(256), 0, s, W, n, Minv);
+    int flag = 0;
+    OMG_HIP(hipMemcpyAsync(&flag, singular, sizeof(int), hipMemcpyDeviceToHost, s));
+    OMG_HIP(hipStreamSynchronize(s));
+    if (flag) throw Error(OMG_ERR_SINGULAR, "coarsest operator is singular to working precision");
+}
+
+// W = [sub-block of A | I]: rows / columns of the plain device CSR (indptr, indices, data) whose
+// maps are >= 0 land at (rmap[r], cmap[c]); m = size of the sub-block.
+void fill_augmented_from_csr(const int32_t *indptr, const int32_t *indices, const double *data, int64_t n_rows,
+                             const int32_t *rmap, const int32_t *cmap, int64_t m, double *W, hipStream_t s) {
+    if (m == 0) return;
+    hipLaunchKernelGGL(fill_aug_kernel, dim3(grid1d(m * 2 * m)), dim3(256), 0, s, W, m);
+    hipLaunchKernelGGL(csr_scatter_sub_kernel, dim3(grid1d(n_rows)), dim3(256), 0, s, indptr, indices, data, n_rows,
+                       rmap, cmap, W, 2 * m);
+    OMG_HIP(hipGetLastError());
+}
+
 // Build the dense inverse of the (square) device CSR matrix A into Minv (n*n doubles).
 void dense_inverse_from_csr(const DevCsr &A, double *Minv, hipStream_t s) {
     const int64_t n = A.n_rows;
@@ -130,26 +180,10 @@ void dense_inverse_from_csr(const DevCsr &A, double *Minv, hipStream_t s) {
                         " unknowns; the dense direct solve is limited to 16384 — use more gridLevels");
     const int64_t ld = 2 * n;
     DevBuf<double> W(size_t(n) * size_t(ld));
-    DevBuf<double> colk(n);
-    DevBuf<int> piv(2);
-    piv.zero(s);
-    int *singular = piv.p + 1;
     hipLaunchKernelGGL(fill_aug_kernel, dim3(grid1d(n * ld)), dim3(256), 0, s, W.p, n);
     hipLaunchKernelGGL(csr_scatter_dense_kernel, dim3(grid1d(n)), dim3(256), 0, s, A.indptr.p,
                        A.indices.p, A.data.p, n, W.p, ld);
-    const dim3 egrid((unsigned)((ld + 255) / 256), (unsigned)std::min<int64_t>(n, 64));
-    for (int64_t k = 0; k < n; ++k) {
-        hipLaunchKernelGGL(pivot_kernel, dim3(1), dim3(1024), 0, s, W.p, n, ld, k, piv.p, singular);
-        hipLaunchKernelGGL(column_kernel, dim3(grid1d(n)), dim3(256), 0, s, W.p, n, ld, k, piv.p, colk.p);
-        hipLaunchKernelGGL(swap_scale_kernel, dim3(grid1d(ld)), dim3(256), 0, s, W.p, ld, k, piv.p, colk.p);
-        hipLaunchKernelGGL(eliminate_kernel, egrid, dim3(256), 0, s, W.p, n, ld, k, colk.p);
-    }
-    OMG_HIP(hipGetLastError());
-    hipLaunchKernelGGL(extract_inverse_kernel, dim3(grid1d(n * n)), dim3(256), 0, s, W.p, n, Minv);
-    int flag = 0;
-    OMG_HIP(hipMemcpyAsync(&flag, singular, sizeof(int), hipMemcpyDeviceToHost, s));
-    OMG_HIP(hipStreamSynchronize(s));
-    if (flag) throw Error(OMG_ERR_SINGULAR, "coarsest operator is singular to working precision");
+    gauss_jordan_inverse(W.p, n, Minv, s);
 }
 
 }  // namespace omg

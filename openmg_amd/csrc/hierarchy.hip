@@ -64,7 +64,7 @@ template <typename V>
 struct Hier {
     using value_type = V;
     std::vector<Level<V>> lv;
-    DevBuf<V> coarse_inv;
+    CoarseSolver<V> coarse;   // direct solve of the coarsest operator (common.h)
     DevBuf<double> norm_dev;
     int smoother = OMG_SMOOTH_GS_LEX;
     double omega = 1.0;
@@ -264,7 +264,7 @@ void prolong_add_level(Hier<V> *h, int l, const V *coarse, V *fine) {
 template <typename V>
 void coarse_solve_level(Hier<V> *h) {
     Level<V> &L = h->lv.back();
-    launch_dense_gemv<V>(h->coarse_inv.p, L.b.p, L.xp, L.n, h->stream);
+    h->coarse.solve(L.b.p, L.xp, h->stream);
 }
 
 // openmg/__init__.py:199-234 with the dead work removed: R[l]*b (:205-206) is computed by the
@@ -416,10 +416,11 @@ std::unique_ptr<Hier<V>> create(int n_levels, const omg_csr *A, const omg_csr *R
     h->stream = h->own;
     h->lv.resize(n_levels);
     h->norm_dev.alloc(1);
-    // The coarsest operator is inverted once (reference: SuperLU factorisation on every
-    // cycle).  That is ~16k tiny dependent launches, so it runs on a helper thread with its
-    // own stream while this thread does the index work of the smoothed levels.  The inverse
-    // is always computed in double; a float hierarchy stores its rounding.
+    // The coarsest operator is factored once (reference: SuperLU factorisation on every
+    // cycle; here: explicit inverse or substructuring along the band, common.h CoarseSolver).
+    // That is thousands of tiny dependent launches, so it runs on a helper thread with its own
+    // stream while this thread does the index work of the smoothed levels.  The factors are
+    // always computed in double; a float hierarchy stores their rounding.
     int device = 0;
     OMG_HIP(hipGetDevice(&device));
     {
@@ -438,18 +439,7 @@ std::unique_ptr<Hier<V>> create(int n_levels, const omg_csr *A, const omg_csr *R
             Lv &L = h->lv.back();
             HostCsr Ap = permute_csr(A[n_levels - 1], nullptr, nullptr);
             L.A.upload(Ap, L.ord.sets, s);
-            const size_t nn = std::max<size_t>(size_t(L.n) * size_t(L.n), 1);
-            h->coarse_inv.alloc(nn);
-            if constexpr (std::is_same<V, double>::value) {
-                dense_inverse_from_csr(L.A, h->coarse_inv.p, s);
-            } else {
-                DevCsr A64;
-                A64.upload(Ap, L.ord.sets, s);
-                DevBuf<double> inv64(nn);
-                dense_inverse_from_csr(A64, inv64.p, s);
-                launch_gather<double, V>(inv64.p, nullptr, h->coarse_inv.p, int64_t(size_t(L.n) * size_t(L.n)), s);
-                OMG_HIP(hipStreamSynchronize(s));     // before inv64 is released
-            }
+            h->coarse.build(Ap, s);               // factors in double, stored in V
         } catch (const Error &e) {
             inv_code = e.code;
             inv_msg = e.what();
@@ -1004,6 +994,18 @@ int omg_coarse_solve(omg_hierarchy *h, const double *b, double *x) {
     });
 }
 
+int omg_hierarchy_coarse_info(const omg_hierarchy *h, int64_t *out4) {
+    return guarded([&] {
+        OMG_REQUIRE(out4, "null argument");
+        with(h, [&](auto *hh) {
+            out4[0] = hh->coarse.P;
+            out4[1] = hh->coarse.n;
+            out4[2] = hh->coarse.w;
+            out4[3] = int64_t(hh->coarse.bytes);
+        });
+    });
+}
+
 // ---- standalone (double only: these mirror the reference's fp64 operators one to one) -------
 static void standalone_rows(const omg_csr *A, int mode, const double *x, const double *b,
                             double *y, double *norm) {
@@ -1103,10 +1105,11 @@ int omg_direct_solve(const omg_csr *A, const double *b, double *x) {
         HostCsr Ah = permute_csr(*A, nullptr, nullptr);
         os.A.upload(Ah, {}, os.s);
         const int64_t n = A->n_rows;
-        DevBuf<double> inv(std::max<size_t>(size_t(n) * size_t(n), 1)), db(std::max<int64_t>(n, 1)), dx(std::max<int64_t>(n, 1));
-        dense_inverse_from_csr(os.A, inv.p, os.s);
+        DevBuf<double> db(std::max<int64_t>(n, 1)), dx(std::max<int64_t>(n, 1));
+        CoarseSolver<double> cs;
+        cs.build(Ah, os.s);
         db.upload(b, n, os.s);
-        launch_dense_gemv<double>(inv.p, db.p, dx.p, n, os.s);
+        cs.solve(db.p, dx.p, os.s);
         dx.download(x, n, os.s);
         OMG_HIP(hipStreamSynchronize(os.s));
     });

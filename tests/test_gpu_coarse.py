@@ -1,0 +1,135 @@
+"""Coarsest-level direct solve on the device (csrc/coarse.hip) against SciPy's SuperLU — what
+openmg/solvers.py:16-26 calls.  Explicit inverse for small / wide-band operators, substructuring
+along the band otherwise (no 16384-unknown limit for banded operators any more).  -m gpu."""
+import time
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import scipy.sparse.linalg as spla
+
+import openmg_amd
+from openmg_amd import _hip, operators, solvers
+from oracle import mg_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def banded_unsymmetric(n, w, rng, density=0.3):
+    """Strictly diagonally dominant, unsymmetric values and pattern, half-bandwidth exactly w,
+    stored column order shuffled."""
+    rows, cols, vals = [], [], []
+    for off in range(-w, w + 1):
+        if off == 0:
+            continue
+        keep = rng.random(n - abs(off)) < (1.0 if abs(off) == w else density)
+        i = np.arange(max(0, -off), min(n, n - off))[keep]
+        rows.append(i); cols.append(i + off); vals.append(rng.standard_normal(i.size))
+    A = sp.csr_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(n, n))
+    d = np.asarray(abs(A).sum(axis=1)).ravel() + 1.0
+    A = sp.csr_matrix(A + sp.diags(d * np.where(rng.random(n) < 0.5, 1.0, -1.0)))
+    for i in range(n):
+        s, e = A.indptr[i], A.indptr[i + 1]
+        q = rng.permutation(e - s)
+        A.indices[s:e] = A.indices[s:e][q]
+        A.data[s:e] = A.data[s:e][q]
+    A.has_sorted_indices = False
+    return A
+
+
+@pytest.mark.parametrize("case", ["poisson3d_16", "poisson2d_128", "galerkin_16", "banded_unsym", "poisson2d_160", "dense_small"])
+def test_direct_solve_against_superlu(monkeypatch, case):
+    rng = np.random.default_rng(5)
+    if case == "poisson3d_16":
+        A = operators.stencil_poisson((16, 16, 16))               # n 4096, w 256
+    elif case == "poisson2d_128":
+        A = operators.stencil_poisson((128, 128))                 # n 16384, w 128: configs[1]'s coarsest level
+    elif case == "galerkin_16":
+        A0 = operators.stencil_poisson((32, 32, 32))
+        R = operators.restriction((32, 32, 32))
+        A = _hip.rap(R, A0)                                       # the coarse operator of a real hierarchy
+    elif case == "banded_unsym":
+        A = banded_unsymmetric(5000, 37, rng)
+    elif case == "poisson2d_160":
+        A = operators.stencil_poisson((160, 160))                 # n 25600 > the old 16384 limit
+    else:
+        A = sp.csr_matrix(rng.standard_normal((300, 300)) + 40 * np.eye(300))
+    n = A.shape[0]
+    b = rng.standard_normal(n)
+    want = spla.spsolve(sp.csc_matrix(A), b)
+    scale = np.abs(want).max()
+    got = solvers.coarseSolve(A, b.reshape(-1, 1))                # the reference's entry point
+    assert got.shape == (n,)
+    np.testing.assert_allclose(got, want, rtol=1e-10, atol=1e-12 * scale)
+    assert np.linalg.norm(b - A @ got) <= 1e-11 * np.linalg.norm(b) * max(1.0, np.linalg.cond(A.toarray()) if n <= 300 else 1e3)
+    if n <= 16384:
+        monkeypatch.setenv("OMG_COARSE_BLOCKS", "1")              # explicit inverse: the round-1 path
+        dense = _hip.direct_solve(A, b)
+        np.testing.assert_allclose(dense, want, rtol=1e-10, atol=1e-12 * scale)
+    monkeypatch.setenv("OMG_COARSE_BLOCKS", "3")                  # substructured whatever the size (3 blocks, 2 separators)
+    sub = _hip.direct_solve(A, b)
+    np.testing.assert_allclose(sub, want, rtol=1e-10, atol=1e-12 * scale)
+
+
+def test_hierarchy_coarse_solver_kind_and_cycle_parity(monkeypatch):
+    """Inside a hierarchy: the 16^3 coarsest level (134 MB inverse: fits the Infinity Cache) keeps
+    the explicit inverse by default; forced to 4 blocks + 3 separators (w = 256) it reads a third
+    of the bytes, and the V-cycle iterate does not depend on which coarse solver runs beyond
+    rounding (both are direct solves)."""
+    shape = (64, 64, 64)
+    A0 = operators.stencil_poisson(shape)
+    R = operators.restrictionList(shape, 1, 8)                    # 64^3, 32^3, 16^3
+    A = operators.coeffecientList(A0, R)
+    b = A0 @ np.random.default_rng(12345).random(A0.shape[0])
+    out = {}
+    for blocks in ("4", "0"):
+        monkeypatch.setenv("OMG_COARSE_BLOCKS", blocks)
+        for dtype in ("float64", "float32"):
+            with _hip.Hierarchy(A, R, smoother="colour", dtype=dtype) as h:
+                info = h.coarse_info()
+                bc = np.random.default_rng(3).random(4096)
+                xc = h.coarse_solve(bc)
+                h.resident_load(b)
+                norms = [h.resident_cycle(1, 1) for _ in range(3)]
+                out[(blocks, dtype)] = (info, xc, norms, h.resident_fetch())
+    sub, inv = out[("4", "float64")], out[("0", "float64")]
+    assert sub[0]["blocks"] > 1 and sub[0]["n"] == 4096 and sub[0]["half_bandwidth"] == 256
+    assert inv[0]["blocks"] == 1 and inv[0]["bytes_per_solve"] == 4096 * 4096 * 8
+    assert sub[0]["bytes_per_solve"] < 0.45 * inv[0]["bytes_per_solve"]
+    want = spla.spsolve(sp.csc_matrix(A[2]), np.random.default_rng(3).random(4096))
+    for run in (sub, inv):
+        np.testing.assert_allclose(run[1], want, rtol=1e-10, atol=1e-13)
+    np.testing.assert_allclose(sub[2], inv[2], rtol=1e-11)
+    np.testing.assert_allclose(sub[3], inv[3], rtol=1e-10, atol=1e-13)
+    eps32 = float(np.finfo(np.float32).eps)
+    s32, i32 = out[("4", "float32")], out[("0", "float32")]
+    cond = np.linalg.cond(A[2].toarray())
+    np.testing.assert_allclose(s32[1], want, rtol=0, atol=16 * eps32 * cond * np.abs(want).max())
+    np.testing.assert_allclose(s32[2], i32[2], rtol=1e-3)
+
+
+def test_config1_setup_and_cycle_no_longer_dominated_by_the_coarse_solve():
+    """1024^2 / 4 grids (coarsest 128^2 = 16384 unknowns) needed a 2.1 GB inverse
+    and 9 s of setup.  Substructured: ~150 MB read per solve; the whole hierarchy is built in
+    seconds and mgCycle at the coarsest level (the reference's direct-solve branch) works."""
+    shape = (1024, 1024)
+    A0 = operators.stencil_poisson(shape)
+    R = operators.restrictionList(shape, 2, 8)
+    A = operators.coeffecientList(A0, R)
+    t0 = time.perf_counter()
+    h = _hip.Hierarchy(A, R, smoother="jacobi", omega=2.0 / 3.0)
+    setup = time.perf_counter() - t0
+    try:
+        info = h.coarse_info()
+        assert info["n"] == 16384 and info["half_bandwidth"] == 128 and info["blocks"] > 1
+        assert info["bytes_per_solve"] < 260e6                    # the inverse: 2.1e9
+        assert setup < 6.0, setup
+        bc = np.random.default_rng(1).random(16384)
+        np.testing.assert_allclose(h.coarse_solve(bc), spla.spsolve(sp.csc_matrix(A[3]), bc), rtol=1e-10, atol=1e-13)
+    finally:
+        h.close()
+    # the reference's `else` branch of mgCycle (openmg/__init__.py:229-234)
+    p = {"preIterations": 1, "postIterations": 1, "coarsestLevel": 3}
+    top, info = openmg_amd.mgCycle(A, bc, 3, R, p)
+    assert info["norm"] == 0
+    np.testing.assert_allclose(top, orc.coarse_solve(A[3], bc.reshape(-1, 1)), rtol=1e-10, atol=1e-13)
