@@ -123,7 +123,9 @@ struct Dist {
     // coarsest level: replicated inverse, gathered right-hand side
     int64_t n_coarse = 0, coarse_lo = 0;
     std::vector<int64_t> coarse_counts;        // rows per rank at the coarsest level
-    DevBuf<V> coarse_inv, coarse_rhs, coarse_sol;
+    CoarseSolver<V> coarse;                    // replicated direct solver of the last distributed level
+    bool have_coarse = false;
+    DevBuf<V> coarse_rhs, coarse_sol;
     DevBuf<double> tail_rhs, tail_sol;         // the tail hierarchy's device boundary is double
     // Optional replicated TAIL: instead of one direct solve, every rank runs the levels below
     // the last distributed one as an ordinary single-GPU hierarchy on the gathered right-hand
@@ -319,19 +321,11 @@ std::unique_ptr<Dist<V>> create(int rank, int n_ranks, int n_levels, const omg_d
             validate_csr(*coarse_global, "coarse_global");
             OMG_REQUIRE(coarse_global->n_rows == coarse_global->n_cols && coarse_global->n_rows == tot,
                         "coarse operator must be square and match the coarse row counts");
-            DevCsr G;                            // inverted in double whatever V is
+            // factored in double whatever V is; the same solver (explicit inverse, or substructuring
+            // along the band for big operators) as a single-GPU hierarchy builds: same bits
             HostCsr Gh = permute_csr(*coarse_global, nullptr, nullptr);
-            G.upload(Gh, {}, d->stream);
-            const size_t nn = std::max<size_t>(size_t(d->n_coarse) * size_t(d->n_coarse), 1);
-            d->coarse_inv.alloc(nn);
-            if constexpr (std::is_same<V, double>::value) {
-                dense_inverse_from_csr(G, d->coarse_inv.p, d->stream);
-            } else {
-                DevBuf<double> inv64(nn);
-                dense_inverse_from_csr(G, inv64.p, d->stream);
-                launch_gather<double, V>(inv64.p, nullptr, d->coarse_inv.p, int64_t(size_t(d->n_coarse) * size_t(d->n_coarse)), d->stream);
-                OMG_HIP(hipStreamSynchronize(d->stream));
-            }
+            d->coarse.build(Gh, d->stream);
+            d->have_coarse = true;
         }
         d->coarse_rhs.alloc(std::max<int64_t>(d->n_coarse, 1));
         d->coarse_sol.alloc(std::max<int64_t>(d->n_coarse, 1));
@@ -561,9 +555,15 @@ struct Runner {
                 if (rc != OMG_OK) throw Error(rc, std::string("tail hierarchy: ") + omg_last_error());
                 if (L.n_loc) launch_gather<double, V>(sol64 + d->coarse_lo, nullptr, L.xp, L.n_loc, d->stream);
             } else {
-                OMG_REQUIRE(d->coarse_inv.p != nullptr, "no coarse solver: pass coarse_global or call omg_dist_set_tail");
-                launch_dense_gemv_rows<V>(d->coarse_inv.p + d->coarse_lo * d->n_coarse, d->coarse_rhs.p, L.xp, L.n_loc,
-                                          d->n_coarse, d->stream);
+                OMG_REQUIRE(d->have_coarse, "no coarse solver: pass coarse_global or call omg_dist_set_tail");
+                if (d->coarse.P == 1) {          // explicit inverse: this rank's rows of it
+                    launch_dense_gemv_rows<V>(d->coarse.inv.p + d->coarse_lo * d->n_coarse, d->coarse_rhs.p, L.xp, L.n_loc,
+                                              d->n_coarse, d->stream);
+                } else {                         // substructured: the whole (replicated) solve, keep this rank's slice
+                    d->coarse.solve(d->coarse_rhs.p, d->coarse_sol.p, d->stream);
+                    if (L.n_loc) OMG_HIP(hipMemcpyAsync(L.xp, d->coarse_sol.p + d->coarse_lo, L.n_loc * sizeof(V),
+                                                        hipMemcpyDeviceToDevice, d->stream));
+                }
             }
         }
     }

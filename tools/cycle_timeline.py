@@ -18,7 +18,7 @@ def main(path, which=-4):
     print("cycle wall us %.1f, %d kernels" % ((cyc[-1][1] - ev[a][1]) / 1e3, len(cyc)))
     gaps = 0
     for s, e, n, g in cyc:
-        m = re.search(r"(rows_kernel<\d|rows_pattern_kernel<\d|rows_serial_kernel<\d|\w+_kernel|__amd\w+)", n)
+        m = re.search(r"(rows_kernel<\d|rows_pattern_kernel<\d|rows_union_kernel<\d|rows_serial_kernel<\d|\w+_kernel|__amd\w+)", n)
         print("%8.1f gap %6.1f dur %7.1f  %s wgs %d" % ((s - t0) / 1e3, (s - prev_end) / 1e3, (e - s) / 1e3,
                                                       m.group(1) if m else n[:30], g // 256 if g >= 256 else g))
         tot += e - s

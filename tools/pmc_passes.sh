@@ -13,7 +13,7 @@ while read -r set; do
   [ -z "$set" ] && continue
   i=$((i+1))
   if [ -n "$PASSES" ] && ! echo " $PASSES " | grep -q " $i "; then continue; fi
-  timeout 240 rocprofv3 --pmc $set --kernel-include-regex "rows_(pattern_)?kernel" --output-format csv \
+  timeout 240 rocprofv3 --pmc $set --kernel-include-regex "rows_(pattern_|union_)?kernel" --output-format csv \
       -d "$root/$out/p$i" -- python3 "$root/tools/prof_cycle.py" --steps 2 "$@" > "$root/$out/p$i.log" 2>&1
   echo "pass $i ($set): rc=$?"
 done <<'SETS'

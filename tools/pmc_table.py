@@ -24,12 +24,15 @@ def main():
         for r in csv.DictReader(open(path)):
             m = re.search(r"rows_kernel<(\d+), (true|false), (true|false), (\d+), (?:true|false), (\w+)>", r["Kernel_Name"])
             mp = re.search(r"rows_pattern_kernel<(\d+), (?:true|false), (?:true|false), (\w+)>", r["Kernel_Name"])
-            if not m and not mp:
+            mu = re.search(r"rows_union_kernel<(\d+), (\d+), (\d+), (\w+)>", r["Kernel_Name"])
+            if not m and not mp and not mu:
                 continue
             blocks = int(r["Grid_Size"]) // 256
             if blocks < min_blocks:
                 continue
-            if mp:
+            if mu:
+                key = (MODES.get(int(mu.group(1)), mu.group(1)), mu.group(4), "union U" + mu.group(2), blocks)
+            elif mp:
                 key = (MODES.get(int(mp.group(1)), mp.group(1)), mp.group(2), "pattern", blocks)
             else:
                 key = (MODES.get(int(m.group(1)), m.group(1)), m.group(5), "short" if m.group(3) == "true" else "lpr" + m.group(4), blocks)

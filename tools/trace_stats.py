@@ -15,6 +15,9 @@ MODES = {0: "spmv", 1: "residual", 2: "resnorm", 3: "gs", 4: "jacobi", 5: "axpy"
 
 
 def short(name):
+    m = re.search(r"rows_union_kernel<(\d+), (\d+), (\d+), (\w+)>", name)
+    if m:
+        return "rows_union_kernel<%s, U%s, %s>" % (MODES[int(m.group(1))], m.group(2), m.group(4))
     m = re.search(r"rows_pattern_kernel<(\d+), (?:true|false), (?:true|false), (\w+)>", name)
     if m:
         return "rows_pattern_kernel<%s, %s>" % (MODES[int(m.group(1))], m.group(2))
