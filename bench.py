@@ -67,14 +67,21 @@ def build_problem(size, grids, smoother, dtype="float64"):
     import numpy as np
     from openmg_amd import _hip, operators
     shape = (size, size, size)
-    A0 = operators.stencil_poisson(shape)
+    t0 = time.perf_counter()
+    A0 = operators.stencil_poisson(shape)                       # synthetic input (NumPy, host)
     u_true = np.random.default_rng(12345).random(A0.shape[0])
     b = A0 @ u_true
+    _hip.device_count()                                         # loads the library
+    t1 = time.perf_counter()
+    # what mgSolve does before its first cycle (openmg/__init__.py:103-109): R list, Galerkin
+    # products (on the device), then the device hierarchy (ordering, coding, upload, coarse factors)
     R = operators.restrictionList(shape, grids - 2, 8)          # gridLevels = grids - 1 -> coarsestLevel = grids - 2 (D5)
-    A = operators.coeffecientList(A0, R)                        # Galerkin products on the device
+    A = operators.coeffecientList(A0, R)
     h = _hip.Hierarchy(A, R, smoother=smoother, dtype=dtype)
+    t2 = time.perf_counter()
     meta = {"n": A0.shape[0], "nnz": A0.nnz, "grids": len(A),
-            "level_rows": [M.shape[0] for M in A], "level_nnz": [M.nnz for M in A]}
+            "level_rows": [M.shape[0] for M in A], "level_nnz": [M.nnz for M in A],
+            "generate_s": t1 - t0, "setup_s": t2 - t1}
     return h, b, meta
 
 
@@ -177,12 +184,11 @@ def main():
     torch.cuda.set_device(0)
     repeats = max(1, args.repeats)
 
-    t_setup = time.perf_counter()
     w = 8 if args.dtype == "f64" else 4
     np_dtype = "float64" if w == 8 else "float32"
     h, b, meta = build_problem(args.size, args.grids, args.smoother, np_dtype)
     h.resident_load(b)
-    setup_s = time.perf_counter() - t_setup
+    setup_s, generate_s = meta["setup_s"], meta["generate_s"]
     pre = post = 1
     if args.graph:
         h.use_graph(True)
@@ -371,7 +377,10 @@ def main():
                    "unknowns": n, "nnz": nnz, "grids": meta["grids"], "pre": pre, "post": post,
                    "smoother": args.smoother, "hipgraph": bool(args.graph),
                    "repeats": repeats, "ms_per_step_all": [round(1e3 * t / args.steps, 4) for t in times],
-                   "final_residual_norm": norm, "setup_s": round(setup_s, 2)},
+                   "final_residual_norm": norm, "setup_s": round(setup_s, 2),
+                   "setup_what": "restrictionList + coeffecientList (device Galerkin products) + device hierarchy; "
+                                 "generating the synthetic operator and right-hand side on the host took generate_s",
+                   "generate_s": round(generate_s, 2)},
         "roofline": roofline,
         "csr_path": csr_path,
         "fine_grid_spmv": fine_spmv,

@@ -150,8 +150,8 @@ struct HostSub {            // small host CSR / CSC piece
     std::vector<double> val;
 };
 
-template <typename T>
-void put(DevBuf<T> &d, const std::vector<T> &h, hipStream_t s) {
+template <typename T, typename Al>
+void put(DevBuf<T> &d, const std::vector<T, Al> &h, hipStream_t s) {
     d.alloc(std::max<size_t>(h.size(), 1));
     d.upload(h.data(), h.size(), s);
 }

@@ -6,7 +6,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <stdexcept>
+#include <memory>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/openmg_hip.h"
@@ -34,6 +36,16 @@ void set_last_error(const std::string &m);
     } while (0)
 
 void require_device();   // throws OMG_ERR_NO_DEVICE when no GPU is visible
+
+// OMG_SETUP_TIMING=1: phases of the hierarchy setup, with their wall time, on stderr
+struct SetupTimer {
+    const char *what;
+    double t0;
+    static bool on() { static const bool v = [] { const char *e = getenv("OMG_SETUP_TIMING"); return e && e[0] == '1'; }(); return v; }
+    static double now();
+    explicit SetupTimer(const char *w) : what(w), t0(on() ? now() : 0.0) {}
+    ~SetupTimer() { if (on()) fprintf(stderr, "[omg setup] %-34s %8.1f ms\n", what, 1e3 * (now() - t0)); }
+};
 
 // ---- device buffers -----------------------------------------------------------------
 // Plain hipMalloc RAII.  Every allocation gets 64 bytes of slack so that the 16-byte
@@ -72,10 +84,24 @@ struct DevBuf {
 };
 
 // ---- host-side CSR (setup only) -----------------------------------------------------
+// Allocator whose construct() default-initialises: resize() of a vector of ints / doubles then
+// leaves the memory untouched instead of zero-filling it on one thread (1.4 GB for the 256^3
+// operator) — the parallel loops that fill the arrays do the first touch.
+template <typename T>
+struct NoInitAlloc : std::allocator<T> {
+    template <typename U> struct rebind { typedef NoInitAlloc<U> other; };
+    NoInitAlloc() = default;
+    template <typename U> NoInitAlloc(const NoInitAlloc<U> &) {}
+    template <typename U> void construct(U *p) noexcept { ::new (static_cast<void *>(p)) U; }
+    template <typename U, typename... Args> void construct(U *p, Args &&...args) { ::new (static_cast<void *>(p)) U(std::forward<Args>(args)...); }
+};
+typedef std::vector<int32_t, NoInitAlloc<int32_t>> IndexVec;
+typedef std::vector<double, NoInitAlloc<double>> ValueVec;
+
 struct HostCsr {
     int64_t n_rows = 0, n_cols = 0, nnz = 0;
-    std::vector<int32_t> indptr, indices;
-    std::vector<double> data;
+    IndexVec indptr, indices;
+    ValueVec data;
 };
 
 // A smoother ordering: rows renumbered so that each independent set is a contiguous range.
@@ -101,7 +127,7 @@ Ordering ordering_from_keys(const int32_t *keys, int64_t n, int32_t n_sets);
 HostCsr transpose_csr(const HostCsr &A);
 // Row blocks for the streaming kernels: greedy split of each set into blocks of at most
 // `max_rows` rows and `max_nnz` entries (a single longer row gets a block of its own).
-void make_row_blocks(const std::vector<int32_t> &indptr, const std::vector<int64_t> &sets,
+void make_row_blocks(const IndexVec &indptr, const std::vector<int64_t> &sets,
                      int max_rows, int max_nnz, std::vector<int32_t> &blk_rows,
                      std::vector<int64_t> &set_blk);
 

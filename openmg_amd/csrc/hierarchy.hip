@@ -5,6 +5,7 @@
 // in (double: the reference's precision; float: BASELINE configs[4]).  The C handle holds
 // one of the two instantiations; the host boundary is double either way.
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstring>
 #include <memory>
@@ -18,6 +19,10 @@ namespace omg {
 
 static thread_local std::string g_last_error;
 void set_last_error(const std::string &m) { g_last_error = m; }
+
+double SetupTimer::now() {
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
 
 void require_device() {
     int n = 0;
@@ -433,6 +438,7 @@ std::unique_ptr<Hier<V>> create(int n_levels, const omg_csr *A, const omg_csr *R
     std::string inv_msg;
     std::thread inverter([&] {
         hipStream_t s = nullptr;
+        SetupTimer tm("coarse factorisation (helper thread)");
         try {
             OMG_HIP(hipSetDevice(device));
             OMG_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
@@ -454,13 +460,16 @@ std::unique_ptr<Hier<V>> create(int n_levels, const omg_csr *A, const omg_csr *R
     for (int l = 0; l + 1 < n_levels; ++l) {
         Lv &L = h->lv[l];
         L.n = A[l].n_rows;
+        SetupTimer tm("ordering (colouring / level schedule)");
         L.ord = make_ordering(A[l], smoother);
     }
     for (int l = 0; l < n_levels; ++l) {
         Lv &L = h->lv[l];
         const bool id = L.ord.identity;
         if (l + 1 < n_levels) {
-            HostCsr Ap = permute_csr(A[l], id ? nullptr : L.ord.perm.data(), id ? nullptr : L.ord.inv.data());
+            HostCsr Ap;
+            { SetupTimer tm("permute A"); Ap = permute_csr(A[l], id ? nullptr : L.ord.perm.data(), id ? nullptr : L.ord.inv.data()); }
+            SetupTimer tm("encode + upload A");
             L.A.upload(Ap, L.ord.sets, h->stream);
         }
         if (!id) {
@@ -470,12 +479,11 @@ std::unique_ptr<Hier<V>> create(int n_levels, const omg_csr *A, const omg_csr *R
         }
         if (l + 1 < n_levels) {
             const Ordering &co = h->lv[l + 1].ord;
-            HostCsr Rp = permute_csr(R[l], co.identity ? nullptr : co.perm.data(), id ? nullptr : L.ord.inv.data());
-            HostCsr Pt = transpose_csr(Rp);
-            L.P.upload(Pt, {}, h->stream);
+            SetupTimer tm("R (and P): permute, encode, upload");
+            HostCsr Rp, Rn;
             const HostCsr *r_used = &Rp;
-            HostCsr Rn;
             if (co.identity) {
+                Rp = permute_csr(R[l], nullptr, id ? nullptr : L.ord.inv.data());
                 L.R.upload(Rp, {}, h->stream);
             } else {
                 // Restriction rows stay in NATURAL coarse order and write through a map into the
@@ -503,6 +511,13 @@ std::unique_ptr<Hier<V>> create(int n_levels, const omg_csr *A, const omg_csr *R
                 }
                 L.scatter_prolong = ok;
             }
+            if (!L.scatter_prolong) {
+                // the explicit transpose P = R^T (rows in this level's ordering, columns in the next
+                // level's) is only built where the prolongation cannot run as a scatter over R's rows
+                if (!co.identity) Rp = permute_csr(R[l], co.perm.data(), id ? nullptr : L.ord.inv.data());
+                HostCsr Pt = transpose_csr(Rp);
+                L.P.upload(Pt, {}, h->stream);
+            }
             L.r.alloc(L.n);
             if (smoother == OMG_SMOOTH_JACOBI) L.tmp.alloc(L.n);
             L.partials.alloc(L.A.n_blocks() + SUM_FOLD);
@@ -513,7 +528,7 @@ std::unique_ptr<Hier<V>> create(int n_levels, const omg_csr *A, const omg_csr *R
         L.xp = L.x.p;
         L.tp = L.tmp.p;
     }
-    inverter.join();
+    { SetupTimer tm("wait for the coarse factorisation"); inverter.join(); }
     if (inv_code != OMG_OK) throw Error(inv_code, inv_msg);
     OMG_HIP(hipStreamSynchronize(h->stream));
     return h;

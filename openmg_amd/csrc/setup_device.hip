@@ -13,6 +13,8 @@
 #include <memory>
 #include <numeric>
 
+#include <hipcub/hipcub.hpp>
+
 #include "common.h"
 
 using namespace omg;
@@ -107,6 +109,66 @@ int grid1d(int64_t n) {
     if (g > 65536) g = 65536;
     if (g < 1) g = 1;
     return (int)g;
+}
+
+// ---- transpose on the device (R^T for the Galerkin product) --------------------------------
+// Counting sort by column: counts (atomics: order-free), exclusive scan, scatter through per-column
+// cursors, then every column's short segment is put in ascending row order — the order SciPy's
+// csc view / the host transpose_csr give (entries with the same (row, column) tie-break by value
+// bits: deterministic).
+__global__ void count_columns_kernel(int64_t nnz, const int32_t *ix, int32_t *cnt) {
+    for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < nnz; p += (int64_t)gridDim.x * blockDim.x)
+        atomicAdd(&cnt[ix[p]], 1);
+}
+
+__global__ void scatter_transpose_kernel(int64_t n_rows, const int32_t *ip, const int32_t *ix, const double *dv,
+                                         const int32_t *tp, int32_t *cursor, int32_t *ti, double *tv) {
+    for (int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r < n_rows; r += (int64_t)gridDim.x * blockDim.x)
+        for (int32_t p = ip[r]; p < ip[r + 1]; ++p) {
+            const int32_t c = ix[p];
+            const int32_t pos = tp[c] + atomicAdd(&cursor[c], 1);
+            ti[pos] = int32_t(r);
+            tv[pos] = dv[p];
+        }
+}
+
+__global__ void sort_segments_kernel(int64_t n_seg, const int32_t *tp, int32_t *ti, double *tv) {
+    for (int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; c < n_seg; c += (int64_t)gridDim.x * blockDim.x) {
+        const int32_t b = tp[c], e = tp[c + 1];
+        for (int32_t i = b + 1; i < e; ++i) {                      // insertion sort: segments are a few entries long
+            const int32_t ki = ti[i];
+            const double kv = tv[i];
+            int32_t j = i - 1;
+            while (j >= b && (ti[j] > ki || (ti[j] == ki && __double_as_longlong(tv[j]) > __double_as_longlong(kv)))) {
+                ti[j + 1] = ti[j];
+                tv[j + 1] = tv[j];
+                --j;
+            }
+            ti[j + 1] = ki;
+            tv[j + 1] = kv;
+        }
+    }
+}
+
+void device_transpose(const DevMat &X, DevMat &T, hipStream_t s) {
+    T.n_rows = X.n_cols; T.n_cols = X.n_rows; T.nnz = X.nnz;
+    const int64_t nc = X.n_cols;
+    T.indptr.alloc(nc + 2);
+    T.indices.alloc(std::max<int64_t>(X.nnz, 1));
+    T.data.alloc(std::max<int64_t>(X.nnz, 1));
+    DevBuf<int32_t> cnt(nc + 2);
+    OMG_HIP(hipMemsetAsync(cnt.p, 0, size_t(nc + 2) * sizeof(int32_t), s));
+    hipLaunchKernelGGL(count_columns_kernel, dim3(grid1d(X.nnz)), dim3(256), 0, s, X.nnz, X.indices.p, cnt.p);
+    size_t bytes = 0;
+    OMG_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, cnt.p, T.indptr.p, int(nc + 1), s));
+    DevBuf<unsigned char> tmp(bytes + 16);
+    OMG_HIP(hipcub::DeviceScan::ExclusiveSum(tmp.p, bytes, cnt.p, T.indptr.p, int(nc + 1), s));
+    OMG_HIP(hipMemsetAsync(cnt.p, 0, size_t(nc + 2) * sizeof(int32_t), s));
+    hipLaunchKernelGGL(scatter_transpose_kernel, dim3(grid1d(X.n_rows)), dim3(256), 0, s, X.n_rows, X.indptr.p,
+                       X.indices.p, X.data.p, T.indptr.p, cnt.p, T.indices.p, T.data.p);
+    hipLaunchKernelGGL(sort_segments_kernel, dim3(grid1d(nc)), dim3(256), 0, s, nc, T.indptr.p, T.indices.p, T.data.p);
+    OMG_HIP(hipGetLastError());
+    OMG_HIP(hipStreamSynchronize(s));       // cnt / tmp die here
 }
 
 // C = X Y on the device.
@@ -238,16 +300,10 @@ int omg_rap(const omg_csr *R, const omg_csr *A, omg_csr_result **out, int64_t *n
         OMG_REQUIRE(A->n_rows == A->n_cols && R->n_cols == A->n_rows, "rap: shapes do not chain");
         Stream st;
         DevMat dR, dA, dRt, dRA;
-        upload(dR, *R, st.s);
-        upload(dA, *A, st.s);
-        {
-            HostCsr Rh = permute_csr(*R, nullptr, nullptr);
-            HostCsr Rt = transpose_csr(Rh);               // index shuffle only
-            omg_csr v{Rt.n_rows, Rt.n_cols, Rt.nnz, Rt.indptr.data(), Rt.indices.data(), Rt.data.data()};
-            upload(dRt, v, st.s);
-            OMG_HIP(hipStreamSynchronize(st.s));
-        }
+        { SetupTimer tm("rap: upload R, A"); upload(dR, *R, st.s); upload(dA, *A, st.s); OMG_HIP(hipStreamSynchronize(st.s)); }
+        { SetupTimer tm("rap: R^T on the device"); device_transpose(dR, dRt, st.s); }   // index shuffle only
         omg_csr_result RA;
+        SetupTimer tm("rap: two sparse products");
         spgemm(dR, dA, RA, st.s);                          // (R A)        operators.py:185
         as_devmat(std::move(RA), dRA);
         std::unique_ptr<omg_csr_result> C(new omg_csr_result);

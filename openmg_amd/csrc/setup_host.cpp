@@ -223,7 +223,7 @@ HostCsr transpose_csr(const HostCsr &A) {
     return T;
 }
 
-void make_row_blocks(const std::vector<int32_t> &indptr, const std::vector<int64_t> &sets,
+void make_row_blocks(const IndexVec &indptr, const std::vector<int64_t> &sets,
                      int max_rows, int max_nnz, std::vector<int32_t> &blk_rows,
                      std::vector<int64_t> &set_blk) {
     blk_rows.clear();
@@ -691,7 +691,9 @@ HostFormat<V> encode_csr(const HostCsr &A, const std::vector<int64_t> &sets_in) 
 
 template <typename V>
 void DevCsrT<V>::upload(const HostCsr &A, const std::vector<int64_t> &sets_in, hipStream_t s) {
-    HostFormat<V> F = encode_csr<V>(A, sets_in);             // host only (setup_host.cpp)
+    HostFormat<V> F;
+    { SetupTimer tm("  encode_csr"); F = encode_csr<V>(A, sets_in); }       // host only (setup_host.cpp)
+    SetupTimer tm_up("  upload");
     n_rows = A.n_rows;
     n_cols = A.n_cols;
     nnz = A.nnz;
