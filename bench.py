@@ -56,8 +56,10 @@ def kernel_source_hash():
     return h.hexdigest()[:16]
 
 
-def kernel_name(fmt, mode):
+def kernel_name(fmt, mode, union=False):
     """Which kernel walks an operator held like `fmt` (csrc/csr_kernels.hip launch_rows_range)."""
+    if union:
+        return "rows_union_kernel<%s>" % mode
     if fmt["rows"] and fmt["pattern_rows"] == fmt["rows"] and os.environ.get("OMG_PATTERN_KERNEL", "1") != "0":
         return "rows_pattern_kernel<%s>" % mode
     return "rows_kernel<%s>" % mode
@@ -223,7 +225,7 @@ def main():
     spmv_csr = spmv_bytes(n, nnz, w)
     fmt_all = h.format_info(0, "A")
     spmv_fmt = fmt_all["format_bytes"] + 2 * w * n              # operator in its device format + x read + y written
-    fine_spmv = {"kernel": "y = A x, all rows of the fine grid (%s)" % kernel_name(fmt_all, "ROW_SPMV"),
+    fine_spmv = {"kernel": "y = A x, all rows of the fine grid (%s)" % kernel_name(fmt_all, "ROW_SPMV", h.level_flags(0)["union_walk"]),
                  "avg_launch_us": round(spmv_ms * 1e3, 2),
                  "bytes_per_launch": spmv_fmt, "achieved": round(spmv_fmt / spmv_ms / 1e6, 1),
                  "frac": round(spmv_fmt / spmv_ms / 1e6 / HBM_PEAK_GBS, 4),
@@ -291,7 +293,7 @@ def main():
                              "frac": round(class_fmt[name] / us / 1e3 / HBM_PEAK_GBS, 4),
                              "csr_equiv_GBps": round(class_csr[name] / us / 1e3, 1)}
     achieved = res_fmt / avg_s / 1e9
-    roofline = {"bound": "hbm", "kernel": "fine grid r = b - A x (%s)" % kernel_name(fmt_cov, "ROW_RESIDUAL"),
+    roofline = {"bound": "hbm", "kernel": "fine grid r = b - A x (%s)" % kernel_name(fmt_cov, "ROW_RESIDUAL", h.level_flags(0)["union_walk"]),
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                 "bytes_per_launch": res_fmt,

@@ -258,6 +258,12 @@ struct DevCsrT {
             if (!set_pattern[q] && sets[q + 1] > sets[q]) return false;
         return true;
     }
+    bool all_union() const {           // every (non-empty) set runs rows_union_kernel (csr_kernels.hip launch_rows_range)
+        if (set_union.empty() || n_rows != n_cols || size_t(n_cols) * sizeof(V) >= (size_t(1) << 31)) return false;
+        for (size_t q = 0; q < set_union.size(); ++q)
+            if (!set_union[q] && sets[q + 1] > sets[q]) return false;
+        return true;
+    }
     int64_t n_blocks() const { return set_blk.empty() ? 0 : set_blk.back(); }
 };
 using DevCsr = DevCsrT<double>;

@@ -680,7 +680,8 @@ int omg_hierarchy_level_flags(const omg_hierarchy *h, int level, int *flags) {
             OMG_REQUIRE(flags, "null");
             const bool smoothed = level + 1 < (int)hh->lv.size();
             *flags = ((smoothed && can_fuse(hh, hh->lv[level])) ? OMG_LEVEL_FUSED_LAST_SET : 0) |
-                     ((smoothed && hh->lv[level].scatter_prolong) ? OMG_LEVEL_SCATTER_PROLONG : 0);
+                     ((smoothed && hh->lv[level].scatter_prolong) ? OMG_LEVEL_SCATTER_PROLONG : 0) |
+                     ((smoothed && hh->lv[level].A.all_union()) ? OMG_LEVEL_UNION_WALK : 0);
         });
     });
 }
