@@ -258,8 +258,10 @@ struct DevCsrT {
             if (!set_pattern[q] && sets[q + 1] > sets[q]) return false;
         return true;
     }
+    // a level operator: square, or one rank's rows of it with the halo columns behind the owned ones
+    bool operator_like() const { return n_cols >= n_rows && n_cols < 2 * n_rows; }
     bool all_union() const {           // every (non-empty) set runs rows_union_kernel (csr_kernels.hip launch_rows_range)
-        if (set_union.empty() || n_rows != n_cols || size_t(n_cols) * sizeof(V) >= (size_t(1) << 31)) return false;
+        if (set_union.empty() || !operator_like() || size_t(n_cols) * sizeof(V) >= (size_t(1) << 31)) return false;
         for (size_t q = 0; q < set_union.size(); ++q)
             if (!set_union[q] && sets[q + 1] > sets[q]) return false;
         return true;

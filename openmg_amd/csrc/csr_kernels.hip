@@ -1110,8 +1110,9 @@ void launch_rows_range(const DevCsrT<V> &A, int mode, int set_begin, int set_end
     const bool prefer = !(e && e[0] == '0');
     const bool x_fits = size_t(A.n_cols) * sizeof(V) < (size_t(1) << 31);       // 32-bit buffer offsets
     auto kind_of = [&](int q) {
-        // (square operators only: restriction / prolongation rows measured faster in the pattern kernel)
-        if (mode != ROW_SCATTER && x_fits && A.n_rows == A.n_cols && !A.set_union.empty() && A.set_union[q]) return 2;
+        // (operators A_l only — square, or a rank's rows with their halo columns behind: restriction
+        // / prolongation rows measured faster in the pattern kernel)
+        if (mode != ROW_SCATTER && x_fits && A.operator_like() && !A.set_union.empty() && A.set_union[q]) return 2;
         const int v = A.set_pattern.empty() ? 0 : A.set_pattern[q];
         if (A.rows_cap > NT && A.union_blocks) return 0;                        // big pattern blocks: rows_kernel walks them
         return (v == 2 || (v == 1 && (prefer || mode == ROW_SCATTER))) ? 1 : 0;   // the scatter exists in the pattern kernel only

@@ -675,13 +675,13 @@ HostFormat<V> encode_csr(const HostCsr &A, const std::vector<int64_t> &sets_in) 
             HostFormat<V> W = encode_with<V>(A, sets_in, ROWBLK_THREADS, 1 << 24, 1, mode);
             if (!W.wide_failed) return W;
         }
-        // Short-row square operators (the smoothed A_l of stencil problems) whose blocks all carry a
+        // Short-row level operators (square A_l, or a rank's rows of it with halo columns) whose blocks all carry a
         // union: blocks of U x 256 rows, U rows per thread in rows_union_kernel (all gathers of a
         // thread's rows in flight together).  Tried first; OMG_UNION_ROWS = 1, 2 or 4 (default 2),
         // OMG_UNION_KERNEL=0 switches the union walk off altogether.
         const int urows = union_rows();
-        if (lanes == 1 && max_rows == ROWBLK_ROWS && urows > 1 && (mode & 4) && A.n_rows == A.n_cols &&
-            A.n_rows >= int64_t(4) * urows * ROWBLK_THREADS) {
+        if (lanes == 1 && max_rows == ROWBLK_ROWS && urows > 1 && (mode & 4) && A.n_cols >= A.n_rows &&
+            A.n_cols < 2 * A.n_rows && A.n_rows >= int64_t(4) * urows * ROWBLK_THREADS) {
             HostFormat<V> W = encode_with<V>(A, sets_in, urows * ROWBLK_THREADS, 1 << 24, 1, mode, true);
             if (!W.union_failed) return W;
         }
