@@ -23,7 +23,8 @@ CASES = [
 
 
 def main():
-    only = sys.argv[1:] and [int(a) for a in sys.argv[1:]]
+    graph = "--graph" in sys.argv
+    only = [int(a) for a in sys.argv[1:] if a.lstrip("-").isdigit()]
     for k, (name, shape, grids, smoother, kind) in enumerate(CASES):
         if only and k not in only:
             continue
@@ -35,6 +36,8 @@ def main():
         h = _hip.Hierarchy(A, R, smoother=smoother, omega=2.0 / 3.0)
         setup = time.perf_counter() - t0
         h.resident_load(b)
+        if graph:
+            h.use_graph(True)
         for _ in range(3):
             h.resident_cycle(1, 1, want_norm=False)
         h.sync()
@@ -45,8 +48,8 @@ def main():
         h.sync()
         dt = (time.perf_counter() - t0) / steps
         norm = h.resident_cycle(1, 1)
-        print("%-78s grids %d sets/level0 %4d  %9.3f ms/cycle  %9.1f cycles/s  setup %.2f s  norm %.3e"
-              % (name, len(A), h.level_sets(0), dt * 1e3, 1.0 / dt, setup, norm))
+        print("%s%-78s grids %d sets/level0 %4d  %9.3f ms/cycle  %9.1f cycles/s  setup %.2f s  norm %.3e"
+              % ("[hipGraph] " if graph else "", name, len(A), h.level_sets(0), dt * 1e3, 1.0 / dt, setup, norm))
         sys.stdout.flush()
         h.close()
 
