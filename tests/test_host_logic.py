@@ -227,3 +227,40 @@ def test_mgcycle_cache_key_follows_content_not_object_identity():
     c0 = openmg_amd._array_checksum(big)
     big[-1] = -1.0
     assert openmg_amd._array_checksum(big) != c0
+
+
+def test_union_partition_is_chosen_and_decodes(monkeypatch):
+    """Round 2: level operators whose row patterns are all subsequences of one short sequence are
+    blocked several-rows-per-thread x 256 rows for rows_union_kernel (csrc/common.h UNION_MAX);
+    omg_format_selftest also expands every row from the block's union and its pattern's mask and
+    compares it with the stored pattern.  Host only."""
+    shape = (32, 32, 32)
+    A = orc.stencil_poisson(shape)
+    order = orc.colour_order(orc.parity_colouring(shape))
+    P = sp.csr_matrix(A[order][:, order])                         # red-black permuted: two interior row patterns per colour
+    natural2d = orc.stencil_poisson((256, 256))
+    galerkin = sp.csr_matrix(orc.restriction(shape) @ A @ orc.restriction(shape).T)
+    galerkin.sort_indices()
+    blocks = {}
+    for rows in ("1", "2", "4"):
+        monkeypatch.setenv("OMG_UNION_ROWS", rows)
+        for name, M in (("rb", P), ("2d", natural2d), ("natural", A), ("galerkin", galerkin)):
+            for dtype in ("float64", "float32"):
+                f = _hip.format_selftest(M, dtype)                # raises if a union / mask does not reproduce a row
+                assert f["pattern_rows"] == f["rows"], (name, rows)
+                blocks[(name, rows, dtype)] = f["blocks"]
+    for name, M in (("rb", P), ("2d", natural2d), ("natural", A)):
+        n = M.shape[0]
+        assert blocks[(name, "1", "float64")] == -(-n // 256)
+        assert blocks[(name, "2", "float64")] == -(-n // 512)
+        assert blocks[(name, "4", "float64")] == -(-n // 1024)
+    assert blocks[("galerkin", "2", "float64")] == -(-galerkin.shape[0] // 512)     # 4096 rows: still >= 4 blocks
+    monkeypatch.setenv("OMG_UNION_KERNEL", "0")                   # the kernel off: 256-row blocks as in round 1
+    assert _hip.format_selftest(P)["blocks"] == -(-P.shape[0] // 256)
+    monkeypatch.delenv("OMG_UNION_KERNEL")
+    monkeypatch.setenv("OMG_UNION_ROWS", "2")
+    # operators without a short common supersequence keep the standard partition: 27-point variable
+    # coefficients (values differ row by row), irregular sparsity, restriction (not a level operator)
+    assert _hip.format_selftest(operators.stencil27_variable((12, 12, 12)))["pattern_rows"] == 0
+    R = orc.restriction(shape)
+    assert _hip.format_selftest(R)["blocks"] == -(-R.shape[0] // 256)

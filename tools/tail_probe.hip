@@ -16,11 +16,14 @@
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 
+__device__ int g_depth = 3;     // dependent loads in front of the gathers (3: record -> dictionary -> gathers; 2: no dictionary hop)
+
 __device__ __forceinline__ void phase_body(const int *__restrict__ idx, const int *__restrict__ table,
                                            const double *__restrict__ src, double *__restrict__ dst, int n, int phase) {
+    const int depth = g_depth;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const int a = idx[i];                       // "block record / code"
-        const int off = table[a & 1023];            // "dictionary"
+        const int off = depth >= 3 ? table[a & 1023] : (a & 3) - 1;   // "dictionary"
         int j = i + off + phase;
         j = j < 0 ? 0 : (j >= n ? n - 1 : j);
         const double v = src[j] + src[(j + 1) % n];  // "gathers"
@@ -62,6 +65,9 @@ __global__ __launch_bounds__(256) void persistent_kernel(const int *idx, const i
 
 int main(int argc, char **argv) {
     const int phases = argc > 1 ? atoi(argv[1]) : 21, reps = 50;
+    const int depth = argc > 2 ? atoi(argv[2]) : 3;
+    CK(hipMemcpyToSymbol(HIP_SYMBOL(g_depth), &depth, sizeof(int)));
+    printf("dependent loads before the store: %d\n", depth);
     hipStream_t s;
     CK(hipStreamCreate(&s));
     hipEvent_t e0, e1;
