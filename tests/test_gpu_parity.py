@@ -828,3 +828,72 @@ def test_long_rows_pattern_kernel_matches_four_lanes_per_row(monkeypatch, dtype)
     np.testing.assert_allclose(out["15"][3], out["0"][3], rtol=1e-13)
     if dtype == "float64":
         np.testing.assert_allclose(out["0"][0], b - A0 @ x0, rtol=0, atol=1e-12 * (abs(A0).sum(axis=1).max() + np.abs(b).max()))
+
+
+# ------------------------------------------------------------ union walk on random stencil-like operators --
+def _random_stencil_operator(rng, n, n_offsets, n_values, drop=0.15, shuffle=False):
+    """n x n operator whose rows repeat: a random set of (column - row) offsets with values drawn
+    from a few constants, entries that would leave the matrix dropped (boundary rows = subsequences
+    of the interior row), a random subset of further entries dropped in runs (more row patterns),
+    a dominant diagonal.  Optionally the stored order inside the rows is shuffled per PATTERN."""
+    offs = np.unique(np.concatenate([[0], rng.integers(-n // 3, n // 3, size=n_offsets)]))
+    vals = rng.choice(rng.standard_normal(n_values), size=offs.size)
+    order = rng.permutation(offs.size) if shuffle else np.arange(offs.size)
+    rows, cols, data = [], [], []
+    i = np.arange(n)
+    for k in order:
+        o, v = int(offs[k]), float(vals[k])
+        keep = (i + o >= 0) & (i + o < n)
+        if o != 0:
+            gate = np.repeat(rng.random(n // 97 + 1) >= drop, 97)[:n]          # runs of 97 rows lose this entry together
+            keep &= gate
+        rows.append(i[keep]); cols.append(i[keep] + o); data.append(np.full(int(keep.sum()), v if o else 0.0))
+    rows, cols, data = np.concatenate(rows), np.concatenate(cols), np.concatenate(data)
+    # CSR with the stored order of `order` inside every row: stable sort by row only
+    perm = np.argsort(rows, kind="stable")
+    indptr = np.searchsorted(rows[perm], np.arange(n + 1)).astype(np.int32)
+    A = sp.csr_matrix((data[perm], cols[perm].astype(np.int32), indptr), shape=(n, n))
+    d = np.asarray(abs(A).sum(axis=1)).ravel() + 1.0
+    diag_pos = A.indices == np.repeat(np.arange(n), np.diff(A.indptr))
+    A.data[diag_pos] = d
+    A.has_sorted_indices = False
+    return A
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_union_walk_on_random_stencil_like_operators_is_bit_identical(monkeypatch, seed):
+    """rows_union_kernel against plain CSR on operators made to have many row patterns per block
+    that are subsequences of one union (and, seed permitting, a shuffled stored order): SpMV,
+    residual + norm, colour / Jacobi sweeps incl. the fused last set, in both precisions."""
+    rng = np.random.default_rng(1000 + seed)
+    n = int(rng.integers(3000, 9000))
+    A0 = _random_stencil_operator(rng, n, n_offsets=int(rng.integers(6, 14)), n_values=3, shuffle=bool(seed % 2))
+    pairs = np.arange(n) // 2
+    R0 = sp.csr_matrix((np.full(n, 0.5), (pairs, np.arange(n))), shape=((n + 1) // 2, n))
+    A = [A0, sp.csr_matrix(R0 @ A0 @ R0.T)]
+    b, x0 = rng.standard_normal(n), rng.standard_normal(n)
+    for dtype in ("float64", "float32"):
+        for smoother in ("colour", "jacobi"):
+            out = {}
+            for mode, uk, ur in (("0", "1", "2"), ("15", "1", "1"), ("15", "1", "2"), ("15", "1", "4"), ("15", "0", "1")):
+                monkeypatch.setenv("OMG_COMPRESS", mode)
+                monkeypatch.setenv("OMG_UNION_KERNEL", uk)
+                monkeypatch.setenv("OMG_UNION_ROWS", ur)
+                with _hip.Hierarchy(A, [R0], smoother=smoother, omega=0.7, dtype=dtype) as h:
+                    flags = h.level_flags(0)
+                    r, nr = h.residual(0, b, x0, want_norm=True)
+                    xs = x0.copy()
+                    h.smooth(0, b, xs, 2)
+                    h.resident_load(b, x0)
+                    norms = [h.resident_cycle(1, 1) for _ in range(2)]
+                    out[(mode, uk, ur)] = (r, xs, h.resident_fetch(), nr, norms, flags["union_walk"])
+            base = out[("0", "1", "2")]
+            assert not base[5]
+            assert not out[("15", "0", "1")][5]
+            if seed >= 2 and smoother == "jacobi":               # natural order: these operators get 512-row union blocks (host check)
+                assert out[("15", "1", "2")][5]                  # the union walk really ran
+            for key, run in out.items():
+                for got, want in zip(run[:3], base[:3]):
+                    assert np.array_equal(got, want), (key, dtype, smoother)
+                np.testing.assert_allclose(run[3], base[3], rtol=1e-13 if dtype == "float64" else 1e-6)
+                np.testing.assert_allclose(run[4], base[4], rtol=1e-13 if dtype == "float64" else 1e-6)
