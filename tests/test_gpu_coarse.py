@@ -37,7 +37,8 @@ def banded_unsymmetric(n, w, rng, density=0.3):
     return A
 
 
-@pytest.mark.parametrize("case", ["poisson3d_16", "poisson2d_128", "galerkin_16", "banded_unsym", "poisson2d_160", "dense_small"])
+@pytest.mark.parametrize("case", ["poisson3d_16", "poisson2d_128", "galerkin_16", "banded_unsym", "poisson2d_160", "dense_small",
+                                  "poisson1d_100k"])
 def test_direct_solve_against_superlu(monkeypatch, case):
     rng = np.random.default_rng(5)
     if case == "poisson3d_16":
@@ -52,6 +53,8 @@ def test_direct_solve_against_superlu(monkeypatch, case):
         A = banded_unsymmetric(5000, 37, rng)
     elif case == "poisson2d_160":
         A = operators.stencil_poisson((160, 160))                 # n 25600 > the old 16384 limit
+    elif case == "poisson1d_100k":
+        A = operators.poisson(100000, sparse=True)                # the reference's 1-D (4, -1) operator, w = 1: 64 blocks, 63 one-row separators
     else:
         A = sp.csr_matrix(rng.standard_normal((300, 300)) + 40 * np.eye(300))
     n = A.shape[0]
@@ -66,9 +69,22 @@ def test_direct_solve_against_superlu(monkeypatch, case):
         monkeypatch.setenv("OMG_COARSE_BLOCKS", "1")              # explicit inverse: the round-1 path
         dense = _hip.direct_solve(A, b)
         np.testing.assert_allclose(dense, want, rtol=1e-10, atol=1e-12 * scale)
-    monkeypatch.setenv("OMG_COARSE_BLOCKS", "3")                  # substructured whatever the size (3 blocks, 2 separators)
-    sub = _hip.direct_solve(A, b)
-    np.testing.assert_allclose(sub, want, rtol=1e-10, atol=1e-12 * scale)
+    if n <= 30000:
+        monkeypatch.setenv("OMG_COARSE_BLOCKS", "3")              # substructured whatever the size (3 blocks, 2 separators)
+        sub = _hip.direct_solve(A, b)
+        np.testing.assert_allclose(sub, want, rtol=1e-10, atol=1e-12 * scale)
+
+
+def test_direct_solve_limits_are_reported():
+    """Neither small nor banded: the reference's SuperLU would still solve it; the device solver says
+    OMG_ERR_UNSUPPORTED instead of running out of memory (README, Limits)."""
+    rng = np.random.default_rng(9)
+    n = 20000
+    S = sp.random(n, n, density=2e-4, random_state=np.random.RandomState(4), format="csr")
+    A = sp.csr_matrix(S + sp.diags(np.full(n, 10.0)))             # couplings anywhere: half-bandwidth ~ n
+    with pytest.raises(_hip.HipError) as e:
+        _hip.direct_solve(A, rng.standard_normal(n))
+    assert e.value.code == _hip.ERR_UNSUPPORTED
 
 
 def test_hierarchy_coarse_solver_kind_and_cycle_parity(monkeypatch):
