@@ -16,6 +16,14 @@ import numpy as np
 SHAPES = {1: (256, 256, 256), 2: (256, 512, 256), 4: (512, 256, 512), 8: (512, 512, 512)}
 
 
+def overlap_candidates(level_rows):
+    """(name, OMG_OVERLAP_MIN_ROWS) candidates for the exchange / compute overlap: every distributed
+    level, the k largest levels for k = 1 .. n - 1, none.  level_rows: owned rows of the smoothed
+    distributed levels, finest first."""
+    sizes = sorted(set(int(n) for n in level_rows), reverse=True)
+    return [("all levels", 0)] + [("levels >= %d rows" % n, n) for n in sizes[:-1]] + [("none", 1 << 62)]
+
+
 def main(args):
     import datetime
     import threading
@@ -76,6 +84,14 @@ def main(args):
     u = np.random.default_rng(12345).random(part.n_rows(0))
     b_loc = A_rows @ u
     del u
+    # Boundary-first (boundary, interior) set pairs on EVERY distributed level: which of those
+    # levels then really run their halo exchanges on the second stream beside the interior rows is
+    # measured below (the threshold is read by the runner at every cycle), not guessed.
+    # (OMG_BENCH_AUTOTUNE=0 keeps the default threshold; =force runs the probe loop with one rank too)
+    mode = os.environ.get("OMG_BENCH_AUTOTUNE", "1")
+    tune = bool(args.overlap) and (world > 1 or mode == "force") and "OMG_OVERLAP_MIN_ROWS" not in os.environ and mode != "0"
+    if tune:
+        os.environ["OMG_OVERLAP_MIN_ROWS"] = "0"
     levels, coarse, counts = dist.build_this_rank(part, rank, A_rows, all_gather, smoother=args.smoother,
                                                   overlap=bool(args.overlap), colouring=colouring)
     nnz_loc, n_loc = A_rows.nnz, hi - lo
@@ -89,6 +105,33 @@ def main(args):
     setup_s = time.perf_counter() - t_setup
 
     pre = post = 1
+    autotune = None
+    if tune:
+        # Exchange / compute overlap threshold: levels with at least this many owned rows send their
+        # boundary values on the second stream while the interior rows are relaxed (two events per
+        # exchange); smaller levels exchange in line.  Every candidate is timed over a few cycles
+        # (slowest rank's time), the fastest is kept for the timed regions.  Identical iterates.
+        cands = overlap_candidates([part.rows(l, rank)[1] - part.rows(l, rank)[0] for l in range(n_dist - 1)])
+        autotune = {}
+        probe = max(10, args.steps)
+        for _ in range(max(args.warmup, 5)):                      # clocks and caches warm before the first candidate
+            r.cycle(pre, post, want_norm=False)
+        for name, thr in cands:
+            os.environ["OMG_OVERLAP_MIN_ROWS"] = str(thr)
+            for _ in range(3):
+                r.cycle(pre, post, want_norm=False)
+            r.sync()
+            td.barrier()
+            t0 = time.perf_counter()
+            for _ in range(probe):
+                r.cycle(pre, post, want_norm=False)
+            r.sync()
+            t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+            td.all_reduce(t, op=td.ReduceOp.MAX)
+            autotune[name] = (thr, float(t[0]) / probe)
+        best = min(autotune, key=lambda k: autotune[k][1])        # the same on every rank: the times were all-reduced
+        os.environ["OMG_OVERLAP_MIN_ROWS"] = str(autotune[best][0])
+        autotune = {"chosen": best, "ms_per_cycle": {k: round(1e3 * v[1], 4) for k, v in autotune.items()}}
     for _ in range(args.warmup):
         r.cycle(pre, post, want_norm=False)
     times = []
@@ -134,7 +177,7 @@ def main(args):
                                       "fp64" if w == 8 else "fp32", world),
                        "unknowns": n_glob, "unknowns_per_gpu": n_loc, "nnz_per_gpu": nnz_loc, "grids": grids,
                        "distributed_grids": n_dist - 1, "replicated_tail_grids": grids - n_dist + 1,
-                       "rccl_ranks": rccl_ranks, "repeats": len(times),
+                       "rccl_ranks": rccl_ranks, "repeats": len(times), "overlap_autotune": autotune,
                        "ms_per_step_all": [round(1e3 * t / args.steps, 4) for t in times],
                        "pre": pre, "post": post, "cycles_per_s": round(args.steps / elapsed, 3),
                        "final_residual_norm": norm, "setup_s": round(setup_s, 2)},

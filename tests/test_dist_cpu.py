@@ -237,3 +237,16 @@ def test_bench_parent_without_gpu_fails_fast_and_prints_no_result():
     assert p.returncode != 0 and time.monotonic() - t0 < 240
     assert "no MI355X" in p.stderr or "no HIP device" in p.stderr
     assert not any(line.startswith("{") for line in p.stdout.splitlines())
+
+
+def test_bench_overlap_autotune_candidates():
+    """dist_bench times the cycle with the halo exchanges of the k largest levels on the second
+    stream, for every k, and keeps the fastest: the candidate thresholds for bench.py's N = 8
+    hierarchy (512^3 over 8 slabs, three distributed smoothed levels)."""
+    from openmg_amd import dist_bench
+    part = dist.SlabPartition((512, 512, 512), 8, 4)
+    rows = [part.rows(l, 3)[1] - part.rows(l, 3)[0] for l in range(3)]
+    assert rows == [16777216, 2097152, 262144]
+    c = dist_bench.overlap_candidates(rows)
+    assert [t for _, t in c] == [0, 16777216, 2097152, 1 << 62]
+    assert dist_bench.overlap_candidates([4096]) == [("all levels", 0), ("none", 1 << 62)]
