@@ -64,7 +64,7 @@ def _dtype_of(parameters):
 # few entries of such a matrix in place.
 _cache = {}
 _CACHE_SLOTS = 2
-_HASH_ALL_BYTES = 1 << 25
+_HASH_ALL_BYTES = 1 << 22
 _HASH_SAMPLES = 1 << 14
 
 try:
