@@ -123,23 +123,24 @@ def timed_regions(h, sync, steps, warmup, repeats, pre, post, classes=("residual
     """`warmup` untimed cycles, then `repeats` timed regions of EXACTLY `steps` cycles each,
     every one bracketed by a device synchronisation on both sides.  Inside the regions the
     launches of `classes` are bracketed by hipEvents on the hierarchy's own stream (one pair per
-    cycle for 'residual': ~1 % of the cycle).  Returns (elapsed seconds per region, profile)."""
-    for _ in range(warmup):
-        h.resident_cycle(pre, post, want_norm=False)
+    cycle for 'residual': ~1 % of the cycle).  Returns (elapsed seconds per region, profile, the
+    last region's norms)."""
+    h.resident_cycles(pre, post, warmup)
     sync()
     if classes:
         h.profile_enable(list(classes))
-    times = []
+    times, norms = [], []
     for _ in range(repeats):
         sync()
         t0 = time.perf_counter()
-        for _ in range(steps):
-            h.resident_cycle(pre, post, want_norm=False)
+        # K cycles enqueued back to back, every cycle's residual norm computed and returned at the end
+        # of the region (omg_resident_cycles: mgSolve's loop with a cycle-count stop rule)
+        norms = h.resident_cycles(pre, post, steps)
         sync()
         times.append(time.perf_counter() - t0)
     prof = h.profile_read() if classes else None
     h.profile_enable(False)
-    return times, prof
+    return times, prof, norms
 
 
 def main():
@@ -204,8 +205,8 @@ def main():
     # eight level-0 launches would cost the cycle ~4 %.  (A hipGraph replay cannot carry the
     # events; with --graph 1 the kernel is timed in the second region below.)
     in_region = not args.graph
-    times, timed = timed_regions(h, sync, args.steps, args.warmup, repeats, pre, post,
-                                 ("residual",) if in_region else ())
+    times, timed, region_norms = timed_regions(h, sync, args.steps, args.warmup, repeats, pre, post,
+                                               ("residual",) if in_region else ())
     elapsed = statistics.median(times)
     norm = h.resident_cycle(pre, post, want_norm=True)          # untimed: read the norm back once
 
@@ -327,7 +328,7 @@ def main():
             h2.sync()
             torch.cuda.synchronize()
 
-        p_times, p_prof = timed_regions(h2, sync2, args.steps, args.warmup, repeats, pre, post, ("residual",))
+        p_times, p_prof, _ = timed_regions(h2, sync2, args.steps, args.warmup, repeats, pre, post, ("residual",))
         p_elapsed = statistics.median(p_times)
         pl, pms = p_prof["residual"]
         p_spmv_ms = h2.spmv_time(20)
@@ -379,7 +380,12 @@ def main():
                    "unknowns": n, "nnz": nnz, "grids": meta["grids"], "pre": pre, "post": post,
                    "smoother": args.smoother, "hipgraph": bool(args.graph),
                    "repeats": repeats, "ms_per_step_all": [round(1e3 * t / args.steps, 4) for t in times],
-                   "final_residual_norm": norm, "setup_s": round(setup_s, 2),
+                   "final_residual_norm": norm,
+                   "norms": "every cycle of a timed region computes its residual norm (all K are returned at the region's "
+                            "end; the red rows' share of cycle k is formed by cycle k+1's first red launch, which computes "
+                            "those residuals anyway - bit-identical, tests/test_gpu_parity.py; OMG_NO_PRENORM=1 gives it a launch of its own)",
+                   "norms_last_region_tail": region_norms[-3:],
+                   "setup_s": round(setup_s, 2),
                    "setup_what": "restrictionList + coeffecientList (device Galerkin products) + device hierarchy; "
                                  "generating the synthetic operator and right-hand side on the host took generate_s",
                    "generate_s": round(generate_s, 2)},

@@ -150,6 +150,13 @@ int omg_hierarchy_cycle_dev(omg_hierarchy *h, const double *b_dev, double *x_dev
  * live in HBM between calls.                                                             */
 int omg_resident_load(omg_hierarchy *h, const double *b, const double *x0 /* NULL = zeros */);
 int omg_resident_cycle(omg_hierarchy *h, int pre, int post, double *norm /* NULL = no readback */);
+/* n_cycles cycles back to back with EVERY cycle's residual norm computed (openmg/__init__.py:227)
+ * and returned in norms[n_cycles]; one host synchronisation at the end.  mgSolve's loop
+ * (openmg/__init__.py:132-138) when it stops on a cycle count.  Where the ordering allows it
+ * (two colour sets, or Jacobi) the norm of cycle k is finished inside the first launch of cycle
+ * k + 1, which forms the same residuals anyway — same bits as n_cycles omg_resident_cycle calls;
+ * OMG_NO_PRENORM=1 switches that off.                                                        */
+int omg_resident_cycles(omg_hierarchy *h, int pre, int post, int n_cycles, double *norms /* nullable */);
 int omg_resident_fetch(omg_hierarchy *h, double *x);
 /* Fine-grid SpMV y = A[0] x (tools.flexibleMmult, openmg/tools.py:26) on the resident
  * operator, `reps` back-to-back launches inside one hipEvent bracket; *avg_ms per launch. */

@@ -161,6 +161,11 @@ def mgSolve(A_in, b, parameters):
             by_norm = "threshold" in parameters and parameters["threshold"] > 0 and norm < parameters["threshold"]
             return by_count or by_norm
 
+        if (not verbose and parameters.get("cycles", 0) > cycle and not parameters.get("threshold", 0) > 0):
+            # stop rule = cycle count only: the remaining cycles go to the device in one call (every
+            # cycle's norm is still computed; only the last one is observable here)
+            norm = hierarchy.resident_cycles(pre, post, parameters["cycles"] - cycle)[-1]
+            cycle = parameters["cycles"]
         while not finished():
             if verbose:
                 print("cycle %i < cycles %i" % (cycle, parameters["cycles"]))

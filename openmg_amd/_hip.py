@@ -72,6 +72,7 @@ SIGNATURES = {
     "omg_solve": (_I, [_P, _P, _P, _I, _I, _I, _D, _IP, _DP]),
     "omg_resident_load": (_I, [_P, _P, _P]),
     "omg_resident_cycle": (_I, [_P, _I, _I, _DP]),
+    "omg_resident_cycles": (_I, [_P, _I, _I, _I, _DP]),
     "omg_resident_fetch": (_I, [_P, _P]),
     "omg_resident_spmv_time": (_I, [_P, _I, _DP]),
     "omg_resident_use_graph": (_I, [_P, _I]),
@@ -287,6 +288,12 @@ class Hierarchy:
             return norm.value
         check(lib().omg_resident_cycle(self._h, int(pre), int(post), None))
         return None
+
+    def resident_cycles(self, pre, post, n_cycles):
+        """n_cycles V-cycles back to back; returns every cycle's residual norm (omg_resident_cycles)."""
+        norms = (ctypes.c_double * max(int(n_cycles), 1))()
+        check(lib().omg_resident_cycles(self._h, int(pre), int(post), int(n_cycles), norms))
+        return [float(norms[k]) for k in range(int(n_cycles))]
 
     def resident_fetch(self):
         x = np.empty(self.sizes[0], dtype=np.float64)

@@ -292,7 +292,19 @@ enum RowMode : int {
     // R^T.  Only for operators whose columns each hold at most one entry (aggregation: no two
     // rows write the same y) and whose blocks are all pattern coded (rows_pattern_kernel).
     ROW_SCATTER = 9,
+    // First launch of a cycle, also finishing the PREVIOUS cycle's residual norm: a Gauss-Seidel
+    // sweep of the first of two colour sets, or a Jacobi sweep, forms b_i - sum_j a_ij x_j with the
+    // iterate the previous cycle left — exactly the residual its norm launch would compute for
+    // these rows (same chain, same bits) — so the launch also leaves the squares in the block
+    // partials and the separate norm launch over these rows is not needed
+    // (hierarchy.hip omg_resident_cycles).
+    ROW_GS_PRENORM = 10,      // x += (b - A x) / diag, block partials of (b - A x)^2
+    ROW_JACOBI_PRENORM = 11,  // y = x + omega (b - A x) / diag, block partials of (b - A x)^2
 };
+constexpr bool mode_fused(int m) { return m == ROW_GS_RES || m == ROW_GS_NORM; }
+constexpr bool mode_prenorm(int m) { return m == ROW_GS_PRENORM || m == ROW_JACOBI_PRENORM; }
+constexpr bool mode_relaxes(int m) { return m == ROW_GS || m == ROW_JACOBI || mode_fused(m) || mode_prenorm(m); }   // needs x_i and the diagonal
+constexpr bool mode_norm(int m) { return m == ROW_RESNORM || m == ROW_NORM_ONLY || m == ROW_GS_NORM || mode_prenorm(m); }
 
 template <typename V>
 struct RowArgsT {

@@ -132,7 +132,7 @@ __device__ __forceinline__ RowPre<V> row_preload(const KArgs<V> &a, int r, int e
     p.bv = V(0);
     p.xv = V(0);
     if constexpr (MODE != ROW_SPMV && MODE != ROW_AXPY && MODE != ROW_SCATTER) p.bv = a.b[r];
-    if constexpr (MODE == ROW_GS || MODE == ROW_JACOBI || MODE == ROW_GS_RES || MODE == ROW_GS_NORM)
+    if constexpr (mode_relaxes(MODE))
         p.xv = a.x[r];
     if constexpr (MODE == ROW_AXPY) p.xv = a.y[r];
     p.out = r;
@@ -205,6 +205,14 @@ __device__ __forceinline__ void row_epilogue(const KArgs<V> &a, int r, const Row
         a.y[r] = p.xv + (p.bv - sum) / diag;
     } else if constexpr (MODE == ROW_JACOBI) {
         a.y[r] = p.xv + a.omega * ((p.bv - sum) / diag);
+    } else if constexpr (MODE == ROW_GS_PRENORM) {
+        const V res = p.bv - sum;                  // the expression ROW_GS divides by the diagonal, and ROW_NORM_ONLY squares
+        a.y[r] = p.xv + res / diag;
+        sq += double(res) * double(res);
+    } else if constexpr (MODE == ROW_JACOBI_PRENORM) {
+        const V res = p.bv - sum;
+        a.y[r] = p.xv + a.omega * (res / diag);
+        sq += double(res) * double(res);
     } else if constexpr (MODE == ROW_AXPY) {
         a.y[r] = p.xv + sum;
     }
@@ -219,8 +227,8 @@ template <int MODE, bool nt, bool SHORT, int LPR, bool LONG, typename V>
 __device__ void process_block(const KArgs<V> &a, int blk, V *s_val, int *s_idx, double *s_red, int *s_cd,
                               V *s_vd) {
     constexpr bool FUSED = (MODE == ROW_GS_RES || MODE == ROW_GS_NORM);
-    constexpr bool NEED_DIAG = (MODE == ROW_GS || MODE == ROW_JACOBI || FUSED);
-    constexpr bool NEED_NORM = (MODE == ROW_RESNORM || MODE == ROW_NORM_ONLY || MODE == ROW_GS_NORM);
+    constexpr bool NEED_DIAG = mode_relaxes(MODE);
+    constexpr bool NEED_NORM = mode_norm(MODE);
     using vdat = typename Vec16<V>::type;
     constexpr int VN = Vec16<V>::N;
     const int tid = threadIdx.x;
@@ -634,7 +642,7 @@ __device__ __forceinline__ void pattern_chunk(const PatDictRef<BIG, V> &d, const
                                               bool whole, bool four, const RowPre<V> &pre, Chains<V> &acc,
                                               Chains<V> &dacc, V &sum2, V &xnew) {
     constexpr bool FUSED = (MODE == ROW_GS_RES || MODE == ROW_GS_NORM);
-    constexpr bool NEED_DIAG = (MODE == ROW_GS || MODE == ROW_JACOBI || FUSED);
+    constexpr bool NEED_DIAG = mode_relaxes(MODE);
     int off[N];
     V val[N], xg[N];
 #pragma unroll
@@ -734,10 +742,10 @@ __device__ __forceinline__ void pattern_rows(const KArgs<V> &a, int r, bool acti
 // ELL: the launch may hold blocks whose values sit in the ELL array (host: set_ell)
 template <int MODE, bool LONG, bool ELL, typename V>
 __global__ __launch_bounds__(NT, (MODE == ROW_GS_RES || MODE == ROW_GS_NORM) ? (LONG ? 4 : 6)
-                                                                              : (MODE == ROW_GS || MODE == ROW_JACOBI) ? 7 : 8)
+                                                                              : (MODE == ROW_GS || MODE == ROW_JACOBI || mode_prenorm(MODE)) ? 7 : 8)
 void rows_pattern_kernel(KArgs<V> a, int blk0) {
     constexpr bool FUSED = (MODE == ROW_GS_RES || MODE == ROW_GS_NORM);
-    constexpr bool NEED_NORM = (MODE == ROW_RESNORM || MODE == ROW_NORM_ONLY || MODE == ROW_GS_NORM);
+    constexpr bool NEED_NORM = mode_norm(MODE);
     __shared__ double s_red[NT / 64];
     const int blk = blk0 + int(blockIdx.x);
     const v4i *info = reinterpret_cast<const v4i *>(a.blk_info);
@@ -819,8 +827,8 @@ __device__ __forceinline__ float buffer_gather(__amdgpu_buffer_rsrc_t rs, int by
 template <int MODE, int U, int UMAX, typename V>
 __global__ __launch_bounds__(NT) void rows_union_kernel(KArgs<V> a, int blk0, unsigned x_bytes) {
     constexpr bool FUSED = (MODE == ROW_GS_RES || MODE == ROW_GS_NORM);
-    constexpr bool NEED_DIAG = (MODE == ROW_GS || MODE == ROW_JACOBI || FUSED);
-    constexpr bool NEED_NORM = (MODE == ROW_RESNORM || MODE == ROW_NORM_ONLY || MODE == ROW_GS_NORM);
+    constexpr bool NEED_DIAG = mode_relaxes(MODE);
+    constexpr bool NEED_NORM = mode_norm(MODE);
     __shared__ double s_red[NT / 64];
     const int blk = blk0 + int(blockIdx.x);
     const v4i *info = reinterpret_cast<const v4i *>(a.blk_info);
@@ -1088,6 +1096,8 @@ void launch_rows_uniform(const DevCsrT<V> &A, int mode, int set_begin, int set_e
         case ROW_NORM_ONLY: launch_mode<ROW_NORM_ONLY>(A, blk0, nblk, k, kind, long_rows, ell, s); break;
         case ROW_GS: launch_mode<ROW_GS>(A, blk0, nblk, k, kind, long_rows, ell, s); break;
         case ROW_JACOBI: launch_mode<ROW_JACOBI>(A, blk0, nblk, k, kind, long_rows, ell, s); break;
+        case ROW_GS_PRENORM: launch_mode<ROW_GS_PRENORM>(A, blk0, nblk, k, kind, long_rows, ell, s); break;
+        case ROW_JACOBI_PRENORM: launch_mode<ROW_JACOBI_PRENORM>(A, blk0, nblk, k, kind, long_rows, ell, s); break;
         case ROW_AXPY: launch_mode<ROW_AXPY>(A, blk0, nblk, k, kind, long_rows, ell, s); break;
         default: throw Error(OMG_ERR_INVALID, "launch_rows: unknown mode");
     }

@@ -35,6 +35,8 @@ void require_device() {
 
 namespace {
 
+inline bool getenv_flag(const char *name) { const char *e = getenv(name); return e && e[0] == '1'; }
+
 struct SweepStep {
     int set_begin, set_end;   // [begin, end)
     bool serial;              // run of single-block sets -> one workgroup
@@ -71,6 +73,7 @@ struct Hier {
     std::vector<Level<V>> lv;
     CoarseSolver<V> coarse;   // direct solve of the coarsest operator (common.h)
     DevBuf<double> norm_dev;
+    DevBuf<double> norms_dev;      // omg_resident_cycles: one norm per cycle of the batch
     int smoother = OMG_SMOOTH_GS_LEX;
     double omega = 1.0;
     hipStream_t own = nullptr, stream = nullptr;
@@ -179,9 +182,23 @@ bool can_fuse(const Hier<V> *h, const Level<V> &L) {
     return !L.plan.back().serial;
 }
 
-// Returns true when the last set launch was fused (its rows' residual / norm is done).
+// Can the FIRST launch of a cycle entered at this level also finish the previous cycle's residual
+// norm (RowMode ROW_GS_PRENORM / ROW_JACOBI_PRENORM)?  Jacobi: its one launch sees the iterate
+// the previous cycle left, for every row.  Gauss-Seidel: only the first set does, so the other
+// sets' share must already be there — two sets, the second one's squares left by the fused
+// post-smoothing launch (ROW_GS_NORM).
 template <typename V>
-bool smooth_level(Hier<V> *h, int l, int iterations, Fuse fuse = FUSE_NONE) {
+bool can_prenorm(const Hier<V> *h, const Level<V> &L, int pre, int post) {
+    if (pre <= 0 || L.plan.empty()) return false;
+    if (h->smoother == OMG_SMOOTH_JACOBI) return true;
+    return L.A.n_sets() == 2 && post > 0 && can_fuse(h, L) && !L.plan.front().serial && L.plan.size() == 2;
+}
+
+// Returns true when the last set launch was fused (its rows' residual / norm is done).
+// prev_norm (device scalar, nullable): the first launch runs in the PRENORM mode and the
+// previous cycle's norm is summed into *prev_norm right behind it (caller checked can_prenorm).
+template <typename V>
+bool smooth_level(Hier<V> *h, int l, int iterations, Fuse fuse = FUSE_NONE, double *prev_norm = nullptr) {
     Level<V> &L = h->lv[l];
     bool fused = false;
     for (int it = 0; it < iterations; ++it) {
@@ -189,7 +206,13 @@ bool smooth_level(Hier<V> *h, int l, int iterations, Fuse fuse = FUSE_NONE) {
             Prof<V> p(h, l, 0);
             RowArgsT<V> a;
             a.x = L.xp; a.b = L.b.p; a.y = L.tp; a.omega = h->omega;
-            launch_rows(L.A, ROW_JACOBI, -1, a, h->stream);
+            if (it == 0 && prev_norm) {
+                a.partials = L.partials.p;
+                launch_rows(L.A, ROW_JACOBI_PRENORM, -1, a, h->stream);
+                launch_sum_sqrt(L.partials.p, L.A.n_blocks(), prev_norm, h->stream);
+            } else {
+                launch_rows(L.A, ROW_JACOBI, -1, a, h->stream);
+            }
             std::swap(L.xp, L.tp);
         } else {
             RowArgsT<V> a;
@@ -206,6 +229,11 @@ bool smooth_level(Hier<V> *h, int l, int iterations, Fuse fuse = FUSE_NONE) {
                     f.partials = L.partials.p;
                     launch_rows(L.A, fuse == FUSE_RESIDUAL ? ROW_GS_RES : ROW_GS_NORM, st.set_begin, f, h->stream);
                     fused = true;
+                } else if (it == 0 && k == 0 && prev_norm) {
+                    RowArgsT<V> f = a;
+                    f.partials = L.partials.p;            // the first set's blocks; the last set's are in place (ROW_GS_NORM)
+                    launch_rows(L.A, ROW_GS_PRENORM, st.set_begin, f, h->stream);
+                    launch_sum_sqrt(L.partials.p, L.A.n_blocks(), prev_norm, h->stream);
                 } else {
                     launch_rows(L.A, ROW_GS, st.set_begin, a, h->stream);
                 }
@@ -230,7 +258,7 @@ void residual_level(Hier<V> *h, int l, V *r_out, bool last_set_done = false) {
 // ||b - A x||_2 of level l into h->norm_dev (device scalar); r_out optional.  With
 // last_set_done the last set's block partials are already in place.
 template <typename V>
-void norm_level(Hier<V> *h, int l, V *r_out, bool last_set_done = false) {
+void norm_level(Hier<V> *h, int l, V *r_out, bool last_set_done = false, double *out = nullptr) {
     Level<V> &L = h->lv[l];
     {
         Prof<V> p(h, l, 4);
@@ -239,7 +267,7 @@ void norm_level(Hier<V> *h, int l, V *r_out, bool last_set_done = false) {
         const int ns = (int)L.A.n_sets();
         launch_rows_range(L.A, r_out ? ROW_RESNORM : ROW_NORM_ONLY, 0, last_set_done ? ns - 1 : ns, a, h->stream);
     }
-    launch_sum_sqrt(L.partials.p, L.A.n_blocks(), h->norm_dev.p, h->stream);
+    launch_sum_sqrt(L.partials.p, L.A.n_blocks(), out ? out : h->norm_dev.p, h->stream);
 }
 
 // coarse = R fine; `clear` (nullable, coarse-sized) is zeroed by the same launch.
@@ -280,7 +308,7 @@ void coarse_solve_level(Hier<V> *h) {
 // post-smoother's last set launch then also leaves that set's share of the norm in the block
 // partials.  Returns true when it did (norm_level(..., last_set_done = true) finishes it).
 template <typename V>
-bool cycle_body(Hier<V> *h, int l, int pre, int post, bool want_norm = false) {
+bool cycle_body(Hier<V> *h, int l, int pre, int post, bool want_norm = false, double *prev_norm = nullptr) {
     const int last = (int)h->lv.size() - 1;
     if (l >= last) {
         coarse_solve_level(h);
@@ -288,7 +316,7 @@ bool cycle_body(Hier<V> *h, int l, int pre, int post, bool want_norm = false) {
     }
     Level<V> &L = h->lv[l];
     Level<V> &C = h->lv[l + 1];
-    const bool res_done = smooth_level(h, l, pre, FUSE_RESIDUAL);   // :201 (+ last set's share of :209)
+    const bool res_done = smooth_level(h, l, pre, FUSE_RESIDUAL, prev_norm);   // :201 (+ last set's share of :209)
     residual_level(h, l, L.r.p, res_done);                          // :209
     // :210, and the coarse cycle's initial=None -> zeros (:191-192) cleared by the same launch
     restrict_level<V>(h, l, L.r.p, C.b.p, l + 1 < last ? C.xp : nullptr);
@@ -801,6 +829,40 @@ int omg_resident_cycle(omg_hierarchy *h, int pre, int post, double *norm) {
             OMG_REQUIRE(pre >= 0 && post >= 0, "negative sweep count");
             run_cycle0(hh, pre, post);
             if (norm) *norm = read_norm(hh);
+        });
+    });
+}
+
+// n cycles back to back, EVERY cycle's residual norm computed and returned (norms[n], host).  Where
+// can_prenorm() holds, the norm of cycle k is finished inside cycle k + 1's first launch instead of
+// by a launch of its own (same partial sums, same order: the same bits as n omg_resident_cycle
+// calls); the last cycle's by the usual norm launch.  One host synchronisation at the end.
+int omg_resident_cycles(omg_hierarchy *h, int pre, int post, int n_cycles, double *norms) {
+    return guarded([&] {
+        with(h, [&](auto *hh) {
+            using V = value_of<decltype(hh)>;
+            check_level(hh, 0);
+            OMG_REQUIRE(hh->resident, "omg_resident_load has not been called");
+            OMG_REQUIRE(pre >= 0 && post >= 0 && n_cycles >= 0, "negative argument");
+            if (n_cycles == 0) return;
+            if (hh->norms_dev.n < size_t(n_cycles)) hh->norms_dev.alloc(size_t(n_cycles));
+            const bool single = hh->lv.size() == 1;
+            const bool defer = !single && !getenv_flag("OMG_NO_PRENORM") && can_prenorm(hh, hh->lv[0], pre, post);
+            for (int k = 0; k < n_cycles; ++k) {
+                if (single) {
+                    cycle_body(hh, 0, pre, post);
+                    OMG_HIP(hipMemsetAsync(hh->norms_dev.p + k, 0, sizeof(double), hh->stream));   // :232
+                    continue;
+                }
+                const bool part = cycle_body(hh, 0, pre, post, true, (defer && k > 0) ? hh->norms_dev.p + (k - 1) : nullptr);
+                if (!defer || k + 1 == n_cycles) {
+                    norm_level<V>(hh, 0, nullptr, part, hh->norms_dev.p + k);                      // :227
+                } else {
+                    OMG_REQUIRE(part || hh->smoother == OMG_SMOOTH_JACOBI, "internal: deferred norm without the fused post-smoothing launch");
+                }
+            }
+            if (norms) OMG_HIP(hipMemcpyAsync(norms, hh->norms_dev.p, size_t(n_cycles) * sizeof(double), hipMemcpyDeviceToHost, hh->stream));
+            OMG_HIP(hipStreamSynchronize(hh->stream));
         });
     });
 }

@@ -897,3 +897,44 @@ def test_union_walk_on_random_stencil_like_operators_is_bit_identical(monkeypatc
                     assert np.array_equal(got, want), (key, dtype, smoother)
                 np.testing.assert_allclose(run[3], base[3], rtol=1e-13 if dtype == "float64" else 1e-6)
                 np.testing.assert_allclose(run[4], base[4], rtol=1e-13 if dtype == "float64" else 1e-6)
+
+
+# -------------------------------------------- batched cycles: the norm finished by the next cycle --
+@pytest.mark.parametrize("smoother,dtype", [("colour", "float64"), ("jacobi", "float64"), ("gs", "float64"),
+                                            ("colour", "float32"), ("jacobi", "float32")])
+def test_batched_cycles_return_every_norm_bit_for_bit(monkeypatch, smoother, dtype):
+    """omg_resident_cycles(n): n cycles, n norms.  With two colour sets (or Jacobi) the norm of cycle
+    k is finished inside cycle k + 1's first launch (ROW_GS_PRENORM / ROW_JACOBI_PRENORM: the launch
+    forms b - A x for its rows with the iterate cycle k left) — the norms and the iterate must be
+    the bits of n single omg_resident_cycle calls, and of the batch with OMG_NO_PRENORM=1."""
+    runs = {}
+    for shape, grids in (((32, 32, 32), 3), ((96, 96), 3)):
+        A0 = operators.stencil_poisson(shape)
+        R = operators.restrictionList(shape, grids - 2, 4)
+        A = operators.coeffecientList(A0, R)
+        b = A0 @ np.random.default_rng(5).random(A0.shape[0])
+        for pre, post in ((1, 1), (2, 1), (1, 0), (0, 1)):
+            out = []
+            for how in ("single", "batch", "batch_noprenorm"):
+                monkeypatch.setenv("OMG_NO_PRENORM", "1" if how == "batch_noprenorm" else "0")
+                with _hip.Hierarchy(A, R, smoother=smoother, omega=0.7, dtype=dtype) as h:
+                    h.resident_load(b)
+                    if how == "single":
+                        norms = [h.resident_cycle(pre, post) for _ in range(5)]
+                    else:
+                        norms = h.resident_cycles(pre, post, 2) + h.resident_cycles(pre, post, 3)     # batches chain
+                    out.append((norms, h.resident_fetch()))
+            for other in out[1:]:
+                assert other[0] == out[0][0], (shape, pre, post)
+                assert np.array_equal(other[1], out[0][1])
+    # through mgSolve: a cycle-count stop rule takes the batched path
+    shape = (32, 32, 32)
+    A0 = operators.stencil_poisson(shape)
+    b = A0 @ np.random.default_rng(6).random(A0.shape[0])
+    p = {"problemShape": shape, "gridLevels": 2, "preIterations": 1, "postIterations": 1, "cycles": 6, "threshold": 0,
+         "giveInfo": True, "smoother": smoother, "dtype": dtype}
+    u, info = openmg_amd.mgSolve(A0, b, dict(p))
+    with _hip.Hierarchy(info["A"], info["R"], smoother=smoother, omega=2.0 / 3.0, dtype=dtype) as h:
+        h.resident_load(b)
+        norms = [h.resident_cycle(1, 1) for _ in range(6)]
+        assert info["cycle"] == 6 and info["norm"] == norms[-1] and np.array_equal(u, h.resident_fetch())
