@@ -298,6 +298,10 @@ int omg_dist_fetch(omg_dist *d, double *x_local);
 /* One V-cycle over all ranks (collective: every rank calls it).  *norm (nullable) = the
  * GLOBAL ||b - A x||_2 (openmg/__init__.py:227).                                          */
 int omg_dist_cycle(omg_dist *d, int pre, int post, double *norm);
+/* n_cycles cycles with every cycle's GLOBAL norm computed, norms[n_cycles] (nullable) returned at
+ * the end — the multi-GPU form of omg_resident_cycles (same deferral of the first colour's share
+ * of the norm into the next cycle's first launches, same bits as n_cycles omg_dist_cycle calls). */
+int omg_dist_cycles(omg_dist *d, int pre, int post, int n_cycles, double *norms);
 /* Per-GPU measurement helpers of a multi-GPU run: `reps` launches of y = A_0 x over this rank's
  * rows in one hipEvent bracket (average ms per launch), and omg_hierarchy_format_info for this
  * rank's operators.                                                                          */
@@ -312,6 +316,7 @@ int omg_dist_level_flags(omg_dist *d, int level, int *flags);
 int omg_dist_group_create(int n, omg_dist **ranks, omg_dist_group **out);
 int omg_dist_group_destroy(omg_dist_group *g);
 int omg_dist_group_cycle(omg_dist_group *g, int pre, int post, double *norm);
+int omg_dist_group_cycles(omg_dist_group *g, int pre, int post, int n_cycles, double *norms);
 
 #ifdef __cplusplus
 }

@@ -106,12 +106,14 @@ SIGNATURES = {
     "omg_dist_load": (_I, [_P, _P, _P]),
     "omg_dist_fetch": (_I, [_P, _P]),
     "omg_dist_cycle": (_I, [_P, _I, _I, _DP]),
+    "omg_dist_cycles": (_I, [_P, _I, _I, _I, _DP]),
     "omg_dist_spmv_time": (_I, [_P, _I, _DP]),
     "omg_dist_format_info": (_I, [_P, _I, _I, _I, _I64P]),
     "omg_dist_level_flags": (_I, [_P, _I, _IP]),
     "omg_dist_group_create": (_I, [_I, _PP, _PP]),
     "omg_dist_group_destroy": (_I, [_P]),
     "omg_dist_group_cycle": (_I, [_P, _I, _I, _DP]),
+    "omg_dist_group_cycles": (_I, [_P, _I, _I, _I, _DP]),
 }
 
 

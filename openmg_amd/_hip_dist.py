@@ -123,6 +123,12 @@ class DistRank:
         return None
 
 
+    def cycles(self, pre, post, n_cycles):
+        """n_cycles V-cycles back to back (collective); every cycle's global norm (omg_dist_cycles)."""
+        norms = (ctypes.c_double * max(int(n_cycles), 1))()
+        check(lib().omg_dist_cycles(self._h, int(pre), int(post), int(n_cycles), norms))
+        return [float(norms[k]) for k in range(int(n_cycles))]
+
     def spmv_time(self, reps=20):
         """Average milliseconds of y = A_0 x over this rank's rows (omg_dist_spmv_time)."""
         ms = ctypes.c_double(0.0)
@@ -155,6 +161,11 @@ class DistGroup:
         norm = ctypes.c_double(0.0)
         check(lib().omg_dist_group_cycle(self._g, int(pre), int(post), ctypes.byref(norm) if want_norm else None))
         return norm.value if want_norm else None
+
+    def cycles(self, pre, post, n_cycles):
+        norms = (ctypes.c_double * max(int(n_cycles), 1))()
+        check(lib().omg_dist_group_cycles(self._g, int(pre), int(post), int(n_cycles), norms))
+        return [float(norms[k]) for k in range(int(n_cycles))]
 
     def close(self):
         if getattr(self, "_g", None):

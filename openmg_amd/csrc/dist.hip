@@ -105,6 +105,7 @@ struct DLevel {
 };
 
 __global__ void sqrt_kernel(double *v) { *v = sqrt(*v); }
+__global__ void sqrt_to_kernel(const double *v, double *out) { *out = sqrt(*v); }
 
 template <typename V> struct NcclType;
 template <> struct NcclType<double> { static constexpr ncclDataType_t value = ncclDouble; };
@@ -133,6 +134,7 @@ struct Dist {
     // exchange latency otherwise).  Borrowed, owned by the caller.
     omg_hierarchy *tail = nullptr;
     DevBuf<double> sumsq;                      // device scalar
+    DevBuf<double> norms;                      // omg_dist_cycles: one norm per cycle of the batch
     ncclComm_t comm = nullptr;
     // RCCL calls go to a second stream so that an exchange can overlap the interior rows of
     // a (boundary, interior) set pair; two events order it against the compute stream.
@@ -461,17 +463,33 @@ struct Runner {
     // their squared residual to the block partials (RowMode ROW_GS_RES / ROW_GS_NORM: exact,
     // because a relaxed row's residual involves no other row of its own set).  Returns true
     // when that happened.
-    bool smooth(int l, int iterations, int fuse = 0) {
+    // Can the first launches of a cycle also finish the PREVIOUS cycle's norm (RowMode ROW_GS_PRENORM /
+    // ROW_JACOBI_PRENORM, hierarchy.hip can_prenorm)?  Two colours (each possibly a (boundary,
+    // interior) pair), the second one's squares left by the fused post-smoothing launches; or Jacobi.
+    bool can_prenorm(int pre, int post) const {
+        if (pre <= 0 || rs[0]->lv.size() < 2) return false;
+        if (rs[0]->smoother == OMG_SMOOTH_JACOBI) return true;
+        if (rs[0]->smoother != OMG_SMOOTH_GS_COLOUR || post <= 0) return false;
+        const DLevel<V> &L = rs[0]->lv[0];
+        return (int)L.A.n_sets() == 2 * L.set_group;
+    }
+
+    // prev_norm_slot >= 0: level 0, first sweep of the cycle: the first colour's launches run in the
+    // PRENORM mode and the previous cycle's norm is finished into norms[prev_norm_slot] behind them
+    bool smooth(int l, int iterations, int fuse = 0, int prev_norm_slot = -1) {
         bool fused = false;
         for (int it = 0; it < iterations; ++it) {
+            const bool prenorm = prev_norm_slot >= 0 && it == 0;
             if (rs[0]->smoother == OMG_SMOOTH_JACOBI) {
                 for (D *d : rs) {
                     DLevel<V> &L = d->lv[l];
                     RowArgs a;
                     a.x = L.xp; a.b = L.b.p; a.y = L.tp; a.omega = d->omega;
-                    launch_rows(L.A, ROW_JACOBI, -1, a, d->stream);
+                    if (prenorm) a.partials = L.partials.p;
+                    launch_rows(L.A, prenorm ? ROW_JACOBI_PRENORM : ROW_JACOBI, -1, a, d->stream);
                     std::swap(L.xp, L.tp);
                 }
+                if (prenorm) finish_norm(prev_norm_slot);
                 exchange(l);
             } else {
                 const int n_sets = (int)rs[0]->lv[l].A.n_sets();
@@ -484,7 +502,10 @@ struct Runner {
                         DLevel<V> &L = d->lv[l];
                         RowArgs a;
                         a.x = L.xp; a.b = L.b.p; a.y = L.xp;
-                        if (fuse && it + 1 == iterations && last_group) {
+                        if (prenorm && s < grp) {             // first colour: sees the iterate the previous cycle left
+                            a.partials = L.partials.p;
+                            launch_rows(L.A, ROW_GS_PRENORM, s, a, d->stream);
+                        } else if (fuse && it + 1 == iterations && last_group) {
                             a.zero = L.r.p;
                             a.partials = L.partials.p;
                             launch_rows(L.A, fuse == 1 ? ROW_GS_RES : ROW_GS_NORM, s, a, d->stream);
@@ -501,6 +522,7 @@ struct Runner {
                     // interior rows of the same colour: touch no halo entry, are not sent
                     if (grp == 2) sweep_set(s + 1, last_group);
                     exchange_finish(l);
+                    if (prenorm && s == 0) finish_norm(prev_norm_slot);
                 }
             }
         }
@@ -568,10 +590,10 @@ struct Runner {
         }
     }
 
-    bool cycle(int l, int pre, int post, bool want_norm = false) {
+    bool cycle(int l, int pre, int post, bool want_norm = false, int prev_norm_slot = -1) {
         const int last = (int)rs[0]->lv.size() - 1;
         if (l >= last) { coarse(pre, post); return false; }
-        const bool res_done = smooth(l, pre, 1);
+        const bool res_done = smooth(l, pre, 1, prev_norm_slot);
         for (D *d : rs) {
             DLevel<V> &L = d->lv[l];
             DLevel<V> &C = d->lv[l + 1];
@@ -623,6 +645,13 @@ struct Runner {
         return false;
     }
 
+    // The level-0 block partials of every rank are complete: global norm -> norms[slot] on every rank.
+    void finish_norm(int slot) {
+        for (D *d : rs) launch_sum(d->lv[0].partials.p, d->lv[0].A.n_blocks(), d->sumsq.p, d->stream);
+        reduce_sumsq();
+        for (D *d : rs) hipLaunchKernelGGL(sqrt_to_kernel, dim3(1), dim3(1), 0, d->stream, d->sumsq.p, d->norms.p + slot);
+    }
+
     // sum over all ranks of the local sums of squares -> sqrt, left in every rank's sumsq
     void norm(bool last_set_done) {
         const bool single = rs[0]->lv.size() == 1;
@@ -636,6 +665,12 @@ struct Runner {
             launch_sum(L.partials.p, L.A.n_blocks(), d->sumsq.p, d->stream);
         }
         if (single) return;
+        reduce_sumsq();
+        for (D *d : rs) hipLaunchKernelGGL(sqrt_kernel, dim3(1), dim3(1), 0, d->stream, d->sumsq.p);
+    }
+
+    // every rank's sumsq <- the sum over all ranks
+    void reduce_sumsq() {
         if (rccl) {
             D *d = rs[0];
             if (d->n_ranks > 1)
@@ -652,7 +687,31 @@ struct Runner {
             for (D *d : rs) OMG_HIP(hipMemcpyAsync(d->sumsq.p, &tot, sizeof(double), hipMemcpyHostToDevice, d->stream));
             for (D *d : rs) OMG_HIP(hipStreamSynchronize(d->stream));
         }
-        for (D *d : rs) hipLaunchKernelGGL(sqrt_kernel, dim3(1), dim3(1), 0, d->stream, d->sumsq.p);
+    }
+
+    // n cycles, every cycle's global norm computed; norms_out (host, nullable) gets all of them.
+    // Where can_prenorm() holds the norm of cycle k is finished by cycle k + 1's first launches.
+    void run_batch(int pre, int post, int n, double *norms_out) {
+        for (D *d : rs) OMG_REQUIRE(d->loaded, "omg_dist_load has not been called");
+        if (n <= 0) return;
+        for (D *d : rs) if (d->norms.n < size_t(n)) d->norms.alloc(size_t(n));
+        bool dirty = false;
+        for (D *d : rs) dirty = dirty || d->halo_dirty;
+        if (dirty) { exchange(0); for (D *d : rs) d->halo_dirty = false; }
+        const bool multi = rs[0]->lv.size() > 1;
+        const char *e = getenv("OMG_NO_PRENORM");
+        const bool defer = multi && !(e && e[0] == '1') && can_prenorm(pre, post);
+        for (int k = 0; k < n; ++k) {
+            const bool part = cycle(0, pre, post, multi, (defer && k > 0) ? k - 1 : -1);
+            if (!defer || k + 1 == n) {
+                norm(part);
+                for (D *d : rs)
+                    OMG_HIP(hipMemcpyAsync(d->norms.p + k, d->sumsq.p, sizeof(double), hipMemcpyDeviceToDevice, d->stream));
+            }
+        }
+        D *d0 = rs[0];
+        if (norms_out) OMG_HIP(hipMemcpyAsync(norms_out, d0->norms.p, size_t(n) * sizeof(double), hipMemcpyDeviceToHost, d0->stream));
+        for (D *d : rs) OMG_HIP(hipStreamSynchronize(d->stream));
     }
 
     void run(int pre, int post, double *norm_out) {
@@ -846,6 +905,20 @@ int omg_dist_cycle(omg_dist *d, int pre, int post, double *norm) {
     });
 }
 
+int omg_dist_cycles(omg_dist *d, int pre, int post, int n_cycles, double *norms) {
+    return guarded([&] {
+        OMG_REQUIRE(pre >= 0 && post >= 0 && n_cycles >= 0, "bad argument");
+        with(d, [&](auto *dd) {
+            using V = value_of<decltype(dd)>;
+            OMG_REQUIRE(dd->n_ranks == 1 || dd->comm, "omg_dist_connect has not been called");
+            Runner<V> r;
+            r.rs = {dd};
+            r.rccl = true;
+            r.run_batch(pre, post, n_cycles, norms);
+        });
+    });
+}
+
 // Plain y = A_0 x over this rank's rows (x: the resident iterate with its halo, y: the residual
 // buffer), `reps` launches in one hipEvent bracket on the rank's stream: the per-GPU fine-grid
 // SpMV rate of a multi-GPU run.
@@ -921,6 +994,22 @@ int omg_dist_group_create(int n, omg_dist **ranks, omg_dist_group **out) {
 int omg_dist_group_destroy(omg_dist_group *g) {
     delete g;
     return OMG_OK;
+}
+
+int omg_dist_group_cycles(omg_dist_group *g, int pre, int post, int n_cycles, double *norms) {
+    return guarded([&] {
+        OMG_REQUIRE(g && !g->ranks.empty() && pre >= 0 && post >= 0 && n_cycles >= 0, "bad argument");
+        with(g->ranks[0], [&](auto *first) {
+            using V = value_of<decltype(first)>;
+            Runner<V> r;
+            for (omg_dist *d : g->ranks) {
+                if constexpr (std::is_same<V, double>::value) r.rs.push_back(d->d.get());
+                else r.rs.push_back(d->f.get());
+            }
+            r.rccl = false;
+            r.run_batch(pre, post, n_cycles, norms);
+        });
+    });
 }
 
 int omg_dist_group_cycle(omg_dist_group *g, int pre, int post, double *norm) {

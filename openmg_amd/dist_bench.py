@@ -123,8 +123,7 @@ def main(args):
             r.sync()
             td.barrier()
             t0 = time.perf_counter()
-            for _ in range(probe):
-                r.cycle(pre, post, want_norm=False)
+            r.cycles(pre, post, probe)
             r.sync()
             t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
             td.all_reduce(t, op=td.ReduceOp.MAX)
@@ -140,8 +139,7 @@ def main(args):
         torch.cuda.synchronize()
         td.barrier()
         t0 = time.perf_counter()
-        for _ in range(args.steps):
-            r.cycle(pre, post, want_norm=False)
+        region_norms = r.cycles(pre, post, args.steps)  # K cycles back to back, every cycle's global norm computed
         r.sync()
         torch.cuda.synchronize()
         td.barrier()
@@ -180,7 +178,8 @@ def main(args):
                        "rccl_ranks": rccl_ranks, "repeats": len(times), "overlap_autotune": autotune,
                        "ms_per_step_all": [round(1e3 * t / args.steps, 4) for t in times],
                        "pre": pre, "post": post, "cycles_per_s": round(args.steps / elapsed, 3),
-                       "final_residual_norm": norm, "setup_s": round(setup_s, 2)},
+                       "final_residual_norm": norm, "norms_last_region_tail": region_norms[-3:],
+                       "setup_s": round(setup_s, 2)},
             # rank 0's y = A x over its own rows: bytes the launch has to move with the operator in
             # its device format over the launch time, frac <= 1 by construction;
             # the rate in SURVEY 8(d)'s plain-CSR bytes is csr_equiv_GBps

@@ -307,3 +307,55 @@ def test_27_point_slabs_with_paired_sets_overlap_and_tail(monkeypatch):
                            colouring="octant", n_dist=2)
         assert np.array_equal(xd, x1), dtype
         np.testing.assert_allclose(nd, n1, rtol=1e-13 if dtype == "float64" else 1e-6)
+
+
+@pytest.mark.parametrize("smoother,n_ranks,n_dist", [("colour", 4, 3), ("colour", 2, 2), ("jacobi", 2, 3), ("gs", 2, 3)])
+def test_batched_cycles_over_slabs_return_every_norm(monkeypatch, smoother, n_ranks, n_dist):
+    """omg_dist_group_cycles / omg_dist_cycles: n cycles, n global norms; with two colours (also as
+    (boundary, interior) pairs with the two-stream schedule) or Jacobi the norm of cycle k is finished
+    by cycle k + 1's first launches.  Same iterate and, up to the grouping of the block sums, same
+    norms as single cycles and as one GPU; bitwise equal between the batched and the single-cycle
+    slab runs."""
+    monkeypatch.setenv("OMG_FORCE_OVERLAP", "1")
+    monkeypatch.setenv("OMG_OVERLAP_MIN_ROWS", "0")
+    shape, grids = (32, 32, 32), 4
+    N = int(np.prod(shape))
+    b = operators.stencil_poisson(shape) @ np.random.default_rng(21).random(N)
+    x1, n1 = single_gpu(shape, grids, smoother, b, 5)
+    out = []
+    for how in ("single", "batch"):
+        part = dist.SlabPartition(shape, n_ranks, n_dist)
+        levels, coarse, counts = dist.build_all_ranks(
+            part, lambda q: dist.stencil_rows(shape, *part.rows(0, q)), smoother=smoother)
+        ranks = [_hip_dist.DistRank(q, n_ranks, levels[q], None, counts, smoother=smoother, omega=0.8,
+                                    tail=dist.make_tail(coarse, part.shapes[-1], grids - n_dist + 1, smoother=smoother, omega=0.8))
+                 for q in range(n_ranks)]
+        group = _hip_dist.DistGroup(ranks)
+        try:
+            for q, r in enumerate(ranks):
+                r.load(b[slice(*part.rows(0, q))])
+            norms = [group.cycle(1, 1) for _ in range(5)] if how == "single" else group.cycles(1, 1, 2) + group.cycles(1, 1, 3)
+            out.append((norms, np.concatenate([r.fetch() for r in ranks])))
+        finally:
+            group.close()
+    assert out[0][0] == out[1][0] and np.array_equal(out[0][1], out[1][1])
+    if smoother == "colour":
+        assert np.array_equal(out[1][1], x1)
+    else:
+        np.testing.assert_allclose(out[1][1], x1, rtol=1e-12, atol=1e-14)
+    np.testing.assert_allclose(out[1][0], n1, rtol=1e-12)
+    # one-rank RCCL communicator: the real collective calls of the batched path
+    part = dist.SlabPartition(shape, 1, 3)
+    levels, coarse, counts = dist.build_all_ranks(part, lambda q: dist.stencil_rows(shape, 0, N), smoother=smoother)
+    r = _hip_dist.DistRank(0, 1, levels[0], coarse, counts, smoother=smoother, omega=0.8)
+    try:
+        r.connect(_hip_dist.rccl_unique_id())
+        assert r.rccl_ranks() == 1
+        r.load(b)
+        norms = r.cycles(1, 1, 3)
+        x = r.fetch()
+    finally:
+        r.close()
+    xs, ns = single_gpu(shape, 3, smoother, b, 3)
+    np.testing.assert_allclose(norms, ns, rtol=1e-12)
+    np.testing.assert_allclose(x, xs, rtol=1e-12, atol=1e-14)
