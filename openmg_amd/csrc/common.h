@@ -316,6 +316,14 @@ struct RowArgsT {
     V *zero = nullptr;           // ROW_SPMV: zero[r] = 0 alongside y[r] (fused clear);
                                  // ROW_GS_RES: residual of the relaxed rows goes here
     const int32_t *ymap = nullptr;   // ROW_SPMV: result of row r goes to y[ymap[r]]
+    // ROW_SPMV with `zero` (restriction: y = next level's right-hand side, zero = its initial
+    // iterate): instead of 0, the slots below first_end get what the next level's FIRST smoothing
+    // launch would make of a zero iterate — 0 + (y - 0) / diag for the first Gauss-Seidel set,
+    // 0 + omega ((y - 0) / diag) for a Jacobi sweep (every entry of the sum is v * 0) — and that
+    // launch is skipped.  diag: the diagonal of the next level's operator (its ordering).
+    const V *first_diag = nullptr;
+    int first_end = 0;
+    bool first_jacobi = false;
 };
 using RowArgs = RowArgsT<double>;
 

@@ -79,6 +79,9 @@ struct KArgs {
     V *zero;                   // SpMV: also clear zero[r] (next level's initial iterate); GS_RES: residual
     const int32_t *ymap;       // SpMV only: row r is stored to y[ymap[r]] (NULL: y[r])
     V omega;
+    const V *first_diag;       // SpMV with `zero`: see RowArgsT::first_diag
+    int first_end;
+    int first_jacobi;
 };
 
 template <typename S>
@@ -190,7 +193,16 @@ __device__ __forceinline__ void row_epilogue(const KArgs<V> &a, int r, const Row
                                              V diag, double &sq) {
     if constexpr (MODE == ROW_SPMV) {
         a.y[p.out] = sum;
-        if (a.zero) a.zero[r] = V(0);
+        if (a.zero) {
+            V x0 = V(0);
+            if (a.first_diag && p.out < a.first_end) {
+                // the next level's first relaxation of a zero iterate, spelled like row_epilogue's
+                // ROW_GS / ROW_JACOBI with x_i = 0 and a row sum of +0
+                const V q = (sum - V(0)) / a.first_diag[p.out];
+                x0 = V(0) + (a.first_jacobi ? a.omega * q : q);
+            }
+            a.zero[p.out] = x0;
+        }
     } else if constexpr (MODE == ROW_RESIDUAL) {
         a.y[r] = p.bv - sum;
     } else if constexpr (MODE == ROW_RESNORM) {
@@ -1050,6 +1062,9 @@ KArgs<V> make_kargs(const DevCsrT<V> &A, const RowArgsT<V> &args) {
     k.zero = args.zero;
     k.ymap = args.ymap;
     k.omega = V(args.omega);
+    k.first_diag = args.first_diag;
+    k.first_end = args.first_end;
+    k.first_jacobi = args.first_jacobi ? 1 : 0;
     return k;
 }
 

@@ -52,6 +52,7 @@ struct Level {
     DevBuf<int32_t> perm;     // new -> old (empty when identity)
     DevBuf<int32_t> r_out;    // restriction row (natural coarse numbering) -> slot in the next level's ordering
     DevBuf<V> x, b, r, tmp;
+    DevBuf<V> diag;           // diagonal of A in this level's ordering (levels entered with a zero iterate: restrict_level)
     DevBuf<double> partials;
     DevBuf<double> nat;       // natural-order (double) staging for host I/O at this level
     V *xp = nullptr, *tp = nullptr;   // current iterate / Jacobi scratch (swap)
@@ -197,12 +198,16 @@ bool can_prenorm(const Hier<V> *h, const Level<V> &L, int pre, int post) {
 // Returns true when the last set launch was fused (its rows' residual / norm is done).
 // prev_norm (device scalar, nullable): the first launch runs in the PRENORM mode and the
 // previous cycle's norm is summed into *prev_norm right behind it (caller checked can_prenorm).
+// first_done: the first launch of the first sweep has already been applied (restrict_level wrote
+// its result for a zero iterate): skip it.
 template <typename V>
-bool smooth_level(Hier<V> *h, int l, int iterations, Fuse fuse = FUSE_NONE, double *prev_norm = nullptr) {
+bool smooth_level(Hier<V> *h, int l, int iterations, Fuse fuse = FUSE_NONE, double *prev_norm = nullptr,
+                  bool first_done = false) {
     Level<V> &L = h->lv[l];
     bool fused = false;
     for (int it = 0; it < iterations; ++it) {
         if (h->smoother == OMG_SMOOTH_JACOBI) {
+            if (it == 0 && first_done) continue;
             Prof<V> p(h, l, 0);
             RowArgsT<V> a;
             a.x = L.xp; a.b = L.b.p; a.y = L.tp; a.omega = h->omega;
@@ -220,6 +225,7 @@ bool smooth_level(Hier<V> *h, int l, int iterations, Fuse fuse = FUSE_NONE, doub
             const bool last_it = it + 1 == iterations;
             for (size_t k = 0; k < L.plan.size(); ++k) {
                 const SweepStep &st = L.plan[k];
+                if (it == 0 && k == 0 && first_done) continue;
                 Prof<V> p(h, l, 0);
                 if (st.serial) {
                     launch_gs_serial(L.A, st.set_begin, st.set_end, a, h->stream);
@@ -270,13 +276,34 @@ void norm_level(Hier<V> *h, int l, V *r_out, bool last_set_done = false, double 
     launch_sum_sqrt(L.partials.p, L.A.n_blocks(), out ? out : h->norm_dev.p, h->stream);
 }
 
-// coarse = R fine; `clear` (nullable, coarse-sized) is zeroed by the same launch.
+// Can the restriction INTO level C also apply C's first smoothing launch?  A cycle enters C with
+// a zero iterate, so that launch — the first set of a Gauss-Seidel sweep, or a whole Jacobi sweep
+// — computes x_i = 0 + (b_i - 0) / a_ii (every term of the row sum is v * 0): no gather needed, and
+// the restriction's thread holds b_i (RowArgsT::first_diag).  OMG_NO_FIRST_SWEEP=1 switches it off.
 template <typename V>
-void restrict_level(Hier<V> *h, int l, const V *fine, V *coarse, V *clear = nullptr) {
+bool first_sweep_in_restrict(const Hier<V> *h, const Level<V> &C, int pre) {
+    if (pre <= 0 || !C.diag.p || C.plan.empty() || getenv_flag("OMG_NO_FIRST_SWEEP")) return false;
+    // (a captured graph bakes the Jacobi ping-pong pointers in: keep two swaps per V(1,1) level there)
+    if (h->smoother == OMG_SMOOTH_JACOBI) return !h->want_graph;
+    const SweepStep &st = C.plan.front();
+    return !st.serial && st.set_begin == 0 && st.set_end == 1;
+}
+
+// coarse = R fine; `clear` (nullable, coarse-sized) is zeroed by the same launch — or, with
+// first_sweep, set to what the coarse level's first smoothing launch makes of a zero iterate.
+template <typename V>
+void restrict_level(Hier<V> *h, int l, const V *fine, V *coarse, V *clear = nullptr, bool first_sweep = false) {
     Level<V> &L = h->lv[l];
     Prof<V> p(h, l, 2);
     RowArgsT<V> a;
     a.x = fine; a.y = coarse; a.zero = clear; a.ymap = L.r_out.p;
+    if (first_sweep && clear) {
+        const Level<V> &C = h->lv[l + 1];
+        a.first_diag = C.diag.p;
+        a.first_jacobi = h->smoother == OMG_SMOOTH_JACOBI;
+        a.first_end = int(a.first_jacobi ? C.n : C.A.sets[1]);
+        a.omega = h->omega;
+    }
     launch_rows(L.R, ROW_SPMV, -1, a, h->stream);
 }
 
@@ -308,7 +335,8 @@ void coarse_solve_level(Hier<V> *h) {
 // post-smoother's last set launch then also leaves that set's share of the norm in the block
 // partials.  Returns true when it did (norm_level(..., last_set_done = true) finishes it).
 template <typename V>
-bool cycle_body(Hier<V> *h, int l, int pre, int post, bool want_norm = false, double *prev_norm = nullptr) {
+bool cycle_body(Hier<V> *h, int l, int pre, int post, bool want_norm = false, double *prev_norm = nullptr,
+                bool first_done = false) {
     const int last = (int)h->lv.size() - 1;
     if (l >= last) {
         coarse_solve_level(h);
@@ -316,11 +344,13 @@ bool cycle_body(Hier<V> *h, int l, int pre, int post, bool want_norm = false, do
     }
     Level<V> &L = h->lv[l];
     Level<V> &C = h->lv[l + 1];
-    const bool res_done = smooth_level(h, l, pre, FUSE_RESIDUAL, prev_norm);   // :201 (+ last set's share of :209)
+    const bool res_done = smooth_level(h, l, pre, FUSE_RESIDUAL, prev_norm, first_done);   // :201 (+ last set's share of :209)
     residual_level(h, l, L.r.p, res_done);                          // :209
-    // :210, and the coarse cycle's initial=None -> zeros (:191-192) cleared by the same launch
-    restrict_level<V>(h, l, L.r.p, C.b.p, l + 1 < last ? C.xp : nullptr);
-    cycle_body(h, l + 1, pre, post);                                // :213
+    // :210, and the coarse cycle's initial=None -> zeros (:191-192) cleared by the same launch —
+    // or already relaxed once (first_sweep_in_restrict)
+    const bool child_first = l + 1 < last && first_sweep_in_restrict(h, C, pre);
+    restrict_level<V>(h, l, L.r.p, C.b.p, l + 1 < last ? C.xp : nullptr, child_first);
+    cycle_body(h, l + 1, pre, post, false, nullptr, child_first);   // :213
     prolong_add_level<V>(h, l, C.xp, L.xp);                         // :214, :220/:224
     if (post > 0) return smooth_level(h, l, post, want_norm ? FUSE_NORM : FUSE_NONE);   // :216-222
     return false;
@@ -499,6 +529,20 @@ std::unique_ptr<Hier<V>> create(int n_levels, const omg_csr *A, const omg_csr *R
             { SetupTimer tm("permute A"); Ap = permute_csr(A[l], id ? nullptr : L.ord.perm.data(), id ? nullptr : L.ord.inv.data()); }
             SetupTimer tm("encode + upload A");
             L.A.upload(Ap, L.ord.sets, h->stream);
+            if (l >= 1) {
+                // the diagonal as the sweeps form it (0 + the stored diagonal entries in stored order,
+                // in V): restrict_level applies this level's first relaxation of a zero iterate with it
+                std::vector<V> dg(size_t(L.n));
+                for (int64_t i = 0; i < L.n; ++i) {
+                    V d = V(0);
+                    for (int32_t q = Ap.indptr[i]; q < Ap.indptr[i + 1]; ++q)
+                        if (Ap.indices[q] == i) d = d + V(Ap.data[q]);
+                    dg[size_t(i)] = d;
+                }
+                L.diag.alloc(std::max<int64_t>(L.n, 1));
+                L.diag.upload(dg.data(), size_t(L.n), h->stream);
+                OMG_HIP(hipStreamSynchronize(h->stream));
+            }
         }
         if (!id) {
             L.perm.alloc(L.n);

@@ -938,3 +938,32 @@ def test_batched_cycles_return_every_norm_bit_for_bit(monkeypatch, smoother, dty
         h.resident_load(b)
         norms = [h.resident_cycle(1, 1) for _ in range(6)]
         assert info["cycle"] == 6 and info["norm"] == norms[-1] and np.array_equal(u, h.resident_fetch())
+
+
+@pytest.mark.parametrize("smoother", ["colour", "jacobi", "gs"])
+def test_first_relaxation_applied_by_the_restriction_is_bit_identical(monkeypatch, smoother):
+    """A cycle enters every coarse level with a zero iterate (openmg/__init__.py:191-192), so the
+    first smoothing launch there computes x_i = 0 + (b_i - 0) / a_ii for its rows; the restriction
+    launch that produces b_i writes that instead of the zero and the launch is skipped
+    (hierarchy.hip first_sweep_in_restrict).  OMG_NO_FIRST_SWEEP=1 runs the launch: same bits, for
+    7-entry and 27-entry rows, both precisions, several sweep counts, under hipGraph replay."""
+    n1 = 16
+    T = sp.diags([np.ones(n1 - 1), np.ones(n1), np.ones(n1 - 1)], [-1, 0, 1])
+    A27 = sp.csr_matrix(-sp.kron(sp.kron(T, T), T) + sp.diags(np.full(n1 ** 3, 28.0)))
+    for A0, shape, grids in ((operators.stencil_poisson((32, 32, 32)), (32, 32, 32), 4), (A27, (n1,) * 3, 3),
+                             (operators.stencil_poisson((128, 128)), (128, 128), 4)):
+        R = operators.restrictionList(shape, grids - 2, 4)
+        A = operators.coeffecientList(A0, R)
+        b = A0 @ np.random.default_rng(3).random(A0.shape[0])
+        for dtype in ("float64", "float32"):
+            for pre, post, graph in ((1, 1, False), (2, 0, False), (1, 2, False), (1, 1, True)):
+                out = []
+                for off in ("1", "0"):
+                    monkeypatch.setenv("OMG_NO_FIRST_SWEEP", off)
+                    with _hip.Hierarchy(A, R, smoother=smoother, omega=0.7, dtype=dtype) as h:
+                        h.use_graph(graph)
+                        h.resident_load(b)
+                        norms = [h.resident_cycle(pre, post) for _ in range(3)] + h.resident_cycles(pre, post, 2)
+                        out.append((norms, h.resident_fetch()))
+                assert out[0][0] == out[1][0], (shape, dtype, pre, post, graph)
+                assert np.array_equal(out[0][1], out[1][1])
