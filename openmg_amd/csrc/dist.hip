@@ -88,6 +88,7 @@ struct DLevel {
     DevBuf<int32_t> perm;
     DevBuf<int32_t> r_out;                     // restriction row -> slot in the next level's ordering
     DevBuf<V> x, tmp, b, r;
+    DevBuf<V> diag;                            // owned rows' diagonal, this level's ordering (levels entered with a zero iterate)
     DevBuf<double> partials, nat;              // block sums of squares; double staging for host I/O
     V *xp = nullptr, *tp = nullptr;
     // halo plan
@@ -211,6 +212,20 @@ std::unique_ptr<Dist<V>> create(int rank, int n_ranks, int n_levels, const omg_d
         {
             HostCsr Ap = permute_csr(in.A, id ? nullptr : L.ord.perm.data(), id ? nullptr : L.ord.inv.data(), L.n_loc);
             L.A.upload(Ap, L.ord.sets, d->stream);
+            if (l >= 1 && !last) {
+                // the diagonal as the sweeps form it (hierarchy.hip): the restriction into this level
+                // applies its first relaxation of a zero iterate
+                std::vector<V> dg(size_t(std::max<int64_t>(L.n_loc, 1)));
+                for (int64_t i = 0; i < L.n_loc; ++i) {
+                    V dsum = V(0);
+                    for (int32_t q = Ap.indptr[i]; q < Ap.indptr[i + 1]; ++q)
+                        if (Ap.indices[q] == i) dsum = dsum + V(Ap.data[q]);
+                    dg[size_t(i)] = dsum;
+                }
+                L.diag.alloc(dg.size());
+                L.diag.upload(dg.data(), dg.size(), d->stream);
+                OMG_HIP(hipStreamSynchronize(d->stream));
+            }
         }
         if (!id) { L.perm.alloc(L.n_loc); L.perm.upload(L.ord.perm.data(), L.n_loc, d->stream); }
         if (l == 0) L.nat.alloc(std::max<int64_t>(L.n_loc, 1));
@@ -476,11 +491,24 @@ struct Runner {
 
     // prev_norm_slot >= 0: level 0, first sweep of the cycle: the first colour's launches run in the
     // PRENORM mode and the previous cycle's norm is finished into norms[prev_norm_slot] behind them
-    bool smooth(int l, int iterations, int fuse = 0, int prev_norm_slot = -1) {
+    // Can the restriction into level l also apply its first smoothing launches (hierarchy.hip
+    // first_sweep_in_restrict)?  First colour of a colour ordering, or a Jacobi sweep.
+    bool first_sweep_in_restrict(int l, int pre) const {
+        const char *e = getenv("OMG_NO_FIRST_SWEEP");
+        if (pre <= 0 || (e && e[0] == '1')) return false;
+        for (D *d : rs) if (!d->lv[l].diag.p) return false;
+        if (rs[0]->smoother == OMG_SMOOTH_JACOBI) return true;
+        return rs[0]->smoother == OMG_SMOOTH_GS_COLOUR && (int)rs[0]->lv[l].A.n_sets() >= rs[0]->lv[l].set_group;
+    }
+
+    // first_done: the first colour's launches (or the first Jacobi sweep) of the first iteration have
+    // been applied by the restriction: only their exchange is left
+    bool smooth(int l, int iterations, int fuse = 0, int prev_norm_slot = -1, bool first_done = false) {
         bool fused = false;
         for (int it = 0; it < iterations; ++it) {
             const bool prenorm = prev_norm_slot >= 0 && it == 0;
             if (rs[0]->smoother == OMG_SMOOTH_JACOBI) {
+                if (it == 0 && first_done) { exchange(l); continue; }
                 for (D *d : rs) {
                     DLevel<V> &L = d->lv[l];
                     RowArgs a;
@@ -517,6 +545,7 @@ struct Runner {
                 };
                 for (int s = 0; s < n_sets; s += grp) {
                     const bool last_group = s + grp == n_sets;
+                    if (it == 0 && s == 0 && first_done) { exchange(l, 0); continue; }   // relaxed by the restriction
                     sweep_set(s, last_group);            // plain set, or the BOUNDARY rows of a colour
                     exchange_start(l, s / grp);          // only this colour's values have changed
                     // interior rows of the same colour: touch no halo entry, are not sent
@@ -590,10 +619,11 @@ struct Runner {
         }
     }
 
-    bool cycle(int l, int pre, int post, bool want_norm = false, int prev_norm_slot = -1) {
+    bool cycle(int l, int pre, int post, bool want_norm = false, int prev_norm_slot = -1, bool first_done = false) {
         const int last = (int)rs[0]->lv.size() - 1;
         if (l >= last) { coarse(pre, post); return false; }
-        const bool res_done = smooth(l, pre, 1, prev_norm_slot);
+        const bool res_done = smooth(l, pre, 1, prev_norm_slot, first_done);
+        const bool child_first = l + 1 < last && first_sweep_in_restrict(l + 1, pre);
         for (D *d : rs) {
             DLevel<V> &L = d->lv[l];
             DLevel<V> &C = d->lv[l + 1];
@@ -603,11 +633,17 @@ struct Runner {
             launch_rows_range(L.A, ROW_RESIDUAL, 0, res_done ? ns - L.set_group : ns, a, d->stream);
             RowArgs q;
             q.x = L.r.p; q.y = C.b.p; q.zero = (l + 1 < last) ? C.xp : nullptr; q.ymap = L.r_out.p;
+            if (child_first) {
+                q.first_diag = C.diag.p;
+                q.first_jacobi = d->smoother == OMG_SMOOTH_JACOBI;
+                q.first_end = int(q.first_jacobi ? C.n_loc : C.A.sets[C.set_group]);
+                q.omega = d->omega;
+            }
             launch_rows(L.R, ROW_SPMV, -1, q, d->stream);
             if (l + 1 < last && C.n_halo)
                 OMG_HIP(hipMemsetAsync(C.xp + C.n_loc, 0, C.n_halo * sizeof(V), d->stream));
         }
-        cycle(l + 1, pre, post);
+        cycle(l + 1, pre, post, false, -1, child_first);
         // x_l += R^T x_{l+1} (:214, :220/:224), then everybody needs the corrected boundary values
         // step 0: everything; first 0 / 1 with step 2: the boundary / the interior part
         auto prolong_sets = [&](int first, int step) {
