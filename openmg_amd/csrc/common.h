@@ -351,6 +351,16 @@ template <typename S, typename D>
 void launch_gather(const S *src, const int32_t *idx, D *dst, int64_t n, hipStream_t s);
 template <typename S, typename D>
 void launch_scatter(const S *src, const int32_t *idx, D *dst, int64_t n, hipStream_t s);
+// diag[i] = 0 + the stored entries (i, i) of row i in stored order, summed in V — the diagonal as the
+// relaxation kernels form it (plain CSR arrays of the operator, which stay on the device)
+template <typename V>
+void launch_diagonal(const DevCsrT<V> &A, V *diag, hipStream_t s);
+// x[i] = i < first_end ? 0 + scale_q((b[i] - 0) / diag[i]) : 0 — the first relaxation launch of a
+// zero iterate (first Gauss-Seidel set, or with jacobi a whole weighted-Jacobi sweep), spelled like
+// the row kernels' epilogues
+template <typename V>
+void launch_first_relaxation(const V *b, const V *diag, V *x, int64_t n, int64_t first_end, bool jacobi, double omega,
+                             hipStream_t s);
 template <typename V>
 void launch_dense_gemv(const V *M, const V *v, V *out, int64_t n, hipStream_t s);    // out = M v (row-major n x n)
 template <typename V>

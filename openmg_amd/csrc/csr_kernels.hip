@@ -1253,6 +1253,30 @@ __global__ __launch_bounds__(256) void dense_gemv_kernel(const V *__restrict__ M
     if (lane == 0) out[row] = acc;
 }
 
+template <typename V>
+__global__ void diagonal_kernel(const int32_t *__restrict__ ip, const int32_t *__restrict__ ix, const V *__restrict__ dv,
+                                V *__restrict__ diag, int64_t n) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        V d = V(0);
+        for (int32_t p = ip[i]; p < ip[i + 1]; ++p)
+            if (ix[p] == i) d = d + dv[p];
+        diag[i] = d;
+    }
+}
+
+template <typename V>
+__global__ void first_relaxation_kernel(const V *__restrict__ b, const V *__restrict__ diag, V *__restrict__ x, int64_t n,
+                                        int64_t first_end, int jacobi, V omega) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        V x0 = V(0);
+        if (i < first_end) {
+            const V q = (b[i] - V(0)) / diag[i];
+            x0 = V(0) + (jacobi ? omega * q : q);
+        }
+        x[i] = x0;
+    }
+}
+
 int grid_for(int64_t n, int threads) {
     int64_t g = (n + threads - 1) / threads;
     if (g > 256 * 8) g = 256 * 8;
@@ -1299,6 +1323,23 @@ void launch_scatter(const S *src, const int32_t *idx, D *dst, int64_t n, hipStre
 }
 
 template <typename V>
+void launch_diagonal(const DevCsrT<V> &A, V *diag, hipStream_t s) {
+    if (A.n_rows <= 0) return;
+    hipLaunchKernelGGL((diagonal_kernel<V>), dim3(grid_for(A.n_rows, 256)), dim3(256), 0, s, A.indptr.p, A.indices.p, A.data.p,
+                       diag, A.n_rows);
+    OMG_HIP(hipGetLastError());
+}
+
+template <typename V>
+void launch_first_relaxation(const V *b, const V *diag, V *x, int64_t n, int64_t first_end, bool jacobi, double omega,
+                             hipStream_t s) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL((first_relaxation_kernel<V>), dim3(grid_for(n, 256)), dim3(256), 0, s, b, diag, x, n, first_end,
+                       jacobi ? 1 : 0, V(omega));
+    OMG_HIP(hipGetLastError());
+}
+
+template <typename V>
 void launch_dense_gemv(const V *M, const V *v, V *out, int64_t n, hipStream_t s) {
     launch_dense_gemv_rows(M, v, out, n, n, s);
 }
@@ -1316,6 +1357,8 @@ void launch_dense_gemv_rows(const V *M, const V *v, V *out, int64_t rows, int64_
     template void launch_rows_range<V>(const DevCsrT<V> &, int, int, int, const RowArgsT<V> &, hipStream_t); \
     template void launch_gs_serial<V>(const DevCsrT<V> &, int, int, const RowArgsT<V> &, hipStream_t);    \
     template void launch_dense_gemv<V>(const V *, const V *, V *, int64_t, hipStream_t);                   \
+    template void launch_diagonal<V>(const DevCsrT<V> &, V *, hipStream_t);                               \
+    template void launch_first_relaxation<V>(const V *, const V *, V *, int64_t, int64_t, bool, double, hipStream_t); \
     template void launch_dense_gemv_rows<V>(const V *, const V *, V *, int64_t, int64_t, hipStream_t);
 OMG_INSTANTIATE(double)
 OMG_INSTANTIATE(float)

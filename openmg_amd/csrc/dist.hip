@@ -215,16 +215,8 @@ std::unique_ptr<Dist<V>> create(int rank, int n_ranks, int n_levels, const omg_d
             if (l >= 1 && !last) {
                 // the diagonal as the sweeps form it (hierarchy.hip): the restriction into this level
                 // applies its first relaxation of a zero iterate
-                std::vector<V> dg(size_t(std::max<int64_t>(L.n_loc, 1)));
-                for (int64_t i = 0; i < L.n_loc; ++i) {
-                    V dsum = V(0);
-                    for (int32_t q = Ap.indptr[i]; q < Ap.indptr[i + 1]; ++q)
-                        if (Ap.indices[q] == i) dsum = dsum + V(Ap.data[q]);
-                    dg[size_t(i)] = dsum;
-                }
-                L.diag.alloc(dg.size());
-                L.diag.upload(dg.data(), dg.size(), d->stream);
-                OMG_HIP(hipStreamSynchronize(d->stream));
+                L.diag.alloc(std::max<int64_t>(L.n_loc, 1));
+                launch_diagonal(L.A, L.diag.p, d->stream);
             }
         }
         if (!id) { L.perm.alloc(L.n_loc); L.perm.upload(L.ord.perm.data(), L.n_loc, d->stream); }

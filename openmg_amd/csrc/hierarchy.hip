@@ -529,19 +529,11 @@ std::unique_ptr<Hier<V>> create(int n_levels, const omg_csr *A, const omg_csr *R
             { SetupTimer tm("permute A"); Ap = permute_csr(A[l], id ? nullptr : L.ord.perm.data(), id ? nullptr : L.ord.inv.data()); }
             SetupTimer tm("encode + upload A");
             L.A.upload(Ap, L.ord.sets, h->stream);
+            // the diagonal as the sweeps form it: restrict_level / omg_hierarchy_cycle_dev apply this
+            // level's first relaxation of a zero iterate with it (level 0: only when it is needed)
             if (l >= 1) {
-                // the diagonal as the sweeps form it (0 + the stored diagonal entries in stored order,
-                // in V): restrict_level applies this level's first relaxation of a zero iterate with it
-                std::vector<V> dg(size_t(L.n));
-                for (int64_t i = 0; i < L.n; ++i) {
-                    V d = V(0);
-                    for (int32_t q = Ap.indptr[i]; q < Ap.indptr[i + 1]; ++q)
-                        if (Ap.indices[q] == i) d = d + V(Ap.data[q]);
-                    dg[size_t(i)] = d;
-                }
                 L.diag.alloc(std::max<int64_t>(L.n, 1));
-                L.diag.upload(dg.data(), size_t(L.n), h->stream);
-                OMG_HIP(hipStreamSynchronize(h->stream));
+                launch_diagonal(L.A, L.diag.p, h->stream);
             }
         }
         if (!id) {
@@ -836,8 +828,22 @@ int omg_hierarchy_cycle_dev(omg_hierarchy *h, const double *b_dev, double *x_dev
                 const int32_t *perm = L.ord.identity ? nullptr : L.perm.p;
                 if (direct_io(L)) OMG_HIP(hipMemcpyAsync(L.b.p, b_dev, L.n * sizeof(double), hipMemcpyDeviceToDevice, hh->stream));
                 else launch_gather<double, V>(b_dev, perm, L.b.p, L.n, hh->stream);
-                if (hh->lv.size() > 1) OMG_HIP(hipMemsetAsync(L.xp, 0, L.n * sizeof(V), hh->stream));
-                cycle_body(hh, 0, pre, post);
+                bool first = false;
+                if (hh->lv.size() > 1) {
+                    // x starts from zero: the first relaxation launch is a pointwise b / diag (restrict_level)
+                    if (!L.diag.p && pre > 0 && !getenv_flag("OMG_NO_FIRST_SWEEP")) {
+                        L.diag.alloc(std::max<int64_t>(L.n, 1));
+                        launch_diagonal(L.A, L.diag.p, hh->stream);
+                    }
+                    first = first_sweep_in_restrict(hh, L, pre);
+                    if (first) {
+                        const bool jac = hh->smoother == OMG_SMOOTH_JACOBI;
+                        launch_first_relaxation<V>(L.b.p, L.diag.p, L.xp, L.n, jac ? L.n : L.A.sets[1], jac, hh->omega, hh->stream);
+                    } else {
+                        OMG_HIP(hipMemsetAsync(L.xp, 0, L.n * sizeof(V), hh->stream));
+                    }
+                }
+                cycle_body(hh, 0, pre, post, false, nullptr, first);
                 if (direct_io(L)) OMG_HIP(hipMemcpyAsync(x_dev, L.xp, L.n * sizeof(double), hipMemcpyDeviceToDevice, hh->stream));
                 else launch_scatter<V, double>(L.xp, perm, x_dev, L.n, hh->stream);
             } catch (...) {
