@@ -22,7 +22,7 @@ def load(path):
     return agg
 
 
-MODES = {0: "spmv", 1: "residual", 2: "resnorm", 3: "gs", 4: "jacobi", 5: "axpy", 6: "norm_only", 7: "gs+res", 8: "gs+norm", 9: "scatter"}
+MODES = {0: "spmv", 1: "residual", 2: "resnorm", 3: "gs", 4: "jacobi", 5: "axpy", 6: "norm_only", 7: "gs+res", 8: "gs+norm", 9: "scatter", 10: "gs+prenorm", 11: "jacobi+prenorm"}
 
 
 def main():
