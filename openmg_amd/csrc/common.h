@@ -345,6 +345,10 @@ void launch_gs_serial(const DevCsrT<V> &A, int set_begin, int set_end, const Row
 constexpr int SUM_FOLD = 64;
 void launch_sum(double *partials, int64_t n, double *out, hipStream_t s);
 void launch_sum_sqrt(double *partials, int64_t n, double *out, hipStream_t s);
+// `count` arrays of n partials, `stride` doubles apart, summed by ONE launch into out[count] with
+// exactly the additions of launch_sum / launch_sum_sqrt (same bits); no scratch needed
+void launch_sum_batch(const double *partials, int64_t stride, int64_t n, int count, double *out, bool take_sqrt,
+                      hipStream_t s);
 // dst[i] = src[idx[i]] / dst[idx[i]] = src[i]; idx == NULL is the identity, S -> D converts
 // (the host boundary of a float hierarchy is double)
 template <typename S, typename D>

@@ -1211,6 +1211,47 @@ __global__ __launch_bounds__(256) void fold_kernel(const double *__restrict__ p,
     if (threadIdx.x == 0) scratch[blockIdx.x] = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
 }
 
+// The two launches above for `count` partial arrays at once, one workgroup each (array c at
+// p_all + c * stride, result out[c]): stage 1 is fold_kernel's sum of SUM_FOLD chunks — four chunks
+// at a time, one per 256 threads — stage 2 sum_kernel's; every addition in the same order, so
+// out[c] has the bits launch_sum / launch_sum_sqrt would give for that array.
+__global__ __launch_bounds__(1024) void sum_batch_kernel(const double *__restrict__ p_all, int64_t stride, int64_t n,
+                                                         double *__restrict__ out, int take_sqrt) {
+    __shared__ double s_fold[SUM_FOLD];
+    __shared__ double s_w[16];
+    const double *__restrict__ p = p_all + blockIdx.x * stride;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    double acc = 0.0;
+    if (n > 8192) {
+        const int64_t chunk = (n + SUM_FOLD - 1) / SUM_FOLD;
+        for (int g = 0; g < SUM_FOLD / 4; ++g) {
+            const int c = 4 * g + (tid >> 8), t = tid & 255;
+            const int64_t lo = c * chunk, hi = min(n, lo + chunk);
+            double a = 0.0;
+            for (int64_t i = lo + t; i < hi; i += 256) a += p[i];
+            a = wave_sum(a);
+            if (lane == 0) s_w[wave] = a;
+            __syncthreads();
+            if (t == 0) {
+                const int w0 = 4 * (tid >> 8);
+                s_fold[c] = (s_w[w0] + s_w[w0 + 1]) + (s_w[w0 + 2] + s_w[w0 + 3]);
+            }
+            __syncthreads();
+        }
+        for (int i = tid; i < SUM_FOLD; i += 1024) acc += s_fold[i];
+    } else {
+        for (int64_t i = tid; i < n; i += 1024) acc += p[i];
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) s_w[wave] = acc;
+    __syncthreads();
+    if (tid == 0) {
+        double t = 0.0;
+        for (int w = 0; w < 16; ++w) t += s_w[w];
+        out[blockIdx.x] = take_sqrt ? sqrt(t) : t;
+    }
+}
+
 template <typename S, typename D>
 __global__ void gather_kernel(const S *__restrict__ src, const int32_t *__restrict__ idx,
                               D *__restrict__ dst, int64_t n) {
@@ -1297,6 +1338,13 @@ void launch_sum_impl(double *partials, int64_t n, double *out, int take_sqrt, hi
     } else {
         hipLaunchKernelGGL(sum_kernel, dim3(1), dim3(1024), 0, s, partials, n, out, take_sqrt);
     }
+    OMG_HIP(hipGetLastError());
+}
+
+void launch_sum_batch(const double *partials, int64_t stride, int64_t n, int count, double *out, bool take_sqrt,
+                      hipStream_t s) {
+    if (count <= 0) return;
+    hipLaunchKernelGGL(sum_batch_kernel, dim3((unsigned)count), dim3(1024), 0, s, partials, stride, n, out, take_sqrt ? 1 : 0);
     OMG_HIP(hipGetLastError());
 }
 

@@ -75,6 +75,7 @@ struct Hier {
     CoarseSolver<V> coarse;   // direct solve of the coarsest operator (common.h)
     DevBuf<double> norm_dev;
     DevBuf<double> norms_dev;      // omg_resident_cycles: one norm per cycle of the batch
+    DevBuf<double> batch_partials; // ... and the block partials of up to 64 deferred norms
     int smoother = OMG_SMOOTH_GS_LEX;
     double omega = 1.0;
     hipStream_t own = nullptr, stream = nullptr;
@@ -196,13 +197,15 @@ bool can_prenorm(const Hier<V> *h, const Level<V> &L, int pre, int post) {
 }
 
 // Returns true when the last set launch was fused (its rows' residual / norm is done).
-// prev_norm (device scalar, nullable): the first launch runs in the PRENORM mode and the
-// previous cycle's norm is summed into *prev_norm right behind it (caller checked can_prenorm).
+// pre_slot (block-partials array, nullable): the first launch runs in the PRENORM mode and leaves
+// the squares of ITS rows' residuals — the previous cycle's — there (caller checked can_prenorm;
+// the other set's were put there by that cycle's fused post-smoothing launch, post_slot).
+// post_slot (nullable = the level's own partials): where a FUSE_NORM launch puts its squares.
 // first_done: the first launch of the first sweep has already been applied (restrict_level wrote
 // its result for a zero iterate): skip it.
 template <typename V>
-bool smooth_level(Hier<V> *h, int l, int iterations, Fuse fuse = FUSE_NONE, double *prev_norm = nullptr,
-                  bool first_done = false) {
+bool smooth_level(Hier<V> *h, int l, int iterations, Fuse fuse = FUSE_NONE, double *pre_slot = nullptr,
+                  bool first_done = false, double *post_slot = nullptr) {
     Level<V> &L = h->lv[l];
     bool fused = false;
     for (int it = 0; it < iterations; ++it) {
@@ -211,10 +214,9 @@ bool smooth_level(Hier<V> *h, int l, int iterations, Fuse fuse = FUSE_NONE, doub
             Prof<V> p(h, l, 0);
             RowArgsT<V> a;
             a.x = L.xp; a.b = L.b.p; a.y = L.tp; a.omega = h->omega;
-            if (it == 0 && prev_norm) {
-                a.partials = L.partials.p;
+            if (it == 0 && pre_slot) {
+                a.partials = pre_slot;
                 launch_rows(L.A, ROW_JACOBI_PRENORM, -1, a, h->stream);
-                launch_sum_sqrt(L.partials.p, L.A.n_blocks(), prev_norm, h->stream);
             } else {
                 launch_rows(L.A, ROW_JACOBI, -1, a, h->stream);
             }
@@ -232,14 +234,13 @@ bool smooth_level(Hier<V> *h, int l, int iterations, Fuse fuse = FUSE_NONE, doub
                 } else if (last_it && k + 1 == L.plan.size() && fuse != FUSE_NONE && can_fuse(h, L)) {
                     RowArgsT<V> f = a;
                     f.zero = L.r.p;
-                    f.partials = L.partials.p;
+                    f.partials = (fuse == FUSE_NORM && post_slot) ? post_slot : L.partials.p;
                     launch_rows(L.A, fuse == FUSE_RESIDUAL ? ROW_GS_RES : ROW_GS_NORM, st.set_begin, f, h->stream);
                     fused = true;
-                } else if (it == 0 && k == 0 && prev_norm) {
+                } else if (it == 0 && k == 0 && pre_slot) {
                     RowArgsT<V> f = a;
-                    f.partials = L.partials.p;            // the first set's blocks; the last set's are in place (ROW_GS_NORM)
+                    f.partials = pre_slot;                // the first set's blocks; the last set's are in place (ROW_GS_NORM)
                     launch_rows(L.A, ROW_GS_PRENORM, st.set_begin, f, h->stream);
-                    launch_sum_sqrt(L.partials.p, L.A.n_blocks(), prev_norm, h->stream);
                 } else {
                     launch_rows(L.A, ROW_GS, st.set_begin, a, h->stream);
                 }
@@ -335,8 +336,8 @@ void coarse_solve_level(Hier<V> *h) {
 // post-smoother's last set launch then also leaves that set's share of the norm in the block
 // partials.  Returns true when it did (norm_level(..., last_set_done = true) finishes it).
 template <typename V>
-bool cycle_body(Hier<V> *h, int l, int pre, int post, bool want_norm = false, double *prev_norm = nullptr,
-                bool first_done = false) {
+bool cycle_body(Hier<V> *h, int l, int pre, int post, bool want_norm = false, double *pre_slot = nullptr,
+                bool first_done = false, double *post_slot = nullptr) {
     const int last = (int)h->lv.size() - 1;
     if (l >= last) {
         coarse_solve_level(h);
@@ -344,7 +345,7 @@ bool cycle_body(Hier<V> *h, int l, int pre, int post, bool want_norm = false, do
     }
     Level<V> &L = h->lv[l];
     Level<V> &C = h->lv[l + 1];
-    const bool res_done = smooth_level(h, l, pre, FUSE_RESIDUAL, prev_norm, first_done);   // :201 (+ last set's share of :209)
+    const bool res_done = smooth_level(h, l, pre, FUSE_RESIDUAL, pre_slot, first_done);   // :201 (+ last set's share of :209)
     residual_level(h, l, L.r.p, res_done);                          // :209
     // :210, and the coarse cycle's initial=None -> zeros (:191-192) cleared by the same launch —
     // or already relaxed once (first_sweep_in_restrict)
@@ -352,7 +353,7 @@ bool cycle_body(Hier<V> *h, int l, int pre, int post, bool want_norm = false, do
     restrict_level<V>(h, l, L.r.p, C.b.p, l + 1 < last ? C.xp : nullptr, child_first);
     cycle_body(h, l + 1, pre, post, false, nullptr, child_first);   // :213
     prolong_add_level<V>(h, l, C.xp, L.xp);                         // :214, :220/:224
-    if (post > 0) return smooth_level(h, l, post, want_norm ? FUSE_NORM : FUSE_NONE);   // :216-222
+    if (post > 0) return smooth_level(h, l, post, want_norm ? FUSE_NORM : FUSE_NONE, nullptr, false, post_slot);   // :216-222
     return false;
 }
 
@@ -898,18 +899,35 @@ int omg_resident_cycles(omg_hierarchy *h, int pre, int post, int n_cycles, doubl
             if (hh->norms_dev.n < size_t(n_cycles)) hh->norms_dev.alloc(size_t(n_cycles));
             const bool single = hh->lv.size() == 1;
             const bool defer = !single && !getenv_flag("OMG_NO_PRENORM") && can_prenorm(hh, hh->lv[0], pre, post);
-            for (int k = 0; k < n_cycles; ++k) {
-                if (single) {
-                    cycle_body(hh, 0, pre, post);
-                    OMG_HIP(hipMemsetAsync(hh->norms_dev.p + k, 0, sizeof(double), hh->stream));   // :232
-                    continue;
+            // Deferred norms: cycle k's block partials are collected in slot k of a batch buffer — the
+            // last set's by its fused post-smoothing launch, the first set's by cycle k + 1's first
+            // launch — and ALL slots of a chunk are added up by one launch at the chunk's end (the
+            // additions of launch_sum_sqrt, same bits).  The last cycle of a chunk has no successor
+            // in it: the usual norm launch.
+            constexpr int CHUNK = 64;
+            const int64_t nb = single ? 0 : hh->lv[0].A.n_blocks();
+            if (defer && hh->batch_partials.n < size_t(CHUNK) * size_t(nb)) hh->batch_partials.alloc(size_t(CHUNK) * size_t(nb));
+            for (int k0 = 0; k0 < n_cycles; k0 += CHUNK) {
+                const int cnt = std::min(CHUNK, n_cycles - k0);
+                for (int j = 0; j < cnt; ++j) {
+                    const int k = k0 + j;
+                    if (single) {
+                        cycle_body(hh, 0, pre, post);
+                        OMG_HIP(hipMemsetAsync(hh->norms_dev.p + k, 0, sizeof(double), hh->stream));   // :232
+                        continue;
+                    }
+                    const bool last_of_chunk = j + 1 == cnt;
+                    double *slot_prev = (defer && j > 0) ? hh->batch_partials.p + size_t(j - 1) * size_t(nb) : nullptr;
+                    double *slot_this = (defer && !last_of_chunk) ? hh->batch_partials.p + size_t(j) * size_t(nb) : nullptr;
+                    const bool part = cycle_body(hh, 0, pre, post, true, slot_prev, false, slot_this);
+                    if (!defer || last_of_chunk) {
+                        norm_level<V>(hh, 0, nullptr, part, hh->norms_dev.p + k);                      // :227
+                    } else {
+                        OMG_REQUIRE(part || hh->smoother == OMG_SMOOTH_JACOBI, "internal: deferred norm without the fused post-smoothing launch");
+                    }
                 }
-                const bool part = cycle_body(hh, 0, pre, post, true, (defer && k > 0) ? hh->norms_dev.p + (k - 1) : nullptr);
-                if (!defer || k + 1 == n_cycles) {
-                    norm_level<V>(hh, 0, nullptr, part, hh->norms_dev.p + k);                      // :227
-                } else {
-                    OMG_REQUIRE(part || hh->smoother == OMG_SMOOTH_JACOBI, "internal: deferred norm without the fused post-smoothing launch");
-                }
+                if (defer && cnt > 1)
+                    launch_sum_batch(hh->batch_partials.p, nb, nb, cnt - 1, hh->norms_dev.p + k0, true, hh->stream);
             }
             if (norms) OMG_HIP(hipMemcpyAsync(norms, hh->norms_dev.p, size_t(n_cycles) * sizeof(double), hipMemcpyDeviceToHost, hh->stream));
             OMG_HIP(hipStreamSynchronize(hh->stream));
