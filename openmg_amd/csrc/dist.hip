@@ -106,7 +106,9 @@ struct DLevel {
 };
 
 __global__ void sqrt_kernel(double *v) { *v = sqrt(*v); }
-__global__ void sqrt_to_kernel(const double *v, double *out) { *out = sqrt(*v); }
+__global__ void sqrt_array_kernel(const double *v, double *out, int n) {
+    for (int i = threadIdx.x; i < n; i += blockDim.x) out[i] = sqrt(v[i]);
+}
 
 template <typename V> struct NcclType;
 template <> struct NcclType<double> { static constexpr ncclDataType_t value = ncclDouble; };
@@ -136,6 +138,7 @@ struct Dist {
     omg_hierarchy *tail = nullptr;
     DevBuf<double> sumsq;                      // device scalar
     DevBuf<double> norms;                      // omg_dist_cycles: one norm per cycle of the batch
+    DevBuf<double> batch_partials, batch_sums; // ... block partials / local sums of squares of up to 64 deferred norms
     ncclComm_t comm = nullptr;
     // RCCL calls go to a second stream so that an exchange can overlap the interior rows of
     // a (boundary, interior) set pair; two events order it against the compute stream.
@@ -481,8 +484,9 @@ struct Runner {
         return (int)L.A.n_sets() == 2 * L.set_group;
     }
 
-    // prev_norm_slot >= 0: level 0, first sweep of the cycle: the first colour's launches run in the
-    // PRENORM mode and the previous cycle's norm is finished into norms[prev_norm_slot] behind them
+    // the slot-th block-partials array of rank d's batch buffer (level 0)
+    static double *slot_of(D *d, int slot) { return d->batch_partials.p + size_t(slot) * size_t(d->lv[0].A.n_blocks()); }
+
     // Can the restriction into level l also apply its first smoothing launches (hierarchy.hip
     // first_sweep_in_restrict)?  First colour of a colour ordering, or a Jacobi sweep.
     bool first_sweep_in_restrict(int l, int pre) const {
@@ -493,23 +497,25 @@ struct Runner {
         return rs[0]->smoother == OMG_SMOOTH_GS_COLOUR && (int)rs[0]->lv[l].A.n_sets() >= rs[0]->lv[l].set_group;
     }
 
+    // pre_slot >= 0: level 0, first sweep of the cycle: the first colour's launches run in the PRENORM
+    // mode and leave the squares of their rows' residuals — the PREVIOUS cycle's — in that slot of the
+    // batch buffer; post_slot >= 0: where the fused post-smoothing launches (fuse == 2) leave theirs.
     // first_done: the first colour's launches (or the first Jacobi sweep) of the first iteration have
     // been applied by the restriction: only their exchange is left
-    bool smooth(int l, int iterations, int fuse = 0, int prev_norm_slot = -1, bool first_done = false) {
+    bool smooth(int l, int iterations, int fuse = 0, int pre_slot = -1, bool first_done = false, int post_slot = -1) {
         bool fused = false;
         for (int it = 0; it < iterations; ++it) {
-            const bool prenorm = prev_norm_slot >= 0 && it == 0;
+            const bool prenorm = pre_slot >= 0 && it == 0;
             if (rs[0]->smoother == OMG_SMOOTH_JACOBI) {
                 if (it == 0 && first_done) { exchange(l); continue; }
                 for (D *d : rs) {
                     DLevel<V> &L = d->lv[l];
                     RowArgs a;
                     a.x = L.xp; a.b = L.b.p; a.y = L.tp; a.omega = d->omega;
-                    if (prenorm) a.partials = L.partials.p;
+                    if (prenorm) a.partials = slot_of(d, pre_slot);
                     launch_rows(L.A, prenorm ? ROW_JACOBI_PRENORM : ROW_JACOBI, -1, a, d->stream);
                     std::swap(L.xp, L.tp);
                 }
-                if (prenorm) finish_norm(prev_norm_slot);
                 exchange(l);
             } else {
                 const int n_sets = (int)rs[0]->lv[l].A.n_sets();
@@ -523,11 +529,11 @@ struct Runner {
                         RowArgs a;
                         a.x = L.xp; a.b = L.b.p; a.y = L.xp;
                         if (prenorm && s < grp) {             // first colour: sees the iterate the previous cycle left
-                            a.partials = L.partials.p;
+                            a.partials = slot_of(d, pre_slot);
                             launch_rows(L.A, ROW_GS_PRENORM, s, a, d->stream);
                         } else if (fuse && it + 1 == iterations && last_group) {
                             a.zero = L.r.p;
-                            a.partials = L.partials.p;
+                            a.partials = (fuse == 2 && post_slot >= 0) ? slot_of(d, post_slot) : L.partials.p;
                             launch_rows(L.A, fuse == 1 ? ROW_GS_RES : ROW_GS_NORM, s, a, d->stream);
                             fused = true;
                         } else {
@@ -543,7 +549,6 @@ struct Runner {
                     // interior rows of the same colour: touch no halo entry, are not sent
                     if (grp == 2) sweep_set(s + 1, last_group);
                     exchange_finish(l);
-                    if (prenorm && s == 0) finish_norm(prev_norm_slot);
                 }
             }
         }
@@ -611,10 +616,11 @@ struct Runner {
         }
     }
 
-    bool cycle(int l, int pre, int post, bool want_norm = false, int prev_norm_slot = -1, bool first_done = false) {
+    bool cycle(int l, int pre, int post, bool want_norm = false, int pre_slot = -1, bool first_done = false,
+               int post_slot = -1) {
         const int last = (int)rs[0]->lv.size() - 1;
         if (l >= last) { coarse(pre, post); return false; }
-        const bool res_done = smooth(l, pre, 1, prev_norm_slot, first_done);
+        const bool res_done = smooth(l, pre, 1, pre_slot, first_done);
         const bool child_first = l + 1 < last && first_sweep_in_restrict(l + 1, pre);
         for (D *d : rs) {
             DLevel<V> &L = d->lv[l];
@@ -669,15 +675,35 @@ struct Runner {
             prolong_sets(0, 0);
             exchange(l);
         }
-        if (post > 0) return smooth(l, post, want_norm ? 2 : 0);
+        if (post > 0) return smooth(l, post, want_norm ? 2 : 0, -1, false, post_slot);
         return false;
     }
 
-    // The level-0 block partials of every rank are complete: global norm -> norms[slot] on every rank.
-    void finish_norm(int slot) {
-        for (D *d : rs) launch_sum(d->lv[0].partials.p, d->lv[0].A.n_blocks(), d->sumsq.p, d->stream);
-        reduce_sumsq();
-        for (D *d : rs) hipLaunchKernelGGL(sqrt_to_kernel, dim3(1), dim3(1), 0, d->stream, d->sumsq.p, d->norms.p + slot);
+    // The first count slots of every rank's batch buffer are complete: local sums (the additions
+    // launch_sum makes), ONE reduction over the ranks for all of them, sqrt -> norms[first ...].
+    void finish_batch(int count, int first) {
+        if (count <= 0) return;
+        for (D *d : rs) {
+            const int64_t nb = d->lv[0].A.n_blocks();
+            launch_sum_batch(d->batch_partials.p, nb, nb, count, d->batch_sums.p, false, d->stream);
+        }
+        if (rccl) {
+            D *d = rs[0];
+            if (d->n_ranks > 1)
+                OMG_NCCL(g_rccl.AllReduce(d->batch_sums.p, d->batch_sums.p, (size_t)count, ncclDouble, ncclSum, d->comm, d->stream));
+        } else if (rs.size() > 1) {
+            // loopback (test path): rank order, on the host
+            std::vector<double> tot(count, 0.0), v(count);
+            for (D *d : rs) {
+                OMG_HIP(hipMemcpyAsync(v.data(), d->batch_sums.p, count * sizeof(double), hipMemcpyDeviceToHost, d->stream));
+                OMG_HIP(hipStreamSynchronize(d->stream));
+                for (int i = 0; i < count; ++i) tot[i] += v[i];
+            }
+            for (D *d : rs) OMG_HIP(hipMemcpyAsync(d->batch_sums.p, tot.data(), count * sizeof(double), hipMemcpyHostToDevice, d->stream));
+            for (D *d : rs) OMG_HIP(hipStreamSynchronize(d->stream));
+        }
+        for (D *d : rs)
+            hipLaunchKernelGGL(sqrt_array_kernel, dim3(1), dim3(64), 0, d->stream, d->batch_sums.p, d->norms.p + first, count);
     }
 
     // sum over all ranks of the local sums of squares -> sqrt, left in every rank's sumsq
@@ -718,7 +744,11 @@ struct Runner {
     }
 
     // n cycles, every cycle's global norm computed; norms_out (host, nullable) gets all of them.
-    // Where can_prenorm() holds the norm of cycle k is finished by cycle k + 1's first launches.
+    // Where can_prenorm() holds, cycles go in chunks of up to 64: the squares of cycle k's norm are
+    // finished by cycle k + 1's first launches into slot k of the batch buffer, and the chunk's
+    // local sums are reduced over the ranks by ONE all-reduce instead of one per cycle (with more
+    // than two ranks RCCL may then add the ranks' sums in another order than the one-value
+    // all-reduce of omg_dist_cycle does: the norms are reported values, the iterate is untouched).
     void run_batch(int pre, int post, int n, double *norms_out) {
         for (D *d : rs) OMG_REQUIRE(d->loaded, "omg_dist_load has not been called");
         if (n <= 0) return;
@@ -729,13 +759,26 @@ struct Runner {
         const bool multi = rs[0]->lv.size() > 1;
         const char *e = getenv("OMG_NO_PRENORM");
         const bool defer = multi && !(e && e[0] == '1') && can_prenorm(pre, post);
-        for (int k = 0; k < n; ++k) {
-            const bool part = cycle(0, pre, post, multi, (defer && k > 0) ? k - 1 : -1);
-            if (!defer || k + 1 == n) {
-                norm(part);
-                for (D *d : rs)
-                    OMG_HIP(hipMemcpyAsync(d->norms.p + k, d->sumsq.p, sizeof(double), hipMemcpyDeviceToDevice, d->stream));
+        const int CHUNK = 64;
+        if (defer)
+            for (D *d : rs) {
+                const size_t need = size_t(CHUNK) * size_t(d->lv[0].A.n_blocks());
+                if (d->batch_partials.n < need) d->batch_partials.alloc(need);
+                if (d->batch_sums.n < size_t(CHUNK)) d->batch_sums.alloc(CHUNK);
             }
+        for (int k0 = 0; k0 < n; k0 += CHUNK) {
+            const int cnt = std::min(CHUNK, n - k0);
+            for (int j = 0; j < cnt; ++j) {
+                const bool last_of_chunk = j + 1 == cnt;
+                const bool part = cycle(0, pre, post, multi, (defer && j > 0) ? j - 1 : -1, false,
+                                        (defer && !last_of_chunk) ? j : -1);
+                if (!defer || last_of_chunk) {
+                    norm(part);
+                    for (D *d : rs)
+                        OMG_HIP(hipMemcpyAsync(d->norms.p + k0 + j, d->sumsq.p, sizeof(double), hipMemcpyDeviceToDevice, d->stream));
+                }
+            }
+            if (defer) finish_batch(cnt - 1, k0);
         }
         D *d0 = rs[0];
         if (norms_out) OMG_HIP(hipMemcpyAsync(norms_out, d0->norms.p, size_t(n) * sizeof(double), hipMemcpyDeviceToHost, d0->stream));
