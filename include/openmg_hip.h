@@ -107,6 +107,7 @@ int omg_hierarchy_level_fused(const omg_hierarchy *h, int level, int *fused);
 #define OMG_LEVEL_FUSED_LAST_SET   1
 #define OMG_LEVEL_SCATTER_PROLONG  2
 #define OMG_LEVEL_UNION_WALK       16  /* every smoother set of A runs rows_union_kernel (several rows per thread) */
+#define OMG_LEVEL_MARCH            32  /* lexicographic Gauss-Seidel runs as one wavefront launch per sweep (march.hip) */
 int omg_hierarchy_level_flags(const omg_hierarchy *h, int level, int *flags);
 /* Rows and stored entries of one smoother set (for byte accounting of per-set launches). */
 int omg_hierarchy_set_info(const omg_hierarchy *h, int level, int set, int64_t *rows, int64_t *nnz);

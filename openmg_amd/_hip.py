@@ -334,10 +334,11 @@ class Hierarchy:
         return bool(v.value)
 
     def level_flags(self, level):
-        """dict(fused_last_set=bool, scatter_prolong=bool, union_walk=bool) of a smoothed level."""
+        """dict(fused_last_set=bool, scatter_prolong=bool, union_walk=bool, march=bool) of a smoothed level."""
         f = ctypes.c_int(0)
         check(lib().omg_hierarchy_level_flags(self._h, int(level), ctypes.byref(f)))
-        return {"fused_last_set": bool(f.value & 1), "scatter_prolong": bool(f.value & 2), "union_walk": bool(f.value & 16)}
+        return {"fused_last_set": bool(f.value & 1), "scatter_prolong": bool(f.value & 2), "union_walk": bool(f.value & 16),
+                "march": bool(f.value & 32)}
 
     def set_info(self, level, s):
         """(rows, stored entries) of smoother set `s` of a level."""

@@ -413,4 +413,38 @@ struct CoarseSolver {
     void solve(const V *b, V *x, hipStream_t s) const;     // original numbering, device pointers
 };
 
+// ---- lexicographic Gauss-Seidel of grid stencils (march.hip) ---------------------------------
+// The reference's own smoother (openmg/solvers.py:56-68) relaxes the rows in their natural order.
+// The general path runs it as a level schedule: one launch per set of mutually uncoupled rows —
+// 766 dependent launches per sweep of a 256^3 seven-point operator.  Where the operator is a
+// star stencil on a lexicographically numbered grid — every stored entry couples row r with
+// r, r -+ 1, r -+ nx or r -+ nx ny, which the plan reads off the CSR structure itself — the sweep
+// runs as ONE launch instead: a wave owns a TJ x TK tile of grid LINES (64 lanes, a line = the nx
+// consecutive rows of one (j, k)), lane (jj, kk) relaxes row i = t - jj - kk of its line at step t,
+// so that the three already relaxed neighbours of a row were relaxed one step earlier by this lane,
+// lane - 1 and lane - TJ (wave shuffles), and the three not yet relaxed ones are old values.
+// Tiles hand their faces over through HBM: a tile publishes the number of steps it has completed
+// (write-through stores, then a flag) after every MARCH_U steps, and its +J / +K neighbours load the
+// face values behind that (tile indices are taken from a ticket counter, so a tile's
+// predecessors have always started).  Every row is the same fma chain in stored order as in the
+// row kernels (absent neighbours contribute 0 * x to the chain, which leaves it unchanged).
+constexpr int MARCH_U = 8;            // steps per block: prefetch distance and publication interval
+struct MarchGeom {
+    int nx = 0, ny = 0, nz = 0;       // rows per line, lines per plane, planes
+    int TJ = 0, TK = 0;               // tile of lines held by one wave (TJ * TK = 64)
+    int ntj = 0, ntk = 0, n_tiles = 0;
+    int T = 0, n_blk = 0;             // steps per tile = nx + TJ + TK - 2; blocks of MARCH_U steps
+    int n_pat = 0;                    // distinct rows (7 coefficients)
+};
+template <typename V>
+struct MarchPlan {
+    MarchGeom g;
+    DevBuf<uint64_t> codes;           // [tile][block][lane]: the pattern codes of the lane's MARCH_U rows
+    DevBuf<V> coef;                   // [pattern][8]: -K, -J, -I, diagonal, +I, +J, +K, unused
+    DevBuf<uint32_t> sync;            // ticket, finished tiles, per-tile progress (one 64-byte slot each)
+    // false: the operator is not such a stencil (the caller keeps the level schedule)
+    bool build(const omg_csr &A, hipStream_t s);
+    void sweep(V *x, const V *b, hipStream_t s) const;   // one in-place lexicographic sweep
+};
+
 }  // namespace omg

@@ -36,6 +36,7 @@ void require_device() {
 namespace {
 
 inline bool getenv_flag(const char *name) { const char *e = getenv(name); return e && e[0] == '1'; }
+inline bool getenv_flag0(const char *name) { const char *e = getenv(name); return e && e[0] == '0'; }   // switched OFF
 
 struct SweepStep {
     int set_begin, set_end;   // [begin, end)
@@ -61,6 +62,9 @@ struct Level {
     // explicit transpose P: possible when no two rows of R share a column (aggregation) and R
     // is row-pattern coded; reads 1 byte per COARSE row instead of ~9 per fine row
     bool scatter_prolong = false;
+    // lexicographic Gauss-Seidel of a grid star stencil: one launch per sweep (common.h MarchPlan);
+    // the level then keeps its natural ordering (one "set") for every other kernel
+    std::unique_ptr<MarchPlan<V>> march;
 };
 
 struct ProfEvent {
@@ -128,6 +132,24 @@ omg_csr view(const HostCsr &A) {
     return omg_csr{A.n_rows, A.n_cols, A.nnz, A.indptr.data(), A.indices.data(), A.data.data()};
 }
 
+// The smoother ordering of a level.  The reference's lexicographic sweep first tries the
+// one-launch wavefront of march.hip (OMG_MARCH=0: always the level schedule; same bits, tested).
+template <typename V>
+void order_level(Level<V> &L, const omg_csr &A, int smoother, hipStream_t s) {
+    L.march.reset();
+    if (smoother == OMG_SMOOTH_GS_LEX && !getenv_flag0("OMG_MARCH")) {
+        std::unique_ptr<MarchPlan<V>> plan(new MarchPlan<V>);
+        if (plan->build(A, s)) {
+            L.march = std::move(plan);
+            L.ord = Ordering();
+            L.ord.identity = true;
+            L.ord.sets = {0, A.n_rows};
+            return;
+        }
+    }
+    L.ord = make_ordering(A, smoother);
+}
+
 template <typename V>
 void build_plan(Level<V> &L) {
     L.plan.clear();
@@ -180,7 +202,7 @@ enum Fuse { FUSE_NONE = 0, FUSE_RESIDUAL = 1, FUSE_NORM = 2 };
 // Fusion needs a Gauss-Seidel ordering whose final step is an ordinary set launch.
 template <typename V>
 bool can_fuse(const Hier<V> *h, const Level<V> &L) {
-    if (h->smoother == OMG_SMOOTH_JACOBI || L.plan.empty() || h->no_fuse) return false;
+    if (h->smoother == OMG_SMOOTH_JACOBI || L.plan.empty() || h->no_fuse || L.march) return false;
     return !L.plan.back().serial;
 }
 
@@ -191,7 +213,7 @@ bool can_fuse(const Hier<V> *h, const Level<V> &L) {
 // post-smoothing launch (ROW_GS_NORM).
 template <typename V>
 bool can_prenorm(const Hier<V> *h, const Level<V> &L, int pre, int post) {
-    if (pre <= 0 || L.plan.empty()) return false;
+    if (pre <= 0 || L.plan.empty() || L.march) return false;
     if (h->smoother == OMG_SMOOTH_JACOBI) return true;
     return L.A.n_sets() == 2 && post > 0 && can_fuse(h, L) && !L.plan.front().serial && L.plan.size() == 2;
 }
@@ -221,6 +243,9 @@ bool smooth_level(Hier<V> *h, int l, int iterations, Fuse fuse = FUSE_NONE, doub
                 launch_rows(L.A, ROW_JACOBI, -1, a, h->stream);
             }
             std::swap(L.xp, L.tp);
+        } else if (L.march) {
+            Prof<V> p(h, l, 0);
+            L.march->sweep(L.xp, L.b.p, h->stream);
         } else {
             RowArgsT<V> a;
             a.x = L.xp; a.b = L.b.p; a.y = L.xp;
@@ -283,7 +308,7 @@ void norm_level(Hier<V> *h, int l, V *r_out, bool last_set_done = false, double 
 // the restriction's thread holds b_i (RowArgsT::first_diag).  OMG_NO_FIRST_SWEEP=1 switches it off.
 template <typename V>
 bool first_sweep_in_restrict(const Hier<V> *h, const Level<V> &C, int pre) {
-    if (pre <= 0 || !C.diag.p || C.plan.empty() || getenv_flag("OMG_NO_FIRST_SWEEP")) return false;
+    if (pre <= 0 || !C.diag.p || C.plan.empty() || C.march || getenv_flag("OMG_NO_FIRST_SWEEP")) return false;
     // (a captured graph bakes the Jacobi ping-pong pointers in: keep two swaps per V(1,1) level there)
     if (h->smoother == OMG_SMOOTH_JACOBI) return !h->want_graph;
     const SweepStep &st = C.plan.front();
@@ -519,8 +544,8 @@ std::unique_ptr<Hier<V>> create(int n_levels, const omg_csr *A, const omg_csr *R
     for (int l = 0; l + 1 < n_levels; ++l) {
         Lv &L = h->lv[l];
         L.n = A[l].n_rows;
-        SetupTimer tm("ordering (colouring / level schedule)");
-        L.ord = make_ordering(A[l], smoother);
+        SetupTimer tm("ordering (colouring / level schedule / wavefront plan)");
+        order_level(L, A[l], smoother, h->stream);
     }
     for (int l = 0; l < n_levels; ++l) {
         Lv &L = h->lv[l];
@@ -746,7 +771,8 @@ int omg_hierarchy_level_flags(const omg_hierarchy *h, int level, int *flags) {
             const bool smoothed = level + 1 < (int)hh->lv.size();
             *flags = ((smoothed && can_fuse(hh, hh->lv[level])) ? OMG_LEVEL_FUSED_LAST_SET : 0) |
                      ((smoothed && hh->lv[level].scatter_prolong) ? OMG_LEVEL_SCATTER_PROLONG : 0) |
-                     ((smoothed && hh->lv[level].A.all_union()) ? OMG_LEVEL_UNION_WALK : 0);
+                     ((smoothed && hh->lv[level].A.all_union()) ? OMG_LEVEL_UNION_WALK : 0) |
+                     ((smoothed && hh->lv[level].march) ? OMG_LEVEL_MARCH : 0);
         });
     });
 }
@@ -1207,7 +1233,7 @@ int omg_gauss_seidel(const omg_csr *A, const double *b, double *x, int smoother,
         h->norm_dev.alloc(1);
         Level<double> &L = h->lv[0];
         L.n = A->n_rows;
-        L.ord = make_ordering(*A, smoother);
+        order_level(L, *A, smoother, h->stream);
         const bool id = L.ord.identity;
         {
             HostCsr Ap = permute_csr(*A, id ? nullptr : L.ord.perm.data(), id ? nullptr : L.ord.inv.data());

@@ -1,0 +1,113 @@
+"""The one-launch lexicographic Gauss-Seidel sweep (openmg_amd/csrc/march.hip) against the level
+schedule it replaces (same bits) and against the oracle's sequential loop (openmg/solvers.py:56-68)."""
+import os
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from openmg_amd import _hip, operators
+from oracle import mg_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+MARCH = 32          # include/openmg_hip.h OMG_LEVEL_MARCH
+
+
+def sweep(A, b, x0, iterations, march):
+    """iterations lexicographic sweeps on the device, with / without the wavefront launch."""
+    old = os.environ.get("OMG_MARCH")
+    os.environ["OMG_MARCH"] = "1" if march else "0"
+    try:
+        x = x0.copy()
+        assert _hip.gauss_seidel(A, b, x, smoother="gs", iterations=iterations) == iterations
+        return x
+    finally:
+        if old is None:
+            del os.environ["OMG_MARCH"]
+        else:
+            os.environ["OMG_MARCH"] = old
+
+
+def scaled_rows(A, rng, kinds=3):
+    """Rows multiplied by one of a few factors: the same sparsity, several times the row patterns."""
+    f = rng.choice(np.array([1.0, 0.5, 3.0, 1.25])[:kinds], size=A.shape[0])
+    B = sp.csr_matrix(sp.diags(f) @ A)
+    B.sort_indices()
+    return B
+
+
+@pytest.mark.parametrize("shape", [(4097,), (64,), (100, 70), (3, 130), (130, 3), (12, 20, 30), (17, 9, 33),
+                                   (8, 8, 8), (5, 64, 16), (48, 48, 48), (64, 64, 64)])
+def test_wavefront_sweep_has_the_bits_of_the_level_schedule(shape):
+    rng = np.random.default_rng(11)
+    A = scaled_rows(operators.stencil_poisson(shape), rng)
+    n = A.shape[0]
+    b, x0 = rng.standard_normal(n), rng.standard_normal(n)
+    for its in (1, 3):
+        got = sweep(A, b, x0, its, march=True)
+        ref = sweep(A, b, x0, its, march=False)
+        assert np.array_equal(got, ref), (shape, its, int(np.sum(got != ref)))
+    np.testing.assert_allclose(sweep(A, b, x0, 2, march=True), orc.gauss_seidel(A, b, x0.copy(), iterations=2),
+                               rtol=1e-12, atol=1e-14)
+
+
+def test_wavefront_sweep_is_deterministic_over_many_runs():
+    """The tiles hand their faces over through HBM inside the launch: a stale read would show here."""
+    rng = np.random.default_rng(12)
+    shape = (40, 72, 56)
+    A = operators.stencil_poisson(shape)
+    n = A.shape[0]
+    b, x0 = rng.standard_normal(n), rng.standard_normal(n)
+    ref = sweep(A, b, x0, 2, march=False)
+    for _ in range(25):
+        assert np.array_equal(sweep(A, b, x0, 2, march=True), ref)
+
+
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+def test_hierarchy_uses_the_wavefront_for_the_reference_smoother(dtype):
+    shape, grids = (32, 32, 32), 3
+    A0 = operators.stencil_poisson(shape)
+    R = operators.restrictionList(shape, grids - 2, 1)
+    A = operators.coeffecientList(A0, R)
+    rng = np.random.default_rng(13)
+    b = rng.standard_normal(A0.shape[0])
+    out = {}
+    for march in ("1", "0"):
+        os.environ["OMG_MARCH"] = march
+        try:
+            h = _hip.Hierarchy(A, R, smoother="gs", dtype=dtype)
+            flags = [h.level_flags(l) for l in range(grids - 1)]
+            assert all(bool(f["march"]) == (march == "1") for f in flags), flags
+            h.resident_load(b)
+            norms = [h.resident_cycle(1, 1) for _ in range(3)]
+            out[march] = (h.resident_fetch(), norms)
+        finally:
+            del os.environ["OMG_MARCH"]
+    assert np.array_equal(out["1"][0], out["0"][0])
+    # same iterate; the norm adds the squares block by block in each ordering's own row order
+    np.testing.assert_allclose(out["1"][1], out["0"][1], rtol=1e-13)
+    if dtype == "float64":
+        p = {"preIterations": 1, "postIterations": 1, "coarsestLevel": len(R)}
+        x, want = None, []
+        for _ in range(3):
+            x, info = orc.mg_cycle(orc.coefficient_list(A0, R), b, 0, R, p, initial=x)
+            want.append(info["norm"])
+        np.testing.assert_allclose(out["1"][1], want, rtol=1e-10)
+        np.testing.assert_allclose(out["1"][0], x, rtol=1e-9, atol=1e-12)
+
+
+def test_operators_that_are_not_grid_star_stencils_keep_the_level_schedule():
+    rng = np.random.default_rng(14)
+    # periodic coupling, a 27-point stencil, unsorted columns, too many distinct rows
+    n = 600
+    per = sp.csr_matrix(operators.stencil_poisson((n,)) + sp.coo_matrix(([-1.0, -1.0], ([0, n - 1], [n - 1, 0])), shape=(n, n)))
+    s27 = sp.csr_matrix(operators.stencil27_variable((6, 6, 6)))
+    var = sp.csr_matrix(sp.diags(rng.random(40 * 40) + 1.0) @ operators.stencil_poisson((40, 40)))
+    for A in (per, s27, var):
+        A.sort_indices()
+        m = A.shape[0]
+        b, x0 = rng.standard_normal(m), rng.standard_normal(m)
+        assert np.array_equal(sweep(A, b, x0, 2, march=True), sweep(A, b, x0, 2, march=False))
+        np.testing.assert_allclose(sweep(A, b, x0, 2, march=True), orc.gauss_seidel(A, b, x0.copy(), iterations=2),
+                                   rtol=1e-10, atol=1e-12)
