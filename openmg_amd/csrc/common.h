@@ -428,20 +428,21 @@ struct CoarseSolver {
 // face values behind that (tile indices are taken from a ticket counter, so a tile's
 // predecessors have always started).  Every row is the same fma chain in stored order as in the
 // row kernels (absent neighbours contribute 0 * x to the chain, which leaves it unchanged).
-constexpr int MARCH_U = 8;            // steps per block: prefetch distance and publication interval
+constexpr int MARCH_FACE_PAD = 72;    // slots in front of / behind the rows of a face line (>= largest skew 63 + steps per block)
 struct MarchGeom {
     int nx = 0, ny = 0, nz = 0;       // rows per line, lines per plane, planes
     int TJ = 0, TK = 0;               // tile of lines held by one wave (TJ * TK = 64)
     int ntj = 0, ntk = 0, n_tiles = 0;
-    int T = 0, n_blk = 0;             // steps per tile = nx + TJ + TK - 2; blocks of MARCH_U steps
+    int T = 0, n_grp = 0;             // steps per tile = nx + TJ + TK - 2; groups of four steps (even count)
     int n_pat = 0;                    // distinct rows (7 coefficients)
 };
 template <typename V>
 struct MarchPlan {
     MarchGeom g;
-    DevBuf<uint64_t> codes;           // [tile][block][lane]: the pattern codes of the lane's MARCH_U rows
+    DevBuf<uint32_t> codes;           // [tile][group][lane]: the pattern codes of the lane's rows of four consecutive steps
     DevBuf<V> coef;                   // [pattern][8]: -K, -J, -I, diagonal, +I, +J, +K, unused
-    DevBuf<uint32_t> sync;            // ticket, finished tiles, per-tile progress (one 64-byte slot each)
+    DevBuf<uint32_t> sync;            // ticket, finished tiles, error flag
+    DevBuf<V> faceJ, faceK;           // [tile][line of the +J / +K face][row]: hand-over slots, unset (a marker NaN) between sweeps
     // false: the operator is not such a stencil (the caller keeps the level schedule)
     bool build(const omg_csr &A, hipStream_t s);
     void sweep(V *x, const V *b, hipStream_t s) const;   // one in-place lexicographic sweep

@@ -19,8 +19,10 @@
 #include <algorithm>
 #include <array>
 #include <atomic>
+#include <cmath>
 #include <cstring>
 #include <thread>
+#include <type_traits>
 
 #include "common.h"
 
@@ -28,18 +30,20 @@ namespace omg {
 
 namespace {
 
-constexpr int U = MARCH_U;
-constexpr int SYNC_HEAD = 32;      // uint32 words in front of the progress slots
-constexpr int SYNC_STRIDE = 16;    // uint32 words per progress slot (64 bytes)
+constexpr int SYNC_WORDS = 16;     // ticket, finished tiles, error flag
+constexpr int SPIN_LIMIT = 1 << 20;
+constexpr int FACE_PAD = MARCH_FACE_PAD;
 
 template <typename V>
 struct MarchArgs {
     V *x;
     const V *b;
-    const uint64_t *codes;
+    const uint32_t *codes;
     const V *coef;
     uint32_t *sync;
-    int nx, ny, nz, TJ, ntj, n_tiles, T, n_blk, n_pat;
+    V *faceJ, *faceK;
+    long long *dbg;      // OMG_MARCH_DEBUG=1: per tile start, end, time in face waits, polls (wall_clock64 ticks)
+    int nx, ny, nz, TJ, ntj, n_tiles, T, n_grp, n_pat, n;
 };
 
 __device__ __forceinline__ double madd(double v, double x, double acc) { return fma(v, x, acc); }
@@ -54,31 +58,84 @@ __device__ __forceinline__ void store_through(T *p, T v) {
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// until the tile behind `flag` has completed `need` steps (uniform over the wave)
-__device__ __forceinline__ void wait_steps(const uint32_t *flag, uint32_t need, uint32_t &seen) {
-    while (seen < need) {
-        seen = load_through(flag);
-        if (seen < need) __builtin_amdgcn_s_sleep(1);
-    }
-    asm volatile("" ::: "memory");
+// "Not written yet" in a face slot: a NaN no arithmetic produces (hardware NaNs are canonical).
+template <typename V> struct Unset;
+template <> struct Unset<double> {
+    static constexpr uint64_t bits = 0x7ff8c0dec0de0001ull;
+    __host__ __device__ static double value() { union { uint64_t u; double d; } c; c.u = bits; return c.d; }
+    __device__ static bool is(double v) { return (uint64_t)__double_as_longlong(v) == bits; }
+};
+template <> struct Unset<float> {
+    static constexpr uint32_t bits = 0x7fc0c0deu;
+    __host__ __device__ static float value() { union { uint32_t u; float f; } c; c.u = bits; return c.f; }
+    __device__ static bool is(float v) { return (uint32_t)__float_as_int(v) == bits; }
+};
+
+// 1 / d as the compiler's expansion of a double division forms it from d alone (v_rcp_f64 and two
+// Newton steps), for operands that v_div_scale_f64 leaves unscaled
+__device__ __forceinline__ double refined_rcp(double d) {
+    double r = __builtin_amdgcn_rcp(d);
+    double e = fma(-d, r, 1.0);
+    r = fma(r, e, r);
+    e = fma(-d, r, 1.0);
+    return fma(r, e, r);
+}
+__device__ __forceinline__ float refined_rcp(float) { return 0.0f; }
+// exponent within 2^-400 .. 2^400: neither operand is scaled, no fix-up case applies
+__device__ __forceinline__ bool plain_range(double v) {
+    const unsigned e = ((unsigned)__double2hiint(v) >> 20) & 0x7ffu;
+    return e - 623u <= 800u;
 }
 
-template <typename V>
+__device__ __forceinline__ bool plain_range(float) { return true; }
+
+// n / d for the relaxation.  double, FAST: the quotient the compiler's division sequence forms, with
+// its denominator half (r = refined_rcp(d), per pattern) taken off the dependent chain — valid for
+// numerators in plain_range(); a block that met another one is repeated with the division itself.
+template <bool FAST>
+__device__ __forceinline__ double quotient(double n, double d, double r) {
+    if (!FAST) return n / d;
+    const double q = n * r;
+    const double rem = fma(-d, q, n);
+    return fma(rem, r, q);
+}
+template <bool FAST>
+__device__ __forceinline__ float quotient(float n, float d, float) { return n / d; }
+
+// the eight table entries of a pattern by 16-byte LDS reads
+__device__ __forceinline__ void load_coefs(const double *c, double (&o)[8]) {
+    typedef double v2d __attribute__((ext_vector_type(2)));
+    const v2d *p = reinterpret_cast<const v2d *>(c);
+    const v2d a = p[0], b = p[1], e = p[2], f = p[3];
+    o[0] = a.x; o[1] = a.y; o[2] = b.x; o[3] = b.y; o[4] = e.x; o[5] = e.y; o[6] = f.x; o[7] = f.y;
+}
+__device__ __forceinline__ void load_coefs(const float *c, float (&o)[8]) {
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    const v4f *p = reinterpret_cast<const v4f *>(c);
+    const v4f a = p[0], b = p[1];
+    o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w;
+}
+
+template <typename V, int U>
 struct BlockData {
     V xs[U];     // own line, old value of row i + 1 at step t
     V bv[U];     // right-hand side of row i
-    V ej[U];     // the -J (lane jj == 0) or +J (jj == TJ - 1) operand from another tile's line
+    V ej[U];     // the -J (lane jj == 0: another tile's face) or +J (jj == TJ - 1: old value) operand
     V ek[U];     // the same for K
-    uint64_t codes;
+    uint32_t codes[U / 4];
 };
 
-template <typename V>
+template <typename V, int U>
 __global__ __launch_bounds__(64) void march_gs_kernel(MarchArgs<V> a) {
     __shared__ V s_coef[256 * 8];
     __shared__ int s_tile;
     const int lane = threadIdx.x;
     if (lane == 0) s_tile = (int)__hip_atomic_fetch_add(a.sync + 0, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    for (int q = lane; q < a.n_pat * 8; q += 64) s_coef[q] = a.coef[q];
+    for (int q = lane; q < a.n_pat * 8; q += 64) {
+        V c = a.coef[q];
+        if ((q & 7) == 7) c = refined_rcp(a.coef[q - 4]);
+        s_coef[q] = c;
+    }
     __syncthreads();
     const int tile = __builtin_amdgcn_readfirstlane(s_tile);
     const int TJ = a.TJ, TK = 64 / TJ;
@@ -86,59 +143,73 @@ __global__ __launch_bounds__(64) void march_gs_kernel(MarchArgs<V> a) {
     const int jj = lane % TJ, kk = lane / TJ;
     const int j = J * TJ + jj, k = K * TK + kk;
     const bool valid = j < a.ny && k < a.nz;
-    const int skew = jj + kk;
-    const int nx = a.nx;
+    const bool whole = (J + 1) * TJ <= a.ny && (K + 1) * TK <= a.nz;     // every lane of the tile has a line
+    const int skew = jj + kk, max_skew = TJ + TK - 2;
+    const int nx = a.nx, last = a.n - 1, nxp = nx + 2 * FACE_PAD;
     const int line = valid ? (k * a.ny + j) * nx : 0;
-    // operands in other tiles' lines
+    // operands in other tiles' lines: relaxed ones come through the face slots, the others are old values of x
     const bool lowJ = valid && jj == 0 && j > 0, highJ = valid && jj == TJ - 1 && j + 1 < a.ny;
     const bool lowK = valid && kk == 0 && k > 0, highK = valid && kk == TK - 1 && k + 1 < a.nz;
-    const bool extJ = lowJ || highJ, extK = lowK || highK;
-    const int offJ = lowJ ? -nx : nx;
-    const int offK = lowK ? -nx * a.ny : nx * a.ny;
-    const bool face = highJ || highK;                       // another tile will load this lane's results
-    uint32_t *progress = a.sync + SYNC_HEAD;
-    const uint32_t *flagJ = J > 0 ? progress + size_t(tile - 1) * SYNC_STRIDE : nullptr;
-    const uint32_t *flagK = K > 0 ? progress + size_t(tile - a.ntj) * SYNC_STRIDE : nullptr;
-    uint32_t seenJ = 0, seenK = 0;
-    const int T = a.T;
+    const int offJ = nx, offK = nx * a.ny;
+    // (a face line carries FACE_PAD slots in front of row 0 and behind row nx - 1: the steps of a lane
+    // that fall outside its line address those, so that nothing here is predicated on the row index)
+    V *inJ = a.faceJ + (size_t(lowJ ? tile - 1 : tile) * TK + kk) * nxp + FACE_PAD;
+    V *inK = a.faceK + (size_t(lowK ? tile - a.ntj : tile) * TJ + jj) * nxp + FACE_PAD;
+    V *outJ = a.faceJ + (size_t(tile) * TK + kk) * nxp + FACE_PAD;
+    V *outK = a.faceK + (size_t(tile) * TJ + jj) * nxp + FACE_PAD;
+    const V unset = Unset<V>::value();
+    const int n_blk = (a.T + U - 1) / U;
+    int spins = 0;
+    long long t_begin = 0, t_wait = 0;
+    if (a.dbg) t_begin = wall_clock64();
 
-    BlockData<V> cur, nxt;
-    auto prefetch = [&](int blk, BlockData<V> &d) {
-        const int T0 = blk * U;
-        // the -J tile relaxes row i of its last lane TJ - 1 steps after this tile's step for row i
-        if (flagJ) wait_steps(flagJ, (uint32_t)min(T, T0 + U + TJ - 1), seenJ);
-        if (flagK) wait_steps(flagK, (uint32_t)min(T, T0 + U + TK - 1), seenK);
+    auto clampi = [&](int q) { return min(max(q, 0), last); };
+    typedef BlockData<V, U> Block;
+    auto prefetch = [&](int blk, Block &d) {
+        const int i0 = blk * U - skew;
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int i = T0 + u - skew;
-            const bool in = valid && i >= 0 && i < nx;
-            d.xs[u] = (valid && i + 1 >= 0 && i + 1 < nx) ? a.x[line + i + 1] : V(0);
-            d.bv[u] = in ? a.b[line + i] : V(0);
-            d.ej[u] = (extJ && in) ? load_through(a.x + line + i + offJ) : V(0);
-            d.ek[u] = (extK && in) ? load_through(a.x + line + i + offK) : V(0);
+            d.xs[u] = a.x[clampi(line + i0 + u + 1)];
+            d.bv[u] = a.b[clampi(line + i0 + u)];
+            d.ej[u] = V(0);
+            d.ek[u] = V(0);
         }
-        d.codes = a.codes[(size_t(tile) * a.n_blk + blk) * 64 + lane];
+        if (highJ) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) d.ej[u] = a.x[clampi(line + i0 + u + offJ)];
+        }
+        if (highK) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) d.ek[u] = a.x[clampi(line + i0 + u + offK)];
+        }
+        if (lowJ) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) d.ej[u] = load_through(inJ + i0 + u);
+        }
+        if (lowK) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) d.ek[u] = load_through(inK + i0 + u);
+        }
+#pragma unroll
+        for (int w = 0; w < U / 4; ++w) d.codes[w] = a.codes[(size_t(tile) * a.n_grp + blk * (U / 4) + w) * 64 + lane];
     };
 
-    prefetch(0, nxt);
-    V xcur = valid ? a.x[line] : V(0);     // old value of the row of the lane's next step (row 0 first)
+    V xcur = a.x[line];                    // old value of the row of the lane's next step (row 0 first)
     V xlast = V(0);                        // the lane's newest result
-    for (int blk = 0; blk < a.n_blk; ++blk) {
-        const int T0 = blk * U;
-        cur = nxt;
-        if (blk > 0) {
-            // steps < T0 are complete once the stores behind them have left the wave
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (lane == 0) store_through(progress + size_t(tile) * SYNC_STRIDE, (uint32_t)T0);
-        }
-        if (blk + 1 < a.n_blk) prefetch(blk + 1, nxt);
-        V out[U];
+
+    // U steps; FAST (double only): returns whether some row's numerator left quotient<true>'s range
+    auto steps = [&](auto full_tag, auto fast_tag, int i0, const Block &cur, V (&out)[U]) {
+        constexpr bool FULL = decltype(full_tag)::value;
+        constexpr bool FAST = decltype(fast_tag)::value;
+        bool bad = false;
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int i = T0 + u - skew;
-            const bool act = valid && i >= 0 && i < nx;
-            const int code = int((cur.codes >> (8 * u)) & 255u);
-            const V *c = s_coef + code * 8;
+            const int i = i0 + u;
+            const bool act = FULL || (valid && i >= 0 && i < nx);
+            const int code = int((cur.codes[u / 4] >> (8 * (u & 3))) & 255u);
+            V c[8];
+            load_coefs(s_coef + code * 8, c);
+            const V c0 = c[0], c1 = c[1], c2 = c[2], c3 = c[3], c4 = c[4], c5 = c[5], c6 = c[6], rc = c[7];
             V xjm = __shfl_up(xlast, 1), xkm = __shfl_up(xlast, TJ);
             if (jj == 0) xjm = cur.ej[u];
             if (kk == 0) xkm = cur.ek[u];
@@ -146,41 +217,123 @@ __global__ __launch_bounds__(64) void march_gs_kernel(MarchArgs<V> a) {
             V xjp = __shfl_down(xip, 1), xkp = __shfl_down(xip, TJ);
             if (jj == TJ - 1) xjp = cur.ej[u];
             if (kk == TK - 1) xkp = cur.ek[u];
-            V sum = madd(c[0], xkm, V(0));
-            sum = madd(c[1], xjm, sum);
-            sum = madd(c[2], xlast, sum);
-            sum = madd(c[3], xcur, sum);
-            sum = madd(c[4], xip, sum);
-            sum = madd(c[5], xjp, sum);
-            sum = madd(c[6], xkp, sum);
-            const V xn = xcur + (cur.bv[u] - sum) / c[3];      // csr_kernels.hip ROW_GS
+            V sum = madd(c0, xkm, V(0));
+            sum = madd(c1, xjm, sum);
+            sum = madd(c2, xlast, sum);
+            sum = madd(c3, xcur, sum);
+            sum = madd(c4, xip, sum);
+            sum = madd(c5, xjp, sum);
+            sum = madd(c6, xkp, sum);
+            const V num = cur.bv[u] - sum;
+            if (FAST) bad = bad || (act && !plain_range(num));
+            const V xn = xcur + quotient<FAST>(num, c3, rc);      // csr_kernels.hip ROW_GS
             out[u] = xn;
-            if (act) xlast = xn;
+            xlast = act ? xn : xlast;
             xcur = xip;
         }
+        return bad;
+    };
+    constexpr bool HAS_FAST = std::is_same<V, double>::value;
+    auto steps_checked = [&](auto full_tag, int i0, const Block &cur, V (&out)[U]) {
+        if constexpr (HAS_FAST) {
+            const V xl0 = xlast, xc0 = xcur;
+            if (__any(steps(full_tag, std::true_type(), i0, cur, out))) {
+                xlast = xl0;
+                xcur = xc0;
+                steps(full_tag, std::false_type(), i0, cur, out);
+            }
+        } else {
+            steps(full_tag, std::false_type(), i0, cur, out);
+        }
+    };
+
+    auto block = [&](int blk, Block &cur, Block &nxt) {
+        const int T0 = blk * U, i0 = T0 - skew;
+        // 1. this block's face operands were loaded a block ago: wait for those their tiles had not written yet
+        if (lowJ || lowK) {
+            auto missing = [&]() {
+                bool m = false;
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int i = T0 + u - skew;
-            if (valid && i >= 0 && i < nx) {
-                if (face) store_through(a.x + line + i, out[u]);
-                else a.x[line + i] = out[u];
+                for (int u = 0; u < U; ++u) {
+                    const bool in = i0 + u >= 0 && i0 + u < nx;
+                    m = m || (in && ((lowJ && Unset<V>::is(cur.ej[u])) || (lowK && Unset<V>::is(cur.ek[u]))));
+                }
+                return m;
+            };
+            long long t0 = 0;
+            if (a.dbg) t0 = wall_clock64();
+            while (__any(missing()) && spins < SPIN_LIMIT) {
+                __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    if (lowJ) cur.ej[u] = load_through(inJ + i0 + u);
+                    if (lowK) cur.ek[u] = load_through(inK + i0 + u);
+                }
+                ++spins;
+            }
+            if (a.dbg) t_wait += wall_clock64() - t0;
+            // ... and leave the slots unset for the next sweep
+            if (lowJ) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) store_through(inJ + i0 + u, unset);
+            }
+            if (lowK) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) store_through(inK + i0 + u, unset);
             }
         }
+        // 2. operands of the next block
+        if (blk + 1 < n_blk) prefetch(blk + 1, nxt);
+        // 3. U steps
+        V out[U];
+        const bool full = whole && T0 >= max_skew && T0 + U <= nx;     // every lane is inside its line for all U steps
+        if (full) {
+            steps_checked(std::true_type(), i0, cur, out);
+#pragma unroll
+            for (int u = 0; u < U; ++u) a.x[line + i0 + u] = out[u];
+        } else {
+            steps_checked(std::false_type(), i0, cur, out);
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (valid && i0 + u >= 0 && i0 + u < nx) a.x[line + i0 + u] = out[u];
+        }
+        // 4. the faces the +J / +K tiles wait for
+        if (highJ) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) store_through(outJ + i0 + u, out[u]);
+        }
+        if (highK) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) store_through(outK + i0 + u, out[u]);
+        }
+    };
+
+    Block A, B;
+    prefetch(0, A);
+    for (int blk = 0; blk < n_blk; blk += 2) {
+        block(blk, A, B);
+        if (blk + 1 < n_blk) block(blk + 1, B, A);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (lane == 0) store_through(progress + size_t(tile) * SYNC_STRIDE, (uint32_t)T);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    // the last tile to finish leaves the counters as the next sweep expects them
+    if (__any(spins >= SPIN_LIMIT) && lane == 0) store_through(a.sync + 2, 1u);
+    if (a.dbg && lane == 0) {
+        a.dbg[4 * tile + 0] = t_begin;
+        a.dbg[4 * tile + 1] = wall_clock64();
+        a.dbg[4 * tile + 2] = t_wait;
+        a.dbg[4 * tile + 3] = spins;
+    }
+    // the last tile to finish leaves the ticket counter as the next sweep expects it
     uint32_t done = 0;
     if (lane == 0) done = __hip_atomic_fetch_add(a.sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     done = __builtin_amdgcn_readfirstlane(done);
-    if (done == uint32_t(a.n_tiles - 1)) {
-        for (int q = lane; q < a.n_tiles; q += 64) store_through(progress + size_t(q) * SYNC_STRIDE, 0u);
-        if (lane == 0) {
-            store_through(a.sync + 0, 0u);
-            store_through(a.sync + 1, 0u);
-        }
+    if (done == uint32_t(a.n_tiles - 1) && lane == 0) {
+        store_through(a.sync + 0, 0u);
+        store_through(a.sync + 1, 0u);
     }
+}
+
+template <typename V>
+__global__ void fill_kernel(V *p, size_t n, V v) {
+    for (size_t q = blockIdx.x * size_t(blockDim.x) + threadIdx.x; q < n; q += size_t(gridDim.x) * blockDim.x) p[q] = v;
 }
 
 }  // namespace
@@ -238,7 +391,8 @@ bool MarchPlan<V>::build(const omg_csr &A, hipStream_t s) {
                 last = slot;
                 p[slot] = A.data[q];
             }
-            if (p[3] == 0.0) { ok = false; return; }
+            // (the diagonal's exponent: the range in which march_gs_kernel's division needs no scaling)
+            if (!(std::fabs(p[3]) >= 0x1p-400 && std::fabs(p[3]) <= 0x1p400)) { ok = false; return; }
             if (hit < pats.size() && !memcmp(&pats[hit], &p, sizeof(Pat))) { code[r] = (uint8_t)hit; continue; }
             size_t f = 0;
             while (f < pats.size() && memcmp(&pats[f], &p, sizeof(Pat))) ++f;
@@ -277,11 +431,11 @@ bool MarchPlan<V>::build(const omg_csr &A, hipStream_t s) {
     g.ntk = (g.nz + g.TK - 1) / g.TK;
     g.n_tiles = g.ntj * g.ntk;
     g.T = g.nx + g.TJ + g.TK - 2;
-    g.n_blk = (g.T + U - 1) / U;
+    g.n_grp = 2 * ((g.T + 7) / 8);
     g.n_pat = (int)pats.size();
 
-    // the codes as the tiles consume them: one 8-byte word per (tile, block, lane)
-    std::vector<uint64_t> words(size_t(g.n_tiles) * g.n_blk * 64);
+    // the codes as the tiles consume them: one 4-byte word per (tile, group of four steps, lane)
+    std::vector<uint32_t> words(size_t(g.n_tiles) * g.n_grp * 64);
     auto arrange = [&](int t) {
         for (int tile = t; tile < g.n_tiles; tile += nt) {
             const int J = tile % g.ntj, K = tile / g.ntj;
@@ -291,17 +445,17 @@ bool MarchPlan<V>::build(const omg_csr &A, hipStream_t s) {
                 const bool valid = j < g.ny && k < g.nz;
                 const int64_t line = valid ? (int64_t(k) * ny + j) * nx : 0;
                 int owner = 0;                       // the scanning thread of the line's rows (for the remap)
-                for (int blk = 0; blk < g.n_blk; ++blk) {
-                    uint64_t w = 0;
-                    for (int u = 0; u < U; ++u) {
-                        const int i = blk * U + u - jj - kk;
+                for (int grp = 0; grp < g.n_grp; ++grp) {
+                    uint32_t w = 0;
+                    for (int u = 0; u < 4; ++u) {
+                        const int i = grp * 4 + u - jj - kk;
                         if (!valid || i < 0 || i >= nx) continue;
                         const int64_t r = line + i;
                         while (r >= n * (owner + 1) / nt) ++owner;
                         while (r < n * owner / nt) --owner;
-                        w |= uint64_t(remap[owner][code[r]]) << (8 * u);
+                        w |= uint32_t(remap[owner][code[r]]) << (8 * u);
                     }
-                    words[(size_t(tile) * g.n_blk + blk) * 64 + lane] = w;
+                    words[(size_t(tile) * g.n_grp + grp) * 64 + lane] = w;
                 }
             }
         }
@@ -317,10 +471,16 @@ bool MarchPlan<V>::build(const omg_csr &A, hipStream_t s) {
         for (int e = 0; e < 7; ++e) cf[size_t(q) * 8 + e] = V(pats[q][e]);
     codes.alloc(words.size());
     coef.alloc(cf.size());
-    sync.alloc(size_t(SYNC_HEAD) + size_t(g.n_tiles) * SYNC_STRIDE);
+    sync.alloc(SYNC_WORDS);
+    // one slot per row of every tile's +J / +K face lines, all unset between sweeps
+    faceJ.alloc(size_t(g.n_tiles) * g.TK * (g.nx + 2 * FACE_PAD));
+    faceK.alloc(size_t(g.n_tiles) * g.TJ * (g.nx + 2 * FACE_PAD));
     codes.upload(words.data(), words.size(), s);
     coef.upload(cf.data(), cf.size(), s);
     sync.zero(s);
+    hipLaunchKernelGGL(fill_kernel<V>, dim3(1024), dim3(256), 0, s, faceJ.p, faceJ.n, Unset<V>::value());
+    hipLaunchKernelGGL(fill_kernel<V>, dim3(1024), dim3(256), 0, s, faceK.p, faceK.n, Unset<V>::value());
+    OMG_HIP(hipGetLastError());
     OMG_HIP(hipStreamSynchronize(s));
     return true;
 }
@@ -330,9 +490,28 @@ void MarchPlan<V>::sweep(V *x, const V *b, hipStream_t s) const {
     MarchArgs<V> a;
     a.x = x; a.b = b; a.codes = codes.p; a.coef = coef.p; a.sync = sync.p;
     a.nx = g.nx; a.ny = g.ny; a.nz = g.nz; a.TJ = g.TJ; a.ntj = g.ntj; a.n_tiles = g.n_tiles;
-    a.T = g.T; a.n_blk = g.n_blk; a.n_pat = g.n_pat;
-    hipLaunchKernelGGL(march_gs_kernel<V>, dim3((unsigned)g.n_tiles), dim3(64), 0, s, a);
+    a.T = g.T; a.n_grp = g.n_grp; a.n_pat = g.n_pat; a.n = g.nx * g.ny * g.nz;
+    a.faceJ = faceJ.p; a.faceK = faceK.p;
+    static const int steps = [] { const char *e = getenv("OMG_MARCH_STEPS"); return e ? atoi(e) : 8; }();
+    static const bool debug = [] { const char *e = getenv("OMG_MARCH_DEBUG"); return e && e[0] == '1'; }();
+    DevBuf<long long> dbg;
+    a.dbg = nullptr;
+    if (debug) { dbg.alloc(size_t(4) * g.n_tiles); a.dbg = dbg.p; }
+    if (steps == 4) hipLaunchKernelGGL((march_gs_kernel<V, 4>), dim3((unsigned)g.n_tiles), dim3(64), 0, s, a);
+    else hipLaunchKernelGGL((march_gs_kernel<V, 8>), dim3((unsigned)g.n_tiles), dim3(64), 0, s, a);
     OMG_HIP(hipGetLastError());
+    if (debug) {
+        std::vector<long long> h(size_t(4) * g.n_tiles);
+        dbg.download(h.data(), h.size(), s);
+        OMG_HIP(hipStreamSynchronize(s));
+        long long t0 = h[0];
+        for (int q = 0; q < g.n_tiles; ++q) t0 = std::min(t0, h[4 * q]);
+        fprintf(stderr, "[omg march] %d x %d x %d, %d tiles (100 MHz ticks: start, end, in face waits, polls)\n", g.nx, g.ny, g.nz, g.n_tiles);
+        for (int q = 0; q < g.n_tiles; ++q)
+            if (q < 12 || q + 4 > g.n_tiles || q % std::max(1, g.n_tiles / 16) == 0)
+                fprintf(stderr, "[omg march]   tile %4d (J %2d K %2d): %8lld %8lld %8lld %6lld\n", q, q % g.ntj, q / g.ntj,
+                        h[4 * q] - t0, h[4 * q + 1] - t0, h[4 * q + 2], h[4 * q + 3]);
+    }
 }
 
 template struct MarchPlan<double>;
