@@ -116,6 +116,15 @@ __device__ __forceinline__ void load_coefs(const float *c, float (&o)[8]) {
     o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w;
 }
 
+// x[q] / b[q] through a buffer descriptor: one instruction per load, and a row index outside the
+// vector (the steps of a lane before / behind its line, wrapped when negative) returns 0
+__device__ __forceinline__ double buffer_at(__amdgpu_buffer_rsrc_t rs, int q, double) {
+    return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs, int(unsigned(q) * 8u), 0, 0));
+}
+__device__ __forceinline__ float buffer_at(__amdgpu_buffer_rsrc_t rs, int q, float) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, int(unsigned(q) * 4u), 0, 0));
+}
+
 template <typename V, int U>
 struct BlockData {
     V xs[U];     // own line, old value of row i + 1 at step t
@@ -125,13 +134,27 @@ struct BlockData {
     uint32_t codes[U / 4];
 };
 
+constexpr int RING = 4;            // blocks of results between the two waves of a tile
+
+// One workgroup = one tile = two waves with the same lane -> line mapping.  Wave 0 loads and
+// computes and never stores to global memory: with stores in flight every wait for a load would
+// also wait for them (one counter, out-of-order between the two kinds), and the write-through face
+// stores take a microsecond.  It hands each block's results to wave 1 through an LDS ring; wave 1
+// stores them: x, the face slots the +J / +K tiles wait for, and "unset" into the consumed slots.
 template <typename V, int U>
-__global__ __launch_bounds__(64) void march_gs_kernel(MarchArgs<V> a) {
+__global__ __launch_bounds__(128) void march_gs_kernel(MarchArgs<V> a) {
     __shared__ V s_coef[256 * 8];
+    __shared__ V s_ring[RING][U][64];
     __shared__ int s_tile;
-    const int lane = threadIdx.x;
-    if (lane == 0) s_tile = (int)__hip_atomic_fetch_add(a.sync + 0, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    for (int q = lane; q < a.n_pat * 8; q += 64) {
+    __shared__ int s_ready, s_taken;       // blocks wave 0 has put into the ring / wave 1 has taken out
+    const int lane = threadIdx.x & 63;
+    const bool storer = threadIdx.x >= 64;
+    if (threadIdx.x == 0) {
+        s_tile = (int)__hip_atomic_fetch_add(a.sync + 0, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_ready = 0;
+        s_taken = 0;
+    }
+    for (int q = threadIdx.x; q < a.n_pat * 8; q += 128) {
         V c = a.coef[q];
         if ((q & 7) == 7) c = refined_rcp(a.coef[q - 4]);
         s_coef[q] = c;
@@ -145,7 +168,7 @@ __global__ __launch_bounds__(64) void march_gs_kernel(MarchArgs<V> a) {
     const bool valid = j < a.ny && k < a.nz;
     const bool whole = (J + 1) * TJ <= a.ny && (K + 1) * TK <= a.nz;     // every lane of the tile has a line
     const int skew = jj + kk, max_skew = TJ + TK - 2;
-    const int nx = a.nx, last = a.n - 1, nxp = nx + 2 * FACE_PAD;
+    const int nx = a.nx, nxp = nx + 2 * FACE_PAD;
     const int line = valid ? (k * a.ny + j) * nx : 0;
     // operands in other tiles' lines: relaxed ones come through the face slots, the others are old values of x
     const bool lowJ = valid && jj == 0 && j > 0, highJ = valid && jj == TJ - 1 && j + 1 < a.ny;
@@ -162,25 +185,78 @@ __global__ __launch_bounds__(64) void march_gs_kernel(MarchArgs<V> a) {
     int spins = 0;
     long long t_begin = 0, t_wait = 0;
     if (a.dbg) t_begin = wall_clock64();
+    auto lds_flag = [&](int *f) { return __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
 
-    auto clampi = [&](int q) { return min(max(q, 0), last); };
+    if (storer) {
+        for (int blk = 0; blk < n_blk; ++blk) {
+            const int i0 = blk * U - skew;
+            long long t0 = 0;
+            if (a.dbg) t0 = wall_clock64();
+            while (lds_flag(&s_ready) <= blk && spins < SPIN_LIMIT) { __builtin_amdgcn_s_sleep(1); ++spins; }
+            if (a.dbg) t_wait += wall_clock64() - t0;
+            asm volatile("" ::: "memory");
+            V out[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) out[u] = s_ring[blk % RING][u][lane];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (lane == 0) __hip_atomic_store(&s_taken, blk + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            // the faces the +J / +K tiles wait for
+            if (highJ) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) store_through(outJ + i0 + u, out[u]);
+            }
+            if (highK) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) store_through(outK + i0 + u, out[u]);
+            }
+            const bool full = whole && blk * U >= max_skew && blk * U + U <= nx;
+            if (full) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) a.x[line + i0 + u] = out[u];
+            } else {
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+                    if (valid && i0 + u >= 0 && i0 + u < nx) a.x[line + i0 + u] = out[u];
+            }
+            // the slots wave 0 consumed for this block are left unset for the next sweep
+            if (lowJ) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) store_through(inJ + i0 + u, unset);
+            }
+            if (lowK) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) store_through(inK + i0 + u, unset);
+            }
+        }
+        if (__any(spins >= SPIN_LIMIT) && lane == 0) store_through(a.sync + 2, 1u);
+        if (a.dbg && lane == 0) {
+            a.dbg[8 * tile + 5] = wall_clock64();
+            a.dbg[8 * tile + 6] = t_wait;
+        }
+        return;
+    }
+    long long t_ring = 0;
+
+    const unsigned vec_bytes = unsigned(a.n) * unsigned(sizeof(V));
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(a.x, 0, vec_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t br = __builtin_amdgcn_make_buffer_rsrc(const_cast<V *>(a.b), 0, vec_bytes, 0x00020000);
     typedef BlockData<V, U> Block;
     auto prefetch = [&](int blk, Block &d) {
         const int i0 = blk * U - skew;
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            d.xs[u] = a.x[clampi(line + i0 + u + 1)];
-            d.bv[u] = a.b[clampi(line + i0 + u)];
+            d.xs[u] = buffer_at(xr, line + i0 + u + 1, V(0));
+            d.bv[u] = buffer_at(br, line + i0 + u, V(0));
             d.ej[u] = V(0);
             d.ek[u] = V(0);
         }
         if (highJ) {
 #pragma unroll
-            for (int u = 0; u < U; ++u) d.ej[u] = a.x[clampi(line + i0 + u + offJ)];
+            for (int u = 0; u < U; ++u) d.ej[u] = buffer_at(xr, line + i0 + u + offJ, V(0));
         }
         if (highK) {
 #pragma unroll
-            for (int u = 0; u < U; ++u) d.ek[u] = a.x[clampi(line + i0 + u + offK)];
+            for (int u = 0; u < U; ++u) d.ek[u] = buffer_at(xr, line + i0 + u + offK, V(0));
         }
         if (lowJ) {
 #pragma unroll
@@ -247,7 +323,8 @@ __global__ __launch_bounds__(64) void march_gs_kernel(MarchArgs<V> a) {
         }
     };
 
-    auto block = [&](int blk, Block &cur, Block &nxt) {
+    int taken_seen = 0;                    // s_taken as last read
+    auto block = [&](int blk, Block &cur, Block &far) {
         const int T0 = blk * U, i0 = T0 - skew;
         // 1. this block's face operands were loaded a block ago: wait for those their tiles had not written yet
         if (lowJ || lowK) {
@@ -272,54 +349,46 @@ __global__ __launch_bounds__(64) void march_gs_kernel(MarchArgs<V> a) {
                 ++spins;
             }
             if (a.dbg) t_wait += wall_clock64() - t0;
-            // ... and leave the slots unset for the next sweep
-            if (lowJ) {
-#pragma unroll
-                for (int u = 0; u < U; ++u) store_through(inJ + i0 + u, unset);
-            }
-            if (lowK) {
-#pragma unroll
-                for (int u = 0; u < U; ++u) store_through(inK + i0 + u, unset);
-            }
         }
-        // 2. operands of the next block
-        if (blk + 1 < n_blk) prefetch(blk + 1, nxt);
+        // 2. operands of the block after the next one (two blocks of steps cover the latency of the loads)
+        if (blk + 2 < n_blk) prefetch(blk + 2, far);
         // 3. U steps
         V out[U];
         const bool full = whole && T0 >= max_skew && T0 + U <= nx;     // every lane is inside its line for all U steps
-        if (full) {
-            steps_checked(std::true_type(), i0, cur, out);
-#pragma unroll
-            for (int u = 0; u < U; ++u) a.x[line + i0 + u] = out[u];
-        } else {
-            steps_checked(std::false_type(), i0, cur, out);
-#pragma unroll
-            for (int u = 0; u < U; ++u)
-                if (valid && i0 + u >= 0 && i0 + u < nx) a.x[line + i0 + u] = out[u];
+        if (full) steps_checked(std::true_type(), i0, cur, out);
+        else steps_checked(std::false_type(), i0, cur, out);
+        // 4. hand the results to the storing wave
+        if (blk - taken_seen >= RING) {
+            long long t0 = 0;
+            if (a.dbg) t0 = wall_clock64();
+            while (blk - taken_seen >= RING && spins < SPIN_LIMIT) {
+                taken_seen = lds_flag(&s_taken);
+                if (blk - taken_seen >= RING) { __builtin_amdgcn_s_sleep(1); ++spins; }
+            }
+            if (a.dbg) t_ring += wall_clock64() - t0;
         }
-        // 4. the faces the +J / +K tiles wait for
-        if (highJ) {
+        asm volatile("" ::: "memory");
 #pragma unroll
-            for (int u = 0; u < U; ++u) store_through(outJ + i0 + u, out[u]);
-        }
-        if (highK) {
-#pragma unroll
-            for (int u = 0; u < U; ++u) store_through(outK + i0 + u, out[u]);
-        }
+        for (int u = 0; u < U; ++u) s_ring[blk % RING][u][lane] = out[u];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (lane == 0) __hip_atomic_store(&s_ready, blk + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     };
 
-    Block A, B;
+    Block A, B, C;
     prefetch(0, A);
-    for (int blk = 0; blk < n_blk; blk += 2) {
-        block(blk, A, B);
+    if (n_blk > 1) prefetch(1, B);
+    for (int blk = 0; blk < n_blk; blk += 3) {
+        block(blk, A, C);
         if (blk + 1 < n_blk) block(blk + 1, B, A);
+        if (blk + 2 < n_blk) block(blk + 2, C, B);
     }
     if (__any(spins >= SPIN_LIMIT) && lane == 0) store_through(a.sync + 2, 1u);
     if (a.dbg && lane == 0) {
-        a.dbg[4 * tile + 0] = t_begin;
-        a.dbg[4 * tile + 1] = wall_clock64();
-        a.dbg[4 * tile + 2] = t_wait;
-        a.dbg[4 * tile + 3] = spins;
+        a.dbg[8 * tile + 0] = t_begin;
+        a.dbg[8 * tile + 1] = wall_clock64();
+        a.dbg[8 * tile + 2] = t_wait;
+        a.dbg[8 * tile + 3] = spins;
+        a.dbg[8 * tile + 4] = t_ring;
     }
     // the last tile to finish leaves the ticket counter as the next sweep expects it
     uint32_t done = 0;
@@ -341,7 +410,7 @@ __global__ void fill_kernel(V *p, size_t n, V v) {
 template <typename V>
 bool MarchPlan<V>::build(const omg_csr &A, hipStream_t s) {
     const int64_t n = A.n_rows;
-    if (n < 2 || n != A.n_cols || n >= (int64_t(1) << 30)) return false;
+    if (n < 2 || n != A.n_cols || uint64_t(n) * sizeof(V) >= (uint64_t(1) << 32)) return false;   // 32-bit byte offsets
     auto has = [&](int64_t r, int64_t c) {
         for (int64_t p = A.indptr[r]; p < A.indptr[r + 1]; ++p)
             if (A.indices[p] == c) return true;
@@ -496,21 +565,39 @@ void MarchPlan<V>::sweep(V *x, const V *b, hipStream_t s) const {
     static const bool debug = [] { const char *e = getenv("OMG_MARCH_DEBUG"); return e && e[0] == '1'; }();
     DevBuf<long long> dbg;
     a.dbg = nullptr;
-    if (debug) { dbg.alloc(size_t(4) * g.n_tiles); a.dbg = dbg.p; }
-    if (steps == 4) hipLaunchKernelGGL((march_gs_kernel<V, 4>), dim3((unsigned)g.n_tiles), dim3(64), 0, s, a);
-    else hipLaunchKernelGGL((march_gs_kernel<V, 8>), dim3((unsigned)g.n_tiles), dim3(64), 0, s, a);
+    if (debug) { dbg.alloc(size_t(8) * g.n_tiles); dbg.zero(s); a.dbg = dbg.p; }
+    if (steps == 4) hipLaunchKernelGGL((march_gs_kernel<V, 4>), dim3((unsigned)g.n_tiles), dim3(128), 0, s, a);
+    else hipLaunchKernelGGL((march_gs_kernel<V, 8>), dim3((unsigned)g.n_tiles), dim3(128), 0, s, a);
     OMG_HIP(hipGetLastError());
     if (debug) {
-        std::vector<long long> h(size_t(4) * g.n_tiles);
+        std::vector<long long> h(size_t(8) * g.n_tiles);
         dbg.download(h.data(), h.size(), s);
         OMG_HIP(hipStreamSynchronize(s));
         long long t0 = h[0];
-        for (int q = 0; q < g.n_tiles; ++q) t0 = std::min(t0, h[4 * q]);
-        fprintf(stderr, "[omg march] %d x %d x %d, %d tiles (100 MHz ticks: start, end, in face waits, polls)\n", g.nx, g.ny, g.nz, g.n_tiles);
-        for (int q = 0; q < g.n_tiles; ++q)
-            if (q < 12 || q + 4 > g.n_tiles || q % std::max(1, g.n_tiles / 16) == 0)
-                fprintf(stderr, "[omg march]   tile %4d (J %2d K %2d): %8lld %8lld %8lld %6lld\n", q, q % g.ntj, q / g.ntj,
-                        h[4 * q] - t0, h[4 * q + 1] - t0, h[4 * q + 2], h[4 * q + 3]);
+        for (int q = 0; q < g.n_tiles; ++q) t0 = std::min(t0, h[8 * q]);
+        fprintf(stderr, "[omg march] %d x %d x %d, %d tiles (100 MHz ticks: start, end, in face waits, polls, ring full | storing wave: end, idle)\n",
+                g.nx, g.ny, g.nz, g.n_tiles);
+        if (g.n_tiles <= 16) {
+            for (int q = 0; q < g.n_tiles; ++q)
+                fprintf(stderr, "[omg march]   tile %4d (J %2d K %2d): %8lld %8lld %8lld %6lld %8lld | %8lld %8lld\n", q, q % g.ntj,
+                        q / g.ntj, h[8 * q] - t0, h[8 * q + 1] - t0, h[8 * q + 2], h[8 * q + 3], h[8 * q + 4], h[8 * q + 5] - t0,
+                        h[8 * q + 6]);
+        } else {
+            // start / end / face-wait of every tile in microseconds, rows = K, columns = J (subsampled to 16 x 16)
+            const int sj = std::max(1, g.ntj / 16), sk = std::max(1, g.ntk / 16);
+            for (int what = 0; what < 3; ++what) {
+                fprintf(stderr, "[omg march]  %s (us):\n", what == 0 ? "start" : what == 1 ? "end" : "in face waits");
+                for (int K = 0; K < g.ntk; K += sk) {
+                    fprintf(stderr, "[omg march]   ");
+                    for (int J = 0; J < g.ntj; J += sj) {
+                        const int q = K * g.ntj + J;
+                        const long long v = what == 2 ? h[8 * q + 2] : h[8 * q + what] - t0;
+                        fprintf(stderr, "%5lld", v / 100);
+                    }
+                    fprintf(stderr, "\n");
+                }
+            }
+        }
     }
 }
 
