@@ -446,6 +446,7 @@ struct MarchPlan {
     // false: the operator is not such a stencil (the caller keeps the level schedule)
     bool build(const omg_csr &A, hipStream_t s);
     void sweep(V *x, const V *b, hipStream_t s) const;   // one in-place lexicographic sweep
+    bool timed_out(hipStream_t s) const;                 // (synchronises) some sweep gave up waiting for a face
 };
 
 }  // namespace omg

@@ -406,6 +406,15 @@ void load_vec(Hier<V> *h, int l, const double *host, V *dst) {
     }
 }
 
+// The wavefront sweeps give up waiting for a face after a bounded number of polls instead of
+// hanging the device; whoever reads results back asks whether that has happened.
+template <typename V>
+void check_march(Hier<V> *h) {
+    for (Level<V> &L : h->lv)
+        if (L.march && L.march->timed_out(h->stream))
+            throw Error(OMG_ERR_HIP, "lexicographic wavefront sweep timed out waiting for a neighbouring tile's face");
+}
+
 template <typename V>
 void fetch_vec(Hier<V> *h, int l, const V *src, double *host) {
     Level<V> &L = h->lv[l];
@@ -417,6 +426,7 @@ void fetch_vec(Hier<V> *h, int l, const V *src, double *host) {
         L.nat.download(host, L.n, h->stream);
     }
     OMG_HIP(hipStreamSynchronize(h->stream));
+    check_march(h);
 }
 
 template <typename V>
@@ -424,6 +434,7 @@ double read_norm(Hier<V> *h) {
     double v = 0.0;
     OMG_HIP(hipMemcpyAsync(&v, h->norm_dev.p, sizeof(double), hipMemcpyDeviceToHost, h->stream));
     OMG_HIP(hipStreamSynchronize(h->stream));
+    check_march(h);
     return v;
 }
 

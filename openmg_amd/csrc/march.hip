@@ -12,10 +12,20 @@
 //   * per step and lane that is one row: the seven-slot fma chain in stored (= column) order with
 //     the coefficients of the row's pattern from LDS, then x_i + (b_i - sum) / a_ii — the
 //     expression of csr_kernels.hip's ROW_GS, hence the same bits as the level schedule;
-//   * operands that live in another tile's lines are loaded MARCH_U steps ahead: not yet relaxed
-//     ones at any time, relaxed ones once the owning tile has published enough steps
-//     (write-through stores -> s_waitcnt vmcnt(0) -> flag; the loads and polls bypass L1/L2
-//     staleness with agent-scope loads: MI355X_MICROARCH.md, inter-workgroup visibility).
+//   * operands that live in another tile's lines: the not yet relaxed ones are old values of x, loaded a
+//     block of steps ahead like the lane's own line and b; the relaxed ones come through FACE SLOTS in
+//     HBM, one per row of a tile's last lines: unset (a marker NaN) between sweeps, written
+//     write-through by the owning tile, loaded a block ahead by the tile that needs them and polled
+//     again while still unset (all of that with agent-scope accesses that bypass the L1 and the other
+//     XCDs' L2: MI355X_MICROARCH.md, inter-workgroup visibility), then reset.  Tiles are numbered by
+//     a ticket counter, so the tiles a tile waits for have always started; a wave gives up after a
+//     bounded number of polls (MarchPlan::timed_out) instead of hanging the device.
+//
+// Measured (profiles/r02_march_*): one step of a tile alone is 0.20 us (the dependent chain: a shuffle
+// round trip through LDS, 72 cycles, + ~25 dependent double operations — tools/lat_probe.hip), a hop
+// from tile to tile 8-13 us ((7 steps of skew + a block published + a block consumed) x the step time
+// + ~2 us for a write-through store to become visible and the load that fetches it); 256^3: 62 hops,
+// 1.3 ms per sweep against 3.4 ms for the 766 launches of the level schedule.
 #include <algorithm>
 #include <array>
 #include <atomic>
@@ -125,6 +135,21 @@ __device__ __forceinline__ float buffer_at(__amdgpu_buffer_rsrc_t rs, int q, flo
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, int(unsigned(q) * 4u), 0, 0));
 }
 
+// value of lane - 1 / lane + 1 (lane 0 / 63 keep their own): one DPP move per dword, no LDS round trip
+template <int CTRL>
+__device__ __forceinline__ double dpp_wave_shift(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+template <int CTRL>
+__device__ __forceinline__ float dpp_wave_shift(float v) {
+    const int w = __float_as_int(v);
+    return __int_as_float(__builtin_amdgcn_update_dpp(w, w, CTRL, 0xf, 0xf, false));
+}
+constexpr int DPP_WAVE_SHR1 = 0x138, DPP_WAVE_SHL1 = 0x130;
+
 template <typename V, int U>
 struct BlockData {
     V xs[U];     // own line, old value of row i + 1 at step t
@@ -134,23 +159,29 @@ struct BlockData {
     uint32_t codes[U / 4];
 };
 
-constexpr int RING = 4;            // blocks of results between the two waves of a tile
+constexpr int RING = 4;            // blocks of results between the computing wave and the storing wave
 
-// One workgroup = one tile = two waves with the same lane -> line mapping.  Wave 0 loads and
-// computes and never stores to global memory: with stores in flight every wait for a load would
-// also wait for them (one counter, out-of-order between the two kinds), and the write-through face
-// stores take a microsecond.  It hands each block's results to wave 1 through an LDS ring; wave 1
-// stores them: x, the face slots the +J / +K tiles wait for, and "unset" into the consumed slots.
+// One workgroup = one tile = two waves with the same lane -> line mapping.
+//   * The COMPUTING wave loads, relaxes, and never stores to global memory: with stores in flight every
+//     wait for a load would also wait for them (one counter for both kinds, out of order between
+//     them), and a write-through face store takes about a microsecond.  It hands each block's results
+//     to the STORING wave through an LDS ring; that wave writes x, the face slots the +J / +K tiles
+//     wait for, and "unset" into the slots this tile has consumed.
 template <typename V, int U>
 __global__ __launch_bounds__(128) void march_gs_kernel(MarchArgs<V> a) {
     __shared__ V s_coef[256 * 8];
     __shared__ V s_ring[RING][U][64];
     __shared__ int s_tile;
-    __shared__ int s_ready, s_taken;       // blocks wave 0 has put into the ring / wave 1 has taken out
+    __shared__ int s_ready, s_taken;           // blocks the computing wave has put into the ring / the storing wave has taken out
     const int lane = threadIdx.x & 63;
     const bool storer = threadIdx.x >= 64;
     if (threadIdx.x == 0) {
-        s_tile = (int)__hip_atomic_fetch_add(a.sync + 0, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // tiles are numbered by a ticket: whatever order the workgroups start in, the tiles a tile
+        // takes faces from (lower numbers) have started
+        const unsigned t = __hip_atomic_fetch_add(a.sync + 0, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_tile = (int)t;
+        // every tile has its ticket: the counter is left as the next sweep expects it
+        if ((int)t == a.n_tiles - 1) store_through(a.sync + 0, 0u);
         s_ready = 0;
         s_taken = 0;
     }
@@ -170,12 +201,13 @@ __global__ __launch_bounds__(128) void march_gs_kernel(MarchArgs<V> a) {
     const int skew = jj + kk, max_skew = TJ + TK - 2;
     const int nx = a.nx, nxp = nx + 2 * FACE_PAD;
     const int line = valid ? (k * a.ny + j) * nx : 0;
-    // operands in other tiles' lines: relaxed ones come through the face slots, the others are old values of x
+    // Operands in other tiles' lines.  Relaxed ones (-J, -K) come from the face slots the owning tile
+    // fills; not yet relaxed ones (+J, +K) are old values of x.
     const bool lowJ = valid && jj == 0 && j > 0, highJ = valid && jj == TJ - 1 && j + 1 < a.ny;
     const bool lowK = valid && kk == 0 && k > 0, highK = valid && kk == TK - 1 && k + 1 < a.nz;
     const int offJ = nx, offK = nx * a.ny;
     // (a face line carries FACE_PAD slots in front of row 0 and behind row nx - 1: the steps of a lane
-    // that fall outside its line address those, so that nothing here is predicated on the row index)
+    // that fall outside its line address those, so that nothing there is predicated on the row)
     V *inJ = a.faceJ + (size_t(lowJ ? tile - 1 : tile) * TK + kk) * nxp + FACE_PAD;
     V *inK = a.faceK + (size_t(lowK ? tile - a.ntj : tile) * TJ + jj) * nxp + FACE_PAD;
     V *outJ = a.faceJ + (size_t(tile) * TK + kk) * nxp + FACE_PAD;
@@ -186,6 +218,7 @@ __global__ __launch_bounds__(128) void march_gs_kernel(MarchArgs<V> a) {
     long long t_begin = 0, t_wait = 0;
     if (a.dbg) t_begin = wall_clock64();
     auto lds_flag = [&](int *f) { return __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
+    auto lds_set = [&](int *f, int v) { __hip_atomic_store(f, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
 
     if (storer) {
         for (int blk = 0; blk < n_blk; ++blk) {
@@ -199,7 +232,7 @@ __global__ __launch_bounds__(128) void march_gs_kernel(MarchArgs<V> a) {
 #pragma unroll
             for (int u = 0; u < U; ++u) out[u] = s_ring[blk % RING][u][lane];
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (lane == 0) __hip_atomic_store(&s_taken, blk + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (lane == 0) lds_set(&s_taken, blk + 1);
             // the faces the +J / +K tiles wait for
             if (highJ) {
 #pragma unroll
@@ -218,7 +251,7 @@ __global__ __launch_bounds__(128) void march_gs_kernel(MarchArgs<V> a) {
                 for (int u = 0; u < U; ++u)
                     if (valid && i0 + u >= 0 && i0 + u < nx) a.x[line + i0 + u] = out[u];
             }
-            // the slots wave 0 consumed for this block are left unset for the next sweep
+            // the slots the computing wave consumed for this block are left unset for the next sweep
             if (lowJ) {
 #pragma unroll
                 for (int u = 0; u < U; ++u) store_through(inJ + i0 + u, unset);
@@ -274,23 +307,34 @@ __global__ __launch_bounds__(128) void march_gs_kernel(MarchArgs<V> a) {
     V xlast = V(0);                        // the lane's newest result
 
     // U steps; FAST (double only): returns whether some row's numerator left quotient<true>'s range
-    auto steps = [&](auto full_tag, auto fast_tag, int i0, const Block &cur, V (&out)[U]) {
+    // UNI: every row of the block has the same pattern, its table entries are in cu[] (no LDS reads)
+    V cu[8];
+    int cu_code = -1;
+    auto steps = [&](auto full_tag, auto fast_tag, auto uni_tag, int i0, const Block &cur, V (&out)[U]) {
         constexpr bool FULL = decltype(full_tag)::value;
         constexpr bool FAST = decltype(fast_tag)::value;
+        constexpr bool UNI = decltype(uni_tag)::value;
         bool bad = false;
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int i = i0 + u;
             const bool act = FULL || (valid && i >= 0 && i < nx);
-            const int code = int((cur.codes[u / 4] >> (8 * (u & 3))) & 255u);
             V c[8];
-            load_coefs(s_coef + code * 8, c);
+            if (UNI) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) c[e] = cu[e];
+            } else {
+                const int code = int((cur.codes[u / 4] >> (8 * (u & 3))) & 255u);
+                load_coefs(s_coef + code * 8, c);
+            }
             const V c0 = c[0], c1 = c[1], c2 = c[2], c3 = c[3], c4 = c[4], c5 = c[5], c6 = c[6], rc = c[7];
-            V xjm = __shfl_up(xlast, 1), xkm = __shfl_up(xlast, TJ);
+            V xjm = dpp_wave_shift<DPP_WAVE_SHR1>(xlast), xkm = xlast;
+            if (TK > 1) xkm = __shfl_up(xlast, TJ);
             if (jj == 0) xjm = cur.ej[u];
             if (kk == 0) xkm = cur.ek[u];
             const V xip = cur.xs[u];
-            V xjp = __shfl_down(xip, 1), xkp = __shfl_down(xip, TJ);
+            V xjp = dpp_wave_shift<DPP_WAVE_SHL1>(xip), xkp = xip;
+            if (TK > 1) xkp = __shfl_down(xip, TJ);
             if (jj == TJ - 1) xjp = cur.ej[u];
             if (kk == TK - 1) xkp = cur.ek[u];
             V sum = madd(c0, xkm, V(0));
@@ -310,23 +354,47 @@ __global__ __launch_bounds__(128) void march_gs_kernel(MarchArgs<V> a) {
         return bad;
     };
     constexpr bool HAS_FAST = std::is_same<V, double>::value;
-    auto steps_checked = [&](auto full_tag, int i0, const Block &cur, V (&out)[U]) {
+    auto steps_checked = [&](auto full_tag, auto uni_tag, int i0, const Block &cur, V (&out)[U]) {
         if constexpr (HAS_FAST) {
             const V xl0 = xlast, xc0 = xcur;
-            if (__any(steps(full_tag, std::true_type(), i0, cur, out))) {
+            if (__any(steps(full_tag, std::true_type(), uni_tag, i0, cur, out))) {
                 xlast = xl0;
                 xcur = xc0;
-                steps(full_tag, std::false_type(), i0, cur, out);
+                steps(full_tag, std::false_type(), uni_tag, i0, cur, out);
             }
         } else {
-            steps(full_tag, std::false_type(), i0, cur, out);
+            steps(full_tag, std::false_type(), uni_tag, i0, cur, out);
         }
     };
+    // one pattern for all rows of the block?  (then its entries are fetched once, and kept while it stays the same)
+    auto uniform_pattern = [&](const Block &cur) {
+        const uint32_t w0 = __builtin_amdgcn_readfirstlane(cur.codes[0]);
+        bool same = w0 == (w0 & 255u) * 0x01010101u;
+#pragma unroll
+        for (int w = 0; w < U / 4; ++w) same = same && cur.codes[w] == w0;
+        if (!__all(same)) return false;
+        if (int(w0 & 255u) != cu_code) {
+            cu_code = int(w0 & 255u);
+            load_coefs(s_coef + cu_code * 8, cu);
+        }
+        return true;
+    };
 
-    int taken_seen = 0;                    // s_taken as last read
-    auto block = [&](int blk, Block &cur, Block &far) {
+    int taken_seen = 0;
+    auto wait_at_least = [&](int *flag, int need, int &seen) {
+        if (seen >= need) return;
+        long long t0 = 0;
+        if (a.dbg) t0 = wall_clock64();
+        while (seen < need && spins < SPIN_LIMIT) {
+            seen = lds_flag(flag);
+            if (seen < need) { __builtin_amdgcn_s_sleep(1); ++spins; }
+        }
+        if (a.dbg) t_ring += wall_clock64() - t0;
+        asm volatile("" ::: "memory");
+    };
+    auto block = [&](int blk, Block &cur, Block &nxt) {
         const int T0 = blk * U, i0 = T0 - skew;
-        // 1. this block's face operands were loaded a block ago: wait for those their tiles had not written yet
+        // 1. the face operands of this block were loaded a block ago: wait for those their tiles had not written yet
         if (lowJ || lowK) {
             auto missing = [&]() {
                 bool m = false;
@@ -350,37 +418,27 @@ __global__ __launch_bounds__(128) void march_gs_kernel(MarchArgs<V> a) {
             }
             if (a.dbg) t_wait += wall_clock64() - t0;
         }
-        // 2. operands of the block after the next one (two blocks of steps cover the latency of the loads)
-        if (blk + 2 < n_blk) prefetch(blk + 2, far);
+        // 2. operands of the next block
+        if (blk + 1 < n_blk) prefetch(blk + 1, nxt);
         // 3. U steps
         V out[U];
         const bool full = whole && T0 >= max_skew && T0 + U <= nx;     // every lane is inside its line for all U steps
-        if (full) steps_checked(std::true_type(), i0, cur, out);
-        else steps_checked(std::false_type(), i0, cur, out);
+        if (full && uniform_pattern(cur)) steps_checked(std::true_type(), std::true_type(), i0, cur, out);
+        else if (full) steps_checked(std::true_type(), std::false_type(), i0, cur, out);
+        else steps_checked(std::false_type(), std::false_type(), i0, cur, out);
         // 4. hand the results to the storing wave
-        if (blk - taken_seen >= RING) {
-            long long t0 = 0;
-            if (a.dbg) t0 = wall_clock64();
-            while (blk - taken_seen >= RING && spins < SPIN_LIMIT) {
-                taken_seen = lds_flag(&s_taken);
-                if (blk - taken_seen >= RING) { __builtin_amdgcn_s_sleep(1); ++spins; }
-            }
-            if (a.dbg) t_ring += wall_clock64() - t0;
-        }
-        asm volatile("" ::: "memory");
+        wait_at_least(&s_taken, blk - RING + 1, taken_seen);
 #pragma unroll
         for (int u = 0; u < U; ++u) s_ring[blk % RING][u][lane] = out[u];
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (lane == 0) __hip_atomic_store(&s_ready, blk + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (lane == 0) lds_set(&s_ready, blk + 1);
     };
 
-    Block A, B, C;
+    Block A, B;
     prefetch(0, A);
-    if (n_blk > 1) prefetch(1, B);
-    for (int blk = 0; blk < n_blk; blk += 3) {
-        block(blk, A, C);
+    for (int blk = 0; blk < n_blk; blk += 2) {
+        block(blk, A, B);
         if (blk + 1 < n_blk) block(blk + 1, B, A);
-        if (blk + 2 < n_blk) block(blk + 2, C, B);
     }
     if (__any(spins >= SPIN_LIMIT) && lane == 0) store_through(a.sync + 2, 1u);
     if (a.dbg && lane == 0) {
@@ -389,14 +447,6 @@ __global__ __launch_bounds__(128) void march_gs_kernel(MarchArgs<V> a) {
         a.dbg[8 * tile + 2] = t_wait;
         a.dbg[8 * tile + 3] = spins;
         a.dbg[8 * tile + 4] = t_ring;
-    }
-    // the last tile to finish leaves the ticket counter as the next sweep expects it
-    uint32_t done = 0;
-    if (lane == 0) done = __hip_atomic_fetch_add(a.sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    done = __builtin_amdgcn_readfirstlane(done);
-    if (done == uint32_t(a.n_tiles - 1) && lane == 0) {
-        store_through(a.sync + 0, 0u);
-        store_through(a.sync + 1, 0u);
     }
 }
 
@@ -561,13 +611,14 @@ void MarchPlan<V>::sweep(V *x, const V *b, hipStream_t s) const {
     a.nx = g.nx; a.ny = g.ny; a.nz = g.nz; a.TJ = g.TJ; a.ntj = g.ntj; a.n_tiles = g.n_tiles;
     a.T = g.T; a.n_grp = g.n_grp; a.n_pat = g.n_pat; a.n = g.nx * g.ny * g.nz;
     a.faceJ = faceJ.p; a.faceK = faceK.p;
-    static const int steps = [] { const char *e = getenv("OMG_MARCH_STEPS"); return e ? atoi(e) : 8; }();
+    static const int steps = [] { const char *e = getenv("OMG_MARCH_STEPS"); return e ? atoi(e) : 8; }();   // steps per block
     static const bool debug = [] { const char *e = getenv("OMG_MARCH_DEBUG"); return e && e[0] == '1'; }();
     DevBuf<long long> dbg;
     a.dbg = nullptr;
     if (debug) { dbg.alloc(size_t(8) * g.n_tiles); dbg.zero(s); a.dbg = dbg.p; }
-    if (steps == 4) hipLaunchKernelGGL((march_gs_kernel<V, 4>), dim3((unsigned)g.n_tiles), dim3(128), 0, s, a);
-    else hipLaunchKernelGGL((march_gs_kernel<V, 8>), dim3((unsigned)g.n_tiles), dim3(128), 0, s, a);
+    const dim3 grid((unsigned)g.n_tiles);
+    if (steps == 4) hipLaunchKernelGGL((march_gs_kernel<V, 4>), grid, dim3(128), 0, s, a);
+    else hipLaunchKernelGGL((march_gs_kernel<V, 8>), grid, dim3(128), 0, s, a);
     OMG_HIP(hipGetLastError());
     if (debug) {
         std::vector<long long> h(size_t(8) * g.n_tiles);
@@ -599,6 +650,14 @@ void MarchPlan<V>::sweep(V *x, const V *b, hipStream_t s) const {
             }
         }
     }
+}
+
+template <typename V>
+bool MarchPlan<V>::timed_out(hipStream_t s) const {
+    uint32_t flag = 0;
+    OMG_HIP(hipMemcpyAsync(&flag, sync.p + 2, sizeof(flag), hipMemcpyDeviceToHost, s));
+    OMG_HIP(hipStreamSynchronize(s));
+    return flag != 0;
 }
 
 template struct MarchPlan<double>;
