@@ -423,11 +423,12 @@ struct CoarseSolver {
 // consecutive rows of one (j, k)), lane (jj, kk) relaxes row i = t - jj - kk of its line at step t,
 // so that the three already relaxed neighbours of a row were relaxed one step earlier by this lane,
 // lane - 1 and lane - TJ (wave shuffles), and the three not yet relaxed ones are old values.
-// Tiles hand their faces over through HBM: a tile publishes the number of steps it has completed
-// (write-through stores, then a flag) after every MARCH_U steps, and its +J / +K neighbours load the
-// face values behind that (tile indices are taken from a ticket counter, so a tile's
-// predecessors have always started).  Every row is the same fma chain in stored order as in the
-// row kernels (absent neighbours contribute 0 * x to the chain, which leaves it unchanged).
+// Tiles hand their faces over through HBM: one slot per row of a tile's last lines, unset (a marker
+// NaN) between sweeps, written write-through by the owning tile's storing wave and polled by the
+// +J / +K tile, which starts a block of steps once every row it needs has arrived (tile indices
+// are taken from a ticket counter, so a tile's predecessors have always started).  Every row is the
+// same fma chain in stored order as in the row kernels (absent neighbours contribute 0 * x to the
+// chain, which leaves it unchanged), and the same division.
 constexpr int MARCH_FACE_PAD = 72;    // slots in front of / behind the rows of a face line (>= largest skew 63 + steps per block)
 struct MarchGeom {
     int nx = 0, ny = 0, nz = 0;       // rows per line, lines per plane, planes

@@ -17,7 +17,7 @@ CASES = [
     ("configs[1] 2-D 5-point 1024^2, 4 grids, weighted Jacobi (omega 2/3)", (1024, 1024), 4, "jacobi", "stencil"),
     ("configs[1] shape with red-black GS", (1024, 1024), 4, "colour", "stencil"),
     ("configs[2] 3-D 7-point 256^3, 5 grids, red-black GS", (256, 256, 256), 5, "colour", "stencil"),
-    ("configs[2] shape with the reference's lexicographic GS (766 level sets)", (256, 256, 256), 5, "gs", "stencil"),
+    ("configs[2] shape with the reference's lexicographic GS (one wavefront launch per sweep; OMG_MARCH=0: 766 level sets)", (256, 256, 256), 5, "gs", "stencil"),
     ("3-D 7-point 128^3, 4 grids, lexicographic GS", (128, 128, 128), 4, "gs", "stencil"),
 ]
 
