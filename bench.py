@@ -22,6 +22,8 @@ Prints ONE JSON line: metric V-cycles/s (median of --repeats timed regions of K 
   csr_path      the same problem with every operator held as plain int32 CSR (OMG_COMPRESS=0),
                 timed with the same loop: V-cycles/s, residual and fine-grid SpMV launches against
                 SURVEY 8(d)'s CSR byte counts;
+  reference_smoother  the same problem with the reference's own lexicographic Gauss-Seidel as the
+                smoother (the headline uses the red-black ordering BASELINE configs[2] names);
   cpu_baseline  the CPU oracle's V-cycle timed on this box's host (one core: the oracle's C
                 sweeps and SciPy's CSR kernels are single-threaded) on a bounded sample.
 """
@@ -160,6 +162,7 @@ def main():
     ap.add_argument("--graph", type=int, default=0, help="replay the cycle from a hipGraph")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-plain", action="store_true", help="skip the plain-CSR (OMG_COMPRESS=0) leg")
+    ap.add_argument("--no-lex", action="store_true", help="skip the leg with the reference's lexicographic Gauss-Seidel")
     ap.add_argument("--dist", type=int, default=0, help="force the multi-GPU code path even with one rank (debug)")
     ap.add_argument("--watchdog", type=int, default=900, help="multi-GPU: abort after this many seconds")
     ap.add_argument("--overlap", type=int, default=1,
@@ -344,6 +347,29 @@ def main():
                                        "frac": round(spmv_csr / p_spmv_ms / 1e6 / HBM_PEAK_GBS, 4)}}
         h2.close()
 
+    # The same problem with the reference's OWN smoother — in-place lexicographic Gauss-Seidel
+    # (openmg/solvers.py:56-68) — instead of the red-black ordering: same loop, fewer repeats.
+    lex_path = None
+    if not args.no_lex and args.smoother == "colour":
+        h3, b3, meta3 = build_problem(args.size, args.grids, "gs", np_dtype)
+        h3.resident_load(b3)
+
+        def sync3():
+            h3.sync()
+            torch.cuda.synchronize()
+
+        l_times, _, l_norms = timed_regions(h3, sync3, args.steps, min(args.warmup, 2), min(repeats, 3), pre, post, ())
+        l_elapsed = statistics.median(l_times)
+        lex_path = {"what": "same problem and timed loop with the reference's lexicographic Gauss-Seidel (openmg/solvers.py:56-68) "
+                            "as the smoother; grid star stencils run a sweep as one wavefront launch (march.hip, "
+                            "OMG_MARCH=0: one launch per level set), bit-identical either way",
+                    "vcycles_per_s": round(args.steps / l_elapsed, 3), "ms_per_step": round(1e3 * l_elapsed / args.steps, 4),
+                    "ms_per_step_all": [round(1e3 * t / args.steps, 4) for t in l_times],
+                    "wavefront_levels": [bool(h3.level_flags(l)["march"]) for l in range(meta3["grids"] - 1)],
+                    "level_sets_fine_grid": h3.level_sets(0), "setup_s": round(meta3["setup_s"], 2),
+                    "norms_last_region_tail": l_norms[-3:]}
+        h3.close()
+
     h.close()
     cpu = None
     if not args.no_cpu:
@@ -391,6 +417,7 @@ def main():
                    "generate_s": round(generate_s, 2)},
         "roofline": roofline,
         "csr_path": csr_path,
+        "reference_smoother": lex_path,
         "fine_grid_spmv": fine_spmv,
         "cpu_baseline": cpu,
     }
