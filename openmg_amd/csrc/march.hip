@@ -221,6 +221,7 @@ __global__ __launch_bounds__(128) void march_gs_kernel(MarchArgs<V> a) {
     auto lds_set = [&](int *f, int v) { __hip_atomic_store(f, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
 
     if (storer) {
+        const __amdgpu_buffer_rsrc_t xw = __builtin_amdgcn_make_buffer_rsrc(a.x, 0, unsigned(a.n) * unsigned(sizeof(V)), 0x00020000);
         for (int blk = 0; blk < n_blk; ++blk) {
             const int i0 = blk * U - skew;
             long long t0 = 0;
@@ -244,8 +245,18 @@ __global__ __launch_bounds__(128) void march_gs_kernel(MarchArgs<V> a) {
             }
             const bool full = whole && blk * U >= max_skew && blk * U + U <= nx;
             if (full) {
+                // 16 bytes per lane and instruction: every lane writes its own cache line, and the
+                // address unit takes a lane per cycle whatever the width — it is what several tiles
+                // sharing a CU run short of
+                typedef int v4i_t __attribute__((ext_vector_type(4)));
+                constexpr int PER = 16 / int(sizeof(V));
 #pragma unroll
-                for (int u = 0; u < U; ++u) a.x[line + i0 + u] = out[u];
+                for (int u = 0; u < U; u += PER) {
+                    union { V v[PER]; v4i_t q; } pack;
+#pragma unroll
+                    for (int e = 0; e < PER; ++e) pack.v[e] = out[u + e];
+                    __builtin_amdgcn_raw_buffer_store_b128(pack.q, xw, int(unsigned(line + i0 + u) * unsigned(sizeof(V))), 0, 0);
+                }
             } else {
 #pragma unroll
                 for (int u = 0; u < U; ++u)
@@ -407,8 +418,12 @@ __global__ __launch_bounds__(128) void march_gs_kernel(MarchArgs<V> a) {
             };
             long long t0 = 0;
             if (a.dbg) t0 = wall_clock64();
+            int nap = 0;
             while (__any(missing()) && spins < SPIN_LIMIT) {
-                __builtin_amdgcn_s_sleep(1);
+                if (nap == 0) __builtin_amdgcn_s_sleep(1);
+                else if (nap == 1) __builtin_amdgcn_s_sleep(4);
+                else __builtin_amdgcn_s_sleep(16);
+                ++nap;
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     if (lowJ) cur.ej[u] = load_through(inJ + i0 + u);
@@ -434,6 +449,29 @@ __global__ __launch_bounds__(128) void march_gs_kernel(MarchArgs<V> a) {
         if (lane == 0) lds_set(&s_ready, blk + 1);
     };
 
+    // Before anything else: wait, politely, until the tiles this one takes faces from have produced
+    // their first rows.  Hundreds of tiles sit here when a sweep starts; polling all the slots of a
+    // block from each of them takes memory bandwidth from the few tiles that can run ("255 pollers cut
+    // chip bandwidth 37-71 %", MI355X_MICROARCH.md), so this polls ONE slot per lane and sleeps
+    // longer and longer (up to ~1.7 us) in between.
+    if (lowJ || lowK) {
+        long long t0 = 0;
+        if (a.dbg) t0 = wall_clock64();
+        int nap = 1;
+        for (;;) {
+            bool wait = false;
+            if (lowJ) wait = Unset<V>::is(load_through(inJ));
+            if (lowK) wait = wait || Unset<V>::is(load_through(inK));
+            if (!__any(wait) || spins >= SPIN_LIMIT) break;
+            if (nap <= 1) __builtin_amdgcn_s_sleep(2);
+            else if (nap <= 2) __builtin_amdgcn_s_sleep(8);
+            else if (nap <= 4) __builtin_amdgcn_s_sleep(24);
+            else __builtin_amdgcn_s_sleep(64);
+            ++nap;
+            ++spins;
+        }
+        if (a.dbg) t_wait += wall_clock64() - t0;
+    }
     Block A, B;
     prefetch(0, A);
     for (int blk = 0; blk < n_blk; blk += 2) {
