@@ -13,7 +13,7 @@ for r in rows:
             run += 1
             prev = None
         continue
-    g = int(r["Grid_Size_X"]) // 64
+    g = int(r["Grid_Size_X"]) // int(r["Workgroup_Size_X"])
     prev = g
     d.setdefault((run if "--runs" in sys.argv else 0, g), []).append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
 print(" ".join(a for a in sys.argv[2:] if a != "--runs"),
