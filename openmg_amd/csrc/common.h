@@ -48,8 +48,11 @@ struct SetupTimer {
 };
 
 // ---- device buffers -----------------------------------------------------------------
-// Plain hipMalloc RAII.  Every allocation gets 64 bytes of slack so that the 16-byte
-// vector loads of the row kernels may run past the logical end of an array.
+// Plain hipMalloc RAII.  Every allocation gets 64 bytes of slack on BOTH sides so that the
+// 16-byte vector loads of the row kernels may run past the logical end of an array, and the
+// paired gathers of rows_union_kernel (x[c], x[c + 1] in one load, c = -1 for a first row whose
+// neighbour does not exist) may start one element in front of it.
+constexpr size_t DEVBUF_SLACK = 64;
 template <typename T>
 struct DevBuf {
     T *p = nullptr;
@@ -67,10 +70,12 @@ struct DevBuf {
     void alloc(size_t count) {
         release();
         n = count;
-        OMG_HIP(hipMalloc(reinterpret_cast<void **>(&p), count * sizeof(T) + 64));
+        char *raw = nullptr;
+        OMG_HIP(hipMalloc(reinterpret_cast<void **>(&raw), count * sizeof(T) + 2 * DEVBUF_SLACK));
+        p = reinterpret_cast<T *>(raw + DEVBUF_SLACK);
     }
     void release() {
-        if (p) (void)hipFree(p);
+        if (p) (void)hipFree(reinterpret_cast<char *>(p) - DEVBUF_SLACK);
         p = nullptr;
         n = 0;
     }

@@ -829,11 +829,25 @@ void rows_pattern_kernel(KArgs<V> a, int blk0) {
 //      pattern's mask lacks: the row's entries in stored order, one fma chain — the bits of
 //      rows_kernel / rows_pattern_kernel (rows here hold at most UNION_MAX <= ASSOC_LEN entries).
 typedef unsigned v2u __attribute__((ext_vector_type(2)));
+typedef unsigned v4u __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ double buffer_gather(__amdgpu_buffer_rsrc_t rs, int byte_off, double) {
     return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs, byte_off, 0, 0));
 }
 __device__ __forceinline__ float buffer_gather(__amdgpu_buffer_rsrc_t rs, int byte_off, float) {
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, byte_off, 0, 0));
+}
+// two consecutive elements in ONE load: the vector L1 serves 16 bytes per lane at twice the rate of
+// 8 (MI355X_MICROARCH.md: "8-B accesses 0.54-0.70x the 16-B rate"), and these launches are short of it
+__device__ __forceinline__ void buffer_gather2(__amdgpu_buffer_rsrc_t rs, int byte_off, double &lo, double &hi) {
+    const v4u q = __builtin_amdgcn_raw_buffer_load_b128(rs, byte_off, 0, 0);
+    lo = __builtin_bit_cast(double, v2u{q.x, q.y});
+    hi = __builtin_bit_cast(double, v2u{q.z, q.w});
+}
+// (float rows are not paired: an 8-byte buffer load at a 4-byte aligned offset returned wrong data on
+// gfx950 — measured, tests/test_gpu_parity.py — while 16-byte loads at 8-byte aligned offsets are served)
+__device__ __forceinline__ void buffer_gather2(__amdgpu_buffer_rsrc_t rs, int byte_off, float &lo, float &hi) {
+    lo = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, byte_off, 0, 0));
+    hi = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, byte_off + 4, 0, 0));
 }
 
 template <int MODE, int U, int UMAX, typename V>
@@ -855,15 +869,22 @@ __global__ __launch_bounds__(NT) void rows_union_kernel(KArgs<V> a, int blk0, un
     const int uo = uidx[min(lane, ul - 1)];
     const V uv = uval[min(lane, ul - 1)];
     const int mk = pmask[min(lane, npat - 1)];
-    // the gathered vector as a buffer: out-of-range offsets (negative ones wrap to huge) read 0
-    const __amdgpu_buffer_rsrc_t xs = __builtin_amdgcn_make_buffer_rsrc(const_cast<V *>(a.x), 0, x_bytes, 0x00020000);
+    // The gathered vector as a buffer: out-of-range offsets (negative ones wrap to huge) read 0.
+    // A thread's rows come in ADJACENT pairs (U even) and a pair's operands of one slot, x[c] and
+    // x[c + 1], in one load; the descriptor starts PAIR_PAD elements in front of the vector and ends as
+    // many behind it (every device vector is a DevBuf: 64 bytes of slack on both sides), so that a
+    // pair whose first or second member alone leaves the vector by one element is still served.
+    constexpr bool PAIRS = U % 2 == 0 && sizeof(V) == 8;
+    constexpr int PAIR_PAD = PAIRS ? 2 : 0;
+    const __amdgpu_buffer_rsrc_t xs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<V *>(a.x) - PAIR_PAD, 0, x_bytes + 2 * PAIR_PAD * unsigned(sizeof(V)), 0x00020000);
 
     int row[U], code[U];
     bool act[U];
     RowPre<V> pre[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-        row[u] = r0 + int(threadIdx.x) + u * NT;
+        row[u] = PAIRS ? r0 + 2 * (int(threadIdx.x) + (u >> 1) * NT) + (u & 1) : r0 + int(threadIdx.x) + u * NT;
         act[u] = row[u] < r1;
         code[u] = 0;
         pre[u].beg = pre[u].end = 0; pre[u].out = row[u]; pre[u].bv = V(0); pre[u].xv = V(0);
@@ -891,10 +912,19 @@ __global__ __launch_bounds__(NT) void rows_union_kernel(KArgs<V> a, int blk0, un
     for (int j = 0; j < UMAX; ++j) {
         if (j < ul) {                                           // block-uniform
             const int oj = __builtin_amdgcn_readlane(uo, j);
+            if constexpr (PAIRS) {
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                xg[u][j] = V(0);
-                if ((mask[u] >> j) & 1) xg[u][j] = buffer_gather(xs, (row[u] + oj) * int(sizeof(V)), V(0));
+                for (int u = 0; u < U; u += 2) {
+                    xg[u][j] = xg[u + 1][j] = V(0);
+                    if (((mask[u] | mask[u + 1]) >> j) & 1)
+                        buffer_gather2(xs, (row[u] + oj + PAIR_PAD) * int(sizeof(V)), xg[u][j], xg[u + 1][j]);
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    xg[u][j] = V(0);
+                    if ((mask[u] >> j) & 1) xg[u][j] = buffer_gather(xs, (row[u] + oj) * int(sizeof(V)), V(0));
+                }
             }
         } else {
 #pragma unroll
