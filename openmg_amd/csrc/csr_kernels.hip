@@ -155,6 +155,11 @@ __device__ __forceinline__ void row_resolve(RowPre<V> &p, const int *s_cd) {
 // modes reproduce the plain residual kernel bit for bit.
 __device__ __forceinline__ double madd(double v, double x, double acc) { return fma(v, x, acc); }
 __device__ __forceinline__ float madd(float v, float x, float acc) { return fmaf(v, x, acc); }
+// sq += res^2 for the residual norms, spelled as ONE fma everywhere: left to the compiler the
+// contraction of "sq += r * r" came out differently in different epilogues (last-bit differences
+// between a norm formed by a PRENORM launch and the same norm formed by a NORM_ONLY launch)
+template <typename V>
+__device__ __forceinline__ void add_square(double &sq, V res) { sq = fma(double(res), double(res), sq); }
 
 // Row-sum association (common.h ASSOC_LEN).  four: the row is long — entry e (counted from the
 // row's first) goes to chain e & 3; callers pass e's low bits as a compile-time j.
@@ -188,6 +193,38 @@ struct Chains {
     __device__ __forceinline__ V total(bool four) const { return four ? ((s0 + s1) + s2) + s3 : s0; }
 };
 
+// Modes whose epilogue is ONE store of one value to y[r]: that value (and the row's share of sq).
+constexpr bool mode_one_store(int m) {
+    return m == ROW_RESIDUAL || m == ROW_RESNORM || m == ROW_GS || m == ROW_JACOBI || m == ROW_GS_PRENORM ||
+           m == ROW_JACOBI_PRENORM || m == ROW_AXPY;
+}
+template <int MODE, typename V>
+__device__ __forceinline__ V row_result(const KArgs<V> &a, const RowPre<V> &p, V sum, V diag, double &sq) {
+    if constexpr (MODE == ROW_RESIDUAL) {
+        return p.bv - sum;
+    } else if constexpr (MODE == ROW_RESNORM) {
+        const V res = p.bv - sum;
+        add_square(sq, res);
+        return res;
+    } else if constexpr (MODE == ROW_GS) {
+        // openmg/solvers.py:68   x[i] = x[i] + (b[i] - Aix) / A[i, i]
+        return p.xv + (p.bv - sum) / diag;
+    } else if constexpr (MODE == ROW_JACOBI) {
+        return p.xv + a.omega * ((p.bv - sum) / diag);
+    } else if constexpr (MODE == ROW_GS_PRENORM) {
+        const V res = p.bv - sum;                  // the expression ROW_GS divides by the diagonal, and ROW_NORM_ONLY squares
+        add_square(sq, res);
+        return p.xv + res / diag;
+    } else if constexpr (MODE == ROW_JACOBI_PRENORM) {
+        const V res = p.bv - sum;
+        add_square(sq, res);
+        return p.xv + a.omega * (res / diag);
+    } else {
+        static_assert(MODE == ROW_AXPY, "row_result: mode has no single stored value");
+        return p.xv + sum;
+    }
+}
+
 template <int MODE, typename V>
 __device__ __forceinline__ void row_epilogue(const KArgs<V> &a, int r, const RowPre<V> &p, V sum,
                                              V diag, double &sq) {
@@ -203,30 +240,11 @@ __device__ __forceinline__ void row_epilogue(const KArgs<V> &a, int r, const Row
             }
             a.zero[p.out] = x0;
         }
-    } else if constexpr (MODE == ROW_RESIDUAL) {
-        a.y[r] = p.bv - sum;
-    } else if constexpr (MODE == ROW_RESNORM) {
-        const V res = p.bv - sum;
-        a.y[r] = res;
-        sq += double(res) * double(res);
     } else if constexpr (MODE == ROW_NORM_ONLY) {
         const V res = p.bv - sum;
-        sq += double(res) * double(res);
-    } else if constexpr (MODE == ROW_GS) {
-        // openmg/solvers.py:68   x[i] = x[i] + (b[i] - Aix) / A[i, i]
-        a.y[r] = p.xv + (p.bv - sum) / diag;
-    } else if constexpr (MODE == ROW_JACOBI) {
-        a.y[r] = p.xv + a.omega * ((p.bv - sum) / diag);
-    } else if constexpr (MODE == ROW_GS_PRENORM) {
-        const V res = p.bv - sum;                  // the expression ROW_GS divides by the diagonal, and ROW_NORM_ONLY squares
-        a.y[r] = p.xv + res / diag;
-        sq += double(res) * double(res);
-    } else if constexpr (MODE == ROW_JACOBI_PRENORM) {
-        const V res = p.bv - sum;
-        a.y[r] = p.xv + a.omega * (res / diag);
-        sq += double(res) * double(res);
-    } else if constexpr (MODE == ROW_AXPY) {
-        a.y[r] = p.xv + sum;
+        add_square(sq, res);
+    } else if constexpr (mode_one_store(MODE)) {
+        a.y[r] = row_result<MODE>(a, p, sum, diag, sq);
     }
 }
 
@@ -482,7 +500,7 @@ __device__ void process_block(const KArgs<V> &a, int blk, V *s_val, int *s_idx, 
                     if (sub == 0) {
                         a.y[r] = xnew;
                         if constexpr (MODE == ROW_GS_RES) a.zero[r] = res;
-                        else sq += double(res) * double(res);
+                        else add_square(sq, res);
                     }
                 } else if (sub == 0) {
                     row_epilogue<MODE>(a, r, pre, sum, diag, sq);
@@ -525,7 +543,7 @@ __device__ void process_block(const KArgs<V> &a, int blk, V *s_val, int *s_idx, 
                 a.y[r] = xnew;
                 const V res = pre.bv - sum2;
                 if constexpr (MODE == ROW_GS_RES) a.zero[r] = res;
-                else sq += double(res) * double(res);
+                else add_square(sq, res);
             }
         } else if (tid == 0) {
             const RowPre<V> pre = row_preload<MODE>(a, r);
@@ -801,7 +819,7 @@ void rows_pattern_kernel(KArgs<V> a, int blk0) {
             const V res = pre.bv - sum2;
             a.y[r] = xnew;
             if constexpr (MODE == ROW_GS_RES) a.zero[r] = res;
-            else sq += double(res) * double(res);
+            else add_square(sq, res);
         } else if constexpr (MODE != ROW_SCATTER) {
             row_epilogue<MODE>(a, r, pre, sum, diag, sq);
         }
@@ -830,6 +848,22 @@ void rows_pattern_kernel(KArgs<V> a, int blk0) {
 //      rows_kernel / rows_pattern_kernel (rows here hold at most UNION_MAX <= ASSOC_LEN entries).
 typedef unsigned v2u __attribute__((ext_vector_type(2)));
 typedef unsigned v4u __attribute__((ext_vector_type(4)));
+// two adjacent elements of a vector as one access, aligned like ONE element
+typedef double pair_d_raw __attribute__((ext_vector_type(2)));
+typedef float pair_f_raw __attribute__((ext_vector_type(2)));
+typedef pair_d_raw pair_d __attribute__((aligned(8)));
+typedef pair_f_raw pair_f __attribute__((aligned(4)));
+template <typename V> struct pair_of;
+template <> struct pair_of<double> { typedef pair_d type; };
+template <> struct pair_of<float> { typedef pair_f type; };
+template <typename V> using pair_t = typename pair_of<V>::type;
+template <typename V>
+__device__ __forceinline__ void store_pair(V *p, V lo, V hi) {
+    pair_t<V> q;
+    q.x = lo;
+    q.y = hi;
+    *reinterpret_cast<pair_t<V> *>(p) = q;
+}
 __device__ __forceinline__ double buffer_gather(__amdgpu_buffer_rsrc_t rs, int byte_off, double) {
     return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs, byte_off, 0, 0));
 }
@@ -888,9 +922,39 @@ __global__ __launch_bounds__(NT) void rows_union_kernel(KArgs<V> a, int blk0, un
         act[u] = row[u] < r1;
         code[u] = 0;
         pre[u].beg = pre[u].end = 0; pre[u].out = row[u]; pre[u].bv = V(0); pre[u].xv = V(0);
-        if (act[u]) {
-            pre[u] = row_preload<MODE>(a, row[u], EXT_PATTERN);
-            code[u] = pre[u].beg;
+        if constexpr (!PAIRS) {
+            if (act[u]) {
+                pre[u] = row_preload<MODE>(a, row[u], EXT_PATTERN);
+                code[u] = pre[u].beg;
+            }
+        }
+    }
+    if constexpr (PAIRS) {
+        // row_preload for a pair of adjacent rows: b, x_i (or y_i) as ONE 16-byte load each (the second
+        // element is read even when the pair's second row is beyond the block: it exists — the next
+        // block's row, or the slack behind the vector — and is not used)
+#pragma unroll
+        for (int u = 0; u < U; u += 2) {
+            if (act[u]) {
+                const int r = row[u];
+                code[u] = a.rcode[r];
+                if (act[u + 1]) code[u + 1] = a.rcode[r + 1];
+                if constexpr (MODE != ROW_SPMV && MODE != ROW_AXPY && MODE != ROW_SCATTER) {
+                    const pair_t<V> q = *reinterpret_cast<const pair_t<V> *>(a.b + r);
+                    pre[u].bv = q.x; pre[u + 1].bv = q.y;
+                }
+                if constexpr (mode_relaxes(MODE)) {
+                    const pair_t<V> q = *reinterpret_cast<const pair_t<V> *>(a.x + r);
+                    pre[u].xv = q.x; pre[u + 1].xv = q.y;
+                }
+                if constexpr (MODE == ROW_AXPY) {
+                    const pair_t<V> q = *reinterpret_cast<const pair_t<V> *>(a.y + r);
+                    pre[u].xv = q.x; pre[u + 1].xv = q.y;
+                }
+                if constexpr (MODE == ROW_SPMV) {
+                    if (a.ymap) { pre[u].out = a.ymap[r]; if (act[u + 1]) pre[u + 1].out = a.ymap[r + 1]; }
+                }
+            }
         }
     }
     // the pattern masks: lane c holds pattern c's.  ds_bpermute outside any divergent branch — an
@@ -967,14 +1031,41 @@ __global__ __launch_bounds__(NT) void rows_union_kernel(KArgs<V> a, int blk0, un
                 }
             }
         }
+        if constexpr (PAIRS) {
 #pragma unroll
-        for (int u = 0; u < U; ++u)
-            if (act[u]) {
-                const V res = pre[u].bv - sum2[u];
-                a.y[row[u]] = xnew[u];
-                if constexpr (MODE == ROW_GS_RES) a.zero[row[u]] = res;
-                else sq += double(res) * double(res);
+            for (int u = 0; u < U; u += 2) {
+                const V res0 = pre[u].bv - sum2[u], res1 = pre[u + 1].bv - sum2[u + 1];
+                if (act[u + 1]) {
+                    store_pair(a.y + row[u], xnew[u], xnew[u + 1]);
+                    if constexpr (MODE == ROW_GS_RES) store_pair(a.zero + row[u], res0, res1);
+                    else { add_square(sq, res0); add_square(sq, res1); }
+                } else if (act[u]) {
+                    a.y[row[u]] = xnew[u];
+                    if constexpr (MODE == ROW_GS_RES) a.zero[row[u]] = res0;
+                    else add_square(sq, res0);
+                }
             }
+        } else {
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (act[u]) {
+                    const V res = pre[u].bv - sum2[u];
+                    a.y[row[u]] = xnew[u];
+                    if constexpr (MODE == ROW_GS_RES) a.zero[row[u]] = res;
+                    else add_square(sq, res);
+                }
+        }
+    } else if constexpr (PAIRS && mode_one_store(MODE)) {
+#pragma unroll
+        for (int u = 0; u < U; u += 2) {
+            if (act[u + 1]) {
+                const V v0 = row_result<MODE>(a, pre[u], sum[u], diag[u], sq);
+                const V v1 = row_result<MODE>(a, pre[u + 1], sum[u + 1], diag[u + 1], sq);
+                store_pair(a.y + row[u], v0, v1);
+            } else if (act[u]) {
+                a.y[row[u]] = row_result<MODE>(a, pre[u], sum[u], diag[u], sq);
+            }
+        }
     } else {
 #pragma unroll
         for (int u = 0; u < U; ++u)
