@@ -877,8 +877,10 @@ __device__ __forceinline__ void buffer_gather2(__amdgpu_buffer_rsrc_t rs, int by
     lo = __builtin_bit_cast(double, v2u{q.x, q.y});
     hi = __builtin_bit_cast(double, v2u{q.z, q.w});
 }
-// (float rows are not paired: an 8-byte buffer load at a 4-byte aligned offset returned wrong data on
-// gfx950 — measured, tests/test_gpu_parity.py — while 16-byte loads at 8-byte aligned offsets are served)
+// (float rows are not paired: the paired fp32 variant was no faster — 2915 against 2890 V-cycles/s — and
+// did not reproduce the other kernels' bits in tests/test_gpu_parity.py's fp32 format case.  The
+// hardware is not the reason: tools/align_probe.hip shows 8- and 16-byte buffer and global loads
+// served correctly at any 4-byte aligned offset.)
 __device__ __forceinline__ void buffer_gather2(__amdgpu_buffer_rsrc_t rs, int byte_off, float &lo, float &hi) {
     lo = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, byte_off, 0, 0));
     hi = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, byte_off + 4, 0, 0));
