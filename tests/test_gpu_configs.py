@@ -186,6 +186,31 @@ def test_config2_full_size_256_cubed_redblack_against_oracle():
     np.testing.assert_allclose(x, xo, rtol=1e-9, atol=1e-11)
 
 
+# ------------------------------------------------------------------------------- configs[3] --
+def test_config3_problem_512_cubed_six_grids_on_one_gpu():
+    """BASELINE configs[3]'s problem (512^3, 6 grids, red-black, V(1,1), fp64) — quoted on 8 GPUs, where
+    the ranks hold 512 x 512 x 64 slabs — runs on ONE MI355X too (134 M unknowns, 938 M stored
+    entries).  Size-independent checks: the device's norm is the norm of the iterate it returns
+    (SciPy on the host), the cycles contract, and the operation is linear in b to the bit."""
+    shape, grids = (512, 512, 512), 6
+    A0 = operators.stencil_poisson(shape)
+    b = A0 @ np.random.default_rng(12345).random(A0.shape[0])
+    R = operators.restrictionList(shape, grids - 2, 8)
+    A = operators.coeffecientList(A0, R)
+    assert len(A) == grids and A[-1].shape[0] == 16 ** 3
+    with _hip.Hierarchy(A, R, smoother="colour") as h:
+        del A, R
+        assert h.level_sets(0) == 2 and h.level_flags(0)["union_walk"]
+        h.resident_load(b)
+        norms = h.resident_cycles(1, 1, 6)
+        x = h.resident_fetch()
+        assert rel(norms[-1], float(np.linalg.norm(b - A0 @ x))) < 1e-10
+        assert all(norms[k + 1] < norms[k] for k in range(5))
+        h.resident_load(4.0 * b)
+        n4 = h.resident_cycles(1, 1, 6)
+        assert n4 == [4.0 * v for v in norms] and np.array_equal(h.resident_fetch(), 4.0 * x)
+
+
 # ------------------------------------------------------------------ 8-rank decompositions --
 def _single(A0, shape, grids, b, cycles, dtype="float64"):
     R = [operators.restriction(tuple(s // 2 ** l for s in shape)) for l in range(grids - 1)]
