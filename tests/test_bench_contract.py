@@ -1,0 +1,48 @@
+"""The committed bench line and the PMC profile it may quote (profiles/r02_*): the driver's contract
+keys, a roofline fraction that is a fraction, and the rule that HBM traffic measured by rocprofv3 is
+only ever attached to a build whose kernel sources hash to the profile's."""
+import json
+import os
+import re
+
+import bench
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _load(name):
+    with open(os.path.join(ROOT, "profiles", name)) as f:
+        return json.loads(f.read().strip().splitlines()[-1]) if name.endswith("bench.json") else json.load(f)
+
+
+def test_committed_bench_line_keeps_the_contract():
+    d = _load("r02_bench.json")
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["unit"] == "V-cycles/s" and d["n_gpus"] == 1 and d["higher_is_better"] is True and d["scaling"] == "weak"
+    assert d["vs_baseline"] is None and d["dtype"] == "f64" and d["data"] == "synthetic"
+    assert "workload" in d["config"] and "model" not in d["config"]
+    assert abs(d["value"] - 1e3 / d["ms_per_step"]) / d["value"] < 1e-3          # value = steps / time of exactly those steps
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert 0.0 < r["frac"] <= 1.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert abs(r["achieved"] - r["bytes_per_launch"] / (r["avg_launch_us"] * 1e-6) / 1e9) / r["achieved"] < 1e-2
+    assert r["csr_equiv_bytes"] > r["bytes_per_launch"]                          # the CSR-byte rate is reported, never used for frac
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] == 1 and c["unit"] == "V-cycles/s" and c["value"] > 0 and c["sample"]
+    assert d["csr_path"]["residual"]["frac"] <= 1.0 and d["csr_path"]["fine_grid_spmv"]["frac"] <= 1.0
+    assert d["reference_smoother"]["vcycles_per_s"] > 0 and all(d["reference_smoother"]["wavefront_levels"])
+
+
+def test_pmc_traffic_is_tied_to_the_kernel_sources_it_was_measured_on():
+    p = _load("r02_pmc_residual.json")
+    assert re.fullmatch(r"[0-9a-f]{16}", p["kernel_src_sha"]) and re.fullmatch(r"[0-9a-f]{40}", p["git_head_at_collection"])
+    assert p["traffic_bytes"] == p["read_bytes"] + p["write_bytes"]
+    assert abs(p["read_bytes"] - 2 * p["fetch_size_KiB"] * 1024) < 1024          # gfx950: reads = 2 x FETCH_SIZE
+    assert p["traffic_bytes"] >= p["bytes_per_launch"]                           # over-fetch, never under
+    h = bench.kernel_source_hash()
+    assert re.fullmatch(r"[0-9a-f]{16}", h) and h == bench.kernel_source_hash()
+    d = _load("r02_bench.json")
+    if d["roofline"]["traffic"] is not None:                                     # only a run of the profiled build may carry it
+        assert d["roofline"]["traffic"] == p["traffic_bytes"] and "NOT measured in this run" in d["roofline"]["traffic_source"]
