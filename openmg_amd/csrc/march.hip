@@ -23,9 +23,10 @@
 //
 // Measured (profiles/r02_march_*): one step of a tile alone is 0.20 us (the dependent chain: a shuffle
 // round trip through LDS, 72 cycles, + ~25 dependent double operations — tools/lat_probe.hip), a hop
-// from tile to tile 8-13 us ((7 steps of skew + a block published + a block consumed) x the step time
-// + ~2 us for a write-through store to become visible and the load that fetches it); 256^3: 62 hops,
-// 1.3 ms per sweep against 3.4 ms for the 766 launches of the level schedule.
+// from tile to tile 8-13 us (the 7 steps of skew, whole blocks published and consumed, and mostly the
+// chain of latencies of a hand-over through HBM: finer-grained and streaming variants, DESIGN.md
+// section 6, did not shorten it); 256^3: 62 hops, 1.26 ms per sweep against 3.4 ms for the 766
+// launches of the level schedule.
 #include <algorithm>
 #include <array>
 #include <atomic>
