@@ -58,6 +58,18 @@ def kernel_source_hash():
     return h.hexdigest()[:16]
 
 
+def git_head():
+    """Commit of the sources this line was measured on: OMG_GIT_HEAD (the GPU boxes have no .git) or git itself."""
+    head = os.environ.get("OMG_GIT_HEAD")
+    if head:
+        return head
+    try:
+        import subprocess
+        return subprocess.check_output(["git", "-C", ROOT, "rev-parse", "HEAD"], text=True, stderr=subprocess.DEVNULL).strip()
+    except Exception:
+        return None
+
+
 def kernel_name(fmt, mode, union=False):
     """Which kernel walks an operator held like `fmt` (csrc/csr_kernels.hip launch_rows_range)."""
     if union:
@@ -414,7 +426,8 @@ def main():
                    "setup_s": round(setup_s, 2),
                    "setup_what": "restrictionList + coeffecientList (device Galerkin products) + device hierarchy; "
                                  "generating the synthetic operator and right-hand side on the host took generate_s",
-                   "generate_s": round(generate_s, 2)},
+                   "generate_s": round(generate_s, 2),
+                   "kernel_src_sha": kernel_source_hash(), "git_head": git_head()},
         "roofline": roofline,
         "csr_path": csr_path,
         "reference_smoother": lex_path,

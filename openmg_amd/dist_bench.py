@@ -24,6 +24,16 @@ def overlap_candidates(level_rows):
     return [("all levels", 0)] + [("levels >= %d rows" % n, n) for n in sizes[:-1]] + [("none", 1 << 62)]
 
 
+def _bench_identity():
+    """(hash of the kernel sources, commit) as bench.py reports them."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("_omg_bench", os.path.join(root, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod.kernel_source_hash(), mod.git_head()
+
+
 def main(args):
     import datetime
     import threading
@@ -176,6 +186,7 @@ def main(args):
                        "unknowns": n_glob, "unknowns_per_gpu": n_loc, "nnz_per_gpu": nnz_loc, "grids": grids,
                        "distributed_grids": n_dist - 1, "replicated_tail_grids": grids - n_dist + 1,
                        "rccl_ranks": rccl_ranks, "repeats": len(times), "overlap_autotune": autotune,
+                       "kernel_src_sha": _bench_identity()[0], "git_head": _bench_identity()[1],
                        "ms_per_step_all": [round(1e3 * t / args.steps, 4) for t in times],
                        "pre": pre, "post": post, "cycles_per_s": round(args.steps / elapsed, 3),
                        "final_residual_norm": norm, "norms_last_region_tail": region_norms[-3:],
