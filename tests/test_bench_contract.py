@@ -33,6 +33,7 @@ def test_committed_bench_line_keeps_the_contract():
     assert c["kind"] == "port" and c["cores"] == 1 and c["unit"] == "V-cycles/s" and c["value"] > 0 and c["sample"]
     assert d["csr_path"]["residual"]["frac"] <= 1.0 and d["csr_path"]["fine_grid_spmv"]["frac"] <= 1.0
     assert d["reference_smoother"]["vcycles_per_s"] > 0 and all(d["reference_smoother"]["wavefront_levels"])
+    assert re.fullmatch(r"[0-9a-f]{16}", d["config"]["kernel_src_sha"]) and re.fullmatch(r"[0-9a-f]{40}", d["config"]["git_head"])
 
 
 def test_pmc_traffic_is_tied_to_the_kernel_sources_it_was_measured_on():
