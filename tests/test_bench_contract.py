@@ -46,4 +46,8 @@ def test_pmc_traffic_is_tied_to_the_kernel_sources_it_was_measured_on():
     assert re.fullmatch(r"[0-9a-f]{16}", h) and h == bench.kernel_source_hash()
     d = _load("r02_bench.json")
     if d["roofline"]["traffic"] is not None:                                     # only a run of the profiled build may carry it
-        assert d["roofline"]["traffic"] == p["traffic_bytes"] and "NOT measured in this run" in d["roofline"]["traffic_source"]
+        # (the line quotes the PMC passes that were committed when it ran; the profile next to it may be a
+        # later collection on the same sources: FETCH_SIZE varies by a few hundred bytes from pass to pass)
+        assert d["config"]["kernel_src_sha"] == p["kernel_src_sha"]
+        assert abs(d["roofline"]["traffic"] - p["traffic_bytes"]) <= 1e-3 * p["traffic_bytes"]
+        assert "NOT measured in this run" in d["roofline"]["traffic_source"]
