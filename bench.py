@@ -14,14 +14,16 @@ itself (openmg_amd/launch.py) before it touches the GPU, relays rank 0's JSON li
 the worst child exit code.
 
 Prints ONE JSON line: metric V-cycles/s (median of --repeats timed regions of K cycles), plus
-  roofline      the fine-grid residual kernel r = b - A x (the SpMV-class kernel of the metric):
-                bytes the launch has to move, with the operator in the format it has in HBM,
-                / average launch time measured with hipEvents on the kernel's own stream inside
-                the timed regions, against 8 TB/s (frac <= 1 by construction); the rate in
-                SURVEY 8(d)'s plain-CSR bytes is reported beside it as csr_equiv_GBps;
-  csr_path      the same problem with every operator held as plain int32 CSR (OMG_COMPRESS=0),
-                timed with the same loop: V-cycles/s, residual and fine-grid SpMV launches against
-                SURVEY 8(d)'s CSR byte counts;
+  roofline      the dominant kernel — the plane-pipelined down pass of the fine grid (red-black
+                sweep + residual + restriction in one launch; without plane passes: the fine-grid
+                residual kernel r = b - A x): bytes the launch has to move / average launch time
+                measured with hipEvents on the kernel's own stream inside the timed regions, against
+                8 TB/s (frac <= 1 by construction); the rate in SURVEY 8(d)'s plain-CSR bytes of the
+                launches it replaces is reported beside it as csr_equiv_GBps;
+  set_schedule  the same problem with the set-by-set schedule (OMG_PLANE=0) the plane passes replace;
+  csr_path      the same problem with every operator held as plain int32 CSR (OMG_COMPRESS=0,
+                OMG_PLANE=0), timed with the same loop: V-cycles/s, residual and fine-grid SpMV
+                launches against SURVEY 8(d)'s CSR byte counts;
   reference_smoother  the same problem with the reference's own lexicographic Gauss-Seidel as the
                 smoother (the headline uses the red-black ordering BASELINE configs[2] names);
   cpu_baseline  the CPU oracle's V-cycle timed on this box's host (one core: the oracle's C
@@ -79,26 +81,56 @@ def kernel_name(fmt, mode, union=False):
     return "rows_kernel<%s>" % mode
 
 
+_PROBLEM = {}
+
+
 def build_problem(size, grids, smoother, dtype="float64"):
+    """Synthetic operator, right-hand side, R list and Galerkin products (made once per (size, grids) and
+    shared by the legs), then the device hierarchy for this leg's smoother / environment."""
     import numpy as np
     from openmg_amd import _hip, operators
     shape = (size, size, size)
-    t0 = time.perf_counter()
-    A0 = operators.stencil_poisson(shape)                       # synthetic input (NumPy, host)
-    u_true = np.random.default_rng(12345).random(A0.shape[0])
-    b = A0 @ u_true
-    _hip.device_count()                                         # loads the library
-    t1 = time.perf_counter()
-    # what mgSolve does before its first cycle (openmg/__init__.py:103-109): R list, Galerkin
-    # products (on the device), then the device hierarchy (ordering, coding, upload, coarse factors)
-    R = operators.restrictionList(shape, grids - 2, 8)          # gridLevels = grids - 1 -> coarsestLevel = grids - 2 (D5)
-    A = operators.coeffecientList(A0, R)
-    h = _hip.Hierarchy(A, R, smoother=smoother, dtype=dtype)
+    key = (size, grids)
+    if key not in _PROBLEM:
+        t0 = time.perf_counter()
+        A0 = operators.stencil_poisson(shape)                       # synthetic input (NumPy, host)
+        u_true = np.random.default_rng(12345).random(A0.shape[0])
+        b = A0 @ u_true
+        _hip.device_count()                                         # loads the library
+        t1 = time.perf_counter()
+        # what mgSolve does before its first cycle (openmg/__init__.py:103-109): R list, Galerkin
+        # products (on the device)
+        R = operators.restrictionList(shape, grids - 2, 8)          # gridLevels = grids - 1 -> coarsestLevel = grids - 2 (D5)
+        A = operators.coeffecientList(A0, R)
+        t2 = time.perf_counter()
+        _PROBLEM.clear()
+        _PROBLEM[key] = (A0, b, R, A, t1 - t0, t2 - t1)
+    A0, b, R, A, gen_s, rap_s = _PROBLEM[key]
     t2 = time.perf_counter()
+    h = _hip.Hierarchy(A, R, smoother=smoother, dtype=dtype)        # ordering, coding, upload, coarse factors
+    t3 = time.perf_counter()
     meta = {"n": A0.shape[0], "nnz": A0.nnz, "grids": len(A),
             "level_rows": [M.shape[0] for M in A], "level_nnz": [M.nnz for M in A],
-            "generate_s": t1 - t0, "setup_s": t2 - t1}
+            "generate_s": gen_s, "setup_s": rap_s + (t3 - t2), "rap_s": rap_s, "hierarchy_s": t3 - t2}
     return h, b, meta
+
+
+class env_override:
+    """Environment switches of one leg (read by the library when a hierarchy is created)."""
+
+    def __init__(self, **kv):
+        self.kv = kv
+
+    def __enter__(self):
+        self.keep = {k: os.environ.get(k) for k in self.kv}
+        os.environ.update(self.kv)
+
+    def __exit__(self, *exc):
+        for k, v in self.keep.items():
+            if v is None:
+                del os.environ[k]
+            else:
+                os.environ[k] = v
 
 
 def cpu_baseline(size, grids, cycles):
@@ -133,13 +165,21 @@ def cpu_baseline(size, grids, cycles):
     return cycles / dt, dt, spmv_bytes(A0.shape[0], A0.nnz) / spmv_s / 1e9
 
 
-def timed_regions(h, sync, steps, warmup, repeats, pre, post, classes=("residual",)):
+def timed_regions(h, sync, steps, warmup, repeats, pre, post, classes=("residual",), graph=False):
     """`warmup` untimed cycles, then `repeats` timed regions of EXACTLY `steps` cycles each,
     every one bracketed by a device synchronisation on both sides.  Inside the regions the
     launches of `classes` are bracketed by hipEvents on the hierarchy's own stream (one pair per
-    cycle for 'residual': ~1 % of the cycle).  Returns (elapsed seconds per region, profile, the
-    last region's norms)."""
-    h.resident_cycles(pre, post, warmup)
+    cycle and class: ~1 % of the cycle).  graph: the cycles are replays of a captured hipGraph
+    (omg_resident_cycle, one norm read back per cycle) instead of one batched call.  Returns (elapsed
+    seconds per region, profile, the last region's norms)."""
+    def cycles(k):
+        if graph:
+            return [h.resident_cycle(pre, post) for _ in range(k)]
+        # K cycles enqueued back to back, every cycle's residual norm computed and returned at the end
+        # of the region (omg_resident_cycles: mgSolve's loop with a cycle-count stop rule)
+        return h.resident_cycles(pre, post, k)
+
+    cycles(warmup)
     sync()
     if classes:
         h.profile_enable(list(classes))
@@ -147,14 +187,99 @@ def timed_regions(h, sync, steps, warmup, repeats, pre, post, classes=("residual
     for _ in range(repeats):
         sync()
         t0 = time.perf_counter()
-        # K cycles enqueued back to back, every cycle's residual norm computed and returned at the end
-        # of the region (omg_resident_cycles: mgSolve's loop with a cycle-count stop rule)
-        norms = h.resident_cycles(pre, post, steps)
+        norms = cycles(steps)
         sync()
         times.append(time.perf_counter() - t0)
     prof = h.profile_read() if classes else None
     h.profile_enable(False)
     return times, prof, norms
+
+
+def residual_launch_bytes(h, meta, w):
+    """The fine-grid residual launch r = b - A x of the set-by-set schedule: rows it covers, SURVEY 8(d)'s
+    CSR bytes, and the bytes it has to move with the operator in its device format."""
+    n = meta["n"]
+    n_sets = h.level_sets(0)
+    # With a Gauss-Seidel ordering the last set's residual comes out of the smoother launch that
+    # relaxed it (bit-identical, DESIGN.md §6), so the launch visits the other sets only.
+    covered = range(n_sets - 1) if h.level_fused(0) else range(n_sets)
+    rows_c = sum(h.set_info(0, s)[0] for s in covered)
+    nnz_c = sum(h.set_info(0, s)[1] for s in covered)
+    res_csr = (w + 4) * nnz_c + 4 * (rows_c + 1) + 2 * w * rows_c + w * n
+    fmt_sets = [h.format_info(0, "A", s) for s in covered]
+    res_fmt = sum(f["format_bytes"] for f in fmt_sets) + 2 * w * rows_c + w * n
+    fmt_cov = {k: sum(f[k] for f in fmt_sets) for k in ("rows", "nnz", "blocks", "pattern_rows", "coldict_nnz", "valdict_nnz")}
+    return rows_c, nnz_c, res_csr, res_fmt, fmt_cov
+
+
+def class_bytes(h, meta, w):
+    """Per class of level-0 launch: bytes one launch has to move (device format) and SURVEY 8(d)'s CSR bytes."""
+    n = meta["n"]
+    n_c = meta["level_rows"][1] if len(meta["level_rows"]) > 1 else 0
+    n_sets = h.level_sets(0)
+    rows_c, nnz_c, res_csr, res_fmt, _ = residual_launch_bytes(h, meta, w)
+    set_rows = [h.set_info(0, s)[0] for s in range(n_sets)]
+    set_nnz = [h.set_info(0, s)[1] for s in range(n_sets)]
+    nnz = meta["nnz"]
+    # one plane-pipelined pass reads x and b once and writes x once; the down pass also writes the coarse
+    # right-hand side (and the coarse initial iterate unless the coarse level's own down pass takes it as
+    # zero), the up pass reads the coarse correction; 4 bytes per coarse cell for its slot in the coarse ordering
+    coarse_plane = len(meta["level_rows"]) > 2 and h.level_flags(1)["plane"]
+    plane_down = 3 * w * n + n_c * (w + 4 + (0 if coarse_plane else w))
+    plane_up = 3 * w * n + n_c * (w + 4)
+    csr = {
+        "smoother_set_sweep": sum((w + 4) * z + 4 * (r + 1) + 3 * w * r for r, z in zip(set_rows, set_nnz)) / max(n_sets, 1) + w * n / max(n_sets, 1),
+        "residual": res_csr,
+        "restrict": (w + 4) * n + 4 * (n_c + 1) + w * n + 2 * w * n_c,    # R entries, indptr, r read, b_c + cleared x_c written
+        "prolong_add": (w + 4) * n + 4 * (n + 1) + w * n_c + 2 * w * n,   # P entries, indptr, e read, x read + written
+        "residual_norm": res_csr - w * rows_c,                            # as the residual launch, nothing stored
+        # what the launches a pass replaces move on plain CSR: two set sweeps, the residual, the restriction /
+        # the prolongation, two set sweeps, the norm (SURVEY 8(d) V-cycle model, level 0)
+        "plane_down": 2 * ((w + 4) * nnz / 2 + 4 * (n / 2 + 1) + 3 * w * n / 2 + w * n / 2) + ((w + 4) * nnz + 4 * (n + 1) + 3 * w * n)
+                      + (w + 4) * n + 4 * (n_c + 1) + w * n + 2 * w * n_c,
+        "plane_up": (w + 4) * n + 4 * (n + 1) + w * n_c + 2 * w * n + 2 * ((w + 4) * nnz / 2 + 4 * (n / 2 + 1) + 3 * w * n / 2 + w * n / 2)
+                    + ((w + 4) * nnz + 4 * (n + 1) + 2 * w * n),
+    }
+    fA = [h.format_info(0, "A", s) for s in range(n_sets)]
+    fR, fP = (h.format_info(0, "R"), h.format_info(0, "P")) if n_c else ({"format_bytes": 0}, {"format_bytes": 0})
+    scatter = bool(n_c) and h.level_flags(0)["scatter_prolong"]
+    fmt = {
+        "smoother_set_sweep": sum(f["format_bytes"] + 3 * w * f["rows"] for f in fA) / max(n_sets, 1) + w * n / max(n_sets, 1),
+        "residual": res_fmt,
+        "restrict": fR["format_bytes"] + w * n + 2 * w * n_c,
+        # prolongation: a pass over P = R^T, or (aggregation R, row-pattern coded) a scatter over R's rows
+        "prolong_add": (fR["format_bytes"] if scatter else fP["format_bytes"]) + w * n_c + 2 * w * n,
+        "residual_norm": res_fmt - w * rows_c,
+        "plane_down": plane_down,
+        "plane_up": plane_up,
+    }
+    return fmt, csr
+
+
+def kernel_table(prof, steps, fmt, csr):
+    kernels = {}
+    for name, (cnt, tot) in prof.items():
+        if cnt:
+            us = 1e3 * tot / cnt
+            kernels[name] = {"launches_per_cycle": cnt / steps, "avg_us": round(us, 2),
+                             "bytes_per_launch": int(fmt[name]),
+                             "achieved": round(fmt[name] / us / 1e3, 1),
+                             "frac": round(fmt[name] / us / 1e3 / HBM_PEAK_GBS, 4),
+                             "csr_equiv_GBps": round(csr[name] / us / 1e3, 1)}
+    return kernels
+
+
+def pmc_traffic(name, bytes_per_launch, w):
+    """HBM traffic from the PMC counters cannot be collected from inside this process.  It is taken from a
+    committed rocprofv3 pass of the same launch ONLY when that pass was made with the kernel sources of this
+    build (hash recorded in the profile) on the same problem."""
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", name)))
+        if pmc.get("kernel_src_sha") == kernel_source_hash() and int(pmc["bytes_per_launch"]) == int(bytes_per_launch) and w == 8:
+            return pmc["traffic_bytes"], "NOT measured in this run: rocprofv3 --pmc passes of the same build, " + pmc["source"]
+    except (OSError, KeyError, ValueError):
+        pass
+    return None, None
 
 
 def main():
@@ -171,9 +296,10 @@ def main():
                     help="precision the levels are stored / computed in (f64 = BASELINE configs[2], the default)")
     ap.add_argument("--stencil", default="7pt", choices=["7pt", "27var"],
                     help="multi-GPU leg only: 27var = BASELINE configs[4]'s 27-point variable-coefficient operator")
-    ap.add_argument("--graph", type=int, default=0, help="replay the cycle from a hipGraph")
+    ap.add_argument("--graph", type=int, default=0, help="replay every cycle of the timed regions from a hipGraph")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-plain", action="store_true", help="skip the plain-CSR (OMG_COMPRESS=0) leg")
+    ap.add_argument("--no-sets", action="store_true", help="skip the set-by-set schedule (OMG_PLANE=0) leg")
     ap.add_argument("--no-lex", action="store_true", help="skip the leg with the reference's lexicographic Gauss-Seidel")
     ap.add_argument("--dist", type=int, default=0, help="force the multi-GPU code path even with one rank (debug)")
     ap.add_argument("--watchdog", type=int, default=900, help="multi-GPU: abort after this many seconds")
@@ -182,8 +308,13 @@ def main():
     ap.add_argument("--dist-grids", type=int, default=4,
                     help="multi-GPU: grids handled across ranks (the last of them and all below run replicated)")
     ap.add_argument("--cpu-size", type=int, default=256, help="CPU baseline leg: grid extent (default: the full workload)")
-    ap.add_argument("--cpu-cycles", type=int, default=16)
+    ap.add_argument("--cpu-cycles", type=int, default=4)
     args = ap.parse_args()
+
+    # identity of the sources, resolved BEFORE anything initialises the GPU (no fork from a GPU process) and
+    # handed to the children of a multi-GPU launch
+    os.environ.setdefault("OMG_GIT_HEAD", git_head() or "")
+    src_sha = kernel_source_hash()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # bare `python bench.py --gpus N`: become the launcher.  Nothing GPU-related has been
@@ -208,20 +339,24 @@ def main():
     h.resident_load(b)
     setup_s, generate_s = meta["setup_s"], meta["generate_s"]
     pre = post = 1
+    n, nnz = meta["n"], meta["nnz"]
+    plane = meta["grids"] > 1 and h.level_flags(0)["plane"]
+    meta["plane_levels"] = [h.level_flags(l)["plane"] for l in range(meta["grids"] - 1)]
     if args.graph:
         h.use_graph(True)
 
-    def sync():
-        h.sync()
-        torch.cuda.synchronize()
+    def syncer(hh):
+        def sync():
+            hh.sync()
+            torch.cuda.synchronize()
+        return sync
 
-    # Timed regions.  Only the roofline kernel (fine-grid residual, one launch per cycle) is
-    # bracketed by hipEvents there: every event pair opens a gap in the stream, so timing all
-    # eight level-0 launches would cost the cycle ~4 %.  (A hipGraph replay cannot carry the
-    # events; with --graph 1 the kernel is timed in the second region below.)
-    in_region = not args.graph
-    times, timed, region_norms = timed_regions(h, sync, args.steps, args.warmup, repeats, pre, post,
-                                               ("residual",) if in_region else ())
+    # Timed regions.  Only the roofline kernel (one launch per cycle) is bracketed by hipEvents there:
+    # every event pair opens a gap in the stream.  (A hipGraph replay cannot carry the events; with
+    # --graph 1 the kernel is timed in the second region below.)
+    roof_class = "plane_down" if plane else "residual"
+    times, timed, region_norms = timed_regions(h, syncer(h), args.steps, args.warmup, repeats, pre, post,
+                                               () if args.graph else (roof_class,), graph=bool(args.graph))
     elapsed = statistics.median(times)
     norm = h.resident_cycle(pre, post, want_norm=True)          # untimed: read the norm back once
 
@@ -237,7 +372,6 @@ def main():
     # The metric's "fine-grid SpMV GB/s": plain y = A x over the whole level-0 operator as it
     # sits in HBM for the cycle, 20 back-to-back launches in one hipEvent bracket (untimed region).
     spmv_ms = h.spmv_time(20)
-    n, nnz = meta["n"], meta["nnz"]
     spmv_csr = spmv_bytes(n, nnz, w)
     fmt_all = h.format_info(0, "A")
     spmv_fmt = fmt_all["format_bytes"] + 2 * w * n              # operator in its device format + x read + y written
@@ -247,142 +381,102 @@ def main():
                  "frac": round(spmv_fmt / spmv_ms / 1e6 / HBM_PEAK_GBS, 4),
                  "csr_equiv_bytes": spmv_csr, "csr_equiv_GBps": round(spmv_csr / spmv_ms / 1e6, 1)}
 
-    launches, ms = timed["residual"]
+    fmt_b, csr_b = class_bytes(h, meta, w)
+    kernels = kernel_table(prof, args.steps, fmt_b, csr_b)
+    launches, ms = timed[roof_class]
     avg_s = (ms / launches) * 1e-3
-    # Rows the fine-grid residual launch covers.  With a Gauss-Seidel ordering the last set's
-    # residual comes out of the smoother launch that relaxed it (bit-identical),
-    # so the launch visits the other sets only: the red half for red-black.
-    n_sets = h.level_sets(0)
-    covered = range(n_sets - 1) if h.level_fused(0) else range(n_sets)
-    rows_c = sum(h.set_info(0, s)[0] for s in covered)
-    nnz_c = sum(h.set_info(0, s)[1] for s in covered)
-    # SURVEY 8(d)'s bytes of that launch on plain CSR (w = value width): entries w+4 B, row
-    # pointers 4 B, b and r w B per covered row, the whole of x once
-    res_csr = (w + 4) * nnz_c + 4 * (rows_c + 1) + 2 * w * rows_c + w * n
-    # ... and the bytes the launch HAS TO MOVE with the operator in its device format (lossless
-    # block recoding): same vectors, the operator as it is stored.  The roofline
-    # fraction is taken on these: a launch cannot be credited with bytes it does not read.
-    fmt_sets = [h.format_info(0, "A", s) for s in covered]
-    res_fmt = sum(f["format_bytes"] for f in fmt_sets) + 2 * w * rows_c + w * n
-    fmt_cov = {k: sum(f[k] for f in fmt_sets) for k in ("rows", "nnz", "blocks", "pattern_rows", "coldict_nnz", "valdict_nnz")}
-    # HBM traffic from the PMC counters cannot be collected from inside this process.  It is taken
-    # from a committed rocprofv3 pass of the same launch ONLY when that pass was made with the
-    # kernel sources of this build (hash recorded in the profile) on the same problem.
-    traffic, traffic_src = None, None
-    try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_residual.json")))
-        if pmc.get("kernel_src_sha") == kernel_source_hash() and int(pmc["bytes_per_launch"]) == int(res_fmt) and w == 8:
-            traffic = pmc["traffic_bytes"]
-            traffic_src = "NOT measured in this run: rocprofv3 --pmc passes of the same build, " + pmc["source"]
-    except (OSError, KeyError, ValueError):
-        pass
-    # Per-class table of the level-0 launches (second region): average time, bytes one launch has
-    # to move in the device format, and the CSR-equivalent rate.
-    n_c = meta["level_rows"][1] if len(meta["level_rows"]) > 1 else 0
-    set_rows = [h.set_info(0, s)[0] for s in range(n_sets)]
-    set_nnz = [h.set_info(0, s)[1] for s in range(n_sets)]
-    class_csr = {
-        "smoother_set_sweep": sum((w + 4) * z + 4 * (r + 1) + 3 * w * r for r, z in zip(set_rows, set_nnz)) / max(n_sets, 1) + w * n / max(n_sets, 1),
-        "residual": res_csr,
-        "restrict": (w + 4) * n + 4 * (n_c + 1) + w * n + 2 * w * n_c,    # R entries, indptr, r read, b_c + cleared x_c written
-        "prolong_add": (w + 4) * n + 4 * (n + 1) + w * n_c + 2 * w * n,   # P entries, indptr, e read, x read + written
-        "residual_norm": res_csr - w * rows_c,                            # as the residual launch, nothing stored
-    }
-    fA = [h.format_info(0, "A", s) for s in range(n_sets)]
-    fR, fP = (h.format_info(0, "R"), h.format_info(0, "P")) if n_c else ({"format_bytes": 0}, {"format_bytes": 0})
-    scatter = bool(n_c) and h.level_flags(0)["scatter_prolong"]
-    class_fmt = {
-        "smoother_set_sweep": sum(f["format_bytes"] + 3 * w * f["rows"] for f in fA) / max(n_sets, 1) + w * n / max(n_sets, 1),
-        "residual": res_fmt,
-        "restrict": fR["format_bytes"] + w * n + 2 * w * n_c,
-        # prolongation: a pass over P = R^T, or (aggregation R, row-pattern coded) a scatter over R's rows
-        "prolong_add": (fR["format_bytes"] if scatter else fP["format_bytes"]) + w * n_c + 2 * w * n,
-        "residual_norm": res_fmt - w * rows_c,
-    }
-    kernels = {}
-    for name, (cnt, tot) in prof.items():
-        if cnt:
-            us = 1e3 * tot / cnt
-            kernels[name] = {"launches_per_cycle": cnt / args.steps, "avg_us": round(us, 2),
-                             "bytes_per_launch": int(class_fmt[name]),
-                             "achieved": round(class_fmt[name] / us / 1e3, 1),
-                             "frac": round(class_fmt[name] / us / 1e3 / HBM_PEAK_GBS, 4),
-                             "csr_equiv_GBps": round(class_csr[name] / us / 1e3, 1)}
-    achieved = res_fmt / avg_s / 1e9
-    roofline = {"bound": "hbm", "kernel": "fine grid r = b - A x (%s)" % kernel_name(fmt_cov, "ROW_RESIDUAL", h.level_flags(0)["union_walk"]),
-                "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
-                "bytes_per_launch": res_fmt,
-                "bytes_definition": "operator bytes as stored in HBM (device format, DESIGN.md §4) + b and r of the covered rows + x once",
-                "avg_launch_us": round(avg_s * 1e6, 2), "launches_timed": launches,
-                "csr_equiv_bytes": res_csr, "csr_equiv_GBps": round(res_csr / avg_s / 1e9, 1),
-                "device_format": {"row_pattern_rows": fmt_cov["pattern_rows"], "rows": fmt_cov["rows"],
-                                  "column_coded_nnz": fmt_cov["coldict_nnz"], "value_coded_nnz": fmt_cov["valdict_nnz"],
-                                  "nnz": fmt_cov["nnz"], "OMG_COMPRESS": os.environ.get("OMG_COMPRESS", "15 (default)")},
-                "rows_covered": rows_c, "nnz_covered": nnz_c, "fused_last_set": h.level_fused(0),
-                "level0_kernels": kernels}
+    if plane:
+        # The dominant kernel of the cycle: the plane-pipelined DOWN pass of the fine grid — red-black sweep,
+        # residual and restriction of openmg/__init__.py:201-210 in one launch.  Algorithmic bytes per unit
+        # (DESIGN.md §5): per fine unknown 3 w (x read, b read, x written), per coarse unknown w (its right-hand
+        # side) + 4 (its slot in the coarse ordering).  The operator itself costs nothing: seven coefficients.
+        bytes_roof = fmt_b["plane_down"]
+        traffic, traffic_src = pmc_traffic("r03_pmc_plane_down.json", bytes_roof, w)
+        achieved = bytes_roof / avg_s / 1e9
+        roofline = {"bound": "hbm", "kernel": "plane_kernel<down>: fine-grid red-black sweep + residual + restriction in one launch (plane.hip)",
+                    "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
+                    "bytes_per_launch": int(bytes_roof),
+                    "bytes_definition": "per fine unknown: x read, b read, x written (3 w); per coarse unknown: right-hand side written (w) "
+                                        "+ its slot in the coarse ordering read (4)",
+                    "avg_launch_us": round(avg_s * 1e6, 2), "avg_launch_us_source": "hipEvents on the kernel's own stream inside the timed regions; "
+                                                                                  "rocprofv3's duration of the same kernel: profiles/r03_bench_kernel_stats*.txt",
+                    "launches_timed": launches,
+                    "csr_equiv_bytes": int(csr_b["plane_down"]), "csr_equiv_GBps": round(csr_b["plane_down"] / avg_s / 1e9, 1),
+                    "tiling": h.plane_info(0),
+                    "level0_kernels": kernels}
+    else:
+        rows_c, nnz_c, res_csr, res_fmt, fmt_cov = residual_launch_bytes(h, meta, w)
+        traffic, traffic_src = pmc_traffic("r02_pmc_residual.json", res_fmt, w)
+        achieved = res_fmt / avg_s / 1e9
+        roofline = {"bound": "hbm", "kernel": "fine grid r = b - A x (%s)" % kernel_name(fmt_cov, "ROW_RESIDUAL", h.level_flags(0)["union_walk"]),
+                    "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
+                    "bytes_per_launch": res_fmt,
+                    "bytes_definition": "operator bytes as stored in HBM (device format, DESIGN.md §4) + b and r of the covered rows + x once",
+                    "avg_launch_us": round(avg_s * 1e6, 2), "launches_timed": launches,
+                    "csr_equiv_bytes": res_csr, "csr_equiv_GBps": round(res_csr / avg_s / 1e9, 1),
+                    "device_format": {"row_pattern_rows": fmt_cov["pattern_rows"], "rows": fmt_cov["rows"],
+                                      "column_coded_nnz": fmt_cov["coldict_nnz"], "value_coded_nnz": fmt_cov["valdict_nnz"],
+                                      "nnz": fmt_cov["nnz"], "OMG_COMPRESS": os.environ.get("OMG_COMPRESS", "15 (default)")},
+                    "rows_covered": rows_c, "nnz_covered": nnz_c, "fused_last_set": h.level_fused(0),
+                    "level0_kernels": kernels}
+    h.close()
 
-    # The same problem with every operator as PLAIN int32 CSR (OMG_COMPRESS=0) — what the north
-    # star's "CSR SpMV ... >= 50 % of the HBM roofline on the fine-grid SpMV" describes — timed
-    # with the same loop (same warm-up, steps, repeats, event bracketing).
+    def leg(env, smoother, what, reps, want_spmv):
+        """The same problem and timed loop under other switches."""
+        with env_override(**env):
+            h2, b2, m2 = build_problem(args.size, args.grids, smoother, np_dtype)
+        h2.resident_load(b2)
+        cls = () if smoother != "colour" else ("residual",)
+        t2, p2, n2 = timed_regions(h2, syncer(h2), args.steps, min(args.warmup, 3), reps, pre, post, cls)
+        e2 = statistics.median(t2)
+        out = {"what": what, "vcycles_per_s": round(args.steps / e2, 3), "ms_per_step": round(1e3 * e2 / args.steps, 4),
+               "ms_per_step_all": [round(1e3 * t / args.steps, 4) for t in t2], "hierarchy_s": round(m2["hierarchy_s"], 2)}
+        if cls:
+            rows_c, nnz_c, res_csr, res_fmt, _ = residual_launch_bytes(h2, m2, w)
+            pl, pms = p2["residual"]
+            p_us = 1e3 * pms / pl
+            plain = env.get("OMG_COMPRESS") == "0"
+            nb = res_csr if plain else res_fmt
+            out["residual"] = {"kernel": "rows_kernel<ROW_RESIDUAL>" if plain else "rows_union_kernel<ROW_RESIDUAL>",
+                               "avg_launch_us": round(p_us, 2), "bytes_per_launch": nb, "achieved": round(nb / p_us / 1e3, 1),
+                               "frac": round(nb / p_us / 1e3 / HBM_PEAK_GBS, 4)}
+            if want_spmv:
+                p_spmv_ms = h2.spmv_time(20)
+                out["fine_grid_spmv"] = {"kernel": "rows_kernel<ROW_SPMV>", "avg_launch_us": round(p_spmv_ms * 1e3, 2),
+                                         "bytes_per_launch": spmv_csr, "achieved": round(spmv_csr / p_spmv_ms / 1e6, 1),
+                                         "frac": round(spmv_csr / p_spmv_ms / 1e6 / HBM_PEAK_GBS, 4)}
+        else:
+            out["wavefront_levels"] = [bool(h2.level_flags(l)["march"]) for l in range(m2["grids"] - 1)]
+            out["level_sets_fine_grid"] = h2.level_sets(0)
+            out["norms_last_region_tail"] = n2[-3:]
+        h2.close()
+        return out
+
+    # The set-by-set schedule the plane passes replace (round 2's headline path): eight level-0 launches per cycle.
+    set_path = None
+    if plane and not args.no_sets:
+        set_path = leg({"OMG_PLANE": "0"}, args.smoother,
+                       "same problem and timed loop, set-by-set schedule (OMG_PLANE=0): operators in the lossless device "
+                       "format, eight level-0 launches per cycle; same iterate bit for bit", min(repeats, 3), False)
+    # The same problem with every operator as PLAIN int32 CSR (OMG_COMPRESS=0) walked by the CSR row kernels
+    # (OMG_PLANE=0) — what the north star's "CSR SpMV ... >= 50 % of the HBM roofline on the fine-grid SpMV"
+    # describes — timed with the same loop.
     csr_path = None
     if not args.no_plain and os.environ.get("OMG_COMPRESS", "15") != "0":
-        h.close()
-        keep = os.environ.get("OMG_COMPRESS")
-        os.environ["OMG_COMPRESS"] = "0"
-        try:
-            h2, b2, _ = build_problem(args.size, args.grids, args.smoother, np_dtype)
-        finally:
-            if keep is None:
-                del os.environ["OMG_COMPRESS"]
-            else:
-                os.environ["OMG_COMPRESS"] = keep
-        h2.resident_load(b2)
-
-        def sync2():
-            h2.sync()
-            torch.cuda.synchronize()
-
-        p_times, p_prof, _ = timed_regions(h2, sync2, args.steps, args.warmup, repeats, pre, post, ("residual",))
-        p_elapsed = statistics.median(p_times)
-        pl, pms = p_prof["residual"]
-        p_spmv_ms = h2.spmv_time(20)
-        p_us = 1e3 * pms / pl
-        csr_path = {"what": "same problem and timed loop, every operator held as plain int32 CSR (OMG_COMPRESS=0)",
-                    "vcycles_per_s": round(args.steps / p_elapsed, 3), "ms_per_step": round(1e3 * p_elapsed / args.steps, 4),
-                    "ms_per_step_all": [round(1e3 * t / args.steps, 4) for t in p_times],
-                    "residual": {"kernel": "rows_kernel<ROW_RESIDUAL>", "avg_launch_us": round(p_us, 2),
-                                 "bytes_per_launch": res_csr, "achieved": round(res_csr / p_us / 1e3, 1),
-                                 "frac": round(res_csr / p_us / 1e3 / HBM_PEAK_GBS, 4)},
-                    "fine_grid_spmv": {"kernel": "rows_kernel<ROW_SPMV>", "avg_launch_us": round(p_spmv_ms * 1e3, 2),
-                                       "bytes_per_launch": spmv_csr, "achieved": round(spmv_csr / p_spmv_ms / 1e6, 1),
-                                       "frac": round(spmv_csr / p_spmv_ms / 1e6 / HBM_PEAK_GBS, 4)}}
-        h2.close()
-
+        csr_path = leg({"OMG_COMPRESS": "0", "OMG_PLANE": "0"}, args.smoother,
+                       "same problem and timed loop, every operator held as plain int32 CSR and walked by the CSR row kernels "
+                       "(OMG_COMPRESS=0, OMG_PLANE=0)", repeats, True)
     # The same problem with the reference's OWN smoother — in-place lexicographic Gauss-Seidel
     # (openmg/solvers.py:56-68) — instead of the red-black ordering: same loop, fewer repeats.
     lex_path = None
     if not args.no_lex and args.smoother == "colour":
-        h3, b3, meta3 = build_problem(args.size, args.grids, "gs", np_dtype)
-        h3.resident_load(b3)
+        lex_path = leg({}, "gs",
+                       "same problem and timed loop with the reference's lexicographic Gauss-Seidel (openmg/solvers.py:56-68) "
+                       "as the smoother; grid star stencils run a sweep as one wavefront launch (march.hip, "
+                       "OMG_MARCH=0: one launch per level set), bit-identical either way", min(repeats, 3), False)
 
-        def sync3():
-            h3.sync()
-            torch.cuda.synchronize()
-
-        l_times, _, l_norms = timed_regions(h3, sync3, args.steps, min(args.warmup, 2), min(repeats, 3), pre, post, ())
-        l_elapsed = statistics.median(l_times)
-        lex_path = {"what": "same problem and timed loop with the reference's lexicographic Gauss-Seidel (openmg/solvers.py:56-68) "
-                            "as the smoother; grid star stencils run a sweep as one wavefront launch (march.hip, "
-                            "OMG_MARCH=0: one launch per level set), bit-identical either way",
-                    "vcycles_per_s": round(args.steps / l_elapsed, 3), "ms_per_step": round(1e3 * l_elapsed / args.steps, 4),
-                    "ms_per_step_all": [round(1e3 * t / args.steps, 4) for t in l_times],
-                    "wavefront_levels": [bool(h3.level_flags(l)["march"]) for l in range(meta3["grids"] - 1)],
-                    "level_sets_fine_grid": h3.level_sets(0), "setup_s": round(meta3["setup_s"], 2),
-                    "norms_last_region_tail": l_norms[-3:]}
-        h3.close()
-
-    h.close()
     cpu = None
     if not args.no_cpu:
         rate, dt, cpu_spmv = cpu_baseline(args.cpu_size, args.grids, args.cpu_cycles)
@@ -409,26 +503,35 @@ def main():
         "vs_baseline": None,
         "dtype": args.dtype,
         "data": "synthetic",
+        "value_set_schedule": None if set_path is None else set_path["vcycles_per_s"],
         "value_plain_csr": None if csr_path is None else csr_path["vcycles_per_s"],
         "config": {"workload": "3-D 7-point Poisson %d^3, %d-grid V(1,1) cycle, %s Gauss-Seidel, %s, "
-                               "int32 CSR at the boundary (BASELINE configs[2]%s); `value`: operators in the lossless "
-                               "device format (row patterns), `value_plain_csr`: the same cycle on plain CSR"
+                               "int32 CSR at the boundary (BASELINE configs[2]%s); `value`: %s; `value_plain_csr`: the same "
+                               "cycle on plain CSR"
                                % (args.size, meta["grids"], "red-black" if args.smoother == "colour" else args.smoother,
-                                  "fp64" if w == 8 else "fp32", "" if w == 8 else " run in fp32: NOT the headline configuration"),
+                                  "fp64" if w == 8 else "fp32", "" if w == 8 else " run in fp32: NOT the headline configuration",
+                                  "each half of the cycle over a grid-stencil level is one plane-pipelined launch (plane.hip); "
+                                  "`value_set_schedule`: the same cycle set by set on the lossless device format" if plane else
+                                  "operators in the lossless device format (row patterns)"),
                    "unknowns": n, "nnz": nnz, "grids": meta["grids"], "pre": pre, "post": post,
                    "smoother": args.smoother, "hipgraph": bool(args.graph),
+                   "plane_levels": [bool(f) for f in meta.get("plane_levels", [])],
                    "repeats": repeats, "ms_per_step_all": [round(1e3 * t / args.steps, 4) for t in times],
                    "final_residual_norm": norm,
-                   "norms": "every cycle of a timed region computes its residual norm (all K are returned at the region's "
-                            "end; the red rows' share of cycle k is formed by cycle k+1's first red launch, which computes "
-                            "those residuals anyway - bit-identical, tests/test_gpu_parity.py; OMG_NO_PRENORM=1 gives it a launch of its own)",
+                   "norms": "every cycle of a timed region computes its residual norm (all K are returned at the region's end): "
+                            + ("the up pass of the fine grid leaves the squared residuals of its rows as one partial per workgroup, "
+                               "one launch per 64 cycles adds them up" if plane else
+                               "the red rows' share of cycle k is formed by cycle k+1's first red launch, which computes "
+                               "those residuals anyway - bit-identical, tests/test_gpu_parity.py; OMG_NO_PRENORM=1 gives it a launch of its own"),
                    "norms_last_region_tail": region_norms[-3:],
                    "setup_s": round(setup_s, 2),
-                   "setup_what": "restrictionList + coeffecientList (device Galerkin products) + device hierarchy; "
+                   "setup_what": "restrictionList + coeffecientList (device Galerkin products: rap_s) + device hierarchy (hierarchy_s); "
                                  "generating the synthetic operator and right-hand side on the host took generate_s",
+                   "rap_s": round(meta["rap_s"], 2), "hierarchy_s": round(meta["hierarchy_s"], 2),
                    "generate_s": round(generate_s, 2),
-                   "kernel_src_sha": kernel_source_hash(), "git_head": git_head()},
+                   "kernel_src_sha": src_sha, "git_head": os.environ.get("OMG_GIT_HEAD") or None},
         "roofline": roofline,
+        "set_schedule": set_path,
         "csr_path": csr_path,
         "reference_smoother": lex_path,
         "fine_grid_spmv": fine_spmv,

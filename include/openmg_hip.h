@@ -108,7 +108,17 @@ int omg_hierarchy_level_fused(const omg_hierarchy *h, int level, int *fused);
 #define OMG_LEVEL_SCATTER_PROLONG  2
 #define OMG_LEVEL_UNION_WALK       16  /* every smoother set of A runs rows_union_kernel (several rows per thread) */
 #define OMG_LEVEL_MARCH            32  /* lexicographic Gauss-Seidel runs as one wavefront launch per sweep (march.hip) */
+#define OMG_LEVEL_PLANE            64  /* red-black sweeps of a grid star stencil: each half of a V(>=1, >=1) cycle over this
+                                        * level (openmg/__init__.py:201-210 and :214-227) is ONE plane-pipelined launch (plane.hip) */
 int omg_hierarchy_level_flags(const omg_hierarchy *h, int level, int *flags);
+/* Switch the plane-pipelined passes of a hierarchy off (enable = 0) or back on: the cycle then runs set
+ * by set (same iterate, bit for bit; the norm's partial sums are associated differently).  A/B only.
+ * OMG_PLANE=0 in the environment at creation never builds them.                                      */
+int omg_hierarchy_use_plane(omg_hierarchy *h, int enable);
+/* Tiling of a level's plane-pipelined passes: out[8] = cells per line, lines per plane, planes, a
+ * workgroup's interior cells in x / lines / planes, workgroups, threads per workgroup (all 0 when the
+ * level has none).                                                                                   */
+int omg_hierarchy_plane_info(const omg_hierarchy *h, int level, int64_t *out8);
 /* Rows and stored entries of one smoother set (for byte accounting of per-set launches). */
 int omg_hierarchy_set_info(const omg_hierarchy *h, int level, int set, int64_t *rows, int64_t *nnz);
 /* How an operator of level l sits in HBM (csrc/common.h "Block-dictionary coding": the device
@@ -167,12 +177,14 @@ int omg_resident_spmv_time(omg_hierarchy *h, int reps, double *avg_ms);
 int omg_resident_use_graph(omg_hierarchy *h, int enable);
 
 /* Per-kernel timing of level-0 launches with hipEvents on the hierarchy's stream.
- * Classes: 0 smoother set-sweep, 1 residual, 2 restrict, 3 prolong-add, 4 residual+norm.
+ * Classes: 0 smoother set-sweep, 1 residual, 2 restrict, 3 prolong-add, 4 residual+norm,
+ * 5 plane-pipelined down pass (sweep + residual + restriction), 6 plane-pipelined up pass
+ * (prolongation + sweep + norm).
  * omg_profile_enable(h, mask): bit c of mask switches class c on (-1 = all, 0 = off) and
  * clears the totals; each timed launch costs two hipEventRecords (~10 us of stream gap), so
  * bench.py times only class 1 inside its timed region.  omg_profile_read syncs and returns,
  * per class, launches and total milliseconds since the last omg_profile_enable.           */
-#define OMG_PROFILE_CLASSES 5
+#define OMG_PROFILE_CLASSES 7
 int omg_profile_enable(omg_hierarchy *h, int mask);
 int omg_profile_read(omg_hierarchy *h, int64_t *launches, double *total_ms);
 

@@ -15,8 +15,8 @@ LIB_PATH = os.environ.get("OMG_LIB_PATH") or os.path.join(_HERE, "lib", "libopen
 OMG_OK = 0
 ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_SINGULAR, ERR_NO_DIAGONAL, ERR_ALLOC, ERR_UNSUPPORTED = range(1, 8)
 SMOOTH_GS_LEX, SMOOTH_GS_COLOUR, SMOOTH_JACOBI = 0, 1, 2
-PROFILE_CLASSES = 5
-PROFILE_NAMES = ("smoother_set_sweep", "residual", "restrict", "prolong_add", "residual_norm")
+PROFILE_CLASSES = 7
+PROFILE_NAMES = ("smoother_set_sweep", "residual", "restrict", "prolong_add", "residual_norm", "plane_down", "plane_up")
 
 SMOOTHERS = {
     "gs": SMOOTH_GS_LEX, "lex": SMOOTH_GS_LEX, "gauss-seidel": SMOOTH_GS_LEX, "gaussSeidel": SMOOTH_GS_LEX,
@@ -66,6 +66,8 @@ SIGNATURES = {
     "omg_hierarchy_set_info": (_I, [_P, _I, _I, _I64P, _I64P]),
     "omg_hierarchy_level_fused": (_I, [_P, _I, _IP]),
     "omg_hierarchy_level_flags": (_I, [_P, _I, _IP]),
+    "omg_hierarchy_use_plane": (_I, [_P, _I]),
+    "omg_hierarchy_plane_info": (_I, [_P, _I, _I64P]),
     "omg_hierarchy_format_info": (_I, [_P, _I, _I, _I, _I64P]),
     "omg_format_selftest": (_I, [_CSR, _I, _I64P]),
     "omg_vcycle": (_I, [_P, _I, _P, _P, _I, _I, _DP]),
@@ -334,11 +336,22 @@ class Hierarchy:
         return bool(v.value)
 
     def level_flags(self, level):
-        """dict(fused_last_set=bool, scatter_prolong=bool, union_walk=bool, march=bool) of a smoothed level."""
+        """dict(fused_last_set=bool, scatter_prolong=bool, union_walk=bool, march=bool, plane=bool) of a smoothed level."""
         f = ctypes.c_int(0)
         check(lib().omg_hierarchy_level_flags(self._h, int(level), ctypes.byref(f)))
         return {"fused_last_set": bool(f.value & 1), "scatter_prolong": bool(f.value & 2), "union_walk": bool(f.value & 16),
-                "march": bool(f.value & 32)}
+                "march": bool(f.value & 32), "plane": bool(f.value & 64)}
+
+    def use_plane(self, enable=True):
+        """Plane-pipelined passes on / off (omg_hierarchy_use_plane; same iterate either way)."""
+        check(lib().omg_hierarchy_use_plane(self._h, 1 if enable else 0))
+
+    PLANE_FIELDS = ("nx", "ny", "nz", "tile_x", "tile_y", "tile_z", "workgroups", "threads")
+
+    def plane_info(self, level):
+        out = (ctypes.c_int64 * len(self.PLANE_FIELDS))()
+        check(lib().omg_hierarchy_plane_info(self._h, int(level), out))
+        return dict(zip(self.PLANE_FIELDS, [int(v) for v in out]))
 
     def set_info(self, level, s):
         """(rows, stored entries) of smoother set `s` of a level."""

@@ -455,4 +455,52 @@ struct MarchPlan {
     bool timed_out(hipStream_t s) const;                 // (synchronises) some sweep gave up waiting for a face
 };
 
+// ---- plane-pipelined red-black passes of grid stencils (plane.hip) -----------------------------
+// A V(1,1) cycle over a red-black ordered level streams x and b through HBM eight times (red
+// sweep, black sweep + residual, red residual, restriction; prolongation, red, black + norm, red
+// norm).  Where the level is a constant-coefficient star stencil on a lexicographically numbered
+// grid (boundary rows drop the entries whose neighbour does not exist; read off the CSR itself) and
+// the restriction is the 2x2x2 aggregation of openmg/operators.py:73-84, the two halves of the
+// cycle run as ONE launch each:
+//   down:  x_new = RB-sweep(x_old),  b_c = R (b - A x_new)  (+ the coarse level's first relaxation)
+//   up:    x_new = RB-sweep(x_old + R^T e),  block partials of ||b - A x_new||^2
+// A workgroup owns an (x, y) tile with an overlapped ring and marches in z over a chunk of planes:
+// red on plane s, black on plane s-1, the residual of plane s-2 and the restriction of finished
+// plane pairs, out of place (x_old is only read, x_new only written), every value a row needs from
+// its own column in registers, from its in-plane neighbours through LDS.  A row is the same fma
+// chain in stored (= slot) order as in the row kernels — an absent neighbour is 0 * c, which leaves
+// the chain as it is — and the same division, so the iterate has the bits of the set-by-set
+// schedule (tests/test_gpu_plane.py; OMG_PLANE=0 switches the path off).
+struct PlaneGeom {
+    int nx = 0, ny = 0, nz = 0;       // cells per line, lines per plane, planes (all even)
+    int hx = 0;                       // cells of one colour per line = nx / 2
+    int TX = 0, TY = 0, LZ = 0;       // a workgroup's interior: cells in x (multiple of 4), lines (even), planes (even)
+    int PX = 0, PY = 0;               // its threads: TX / 4 + 2 (four cells each) x TY / 2 + 4 (two lines each)
+    int ntx = 0, nty = 0, ntz = 0, n_wg = 0;
+    int threads = 0;                  // PX * PY rounded up to whole waves
+    size_t lds_bytes = 0;
+    double c[7] = {0, 0, 0, 0, 0, 0, 0};   // -K, -J, -I, diagonal, +I, +J, +K
+    double w = 0.0;                   // the restriction's weight
+};
+template <typename V>
+struct PlanePlan {
+    PlaneGeom g;
+    DevBuf<double> partials;          // one per workgroup (+ SUM_FOLD): the up pass's share of ||b - A x||^2
+    // false: the level does not qualify (the caller keeps the set-by-set schedule).  A, R: the
+    // caller's CSR in natural numbering; ord: the level's colour ordering (must be the parity one).
+    bool build(const omg_csr &A, const omg_csr &R, const Ordering &ord);
+    struct Coarse {
+        const int32_t *map = nullptr; // coarse natural index -> slot in the coarse ordering (null: identity)
+        V *b = nullptr;               // down: coarse right-hand side
+        V *x = nullptr;               // down: coarse initial iterate (null: not written)
+        const V *diag = nullptr;      // down: first relaxation of the coarse zero iterate for slots < first_end (null: zeros)
+        int first_end = 0;
+        const V *e = nullptr;         // up: coarse correction
+    };
+    // x_zero: x_old is known to be zero and is not read
+    void down(const V *x_old, V *x_new, const V *b, bool x_zero, const Coarse &c, hipStream_t s) const;
+    // out (nullable): block partials of the squared residual norm, g.n_wg doubles
+    void up(const V *x_old, V *x_new, const V *b, const Coarse &c, double *out, hipStream_t s) const;
+};
+
 }  // namespace omg

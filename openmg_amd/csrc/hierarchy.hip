@@ -65,6 +65,10 @@ struct Level {
     // lexicographic Gauss-Seidel of a grid star stencil: one launch per sweep (common.h MarchPlan);
     // the level then keeps its natural ordering (one "set") for every other kernel
     std::unique_ptr<MarchPlan<V>> march;
+    // red-black sweeps of a constant-coefficient grid star stencil under the 2x2x2 aggregation: each half
+    // of a V(pre >= 1, post >= 1) cycle is one plane-pipelined launch (common.h PlanePlan), out of place
+    // between x and tmp
+    std::unique_ptr<PlanePlan<V>> plane;
 };
 
 struct ProfEvent {
@@ -88,6 +92,8 @@ struct Hier {
     // OMG_NO_FUSE=1: never fuse the last smoother set with the residual / norm (A/B switch;
     // results are bit-identical either way, tests/test_gpu_parity.py checks that)
     bool no_fuse = [] { const char *e = getenv("OMG_NO_FUSE"); return e && e[0] == '1'; }();
+    // OMG_PLANE=0 (at creation): no plane-pipelined passes; set by omg_hierarchy_use_plane afterwards
+    bool no_plane = false;
     // graph
     bool want_graph = false;
     hipGraphExec_t gexec = nullptr;
@@ -353,33 +359,120 @@ void coarse_solve_level(Hier<V> *h) {
     h->coarse.solve(L.b.p, L.xp, h->stream);
 }
 
+// What a cycle leaves of the entry level's residual norm (openmg/__init__.py:227)
+enum NormState { NORM_NONE = 0, NORM_LAST_SET = 1, NORM_PLANE = 2 };
+
+// Do both halves of a cycle over this level run as plane-pipelined launches?
+template <typename V>
+bool use_plane(const Hier<V> *h, const Level<V> &L, int pre, int post) {
+    return L.plane && pre >= 1 && post >= 1 && !h->no_plane;
+}
+
 // openmg/__init__.py:199-234 with the dead work removed: R[l]*b (:205-206) is computed by the
 // reference only for its length, and the norm at levels > entry (:227) is discarded by the
 // caller (:213 takes [0]); neither changes any returned value.
 //
-// want_norm: the caller will ask for ||b - A x|| of THIS level right after the cycle; the
-// post-smoother's last set launch then also leaves that set's share of the norm in the block
-// partials.  Returns true when it did (norm_level(..., last_set_done = true) finishes it).
+// want_norm: the caller will ask for ||b - A x|| of THIS level right after the cycle.  Returns what
+// is already there of it: NORM_LAST_SET — the post-smoother's last set launch has left that set's
+// share in the block partials (norm_level(..., last_set_done = true) finishes it); NORM_PLANE — the
+// plane-pipelined up pass has left ALL of it in its workgroup partials (post_slot, or the plan's own
+// array: finish_plane_norm).
+// x_zero: the level's iterate is zero and has not been written (plane levels only).
 template <typename V>
-bool cycle_body(Hier<V> *h, int l, int pre, int post, bool want_norm = false, double *pre_slot = nullptr,
-                bool first_done = false, double *post_slot = nullptr) {
+int cycle_body(Hier<V> *h, int l, int pre, int post, bool want_norm = false, double *pre_slot = nullptr,
+               bool first_done = false, double *post_slot = nullptr, bool x_zero = false) {
     const int last = (int)h->lv.size() - 1;
     if (l >= last) {
         coarse_solve_level(h);
-        return false;
+        return NORM_NONE;
     }
     Level<V> &L = h->lv[l];
     Level<V> &C = h->lv[l + 1];
+    // OMG_PLANE_HALVES=1|2 (debugging, not under hipGraph): only the down / only the up pass plane-pipelined
+    static const int halves = [] { const char *e = getenv("OMG_PLANE_HALVES"); return (e && (e[0] == '1' || e[0] == '2')) ? e[0] - '0' : 3; }();
+    if (use_plane(h, L, pre, post) && halves == 2 && !x_zero) {
+        const bool res_done = smooth_level(h, l, pre, FUSE_RESIDUAL, nullptr, first_done);
+        residual_level(h, l, L.r.p, res_done);
+        const bool child_first = l + 1 < last && first_sweep_in_restrict(h, C, pre);
+        restrict_level<V>(h, l, L.r.p, C.b.p, l + 1 < last ? C.xp : nullptr, child_first);
+        cycle_body(h, l + 1, pre, post, false, nullptr, child_first);
+        typename PlanePlan<V>::Coarse c;
+        c.map = L.r_out.p;
+        c.e = C.xp;
+        double *out = (want_norm && post == 1) ? (post_slot ? post_slot : L.plane->partials.p) : nullptr;
+        L.plane->up(L.xp, L.tp, L.b.p, c, out, h->stream);
+        std::swap(L.xp, L.tp);
+        if (post > 1)
+            return smooth_level(h, l, post - 1, want_norm ? FUSE_NORM : FUSE_NONE, nullptr, false, post_slot) ? NORM_LAST_SET : NORM_NONE;
+        return out ? NORM_PLANE : NORM_NONE;
+    }
+    if (use_plane(h, L, pre, post) && halves == 1) {
+        if (pre > 1) smooth_level(h, l, pre - 1, FUSE_NONE, nullptr, first_done);
+        const bool child_first = l + 1 < last && first_sweep_in_restrict(h, C, pre);
+        typename PlanePlan<V>::Coarse c;
+        c.map = L.r_out.p;
+        c.b = C.b.p;
+        c.x = l + 1 < last ? C.xp : nullptr;
+        c.diag = child_first ? C.diag.p : nullptr;
+        c.first_end = child_first ? int(C.A.sets[1]) : 0;
+        L.plane->down(L.xp, L.tp, L.b.p, x_zero, c, h->stream);
+        std::swap(L.xp, L.tp);
+        cycle_body(h, l + 1, pre, post, false, nullptr, child_first);
+        prolong_add_level<V>(h, l, C.xp, L.xp);
+        return smooth_level(h, l, post, want_norm ? FUSE_NORM : FUSE_NONE, nullptr, false, post_slot) ? NORM_LAST_SET : NORM_NONE;
+    }
+    if (use_plane(h, L, pre, post)) {
+        // :201 all but the last pre-smoothing sweep set by set (in place); the last one inside the down pass
+        if (pre > 1) smooth_level(h, l, pre - 1, FUSE_NONE, nullptr, first_done);
+        const bool child_plane = l + 1 < last && use_plane(h, C, pre, post);
+        const bool child_zero = child_plane && pre == 1 && halves == 3;       // the child's down pass never reads its zero iterate
+        const bool child_first = l + 1 < last && !child_zero && first_sweep_in_restrict(h, C, pre);
+        typename PlanePlan<V>::Coarse c;
+        c.map = L.r_out.p;
+        c.b = C.b.p;
+        c.x = (l + 1 < last && !child_zero) ? C.xp : nullptr;
+        c.diag = child_first ? C.diag.p : nullptr;
+        c.first_end = child_first ? int(C.A.sets[1]) : 0;
+        {
+            Prof<V> p(h, l, 5);
+            L.plane->down(L.xp, L.tp, L.b.p, x_zero, c, h->stream);      // :201 (last sweep), :209, :210
+        }
+        std::swap(L.xp, L.tp);
+        cycle_body(h, l + 1, pre, post, false, nullptr, child_first, nullptr, child_zero);   // :213
+        c.e = C.xp;
+        double *out = (want_norm && post == 1) ? (post_slot ? post_slot : L.plane->partials.p) : nullptr;
+        {
+            Prof<V> p(h, l, 6);
+            L.plane->up(L.xp, L.tp, L.b.p, c, out, h->stream);           // :214, :220/:224, first sweep of :216-222 (, :227)
+        }
+        std::swap(L.xp, L.tp);
+        if (post > 1)
+            return smooth_level(h, l, post - 1, want_norm ? FUSE_NORM : FUSE_NONE, nullptr, false, post_slot) ? NORM_LAST_SET : NORM_NONE;
+        return out ? NORM_PLANE : NORM_NONE;
+    }
     const bool res_done = smooth_level(h, l, pre, FUSE_RESIDUAL, pre_slot, first_done);   // :201 (+ last set's share of :209)
     residual_level(h, l, L.r.p, res_done);                          // :209
     // :210, and the coarse cycle's initial=None -> zeros (:191-192) cleared by the same launch —
     // or already relaxed once (first_sweep_in_restrict)
-    const bool child_first = l + 1 < last && first_sweep_in_restrict(h, C, pre);
-    restrict_level<V>(h, l, L.r.p, C.b.p, l + 1 < last ? C.xp : nullptr, child_first);
-    cycle_body(h, l + 1, pre, post, false, nullptr, child_first);   // :213
+    const bool child_zero = l + 1 < last && use_plane(h, C, pre, post) && pre == 1 && halves == 3;
+    const bool child_first = l + 1 < last && !child_zero && first_sweep_in_restrict(h, C, pre);
+    restrict_level<V>(h, l, L.r.p, C.b.p, (l + 1 < last && !child_zero) ? C.xp : nullptr, child_first);
+    cycle_body(h, l + 1, pre, post, false, nullptr, child_first, nullptr, child_zero);   // :213
     prolong_add_level<V>(h, l, C.xp, L.xp);                         // :214, :220/:224
-    if (post > 0) return smooth_level(h, l, post, want_norm ? FUSE_NORM : FUSE_NONE, nullptr, false, post_slot);   // :216-222
-    return false;
+    if (post > 0)
+        return smooth_level(h, l, post, want_norm ? FUSE_NORM : FUSE_NONE, nullptr, false, post_slot) ? NORM_LAST_SET : NORM_NONE;   // :216-222
+    return NORM_NONE;
+}
+
+// ||b - A x|| of level l into out (device scalar; null: h->norm_dev) after a cycle that returned `state`
+template <typename V>
+void finish_norm(Hier<V> *h, int l, int state, double *out = nullptr) {
+    if (state == NORM_PLANE) {
+        Level<V> &L = h->lv[l];
+        launch_sum_sqrt(L.plane->partials.p, L.plane->g.n_wg, out ? out : h->norm_dev.p, h->stream);
+    } else {
+        norm_level<V>(h, l, nullptr, state == NORM_LAST_SET, out);
+    }
 }
 
 // Host vectors are double for either V.  A double level in its natural ordering copies
@@ -450,8 +543,8 @@ template <typename V>
 void run_cycle0(Hier<V> *h, int pre, int post) {
     const bool single = h->lv.size() == 1;
     auto body = [&]() {
-        const bool part = cycle_body(h, 0, pre, post, !single);
-        if (!single) norm_level<V>(h, 0, nullptr, part);      // :227
+        const int part = cycle_body(h, 0, pre, post, !single);
+        if (!single) finish_norm(h, 0, part);                 // :227
         else OMG_HIP(hipMemsetAsync(h->norm_dev.p, 0, sizeof(double), h->stream));   // :232
     };
     if (!h->want_graph || h->profiling) {
@@ -557,6 +650,11 @@ std::unique_ptr<Hier<V>> create(int n_levels, const omg_csr *A, const omg_csr *R
         L.n = A[l].n_rows;
         SetupTimer tm("ordering (colouring / level schedule / wavefront plan)");
         order_level(L, A[l], smoother, h->stream);
+        if (smoother == OMG_SMOOTH_GS_COLOUR) {
+            SetupTimer tp("plane-pipelined passes: does the level qualify");
+            std::unique_ptr<PlanePlan<V>> plan(new PlanePlan<V>);
+            if (plan->build(A[l], R[l], L.ord)) L.plane = std::move(plan);
+        }
     }
     for (int l = 0; l < n_levels; ++l) {
         Lv &L = h->lv[l];
@@ -620,7 +718,7 @@ std::unique_ptr<Hier<V>> create(int n_levels, const omg_csr *A, const omg_csr *R
                 L.P.upload(Pt, {}, h->stream);
             }
             L.r.alloc(L.n);
-            if (smoother == OMG_SMOOTH_JACOBI) L.tmp.alloc(L.n);
+            if (smoother == OMG_SMOOTH_JACOBI || L.plane) L.tmp.alloc(L.n);
             L.partials.alloc(L.A.n_blocks() + SUM_FOLD);
             build_plan(L);
         }
@@ -783,7 +881,33 @@ int omg_hierarchy_level_flags(const omg_hierarchy *h, int level, int *flags) {
             *flags = ((smoothed && can_fuse(hh, hh->lv[level])) ? OMG_LEVEL_FUSED_LAST_SET : 0) |
                      ((smoothed && hh->lv[level].scatter_prolong) ? OMG_LEVEL_SCATTER_PROLONG : 0) |
                      ((smoothed && hh->lv[level].A.all_union()) ? OMG_LEVEL_UNION_WALK : 0) |
-                     ((smoothed && hh->lv[level].march) ? OMG_LEVEL_MARCH : 0);
+                     ((smoothed && hh->lv[level].march) ? OMG_LEVEL_MARCH : 0) |
+                     ((smoothed && hh->lv[level].plane && !hh->no_plane) ? OMG_LEVEL_PLANE : 0);
+        });
+    });
+}
+
+int omg_hierarchy_use_plane(omg_hierarchy *h, int enable) {
+    return guarded([&] {
+        with(h, [&](auto *hh) {
+            OMG_HIP(hipStreamSynchronize(hh->stream));
+            drop_graph(hh);
+            hh->no_plane = enable == 0;
+        });
+    });
+}
+
+int omg_hierarchy_plane_info(const omg_hierarchy *h, int level, int64_t *out8) {
+    return guarded([&] {
+        with(h, [&](auto *hh) {
+            check_level(hh, level);
+            OMG_REQUIRE(out8, "null");
+            for (int i = 0; i < 8; ++i) out8[i] = 0;
+            const auto &L = hh->lv[level];
+            if (!L.plane) return;
+            const PlaneGeom &g = L.plane->g;
+            const int64_t v[8] = {g.nx, g.ny, g.nz, g.TX, g.TY, g.LZ, g.n_wg, g.threads};
+            for (int i = 0; i < 8; ++i) out8[i] = v[i];
         });
     });
 }
@@ -835,10 +959,10 @@ int omg_vcycle(omg_hierarchy *h, int level, const double *b, double *x, int pre,
             load_vec(hh, level, b, L.b.p);
             load_vec(hh, level, x, L.xp);
             const int last = (int)hh->lv.size() - 1;
-            const bool part = cycle_body(hh, level, pre, post, level < last);
+            const int part = cycle_body(hh, level, pre, post, level < last);
             double nv = 0.0;
             if (level < last) {
-                norm_level<V>(hh, level, nullptr, part);
+                finish_norm(hh, level, part);
                 nv = read_norm(hh);
             }
             fetch_vec<V>(hh, level, L.xp, x);
@@ -866,22 +990,25 @@ int omg_hierarchy_cycle_dev(omg_hierarchy *h, const double *b_dev, double *x_dev
                 const int32_t *perm = L.ord.identity ? nullptr : L.perm.p;
                 if (direct_io(L)) OMG_HIP(hipMemcpyAsync(L.b.p, b_dev, L.n * sizeof(double), hipMemcpyDeviceToDevice, hh->stream));
                 else launch_gather<double, V>(b_dev, perm, L.b.p, L.n, hh->stream);
-                bool first = false;
+                bool first = false, zero_in = false;
                 if (hh->lv.size() > 1) {
                     // x starts from zero: the first relaxation launch is a pointwise b / diag (restrict_level)
                     if (!L.diag.p && pre > 0 && !getenv_flag("OMG_NO_FIRST_SWEEP")) {
                         L.diag.alloc(std::max<int64_t>(L.n, 1));
                         launch_diagonal(L.A, L.diag.p, hh->stream);
                     }
-                    first = first_sweep_in_restrict(hh, L, pre);
-                    if (first) {
+                    zero_in = use_plane(hh, L, pre, post) && pre == 1;     // the down pass does not read a zero iterate
+                    first = !zero_in && first_sweep_in_restrict(hh, L, pre);
+                    if (zero_in) {
+                        // nothing to write
+                    } else if (first) {
                         const bool jac = hh->smoother == OMG_SMOOTH_JACOBI;
                         launch_first_relaxation<V>(L.b.p, L.diag.p, L.xp, L.n, jac ? L.n : L.A.sets[1], jac, hh->omega, hh->stream);
                     } else {
                         OMG_HIP(hipMemsetAsync(L.xp, 0, L.n * sizeof(V), hh->stream));
                     }
                 }
-                cycle_body(hh, 0, pre, post, false, nullptr, first);
+                cycle_body(hh, 0, pre, post, false, nullptr, first, nullptr, zero_in);
                 if (direct_io(L)) OMG_HIP(hipMemcpyAsync(x_dev, L.xp, L.n * sizeof(double), hipMemcpyDeviceToDevice, hh->stream));
                 else launch_scatter<V, double>(L.xp, perm, x_dev, L.n, hh->stream);
             } catch (...) {
@@ -928,14 +1055,35 @@ int omg_resident_cycle(omg_hierarchy *h, int pre, int post, double *norm) {
 int omg_resident_cycles(omg_hierarchy *h, int pre, int post, int n_cycles, double *norms) {
     return guarded([&] {
         with(h, [&](auto *hh) {
-            using V = value_of<decltype(hh)>;
             check_level(hh, 0);
             OMG_REQUIRE(hh->resident, "omg_resident_load has not been called");
             OMG_REQUIRE(pre >= 0 && post >= 0 && n_cycles >= 0, "negative argument");
             if (n_cycles == 0) return;
             if (hh->norms_dev.n < size_t(n_cycles)) hh->norms_dev.alloc(size_t(n_cycles));
             const bool single = hh->lv.size() == 1;
-            const bool defer = !single && !getenv_flag("OMG_NO_PRENORM") && can_prenorm(hh, hh->lv[0], pre, post);
+            if (!single && use_plane(hh, hh->lv[0], pre, post) && post == 1) {
+                // every cycle's up pass leaves its workgroup partials in a slot of the batch buffer; one
+                // launch per chunk adds the slots up (the additions of launch_sum_sqrt: same bits as
+                // omg_resident_cycle)
+                constexpr int CHUNK = 64;
+                const int64_t nb = hh->lv[0].plane->g.n_wg;
+                if (hh->batch_partials.n < size_t(CHUNK) * size_t(nb)) hh->batch_partials.alloc(size_t(CHUNK) * size_t(nb));
+                for (int k0 = 0; k0 < n_cycles; k0 += CHUNK) {
+                    const int cnt = std::min(CHUNK, n_cycles - k0);
+                    for (int j = 0; j < cnt; ++j) {
+                        const int st = cycle_body(hh, 0, pre, post, true, nullptr, false, hh->batch_partials.p + size_t(j) * size_t(nb));
+                        OMG_REQUIRE(st == NORM_PLANE, "internal: plane-pipelined cycle without its norm partials");
+                    }
+                    launch_sum_batch(hh->batch_partials.p, nb, nb, cnt, hh->norms_dev.p + k0, true, hh->stream);
+                }
+                if (norms) OMG_HIP(hipMemcpyAsync(norms, hh->norms_dev.p, size_t(n_cycles) * sizeof(double), hipMemcpyDeviceToHost, hh->stream));
+                OMG_HIP(hipStreamSynchronize(hh->stream));
+                check_march(hh);
+                return;
+            }
+            // (a plane-pipelined cycle with post > 1 ends set by set: its first launch is no PRENORM launch)
+            const bool defer = !single && !getenv_flag("OMG_NO_PRENORM") && can_prenorm(hh, hh->lv[0], pre, post) &&
+                               !use_plane(hh, hh->lv[0], pre, post);
             // Deferred norms: cycle k's block partials are collected in slot k of a batch buffer — the
             // last set's by its fused post-smoothing launch, the first set's by cycle k + 1's first
             // launch — and ALL slots of a chunk are added up by one launch at the chunk's end (the
@@ -956,9 +1104,9 @@ int omg_resident_cycles(omg_hierarchy *h, int pre, int post, int n_cycles, doubl
                     const bool last_of_chunk = j + 1 == cnt;
                     double *slot_prev = (defer && j > 0) ? hh->batch_partials.p + size_t(j - 1) * size_t(nb) : nullptr;
                     double *slot_this = (defer && !last_of_chunk) ? hh->batch_partials.p + size_t(j) * size_t(nb) : nullptr;
-                    const bool part = cycle_body(hh, 0, pre, post, true, slot_prev, false, slot_this);
+                    const int part = cycle_body(hh, 0, pre, post, true, slot_prev, false, slot_this);
                     if (!defer || last_of_chunk) {
-                        norm_level<V>(hh, 0, nullptr, part, hh->norms_dev.p + k);                      // :227
+                        finish_norm(hh, 0, part, hh->norms_dev.p + k);                                 // :227
                     } else {
                         OMG_REQUIRE(part || hh->smoother == OMG_SMOOTH_JACOBI, "internal: deferred norm without the fused post-smoothing launch");
                     }
@@ -968,6 +1116,7 @@ int omg_resident_cycles(omg_hierarchy *h, int pre, int post, int n_cycles, doubl
             }
             if (norms) OMG_HIP(hipMemcpyAsync(norms, hh->norms_dev.p, size_t(n_cycles) * sizeof(double), hipMemcpyDeviceToHost, hh->stream));
             OMG_HIP(hipStreamSynchronize(hh->stream));
+            check_march(hh);       // (the batched entry returned norms of a sweep that had given up)
         });
     });
 }

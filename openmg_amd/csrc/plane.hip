@@ -1,0 +1,691 @@
+// Plane-pipelined red-black passes of grid star stencils (common.h PlanePlan) — gfx950 only.
+//
+// The two halves of a V(1,1) cycle over a red-black ordered level (openmg/__init__.py:201-227) as
+// ONE launch each.  Level vectors are in the colour ordering the set-by-set kernels use: the red
+// cells ((i + j + k) even) in natural order, then the black ones, so a grid line (j, k) of nx cells
+// is two runs of hx = nx / 2 values — its reds at [(k ny + j) hx, +hx) and its blacks nr further —
+// and in that "half-index" space the seven-point stencil is regular: a cell h of one colour has its
+// four j / k neighbours at the SAME h of the other colour's run of the neighbouring line, and its
+// two i neighbours at h - 1 + p, h + p (red) or h - p, h + 1 - p (black), p = (j + k) & 1.
+//
+// A thread owns four consecutive cells of two adjacent lines — per line one pair (h = 2q, 2q + 1)
+// of either colour, 16-byte accesses throughout — and keeps every plane it still needs of them in
+// registers while the workgroup marches in z.  Step s:
+//     B  red   sweep of plane s      (black: old values of planes s-1, s, s+1)
+//     C  black sweep of plane s-1    (red: new values of s-2, s-1, s), and that row's residual
+//     D  red residual of plane s-2   (black: new values of s-3, s-2, s-1)
+//     restriction of a finished pair of planes (down) / squares for the norm (up)
+// Values of the neighbouring lines and of the neighbouring threads' cells come from three LDS
+// images written at the end of the previous step (double buffered: one barrier per step).  The
+// (x, y) tile carries a ring that is relaxed redundantly — red two cells deep, black one — so no
+// workgroup waits for another; everything is out of place (x_old read, x_new written by the owner).
+// All global traffic of a step is issued at its top (the loads the NEXT step consumes, the stores
+// of what the previous step finished), so the one wait per step finds them done.
+#include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <cstring>
+#include <thread>
+
+#include "common.h"
+
+namespace omg {
+namespace {
+
+typedef unsigned v2u __attribute__((ext_vector_type(2)));
+typedef unsigned v4u __attribute__((ext_vector_type(4)));
+typedef int v2i __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ double madd(double v, double x, double acc) { return fma(v, x, acc); }
+__device__ __forceinline__ float madd(float v, float x, float acc) { return fmaf(v, x, acc); }
+
+template <typename V>
+struct P2 {
+    V x, y;
+};
+template <typename V> struct VecOf;
+template <> struct VecOf<double> {
+    typedef double type __attribute__((ext_vector_type(2)));
+    typedef type gtype __attribute__((aligned(8)));       // global: aligned like one element
+};
+template <> struct VecOf<float> {
+    typedef float type __attribute__((ext_vector_type(2)));
+    typedef type gtype __attribute__((aligned(4)));
+};
+
+__device__ __forceinline__ P2<double> bload2(__amdgpu_buffer_rsrc_t rs, int off, double) {
+    const v4u q = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0);
+    return {__builtin_bit_cast(double, v2u{q.x, q.y}), __builtin_bit_cast(double, v2u{q.z, q.w})};
+}
+__device__ __forceinline__ P2<float> bload2(__amdgpu_buffer_rsrc_t rs, int off, float) {
+    // (the whole vector is cast: hipcc 7.2 turns __builtin_bit_cast(float, q.y) of a vector ELEMENT into
+    // element 0 and narrows the load to one dword)
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    const v2f q = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(rs, off, 0, 0));
+    return {q.x, q.y};
+}
+__device__ __forceinline__ double bload1(__amdgpu_buffer_rsrc_t rs, int off, double) {
+    return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs, off, 0, 0));
+}
+__device__ __forceinline__ float bload1(__amdgpu_buffer_rsrc_t rs, int off, float) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, off, 0, 0));
+}
+template <typename V>
+__device__ __forceinline__ P2<V> lds_pair(const V *p) {
+    const typename VecOf<V>::type q = *reinterpret_cast<const typename VecOf<V>::type *>(p);
+    return {q.x, q.y};
+}
+template <typename V>
+__device__ __forceinline__ void lds_put(V *p, const P2<V> &v) {
+    typename VecOf<V>::type q;
+    q.x = v.x;
+    q.y = v.y;
+    *reinterpret_cast<typename VecOf<V>::type *>(p) = q;
+}
+template <typename V>
+__device__ __forceinline__ void store2(V *p, const P2<V> &v, bool both) {
+    if (both) {
+        typename VecOf<V>::gtype q;
+        q.x = v.x;
+        q.y = v.y;
+        *reinterpret_cast<typename VecOf<V>::gtype *>(p) = q;
+    } else {
+        p[0] = v.x;
+    }
+}
+
+constexpr int OOB = 0x7FFFFFF0;      // a byte offset behind every vector: the buffer's range check answers 0
+
+template <typename V>
+struct PlaneKArgs {
+    const V *x_old;
+    V *x_new;
+    const V *b;
+    unsigned vec_bytes;              // n * sizeof(V)
+    int nr;                          // slot of the first black cell
+    int hx, ny, nz;
+    int TXq, TY, LZ, PX, PY, ntx, nty, ntz;
+    V c0, c1, c2, c3, c4, c5, c6, w;
+    int x_zero;
+    // coarse level
+    int nxc, nyc, nzc;
+    unsigned cvec_bytes, cmap_bytes;
+    const int32_t *cmap;
+    V *bc, *xc;
+    const V *cdiag;
+    int first_end;
+    const V *ec;
+    double *partials;
+};
+
+// The row of a cell as the row kernels walk it: one fma chain over the seven slots in column order
+// (-K, -J, -I, diagonal, +I, +J, +K), started from +0.  The first three terms do not involve the
+// cell itself, so a sweep's chain and the residual chain after it share them.
+template <typename V>
+__device__ __forceinline__ V chain_head(const PlaneKArgs<V> &a, V km, V jm, V im) {
+    V s = madd(a.c0, km, V(0));
+    s = madd(a.c1, jm, s);
+    return madd(a.c2, im, s);
+}
+template <typename V>
+__device__ __forceinline__ V chain_tail(const PlaneKArgs<V> &a, V s, V d, V ip, V jp, V kp) {
+    s = madd(a.c3, d, s);
+    s = madd(a.c4, ip, s);
+    s = madd(a.c5, jp, s);
+    return madd(a.c6, kp, s);
+}
+
+// The in-line neighbours of a pair (h = 2q, 2q + 1) of one colour: O = the pair of the other colour
+// at the same h, nb = the one value beyond it — rule 0: the LEFT thread's second value, rule 1: the
+// RIGHT thread's first (rule = line parity for a red cell, its complement for a black one).
+template <typename V>
+struct Inline {
+    V imx, ipx, imy, ipy;
+};
+template <typename V>
+__device__ __forceinline__ Inline<V> in_line(int rule, const P2<V> &O, V nb) {
+    Inline<V> r;
+    r.imx = rule ? O.x : nb;
+    r.ipx = rule ? O.y : O.x;
+    r.imy = rule ? O.y : O.x;
+    r.ipy = rule ? nb : O.y;
+    return r;
+}
+
+// MODE 0: down (sweep, residual, restriction), 1: up (prolongation, sweep, optionally the norm)
+template <typename V, int MODE, bool NORM>
+__global__ __launch_bounds__(512) void plane_kernel(const PlaneKArgs<V> a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char plane_smem[];
+    V *const lds = reinterpret_cast<V *>(plane_smem);
+    __shared__ double s_red[8];
+
+    const int PX = a.PX, PY = a.PY;
+    const int S = 2 * PX + 4;                        // LDS row: guard pair, PX pairs, guard pair
+    const int BUF = (2 * PY + 2) * S;                // guard row, 2 PY lines, guard row
+    const int t = int(threadIdx.x);
+    const bool live = t < PX * PY;
+    const int px = live ? t % PX : 0, py = live ? t / PX : 0;
+    // workgroup -> (tx, ty, tz).  Blocks b and b + 8 share an XCD (observed, speed only): give an
+    // XCD a contiguous run of z chunks so that the tiles sharing a ring also share an L2.
+    int L = int(blockIdx.x);
+    const int nwg = int(gridDim.x);
+    if ((nwg & 7) == 0) L = (L & 7) * (nwg >> 3) + (L >> 3);
+    const int nxy = a.ntx * a.nty;
+    const int tz = L / nxy, rem = L - tz * nxy;
+    const int ty = rem / a.ntx, tx = rem - ty * a.ntx;
+    const int z0 = tz * a.LZ, z1 = min(a.nz, z0 + a.LZ);
+    const int q = tx * a.TXq + px - 1;               // pair index in the line
+    const int ja = ty * a.TY + 2 * py - 4;           // the thread's lines ja (even), ja + 1
+    const bool vx0 = live && q >= 0 && 2 * q < a.hx, vx1 = live && q >= 0 && 2 * q + 1 < a.hx;
+    const bool vl[2] = {ja >= 0 && ja < a.ny, ja + 1 >= 0 && ja + 1 < a.ny};
+    const bool inner = live && px >= 1 && px <= PX - 2 && py >= 2 && py <= PY - 3;
+    const int ps = a.ny * a.hx;                      // one colour's values per plane
+    const int lb[2] = {ja * a.hx + 2 * q, (ja + 1) * a.hx + 2 * q};
+
+    const __amdgpu_buffer_rsrc_t xs = __builtin_amdgcn_make_buffer_rsrc(const_cast<V *>(a.x_old), 0, a.vec_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t bs = __builtin_amdgcn_make_buffer_rsrc(const_cast<V *>(a.b), 0, a.vec_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t es = __builtin_amdgcn_make_buffer_rsrc(const_cast<V *>(MODE == 1 ? a.ec : a.cdiag), 0, a.cvec_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ms = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t *>(a.cmap), 0, a.cmap_bytes, 0x00020000);
+
+    // a pair of the level vector: colour (0 red, 1 black), plane k, line ja + l; 0 outside the grid
+    auto fetch = [&](const __amdgpu_buffer_rsrc_t &rs, int colour, int k, int l) -> P2<V> {
+        const bool ok = vl[l] && vx0 && k >= 0 && k < a.nz;
+        P2<V> r = bload2(rs, ok ? ((colour ? a.nr : 0) + k * ps + lb[l]) * int(sizeof(V)) : OOB, V(0));
+        if (!vx1) r.y = V(0);
+        return r;
+    };
+    auto fetch_x = [&](int colour, int k, int l) -> P2<V> {
+        if (MODE == 0 && a.x_zero) return {V(0), V(0)};
+        return fetch(xs, colour, k, l);
+    };
+    // the coarse cells (2q, J, kc), (2q + 1, J, kc) of this thread, J = ja / 2: slots in the coarse ordering
+    const bool vcoarse = vl[0] && vx0;
+    const int cbase = (ja >> 1) * a.nxc + 2 * q;
+    auto coarse_slots = [&](int kc) -> v2i {
+        const bool ok = vcoarse && kc >= 0 && kc < a.nzc;
+        const int cn = kc * a.nyc * a.nxc + cbase;
+        if (!a.cmap) return v2i{ok ? cn : -1, (ok && vx1) ? cn + 1 : -1};
+        const v2u m = __builtin_amdgcn_raw_buffer_load_b64(ms, ok ? cn * 4 : OOB, 0, 0);     // (second word unused when !vx1)
+        return v2i{ok ? int(m.x) : -1, (ok && vx1) ? int(m.y) : -1};
+    };
+    auto coarse_vals = [&](const v2i &sl) -> P2<V> {
+        return {bload1(es, sl.x >= 0 ? sl.x * int(sizeof(V)) : OOB, V(0)), bload1(es, sl.y >= 0 ? sl.y * int(sizeof(V)) : OOB, V(0))};
+    };
+    auto prolonged = [&](const P2<V> &x, const P2<V> &e) -> P2<V> {
+        // openmg/__init__.py:214,220: x + R^T e — the product rounded, then added (ROW_SCATTER's two roundings)
+        return {x.x + madd(a.w, e.x, V(0)), x.y + madd(a.w, e.y, V(0))};
+    };
+
+    const int row_a = 1 + 2 * py, col = 2 + 2 * px;
+    const int idx[2] = {row_a * S + col, (row_a + 1) * S + col};
+    for (int i = t; i < 6 * BUF; i += int(blockDim.x)) lds[i] = V(0);
+    __syncthreads();
+
+    const P2<V> zero2 = {V(0), V(0)};
+    P2<V> XR[3][2], XB[5][2], BR[3][2], BB[2], LXB[2], LXR[2], LBR[2], LBB[2], RB[2];
+#pragma unroll
+    for (int l = 0; l < 2; ++l) {
+#pragma unroll
+        for (int p = 0; p < 3; ++p) { XR[p][l] = zero2; BR[p][l] = zero2; }
+#pragma unroll
+        for (int p = 0; p < 5; ++p) XB[p][l] = zero2;
+        BB[l] = zero2;
+        RB[l] = zero2;
+    }
+    P2<V> ACC = zero2;               // down: the restriction's running chain
+    P2<V> CO = zero2, CX = zero2;    // ... a finished coarse pair waiting for its store: right-hand side, first iterate
+    v2i SLd = {-1, -1}, SLo = {-1, -1};
+    P2<V> DG = zero2;                // ... the coarse diagonal at those slots
+    bool co_pending = false;
+    P2<V> E0 = zero2, E1n = zero2;   // up: coarse correction of coarse planes s >> 1 and (s >> 1) + 1
+    v2i SLn = {-1, -1};
+    double sq = 0.0;
+
+    // ---- prologue: the state step s0 = z0 - 2 expects ---------------------------------------------
+    const int s0 = z0 - 2;
+    {
+        P2<V> em = zero2;
+        if (MODE == 1) {
+            const v2i sl0 = coarse_slots(s0 >> 1), slm = coarse_slots((s0 >> 1) - 1);
+            SLn = coarse_slots((s0 >> 1) + 1);
+            E0 = coarse_vals(sl0);
+            em = coarse_vals(slm);
+        }
+#pragma unroll
+        for (int l = 0; l < 2; ++l) {
+            XB[0][l] = fetch_x(1, s0, l);            // becomes XB[1] at the first shift
+            XB[1][l] = fetch_x(1, s0 - 1, l);        // becomes XB[2]
+            if (MODE == 1) {
+                XB[0][l] = prolonged(XB[0][l], E0);
+                XB[1][l] = prolonged(XB[1][l], em);
+            }
+            LXB[l] = fetch_x(1, s0 + 1, l);
+            LXR[l] = fetch_x(0, s0, l);
+            LBR[l] = fetch(bs, 0, s0, l);
+            LBB[l] = fetch(bs, 1, s0 - 1, l);
+            if (live) lds_put(lds + (0 * 2 + (s0 & 1)) * BUF + idx[l], XB[0][l]);
+        }
+    }
+    __syncthreads();
+
+    for (int s = s0; s <= z1 + 1; ++s) {
+        const int par = s & 1;
+        // ---- top: take what has arrived, request what the next step needs, store what is final ----
+#pragma unroll
+        for (int l = 0; l < 2; ++l) {
+            XB[4][l] = XB[3][l]; XB[3][l] = XB[2][l]; XB[2][l] = XB[1][l]; XB[1][l] = XB[0][l];
+            XR[2][l] = XR[1][l]; XR[1][l] = XR[0][l];
+            BR[2][l] = BR[1][l]; BR[1][l] = BR[0][l];
+            if (MODE == 1) {
+                XB[0][l] = prolonged(LXB[l], par ? E1n : E0);     // plane s + 1: coarse plane (s + 1) >> 1
+                XR[0][l] = prolonged(LXR[l], E0);                 // plane s
+            } else {
+                XB[0][l] = LXB[l];
+                XR[0][l] = LXR[l];
+            }
+            BR[0][l] = LBR[l];
+            BB[l] = LBB[l];
+        }
+        if (MODE == 1) {
+            if (par) {
+                E0 = E1n;
+                SLn = coarse_slots((s >> 1) + 2);
+            } else {
+                E1n = coarse_vals(SLn);                           // coarse plane (s >> 1) + 1, slots requested one step ago
+            }
+        }
+#pragma unroll
+        for (int l = 0; l < 2; ++l) {
+            LXB[l] = fetch_x(1, s + 2, l);
+            LXR[l] = fetch_x(0, s + 1, l);
+            LBR[l] = fetch(bs, 0, s + 1, l);
+            LBB[l] = fetch(bs, 1, s, l);
+        }
+        if (inner) {
+            // red of plane s - 1 and black of plane s - 2 became final in the previous step
+            if (s - 1 >= z0 && s - 1 < z1) {
+#pragma unroll
+                for (int l = 0; l < 2; ++l)
+                    if (vl[l] && vx0) store2(a.x_new + size_t(s - 1) * ps + lb[l], XR[1][l], vx1);
+            }
+            if (s - 2 >= z0 && s - 2 < z1) {
+#pragma unroll
+                for (int l = 0; l < 2; ++l)
+                    if (vl[l] && vx0) store2(a.x_new + a.nr + size_t(s - 2) * ps + lb[l], XB[3][l], vx1);
+            }
+        }
+        if (MODE == 0) {
+            if (co_pending) {
+                if (SLo.x >= 0) { a.bc[SLo.x] = CO.x; if (a.xc) a.xc[SLo.x] = CX.x; }
+                if (SLo.y >= 0) { a.bc[SLo.y] = CO.y; if (a.xc) a.xc[SLo.y] = CX.y; }
+                co_pending = false;
+            }
+            if (!par) {
+                SLd = coarse_slots((s - 2) >> 1);                 // the coarse plane finished by the next step
+            } else if (a.cdiag) {
+                DG = coarse_vals(SLd);
+            }
+        }
+
+        if (live) {
+            const V *const E1 = lds + (0 * 2 + par) * BUF;        // black, old, plane s
+            const V *const E2 = lds + (1 * 2 + par) * BUF;        // red, new, plane s - 1
+            const V *const E3 = lds + (2 * 2 + par) * BUF;        // black, new, plane s - 2
+            const bool pvB = s >= 0 && s < a.nz, pvC = s - 1 >= 0 && s - 1 < a.nz, pvD = s - 2 >= 0 && s - 2 < a.nz;
+            // B: red sweep of plane s
+            {
+                const P2<V> jm = lds_pair(E1 + idx[0] - S), jp = lds_pair(E1 + idx[1] + S);
+                const P2<V> o0 = XB[1][0], o1 = XB[1][1];
+#pragma unroll
+                for (int l = 0; l < 2; ++l) {
+                    const int rule = (l + s) & 1;
+                    const P2<V> O = l ? o1 : o0, Ojm = l ? o0 : jm, Ojp = l ? jp : o1;
+                    const Inline<V> n = in_line(rule, O, E1[idx[l] + (rule ? 2 : -1)]);
+                    const P2<V> D = XR[0][l], Bv = BR[0][l], Km = XB[2][l], Kp = XB[0][l];
+                    const V sx = chain_tail(a, chain_head(a, Km.x, Ojm.x, n.imx), D.x, n.ipx, Ojp.x, Kp.x);
+                    const V sy = chain_tail(a, chain_head(a, Km.y, Ojm.y, n.imy), D.y, n.ipy, Ojp.y, Kp.y);
+                    // openmg/solvers.py:68   x[i] = x[i] + (b[i] - Aix) / A[i, i]
+                    const V nx_ = D.x + (Bv.x - sx) / a.c3, ny_ = D.y + (Bv.y - sy) / a.c3;
+                    const bool ok = pvB && vl[l];
+                    XR[0][l].x = (ok && vx0) ? nx_ : V(0);
+                    XR[0][l].y = (ok && vx1) ? ny_ : V(0);
+                }
+            }
+            // C: black sweep of plane s - 1, and the residual of the rows it has just relaxed
+            P2<V> rb[2];
+            {
+                const P2<V> jm = lds_pair(E2 + idx[0] - S), jp = lds_pair(E2 + idx[1] + S);
+                const P2<V> o0 = XR[1][0], o1 = XR[1][1];
+#pragma unroll
+                for (int l = 0; l < 2; ++l) {
+                    const int rule = (l + s) & 1;
+                    const P2<V> O = l ? o1 : o0, Ojm = l ? o0 : jm, Ojp = l ? jp : o1;
+                    const Inline<V> n = in_line(rule, O, E2[idx[l] + (rule ? 2 : -1)]);
+                    const P2<V> D = XB[2][l], Bv = BB[l], Km = XR[2][l], Kp = XR[0][l];
+                    const V hx_ = chain_head(a, Km.x, Ojm.x, n.imx), hy_ = chain_head(a, Km.y, Ojm.y, n.imy);
+                    const V sx = chain_tail(a, hx_, D.x, n.ipx, Ojp.x, Kp.x);
+                    const V sy = chain_tail(a, hy_, D.y, n.ipy, Ojp.y, Kp.y);
+                    const bool ok = pvC && vl[l];
+                    const V nx_ = (ok && vx0) ? D.x + (Bv.x - sx) / a.c3 : V(0);
+                    const V ny_ = (ok && vx1) ? D.y + (Bv.y - sy) / a.c3 : V(0);
+                    // the same chain with the new x_i: what a residual pass over the updated vector computes
+                    const V tx_ = chain_tail(a, hx_, nx_, n.ipx, Ojp.x, Kp.x);
+                    const V ty_ = chain_tail(a, hy_, ny_, n.ipy, Ojp.y, Kp.y);
+                    rb[l].x = (ok && vx0) ? Bv.x - tx_ : V(0);
+                    rb[l].y = (ok && vx1) ? Bv.y - ty_ : V(0);
+                    XB[2][l].x = nx_;
+                    XB[2][l].y = ny_;
+                }
+            }
+            // D: residual of the red rows of plane s - 2
+            P2<V> rr[2];
+            {
+                const P2<V> jm = lds_pair(E3 + idx[0] - S), jp = lds_pair(E3 + idx[1] + S);
+                const P2<V> o0 = XB[3][0], o1 = XB[3][1];
+#pragma unroll
+                for (int l = 0; l < 2; ++l) {
+                    const int rule = (l + s) & 1;
+                    const P2<V> O = l ? o1 : o0, Ojm = l ? o0 : jm, Ojp = l ? jp : o1;
+                    const Inline<V> n = in_line(rule, O, E3[idx[l] + (rule ? 2 : -1)]);
+                    const P2<V> D = XR[2][l], Bv = BR[2][l], Km = XB[4][l], Kp = XB[2][l];
+                    const V sx = chain_tail(a, chain_head(a, Km.x, Ojm.x, n.imx), D.x, n.ipx, Ojp.x, Kp.x);
+                    const V sy = chain_tail(a, chain_head(a, Km.y, Ojm.y, n.imy), D.y, n.ipy, Ojp.y, Kp.y);
+                    const bool ok = pvD && vl[l];
+                    rr[l].x = (ok && vx0) ? Bv.x - sx : V(0);
+                    rr[l].y = (ok && vx1) ? Bv.y - sy : V(0);
+                }
+            }
+            if (MODE == 0) {
+                // openmg/__init__.py:210: the coarse cell's eight fine residuals in column order — plane
+                // 2K: (line a: red, black), (line b: black, red); plane 2K + 1: the colours swapped.  RB holds
+                // the black residuals of plane s - 2 (formed one step ago).
+                if (!par) {
+                    ACC.x = madd(a.w, rr[0].x, V(0)); ACC.y = madd(a.w, rr[0].y, V(0));
+                    ACC.x = madd(a.w, RB[0].x, ACC.x); ACC.y = madd(a.w, RB[0].y, ACC.y);
+                    ACC.x = madd(a.w, RB[1].x, ACC.x); ACC.y = madd(a.w, RB[1].y, ACC.y);
+                    ACC.x = madd(a.w, rr[1].x, ACC.x); ACC.y = madd(a.w, rr[1].y, ACC.y);
+                } else {
+                    ACC.x = madd(a.w, RB[0].x, ACC.x); ACC.y = madd(a.w, RB[0].y, ACC.y);
+                    ACC.x = madd(a.w, rr[0].x, ACC.x); ACC.y = madd(a.w, rr[0].y, ACC.y);
+                    ACC.x = madd(a.w, rr[1].x, ACC.x); ACC.y = madd(a.w, rr[1].y, ACC.y);
+                    ACC.x = madd(a.w, RB[1].x, ACC.x); ACC.y = madd(a.w, RB[1].y, ACC.y);
+                    if (inner && s - 2 >= z0 && s - 2 < z1) {
+                        CO = ACC;
+                        SLo = SLd;
+                        // the coarse level's first relaxation of a zero iterate, spelled like row_epilogue's
+                        CX.x = (a.cdiag && SLd.x >= 0 && SLd.x < a.first_end) ? V(0) + (ACC.x - V(0)) / DG.x : V(0);
+                        CX.y = (a.cdiag && SLd.y >= 0 && SLd.y < a.first_end) ? V(0) + (ACC.y - V(0)) / DG.y : V(0);
+                        co_pending = true;
+                    }
+                }
+                RB[0] = rb[0];
+                RB[1] = rb[1];
+            }
+            if (NORM && inner) {
+                if (s - 1 >= z0 && s - 1 < z1) {
+#pragma unroll
+                    for (int l = 0; l < 2; ++l) {
+                        sq = fma(double(rb[l].x), double(rb[l].x), sq);
+                        sq = fma(double(rb[l].y), double(rb[l].y), sq);
+                    }
+                }
+                if (s - 2 >= z0 && s - 2 < z1) {
+#pragma unroll
+                    for (int l = 0; l < 2; ++l) {
+                        sq = fma(double(rr[l].x), double(rr[l].x), sq);
+                        sq = fma(double(rr[l].y), double(rr[l].y), sq);
+                    }
+                }
+            }
+            // the images the next step reads
+            V *const W1 = lds + (0 * 2 + (par ^ 1)) * BUF;
+            V *const W2 = lds + (1 * 2 + (par ^ 1)) * BUF;
+            V *const W3 = lds + (2 * 2 + (par ^ 1)) * BUF;
+#pragma unroll
+            for (int l = 0; l < 2; ++l) {
+                lds_put(W1 + idx[l], XB[0][l]);
+                lds_put(W2 + idx[l], XR[0][l]);
+                lds_put(W3 + idx[l], XB[2][l]);
+            }
+        }
+        __syncthreads();
+    }
+    if (MODE == 0 && co_pending) {
+        if (SLo.x >= 0) { a.bc[SLo.x] = CO.x; if (a.xc) a.xc[SLo.x] = CX.x; }
+        if (SLo.y >= 0) { a.bc[SLo.y] = CO.y; if (a.xc) a.xc[SLo.y] = CX.y; }
+    }
+    if (NORM) {
+        // fixed order: lanes of a wave (shuffle tree), then the waves in turn
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) sq += __shfl_down(sq, off, 64);
+        if ((t & 63) == 0) s_red[t >> 6] = sq;
+        __syncthreads();
+        if (t == 0) {
+            double tot = 0.0;
+            for (int wv = 0; wv < int(blockDim.x) >> 6; ++wv) tot += s_red[wv];
+            a.partials[blockIdx.x] = tot;
+        }
+    }
+}
+
+// ---- host: does the level qualify, and how is it tiled -----------------------------------------------
+int env_int3(const char *name, int out[3]) {
+    const char *e = getenv(name);
+    if (!e || !e[0]) return 0;
+    return sscanf(e, "%d,%d,%d", &out[0], &out[1], &out[2]) == 3 ? 1 : 0;
+}
+
+inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+void choose_tiles(PlaneGeom &g, size_t value_bytes) {
+    auto set = [&](int TX, int TY, int LZ) {
+        g.TX = TX; g.TY = TY; g.LZ = LZ;
+        g.PX = TX / 4 + 2; g.PY = TY / 2 + 4;
+        g.ntx = (g.nx + TX - 1) / TX; g.nty = (g.ny + TY - 1) / TY; g.ntz = (g.nz + LZ - 1) / LZ;
+        g.n_wg = g.ntx * g.nty * g.ntz;
+        g.threads = round_up(g.PX * g.PY, 64);
+        g.lds_bytes = size_t(6) * size_t(2 * g.PY + 2) * size_t(2 * g.PX + 4) * value_bytes;
+    };
+    int forced[3];
+    if (env_int3("OMG_PLANE_TILE", forced)) {
+        const int TX = std::max(4, round_up(forced[0], 4)), TY = std::max(2, round_up(forced[1], 2)), LZ = std::max(2, round_up(forced[2], 2));
+        set(TX, TY, LZ);
+        if (g.threads <= 512 && g.lds_bytes <= size_t(160) * 1024) return;
+    }
+    // Few, fat workgroups: one per CU (256), each as large a tile as its registers hold (<= 512 threads of
+    // two lines x four cells), the z chunk as long as the count allows.  cost ~ rounds of workgroups x
+    // steps x (threads + a fixed per-step price).
+    double best = 1e300;
+    int bx = 0, by = 0, bz = 0;
+    for (int ntx = 1; ntx <= (g.nx + 3) / 4; ++ntx) {
+        const int TX = round_up((g.nx + ntx - 1) / ntx, 4);
+        if ((g.nx + TX - 1) / TX != ntx) continue;
+        for (int nty = 1; nty <= g.ny / 2; ++nty) {
+            const int TY = round_up((g.ny + nty - 1) / nty, 2);
+            if ((g.ny + TY - 1) / TY != nty) continue;
+            const int thr = round_up((TX / 4 + 2) * (TY / 2 + 4), 64);
+            if (thr > 512) continue;
+            if (size_t(6) * size_t(TY + 10) * size_t(TX / 2 + 8) * value_bytes > size_t(150) * 1024) continue;
+            for (int ntz = 1; ntz <= g.nz / 2; ++ntz) {
+                const int LZ = round_up((g.nz + ntz - 1) / ntz, 2);
+                if ((g.nz + LZ - 1) / LZ != ntz) continue;
+                const double rounds = std::ceil(double(ntx) * nty * ntz / 256.0);
+                const double cost = rounds * (LZ + 4) * (thr + 192.0);
+                if (cost < best) { best = cost; bx = TX; by = TY; bz = LZ; }
+            }
+        }
+    }
+    set(bx, by, bz);
+}
+
+}  // namespace
+
+template <typename V>
+bool PlanePlan<V>::build(const omg_csr &A, const omg_csr &R, const Ordering &ord) {
+    {
+        const char *e = getenv("OMG_PLANE");
+        if (e && e[0] == '0') return false;
+    }
+    const int64_t n = A.n_rows;
+    if (n < 8 || n != A.n_cols || uint64_t(n) * sizeof(V) >= (uint64_t(1) << 31)) return false;
+    auto has = [&](int64_t r, int64_t c) {
+        for (int64_t p = A.indptr[r]; p < A.indptr[r + 1]; ++p)
+            if (A.indices[p] == c) return true;
+        return false;
+    };
+    // the grid, read off the couplings: the first row not coupled to its predecessor starts the second
+    // line, the first line not coupled to the previous one the second plane
+    int64_t nx = n;
+    for (int64_t r = 1; r < n; ++r)
+        if (!has(r, r - 1)) { nx = r; break; }
+    if (nx < 2 || n % nx) return false;
+    const int64_t lines = n / nx;
+    int64_t ny = lines;
+    for (int64_t q = 1; q < lines; ++q)
+        if (!has(q * nx, (q - 1) * nx)) { ny = q; break; }
+    if (lines % ny) return false;
+    const int64_t nz = lines / ny;
+    if ((nx & 1) || (ny & 1) || (nz & 1) || ny < 2 || nz < 2) return false;
+    const int64_t sj = nx, sk = nx * ny;
+    // two colours by parity, red first: the ordering the greedy colouring finds on such a stencil
+    if (ord.identity || ord.sets.size() != 3 || ord.sets[1] != n / 2 || int64_t(ord.inv.size()) != n) return false;
+    // the coefficients: from the first row that has each slot
+    bool havec[7] = {false, false, false, false, false, false, false};
+    double c[7] = {0, 0, 0, 0, 0, 0, 0};
+    auto slot_of = [&](int64_t r, int64_t col) -> int {
+        const int64_t i = r % nx, jl = (r / nx) % ny, kl = r / sk, off = col - r;
+        if (off == 0) return 3;
+        if (off == -1 && i > 0) return 2;
+        if (off == 1 && i + 1 < nx) return 4;
+        if (off == -sj && jl > 0) return 1;
+        if (off == sj && jl + 1 < ny) return 5;
+        if (off == -sk && kl > 0) return 0;
+        if (off == sk && kl + 1 < nz) return 6;
+        return -1;
+    };
+    {
+        const int64_t probe = std::min<int64_t>(n - 1, sk + sj + 1);      // cell (1, 1, 1): an interior row when every extent is >= 3
+        for (int64_t r : {probe, int64_t(0), n - 1}) {
+            for (int64_t p = A.indptr[r]; p < A.indptr[r + 1]; ++p) {
+                const int sl = slot_of(r, A.indices[p]);
+                if (sl < 0) return false;
+                if (!havec[sl]) { havec[sl] = true; c[sl] = A.data[p]; }
+            }
+        }
+        for (int e = 0; e < 7; ++e)
+            if (!havec[e]) return false;
+        if (!(std::fabs(c[3]) > 0.0) || !std::isfinite(c[3])) return false;
+    }
+    // every row: exactly its in-grid neighbours, in slot (= column) order, with those coefficients (as V
+    // they are what the device format holds); its slot in the ordering; and R's row of every coarse cell
+    const int64_t nxc = nx / 2, nyc = ny / 2, nzc = nz / 2;
+    if (R.n_cols != n || R.n_rows != nxc * nyc * nzc || R.nnz != n) return false;
+    const double w = R.nnz ? R.data[0] : 0.0;
+    const unsigned hw = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+    const int nt = (int)std::min<int64_t>(hw, std::max<int64_t>(1, n / 65536));
+    std::atomic<bool> ok(true);
+    auto scan = [&](int tnum) {
+        const int64_t lo = n * tnum / nt, hi = n * (tnum + 1) / nt;
+        for (int64_t r = lo; r < hi; ++r) {
+            const int64_t i = r % nx, jl = (r / nx) % ny, kl = r / sk;
+            const bool present[7] = {kl > 0, jl > 0, i > 0, true, i + 1 < nx, jl + 1 < ny, kl + 1 < nz};
+            int64_t p = A.indptr[r];
+            const int64_t pe = A.indptr[r + 1];
+            for (int e = 0; e < 7; ++e) {
+                if (!present[e]) continue;
+                if (p >= pe || slot_of(r, A.indices[p]) != e || A.data[p] != c[e]) { ok = false; return; }
+                ++p;
+            }
+            if (p != pe) { ok = false; return; }
+            const int64_t want = ((i + jl + kl) & 1 ? n / 2 : 0) + r / 2;
+            if (ord.inv[r] != want) { ok = false; return; }
+        }
+        const int64_t clo = R.n_rows * tnum / nt, chi = R.n_rows * (tnum + 1) / nt;
+        for (int64_t cr = clo; cr < chi; ++cr) {
+            const int64_t I = cr % nxc, J = (cr / nxc) % nyc, K = cr / (nxc * nyc);
+            int64_t p = R.indptr[cr];
+            if (R.indptr[cr + 1] - p != 8) { ok = false; return; }
+            for (int dk = 0; dk < 2; ++dk)
+                for (int dj = 0; dj < 2; ++dj)
+                    for (int di = 0; di < 2; ++di, ++p) {
+                        const int64_t f = (2 * K + dk) * sk + (2 * J + dj) * sj + 2 * I + di;
+                        if (R.indices[p] != f || R.data[p] != w) { ok = false; return; }
+                    }
+        }
+    };
+    {
+        std::vector<std::thread> th;
+        for (int tnum = 1; tnum < nt; ++tnum) th.emplace_back(scan, tnum);
+        scan(0);
+        for (auto &q : th) q.join();
+    }
+    if (!ok) return false;
+    // (a float level holds the rounded coefficients: every entry with one value rounds to one value)
+    g = PlaneGeom();
+    g.nx = (int)nx; g.ny = (int)ny; g.nz = (int)nz; g.hx = (int)(nx / 2);
+    for (int e = 0; e < 7; ++e) g.c[e] = double(V(c[e]));
+    g.w = double(V(w));
+    choose_tiles(g, sizeof(V));
+    if (g.TX <= 0 || g.threads > 512) return false;
+    partials.alloc(size_t(g.n_wg) + SUM_FOLD);
+    return true;
+}
+
+namespace {
+
+template <typename V>
+PlaneKArgs<V> plane_args(const PlaneGeom &g, const V *x_old, V *x_new, const V *b, const typename PlanePlan<V>::Coarse &c) {
+    PlaneKArgs<V> k;
+    std::memset(&k, 0, sizeof(k));
+    const int64_t n = int64_t(g.nx) * g.ny * g.nz;
+    k.x_old = x_old; k.x_new = x_new; k.b = b;
+    k.vec_bytes = unsigned(n * int64_t(sizeof(V)));
+    k.nr = int(n / 2);
+    k.hx = g.hx; k.ny = g.ny; k.nz = g.nz;
+    k.TXq = g.TX / 4; k.TY = g.TY; k.LZ = g.LZ; k.PX = g.PX; k.PY = g.PY; k.ntx = g.ntx; k.nty = g.nty; k.ntz = g.ntz;
+    k.c0 = V(g.c[0]); k.c1 = V(g.c[1]); k.c2 = V(g.c[2]); k.c3 = V(g.c[3]); k.c4 = V(g.c[4]); k.c5 = V(g.c[5]); k.c6 = V(g.c[6]);
+    k.w = V(g.w);
+    k.nxc = g.nx / 2; k.nyc = g.ny / 2; k.nzc = g.nz / 2;
+    const int64_t nc = int64_t(k.nxc) * k.nyc * k.nzc;
+    k.cvec_bytes = unsigned(nc * int64_t(sizeof(V)));
+    k.cmap_bytes = unsigned(nc * 4);
+    k.cmap = c.map;
+    k.bc = c.b; k.xc = c.x; k.cdiag = c.diag; k.first_end = c.first_end; k.ec = c.e;
+    return k;
+}
+
+template <typename K>
+void allow_lds(K kernel, size_t bytes) {
+    if (bytes > size_t(64) * 1024)
+        OMG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(bytes)));
+}
+
+}  // namespace
+
+template <typename V>
+void PlanePlan<V>::down(const V *x_old, V *x_new, const V *b, bool x_zero, const Coarse &c, hipStream_t s) const {
+    PlaneKArgs<V> k = plane_args<V>(g, x_old, x_new, b, c);
+    k.x_zero = x_zero ? 1 : 0;
+    allow_lds(plane_kernel<V, 0, false>, g.lds_bytes);
+    hipLaunchKernelGGL((plane_kernel<V, 0, false>), dim3(unsigned(g.n_wg)), dim3(unsigned(g.threads)), g.lds_bytes, s, k);
+    OMG_HIP(hipGetLastError());
+}
+
+template <typename V>
+void PlanePlan<V>::up(const V *x_old, V *x_new, const V *b, const Coarse &c, double *out, hipStream_t s) const {
+    PlaneKArgs<V> k = plane_args<V>(g, x_old, x_new, b, c);
+    k.partials = out;
+    if (out) {
+        allow_lds(plane_kernel<V, 1, true>, g.lds_bytes);
+        hipLaunchKernelGGL((plane_kernel<V, 1, true>), dim3(unsigned(g.n_wg)), dim3(unsigned(g.threads)), g.lds_bytes, s, k);
+    } else {
+        allow_lds(plane_kernel<V, 1, false>, g.lds_bytes);
+        hipLaunchKernelGGL((plane_kernel<V, 1, false>), dim3(unsigned(g.n_wg)), dim3(unsigned(g.threads)), g.lds_bytes, s, k);
+    }
+    OMG_HIP(hipGetLastError());
+}
+
+template struct PlanePlan<double>;
+template struct PlanePlan<float>;
+
+}  // namespace omg
