@@ -116,6 +116,10 @@ struct PlaneKArgs {
     int first_end;
     const V *ec;
     double *partials;
+#ifdef OMG_PLANE_STAMPS
+    unsigned long long *stamps;      // diagnostic build: per workgroup and wave, cycles spent waiting for loads / computing / at the barrier
+    int dbg;                         // ... OMG_PLANE_DBG bits: 1 no x stores, 2 no coarse stores, 4 x taken as zero (wrong results, timing only)
+#endif
 };
 
 // The row of a cell as the row kernels walk it: one fma chain over the seven slots in column order
@@ -153,7 +157,12 @@ __device__ __forceinline__ Inline<V> in_line(int rule, const P2<V> &O, V nb) {
 }
 
 // MODE 0: down (sweep, residual, restriction), 1: up (prolongation, sweep, optionally the norm)
-template <typename V, int MODE, bool NORM>
+// XZ (down): x_old is zero and is not read.
+// Every load of the loop is UNCONDITIONAL (a lane that needs nothing asks for an offset behind the buffer,
+// which costs no memory traffic) and is committed at the top of the NEXT step: a load inside a branch is
+// followed by s_waitcnt vmcnt(0) where the branch rejoins — which also waits for the whole step's
+// prefetch (measured: 4600 of a step's 12000 cycles).
+template <typename V, int MODE, bool NORM, bool XZ>
 __global__ __launch_bounds__(512) void plane_kernel(const PlaneKArgs<V> a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char plane_smem[];
     V *const lds = reinterpret_cast<V *>(plane_smem);
@@ -195,19 +204,25 @@ __global__ __launch_bounds__(512) void plane_kernel(const PlaneKArgs<V> a) {
         return r;
     };
     auto fetch_x = [&](int colour, int k, int l) -> P2<V> {
-        if (MODE == 0 && a.x_zero) return {V(0), V(0)};
+        if (XZ) return {V(0), V(0)};
         return fetch(xs, colour, k, l);
     };
     // the coarse cells (2q, J, kc), (2q + 1, J, kc) of this thread, J = ja / 2: slots in the coarse ordering
     const bool vcoarse = vl[0] && vx0;
     const int cbase = (ja >> 1) * a.nxc + 2 * q;
-    auto coarse_slots = [&](int kc) -> v2i {
-        const bool ok = vcoarse && kc >= 0 && kc < a.nzc;
-        const int cn = kc * a.nyc * a.nxc + cbase;
-        if (!a.cmap) return v2i{ok ? cn : -1, (ok && vx1) ? cn + 1 : -1};
-        const v2u m = __builtin_amdgcn_raw_buffer_load_b64(ms, ok ? cn * 4 : OOB, 0, 0);     // (second word unused when !vx1)
-        return v2i{ok ? int(m.x) : -1, (ok && vx1) ? int(m.y) : -1};
+    // ... in two halves, so that the load has no consumer in the step that issues it: the request
+    // (raw words of the slot map; nothing is fetched for a lane that needs none) and, a step later, the slots
+    auto slots_request = [&](int kc, bool want) -> v2u {
+        const bool ok = want && a.cmap && vcoarse && kc >= 0 && kc < a.nzc;
+        return __builtin_amdgcn_raw_buffer_load_b64(ms, ok ? (kc * a.nyc * a.nxc + cbase) * 4 : OOB, 0, 0);   // (second word unused when !vx1)
     };
+    auto slots_commit = [&](const v2u &m, int kc, bool want) -> v2i {
+        const bool ok = want && vcoarse && kc >= 0 && kc < a.nzc;
+        const int cn = kc * a.nyc * a.nxc + cbase;
+        const int s0_ = a.cmap ? int(m.x) : cn, s1_ = a.cmap ? int(m.y) : cn + 1;
+        return v2i{ok ? s0_ : -1, (ok && vx1) ? s1_ : -1};
+    };
+    auto coarse_slots = [&](int kc) -> v2i { return slots_commit(slots_request(kc, true), kc, true); };
     auto coarse_vals = [&](const v2i &sl) -> P2<V> {
         return {bload1(es, sl.x >= 0 ? sl.x * int(sizeof(V)) : OOB, V(0)), bload1(es, sl.y >= 0 ? sl.y * int(sizeof(V)) : OOB, V(0))};
     };
@@ -235,9 +250,11 @@ __global__ __launch_bounds__(512) void plane_kernel(const PlaneKArgs<V> a) {
     P2<V> ACC = zero2;               // down: the restriction's running chain
     P2<V> CO = zero2, CX = zero2;    // ... a finished coarse pair waiting for its store: right-hand side, first iterate
     v2i SLd = {-1, -1}, SLo = {-1, -1};
-    P2<V> DG = zero2;                // ... the coarse diagonal at those slots
+    v2u SLt = {0u, 0u};              // SLt, DGt, Et: requested in one step, committed at the top of the next
+    int SLt_kc = -1;
+    P2<V> DG = zero2, DGt = zero2;   // ... the coarse diagonal at those slots
     bool co_pending = false;
-    P2<V> E0 = zero2, E1n = zero2;   // up: coarse correction of coarse planes s >> 1 and (s >> 1) + 1
+    P2<V> E0 = zero2, E1n = zero2, Et = zero2;   // up: coarse correction of coarse planes s >> 1 and (s >> 1) + 1
     v2i SLn = {-1, -1};
     double sq = 0.0;
 
@@ -247,7 +264,8 @@ __global__ __launch_bounds__(512) void plane_kernel(const PlaneKArgs<V> a) {
         P2<V> em = zero2;
         if (MODE == 1) {
             const v2i sl0 = coarse_slots(s0 >> 1), slm = coarse_slots((s0 >> 1) - 1);
-            SLn = coarse_slots((s0 >> 1) + 1);
+            SLt_kc = (s0 >> 1) + 1;
+            SLt = slots_request(SLt_kc, true);        // committed to SLn at the top of the first step
             E0 = coarse_vals(sl0);
             em = coarse_vals(slm);
         }
@@ -268,9 +286,32 @@ __global__ __launch_bounds__(512) void plane_kernel(const PlaneKArgs<V> a) {
     }
     __syncthreads();
 
+#ifdef OMG_PLANE_STAMPS
+    unsigned long long st_mem = 0, st_cmp = 0, st_bar = 0, st_top = 0, st_B = 0, st_C = 0, st_t = __builtin_amdgcn_s_memtime();
+#define PLANE_STAMP(acc) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); acc += now_ - st_t; st_t = now_; }
+#else
+#define PLANE_STAMP(acc)
+#endif
     for (int s = s0; s <= z1 + 1; ++s) {
         const int par = s & 1;
+#ifdef OMG_PLANE_STAMPS
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        PLANE_STAMP(st_mem)
+#endif
         // ---- top: take what has arrived, request what the next step needs, store what is final ----
+        if (MODE == 1) {
+            // commit what the previous step requested: an even step asked for the next coarse plane's values,
+            // an odd one for the slots of the one after
+            E1n.x = par ? Et.x : E1n.x; E1n.y = par ? Et.y : E1n.y;
+            const v2i sl = slots_commit(SLt, SLt_kc, true);
+            SLn.x = par ? SLn.x : sl.x; SLn.y = par ? SLn.y : sl.y;
+        } else {
+            // an odd step asked for the slots of the coarse plane finished two steps later, the even step
+            // after it for the coarse diagonal there
+            const v2i sl = slots_commit(SLt, SLt_kc, true);
+            SLd.x = par ? SLd.x : sl.x; SLd.y = par ? SLd.y : sl.y;
+            DG.x = par ? DGt.x : DG.x; DG.y = par ? DGt.y : DG.y;
+        }
 #pragma unroll
         for (int l = 0; l < 2; ++l) {
             XB[4][l] = XB[3][l]; XB[3][l] = XB[2][l]; XB[2][l] = XB[1][l]; XB[1][l] = XB[0][l];
@@ -287,12 +328,14 @@ __global__ __launch_bounds__(512) void plane_kernel(const PlaneKArgs<V> a) {
             BB[l] = LBB[l];
         }
         if (MODE == 1) {
-            if (par) {
-                E0 = E1n;
-                SLn = coarse_slots((s >> 1) + 2);
-            } else {
-                E1n = coarse_vals(SLn);                           // coarse plane (s >> 1) + 1, slots requested one step ago
-            }
+            E0.x = par ? E1n.x : E0.x; E0.y = par ? E1n.y : E0.y;
+            SLt_kc = (s >> 1) + 2;
+            SLt = slots_request(SLt_kc, par != 0);
+            Et = coarse_vals(par ? v2i{-1, -1} : SLn);            // coarse plane (s >> 1) + 1, slots committed above
+        } else {
+            SLt_kc = (s - 1) >> 1;                                // the coarse plane finished by step s + 2
+            SLt = slots_request(SLt_kc, par != 0);
+            DGt = coarse_vals((par || !a.cdiag) ? v2i{-1, -1} : SLd);
         }
 #pragma unroll
         for (int l = 0; l < 2; ++l) {
@@ -301,7 +344,11 @@ __global__ __launch_bounds__(512) void plane_kernel(const PlaneKArgs<V> a) {
             LBR[l] = fetch(bs, 0, s + 1, l);
             LBB[l] = fetch(bs, 1, s, l);
         }
+#ifdef OMG_PLANE_STAMPS
+        if (inner && !(a.dbg & 1)) {
+#else
         if (inner) {
+#endif
             // red of plane s - 1 and black of plane s - 2 became final in the previous step
             if (s - 1 >= z0 && s - 1 < z1) {
 #pragma unroll
@@ -315,18 +362,17 @@ __global__ __launch_bounds__(512) void plane_kernel(const PlaneKArgs<V> a) {
             }
         }
         if (MODE == 0) {
+#ifdef OMG_PLANE_STAMPS
+            if (a.dbg & 2) co_pending = false;
+#endif
             if (co_pending) {
                 if (SLo.x >= 0) { a.bc[SLo.x] = CO.x; if (a.xc) a.xc[SLo.x] = CX.x; }
                 if (SLo.y >= 0) { a.bc[SLo.y] = CO.y; if (a.xc) a.xc[SLo.y] = CX.y; }
                 co_pending = false;
             }
-            if (!par) {
-                SLd = coarse_slots((s - 2) >> 1);                 // the coarse plane finished by the next step
-            } else if (a.cdiag) {
-                DG = coarse_vals(SLd);
-            }
         }
 
+        PLANE_STAMP(st_top)
         if (live) {
             const V *const E1 = lds + (0 * 2 + par) * BUF;        // black, old, plane s
             const V *const E2 = lds + (1 * 2 + par) * BUF;        // red, new, plane s - 1
@@ -351,6 +397,7 @@ __global__ __launch_bounds__(512) void plane_kernel(const PlaneKArgs<V> a) {
                     XR[0][l].y = (ok && vx1) ? ny_ : V(0);
                 }
             }
+            PLANE_STAMP(st_B)
             // C: black sweep of plane s - 1, and the residual of the rows it has just relaxed
             P2<V> rb[2];
             {
@@ -377,6 +424,7 @@ __global__ __launch_bounds__(512) void plane_kernel(const PlaneKArgs<V> a) {
                     XB[2][l].y = ny_;
                 }
             }
+            PLANE_STAMP(st_C)
             // D: residual of the red rows of plane s - 2
             P2<V> rr[2];
             {
@@ -448,8 +496,16 @@ __global__ __launch_bounds__(512) void plane_kernel(const PlaneKArgs<V> a) {
                 lds_put(W3 + idx[l], XB[2][l]);
             }
         }
+        PLANE_STAMP(st_cmp)
         __syncthreads();
+        PLANE_STAMP(st_bar)
     }
+#ifdef OMG_PLANE_STAMPS
+    if ((t & 63) == 0) {
+        unsigned long long *o = a.stamps + (size_t(blockIdx.x) * 8 + (t >> 6)) * 8;
+        o[0] = st_mem; o[1] = st_cmp; o[2] = st_bar; o[3] = unsigned(z1 + 2 - s0); o[4] = st_top; o[5] = st_B; o[6] = st_C;
+    }
+#endif
     if (MODE == 0 && co_pending) {
         if (SLo.x >= 0) { a.bc[SLo.x] = CO.x; if (a.xc) a.xc[SLo.x] = CX.x; }
         if (SLo.y >= 0) { a.bc[SLo.y] = CO.y; if (a.xc) a.xc[SLo.y] = CX.y; }
@@ -654,6 +710,32 @@ PlaneKArgs<V> plane_args(const PlaneGeom &g, const V *x_old, V *x_new, const V *
     return k;
 }
 
+#ifdef OMG_PLANE_STAMPS
+template <typename V>
+void stamps_begin(PlaneKArgs<V> &k, const PlaneGeom &g, DevBuf<unsigned long long> &buf) {
+    buf.alloc(size_t(g.n_wg) * 8 * 8);
+    OMG_HIP(hipMemset(buf.p, 0, buf.n * 8));
+    k.stamps = buf.p;
+    const char *e = getenv("OMG_PLANE_DBG");
+    k.dbg = e ? atoi(e) : 0;
+
+}
+inline void stamps_end(const char *what, const PlaneGeom &g, DevBuf<unsigned long long> &buf, hipStream_t s) {
+    OMG_HIP(hipStreamSynchronize(s));
+    std::vector<unsigned long long> hst(buf.n);
+    OMG_HIP(hipMemcpy(hst.data(), buf.p, buf.n * 8, hipMemcpyDeviceToHost));
+    double m = 0, c = 0, b = 0, steps = 0, tp = 0, sB = 0, sC = 0;
+    const int waves = g.threads / 64;
+    for (int w = 0; w < g.n_wg; ++w)
+        for (int v = 0; v < waves; ++v) {
+            const unsigned long long *o = &hst[(size_t(w) * 8 + v) * 8];
+            m += o[0]; c += o[1]; b += o[2]; steps += o[3]; tp += o[4]; sB += o[5]; sC += o[6];
+        }
+    fprintf(stderr, "[plane stamps] %-5s n %dx%dx%d wg %d thr %d: cycles per step and wave: wait-for-loads %.0f | top (shift, issue loads + stores) %.0f | B %.0f | C %.0f | D + rest %.0f | barrier %.0f\n",
+            what, g.nx, g.ny, g.nz, g.n_wg, g.threads, m / steps, tp / steps, sB / steps, sC / steps, c / steps, b / steps);
+}
+#endif
+
 template <typename K>
 void allow_lds(K kernel, size_t bytes) {
     if (bytes > size_t(64) * 1024)
@@ -666,23 +748,42 @@ template <typename V>
 void PlanePlan<V>::down(const V *x_old, V *x_new, const V *b, bool x_zero, const Coarse &c, hipStream_t s) const {
     PlaneKArgs<V> k = plane_args<V>(g, x_old, x_new, b, c);
     k.x_zero = x_zero ? 1 : 0;
-    allow_lds(plane_kernel<V, 0, false>, g.lds_bytes);
-    hipLaunchKernelGGL((plane_kernel<V, 0, false>), dim3(unsigned(g.n_wg)), dim3(unsigned(g.threads)), g.lds_bytes, s, k);
+#ifdef OMG_PLANE_STAMPS
+    DevBuf<unsigned long long> sb;
+    stamps_begin(k, g, sb);
+#endif
+    if (x_zero) {
+        allow_lds(plane_kernel<V, 0, false, true>, g.lds_bytes);
+        hipLaunchKernelGGL((plane_kernel<V, 0, false, true>), dim3(unsigned(g.n_wg)), dim3(unsigned(g.threads)), g.lds_bytes, s, k);
+    } else {
+        allow_lds(plane_kernel<V, 0, false, false>, g.lds_bytes);
+        hipLaunchKernelGGL((plane_kernel<V, 0, false, false>), dim3(unsigned(g.n_wg)), dim3(unsigned(g.threads)), g.lds_bytes, s, k);
+    }
     OMG_HIP(hipGetLastError());
+#ifdef OMG_PLANE_STAMPS
+    stamps_end("down", g, sb, s);
+#endif
 }
 
 template <typename V>
 void PlanePlan<V>::up(const V *x_old, V *x_new, const V *b, const Coarse &c, double *out, hipStream_t s) const {
     PlaneKArgs<V> k = plane_args<V>(g, x_old, x_new, b, c);
     k.partials = out;
+#ifdef OMG_PLANE_STAMPS
+    DevBuf<unsigned long long> sb;
+    stamps_begin(k, g, sb);
+#endif
     if (out) {
-        allow_lds(plane_kernel<V, 1, true>, g.lds_bytes);
-        hipLaunchKernelGGL((plane_kernel<V, 1, true>), dim3(unsigned(g.n_wg)), dim3(unsigned(g.threads)), g.lds_bytes, s, k);
+        allow_lds(plane_kernel<V, 1, true, false>, g.lds_bytes);
+        hipLaunchKernelGGL((plane_kernel<V, 1, true, false>), dim3(unsigned(g.n_wg)), dim3(unsigned(g.threads)), g.lds_bytes, s, k);
     } else {
-        allow_lds(plane_kernel<V, 1, false>, g.lds_bytes);
-        hipLaunchKernelGGL((plane_kernel<V, 1, false>), dim3(unsigned(g.n_wg)), dim3(unsigned(g.threads)), g.lds_bytes, s, k);
+        allow_lds(plane_kernel<V, 1, false, false>, g.lds_bytes);
+        hipLaunchKernelGGL((plane_kernel<V, 1, false, false>), dim3(unsigned(g.n_wg)), dim3(unsigned(g.threads)), g.lds_bytes, s, k);
     }
     OMG_HIP(hipGetLastError());
+#ifdef OMG_PLANE_STAMPS
+    stamps_end("up", g, sb, s);
+#endif
 }
 
 template struct PlanePlan<double>;
