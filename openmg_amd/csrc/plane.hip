@@ -26,6 +26,7 @@
 #include <cmath>
 #include <cstring>
 #include <thread>
+#include <type_traits>
 
 #include "common.h"
 
@@ -94,6 +95,9 @@ __device__ __forceinline__ void store2(V *p, const P2<V> &v, bool both) {
     }
 }
 
+#ifndef PLANE_LA
+#define PLANE_LA 1
+#endif
 constexpr int OOB = 0x7FFFFFF0;      // a byte offset behind every vector: the buffer's range check answers 0
 
 template <typename V>
@@ -107,6 +111,7 @@ struct PlaneKArgs {
     int TXq, TY, LZ, PX, PY, ntx, nty, ntz;
     V c0, c1, c2, c3, c4, c5, c6, w;
     int x_zero;
+    int fast_div;                    // the diagonal's exponent is within 2^-400 .. 2^400 (quotients())
     // coarse level
     int nxc, nyc, nzc;
     unsigned cvec_bytes, cmap_bytes;
@@ -139,6 +144,44 @@ __device__ __forceinline__ V chain_tail(const PlaneKArgs<V> &a, V s, V d, V ip, 
     return madd(a.c6, kp, s);
 }
 
+// n / c3 for the relaxation.  The compiler's expansion of a double division — v_div_scale x 2, v_rcp_f64,
+// two Newton steps on the reciprocal, quotient, one correction, v_div_fmas, v_div_fixup — spends most of
+// its dozen dependent instructions on the DENOMINATOR, which here is one constant per level.  For a
+// numerator v_div_scale_f64 leaves unscaled (exponent within 2^-400 .. 2^400, or zero) and such a
+// denominator, the sequence reduces to q0 = n r, q = fma(fma(-c, q0, n), r, q0) with r = the refined
+// reciprocal: the same instructions on the same operands, hence the same bits (march.hip does the same;
+// tests/test_gpu_plane.py compares with the row kernels, which divide).  A wave that meets any other
+// numerator redoes its four quotients with the division itself.
+__device__ __forceinline__ double refined_rcp(double d) {
+    double r = __builtin_amdgcn_rcp(d);
+    double e = fma(-d, r, 1.0);
+    r = fma(r, e, r);
+    e = fma(-d, r, 1.0);
+    return fma(r, e, r);
+}
+__device__ __forceinline__ float refined_rcp(float) { return 0.0f; }
+__device__ __forceinline__ bool plain_numerator(double v) {
+    const unsigned e = ((unsigned)__double2hiint(v) >> 20) & 0x7ffu;
+    return e - 623u <= 800u || v == 0.0;
+}
+__device__ __forceinline__ bool plain_numerator(float) { return false; }
+// q[i] = n[i] / c for the lanes' four numerators; act[i]: the lane uses quotient i
+template <typename V>
+__device__ __forceinline__ void quotients(const V (&n)[4], const bool (&act)[4], V c, V r, bool fast, V (&q)[4]) {
+    if (sizeof(V) == 8 && fast) {
+        bool bad = false;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const V q0 = n[i] * r;
+            q[i] = madd(madd(-c, q0, n[i]), r, q0);
+            bad = bad || (act[i] && !plain_numerator(n[i]));
+        }
+        if (__builtin_amdgcn_ballot_w64(bad) == 0) return;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) q[i] = n[i] / c;
+}
+
 // The in-line neighbours of a pair (h = 2q, 2q + 1) of one colour: O = the pair of the other colour
 // at the same h, nb = the one value beyond it — rule 0: the LEFT thread's second value, rule 1: the
 // RIGHT thread's first (rule = line parity for a red cell, its complement for a black one).
@@ -162,7 +205,10 @@ __device__ __forceinline__ Inline<V> in_line(int rule, const P2<V> &O, V nb) {
 // which costs no memory traffic) and is committed at the top of the NEXT step: a load inside a branch is
 // followed by s_waitcnt vmcnt(0) where the branch rejoins — which also waits for the whole step's
 // prefetch (measured: 4600 of a step's 12000 cycles).
-template <typename V, int MODE, bool NORM, bool XZ>
+// LA: how many steps ahead a step's loads are requested (2: two sets of registers in flight — the vector
+// memory pipe then streams while a step computes and waits at its barrier; the loop runs two steps per
+// iteration so that every register has a fixed role and the step's parity is a compile-time constant).
+template <typename V, int MODE, bool NORM, bool XZ, int LA>
 __global__ __launch_bounds__(512) void plane_kernel(const PlaneKArgs<V> a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char plane_smem[];
     V *const lds = reinterpret_cast<V *>(plane_smem);
@@ -199,10 +245,11 @@ __global__ __launch_bounds__(512) void plane_kernel(const PlaneKArgs<V> a) {
     // a pair of the level vector: colour (0 red, 1 black), plane k, line ja + l; 0 outside the grid
     auto fetch = [&](const __amdgpu_buffer_rsrc_t &rs, int colour, int k, int l) -> P2<V> {
         const bool ok = vl[l] && vx0 && k >= 0 && k < a.nz;
-        P2<V> r = bload2(rs, ok ? ((colour ? a.nr : 0) + k * ps + lb[l]) * int(sizeof(V)) : OOB, V(0));
-        if (!vx1) r.y = V(0);
-        return r;
+        // (a pair's second value is cleared where it is TAKEN — clean() — not here: a select on the loaded
+        // register would be the load's first consumer, in the step that issues it)
+        return bload2(rs, ok ? ((colour ? a.nr : 0) + k * ps + lb[l]) * int(sizeof(V)) : OOB, V(0));
     };
+    auto clean = [&](const P2<V> &r) -> P2<V> { return {r.x, vx1 ? r.y : V(0)}; };
     auto fetch_x = [&](int colour, int k, int l) -> P2<V> {
         if (XZ) return {V(0), V(0)};
         return fetch(xs, colour, k, l);
@@ -231,13 +278,15 @@ __global__ __launch_bounds__(512) void plane_kernel(const PlaneKArgs<V> a) {
         return {x.x + madd(a.w, e.x, V(0)), x.y + madd(a.w, e.y, V(0))};
     };
 
+    const V rc3 = refined_rcp(a.c3);
+    const bool fast = a.fast_div != 0;
     const int row_a = 1 + 2 * py, col = 2 + 2 * px;
     const int idx[2] = {row_a * S + col, (row_a + 1) * S + col};
     for (int i = t; i < 6 * BUF; i += int(blockDim.x)) lds[i] = V(0);
     __syncthreads();
 
     const P2<V> zero2 = {V(0), V(0)};
-    P2<V> XR[3][2], XB[5][2], BR[3][2], BB[2], LXB[2], LXR[2], LBR[2], LBB[2], RB[2];
+    P2<V> XR[3][2], XB[5][2], BR[3][2], BB[2], LXB[LA][2], LXR[LA][2], LBR[LA][2], LBB[LA][2], RB[2];
 #pragma unroll
     for (int l = 0; l < 2; ++l) {
 #pragma unroll
@@ -271,16 +320,19 @@ __global__ __launch_bounds__(512) void plane_kernel(const PlaneKArgs<V> a) {
         }
 #pragma unroll
         for (int l = 0; l < 2; ++l) {
-            XB[0][l] = fetch_x(1, s0, l);            // becomes XB[1] at the first shift
-            XB[1][l] = fetch_x(1, s0 - 1, l);        // becomes XB[2]
+            XB[0][l] = clean(fetch_x(1, s0, l));     // becomes XB[1] at the first shift
+            XB[1][l] = clean(fetch_x(1, s0 - 1, l)); // becomes XB[2]
             if (MODE == 1) {
                 XB[0][l] = prolonged(XB[0][l], E0);
                 XB[1][l] = prolonged(XB[1][l], em);
             }
-            LXB[l] = fetch_x(1, s0 + 1, l);
-            LXR[l] = fetch_x(0, s0, l);
-            LBR[l] = fetch(bs, 0, s0, l);
-            LBB[l] = fetch(bs, 1, s0 - 1, l);
+#pragma unroll
+            for (int d = 0; d < LA; ++d) {            // what steps s0 (, s0 + 1) take at their top
+                LXB[d][l] = fetch_x(1, s0 + d + 1, l);
+                LXR[d][l] = fetch_x(0, s0 + d, l);
+                LBR[d][l] = fetch(bs, 0, s0 + d, l);
+                LBB[d][l] = fetch(bs, 1, s0 + d - 1, l);
+            }
             if (live) lds_put(lds + (0 * 2 + (s0 & 1)) * BUF + idx[l], XB[0][l]);
         }
     }
@@ -292,8 +344,18 @@ __global__ __launch_bounds__(512) void plane_kernel(const PlaneKArgs<V> a) {
 #else
 #define PLANE_STAMP(acc)
 #endif
-    for (int s = s0; s <= z1 + 1; ++s) {
-        const int par = s & 1;
+    // one step; PARC: the parity of s as a type (s0 is even)
+    auto step = [&](auto PARC, const int s) {
+        const int par = PARC;                            // (a compile-time constant after inlining when LA == 2)
+        const int set = LA == 2 ? par : 0;               // the registers this step's loads arrive in, and its requests go to
+        // The step's loads are taken HERE, behind the barrier — not where the compiler would sink the copies
+        // into the state registers (the bottom of the previous step, in front of the barrier): a whole step
+        // to arrive instead of the step's arithmetic only.
+#pragma unroll
+        for (int l = 0; l < 2; ++l) {
+            asm volatile("" : "+v"(LXB[set][l].x), "+v"(LXB[set][l].y), "+v"(LXR[set][l].x), "+v"(LXR[set][l].y));
+            asm volatile("" : "+v"(LBR[set][l].x), "+v"(LBR[set][l].y), "+v"(LBB[set][l].x), "+v"(LBB[set][l].y));
+        }
 #ifdef OMG_PLANE_STAMPS
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         PLANE_STAMP(st_mem)
@@ -318,14 +380,14 @@ __global__ __launch_bounds__(512) void plane_kernel(const PlaneKArgs<V> a) {
             XR[2][l] = XR[1][l]; XR[1][l] = XR[0][l];
             BR[2][l] = BR[1][l]; BR[1][l] = BR[0][l];
             if (MODE == 1) {
-                XB[0][l] = prolonged(LXB[l], par ? E1n : E0);     // plane s + 1: coarse plane (s + 1) >> 1
-                XR[0][l] = prolonged(LXR[l], E0);                 // plane s
+                XB[0][l] = prolonged(clean(LXB[set][l]), par ? E1n : E0);     // plane s + 1: coarse plane (s + 1) >> 1
+                XR[0][l] = prolonged(clean(LXR[set][l]), E0);                 // plane s
             } else {
-                XB[0][l] = LXB[l];
-                XR[0][l] = LXR[l];
+                XB[0][l] = clean(LXB[set][l]);
+                XR[0][l] = clean(LXR[set][l]);
             }
-            BR[0][l] = LBR[l];
-            BB[l] = LBB[l];
+            BR[0][l] = clean(LBR[set][l]);
+            BB[l] = clean(LBB[set][l]);
         }
         if (MODE == 1) {
             E0.x = par ? E1n.x : E0.x; E0.y = par ? E1n.y : E0.y;
@@ -339,27 +401,10 @@ __global__ __launch_bounds__(512) void plane_kernel(const PlaneKArgs<V> a) {
         }
 #pragma unroll
         for (int l = 0; l < 2; ++l) {
-            LXB[l] = fetch_x(1, s + 2, l);
-            LXR[l] = fetch_x(0, s + 1, l);
-            LBR[l] = fetch(bs, 0, s + 1, l);
-            LBB[l] = fetch(bs, 1, s, l);
-        }
-#ifdef OMG_PLANE_STAMPS
-        if (inner && !(a.dbg & 1)) {
-#else
-        if (inner) {
-#endif
-            // red of plane s - 1 and black of plane s - 2 became final in the previous step
-            if (s - 1 >= z0 && s - 1 < z1) {
-#pragma unroll
-                for (int l = 0; l < 2; ++l)
-                    if (vl[l] && vx0) store2(a.x_new + size_t(s - 1) * ps + lb[l], XR[1][l], vx1);
-            }
-            if (s - 2 >= z0 && s - 2 < z1) {
-#pragma unroll
-                for (int l = 0; l < 2; ++l)
-                    if (vl[l] && vx0) store2(a.x_new + a.nr + size_t(s - 2) * ps + lb[l], XB[3][l], vx1);
-            }
+            LXB[set][l] = fetch_x(1, s + LA + 1, l);
+            LXR[set][l] = fetch_x(0, s + LA, l);
+            LBR[set][l] = fetch(bs, 0, s + LA, l);
+            LBB[set][l] = fetch(bs, 1, s + LA - 1, l);
         }
         if (MODE == 0) {
 #ifdef OMG_PLANE_STAMPS
@@ -382,6 +427,8 @@ __global__ __launch_bounds__(512) void plane_kernel(const PlaneKArgs<V> a) {
             {
                 const P2<V> jm = lds_pair(E1 + idx[0] - S), jp = lds_pair(E1 + idx[1] + S);
                 const P2<V> o0 = XB[1][0], o1 = XB[1][1];
+                V num[4], quo[4];
+                bool act[4];
 #pragma unroll
                 for (int l = 0; l < 2; ++l) {
                     const int rule = (l + s) & 1;
@@ -390,12 +437,25 @@ __global__ __launch_bounds__(512) void plane_kernel(const PlaneKArgs<V> a) {
                     const P2<V> D = XR[0][l], Bv = BR[0][l], Km = XB[2][l], Kp = XB[0][l];
                     const V sx = chain_tail(a, chain_head(a, Km.x, Ojm.x, n.imx), D.x, n.ipx, Ojp.x, Kp.x);
                     const V sy = chain_tail(a, chain_head(a, Km.y, Ojm.y, n.imy), D.y, n.ipy, Ojp.y, Kp.y);
-                    // openmg/solvers.py:68   x[i] = x[i] + (b[i] - Aix) / A[i, i]
-                    const V nx_ = D.x + (Bv.x - sx) / a.c3, ny_ = D.y + (Bv.y - sy) / a.c3;
-                    const bool ok = pvB && vl[l];
-                    XR[0][l].x = (ok && vx0) ? nx_ : V(0);
-                    XR[0][l].y = (ok && vx1) ? ny_ : V(0);
+                    num[2 * l] = Bv.x - sx;
+                    num[2 * l + 1] = Bv.y - sy;
+                    act[2 * l] = pvB && vl[l] && vx0;
+                    act[2 * l + 1] = pvB && vl[l] && vx1;
                 }
+                quotients(num, act, a.c3, rc3, fast, quo);
+#pragma unroll
+                for (int l = 0; l < 2; ++l) {
+                    // openmg/solvers.py:68   x[i] = x[i] + (b[i] - Aix) / A[i, i]
+                    XR[0][l].x = act[2 * l] ? XR[0][l].x + quo[2 * l] : V(0);
+                    XR[0][l].y = act[2 * l + 1] ? XR[0][l].y + quo[2 * l + 1] : V(0);
+                }
+            }
+            if (inner && s - 1 >= z0 && s - 1 < z1) {
+                // red of plane s - 1 became final in the previous step (stored here, not at the top: the
+                // vector memory pipe is busy with the step's loads there)
+#pragma unroll
+                for (int l = 0; l < 2; ++l)
+                    if (vl[l] && vx0) store2(a.x_new + size_t(s - 1) * ps + lb[l], XR[1][l], vx1);
             }
             PLANE_STAMP(st_B)
             // C: black sweep of plane s - 1, and the residual of the rows it has just relaxed
@@ -403,26 +463,44 @@ __global__ __launch_bounds__(512) void plane_kernel(const PlaneKArgs<V> a) {
             {
                 const P2<V> jm = lds_pair(E2 + idx[0] - S), jp = lds_pair(E2 + idx[1] + S);
                 const P2<V> o0 = XR[1][0], o1 = XR[1][1];
+                V num[4], quo[4], head[4];
+                bool act[4];
+                Inline<V> nl[2];
+                P2<V> Jp[2];
 #pragma unroll
                 for (int l = 0; l < 2; ++l) {
                     const int rule = (l + s) & 1;
                     const P2<V> O = l ? o1 : o0, Ojm = l ? o0 : jm, Ojp = l ? jp : o1;
-                    const Inline<V> n = in_line(rule, O, E2[idx[l] + (rule ? 2 : -1)]);
+                    nl[l] = in_line(rule, O, E2[idx[l] + (rule ? 2 : -1)]);
+                    Jp[l] = Ojp;
                     const P2<V> D = XB[2][l], Bv = BB[l], Km = XR[2][l], Kp = XR[0][l];
-                    const V hx_ = chain_head(a, Km.x, Ojm.x, n.imx), hy_ = chain_head(a, Km.y, Ojm.y, n.imy);
-                    const V sx = chain_tail(a, hx_, D.x, n.ipx, Ojp.x, Kp.x);
-                    const V sy = chain_tail(a, hy_, D.y, n.ipy, Ojp.y, Kp.y);
-                    const bool ok = pvC && vl[l];
-                    const V nx_ = (ok && vx0) ? D.x + (Bv.x - sx) / a.c3 : V(0);
-                    const V ny_ = (ok && vx1) ? D.y + (Bv.y - sy) / a.c3 : V(0);
+                    head[2 * l] = chain_head(a, Km.x, Ojm.x, nl[l].imx);
+                    head[2 * l + 1] = chain_head(a, Km.y, Ojm.y, nl[l].imy);
+                    num[2 * l] = Bv.x - chain_tail(a, head[2 * l], D.x, nl[l].ipx, Ojp.x, Kp.x);
+                    num[2 * l + 1] = Bv.y - chain_tail(a, head[2 * l + 1], D.y, nl[l].ipy, Ojp.y, Kp.y);
+                    act[2 * l] = pvC && vl[l] && vx0;
+                    act[2 * l + 1] = pvC && vl[l] && vx1;
+                }
+                quotients(num, act, a.c3, rc3, fast, quo);
+#pragma unroll
+                for (int l = 0; l < 2; ++l) {
+                    const P2<V> Bv = BB[l], Kp = XR[0][l];
+                    const V nx_ = act[2 * l] ? XB[2][l].x + quo[2 * l] : V(0);
+                    const V ny_ = act[2 * l + 1] ? XB[2][l].y + quo[2 * l + 1] : V(0);
                     // the same chain with the new x_i: what a residual pass over the updated vector computes
-                    const V tx_ = chain_tail(a, hx_, nx_, n.ipx, Ojp.x, Kp.x);
-                    const V ty_ = chain_tail(a, hy_, ny_, n.ipy, Ojp.y, Kp.y);
-                    rb[l].x = (ok && vx0) ? Bv.x - tx_ : V(0);
-                    rb[l].y = (ok && vx1) ? Bv.y - ty_ : V(0);
+                    const V tx_ = chain_tail(a, head[2 * l], nx_, nl[l].ipx, Jp[l].x, Kp.x);
+                    const V ty_ = chain_tail(a, head[2 * l + 1], ny_, nl[l].ipy, Jp[l].y, Kp.y);
+                    rb[l].x = act[2 * l] ? Bv.x - tx_ : V(0);
+                    rb[l].y = act[2 * l + 1] ? Bv.y - ty_ : V(0);
                     XB[2][l].x = nx_;
                     XB[2][l].y = ny_;
                 }
+            }
+            if (inner && s - 2 >= z0 && s - 2 < z1) {
+                // black of plane s - 2 became final in the previous step
+#pragma unroll
+                for (int l = 0; l < 2; ++l)
+                    if (vl[l] && vx0) store2(a.x_new + a.nr + size_t(s - 2) * ps + lb[l], XB[3][l], vx1);
             }
             PLANE_STAMP(st_C)
             // D: residual of the red rows of plane s - 2
@@ -499,6 +577,14 @@ __global__ __launch_bounds__(512) void plane_kernel(const PlaneKArgs<V> a) {
         PLANE_STAMP(st_cmp)
         __syncthreads();
         PLANE_STAMP(st_bar)
+    };
+    if (LA == 2) {
+        for (int s = s0; s <= z1 + 1; s += 2) {          // s0 even, z1 + 1 odd: whole pairs of steps
+            step(std::integral_constant<int, 0>(), s);
+            step(std::integral_constant<int, 1>(), s + 1);
+        }
+    } else {
+        for (int s = s0; s <= z1 + 1; ++s) step(s & 1, s);
     }
 #ifdef OMG_PLANE_STAMPS
     if ((t & 63) == 0) {
@@ -701,6 +787,7 @@ PlaneKArgs<V> plane_args(const PlaneGeom &g, const V *x_old, V *x_new, const V *
     k.TXq = g.TX / 4; k.TY = g.TY; k.LZ = g.LZ; k.PX = g.PX; k.PY = g.PY; k.ntx = g.ntx; k.nty = g.nty; k.ntz = g.ntz;
     k.c0 = V(g.c[0]); k.c1 = V(g.c[1]); k.c2 = V(g.c[2]); k.c3 = V(g.c[3]); k.c4 = V(g.c[4]); k.c5 = V(g.c[5]); k.c6 = V(g.c[6]);
     k.w = V(g.w);
+    k.fast_div = (std::fabs(g.c[3]) >= 0x1p-400 && std::fabs(g.c[3]) <= 0x1p400) ? 1 : 0;
     k.nxc = g.nx / 2; k.nyc = g.ny / 2; k.nzc = g.nz / 2;
     const int64_t nc = int64_t(k.nxc) * k.nyc * k.nzc;
     k.cvec_bytes = unsigned(nc * int64_t(sizeof(V)));
@@ -753,11 +840,11 @@ void PlanePlan<V>::down(const V *x_old, V *x_new, const V *b, bool x_zero, const
     stamps_begin(k, g, sb);
 #endif
     if (x_zero) {
-        allow_lds(plane_kernel<V, 0, false, true>, g.lds_bytes);
-        hipLaunchKernelGGL((plane_kernel<V, 0, false, true>), dim3(unsigned(g.n_wg)), dim3(unsigned(g.threads)), g.lds_bytes, s, k);
+        allow_lds(plane_kernel<V, 0, false, true, PLANE_LA>, g.lds_bytes);
+        hipLaunchKernelGGL((plane_kernel<V, 0, false, true, PLANE_LA>), dim3(unsigned(g.n_wg)), dim3(unsigned(g.threads)), g.lds_bytes, s, k);
     } else {
-        allow_lds(plane_kernel<V, 0, false, false>, g.lds_bytes);
-        hipLaunchKernelGGL((plane_kernel<V, 0, false, false>), dim3(unsigned(g.n_wg)), dim3(unsigned(g.threads)), g.lds_bytes, s, k);
+        allow_lds(plane_kernel<V, 0, false, false, PLANE_LA>, g.lds_bytes);
+        hipLaunchKernelGGL((plane_kernel<V, 0, false, false, PLANE_LA>), dim3(unsigned(g.n_wg)), dim3(unsigned(g.threads)), g.lds_bytes, s, k);
     }
     OMG_HIP(hipGetLastError());
 #ifdef OMG_PLANE_STAMPS
@@ -774,11 +861,11 @@ void PlanePlan<V>::up(const V *x_old, V *x_new, const V *b, const Coarse &c, dou
     stamps_begin(k, g, sb);
 #endif
     if (out) {
-        allow_lds(plane_kernel<V, 1, true, false>, g.lds_bytes);
-        hipLaunchKernelGGL((plane_kernel<V, 1, true, false>), dim3(unsigned(g.n_wg)), dim3(unsigned(g.threads)), g.lds_bytes, s, k);
+        allow_lds(plane_kernel<V, 1, true, false, PLANE_LA>, g.lds_bytes);
+        hipLaunchKernelGGL((plane_kernel<V, 1, true, false, PLANE_LA>), dim3(unsigned(g.n_wg)), dim3(unsigned(g.threads)), g.lds_bytes, s, k);
     } else {
-        allow_lds(plane_kernel<V, 1, false, false>, g.lds_bytes);
-        hipLaunchKernelGGL((plane_kernel<V, 1, false, false>), dim3(unsigned(g.n_wg)), dim3(unsigned(g.threads)), g.lds_bytes, s, k);
+        allow_lds(plane_kernel<V, 1, false, false, PLANE_LA>, g.lds_bytes);
+        hipLaunchKernelGGL((plane_kernel<V, 1, false, false, PLANE_LA>), dim3(unsigned(g.n_wg)), dim3(unsigned(g.threads)), g.lds_bytes, s, k);
     }
     OMG_HIP(hipGetLastError());
 #ifdef OMG_PLANE_STAMPS
