@@ -128,8 +128,10 @@ int omg_hierarchy_set_info(const omg_hierarchy *h, int level, int set, int64_t *
  *   3 row blocks / 4 rows / 5 entries held as row patterns (one byte per row)
  *   6 entries with a one-byte column code   7 entries with a one-byte value code
  *   8 bytes of the operator one launch over these rows reads from HBM in this format
- *   9 the same for plain int32 CSR: entries * (4 + sizeof value) + 4 * rows                  */
-#define OMG_FORMAT_FIELDS 10
+ *   9 the same for plain int32 CSR: entries * (4 + sizeof value) + 4 * rows
+ *  10 row blocks / 11 entries whose values sit block-transposed beside offset-only row patterns
+ *     (variable coefficients: the one-thread-per-row kernel reads them coalesced)              */
+#define OMG_FORMAT_FIELDS 12
 int omg_hierarchy_format_info(const omg_hierarchy *h, int level, int op, int set, int64_t *out);
 /* Host-only check of that recoding (needs no GPU): codes the operator exactly as an upload
  * would (one smoother set, dtype as in omg_hierarchy_create_ex), decodes it the way the kernels

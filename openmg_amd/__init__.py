@@ -14,6 +14,8 @@ Extra keys understood in the `parameters` dict (ignored by the reference):
     'dtype'     'float64' (default, the reference's precision) or 'float32': the precision the
                 levels are stored and computed in on the device (inputs / outputs stay float64)
 """
+import weakref
+
 import numpy as np
 import scipy.sparse as sp
 
@@ -58,14 +60,11 @@ def _dtype_of(parameters):
 # them each time would dominate.  A cache entry holds the device hierarchy TOGETHER WITH strong
 # references to the list members it was built from, so that neither their ids nor their buffer
 # addresses can be recycled for other matrices while the entry lives, and the key carries a
-# checksum of the stored arrays, so that a matrix edited in place (or rebuilt into the same
-# buffers) misses.  Small operators are hashed whole; above _HASH_ALL_BYTES per array the
-# checksum covers the head, the tail and a strided sample — call clear_cache() after editing a
-# few entries of such a matrix in place.
+# checksum of the stored arrays (every byte), so that a matrix edited in place (or rebuilt into
+# the same buffers) misses.  Members that are not CSR are converted once per object (cached by id
+# while the object lives).
 _cache = {}
 _CACHE_SLOTS = 2
-_HASH_ALL_BYTES = 1 << 22
-_HASH_SAMPLES = 1 << 14
 
 try:
     from xxhash import xxh64_intdigest as _digest
@@ -77,19 +76,38 @@ except ImportError:                                   # pragma: no cover - xxhas
 
 
 def _array_checksum(a):
+    """Checksum of the WHOLE array (xxhash runs at several GB/s: a 256^3 operator costs ~0.3 s per
+    mgCycle call, small next to the 0.4 GB it then ships over PCIe) — an in-place edit of a few
+    entries of a large operator must not hit the stale device copy."""
     a = np.ascontiguousarray(a).reshape(-1)
-    if a.nbytes <= _HASH_ALL_BYTES:
-        return _digest(a.view(np.uint8))
-    step = max(1, a.size // _HASH_SAMPLES)
-    head = _HASH_SAMPLES
-    return (_digest(np.ascontiguousarray(a[:head]).view(np.uint8)), _digest(np.ascontiguousarray(a[-head:]).view(np.uint8)),
-            _digest(np.ascontiguousarray(a[::step]).view(np.uint8)))
+    return _digest(a.view(np.uint8))
+
+
+_csr_of = {}          # id(non-CSR sparse member) -> (weak reference, checksum of its own arrays, its CSR form)
+
+
+def _as_csr_cached(M):
+    """CSR form of a sparse member, converted once while the member lives and keeps its content."""
+    if sp.isspmatrix_csr(M):
+        return M
+    src = tuple(_array_checksum(getattr(M, name)) for name in ("data", "indices", "indptr", "row", "col", "offsets")
+                if isinstance(getattr(M, name, None), np.ndarray))
+    entry = _csr_of.get(id(M))
+    if entry is not None and entry[0]() is M and entry[1] == src:
+        return entry[2]
+    C = sp.csr_matrix(M)
+    try:
+        ref = weakref.ref(M, lambda _r, k=id(M): _csr_of.pop(k, None))
+    except TypeError:                           # not weakly referenceable: convert every time
+        return C
+    _csr_of[id(M)] = (ref, src, C)
+    return C
 
 
 def _fingerprint(A, R, n_levels, code, omega, dtype):
     def one(M):
         if sp.issparse(M):
-            M = M if sp.isspmatrix_csr(M) else sp.csr_matrix(M)
+            M = _as_csr_cached(M)
             return (M.shape, M.nnz, _array_checksum(M.indptr), _array_checksum(M.indices), _array_checksum(M.data))
         M = np.asarray(M)
         return (M.shape, _array_checksum(M))
@@ -216,7 +234,16 @@ def mgCycle(A, b, level, R, parameters, initial=None):
         for l in range(level, coarsest):
             print(l * " " + "calling mgCycle at level %i" % l)
         print(coarsest * " " + "direct solving at level %i" % coarsest)
-    norm = hierarchy.vcycle(b, x, parameters["preIterations"], parameters["postIterations"], level=level)
+    pre = parameters["preIterations"]
+    if (pre > 0 and isinstance(initial, np.ndarray) and initial.dtype == np.float64 and initial.flags.writeable
+            and initial.size == b.size and np.shares_memory(initial, initial.reshape(-1))):
+        # Q2: the reference's pre-smoother works IN PLACE on the caller's `initial`
+        # (openmg/__init__.py:201 -> solvers.py:68,75): after the call it holds the pre-smoothed
+        # iterate, uOut is a new array.  Same sweeps on the device (same bits as inside the cycle).
+        smoothed = x.copy()
+        hierarchy.smooth(level, b, smoothed, pre)
+        initial.reshape(-1)[:] = smoothed
+    norm = hierarchy.vcycle(b, x, pre, parameters["postIterations"], level=level)
     return x, {"norm": norm}
 
 

@@ -360,7 +360,7 @@ class Hierarchy:
         return rows.value, nnz.value
 
     FORMAT_FIELDS = ("rows", "nnz", "blocks", "pattern_blocks", "pattern_rows", "pattern_nnz",
-                     "coldict_nnz", "valdict_nnz", "format_bytes", "csr_bytes")
+                     "coldict_nnz", "valdict_nnz", "format_bytes", "csr_bytes", "ell_blocks", "ell_nnz")
 
     def format_info(self, level, op="A", set=-1):
         """How A / R / P (= R^T) of `level` is held in HBM (omg_hierarchy_format_info)."""

@@ -505,7 +505,8 @@ template <typename V>
 void check_march(Hier<V> *h) {
     for (Level<V> &L : h->lv)
         if (L.march && L.march->timed_out(h->stream))
-            throw Error(OMG_ERR_HIP, "lexicographic wavefront sweep timed out waiting for a neighbouring tile's face");
+            throw Error(OMG_ERR_HIP, "lexicographic wavefront sweep timed out waiting for a neighbouring tile's face; the iterate and "
+                                     "the hand-over slots of this hierarchy are no longer consistent: destroy it and build a new one");
 }
 
 template <typename V>

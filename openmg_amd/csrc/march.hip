@@ -43,6 +43,7 @@ namespace {
 
 constexpr int SYNC_WORDS = 16;     // ticket, finished tiles, error flag
 constexpr int SPIN_LIMIT = 1 << 20;
+constexpr int STORE_SPIN_LIMIT = 1 << 22;   // the storing wave's polls of its own computing wave (LDS), most of them ~1 us apart
 constexpr int FACE_PAD = MARCH_FACE_PAD;
 
 template <typename V>
@@ -227,7 +228,15 @@ __global__ __launch_bounds__(128) void march_gs_kernel(MarchArgs<V> a) {
             const int i0 = blk * U - skew;
             long long t0 = 0;
             if (a.dbg) t0 = wall_clock64();
-            while (lds_flag(&s_ready) <= blk && spins < SPIN_LIMIT) { __builtin_amdgcn_s_sleep(1); ++spins; }
+            // (this wave starts polling when the tile starts and has to outlast the computing wave's whole wait
+            // for the tile's predecessors: back off to ~1 us per poll after a while, and give it seconds)
+            int polls = 0;
+            while (lds_flag(&s_ready) <= blk && polls < STORE_SPIN_LIMIT) {
+                if (polls < 4096) __builtin_amdgcn_s_sleep(1);
+                else __builtin_amdgcn_s_sleep(32);
+                ++polls;
+            }
+            if (polls >= STORE_SPIN_LIMIT) spins = SPIN_LIMIT;
             if (a.dbg) t_wait += wall_clock64() - t0;
             asm volatile("" ::: "memory");
             V out[U];

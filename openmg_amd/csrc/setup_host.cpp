@@ -818,7 +818,7 @@ void format_stats(const std::vector<int32_t> &info, const std::vector<int64_t> &
             out[4] += rows;
             out[5] += ent;
             out[8] += rows;
-            if (rec[2]) out[8] += w * rows * rec[3];              // + the block's (padded) ELL values
+            if (rec[2]) { out[8] += w * rows * rec[3]; out[10] += 1; out[11] += ent; }   // + the block's (padded) ELL values
         } else {
             if (!(rec[6] == 1 && rows_cap > ROWBLK_THREADS)) out[8] += 4 * rows;   // row pointers (not read for one-entry rows)
             if (rec[2]) { out[6] += ent; out[8] += ent; } else out[8] += 4 * ent;

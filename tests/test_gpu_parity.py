@@ -822,6 +822,18 @@ def test_long_rows_pattern_kernel_matches_four_lanes_per_row(monkeypatch, dtype)
     assert out["15"][5] == out["0"][5] >= 8
     wide, plain = out["15"][4], out["0"][4]
     assert wide["pattern_rows"] == wide["rows"] and wide["blocks"] * 4 <= plain["blocks"] + 32    # 256-row blocks vs 64-row
+    # the kernel configs[4] runs at full size — offset patterns + block-transposed (ELL) values on EVERY block
+    assert wide["ell_blocks"] == wide["blocks"] and wide["ell_nnz"] == wide["nnz"] and plain["ell_blocks"] == 0
+    if dtype == "float64":
+        # ... directly against the CPU oracle on the same A / R lists (openmg/__init__.py:151-236 with the
+        # reference's sweep on the greedy colours): 1e-10 on every norm, rtol 1e-9 on the iterate
+        sm = orc.make_smoother("colour", A)
+        p = {"preIterations": 2, "postIterations": 2, "coarsestLevel": len(Rs)}
+        xo = x0.copy()
+        for k in range(2):
+            xo, inf = orc.mg_cycle(A, b, 0, Rs, p, initial=xo, smoother=sm)
+            assert rel(out["15"][2][k], inf["norm"]) < 1e-10, k
+        np.testing.assert_allclose(out["15"][1], xo, rtol=1e-9, atol=1e-12)
     assert np.array_equal(out["15"][0], out["0"][0])
     assert np.array_equal(out["15"][1], out["0"][1])
     np.testing.assert_allclose(out["15"][2], out["0"][2], rtol=1e-13)
@@ -967,3 +979,32 @@ def test_first_relaxation_applied_by_the_restriction_is_bit_identical(monkeypatc
                         out.append((norms, h.resident_fetch()))
                 assert out[0][0] == out[1][0], (shape, dtype, pre, post, graph)
                 assert np.array_equal(out[0][1], out[1][1])
+
+
+def test_mgcycle_overwrites_initial_with_the_presmoothed_iterate():
+    """Q2: the reference's smoother works in place (openmg/solvers.py:68,75), so the array passed as
+    `initial` holds the PRE-SMOOTHED iterate after mgCycle (openmg/__init__.py:201) and uOut is another
+    array.  Checked against the oracle's sequential sweep and, bit for bit, the device's own smoother."""
+    shape = (12, 12, 12)
+    A0 = operators.stencil_poisson(shape)
+    rng = np.random.default_rng(77)
+    b, start = rng.standard_normal(A0.shape[0]), rng.standard_normal(A0.shape[0])
+    R = operators.restrictionList(shape, 1, 8)
+    A = operators.coeffecientList(A0, R)
+    for smoother, pre in (("gs", 1), ("gs", 2), ("colour", 1)):
+        p = {"coarsestLevel": len(R), "preIterations": pre, "postIterations": 1, "smoother": smoother}
+        x0 = start.copy()
+        u, info = openmg_amd.mgCycle(A, b, 0, R, p, initial=x0)
+        assert u is not x0 and not np.array_equal(x0, start)
+        want = start.copy()
+        _hip.gauss_seidel(A[0], b, want, smoother=smoother, iterations=pre)
+        assert np.array_equal(x0, want)
+        if smoother == "gs":
+            np.testing.assert_allclose(x0, orc.gauss_seidel(A[0], b, start.copy(), iterations=pre), rtol=1e-12, atol=1e-14)
+        # the cycle itself is unchanged by that
+        u2, info2 = openmg_amd.mgCycle(A, b, 0, R, p, initial=start.copy())
+        assert np.array_equal(u, u2) and info["norm"] == info2["norm"]
+        # pre = 0: nothing is relaxed in place
+        x1 = start.copy()
+        openmg_amd.mgCycle(A, b, 0, R, dict(p, preIterations=0), initial=x1)
+        assert np.array_equal(x1, start)

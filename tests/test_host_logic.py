@@ -222,11 +222,22 @@ def test_mgcycle_cache_key_follows_content_not_object_identity():
     A[0].data[5] += 1.0
     assert openmg_amd._fingerprint(A, R, 2, 0, 1.0, 0) != before
     assert openmg_amd._fingerprint(A, R, 2, 1, 1.0, 0) != openmg_amd._fingerprint(A, R, 2, 0, 1.0, 0)
-    # large arrays are sampled (head, tail, stride), never skipped
-    big = np.arange(openmg_amd._HASH_ALL_BYTES // 8 + 1000, dtype=np.float64)
+    # large arrays are hashed WHOLE: an edit of one entry anywhere changes the key
+    big = np.arange((1 << 19) + 1000, dtype=np.float64)
     c0 = openmg_amd._array_checksum(big)
-    big[-1] = -1.0
-    assert openmg_amd._array_checksum(big) != c0
+    for where in (-1, 0, 123457, big.size // 2 + 3):
+        keep = big[where]
+        big[where] = -1.0
+        assert openmg_amd._array_checksum(big) != c0
+        big[where] = keep
+    assert openmg_amd._array_checksum(big) == c0
+    # a member that is not CSR is converted once while it lives, and follows in-place edits of the ORIGINAL
+    csc = sp.csc_matrix(A[0])
+    k1 = openmg_amd._fingerprint([csc, A[1]], R, 2, 0, 1.0, 0)
+    assert openmg_amd._as_csr_cached(csc) is openmg_amd._as_csr_cached(csc)
+    assert k1 == openmg_amd._fingerprint([csc, A[1]], R, 2, 0, 1.0, 0)
+    csc.data[3] += 0.5
+    assert openmg_amd._fingerprint([csc, A[1]], R, 2, 0, 1.0, 0) != k1
 
 
 def test_union_partition_is_chosen_and_decodes(monkeypatch):
