@@ -486,9 +486,11 @@ template <typename V>
 struct PlanePlan {
     PlaneGeom g;
     DevBuf<double> partials;          // one per workgroup (+ SUM_FOLD): the up pass's share of ||b - A x||^2
-    // false: the level does not qualify (the caller keeps the set-by-set schedule).  A, R: the
-    // caller's CSR in natural numbering; ord: the level's colour ordering (must be the parity one).
-    bool build(const omg_csr &A, const omg_csr &R, const Ordering &ord);
+    // false: the level does not qualify (the caller keeps the set-by-set schedule; ord untouched).  A, R:
+    // the caller's CSR in natural numbering.  true: ord = the level's colour ordering, written in closed
+    // form (parity colours, red first — what the greedy colouring of such a stencil gives, without its
+    // sequential pass over the rows).
+    bool build(const omg_csr &A, const omg_csr &R, Ordering &ord);
     struct Coarse {
         const int32_t *map = nullptr; // coarse natural index -> slot in the coarse ordering (null: identity)
         V *b = nullptr;               // down: coarse right-hand side

@@ -649,13 +649,23 @@ std::unique_ptr<Hier<V>> create(int n_levels, const omg_csr *A, const omg_csr *R
     for (int l = 0; l + 1 < n_levels; ++l) {
         Lv &L = h->lv[l];
         L.n = A[l].n_rows;
+        if (smoother == OMG_SMOOTH_GS_COLOUR) {
+            SetupTimer tp("plane-pipelined passes: does the level qualify (+ its parity ordering)");
+            std::unique_ptr<PlanePlan<V>> plan(new PlanePlan<V>);
+            L.march.reset();
+            if (plan->build(A[l], R[l], L.ord)) {
+                L.plane = std::move(plan);
+                // OMG_PLANE_CHECK_ORDER=1 (tests): the closed-form ordering is the greedy colouring's
+                if (getenv_flag("OMG_PLANE_CHECK_ORDER")) {
+                    const Ordering g = make_ordering(A[l], smoother);
+                    OMG_REQUIRE(g.sets == L.ord.sets && g.perm == L.ord.perm && g.inv == L.ord.inv,
+                                "internal: the parity ordering differs from the greedy colouring");
+                }
+                continue;
+            }
+        }
         SetupTimer tm("ordering (colouring / level schedule / wavefront plan)");
         order_level(L, A[l], smoother, h->stream);
-        if (smoother == OMG_SMOOTH_GS_COLOUR) {
-            SetupTimer tp("plane-pipelined passes: does the level qualify");
-            std::unique_ptr<PlanePlan<V>> plan(new PlanePlan<V>);
-            if (plan->build(A[l], R[l], L.ord)) L.plane = std::move(plan);
-        }
     }
     for (int l = 0; l < n_levels; ++l) {
         Lv &L = h->lv[l];

@@ -663,7 +663,7 @@ void choose_tiles(PlaneGeom &g, size_t value_bytes) {
 }  // namespace
 
 template <typename V>
-bool PlanePlan<V>::build(const omg_csr &A, const omg_csr &R, const Ordering &ord) {
+bool PlanePlan<V>::build(const omg_csr &A, const omg_csr &R, Ordering &ord) {
     {
         const char *e = getenv("OMG_PLANE");
         if (e && e[0] == '0') return false;
@@ -689,8 +689,9 @@ bool PlanePlan<V>::build(const omg_csr &A, const omg_csr &R, const Ordering &ord
     const int64_t nz = lines / ny;
     if ((nx & 1) || (ny & 1) || (nz & 1) || ny < 2 || nz < 2) return false;
     const int64_t sj = nx, sk = nx * ny;
-    // two colours by parity, red first: the ordering the greedy colouring finds on such a stencil
-    if (ord.identity || ord.sets.size() != 3 || ord.sets[1] != n / 2 || int64_t(ord.inv.size()) != n) return false;
+    // (the ordering — two colours by parity, red first — is WRITTEN below once the level has qualified: it is
+    // what the greedy smallest-free-colour pass in natural order finds on such a stencil, every lower
+    // neighbour of a cell having the other parity; tests/test_gpu_plane.py compares the two)
     // the coefficients: from the first row that has each slot
     bool havec[7] = {false, false, false, false, false, false, false};
     double c[7] = {0, 0, 0, 0, 0, 0, 0};
@@ -739,8 +740,6 @@ bool PlanePlan<V>::build(const omg_csr &A, const omg_csr &R, const Ordering &ord
                 ++p;
             }
             if (p != pe) { ok = false; return; }
-            const int64_t want = ((i + jl + kl) & 1 ? n / 2 : 0) + r / 2;
-            if (ord.inv[r] != want) { ok = false; return; }
         }
         const int64_t clo = R.n_rows * tnum / nt, chi = R.n_rows * (tnum + 1) / nt;
         for (int64_t cr = clo; cr < chi; ++cr) {
@@ -762,6 +761,26 @@ bool PlanePlan<V>::build(const omg_csr &A, const omg_csr &R, const Ordering &ord
         for (auto &q : th) q.join();
     }
     if (!ok) return false;
+    ord = Ordering();
+    ord.identity = false;
+    ord.sets = {0, n / 2, n};
+    ord.perm.resize(size_t(n));
+    ord.inv.resize(size_t(n));
+    {
+        auto fill = [&](int tnum) {
+            const int64_t lo = n * tnum / nt, hi = n * (tnum + 1) / nt;
+            for (int64_t r = lo; r < hi; ++r) {
+                const int64_t i = r % nx, jl = (r / nx) % ny, kl = r / sk;
+                const int64_t slot = ((i + jl + kl) & 1 ? n / 2 : 0) + r / 2;
+                ord.inv[size_t(r)] = int32_t(slot);
+                ord.perm[size_t(slot)] = int32_t(r);
+            }
+        };
+        std::vector<std::thread> th;
+        for (int tnum = 1; tnum < nt; ++tnum) th.emplace_back(fill, tnum);
+        fill(0);
+        for (auto &q : th) q.join();
+    }
     // (a float level holds the rounded coefficients: every entry with one value rounds to one value)
     g = PlaneGeom();
     g.nx = (int)nx; g.ny = (int)ny; g.nz = (int)nz; g.hx = (int)(nx / 2);

@@ -85,6 +85,16 @@ def test_plane_passes_have_the_bits_of_the_set_schedule(shape, grids):
             assert got[0] == ref[0] and np.array_equal(got[1], ref[1])
 
 
+def test_parity_ordering_is_the_greedy_colouring(monkeypatch):
+    """A level that qualifies gets its red-black ordering in closed form instead of the sequential greedy
+    pass; OMG_PLANE_CHECK_ORDER=1 makes the library compare the two (sets, perm, inv) at creation."""
+    monkeypatch.setenv("OMG_PLANE_CHECK_ORDER", "1")
+    for shape, grids in (((16, 16, 16), 3), ((8, 12, 20), 2), ((10, 8, 6), 2), ((40, 24, 72), 3)):
+        A, R = hierarchy(shape, grids)
+        with _hip.Hierarchy(A, R, smoother="colour") as h:
+            assert h.level_flags(0)["plane"] and h.level_sets(0) == 2
+
+
 @pytest.mark.parametrize("tile", ["4,2,2", "8,4,2", "8,2,4", "12,6,4", "16,8,8", "64,32,32", "32,8,2"])
 def test_plane_tilings_agree(monkeypatch, tile):
     """Every tiling — rings, partial tiles at the grid's edges, chunks of two planes — is the same

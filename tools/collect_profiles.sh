@@ -1,8 +1,8 @@
 #!/bin/bash
 # Everything under profiles/rNN_* from ONE gpurun call (run from the repository root on the GPU box):
-#     OMG_GIT_HEAD=$(git rev-parse HEAD) gpurun -- 'bash tools/collect_profiles.sh r02'
+#     OMG_GIT_HEAD=$(git rev-parse HEAD) gpurun -- 'bash tools/collect_profiles.sh r03'
 # writes gpurun_out/fin/<prefix>_*; copy what is to be judged into profiles/.
-p=${1:-r02}
+p=${1:-r03}
 root=$(cd "$(dirname "$0")/.." && pwd)
 out=$root/gpurun_out/fin
 rm -rf "$out"; mkdir -p "$out"
@@ -11,13 +11,11 @@ last() { tail -1 "$1" > "$2"; }
 timeout 600 python bench.py > $out/bench.log 2>$out/bench.err; last $out/bench.log $out/${p}_bench.json
 timeout 300 python bench.py --no-cpu --no-plain --no-lex --dtype f32 > $out/f32.log 2>/dev/null; last $out/f32.log $out/${p}_bench_f32.json
 timeout 300 python bench.py --dist 1 --no-cpu > $out/dist1.log 2>/dev/null; last $out/dist1.log $out/${p}_bench_dist1.json
-OMG_NO_PRENORM=1 OMG_NO_FIRST_SWEEP=1 timeout 300 python bench.py --no-cpu --no-plain --no-lex > $out/plain.log 2>/dev/null; last $out/plain.log $out/${p}_bench_plain_schedule.json
 timeout 600 python tools/run_configs.py > $out/${p}_configs.txt 2>&1
-OMG_MARCH=0 timeout 300 python tools/run_configs.py 0 4 5 > $out/${p}_configs_level_sets.txt 2>&1
 timeout 900 python tools/config3_single.py 512 6 > $out/${p}_config3_single_gpu.txt 2>&1
-[ -x tools/build/tail_probe ] && timeout 60 tools/build/tail_probe 21 > $out/${p}_tail_probe.txt 2>&1
-[ -x build/lat_probe ] && timeout 60 build/lat_probe > $out/${p}_lat_probe.txt 2>&1
+timeout 600 python tools/config4_probe.py --size 256 > $out/${p}_config4_256_fp32.txt 2>&1
 OMG_MARCH_DEBUG=1 timeout 120 python tools/march_probe.py 8x8x2048 8x64x2048 32x32x32 128x128x128 256x256x256 2> $out/${p}_march_timeline.txt > /dev/null
+OMG_SETUP_TIMING=1 timeout 120 python tools/setup_timing.py > $out/${p}_setup_timing.txt 2>&1
 cd /tmp && export TMPDIR=/tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -o b -- python3 $root/bench.py --no-cpu > $out/under.log 2>/dev/null
 last $out/under.log $out/${p}_bench_under_rocprof.json
@@ -28,9 +26,9 @@ python3 $root/tools/cycle_timeline.py $out/cyc/c_kernel_trace.csv -3 > $out/${p}
 timeout 300 rocprofv3 --kernel-trace --output-format csv -d $out/lex -o l -- python3 $root/tools/run_configs.py 0 4 5 > /dev/null 2>&1
 python3 $root/tools/march_trace.py $out/lex/l_kernel_trace.csv > $out/${p}_march_by_level.txt 2>&1
 cd "$root"
-PASSES="1 2 4 5 7 8" bash tools/pmc_passes.sh gpurun_out/fin/pmc > $out/pmc.log 2>&1
-python tools/pmc_table.py gpurun_out/fin/pmc 4000 > $out/${p}_pmc_union_kernels.txt 2>&1
-python tools/pmc_residual_json.py gpurun_out/fin/pmc $out/${p}_bench.json $out/${p}_pmc_residual.json \
-  "tools/pmc_passes.sh passes 7 and 8 (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, --kernel-include-regex 'rows_(pattern_|union_)?kernel', tools/prof_cycle.py --steps 2), table in profiles/${p}_pmc_union_kernels.txt" > $out/pmc_json.log 2>&1
+PASSES="1 2 4 5 6 7" bash tools/pmc_plane.sh gpurun_out/fin/pmc > $out/pmc.log 2>&1
+python tools/pmc_any.py gpurun_out/fin/pmc > $out/${p}_pmc_plane_kernels.txt 2>&1
+python tools/pmc_plane_json.py gpurun_out/fin/pmc $out/${p}_bench.json $out/${p}_pmc_plane_down.json \
+  "tools/pmc_plane.sh passes 6 and 7 (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, --kernel-include-regex plane_kernel, tools/prof_cycle.py --steps 2), table in profiles/${p}_pmc_plane_kernels.txt" > $out/pmc_json.log 2>&1
 rm -rf $out/trace $out/cyc $out/lex $out/pmc
 ls -la $out

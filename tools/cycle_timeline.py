@@ -19,8 +19,12 @@ def main(path, which=-4):
     gaps = 0
     for s, e, n, g in cyc:
         m = re.search(r"(rows_kernel<\d|rows_pattern_kernel<\d|rows_union_kernel<\d|rows_serial_kernel<\d|\w+_kernel|__amd\w+)", n)
-        print("%8.1f gap %6.1f dur %7.1f  %s wgs %d" % ((s - t0) / 1e3, (s - prev_end) / 1e3, (e - s) / 1e3,
-                                                      m.group(1) if m else n[:30], g // 256 if g >= 256 else g))
+        label = m.group(1) if m else n[:30]
+        pm = re.search(r"plane_kernel<(\w+), (\d+), (true|false), (true|false)", n)
+        if pm:
+            label = "plane_kernel<%s%s%s>" % ("down" if pm.group(2) == "0" else "up", ", norm" if pm.group(3) == "true" else "",
+                                              ", x=0" if pm.group(4) == "true" else "")
+        print("%8.1f gap %6.1f dur %7.1f  %s grid %d" % ((s - t0) / 1e3, (s - prev_end) / 1e3, (e - s) / 1e3, label, g))
         tot += e - s
         gaps += max(0, s - prev_end)
         prev_end = e

@@ -15,6 +15,10 @@ MODES = {0: "spmv", 1: "residual", 2: "resnorm", 3: "gs", 4: "jacobi", 5: "axpy"
 
 
 def short(name):
+    m = re.search(r"plane_kernel<(\w+), (\d+), (true|false), (true|false), (\d+)>", name)
+    if m:
+        return "plane_kernel<%s, %s%s%s>" % (m.group(1), "down" if m.group(2) == "0" else "up", ", norm" if m.group(3) == "true" else "",
+                                             ", x=0" if m.group(4) == "true" else "")
     m = re.search(r"rows_union_kernel<(\d+), (\d+), (\d+), (\w+)>", name)
     if m:
         return "rows_union_kernel<%s, U%s, %s>" % (MODES[int(m.group(1))], m.group(2), m.group(4))
