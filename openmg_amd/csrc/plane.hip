@@ -33,6 +33,13 @@
 namespace omg {
 namespace {
 
+// cache policy of the x_new stores: 0 = plain; 16 = sc1 (write-through: the lines leave the XCD's L2 while the
+// kernel runs instead of in one write-back at its end — the 5-6 us gap behind every level-0 pass in the
+// trace); measured at 256^3: 134.6 / 124.2 us per pass and 388 us per cycle with sc1, 132.8 / 123.0 and 387
+// plain, nt (2) 131.6 / 124.4 and 389 — no difference worth a policy
+#ifndef PLANE_STORE_AUX
+#define PLANE_STORE_AUX 0
+#endif
 typedef unsigned v2u __attribute__((ext_vector_type(2)));
 typedef unsigned v4u __attribute__((ext_vector_type(4)));
 typedef int v2i __attribute__((ext_vector_type(2)));
@@ -82,6 +89,21 @@ __device__ __forceinline__ void lds_put(V *p, const P2<V> &v) {
     q.x = v.x;
     q.y = v.y;
     *reinterpret_cast<typename VecOf<V>::type *>(p) = q;
+}
+__device__ __forceinline__ void bstore2(__amdgpu_buffer_rsrc_t rs, int off, const P2<double> &v, bool both) {
+    if (both) {
+        const v2u lo = __builtin_bit_cast(v2u, v.x), hi = __builtin_bit_cast(v2u, v.y);
+        __builtin_amdgcn_raw_buffer_store_b128(v4u{lo.x, lo.y, hi.x, hi.y}, rs, off, 0, PLANE_STORE_AUX);
+    } else {
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, v.x), rs, off, 0, PLANE_STORE_AUX);
+    }
+}
+__device__ __forceinline__ void bstore2(__amdgpu_buffer_rsrc_t rs, int off, const P2<float> &v, bool both) {
+    if (both) {
+        __builtin_amdgcn_raw_buffer_store_b64(v2u{__builtin_bit_cast(unsigned, v.x), __builtin_bit_cast(unsigned, v.y)}, rs, off, 0, PLANE_STORE_AUX);
+    } else {
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v.x), rs, off, 0, PLANE_STORE_AUX);
+    }
 }
 template <typename V>
 __device__ __forceinline__ void store2(V *p, const P2<V> &v, bool both) {
@@ -239,6 +261,7 @@ __global__ __launch_bounds__(512) void plane_kernel(const PlaneKArgs<V> a) {
 
     const __amdgpu_buffer_rsrc_t xs = __builtin_amdgcn_make_buffer_rsrc(const_cast<V *>(a.x_old), 0, a.vec_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t bs = __builtin_amdgcn_make_buffer_rsrc(const_cast<V *>(a.b), 0, a.vec_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ws = __builtin_amdgcn_make_buffer_rsrc(a.x_new, 0, a.vec_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t es = __builtin_amdgcn_make_buffer_rsrc(const_cast<V *>(MODE == 1 ? a.ec : a.cdiag), 0, a.cvec_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t ms = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t *>(a.cmap), 0, a.cmap_bytes, 0x00020000);
 
@@ -455,7 +478,7 @@ __global__ __launch_bounds__(512) void plane_kernel(const PlaneKArgs<V> a) {
                 // vector memory pipe is busy with the step's loads there)
 #pragma unroll
                 for (int l = 0; l < 2; ++l)
-                    if (vl[l] && vx0) store2(a.x_new + size_t(s - 1) * ps + lb[l], XR[1][l], vx1);
+                    if (vl[l] && vx0) bstore2(ws, ((s - 1) * ps + lb[l]) * int(sizeof(V)), XR[1][l], vx1);
             }
             PLANE_STAMP(st_B)
             // C: black sweep of plane s - 1, and the residual of the rows it has just relaxed
@@ -500,7 +523,7 @@ __global__ __launch_bounds__(512) void plane_kernel(const PlaneKArgs<V> a) {
                 // black of plane s - 2 became final in the previous step
 #pragma unroll
                 for (int l = 0; l < 2; ++l)
-                    if (vl[l] && vx0) store2(a.x_new + a.nr + size_t(s - 2) * ps + lb[l], XB[3][l], vx1);
+                    if (vl[l] && vx0) bstore2(ws, (a.nr + (s - 2) * ps + lb[l]) * int(sizeof(V)), XB[3][l], vx1);
             }
             PLANE_STAMP(st_C)
             // D: residual of the red rows of plane s - 2
