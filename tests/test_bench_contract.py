@@ -1,4 +1,4 @@
-"""The committed bench line and the PMC profile it may quote (profiles/r02_*): the driver's contract
+"""The committed bench line and the PMC profile it may quote (profiles/r03_*): the driver's contract
 keys, a roofline fraction that is a fraction, and the rule that HBM traffic measured by rocprofv3 is
 only ever attached to a build whose kernel sources hash to the profile's."""
 import json
@@ -16,7 +16,7 @@ def _load(name):
 
 
 def test_committed_bench_line_keeps_the_contract():
-    d = _load("r02_bench.json")
+    d = _load("r03_bench.json")
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                 "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert key in d, key
@@ -32,19 +32,22 @@ def test_committed_bench_line_keeps_the_contract():
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] == 1 and c["unit"] == "V-cycles/s" and c["value"] > 0 and c["sample"]
     assert d["csr_path"]["residual"]["frac"] <= 1.0 and d["csr_path"]["fine_grid_spmv"]["frac"] <= 1.0
+    assert all(d["config"]["plane_levels"]) and d["set_schedule"]["vcycles_per_s"] < d["value"]
+    for k in ("plane_down", "plane_up"):
+        assert 0.0 < r["level0_kernels"][k]["frac"] <= 1.0 and r["level0_kernels"][k]["launches_per_cycle"] == 1.0
     assert d["reference_smoother"]["vcycles_per_s"] > 0 and all(d["reference_smoother"]["wavefront_levels"])
     assert re.fullmatch(r"[0-9a-f]{16}", d["config"]["kernel_src_sha"]) and re.fullmatch(r"[0-9a-f]{40}", d["config"]["git_head"])
 
 
 def test_pmc_traffic_is_tied_to_the_kernel_sources_it_was_measured_on():
-    p = _load("r02_pmc_residual.json")
+    p = _load("r03_pmc_plane_down.json")
     assert re.fullmatch(r"[0-9a-f]{16}", p["kernel_src_sha"]) and re.fullmatch(r"[0-9a-f]{40}", p["git_head_at_collection"])
     assert p["traffic_bytes"] == p["read_bytes"] + p["write_bytes"]
     assert abs(p["read_bytes"] - 2 * p["fetch_size_KiB"] * 1024) < 1024          # gfx950: reads = 2 x FETCH_SIZE
     assert p["traffic_bytes"] >= p["bytes_per_launch"]                           # over-fetch, never under
     h = bench.kernel_source_hash()
     assert re.fullmatch(r"[0-9a-f]{16}", h) and h == bench.kernel_source_hash()
-    d = _load("r02_bench.json")
+    d = _load("r03_bench.json")
     if d["roofline"]["traffic"] is not None:                                     # only a run of the profiled build may carry it
         # (the line quotes the PMC passes that were committed when it ran; the profile next to it may be a
         # later collection on the same sources: FETCH_SIZE varies by a few hundred bytes from pass to pass)
