@@ -13,8 +13,6 @@
 #include <memory>
 #include <numeric>
 
-#include <hipcub/hipcub.hpp>
-
 #include "common.h"
 
 using namespace omg;
@@ -104,6 +102,9 @@ __global__ void compact_rows_kernel(int64_t n, const int64_t *off, const int32_t
     }
 }
 
+// indptr[0..n] = exclusive scan of len[0..n) on the device (below); returns the total
+int64_t device_row_pointers(int64_t n, const int32_t *len, int32_t *indptr, hipStream_t s);
+
 int grid1d(int64_t n) {
     int64_t g = (n + 255) / 256;
     if (g > 65536) g = 65536;
@@ -159,10 +160,7 @@ void device_transpose(const DevMat &X, DevMat &T, hipStream_t s) {
     DevBuf<int32_t> cnt(nc + 2);
     OMG_HIP(hipMemsetAsync(cnt.p, 0, size_t(nc + 2) * sizeof(int32_t), s));
     hipLaunchKernelGGL(count_columns_kernel, dim3(grid1d(X.nnz)), dim3(256), 0, s, X.nnz, X.indices.p, cnt.p);
-    size_t bytes = 0;
-    OMG_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, cnt.p, T.indptr.p, int(nc + 1), s));
-    DevBuf<unsigned char> tmp(bytes + 16);
-    OMG_HIP(hipcub::DeviceScan::ExclusiveSum(tmp.p, bytes, cnt.p, T.indptr.p, int(nc + 1), s));
+    (void)device_row_pointers(nc, cnt.p, T.indptr.p, s);          // (own wave-scan kernels; no library scan)
     OMG_HIP(hipMemsetAsync(cnt.p, 0, size_t(nc + 2) * sizeof(int32_t), s));
     hipLaunchKernelGGL(scatter_transpose_kernel, dim3(grid1d(X.n_rows)), dim3(256), 0, s, X.n_rows, X.indptr.p,
                        X.indices.p, X.data.p, T.indptr.p, cnt.p, T.indices.p, T.data.p);
@@ -192,24 +190,297 @@ void spgemm(const DevMat &X, const DevMat &Y, omg_csr_result &C, hipStream_t s) 
     hipLaunchKernelGGL(gustavson_rows_kernel, dim3(grid1d(n)), dim3(256), 0, s, n, X.indptr.p,
                        X.indices.p, X.data.p, Y.indptr.p, Y.indices.p, Y.data.p, off.p, scols.p,
                        svals.p, row_nnz.p);
-    std::vector<int32_t> h_nnz(n), h_cp(n + 1, 0);
-    row_nnz.download(h_nnz.data(), n, s);
-    OMG_HIP(hipStreamSynchronize(s));
-    int64_t acc = 0;
-    for (int64_t i = 0; i < n; ++i) {
-        acc += h_nnz[i];
-        OMG_REQUIRE(acc < INT32_MAX, "spgemm: result exceeds int32 nnz");
-        h_cp[i + 1] = (int32_t)acc;
-    }
-    C.nnz = acc;
     C.indptr.alloc(n + 1);
-    C.indptr.upload(h_cp.data(), n + 1, s);
+    const int64_t acc = device_row_pointers(n, row_nnz.p, C.indptr.p, s);
+    C.nnz = acc;
     C.indices.alloc(std::max<int64_t>(acc, 1));
     C.data.alloc(std::max<int64_t>(acc, 1));
     hipLaunchKernelGGL(compact_rows_kernel, dim3(grid1d(n)), dim3(256), 0, s, n, off.p, scols.p,
                        svals.p, C.indptr.p, C.indices.p, C.data.p);
     OMG_HIP(hipGetLastError());
     OMG_HIP(hipStreamSynchronize(s));
+}
+
+// ---- row pointers: exclusive scan of the row lengths on the device -------------------------------------
+// Three small launches (a workgroup's total, the totals' scan by one workgroup, the final offsets); the
+// lengths of a workgroup's 1024 rows are scanned by its waves (shuffle scan) and its 16 wave totals in LDS.
+constexpr int SCAN_WG = 1024;
+__device__ __forceinline__ int wave_inclusive_scan(int v) {
+    const int lane = int(threadIdx.x) & 63;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int t = __shfl_up(v, off, 64);
+        if (lane >= off) v += t;
+    }
+    return v;
+}
+// out[i] = base + exclusive scan of in[] inside the workgroup's 1024 entries; total[wg] = their sum
+__global__ __launch_bounds__(SCAN_WG) void scan_local_kernel(int64_t n, const int32_t *in, int32_t *out, int64_t *total) {
+    __shared__ int s_wave[SCAN_WG / 64];
+    const int64_t i = int64_t(blockIdx.x) * SCAN_WG + threadIdx.x;
+    const int v = i < n ? in[i] : 0;
+    const int inc = wave_inclusive_scan(v);
+    const int lane = int(threadIdx.x) & 63, wave = int(threadIdx.x) >> 6;
+    if (lane == 63) s_wave[wave] = inc;
+    __syncthreads();
+    int before = 0;
+    for (int w = 0; w < wave; ++w) before += s_wave[w];
+    if (i < n) out[i] = before + inc - v;
+    if (threadIdx.x == SCAN_WG - 1) total[blockIdx.x] = int64_t(before) + inc;
+}
+// exclusive scan of the workgroup totals (one workgroup, sequential over chunks of 1024), grand total behind them
+__global__ __launch_bounds__(SCAN_WG) void scan_totals_kernel(int64_t n_wg, int64_t *total) {
+    __shared__ long long s_wave[SCAN_WG / 64];
+    __shared__ long long s_carry;
+    if (threadIdx.x == 0) s_carry = 0;
+    __syncthreads();
+    for (int64_t base = 0; base < n_wg; base += SCAN_WG) {
+        const int64_t i = base + threadIdx.x;
+        const long long v = i < n_wg ? total[i] : 0;
+        long long inc = v;
+        const int lane = int(threadIdx.x) & 63, wave = int(threadIdx.x) >> 6;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const long long t = __shfl_up(inc, off, 64);
+            if (lane >= off) inc += t;
+        }
+        if (lane == 63) s_wave[wave] = inc;
+        __syncthreads();
+        long long before = s_carry;
+        for (int w = 0; w < wave; ++w) before += s_wave[w];
+        if (i < n_wg) total[i] = before + inc - v;
+        __syncthreads();
+        if (threadIdx.x == SCAN_WG - 1) s_carry = before + inc;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) total[n_wg] = s_carry;
+}
+__global__ __launch_bounds__(SCAN_WG) void scan_add_kernel(int64_t n, int32_t *out, const int64_t *total) {
+    const int64_t i = int64_t(blockIdx.x) * SCAN_WG + threadIdx.x;
+    if (i < n) out[i] += int32_t(total[blockIdx.x]);
+    if (i == n - 1 || (n == 0 && i == 0)) out[n] = int32_t(total[gridDim.x]);
+}
+// indptr[0..n] = exclusive scan of len[0..n); returns the total (synchronises)
+int64_t device_row_pointers(int64_t n, const int32_t *len, int32_t *indptr, hipStream_t s) {
+    if (n == 0) { OMG_HIP(hipMemsetAsync(indptr, 0, sizeof(int32_t), s)); return 0; }
+    const int64_t n_wg = (n + SCAN_WG - 1) / SCAN_WG;
+    DevBuf<int64_t> total(n_wg + 1);
+    hipLaunchKernelGGL(scan_local_kernel, dim3(unsigned(n_wg)), dim3(SCAN_WG), 0, s, n, len, indptr, total.p);
+    hipLaunchKernelGGL(scan_totals_kernel, dim3(1), dim3(SCAN_WG), 0, s, n_wg, total.p);
+    hipLaunchKernelGGL(scan_add_kernel, dim3(unsigned(n_wg)), dim3(SCAN_WG), 0, s, n, indptr, total.p);
+    OMG_HIP(hipGetLastError());
+    int64_t grand = 0;
+    OMG_HIP(hipMemcpyAsync(&grand, total.p + n_wg, sizeof(int64_t), hipMemcpyDeviceToHost, s));
+    OMG_HIP(hipStreamSynchronize(s));
+    OMG_REQUIRE(grand < INT32_MAX, "sparse product: result exceeds int32 nnz");
+    return grand;
+}
+
+// ---- fused Galerkin product for an aggregation restriction ------------------------------------------------
+// (R A) R^T of openmg/operators.py:184-186 where every column of R holds exactly ONE entry (cell
+// aggregation: a fine unknown belongs to one coarse one) and A's rows have ascending columns — the
+// hierarchy path.  One WAVE per coarse row I, both products in LDS, no intermediate in HBM:
+//   1. (R A)(I, j) for the columns j of the rows k of I's aggregate: k in R's stored order (one after the
+//      other), the entries of row k by the lanes, product R(I,k) * A(k,j) rounded, then ADDED to the
+//      column's sum in a hash table keyed by j — per column the additions of SciPy's csr_matmat in its
+//      order; sums that are exactly zero are dropped, as SciPy drops them;
+//   2. C(I, J) = sum over the j of aggregate J, ascending j, of (R A)(I, j) * R(J, j): the kept columns
+//      are ranked by (J, j) (a rank sort: a few hundred keys per row), a lane adds up one J's run in that
+//      order, zero sums are dropped, and the row comes out with ascending columns.
+// Exactly the arithmetic, in exactly the order, of spgemm(spgemm(R, A), R^T) above (tests: bit for bit
+// against it, and against the reference's products of golden g3).  Two passes — row lengths, then the
+// entries straight into the result — instead of a scratch list per row.
+constexpr int RAP_WAVES = 4;          // coarse rows per workgroup
+constexpr int RAP_CAP = 512;          // hash slots per wave (distinct columns of a row's aggregate: at most RAP_CAP / 2)
+constexpr int RAP_EMPTY = -1;
+
+__global__ void column_owner_kernel(int64_t n_rows, const int32_t *rp, const int32_t *ri, const double *rv,
+                                    int32_t *owner, double *weight, int32_t *seen) {
+    for (int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r < n_rows; r += (int64_t)gridDim.x * blockDim.x)
+        for (int32_t p = rp[r]; p < rp[r + 1]; ++p) {
+            const int32_t c = ri[p];
+            owner[c] = int32_t(r);
+            weight[c] = rv[p];
+            atomicAdd(&seen[c], 1);
+        }
+}
+// flag[0] |= 1 when some column of R is owned more than once (or never: handled by owner = -1);
+// flag[0] |= 2 when a row of A has columns that do not ascend strictly; flag[1] = max over coarse rows of
+// the number of entries of its aggregate's rows
+__global__ void rap_check_kernel(int64_t n, int64_t nc, const int32_t *seen, const int32_t *ap, const int32_t *ai,
+                                 const int32_t *rp, const int32_t *ri, int32_t *flag) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        if (seen[i] > 1) atomicOr(&flag[0], 1);
+        for (int32_t p = ap[i] + 1; p < ap[i + 1]; ++p)
+            if (ai[p] <= ai[p - 1]) { atomicOr(&flag[0], 2); break; }
+        if (i < nc) {
+            int32_t t = 0;
+            for (int32_t p = rp[i]; p < rp[i + 1]; ++p) t += ap[ri[p] + 1] - ap[ri[p]];
+            atomicMax(&flag[1], t);
+        }
+    }
+}
+
+template <bool FILL, int CAP>
+__global__ __launch_bounds__(RAP_WAVES * 64) void rap_aggregation_kernel(
+    int64_t nc, const int32_t *rp, const int32_t *ri, const double *rv, const int32_t *ap, const int32_t *ai,
+    const double *av, const int32_t *owner, const double *weight, int32_t *row_len, const int32_t *cp, int32_t *ci,
+    double *cv) {
+    __shared__ int s_key[RAP_WAVES][CAP];
+    __shared__ double s_val[RAP_WAVES][CAP];
+    __shared__ unsigned long long s_sort[RAP_WAVES][CAP / 2];     // (J << 32 | j) of the kept columns, then ranked
+    __shared__ double s_prod[RAP_WAVES][CAP / 2];
+    const int lane = int(threadIdx.x) & 63, wave = int(threadIdx.x) >> 6;
+    const int64_t I = int64_t(blockIdx.x) * RAP_WAVES + wave;
+    if (I >= nc) return;                                             // (whole waves: no workgroup barrier below)
+    int *key = s_key[wave];
+    double *val = s_val[wave];
+    unsigned long long *srt = s_sort[wave];
+    double *prd = s_prod[wave];
+    for (int q = lane; q < CAP; q += 64) key[q] = RAP_EMPTY;
+    // 1. (R A)(I, :).  All of the aggregate's rows are fetched at once (two dependent loads instead of three
+    // per row): lane m takes R's entry m and row k_m's extent, a wave scan lays the rows' entries end to end,
+    // every lane then fetches entries of that list (products into LDS); the additions follow row by row.
+    const int32_t r0 = rp[I], nk = rp[I + 1] - r0;
+    int32_t *ent_j = reinterpret_cast<int32_t *>(srt);               // staging (the sort arrays are free until step 2)
+    double *ent_p = prd;
+    int done = 0;                                                    // rows of the aggregate handled so far (64 per round)
+    while (done < nk) {
+        const int m = done + lane;
+        int32_t k = 0, beg = 0, len = 0;
+        double r = 0.0;
+        if (m < nk) { k = ri[r0 + m]; r = rv[r0 + m]; beg = ap[k]; len = ap[k + 1] - beg; }
+        int inc = len;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int t = __shfl_up(inc, off, 64);
+            if (lane >= off) inc += t;
+        }
+        const int total = __shfl(inc, 63, 64);                      // <= CAP / 2 (host check)
+        const int start = inc - len;
+        const int rows_here = min(64, nk - done);
+        for (int e = lane; e < total; e += 64) {
+            // the row this entry belongs to: the last one whose start is <= e
+            int row = 0;
+            for (int q = 1; q < rows_here; ++q) row = __shfl(start, q, 64) <= e ? q : row;
+            const int32_t p = __shfl(beg, row, 64) + (e - __shfl(start, row, 64));
+            ent_j[e] = ai[p];
+            ent_p[e] = __dmul_rn(__shfl(r, row, 64), av[p]);         // no FMA contraction: SciPy's order and rounding
+        }
+        __builtin_amdgcn_wave_barrier();
+        for (int q = 0; q < rows_here; ++q) {                        // the additions, one row of the aggregate after the other
+            const int qs = __shfl(start, q, 64), ql = __shfl(len, q, 64);
+            for (int e = lane; e < ql; e += 64) {
+                const int32_t j = ent_j[qs + e];
+                const double prod = ent_p[qs + e];
+                unsigned h = ((unsigned(j) * 2654435761u) >> 23) & (CAP - 1);
+                for (;;) {
+                    const int old = atomicCAS(&key[h], RAP_EMPTY, j);
+                    if (old == RAP_EMPTY) { val[h] = prod; break; }  // csr_matmat: sums[j] starts at 0 and 0 + prod == prod
+                    if (old == j) { val[h] = __dadd_rn(val[h], prod); break; }
+                    h = (h + 1) & (CAP - 1);
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        done += rows_here;
+    }
+    // 2. the kept columns, compacted; key (J, j), product with R(J, j)
+    int count = 0;
+    for (int base = 0; base < CAP; base += 64) {
+        const int j = key[base + lane];
+        const double v = j != RAP_EMPTY ? val[base + lane] : 0.0;
+        const bool keep = j != RAP_EMPTY && v != 0.0;
+        const unsigned long long mask = __ballot(keep);
+        if (keep) {
+            const int pos = count + __popcll(mask & ((1ull << lane) - 1ull));
+            srt[pos] = (unsigned long long)(unsigned)owner[j] << 32 | (unsigned)j;
+            prd[pos] = __dmul_rn(v, weight[j]);
+        }
+        count += __popcll(mask);
+    }
+    __builtin_amdgcn_wave_barrier();
+    // rank sort by (J, j) into key[] (ranks) — keys are distinct
+    int *rank_of = key;                                              // reuse: rank -> position
+    for (int e = lane; e < count; e += 64) {
+        const unsigned long long mine = srt[e];
+        int rank = 0;
+        for (int f = 0; f < count; ++f) rank += srt[f] < mine ? 1 : 0;
+        rank_of[rank] = e;
+    }
+    __builtin_amdgcn_wave_barrier();
+    // runs of equal J in rank order: a lane per run head adds the run up in order
+    int out_count = 0;
+    const int32_t dst0 = FILL ? cp[I] : 0;
+    for (int base = 0; base < count; base += 64) {
+        const int rk = base + lane;
+        bool head = false;
+        unsigned J = 0;
+        if (rk < count) {
+            J = unsigned(srt[rank_of[rk]] >> 32);
+            head = rk == 0 || unsigned(srt[rank_of[rk - 1]] >> 32) != J;
+        }
+        double sum = 0.0;
+        if (head) {
+            for (int q = rk; q < count && unsigned(srt[rank_of[q]] >> 32) == J; ++q) sum = __dadd_rn(sum, prd[rank_of[q]]);
+        }
+        const bool keep = head && sum != 0.0;
+        const unsigned long long mask = __ballot(keep);
+        if (FILL && keep) {
+            const int pos = out_count + __popcll(mask & ((1ull << lane) - 1ull));
+            ci[dst0 + pos] = int32_t(J);
+            cv[dst0 + pos] = sum;
+        }
+        out_count += __popcll(mask);
+    }
+    if (!FILL && lane == 0) row_len[I] = out_count;
+}
+
+// true: C = (R A) R^T by the fused kernel; false: the operands do not qualify (the caller takes the two products)
+bool rap_aggregation(const DevMat &R, const DevMat &A, omg_csr_result &C, hipStream_t s) {
+    {
+        const char *e = getenv("OMG_RAP_FUSED");
+        if (e && e[0] == '0') return false;
+    }
+    const int64_t nc = R.n_rows, n = A.n_rows;
+    if (nc == 0 || n == 0 || R.nnz == 0) return false;
+    DevBuf<int32_t> owner(n), seen(n), flag(2);
+    DevBuf<double> weight(n);
+    OMG_HIP(hipMemsetAsync(owner.p, 0xff, size_t(n) * sizeof(int32_t), s));
+    OMG_HIP(hipMemsetAsync(seen.p, 0, size_t(n) * sizeof(int32_t), s));
+    OMG_HIP(hipMemsetAsync(flag.p, 0, 2 * sizeof(int32_t), s));
+    hipLaunchKernelGGL(column_owner_kernel, dim3(grid1d(nc)), dim3(256), 0, s, nc, R.indptr.p, R.indices.p, R.data.p, owner.p,
+                       weight.p, seen.p);
+    hipLaunchKernelGGL(rap_check_kernel, dim3(grid1d(n)), dim3(256), 0, s, n, nc, seen.p, A.indptr.p, A.indices.p, R.indptr.p,
+                       R.indices.p, flag.p);
+    int32_t h_flag[2] = {0, 0};
+    OMG_HIP(hipMemcpyAsync(h_flag, flag.p, sizeof(h_flag), hipMemcpyDeviceToHost, s));
+    OMG_HIP(hipStreamSynchronize(s));
+    // (a column of R that nobody owns contributes nothing to R^T: owner -1 would be read — require full cover)
+    if (h_flag[0] != 0 || h_flag[1] > RAP_CAP / 2 || R.nnz != n) return false;
+    C.n_rows = nc;
+    C.n_cols = nc;
+    DevBuf<int32_t> row_len(nc);
+    const dim3 grid(unsigned((nc + RAP_WAVES - 1) / RAP_WAVES)), block(RAP_WAVES * 64);
+    // the hash table is sized by the longest aggregate (the compaction walks every slot)
+    const int cap = h_flag[1] <= 64 ? 128 : h_flag[1] <= 128 ? 256 : RAP_CAP;
+    auto pass = [&](bool fill) {
+#define OMG_RAP_LAUNCH(F, CAPV)                                                                                              \
+        hipLaunchKernelGGL((rap_aggregation_kernel<F, CAPV>), grid, block, 0, s, nc, R.indptr.p, R.indices.p, R.data.p,        \
+                           A.indptr.p, A.indices.p, A.data.p, owner.p, weight.p, row_len.p, C.indptr.p, C.indices.p, C.data.p)
+        if (fill) { if (cap == 128) OMG_RAP_LAUNCH(true, 128); else if (cap == 256) OMG_RAP_LAUNCH(true, 256); else OMG_RAP_LAUNCH(true, RAP_CAP); }
+        else { if (cap == 128) OMG_RAP_LAUNCH(false, 128); else if (cap == 256) OMG_RAP_LAUNCH(false, 256); else OMG_RAP_LAUNCH(false, RAP_CAP); }
+#undef OMG_RAP_LAUNCH
+    };
+    pass(false);
+    C.indptr.alloc(nc + 1);
+    C.nnz = device_row_pointers(nc, row_len.p, C.indptr.p, s);
+    C.indices.alloc(std::max<int64_t>(C.nnz, 1));
+    C.data.alloc(std::max<int64_t>(C.nnz, 1));
+    pass(true);
+    OMG_HIP(hipGetLastError());
+    OMG_HIP(hipStreamSynchronize(s));
+    return true;
 }
 
 void as_devmat(omg_csr_result &&R, DevMat &M) {
@@ -301,6 +572,15 @@ int omg_rap(const omg_csr *R, const omg_csr *A, omg_csr_result **out, int64_t *n
         Stream st;
         DevMat dR, dA, dRt, dRA;
         { SetupTimer tm("rap: upload R, A"); upload(dR, *R, st.s); upload(dA, *A, st.s); OMG_HIP(hipStreamSynchronize(st.s)); }
+        {
+            SetupTimer tm("rap: fused (R A) R^T, one wave per coarse row");
+            std::unique_ptr<omg_csr_result> F(new omg_csr_result);
+            if (rap_aggregation(dR, dA, *F, st.s)) {
+                *n_rows = F->n_rows; *n_cols = F->n_cols; *nnz = F->nnz;
+                *out = F.release();
+                return;
+            }
+        }
         { SetupTimer tm("rap: R^T on the device"); device_transpose(dR, dRt, st.s); }   // index shuffle only
         omg_csr_result RA;
         SetupTimer tm("rap: two sparse products");

@@ -259,6 +259,68 @@ def test_spgemm_bitwise_against_scipy_order():
     np.testing.assert_allclose(both, X.toarray() @ Y.toarray(), rtol=1e-12, atol=1e-13)
 
 
+def _identical_csr(a, b):
+    return (a.shape == b.shape and np.array_equal(a.indptr, b.indptr) and np.array_equal(a.indices, b.indices)
+            and np.array_equal(a.data, b.data))
+
+
+def test_fused_galerkin_kernel_has_the_bits_of_the_two_products(monkeypatch):
+    """omg_rap on an aggregation restriction (every column of R owned by one row) runs the fused
+    one-wave-per-coarse-row kernel; OMG_RAP_FUSED=0 takes the two Gustavson products.  Same structure, same
+    bits: 7-point, 27-point variable-coefficient (216 products per coarse row), unsymmetric random values on a
+    stencil pattern, irregular aggregates with cancellation, a second level; operands that do not qualify
+    (a column owned twice, unsorted rows) fall back by themselves."""
+    rng = np.random.default_rng(23)
+    cases = []
+    for shape in ((16, 16, 16), (12, 12, 12)):
+        cases.append((operators.restriction(shape), operators.stencil_poisson(shape)))
+    shape = (8, 8, 8)
+    A27 = operators.stencil27_variable(shape)
+    cases.append((operators.restriction(shape), A27))
+    U = A27.copy()
+    U.data = rng.standard_normal(U.nnz)                                   # unsymmetric values, same pattern
+    cases.append((operators.restriction(shape), U))
+    n = 3000                                                              # irregular aggregates of 1..7 unknowns
+    cuts = np.unique(np.concatenate([[0, n], rng.integers(1, n, 900)]))
+    agg = np.repeat(np.arange(cuts.size - 1), np.diff(cuts))
+    Rirr = sp.csr_matrix((rng.choice([0.5, 1.0, -1.0, 0.25], n), (agg, np.arange(n))), shape=(cuts.size - 1, n))
+    Airr = random_csr(n, n, rng, density=0.004, unsorted=False)
+    Airr.data = rng.choice([1.0, -1.0, 2.0, 0.5], Airr.nnz)               # exact cancellations happen
+    Airr.sort_indices()
+    cases.append((Rirr, Airr))
+    for Rl, Al in cases:
+        Rl, Al = sp.csr_matrix(Rl), sp.csr_matrix(Al)
+        monkeypatch.setenv("OMG_RAP_FUSED", "1")
+        fused = _hip.rap(Rl, Al)
+        monkeypatch.setenv("OMG_RAP_FUSED", "0")
+        two = _hip.rap(Rl, Al)
+        assert _identical_csr(fused, two), (Rl.shape, abs(fused - two).max())
+        assert all(np.all(np.diff(fused.indices[fused.indptr[i]:fused.indptr[i + 1]]) > 0) for i in range(fused.shape[0]))
+        want = sp.csr_matrix((Rl @ Al) @ Rl.T)
+        assert abs(fused - want).max() <= 1e-13 * max(abs(want).max(), 1.0)
+        # the next level of the hierarchy: a product of a product
+        if Rl.shape[0] % 8 == 0 and Rl.shape[0] >= 64:
+            m = Rl.shape[0]
+            R2 = sp.csr_matrix((np.full(m, 0.5), (np.arange(m) // 2, np.arange(m))), shape=(m // 2, m))
+            monkeypatch.setenv("OMG_RAP_FUSED", "1")
+            f2 = _hip.rap(R2, fused)
+            monkeypatch.setenv("OMG_RAP_FUSED", "0")
+            assert _identical_csr(f2, _hip.rap(R2, fused))
+    monkeypatch.setenv("OMG_RAP_FUSED", "1")
+    # not an aggregation: a column in two rows -> the two products, silently
+    Rdup = sp.csr_matrix(np.array([[1.0, 0.5, 0.0, 0.0], [0.0, 0.5, 1.0, 1.0]]))
+    T = sp.diags([-np.ones(3), 2.0 * np.ones(4), -np.ones(3)], [-1, 0, 1], format="csr")
+    assert abs(_hip.rap(Rdup, T) - sp.csr_matrix((Rdup @ T) @ Rdup.T)).max() < 1e-14
+    # rows of A out of order -> the two products (SciPy's order follows the STORED order)
+    Au = sp.csr_matrix(operators.stencil_poisson((4, 4, 4)))
+    Au.indices[0:2] = Au.indices[0:2][::-1].copy()
+    Au.data[0:2] = Au.data[0:2][::-1].copy()
+    Rl = sp.csr_matrix(operators.restriction((4, 4, 4)))
+    got = _hip.rap(Rl, Au)
+    monkeypatch.setenv("OMG_RAP_FUSED", "0")
+    assert _identical_csr(got, _hip.rap(Rl, Au))
+
+
 def test_spgemm_drops_cancelled_entries_and_dense_operands_give_dense_results():
     """SciPy's csr_matmat stores an accumulated entry only when it is != 0, so sums
     that cancel exactly must not appear in the device product either (structure == SciPy's);
