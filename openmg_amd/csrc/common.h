@@ -491,6 +491,11 @@ struct PlanePlan {
     // form (parity colours, red first — what the greedy colouring of such a stencil gives, without its
     // sequential pass over the rows).
     bool build(const omg_csr &A, const omg_csr &R, Ordering &ord);
+    // The operator and the restriction the plan stands for, as the caller's CSR had them (natural numbering,
+    // ascending columns; doubles — of the rounded coefficients for a float plan): what the row kernels'
+    // format of a plane level is built from when something asks for it (hierarchy.hip ensure_format).
+    HostCsr operator_csr() const;
+    HostCsr restriction_csr() const;
     struct Coarse {
         const int32_t *map = nullptr; // coarse natural index -> slot in the coarse ordering (null: identity)
         V *b = nullptr;               // down: coarse right-hand side

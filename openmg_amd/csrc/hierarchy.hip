@@ -69,6 +69,10 @@ struct Level {
     // of a V(pre >= 1, post >= 1) cycle is one plane-pipelined launch (common.h PlanePlan), out of place
     // between x and tmp
     std::unique_ptr<PlanePlan<V>> plane;
+    // A plane level's cycle never touches the row-kernel format of A and R (nor r, the block partials, the
+    // sweep plan): they are built on first use — by a cycle with pre = 0 or post = 0, a single-level
+    // operation, a format query — from the operator the plan describes (ensure_format; OMG_PLANE_LAZY=0: at creation)
+    bool format_pending = false;
 };
 
 struct ProfEvent {
@@ -200,6 +204,9 @@ struct Prof {
     }
 };
 
+template <typename V>
+void ensure_format(Hier<V> *h, int l);            // (a plane level's row-kernel side is built on first use: below)
+
 // ---- level operations (device vectors in the level's ordering) ---------------------------
 // What the LAST set launch of a Gauss-Seidel smoothing call also produces for its own rows
 // (RowMode ROW_GS_RES / ROW_GS_NORM): the residual pass that follows then skips that set.
@@ -234,6 +241,7 @@ bool can_prenorm(const Hier<V> *h, const Level<V> &L, int pre, int post) {
 template <typename V>
 bool smooth_level(Hier<V> *h, int l, int iterations, Fuse fuse = FUSE_NONE, double *pre_slot = nullptr,
                   bool first_done = false, double *post_slot = nullptr) {
+    ensure_format(h, l);
     Level<V> &L = h->lv[l];
     bool fused = false;
     for (int it = 0; it < iterations; ++it) {
@@ -285,6 +293,7 @@ bool smooth_level(Hier<V> *h, int l, int iterations, Fuse fuse = FUSE_NONE, doub
 // produced the last set's residual.
 template <typename V>
 void residual_level(Hier<V> *h, int l, V *r_out, bool last_set_done = false) {
+    ensure_format(h, l);
     Level<V> &L = h->lv[l];
     Prof<V> p(h, l, 1);
     RowArgsT<V> a;
@@ -297,6 +306,7 @@ void residual_level(Hier<V> *h, int l, V *r_out, bool last_set_done = false) {
 // last_set_done the last set's block partials are already in place.
 template <typename V>
 void norm_level(Hier<V> *h, int l, V *r_out, bool last_set_done = false, double *out = nullptr) {
+    ensure_format(h, l);
     Level<V> &L = h->lv[l];
     {
         Prof<V> p(h, l, 4);
@@ -325,6 +335,8 @@ bool first_sweep_in_restrict(const Hier<V> *h, const Level<V> &C, int pre) {
 // first_sweep, set to what the coarse level's first smoothing launch makes of a zero iterate.
 template <typename V>
 void restrict_level(Hier<V> *h, int l, const V *fine, V *coarse, V *clear = nullptr, bool first_sweep = false) {
+    ensure_format(h, l);
+    if (first_sweep) ensure_format(h, l + 1);
     Level<V> &L = h->lv[l];
     Prof<V> p(h, l, 2);
     RowArgsT<V> a;
@@ -341,6 +353,7 @@ void restrict_level(Hier<V> *h, int l, const V *fine, V *coarse, V *clear = null
 
 template <typename V>
 void prolong_add_level(Hier<V> *h, int l, const V *coarse, V *fine) {
+    ensure_format(h, l);
     Level<V> &L = h->lv[l];
     Prof<V> p(h, l, 3);
     RowArgsT<V> a;
@@ -393,6 +406,7 @@ int cycle_body(Hier<V> *h, int l, int pre, int post, bool want_norm = false, dou
     if (use_plane(h, L, pre, post) && halves == 2 && !x_zero) {
         const bool res_done = smooth_level(h, l, pre, FUSE_RESIDUAL, nullptr, first_done);
         residual_level(h, l, L.r.p, res_done);
+        if (l + 1 < last) ensure_format(h, l + 1);
         const bool child_first = l + 1 < last && first_sweep_in_restrict(h, C, pre);
         restrict_level<V>(h, l, L.r.p, C.b.p, l + 1 < last ? C.xp : nullptr, child_first);
         cycle_body(h, l + 1, pre, post, false, nullptr, child_first);
@@ -408,6 +422,7 @@ int cycle_body(Hier<V> *h, int l, int pre, int post, bool want_norm = false, dou
     }
     if (use_plane(h, L, pre, post) && halves == 1) {
         if (pre > 1) smooth_level(h, l, pre - 1, FUSE_NONE, nullptr, first_done);
+        if (l + 1 < last) ensure_format(h, l + 1);
         const bool child_first = l + 1 < last && first_sweep_in_restrict(h, C, pre);
         typename PlanePlan<V>::Coarse c;
         c.map = L.r_out.p;
@@ -426,6 +441,7 @@ int cycle_body(Hier<V> *h, int l, int pre, int post, bool want_norm = false, dou
         if (pre > 1) smooth_level(h, l, pre - 1, FUSE_NONE, nullptr, first_done);
         const bool child_plane = l + 1 < last && use_plane(h, C, pre, post);
         const bool child_zero = child_plane && pre == 1 && halves == 3;       // the child's down pass never reads its zero iterate
+        if (l + 1 < last && !child_zero) ensure_format(h, l + 1);
         const bool child_first = l + 1 < last && !child_zero && first_sweep_in_restrict(h, C, pre);
         typename PlanePlan<V>::Coarse c;
         c.map = L.r_out.p;
@@ -455,6 +471,7 @@ int cycle_body(Hier<V> *h, int l, int pre, int post, bool want_norm = false, dou
     // :210, and the coarse cycle's initial=None -> zeros (:191-192) cleared by the same launch —
     // or already relaxed once (first_sweep_in_restrict)
     const bool child_zero = l + 1 < last && use_plane(h, C, pre, post) && pre == 1 && halves == 3;
+    if (l + 1 < last && !child_zero) ensure_format(h, l + 1);
     const bool child_first = l + 1 < last && !child_zero && first_sweep_in_restrict(h, C, pre);
     restrict_level<V>(h, l, L.r.p, C.b.p, (l + 1 < last && !child_zero) ? C.xp : nullptr, child_first);
     cycle_body(h, l + 1, pre, post, false, nullptr, child_first, nullptr, child_zero);   // :213
@@ -584,6 +601,83 @@ void check_level(const Hier<V> *h, int level) {
     OMG_REQUIRE(level >= 0 && level < (int)h->lv.size(), "level out of range");
 }
 
+
+// The row-kernel side of a smoothed level: A and R (and P where the prolongation cannot scatter over R) in
+// the device format of common.h, the residual vector, the block partials, the sweep plan.  A, R: natural
+// numbering (the caller's, or — for a plane level, later — what its plan describes).
+template <typename V>
+void build_format(Hier<V> *h, int l, const omg_csr &A, const omg_csr &R) {
+    Level<V> &L = h->lv[l];
+    const bool id = L.ord.identity;
+    {
+        HostCsr Ap;
+        { SetupTimer tm("permute A"); Ap = permute_csr(A, id ? nullptr : L.ord.perm.data(), id ? nullptr : L.ord.inv.data()); }
+        SetupTimer tm("encode + upload A");
+        L.A.upload(Ap, L.ord.sets, h->stream);
+        // the diagonal as the sweeps form it: restrict_level / omg_hierarchy_cycle_dev apply this
+        // level's first relaxation of a zero iterate with it (level 0: only when it is needed)
+        if (l >= 1) {
+            L.diag.alloc(std::max<int64_t>(L.n, 1));
+            launch_diagonal(L.A, L.diag.p, h->stream);
+        }
+    }
+    const Ordering &co = h->lv[l + 1].ord;
+    SetupTimer tm("R (and P): permute, encode, upload");
+    HostCsr Rp, Rn;
+    const HostCsr *r_used = &Rp;
+    if (co.identity) {
+        Rp = permute_csr(R, nullptr, id ? nullptr : L.ord.inv.data());
+        L.R.upload(Rp, {}, h->stream);
+    } else {
+        // Restriction rows stay in NATURAL coarse order and write through a map (r_out) into the
+        // coarse level's ordering: consecutive rows are then consecutive aggregates,
+        // whose fine unknowns are consecutive inside each colour segment (dense
+        // gathers).  In the coarse COLOUR order consecutive rows are every other
+        // aggregate and each gather used half of every cache line (measured: 480 MB
+        // read for 343 MB algorithmic).
+        Rn = permute_csr(R, nullptr, id ? nullptr : L.ord.inv.data());
+        r_used = &Rn;
+        L.R.upload(Rn, {}, h->stream);
+    }
+    {   // OMG_PROLONG_SCATTER=0: always the explicit transpose (identical bits, tested)
+        const char *e = getenv("OMG_PROLONG_SCATTER");
+        bool ok = !(e && e[0] == '0') && L.R.all_pattern();
+        if (ok) {
+            std::vector<char> seen(size_t(L.n), 0);
+            for (int32_t c : r_used->indices) {
+                if (seen[c]) { ok = false; break; }
+                seen[c] = 1;
+            }
+        }
+        L.scatter_prolong = ok;
+    }
+    if (!L.scatter_prolong) {
+        // the explicit transpose P = R^T (rows in this level's ordering, columns in the next
+        // level's) is only built where the prolongation cannot run as a scatter over R's rows
+        if (!co.identity) Rp = permute_csr(R, co.perm.data(), id ? nullptr : L.ord.inv.data());
+        HostCsr Pt = transpose_csr(Rp);
+        L.P.upload(Pt, {}, h->stream);
+    }
+    L.r.alloc(L.n);
+    if (h->smoother == OMG_SMOOTH_JACOBI && !L.tmp.p) { L.tmp.alloc(L.n); L.tp = L.tmp.p; }
+    L.partials.alloc(L.A.n_blocks() + SUM_FOLD);
+    build_plan(L);
+    OMG_HIP(hipStreamSynchronize(h->stream));
+}
+
+// A plane level's row-kernel side, on first use.
+template <typename V>
+void ensure_format(Hier<V> *h, int l) {
+    if (l < 0 || l >= (int)h->lv.size() || !h->lv[l].format_pending) return;
+    Level<V> &L = h->lv[l];
+    SetupTimer tm("plane level: row-kernel format on first use");
+    const HostCsr A = L.plane->operator_csr(), R = L.plane->restriction_csr();
+    L.format_pending = false;
+    build_format(h, l, view(A), view(R));
+}
+template <typename V>
+void ensure_format(const Hier<V> *h, int l) { ensure_format(const_cast<Hier<V> *>(h), l); }
+
 template <typename V>
 std::unique_ptr<Hier<V>> create(int n_levels, const omg_csr *A, const omg_csr *R, int smoother,
                                 double omega) {
@@ -670,18 +764,6 @@ std::unique_ptr<Hier<V>> create(int n_levels, const omg_csr *A, const omg_csr *R
     for (int l = 0; l < n_levels; ++l) {
         Lv &L = h->lv[l];
         const bool id = L.ord.identity;
-        if (l + 1 < n_levels) {
-            HostCsr Ap;
-            { SetupTimer tm("permute A"); Ap = permute_csr(A[l], id ? nullptr : L.ord.perm.data(), id ? nullptr : L.ord.inv.data()); }
-            SetupTimer tm("encode + upload A");
-            L.A.upload(Ap, L.ord.sets, h->stream);
-            // the diagonal as the sweeps form it: restrict_level / omg_hierarchy_cycle_dev apply this
-            // level's first relaxation of a zero iterate with it (level 0: only when it is needed)
-            if (l >= 1) {
-                L.diag.alloc(std::max<int64_t>(L.n, 1));
-                launch_diagonal(L.A, L.diag.p, h->stream);
-            }
-        }
         if (!id) {
             L.perm.alloc(L.n);
             L.perm.upload(L.ord.perm.data(), L.n, h->stream);
@@ -689,49 +771,16 @@ std::unique_ptr<Hier<V>> create(int n_levels, const omg_csr *A, const omg_csr *R
         }
         if (l + 1 < n_levels) {
             const Ordering &co = h->lv[l + 1].ord;
-            SetupTimer tm("R (and P): permute, encode, upload");
-            HostCsr Rp, Rn;
-            const HostCsr *r_used = &Rp;
-            if (co.identity) {
-                Rp = permute_csr(R[l], nullptr, id ? nullptr : L.ord.inv.data());
-                L.R.upload(Rp, {}, h->stream);
-            } else {
-                // Restriction rows stay in NATURAL coarse order and write through a map into the
-                // coarse level's ordering: consecutive rows are then consecutive aggregates,
-                // whose fine unknowns are consecutive inside each colour segment (dense
-                // gathers).  In the coarse COLOUR order consecutive rows are every other
-                // aggregate and each gather used half of every cache line (measured: 480 MB
-                // read for 343 MB algorithmic).
-                Rn = permute_csr(R[l], nullptr, id ? nullptr : L.ord.inv.data());
-                r_used = &Rn;
-                L.R.upload(Rn, {}, h->stream);
+            if (!co.identity) {
+                // restriction rows are in NATURAL coarse order and write through this map into the coarse
+                // level's ordering (build_format; the plane passes use it too)
                 L.r_out.alloc(co.inv.size());
                 L.r_out.upload(co.inv.data(), co.inv.size(), h->stream);
                 OMG_HIP(hipStreamSynchronize(h->stream));
             }
-            {   // OMG_PROLONG_SCATTER=0: always the explicit transpose (identical bits, tested)
-                const char *e = getenv("OMG_PROLONG_SCATTER");
-                bool ok = !(e && e[0] == '0') && L.R.all_pattern();
-                if (ok) {
-                    std::vector<char> seen(size_t(L.n), 0);
-                    for (int32_t c : r_used->indices) {
-                        if (seen[c]) { ok = false; break; }
-                        seen[c] = 1;
-                    }
-                }
-                L.scatter_prolong = ok;
-            }
-            if (!L.scatter_prolong) {
-                // the explicit transpose P = R^T (rows in this level's ordering, columns in the next
-                // level's) is only built where the prolongation cannot run as a scatter over R's rows
-                if (!co.identity) Rp = permute_csr(R[l], co.perm.data(), id ? nullptr : L.ord.inv.data());
-                HostCsr Pt = transpose_csr(Rp);
-                L.P.upload(Pt, {}, h->stream);
-            }
-            L.r.alloc(L.n);
-            if (smoother == OMG_SMOOTH_JACOBI || L.plane) L.tmp.alloc(L.n);
-            L.partials.alloc(L.A.n_blocks() + SUM_FOLD);
-            build_plan(L);
+            if (L.plane) L.tmp.alloc(L.n);
+            if (L.plane && !getenv_flag0("OMG_PLANE_LAZY")) L.format_pending = true;
+            else build_format(h.get(), l, A[l], R[l]);
         }
         L.x.alloc(std::max<int64_t>(L.n, 1));
         L.b.alloc(std::max<int64_t>(L.n, 1));
@@ -868,7 +917,7 @@ int omg_hierarchy_level_sets(const omg_hierarchy *h, int level, int64_t *n_sets)
         with(h, [&](auto *hh) {
             check_level(hh, level);
             OMG_REQUIRE(n_sets, "null");
-            *n_sets = (int64_t)hh->lv[level].A.n_sets();
+            *n_sets = (int64_t)hh->lv[level].ord.sets.size() - 1;      // (of the ordering: the format may not be built yet)
         });
     });
 }
@@ -878,6 +927,7 @@ int omg_hierarchy_level_fused(const omg_hierarchy *h, int level, int *fused) {
         with(h, [&](auto *hh) {
             check_level(hh, level);
             OMG_REQUIRE(fused, "null");
+            ensure_format(hh, level);
             *fused = (level + 1 < (int)hh->lv.size() && can_fuse(hh, hh->lv[level])) ? 1 : 0;
         });
     });
@@ -888,6 +938,7 @@ int omg_hierarchy_level_flags(const omg_hierarchy *h, int level, int *flags) {
         with(h, [&](auto *hh) {
             check_level(hh, level);
             OMG_REQUIRE(flags, "null");
+            ensure_format(hh, level);
             const bool smoothed = level + 1 < (int)hh->lv.size();
             *flags = ((smoothed && can_fuse(hh, hh->lv[level])) ? OMG_LEVEL_FUSED_LAST_SET : 0) |
                      ((smoothed && hh->lv[level].scatter_prolong) ? OMG_LEVEL_SCATTER_PROLONG : 0) |
@@ -927,6 +978,7 @@ int omg_hierarchy_set_info(const omg_hierarchy *h, int level, int set, int64_t *
     return guarded([&] {
         with(h, [&](auto *hh) {
             check_level(hh, level);
+            ensure_format(hh, level);
             const auto &A = hh->lv[level].A;
             OMG_REQUIRE(set >= 0 && size_t(set) < A.n_sets() && rows && nnz, "set out of range / null");
             *rows = A.sets[set + 1] - A.sets[set];
@@ -941,6 +993,7 @@ int omg_hierarchy_format_info(const omg_hierarchy *h, int level, int op, int set
             check_level(hh, level);
             OMG_REQUIRE(out && op >= 0 && op <= 2, "null / unknown operator");
             OMG_REQUIRE(op == 0 || level + 1 < (int)hh->lv.size(), "the coarsest level has no restriction");
+            ensure_format(hh, level);
             const auto &L = hh->lv[level];
             (op == 0 ? L.A : op == 1 ? L.R : L.P).format_info(set, out);
         });
@@ -1009,6 +1062,7 @@ int omg_hierarchy_cycle_dev(omg_hierarchy *h, const double *b_dev, double *x_dev
                         launch_diagonal(L.A, L.diag.p, hh->stream);
                     }
                     zero_in = use_plane(hh, L, pre, post) && pre == 1;     // the down pass does not read a zero iterate
+                    if (!zero_in) ensure_format(hh, 0);
                     first = !zero_in && first_sweep_in_restrict(hh, L, pre);
                     if (zero_in) {
                         // nothing to write
@@ -1092,6 +1146,7 @@ int omg_resident_cycles(omg_hierarchy *h, int pre, int post, int n_cycles, doubl
                 check_march(hh);
                 return;
             }
+            if (!single) ensure_format(hh, 0);
             // (a plane-pipelined cycle with post > 1 ends set by set: its first launch is no PRENORM launch)
             const bool defer = !single && !getenv_flag("OMG_NO_PRENORM") && can_prenorm(hh, hh->lv[0], pre, post) &&
                                !use_plane(hh, hh->lv[0], pre, post);
@@ -1143,6 +1198,7 @@ int omg_resident_spmv_time(omg_hierarchy *h, int reps, double *avg_ms) {
             check_level(hh, 0);
             OMG_REQUIRE(hh->resident && reps > 0 && avg_ms, "nothing resident / bad argument");
             OMG_REQUIRE(hh->lv.size() > 1, "single-level hierarchy has no smoothed operator");
+            ensure_format(hh, 0);
             auto &L = hh->lv[0];
             RowArgsT<V> a;
             a.x = L.xp; a.y = L.r.p;

@@ -815,6 +815,68 @@ bool PlanePlan<V>::build(const omg_csr &A, const omg_csr &R, Ordering &ord) {
     return true;
 }
 
+template <typename V>
+HostCsr PlanePlan<V>::operator_csr() const {
+    const int64_t nx = g.nx, ny = g.ny, nz = g.nz, n = nx * ny * nz, sj = nx, sk = nx * ny;
+    HostCsr A;
+    A.n_rows = A.n_cols = n;
+    A.nnz = 7 * n - 2 * (nx * ny + ny * nz + nx * nz);
+    A.indptr.resize(size_t(n) + 1);
+    A.indices.resize(size_t(A.nnz));
+    A.data.resize(size_t(A.nnz));
+    const int nt = (int)std::max<int64_t>(1, std::min<int64_t>(std::max(1u, std::min(16u, std::thread::hardware_concurrency())), nz));
+    auto fill = [&](int tnum) {
+        // rows of planes [k0, k1): entries before plane k = 7 (rows) - 2 per missing neighbour
+        const int64_t k0 = nz * tnum / nt, k1 = nz * (tnum + 1) / nt;
+        auto before_plane = [&](int64_t k) {       // stored entries of the rows of planes < k
+            // per plane: 7 nx ny - 2 nx (j faces) - 2 ny (i faces); - nx ny for each of -K (plane 0) and +K (last plane)
+            int64_t t = k * (7 * nx * ny - 2 * nx - 2 * ny) - (k > 0 ? nx * ny : 0) - (k == nz ? nx * ny : 0);
+            return t;
+        };
+        int64_t p = before_plane(k0);
+        for (int64_t r = k0 * sk; r < k1 * sk; ++r) {
+            const int64_t i = r % nx, jl = (r / nx) % ny, kl = r / sk;
+            A.indptr[size_t(r)] = int32_t(p);
+            const bool present[7] = {kl > 0, jl > 0, i > 0, true, i + 1 < nx, jl + 1 < ny, kl + 1 < nz};
+            const int64_t off[7] = {-sk, -sj, -1, 0, 1, sj, sk};
+            for (int e = 0; e < 7; ++e)
+                if (present[e]) { A.indices[size_t(p)] = int32_t(r + off[e]); A.data[size_t(p)] = g.c[e]; ++p; }
+        }
+        if (k1 == nz) A.indptr[size_t(n)] = int32_t(p);
+    };
+    std::vector<std::thread> th;
+    for (int tnum = 1; tnum < nt; ++tnum) th.emplace_back(fill, tnum);
+    fill(0);
+    for (auto &q : th) q.join();
+    OMG_REQUIRE(A.indptr[size_t(n)] == A.nnz, "internal: synthesised operator has the wrong number of entries");
+    return A;
+}
+
+template <typename V>
+HostCsr PlanePlan<V>::restriction_csr() const {
+    const int64_t nx = g.nx, ny = g.ny, nz = g.nz, n = nx * ny * nz, sj = nx, sk = nx * ny;
+    const int64_t nxc = nx / 2, nyc = ny / 2, nc = nxc * nyc * (nz / 2);
+    HostCsr R;
+    R.n_rows = nc;
+    R.n_cols = n;
+    R.nnz = n;
+    R.indptr.resize(size_t(nc) + 1);
+    R.indices.resize(size_t(n));
+    R.data.resize(size_t(n));
+    for (int64_t cr = 0; cr <= nc; ++cr) R.indptr[size_t(cr)] = int32_t(8 * cr);
+    for (int64_t cr = 0; cr < nc; ++cr) {
+        const int64_t I = cr % nxc, J = (cr / nxc) % nyc, K = cr / (nxc * nyc);
+        int64_t p = 8 * cr;
+        for (int dk = 0; dk < 2; ++dk)
+            for (int dj = 0; dj < 2; ++dj)
+                for (int di = 0; di < 2; ++di, ++p) {
+                    R.indices[size_t(p)] = int32_t((2 * K + dk) * sk + (2 * J + dj) * sj + 2 * I + di);
+                    R.data[size_t(p)] = g.w;
+                }
+    }
+    return R;
+}
+
 namespace {
 
 template <typename V>
