@@ -163,6 +163,139 @@ void put_values(DevBuf<V> &d, const std::vector<double> &h, hipStream_t s, std::
     d.upload(keep.data(), keep.size(), s);
 }
 
+// ---- sine-transform solve (CoarseSolver P == 0) ---------------------------------------------------------
+constexpr int SINE_THREADS = 1024;
+// x = S ((S b) / lambda), S = Sz (x) Sy (x) Sx: six passes of short dense transforms through LDS.  A pass is
+// out(ne x lines) = S(ne x ne) in(ne x lines) — a small dense matrix product, and the one place of this path where the
+// matrix cores earn their keep: v_mfma_f64_16x16x4 (A: lane 16 k + i holds S[i][k]; B: lane 16 k + j holds in[k][line j];
+// D: register r of lane l holds row 4 r + l / 16 of column l % 16).  A wave takes 16 lines at a time, all of their outputs, so a
+// pass works in place; one workgroup barrier per pass.  E (16 or 32) >= every extent: the tables' row stride.
+typedef double v4d __attribute__((ext_vector_type(4)));
+template <typename V, int E>
+__global__ __launch_bounds__(SINE_THREADS) void sine_solve_kernel(const V *__restrict__ b, V *__restrict__ x, int nx, int ny, int nz,
+                                                                 const double *__restrict__ tables, const double *__restrict__ lambda) {
+    extern __shared__ double sine_buf[];              // (i, j, k) at (k ny + j) (nx + 1) + i: lines along x one bank apart
+    const int px = nx + 1, n = nx * ny * nz;
+    double *const lt = sine_buf + ((px * ny * nz + 1) & ~1);       // the three tables behind the vector
+    const int nt = (nx + ny + nz) * E;
+    for (int r = int(threadIdx.x); r < nt; r += SINE_THREADS) lt[r] = tables[r];
+    // a thread's elements r = tid + 1024 q (n <= 8192: q < 8): their places in the padded image and their eigenvalues,
+    // fetched once (the kernel is a chain of latencies: nothing global is left between the passes)
+    constexpr int PER = 8192 / SINE_THREADS;
+    int place[PER];
+    double lam[PER];
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+        const int r = int(threadIdx.x) + q * SINE_THREADS;
+        place[q] = r < n ? (r / nx) * px + r % nx : -1;
+        lam[q] = r < n ? lambda[r] : 1.0;
+        if (r < n) sine_buf[place[q]] = double(b[r]);
+    }
+    __syncthreads();
+    const int lane = int(threadIdx.x) & 63, wave = int(threadIdx.x) >> 6;
+    const int c16 = lane & 15, k4 = lane >> 4;
+#pragma unroll 1
+    for (int pass = 0; pass < 6; ++pass) {
+        const int axis = pass % 3;
+        // a line's first element: (line / da) sa + (line % da) sb; its elements `stride` apart
+        const int ne = axis == 0 ? nx : axis == 1 ? ny : nz;
+        const int n_lines = n / ne;
+        const int da = axis == 0 ? 1 : nx, sb = axis == 0 ? 0 : 1;
+        const int sa = axis == 0 ? px : axis == 1 ? ny * px : px;
+        const int stride = axis == 0 ? 1 : axis == 1 ? px : ny * px;
+        const double *S = lt + (axis == 0 ? 0 : axis == 1 ? nx : nx + ny) * E;
+        if (pass == 3) {
+#pragma unroll
+            for (int q = 0; q < PER; ++q)
+                if (place[q] >= 0) sine_buf[place[q]] = sine_buf[place[q]] / lam[q];
+            __syncthreads();
+        }
+        if (ne <= 1) continue;                        // a 1 x 1 transform is the identity
+        const int n_blocks = (n_lines + 15) >> 4, k_steps = (ne + 3) >> 2;
+#pragma unroll 1
+        for (int bl = wave; bl < n_blocks; bl += SINE_THREADS / 64) {
+            const int line = 16 * bl + c16;
+            const bool live = line < n_lines;
+            const int bs = live ? (line / da) * sa + (line % da) * sb : 0;
+            v4d acc[E / 16];
+#pragma unroll
+            for (int ib = 0; ib < E / 16; ++ib) acc[ib] = v4d{0.0, 0.0, 0.0, 0.0};
+#pragma unroll 1
+            for (int ks = 0; ks < k_steps; ++ks) {
+                const int k = 4 * ks + k4;
+                const double bv = (live && k < ne) ? sine_buf[bs + k * stride] : 0.0;
+#pragma unroll
+                for (int ib = 0; ib < E / 16; ++ib) {
+                    const double av = S[(16 * ib + c16) * E + (k < E ? k : 0)];     // rows and columns beyond ne are zeros
+                    acc[ib] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc[ib], 0, 0, 0);
+                }
+            }
+            // (the wave has read all it needs of its 16 lines: LDS operations of a wave complete in order)
+            if (live) {
+#pragma unroll
+                for (int ib = 0; ib < E / 16; ++ib)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int i = 16 * ib + 4 * r + k4;       // (measured layout: tools/mfma_probe.hip)
+                        if (i < ne) sine_buf[bs + i * stride] = acc[ib][r];
+                    }
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int q = 0; q < PER; ++q)
+        if (place[q] >= 0) x[int(threadIdx.x) + q * SINE_THREADS] = V(sine_buf[place[q]]);
+}
+
+// Is A a constant-coefficient SYMMETRIC star stencil on a lexicographically numbered grid whose boundary rows
+// drop the entries of missing neighbours?  (extents and the four coefficients: diagonal, x, y, z couplings)
+bool detect_symmetric_star(const HostCsr &A, int64_t &nx, int64_t &ny, int64_t &nz, double (&c)[4]) {
+    const int64_t n = A.n_rows;
+    if (n < 2) return false;
+    auto has = [&](int64_t r, int64_t col) {
+        for (int32_t p = A.indptr[r]; p < A.indptr[r + 1]; ++p)
+            if (A.indices[p] == col) return true;
+        return false;
+    };
+    nx = n;
+    for (int64_t r = 1; r < n; ++r)
+        if (!has(r, r - 1)) { nx = r; break; }
+    if (nx < 2 || n % nx) return false;
+    const int64_t lines = n / nx;
+    ny = lines;
+    for (int64_t q = 1; q < lines; ++q)
+        if (!has(q * nx, (q - 1) * nx)) { ny = q; break; }
+    if (lines % ny) return false;
+    nz = lines / ny;
+    const int64_t sj = nx, sk = nx * ny;
+    bool have[4] = {false, false, false, false};
+    c[0] = c[1] = c[2] = c[3] = 0.0;
+    for (int64_t r = 0; r < n; ++r) {
+        const int64_t i = r % nx, jl = (r / nx) % ny, kl = r / sk;
+        const int want = 1 + (i > 0) + (i + 1 < nx) + (jl > 0) + (jl + 1 < ny) + (kl > 0) + (kl + 1 < nz);
+        if (A.indptr[r + 1] - A.indptr[r] != want) return false;
+        int seen = 0;
+        for (int32_t p = A.indptr[r]; p < A.indptr[r + 1]; ++p) {
+            const int64_t off = int64_t(A.indices[p]) - r;
+            int slot, bit;
+            if (off == 0) { slot = 0; bit = 1; }
+            else if (off == -1 && i > 0) { slot = 1; bit = 2; }
+            else if (off == 1 && i + 1 < nx) { slot = 1; bit = 4; }
+            else if (off == -sj && jl > 0 && ny > 1) { slot = 2; bit = 8; }
+            else if (off == sj && jl + 1 < ny) { slot = 2; bit = 16; }
+            else if (off == -sk && kl > 0 && nz > 1) { slot = 3; bit = 32; }
+            else if (off == sk && kl + 1 < nz) { slot = 3; bit = 64; }
+            else return false;
+            if (seen & bit) return false;
+            seen |= bit;
+            if (!have[slot]) { have[slot] = true; c[slot] = A.data[p]; }
+            else if (A.data[p] != c[slot]) return false;
+        }
+    }
+    return have[0];
+}
+
 }  // namespace
 
 template <typename V>
@@ -170,6 +303,10 @@ void CoarseSolver<V>::build(const HostCsr &A, hipStream_t s) {
     OMG_REQUIRE(A.n_rows == A.n_cols, "coarse operator must be square");
     n = A.n_rows;
     if (n == 0) return;
+    {   // OMG_COARSE_BLOCKS forces the inverse / substructuring, OMG_COARSE_SINE=0 switches the sine solve off
+        const char *e = getenv("OMG_COARSE_BLOCKS"), *q = getenv("OMG_COARSE_SINE");
+        if (!(e && atoi(e) > 0) && !(q && q[0] == '0') && build_sine(A, s)) return;
+    }
     // half-bandwidth
     int64_t band = 0;
     for (int64_t i = 0; i < n; ++i)
@@ -356,8 +493,61 @@ void CoarseSolver<V>::build(const HostCsr &A, hipStream_t s) {
 }
 
 template <typename V>
+bool CoarseSolver<V>::build_sine(const HostCsr &A, hipStream_t s) {
+    int64_t gx = 0, gy = 0, gz = 0;
+    double c[4];
+    if (A.n_rows > 8192 || !detect_symmetric_star(A, gx, gy, gz, c) || gx > 32 || gy > 32 || gz > 32) return false;
+    const double pi = 3.14159265358979323846264338327950288;
+    const int64_t E = std::max(gx, std::max(gy, gz)) <= 16 ? 16 : 32;                 // row stride of the tables (zeros behind a row)
+    std::vector<double> tab(size_t((gx + gy + gz) * E), 0.0), lam(size_t(A.n_rows));
+    auto table = [&](double *t, int64_t m) {
+        const long double f = std::sqrt(2.0L / (long double)(m + 1));
+        for (int64_t i = 0; i < m; ++i)
+            for (int64_t p = 0; p < m; ++p)
+                t[i * E + p] = m == 1 ? 1.0 : double(f * sinl((long double)pi * (long double)((i + 1) * (p + 1)) / (long double)(m + 1)));
+    };
+    table(tab.data(), gx);
+    table(tab.data() + gx * E, gy);
+    table(tab.data() + (gx + gy) * E, gz);
+    double smallest = 1e300, largest = 0.0;
+    for (int64_t r = 0; r < A.n_rows; ++r) {
+        const int64_t p = r % gx, q = (r / gx) % gy, t = r / (gx * gy);
+        double l = c[0] + 2.0 * c[1] * std::cos(pi * double(p + 1) / double(gx + 1));
+        if (gy > 1) l += 2.0 * c[2] * std::cos(pi * double(q + 1) / double(gy + 1));
+        if (gz > 1) l += 2.0 * c[3] * std::cos(pi * double(t + 1) / double(gz + 1));
+        lam[size_t(r)] = l;
+        smallest = std::min(smallest, std::fabs(l));
+        largest = std::max(largest, std::fabs(l));
+    }
+    if (!(smallest > 1e-13 * largest)) return false;     // (numerically) singular: let the factorisation say so
+    P = 0;
+    sx = int(gx); sy = int(gy); sz = int(gz);
+    sine.alloc(tab.size());
+    lambda.alloc(lam.size());
+    sine.upload(tab.data(), tab.size(), s);
+    lambda.upload(lam.data(), lam.size(), s);
+    OMG_HIP(hipStreamSynchronize(s));
+    w = gx * gy;
+    bytes = (tab.size() + lam.size()) * sizeof(double);
+    return true;
+}
+
+template <typename V>
 void CoarseSolver<V>::solve(const V *b, V *x, hipStream_t s) const {
     if (n == 0) return;
+    if (P == 0) {
+        const int E = std::max(sx, std::max(sy, sz)) <= 16 ? 16 : 32;
+        const size_t lds = (size_t(sx + 1) * size_t(sy) * size_t(sz) + 2 + size_t(sx + sy + sz) * size_t(E)) * sizeof(double);
+        if (E == 16) {
+            hipLaunchKernelGGL((sine_solve_kernel<V, 16>), dim3(1), dim3(SINE_THREADS), lds, s, b, x, sx, sy, sz, sine.p, lambda.p);
+        } else {
+            if (lds > size_t(64) * 1024)
+                OMG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(sine_solve_kernel<V, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
+            hipLaunchKernelGGL((sine_solve_kernel<V, 32>), dim3(1), dim3(SINE_THREADS), lds, s, b, x, sx, sy, sz, sine.p, lambda.p);
+        }
+        OMG_HIP(hipGetLastError());
+        return;
+    }
     if (P == 1) {
         launch_dense_gemv<V>(inv.p, b, x, n, s);
         return;

@@ -38,7 +38,7 @@ def banded_unsymmetric(n, w, rng, density=0.3):
 
 
 @pytest.mark.parametrize("case", ["poisson3d_16", "poisson2d_128", "galerkin_16", "banded_unsym", "poisson2d_160", "dense_small",
-                                  "poisson1d_100k"])
+                                  "poisson1d_100k", "sine_1d_31", "sine_2d_20x32", "sine_3d_6x10x30", "sine_aniso"])
 def test_direct_solve_against_superlu(monkeypatch, case):
     rng = np.random.default_rng(5)
     if case == "poisson3d_16":
@@ -49,6 +49,20 @@ def test_direct_solve_against_superlu(monkeypatch, case):
         A0 = operators.stencil_poisson((32, 32, 32))
         R = operators.restriction((32, 32, 32))
         A = _hip.rap(R, A0)                                       # the coarse operator of a real hierarchy
+    elif case == "sine_1d_31":
+        A = operators.stencil_poisson((31,))
+    elif case == "sine_2d_20x32":
+        A = operators.stencil_poisson((20, 32))
+    elif case == "sine_3d_6x10x30":
+        A = operators.stencil_poisson((6, 10, 30))
+    elif case == "sine_aniso":                                    # different couplings per axis, shifted diagonal
+        n3 = (7, 9, 12)
+        T = [sp.diags([np.ones(m - 1), np.zeros(m), np.ones(m - 1)], [-1, 0, 1]) for m in n3]
+        I = [sp.identity(m) for m in n3]
+        A = sp.csr_matrix(5.0 * sp.identity(7 * 9 * 12) - 0.3 * sp.kron(sp.kron(T[0], I[1]), I[2])
+                          - 1.1 * sp.kron(sp.kron(I[0], T[1]), I[2]) + 0.7 * sp.kron(sp.kron(I[0], I[1]), T[2]))
+        A.eliminate_zeros()
+        A.sort_indices()
     elif case == "banded_unsym":
         A = banded_unsymmetric(5000, 37, rng)
     elif case == "poisson2d_160":
@@ -65,6 +79,11 @@ def test_direct_solve_against_superlu(monkeypatch, case):
     assert got.shape == (n,)
     np.testing.assert_allclose(got, want, rtol=1e-10, atol=1e-12 * scale)
     assert np.linalg.norm(b - A @ got) <= 1e-11 * np.linalg.norm(b) * max(1.0, np.linalg.cond(A.toarray()) if n <= 300 else 1e3)
+    if case in ("poisson3d_16", "galerkin_16"):
+        # (the default above was the sine-transform solve; without it: the factorisation paths' own choice)
+        monkeypatch.setenv("OMG_COARSE_SINE", "0")
+        np.testing.assert_allclose(_hip.direct_solve(A, b), want, rtol=1e-10, atol=1e-12 * scale)
+        monkeypatch.delenv("OMG_COARSE_SINE")
     if n <= 16384:
         monkeypatch.setenv("OMG_COARSE_BLOCKS", "1")              # explicit inverse: the round-1 path
         dense = _hip.direct_solve(A, b)
@@ -98,7 +117,7 @@ def test_hierarchy_coarse_solver_kind_and_cycle_parity(monkeypatch):
     A = operators.coeffecientList(A0, R)
     b = A0 @ np.random.default_rng(12345).random(A0.shape[0])
     out = {}
-    for blocks in ("4", "0"):
+    for blocks in ("4", "1", "0"):
         monkeypatch.setenv("OMG_COARSE_BLOCKS", blocks)
         for dtype in ("float64", "float32"):
             with _hip.Hierarchy(A, R, smoother="colour", dtype=dtype) as h:
@@ -108,17 +127,24 @@ def test_hierarchy_coarse_solver_kind_and_cycle_parity(monkeypatch):
                 h.resident_load(b)
                 norms = [h.resident_cycle(1, 1) for _ in range(3)]
                 out[(blocks, dtype)] = (info, xc, norms, h.resident_fetch())
-    sub, inv = out[("4", "float64")], out[("0", "float64")]
+    sub, inv, sine = out[("4", "float64")], out[("1", "float64")], out[("0", "float64")]
     assert sub[0]["blocks"] > 1 and sub[0]["n"] == 4096 and sub[0]["half_bandwidth"] == 256
     assert inv[0]["blocks"] == 1 and inv[0]["bytes_per_solve"] == 4096 * 4096 * 8
     assert sub[0]["bytes_per_solve"] < 0.45 * inv[0]["bytes_per_solve"]
+    # round 3, the default for such an operator (constant-coefficient symmetric star stencil, extents <= 32):
+    # sine transforms — blocks == 0, three 16 x 16 tables and 4096 eigenvalues instead of the 134 MB inverse
+    assert sine[0]["blocks"] == 0 and sine[0]["bytes_per_solve"] == (3 * 256 + 4096) * 8       # three 16 x 16 tables, 4096 eigenvalues
     want = spla.spsolve(sp.csc_matrix(A[2]), np.random.default_rng(3).random(4096))
-    for run in (sub, inv):
+    for run in (sub, inv, sine):
         np.testing.assert_allclose(run[1], want, rtol=1e-10, atol=1e-13)
     np.testing.assert_allclose(sub[2], inv[2], rtol=1e-11)
     np.testing.assert_allclose(sub[3], inv[3], rtol=1e-10, atol=1e-13)
+    np.testing.assert_allclose(sine[2], inv[2], rtol=1e-11)
+    np.testing.assert_allclose(sine[3], inv[3], rtol=1e-10, atol=1e-13)
     eps32 = float(np.finfo(np.float32).eps)
-    s32, i32 = out[("4", "float32")], out[("0", "float32")]
+    s32, i32 = out[("4", "float32")], out[("1", "float32")]
+    np.testing.assert_allclose(out[("0", "float32")][1], want, rtol=0, atol=16 * eps32 * np.linalg.cond(A[2].toarray()) * np.abs(want).max())
+    np.testing.assert_allclose(out[("0", "float32")][2], i32[2], rtol=1e-3)
     cond = np.linalg.cond(A[2].toarray())
     np.testing.assert_allclose(s32[1], want, rtol=0, atol=16 * eps32 * cond * np.abs(want).max())
     np.testing.assert_allclose(s32[2], i32[2], rtol=1e-3)
