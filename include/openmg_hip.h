@@ -303,6 +303,10 @@ int omg_dist_sync(omg_dist *d);
  * every rank connects.  librccl is dlopen'ed on first use.                                */
 int omg_rccl_unique_id(void *out128);
 int omg_dist_connect(omg_dist *d, const void *unique_id128);
+/* Microseconds per grouped ncclSend + ncclRecv of `bytes` to the calling rank itself on a one-rank
+ * communicator, each followed by a small kernel, `reps` back to back on one stream (hipEvents): the floor
+ * of a halo exchange on this GPU (no link involved) — tools/exchange_probe.py, DESIGN.md section 7. */
+int omg_rccl_self_exchange_time(int64_t bytes, int reps, double *avg_us);
 /* Number of ranks of the RCCL communicator this rank is connected to (ncclCommCount); 0 before
  * omg_dist_connect.  bench.py prints it (config.rccl_ranks) as evidence that the N-GPU run
  * really is one N-rank communicator.                                                        */

@@ -103,6 +103,7 @@ SIGNATURES = {
     "omg_dist_set_stream": (_I, [_P, _P]),
     "omg_dist_sync": (_I, [_P]),
     "omg_rccl_unique_id": (_I, [_P]),
+    "omg_rccl_self_exchange_time": (_I, [ctypes.c_int64, _I, _DP]),
     "omg_dist_connect": (_I, [_P, _P]),
     "omg_dist_rccl_ranks": (_I, [_P, _IP]),
     "omg_dist_load": (_I, [_P, _P, _P]),

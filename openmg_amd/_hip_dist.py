@@ -11,6 +11,14 @@ def set_device(device):
     check(lib().omg_set_device(int(device)))
 
 
+def self_exchange_us(n_bytes, reps=200):
+    """Microseconds per grouped ncclSend + ncclRecv of n_bytes to this rank itself (one-rank communicator):
+    the floor of one halo exchange (omg_rccl_self_exchange_time)."""
+    us = ctypes.c_double(0.0)
+    check(lib().omg_rccl_self_exchange_time(int(n_bytes), int(reps), ctypes.byref(us)))
+    return us.value
+
+
 def rccl_unique_id():
     """128-byte RCCL bootstrap id (make it on rank 0, broadcast it, connect everywhere)."""
     buf = ctypes.create_string_buffer(128)

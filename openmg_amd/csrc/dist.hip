@@ -898,6 +898,57 @@ int omg_rccl_unique_id(void *out128) {
     });
 }
 
+// What one grouped halo exchange costs on this GPU, measured with the calls the runner makes: a ONE-rank
+// communicator, ncclSend + ncclRecv of `bytes` to the rank itself inside ncclGroupStart / ncclGroupEnd on a
+// stream, `reps` of them back to back, each followed by a small kernel (as a smoother set follows an exchange
+// in the cycle), one hipEvent bracket.  No xGMI hop is involved, so this is the FLOOR of an exchange: API
+// and launch cost of the grouped pair plus a device copy — what N = 8 adds on top is the link.
+__global__ void exchange_probe_touch(double *p) { p[threadIdx.x] += 1.0; }
+int omg_rccl_self_exchange_time(int64_t bytes, int reps, double *avg_us) {
+    return guarded([&] {
+        OMG_REQUIRE(bytes > 0 && reps > 0 && avg_us, "bad argument");
+        require_device();
+        g_rccl.load();
+        ncclUniqueId id;
+        OMG_NCCL(g_rccl.GetUniqueId(&id));
+        ncclComm_t comm = nullptr;
+        OMG_NCCL(g_rccl.CommInitRank(&comm, 1, id, 0));
+        hipStream_t s = nullptr;
+        OMG_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+        {
+            DevBuf<char> a, b;
+            a.alloc(size_t(bytes));
+            b.alloc(size_t(bytes));
+            DevBuf<double> t(64);
+            OMG_HIP(hipMemsetAsync(a.p, 1, size_t(bytes), s));
+            OMG_HIP(hipMemsetAsync(t.p, 0, 64 * sizeof(double), s));
+            auto once = [&]() {
+                OMG_NCCL(g_rccl.GroupStart());
+                OMG_NCCL(g_rccl.Send(a.p, size_t(bytes), ncclChar, 0, comm, s));
+                OMG_NCCL(g_rccl.Recv(b.p, size_t(bytes), ncclChar, 0, comm, s));
+                OMG_NCCL(g_rccl.GroupEnd());
+                hipLaunchKernelGGL(exchange_probe_touch, dim3(1), dim3(64), 0, s, t.p);
+            };
+            for (int i = 0; i < 5; ++i) once();
+            hipEvent_t e0, e1;
+            OMG_HIP(hipEventCreate(&e0));
+            OMG_HIP(hipEventCreate(&e1));
+            OMG_HIP(hipEventRecord(e0, s));
+            for (int i = 0; i < reps; ++i) once();
+            OMG_HIP(hipEventRecord(e1, s));
+            OMG_HIP(hipEventSynchronize(e1));
+            float ms = 0.f;
+            OMG_HIP(hipEventElapsedTime(&ms, e0, e1));
+            (void)hipEventDestroy(e0);
+            (void)hipEventDestroy(e1);
+            *avg_us = 1e3 * double(ms) / reps;
+        }
+        (void)hipStreamSynchronize(s);
+        (void)g_rccl.CommDestroy(comm);
+        (void)hipStreamDestroy(s);
+    });
+}
+
 int omg_dist_connect(omg_dist *d, const void *unique_id128) {
     return guarded([&] {
         OMG_REQUIRE(unique_id128, "null argument");
