@@ -337,6 +337,30 @@ int omg_dist_group_destroy(omg_dist_group *g);
 int omg_dist_group_cycle(omg_dist_group *g, int pre, int post, double *norm);
 int omg_dist_group_cycles(omg_dist_group *g, int pre, int post, int n_cycles, double *norms);
 
+/* ---- plane-pipelined slabs (csrc/dist.hip, round 3): the multi-GPU cycle of constant-coefficient grid stencils ----
+ * A rank owns nz_global / n_ranks planes of every distributed level (halved per level) plus ghost planes; each half of
+ * the cycle over a level is the single-GPU plane-pipelined launch on that slab (csrc/plane.hip), the exchanges are
+ * ghost PLANES (three of x before a pass, two of the right-hand side / the coarse correction), the level below the
+ * slabs is gathered and run replicated (`tail`, an ordinary hierarchy, borrowed).  coef7: seven coefficients per
+ * distributed level (-K, -J, -I, diagonal, +I, +J, +K), weight: the aggregation's.  double, V(1,1).  The iterate is
+ * bit-identical to the single-GPU cycle for every number of ranks.                                                  */
+typedef struct omg_pdist omg_pdist;
+typedef struct omg_pdist_group omg_pdist_group;
+int omg_pdist_create(int rank, int n_ranks, int nx, int ny, int nz_global, int n_levels, const double *coef7, double weight,
+                     omg_pdist **out);
+int omg_pdist_destroy(omg_pdist *d);
+int omg_pdist_set_tail(omg_pdist *d, omg_hierarchy *tail);
+int omg_pdist_connect(omg_pdist *d, const void *unique_id128);
+int omg_pdist_rccl_ranks(omg_pdist *d, int *count);
+int omg_pdist_load(omg_pdist *d, const double *b_local, const double *x0_local /* NULL = zeros */);   /* collective */
+int omg_pdist_fetch(omg_pdist *d, double *x_local);
+int omg_pdist_sync(omg_pdist *d);
+int omg_pdist_cycles(omg_pdist *d, int n_cycles, double *norms /* nullable */);                         /* collective */
+/* all ranks in one process on one GPU, device copies in place of RCCL (verification) */
+int omg_pdist_group_create(int n, omg_pdist **ranks, omg_pdist_group **out);
+int omg_pdist_group_destroy(omg_pdist_group *g);
+int omg_pdist_group_cycles(omg_pdist_group *g, int n_cycles, double *norms /* nullable */);
+
 #ifdef __cplusplus
 }
 #endif

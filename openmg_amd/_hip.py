@@ -104,6 +104,18 @@ SIGNATURES = {
     "omg_dist_sync": (_I, [_P]),
     "omg_rccl_unique_id": (_I, [_P]),
     "omg_rccl_self_exchange_time": (_I, [ctypes.c_int64, _I, _DP]),
+    "omg_pdist_create": (_I, [_I, _I, _I, _I, _I, _I, _P, _D, _PP]),
+    "omg_pdist_destroy": (_I, [_P]),
+    "omg_pdist_set_tail": (_I, [_P, _P]),
+    "omg_pdist_connect": (_I, [_P, _P]),
+    "omg_pdist_rccl_ranks": (_I, [_P, _IP]),
+    "omg_pdist_load": (_I, [_P, _P, _P]),
+    "omg_pdist_fetch": (_I, [_P, _P]),
+    "omg_pdist_sync": (_I, [_P]),
+    "omg_pdist_cycles": (_I, [_P, _I, _P]),
+    "omg_pdist_group_create": (_I, [_I, _P, _PP]),
+    "omg_pdist_group_destroy": (_I, [_P]),
+    "omg_pdist_group_cycles": (_I, [_P, _I, _P]),
     "omg_dist_connect": (_I, [_P, _P]),
     "omg_dist_rccl_ranks": (_I, [_P, _IP]),
     "omg_dist_load": (_I, [_P, _P, _P]),

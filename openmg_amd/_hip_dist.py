@@ -181,3 +181,96 @@ class DistGroup:
             self._g = None
         for r in self.ranks:
             r.close()
+
+
+# ---- plane-pipelined slabs (omg_pdist_*) ------------------------------------------------------
+def star_coefficients(A, shape):
+    """The seven coefficients (-K, -J, -I, diagonal, +I, +J, +K) of a constant-coefficient star stencil on a
+    C-ordered grid of `shape` (planes, lines, cells), read off the row of cell (1, 1, 1)."""
+    A = as_csr(A)
+    nz, ny, nx = (int(s) for s in shape)
+    r = (1 * ny + 1) * nx + 1
+    lo, hi = A.indptr[r], A.indptr[r + 1]
+    cols, vals = A.indices[lo:hi], A.data[lo:hi]
+    want = [r - nx * ny, r - nx, r - 1, r, r + 1, r + nx, r + nx * ny]
+    if list(cols) != want:
+        raise ValueError("not a seven-point star stencil with ascending columns")
+    return [float(v) for v in vals]
+
+
+class PlaneDistRank:
+    """One rank's slab of a constant-coefficient 7-point hierarchy run as plane-pipelined passes (omg_pdist).
+    shape: the GLOBAL finest grid (planes, lines, cells); coefficients: seven per distributed level; tail: a
+    _hip.Hierarchy over the levels below the slabs (kept alive here)."""
+
+    def __init__(self, rank, n_ranks, shape, coefficients, weight, tail):
+        nz, ny, nx = (int(s) for s in shape)
+        c = np.ascontiguousarray(np.asarray(coefficients, dtype=np.float64).reshape(-1, 7))
+        h = ctypes.c_void_p()
+        check(lib().omg_pdist_create(int(rank), int(n_ranks), nx, ny, nz, c.shape[0], c.ctypes.data, float(weight), ctypes.byref(h)))
+        self._h = h
+        self._tail = tail
+        self.rank, self.n_ranks = int(rank), int(n_ranks)
+        self.n_local = nx * ny * (nz // int(n_ranks))
+        check(lib().omg_pdist_set_tail(self._h, tail._h))
+
+    def connect(self, unique_id):
+        buf = ctypes.create_string_buffer(bytes(unique_id), 128)
+        check(lib().omg_pdist_connect(self._h, buf))
+
+    def rccl_ranks(self):
+        n = ctypes.c_int(0)
+        check(lib().omg_pdist_rccl_ranks(self._h, ctypes.byref(n)))
+        return n.value
+
+    def load(self, b_local, x0_local=None):
+        b = vec(b_local, self.n_local)
+        x0 = None if x0_local is None else vec(x0_local, self.n_local)
+        check(lib().omg_pdist_load(self._h, b.ctypes.data, None if x0 is None else x0.ctypes.data))
+
+    def fetch(self):
+        x = np.empty(self.n_local, dtype=np.float64)
+        check(lib().omg_pdist_fetch(self._h, x.ctypes.data))
+        return x
+
+    def sync(self):
+        check(lib().omg_pdist_sync(self._h))
+
+    def cycles(self, n_cycles):
+        norms = (ctypes.c_double * max(int(n_cycles), 1))()
+        check(lib().omg_pdist_cycles(self._h, int(n_cycles), norms))
+        return [float(norms[k]) for k in range(int(n_cycles))]
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().omg_pdist_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class PlaneDistGroup:
+    """All ranks of a plane-slab decomposition in one process on one GPU (device copies in place of RCCL)."""
+
+    def __init__(self, ranks):
+        self.ranks = list(ranks)
+        arr = (ctypes.c_void_p * len(self.ranks))(*[r._h for r in self.ranks])
+        g = ctypes.c_void_p()
+        check(lib().omg_pdist_group_create(len(self.ranks), arr, ctypes.byref(g)))
+        self._g = g
+
+    def cycles(self, n_cycles):
+        norms = (ctypes.c_double * max(int(n_cycles), 1))()
+        check(lib().omg_pdist_group_cycles(self._g, int(n_cycles), norms))
+        return [float(norms[k]) for k in range(int(n_cycles))]
+
+    def close(self):
+        if getattr(self, "_g", None):
+            lib().omg_pdist_group_destroy(self._g)
+            self._g = None
+        for r in self.ranks:
+            r.close()

@@ -482,6 +482,9 @@ struct MarchPlan {
 struct PlaneGeom {
     int nx = 0, ny = 0, nz = 0;       // cells per line, lines per plane, planes (all even)
     int hx = 0;                       // cells of one colour per line = nx / 2
+    // a slab with ghost planes (plane_dist.hip): planes [z_base, z_end) are relaxed and stored, [kv0, kv1) exist in
+    // the global grid; the coarse grid has nzc planes and fine plane k restricts into coarse plane (k >> 1) + kc_off
+    int z_base = 0, z_end = 0, kv0 = 0, kv1 = 0, kc_off = 0, nzc = 0;
     int TX = 0, TY = 0, LZ = 0;       // a workgroup's interior: cells in x (multiple of 4), lines (even), planes (even)
     int PX = 0, PY = 0;               // its threads: TX / 4 + 2 (four cells each) x TY / 2 + 4 (two lines each)
     int ntx = 0, nty = 0, ntz = 0, n_wg = 0;
@@ -504,6 +507,10 @@ struct PlanePlan {
     // format of a plane level is built from when something asks for it (hierarchy.hip ensure_format).
     HostCsr operator_csr() const;
     HostCsr restriction_csr() const;
+    // A slab of such a level with `ghost` planes on either side (plane_dist.hip): nz_own planes of nx x ny cells
+    // behind `ghost` ghost planes; first / last: the slab holds the global grid's first / last plane (its outer
+    // ghost planes do not exist and stay zero).  The coarse slab has `ghost_c` ghost planes of its own.
+    void build_slab(int nx, int ny, int nz_own, int ghost, int ghost_c, bool first, bool last, const double (&c)[7], double w);
     struct Coarse {
         const int32_t *map = nullptr; // coarse natural index -> slot in the coarse ordering (null: identity)
         V *b = nullptr;               // down: coarse right-hand side

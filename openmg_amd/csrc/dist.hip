@@ -828,6 +828,259 @@ void with(omg_dist *d, F &&f) {
 template <typename HP>
 using value_of = typename std::remove_pointer<HP>::type::value_type;
 
+
+// ============================================================================================================
+// Plane-pipelined slabs (round 3).  The runner above exchanges one boundary plane per colour after every
+// smoother set: ~8 exchanges per level and cycle, each at least 10-12 us (profiles/r03_exchange_probe.txt) — more
+// than a level's arithmetic on the small levels.  For the constant-coefficient grid stencils the single-GPU
+// cycle runs as plane-pipelined passes (plane.hip), a rank's slab — its planes of every distributed level plus
+// GHOST planes on either side, in the red-black ordering of that extended grid — runs the SAME kernel: the
+// passes' overlapped ring does in z what it does in x and y, the neighbour's planes take the place of the
+// redundantly relaxed ring.  Exchanges per cycle and distributed level: three ghost planes of x before each pass
+// (the one before the up pass travels while the coarser levels run), two ghost planes of the right-hand side
+// (levels >= 1) and of the coarse correction — contiguous runs of the plane-major vectors, no pack kernels.
+// Below the last distributed level every rank all-gathers the right-hand side and runs the replicated tail
+// hierarchy (as above).  The iterate has the bits of the single-GPU cycle for every number of ranks
+// (tests/test_gpu_plane_dist.py: loopback groups of 2, 4, 8 slabs on one GPU against the hierarchy).
+// double only; V(1,1).
+constexpr int PD_GHOST = 4;                   // ghost planes on either side of a slab (three are read; even: colour parity)
+
+struct PDLevel {
+    int nx = 0, ny = 0, nzo = 0;              // cells per line, lines per plane, owned planes
+    int64_t pc = 0, n_ext = 0;                // one colour's values per plane; values of the extended slab
+    PlanePlan<double> plan;
+    DevBuf<double> x, tmp, b;
+    double *xp = nullptr, *tp = nullptr;
+    DevBuf<int32_t> cmap;                     // coarse slab (natural, extended) -> slot in the next level's ordering (not the last level)
+};
+
+struct PlaneDist {
+    int rank = 0, n_ranks = 1;
+    std::vector<PDLevel> lv;
+    // the level below the last distributed one: every rank's planes of its right-hand side / of the correction in
+    // natural order with ghost planes (cb, ce), and the whole of them for the replicated tail (full_b, full_x)
+    int cnx = 0, cny = 0, cnzo = 0;
+    DevBuf<double> cb, ce, full_b, full_x;
+    omg_hierarchy *tail = nullptr;
+    DevBuf<double> norm2, norms;              // this rank's sum of squares; the batch's norms
+    DevBuf<double> nat;                       // host I/O staging (owned planes, natural order)
+    hipStream_t own = nullptr, stream = nullptr;
+    ncclComm_t comm = nullptr;
+    ~PlaneDist() {
+        if (comm) (void)g_rccl.CommDestroy(comm);
+        if (own) (void)hipStreamDestroy(own);
+    }
+};
+
+// owned planes, natural order <-> the extended slab's red-black ordering
+__global__ void pd_scatter_kernel(const double *__restrict__ nat, double *__restrict__ ext, int nx, int ny, int nzo, int ghost, int to_ext) {
+    const int64_t n = int64_t(nx) * ny * nzo, nr = int64_t(nx) * ny * (nzo + 2 * ghost) / 2;
+    for (int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r < n; r += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t i = r % nx, j = (r / nx) % ny, k = r / (int64_t(nx) * ny) + ghost;
+        const int64_t e = (k * ny + j) * nx + i;                  // natural index in the extended slab
+        const int64_t slot = (((i + j + k) & 1) ? nr : 0) + e / 2;
+        if (to_ext) ext[slot] = nat[r];
+        else const_cast<double *>(nat)[r] = ext[slot];
+    }
+}
+__global__ void pd_add_kernel(double *acc, const double *v) { *acc += *v; }
+__global__ void pd_sqrt_kernel(const double *v, double *out) { *out = sqrt(*v); }
+
+// The schedule over a set of ranks: ONE rank with RCCL exchanges, or all of them in one process with device copies
+// in their place (loopback group: the same launches in the same order per rank).
+struct PDExchange {
+    std::vector<PlaneDist *> ranks;           // the ranks this process drives, ascending
+    bool loopback = false;
+
+    // ghost planes of a plane-major vector of level l (both colours): `count` planes from either neighbour
+    void halo(int l, int which /* 0 x (current), 1 b */, int count) {
+        for (PlaneDist *d : ranks) {
+            PDLevel &L = d->lv[l];
+            if (!loopback && d->n_ranks > 1) OMG_NCCL(g_rccl.GroupStart());
+            for (int colour = 0; colour < 2; ++colour) {
+                double *mine = (which == 0 ? L.xp : L.b.p) + (colour ? L.n_ext / 2 : 0);
+                const size_t cnt = size_t(count) * size_t(L.pc);
+                // up: my last owned planes -> rank + 1's lower ghosts; down: my first owned planes -> rank - 1's upper ghosts
+                double *send_up = mine + int64_t(PD_GHOST + L.nzo - count) * L.pc, *recv_lo = mine + int64_t(PD_GHOST - count) * L.pc;
+                double *send_dn = mine + int64_t(PD_GHOST) * L.pc, *recv_hi = mine + int64_t(PD_GHOST + L.nzo) * L.pc;
+                if (loopback) {
+                    // (only the receives: every rank pulls from its neighbours' owned planes, which no launch between
+                    // the passes writes)
+                    if (d->rank > 0) {
+                        PlaneDist *o = ranks[d->rank - 1];
+                        PDLevel &O = o->lv[l];
+                        const double *src = (which == 0 ? O.xp : O.b.p) + (colour ? O.n_ext / 2 : 0) + int64_t(PD_GHOST + O.nzo - count) * O.pc;
+                        OMG_HIP(hipMemcpyAsync(recv_lo, src, cnt * sizeof(double), hipMemcpyDeviceToDevice, d->stream));
+                    }
+                    if (d->rank + 1 < d->n_ranks) {
+                        PlaneDist *o = ranks[d->rank + 1];
+                        PDLevel &O = o->lv[l];
+                        const double *src = (which == 0 ? O.xp : O.b.p) + (colour ? O.n_ext / 2 : 0) + int64_t(PD_GHOST) * O.pc;
+                        OMG_HIP(hipMemcpyAsync(recv_hi, src, cnt * sizeof(double), hipMemcpyDeviceToDevice, d->stream));
+                    }
+                } else if (d->n_ranks > 1) {
+                    if (d->rank + 1 < d->n_ranks) {
+                        OMG_NCCL(g_rccl.Send(send_up, cnt, ncclDouble, d->rank + 1, d->comm, d->stream));
+                        OMG_NCCL(g_rccl.Recv(recv_hi, cnt, ncclDouble, d->rank + 1, d->comm, d->stream));
+                    }
+                    if (d->rank > 0) {
+                        OMG_NCCL(g_rccl.Send(send_dn, cnt, ncclDouble, d->rank - 1, d->comm, d->stream));
+                        OMG_NCCL(g_rccl.Recv(recv_lo, cnt, ncclDouble, d->rank - 1, d->comm, d->stream));
+                    }
+                }
+            }
+            if (!loopback && d->n_ranks > 1) OMG_NCCL(g_rccl.GroupEnd());
+        }
+    }
+    // loopback: all ranks of a group share one stream order only per rank; a copy must not start before the
+    // source rank's producing kernel has finished -> the group runs on ONE stream (set at creation)
+
+    void down(int l) {
+        for (PlaneDist *d : ranks) {
+            PDLevel &L = d->lv[l];
+            const bool last = l + 1 == (int)d->lv.size();
+            PlanePlan<double>::Coarse c;
+            c.map = last ? nullptr : L.cmap.p;
+            c.b = last ? d->cb.p : d->lv[l + 1].b.p;
+            c.x = nullptr;                                        // the level below takes its iterate as zero
+            L.plan.down(L.xp, L.tp, L.b.p, l > 0, c, d->stream);
+            std::swap(L.xp, L.tp);
+        }
+    }
+    void up(int l, double *partials) {
+        for (PlaneDist *d : ranks) {
+            PDLevel &L = d->lv[l];
+            const bool last = l + 1 == (int)d->lv.size();
+            PlanePlan<double>::Coarse c;
+            c.map = last ? nullptr : L.cmap.p;
+            c.e = last ? d->ce.p : d->lv[l + 1].xp;
+            L.plan.up(L.xp, L.tp, L.b.p, c, l == 0 ? (partials ? partials : L.plan.partials.p) : nullptr, d->stream);
+            std::swap(L.xp, L.tp);
+        }
+    }
+    // right-hand side of the level below the slabs: gathered, solved by the replicated tail, the slab's planes
+    // (and ghosts) of the correction taken out of it
+    void tail_solve() {
+        for (PlaneDist *d : ranks) {
+            const int64_t plane = int64_t(d->cnx) * d->cny, own = plane * d->cnzo;
+            const double *mine = d->cb.p + int64_t(PD_GHOST) * plane;
+            if (loopback) {
+                for (PlaneDist *o : ranks)
+                    OMG_HIP(hipMemcpyAsync(o->full_b.p + int64_t(d->rank) * own, mine, size_t(own) * sizeof(double), hipMemcpyDeviceToDevice, d->stream));
+            } else if (d->n_ranks > 1) {
+                OMG_NCCL(g_rccl.AllGather(mine, d->full_b.p, size_t(own), ncclDouble, d->comm, d->stream));
+            } else {
+                OMG_HIP(hipMemcpyAsync(d->full_b.p, mine, size_t(own) * sizeof(double), hipMemcpyDeviceToDevice, d->stream));
+            }
+        }
+        for (PlaneDist *d : ranks) {
+            const int64_t plane = int64_t(d->cnx) * d->cny;
+            if (omg_hierarchy_cycle_dev(d->tail, d->full_b.p, d->full_x.p, 1, 1, d->stream) != OMG_OK)
+                throw Error(OMG_ERR_HIP, std::string("replicated tail cycle: ") + omg_last_error());
+            // planes [k0 - ghost, k0 + own + ghost) of the correction, clipped to the grid (the rest stays zero)
+            const int64_t k0 = int64_t(d->rank) * d->cnzo, nzg = int64_t(d->n_ranks) * d->cnzo;
+            const int64_t lo = std::max<int64_t>(0, k0 - PD_GHOST), hi = std::min<int64_t>(nzg, k0 + d->cnzo + PD_GHOST);
+            OMG_HIP(hipMemcpyAsync(d->ce.p + (lo - (k0 - PD_GHOST)) * plane, d->full_x.p + lo * plane, size_t(hi - lo) * size_t(plane) * sizeof(double),
+                                   hipMemcpyDeviceToDevice, d->stream));
+        }
+    }
+    // one V(1,1) cycle; the norm's squares of every rank in its norm2 (level-0 up pass partials summed)
+    void cycle() {
+        const int nd = (int)ranks[0]->lv.size();
+        halo(0, 0, 3);
+        for (int l = 0; l < nd; ++l) {
+            if (l > 0) halo(l, 1, 2);
+            down(l);
+            halo(l, 0, 3);                                        // for the up pass (nothing before it reads these planes)
+        }
+        tail_solve();
+        for (int l = nd - 1; l >= 0; --l) {
+            if (l + 1 < nd) halo(l + 1, 0, 2);                    // ghost planes of the correction
+            up(l, nullptr);
+        }
+        for (PlaneDist *d : ranks) launch_sum(d->lv[0].plan.partials.p, d->lv[0].plan.g.n_wg, d->norm2.p, d->stream);
+    }
+    // ||b - A x|| of the cycle just run into out (device) on every rank
+    void norm(double *const *out_per_rank) {
+        if (loopback) {
+            // ranks in ascending order into rank 0's accumulator, then to everybody (one stream)
+            PlaneDist *z = ranks[0];
+            for (size_t r = 1; r < ranks.size(); ++r) hipLaunchKernelGGL(pd_add_kernel, dim3(1), dim3(1), 0, z->stream, z->norm2.p, ranks[r]->norm2.p);
+            for (size_t r = 0; r < ranks.size(); ++r) hipLaunchKernelGGL(pd_sqrt_kernel, dim3(1), dim3(1), 0, z->stream, z->norm2.p, out_per_rank[r]);
+        } else {
+            PlaneDist *d = ranks[0];
+            if (d->n_ranks > 1) OMG_NCCL(g_rccl.AllReduce(d->norm2.p, d->norm2.p, 1, ncclDouble, ncclSum, d->comm, d->stream));
+            hipLaunchKernelGGL(pd_sqrt_kernel, dim3(1), dim3(1), 0, d->stream, d->norm2.p, out_per_rank[0]);
+        }
+        OMG_HIP(hipGetLastError());
+    }
+};
+
+std::unique_ptr<PlaneDist> pd_create(int rank, int n_ranks, int nx, int ny, int nz_global, int n_levels, const double *coef7, double w) {
+    OMG_REQUIRE(n_ranks >= 1 && rank >= 0 && rank < n_ranks && n_levels >= 1 && coef7, "bad argument");
+    OMG_REQUIRE(nz_global % n_ranks == 0, "planes must divide evenly over the ranks");
+    require_device();
+    std::unique_ptr<PlaneDist> d(new PlaneDist);
+    d->rank = rank;
+    d->n_ranks = n_ranks;
+    OMG_HIP(hipStreamCreateWithFlags(&d->own, hipStreamNonBlocking));
+    d->stream = d->own;
+    d->lv.resize(size_t(n_levels));
+    int lx = nx, ly = ny, lz = nz_global / n_ranks;
+    for (int l = 0; l < n_levels; ++l) {
+        PDLevel &L = d->lv[size_t(l)];
+        OMG_REQUIRE(lz >= 2 && !(lz & 1) && !(lx & 1) && !(ly & 1), "every distributed level needs an even number (>= 2) of planes per rank and even extents");
+        L.nx = lx; L.ny = ly; L.nzo = lz;
+        L.pc = int64_t(lx / 2) * ly;
+        L.n_ext = int64_t(lx) * ly * (lz + 2 * PD_GHOST);
+        double c[7];
+        for (int e = 0; e < 7; ++e) c[e] = coef7[7 * l + e];
+        L.plan.build_slab(lx, ly, lz, PD_GHOST, PD_GHOST, rank == 0, rank == n_ranks - 1, c, w);
+        L.x.alloc(size_t(L.n_ext)); L.tmp.alloc(size_t(L.n_ext)); L.b.alloc(size_t(L.n_ext));
+        L.x.zero(d->stream); L.tmp.zero(d->stream); L.b.zero(d->stream);
+        L.xp = L.x.p; L.tp = L.tmp.p;
+        lx /= 2; ly /= 2; lz /= 2;
+    }
+    // coarse slab (natural, extended) -> slot in the next level's red-black ordering
+    for (int l = 0; l + 1 < n_levels; ++l) {
+        const PDLevel &C = d->lv[size_t(l) + 1];
+        std::vector<int32_t> map(size_t(C.n_ext));
+        const int64_t nr = C.n_ext / 2;
+        for (int64_t e = 0; e < C.n_ext; ++e) {
+            const int64_t i = e % C.nx, j = (e / C.nx) % C.ny, k = e / (int64_t(C.nx) * C.ny);
+            map[size_t(e)] = int32_t((((i + j + k) & 1) ? nr : 0) + e / 2);
+        }
+        d->lv[size_t(l)].cmap.alloc(map.size());
+        d->lv[size_t(l)].cmap.upload(map.data(), map.size(), d->stream);
+        OMG_HIP(hipStreamSynchronize(d->stream));
+    }
+    OMG_REQUIRE(lz >= 1, "the level below the slabs needs at least one plane per rank");
+    d->cnx = lx; d->cny = ly; d->cnzo = lz;
+    const int64_t cplane = int64_t(lx) * ly;
+    d->cb.alloc(size_t(cplane * (lz + 2 * PD_GHOST)));
+    d->ce.alloc(size_t(cplane * (lz + 2 * PD_GHOST)));
+    d->cb.zero(d->stream); d->ce.zero(d->stream);
+    d->full_b.alloc(size_t(cplane * lz * n_ranks));
+    d->full_x.alloc(size_t(cplane * lz * n_ranks));
+    d->norm2.alloc(1);
+    d->norms.alloc(64);
+    d->nat.alloc(size_t(int64_t(nx) * ny * (nz_global / n_ranks)));
+    OMG_HIP(hipStreamSynchronize(d->stream));
+    return d;
+}
+
+}  // namespace
+}  // namespace omg
+
+struct omg_pdist {
+    std::unique_ptr<omg::PlaneDist> d;
+};
+struct omg_pdist_group {
+    std::vector<omg_pdist *> ranks;
+};
+
+namespace omg {
+namespace {
 }  // namespace
 }  // namespace omg
 
@@ -1147,6 +1400,174 @@ int omg_dist_group_cycle(omg_dist_group *g, int pre, int post, double *norm) {
             r.rccl = false;
             r.run(pre, post, norm);
         });
+    });
+}
+
+// ---- plane-pipelined slabs -----------------------------------------------------------------------------------
+int omg_pdist_create(int rank, int n_ranks, int nx, int ny, int nz_global, int n_levels, const double *coef7, double weight,
+                     omg_pdist **out) {
+    return guarded([&] {
+        OMG_REQUIRE(out, "out is null");
+        *out = nullptr;
+        std::unique_ptr<omg_pdist> h(new omg_pdist);
+        h->d = pd_create(rank, n_ranks, nx, ny, nz_global, n_levels, coef7, weight);
+        *out = h.release();
+    });
+}
+
+int omg_pdist_destroy(omg_pdist *d) {
+    return guarded([&] {
+        if (!d) return;
+        if (d->d) (void)hipStreamSynchronize(d->d->stream);
+        delete d;
+    });
+}
+
+int omg_pdist_set_tail(omg_pdist *d, omg_hierarchy *tail) {
+    return guarded([&] {
+        OMG_REQUIRE(d && d->d && tail, "null argument");
+        int64_t n = 0;
+        OMG_REQUIRE(omg_hierarchy_level_rows(tail, 0, &n) == OMG_OK &&
+                        n == int64_t(d->d->cnx) * d->d->cny * d->d->cnzo * d->d->n_ranks,
+                    "tail hierarchy's finest level must be the level below the slabs");
+        d->d->tail = tail;
+    });
+}
+
+int omg_pdist_connect(omg_pdist *d, const void *unique_id128) {
+    return guarded([&] {
+        OMG_REQUIRE(d && d->d && unique_id128, "null argument");
+        g_rccl.load();
+        ncclUniqueId id;
+        std::memcpy(&id, unique_id128, sizeof(id));
+        OMG_NCCL(g_rccl.CommInitRank(&d->d->comm, d->d->n_ranks, id, d->d->rank));
+    });
+}
+
+int omg_pdist_rccl_ranks(omg_pdist *d, int *count) {
+    return guarded([&] {
+        OMG_REQUIRE(d && d->d && count, "null argument");
+        *count = 0;
+        if (d->d->comm) OMG_NCCL(g_rccl.CommCount(d->d->comm, count));
+    });
+}
+
+static void pd_put(PlaneDist *d, const double *host, double *ext) {
+    PDLevel &L = d->lv[0];
+    const int64_t n = int64_t(L.nx) * L.ny * L.nzo;
+    if (host) {
+        d->nat.upload(host, size_t(n), d->stream);
+        hipLaunchKernelGGL(pd_scatter_kernel, dim3(1024), dim3(256), 0, d->stream, d->nat.p, ext, L.nx, L.ny, L.nzo, PD_GHOST, 1);
+        OMG_HIP(hipGetLastError());
+        OMG_HIP(hipStreamSynchronize(d->stream));           // (nat is reused by the next vector)
+    } else {
+        OMG_HIP(hipMemsetAsync(ext, 0, size_t(L.n_ext) * sizeof(double), d->stream));
+    }
+}
+
+/* b_local, x0_local: this rank's planes of the finest level in natural order (x0 NULL: zeros).  With a
+ * communicator of more than one rank the call is COLLECTIVE (the ghost planes of b are exchanged). */
+int omg_pdist_load(omg_pdist *d, const double *b_local, const double *x0_local) {
+    return guarded([&] {
+        OMG_REQUIRE(d && d->d && b_local, "null argument");
+        PlaneDist *dd = d->d.get();
+        pd_put(dd, b_local, dd->lv[0].b.p);
+        pd_put(dd, x0_local, dd->lv[0].xp);
+        if (dd->comm && dd->n_ranks > 1) {
+            PDExchange ex;
+            ex.ranks = {dd};
+            ex.halo(0, 1, 2);
+        }
+        OMG_HIP(hipStreamSynchronize(dd->stream));
+    });
+}
+
+int omg_pdist_fetch(omg_pdist *d, double *x_local) {
+    return guarded([&] {
+        OMG_REQUIRE(d && d->d && x_local, "null argument");
+        PlaneDist *dd = d->d.get();
+        PDLevel &L = dd->lv[0];
+        const int64_t n = int64_t(L.nx) * L.ny * L.nzo;
+        hipLaunchKernelGGL(pd_scatter_kernel, dim3(1024), dim3(256), 0, dd->stream, dd->nat.p, L.xp, L.nx, L.ny, L.nzo, PD_GHOST, 0);
+        OMG_HIP(hipGetLastError());
+        dd->nat.download(x_local, size_t(n), dd->stream);
+        OMG_HIP(hipStreamSynchronize(dd->stream));
+    });
+}
+
+int omg_pdist_sync(omg_pdist *d) {
+    return guarded([&] { OMG_REQUIRE(d && d->d, "null"); OMG_HIP(hipStreamSynchronize(d->d->stream)); });
+}
+
+/* n_cycles V(1,1) cycles, every cycle's global residual norm computed and returned; collective. */
+int omg_pdist_cycles(omg_pdist *d, int n_cycles, double *norms) {
+    return guarded([&] {
+        OMG_REQUIRE(d && d->d && n_cycles >= 0, "bad argument");
+        PlaneDist *dd = d->d.get();
+        OMG_REQUIRE(dd->tail, "omg_pdist_set_tail has not been called");
+        OMG_REQUIRE(dd->n_ranks == 1 || dd->comm, "omg_pdist_connect has not been called");
+        if (n_cycles == 0) return;
+        if (dd->norms.n < size_t(n_cycles)) dd->norms.alloc(size_t(n_cycles));
+        PDExchange ex;
+        ex.ranks = {dd};
+        for (int k = 0; k < n_cycles; ++k) {
+            ex.cycle();
+            double *out = dd->norms.p + k;
+            ex.norm(&out);
+        }
+        if (norms) OMG_HIP(hipMemcpyAsync(norms, dd->norms.p, size_t(n_cycles) * sizeof(double), hipMemcpyDeviceToHost, dd->stream));
+        OMG_HIP(hipStreamSynchronize(dd->stream));
+    });
+}
+
+/* All ranks of a decomposition in ONE process on one GPU: the same launches per rank, device copies in place of
+ * the RCCL exchanges (verification of the schedule without several GPUs).  The ranks run on rank 0's stream. */
+int omg_pdist_group_create(int n, omg_pdist **ranks, omg_pdist_group **out) {
+    return guarded([&] {
+        OMG_REQUIRE(n >= 1 && ranks && out, "bad argument");
+        std::unique_ptr<omg_pdist_group> g(new omg_pdist_group);
+        for (int r = 0; r < n; ++r) {
+            OMG_REQUIRE(ranks[r] && ranks[r]->d && ranks[r]->d->rank == r && ranks[r]->d->n_ranks == n, "ranks must be 0 .. n-1 of an n-rank decomposition");
+            OMG_HIP(hipStreamSynchronize(ranks[r]->d->stream));
+            ranks[r]->d->stream = ranks[0]->d->own;
+            g->ranks.push_back(ranks[r]);
+        }
+        *out = g.release();
+    });
+}
+
+int omg_pdist_group_destroy(omg_pdist_group *g) {
+    delete g;
+    return OMG_OK;
+}
+
+int omg_pdist_group_cycles(omg_pdist_group *g, int n_cycles, double *norms) {
+    return guarded([&] {
+        OMG_REQUIRE(g && !g->ranks.empty() && n_cycles >= 0, "bad argument");
+        PDExchange ex;
+        ex.loopback = true;
+        for (omg_pdist *r : g->ranks) {
+            OMG_REQUIRE(r->d->tail, "omg_pdist_set_tail has not been called on every rank");
+            ex.ranks.push_back(r->d.get());
+        }
+        if (n_cycles == 0) return;
+        PlaneDist *z = ex.ranks[0];
+        if (z->norms.n < size_t(n_cycles) * ex.ranks.size()) z->norms.alloc(size_t(n_cycles) * ex.ranks.size());
+        ex.halo(0, 1, 2);                                     // ghost planes of the right-hand side
+        std::vector<double *> outs(ex.ranks.size());
+        for (int k = 0; k < n_cycles; ++k) {
+            ex.cycle();
+            for (size_t r = 0; r < ex.ranks.size(); ++r) outs[r] = z->norms.p + size_t(k) * ex.ranks.size() + r;
+            ex.norm(outs.data());
+        }
+        std::vector<double> all(size_t(n_cycles) * ex.ranks.size());
+        OMG_HIP(hipMemcpyAsync(all.data(), z->norms.p, all.size() * sizeof(double), hipMemcpyDeviceToHost, z->stream));
+        OMG_HIP(hipStreamSynchronize(z->stream));
+        for (int k = 0; k < n_cycles; ++k) {
+            for (size_t r = 1; r < ex.ranks.size(); ++r)
+                OMG_REQUIRE(all[size_t(k) * ex.ranks.size() + r] == all[size_t(k) * ex.ranks.size()], "internal: ranks disagree about the norm");
+            if (norms) norms[k] = all[size_t(k) * ex.ranks.size()];
+        }
     });
 }
 

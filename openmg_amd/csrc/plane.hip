@@ -130,6 +130,10 @@ struct PlaneKArgs {
     unsigned vec_bytes;              // n * sizeof(V)
     int nr;                          // slot of the first black cell
     int hx, ny, nz;
+    // a slab of a larger grid (plane_dist.hip): the planes [z_base, z_end) are this launch's (relaxed, stored), the
+    // planes [kv0, kv1) exist in the global grid (the others — ghost planes beyond its first / last plane — are
+    // zeros and stay zeros); a whole grid: 0, nz, 0, nz.  kc_off: coarse plane of fine plane k = (k >> 1) + kc_off
+    int z_base, z_end, kv0, kv1, kc_off;
     int TXq, TY, LZ, PX, PY, ntx, nty, ntz;
     V c0, c1, c2, c3, c4, c5, c6, w;
     int x_zero;
@@ -250,7 +254,7 @@ __global__ __launch_bounds__(512) void plane_kernel(const PlaneKArgs<V> a) {
     const int nxy = a.ntx * a.nty;
     const int tz = L / nxy, rem = L - tz * nxy;
     const int ty = rem / a.ntx, tx = rem - ty * a.ntx;
-    const int z0 = tz * a.LZ, z1 = min(a.nz, z0 + a.LZ);
+    const int z0 = a.z_base + tz * a.LZ, z1 = min(a.z_end, z0 + a.LZ);
     const int q = tx * a.TXq + px - 1;               // pair index in the line
     const int ja = ty * a.TY + 2 * py - 4;           // the thread's lines ja (even), ja + 1
     const bool vx0 = live && q >= 0 && 2 * q < a.hx, vx1 = live && q >= 0 && 2 * q + 1 < a.hx;
@@ -267,7 +271,7 @@ __global__ __launch_bounds__(512) void plane_kernel(const PlaneKArgs<V> a) {
 
     // a pair of the level vector: colour (0 red, 1 black), plane k, line ja + l; 0 outside the grid
     auto fetch = [&](const __amdgpu_buffer_rsrc_t &rs, int colour, int k, int l) -> P2<V> {
-        const bool ok = vl[l] && vx0 && k >= 0 && k < a.nz;
+        const bool ok = vl[l] && vx0 && k >= a.kv0 && k < a.kv1;
         // (a pair's second value is cleared where it is TAKEN — clean() — not here: a select on the loaded
         // register would be the load's first consumer, in the step that issues it)
         return bload2(rs, ok ? ((colour ? a.nr : 0) + k * ps + lb[l]) * int(sizeof(V)) : OOB, V(0));
@@ -283,10 +287,12 @@ __global__ __launch_bounds__(512) void plane_kernel(const PlaneKArgs<V> a) {
     // ... in two halves, so that the load has no consumer in the step that issues it: the request
     // (raw words of the slot map; nothing is fetched for a lane that needs none) and, a step later, the slots
     auto slots_request = [&](int kc, bool want) -> v2u {
+        kc += a.kc_off;
         const bool ok = want && a.cmap && vcoarse && kc >= 0 && kc < a.nzc;
         return __builtin_amdgcn_raw_buffer_load_b64(ms, ok ? (kc * a.nyc * a.nxc + cbase) * 4 : OOB, 0, 0);   // (second word unused when !vx1)
     };
     auto slots_commit = [&](const v2u &m, int kc, bool want) -> v2i {
+        kc += a.kc_off;
         const bool ok = want && vcoarse && kc >= 0 && kc < a.nzc;
         const int cn = kc * a.nyc * a.nxc + cbase;
         const int s0_ = a.cmap ? int(m.x) : cn, s1_ = a.cmap ? int(m.y) : cn + 1;
@@ -445,7 +451,7 @@ __global__ __launch_bounds__(512) void plane_kernel(const PlaneKArgs<V> a) {
             const V *const E1 = lds + (0 * 2 + par) * BUF;        // black, old, plane s
             const V *const E2 = lds + (1 * 2 + par) * BUF;        // red, new, plane s - 1
             const V *const E3 = lds + (2 * 2 + par) * BUF;        // black, new, plane s - 2
-            const bool pvB = s >= 0 && s < a.nz, pvC = s - 1 >= 0 && s - 1 < a.nz, pvD = s - 2 >= 0 && s - 2 < a.nz;
+            const bool pvB = s >= a.kv0 && s < a.kv1, pvC = s - 1 >= a.kv0 && s - 1 < a.kv1, pvD = s - 2 >= a.kv0 && s - 2 < a.kv1;
             // B: red sweep of plane s
             {
                 const P2<V> jm = lds_pair(E1 + idx[0] - S), jp = lds_pair(E1 + idx[1] + S);
@@ -643,10 +649,11 @@ int env_int3(const char *name, int out[3]) {
 inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
 void choose_tiles(PlaneGeom &g, size_t value_bytes) {
+    const int nzo = g.z_end - g.z_base;             // planes the launch relaxes
     auto set = [&](int TX, int TY, int LZ) {
         g.TX = TX; g.TY = TY; g.LZ = LZ;
         g.PX = TX / 4 + 2; g.PY = TY / 2 + 4;
-        g.ntx = (g.nx + TX - 1) / TX; g.nty = (g.ny + TY - 1) / TY; g.ntz = (g.nz + LZ - 1) / LZ;
+        g.ntx = (g.nx + TX - 1) / TX; g.nty = (g.ny + TY - 1) / TY; g.ntz = (nzo + LZ - 1) / LZ;
         g.n_wg = g.ntx * g.nty * g.ntz;
         g.threads = round_up(g.PX * g.PY, 64);
         g.lds_bytes = size_t(6) * size_t(2 * g.PY + 2) * size_t(2 * g.PX + 4) * value_bytes;
@@ -671,9 +678,9 @@ void choose_tiles(PlaneGeom &g, size_t value_bytes) {
             const int thr = round_up((TX / 4 + 2) * (TY / 2 + 4), 64);
             if (thr > 512) continue;
             if (size_t(6) * size_t(TY + 10) * size_t(TX / 2 + 8) * value_bytes > size_t(150) * 1024) continue;
-            for (int ntz = 1; ntz <= g.nz / 2; ++ntz) {
-                const int LZ = round_up((g.nz + ntz - 1) / ntz, 2);
-                if ((g.nz + LZ - 1) / LZ != ntz) continue;
+            for (int ntz = 1; ntz <= nzo / 2; ++ntz) {
+                const int LZ = round_up((nzo + ntz - 1) / ntz, 2);
+                if ((nzo + LZ - 1) / LZ != ntz) continue;
                 const double rounds = std::ceil(double(ntx) * nty * ntz / 256.0);
                 const double cost = rounds * (LZ + 4) * (thr + 192.0);
                 if (cost < best) { best = cost; bx = TX; by = TY; bz = LZ; }
@@ -809,10 +816,30 @@ bool PlanePlan<V>::build(const omg_csr &A, const omg_csr &R, Ordering &ord) {
     g.nx = (int)nx; g.ny = (int)ny; g.nz = (int)nz; g.hx = (int)(nx / 2);
     for (int e = 0; e < 7; ++e) g.c[e] = double(V(c[e]));
     g.w = double(V(w));
+    g.z_base = 0; g.z_end = g.nz; g.kv0 = 0; g.kv1 = g.nz; g.kc_off = 0; g.nzc = g.nz / 2;
     choose_tiles(g, sizeof(V));
     if (g.TX <= 0 || g.threads > 512) return false;
     partials.alloc(size_t(g.n_wg) + SUM_FOLD);
     return true;
+}
+
+template <typename V>
+void PlanePlan<V>::build_slab(int nx, int ny, int nz_own, int ghost, int ghost_c, bool first, bool last, const double (&c)[7], double w) {
+    OMG_REQUIRE(nx >= 2 && ny >= 2 && nz_own >= 2 && !(nx & 1) && !(ny & 1) && !(nz_own & 1) && !(ghost & 1) && ghost >= 4 && ghost_c >= 2,
+                "plane slab: extents must be even, at least four ghost planes (two on the coarse slab)");
+    g = PlaneGeom();
+    g.nx = nx; g.ny = ny; g.nz = nz_own + 2 * ghost; g.hx = nx / 2;
+    for (int e = 0; e < 7; ++e) g.c[e] = double(V(c[e]));
+    g.w = double(V(w));
+    g.z_base = ghost; g.z_end = ghost + nz_own;
+    g.kv0 = first ? ghost : 0;
+    g.kv1 = last ? ghost + nz_own : g.nz;
+    g.nzc = nz_own / 2 + 2 * ghost_c;
+    g.kc_off = ghost_c - ghost / 2;
+    OMG_REQUIRE(uint64_t(nx) * ny * g.nz * sizeof(V) < (uint64_t(1) << 31), "plane slab: vector exceeds 2 GiB");
+    choose_tiles(g, sizeof(V));
+    OMG_REQUIRE(g.TX > 0 && g.threads <= 512, "plane slab: no tiling");
+    partials.alloc(size_t(g.n_wg) + SUM_FOLD);
 }
 
 template <typename V>
@@ -888,11 +915,12 @@ PlaneKArgs<V> plane_args(const PlaneGeom &g, const V *x_old, V *x_new, const V *
     k.vec_bytes = unsigned(n * int64_t(sizeof(V)));
     k.nr = int(n / 2);
     k.hx = g.hx; k.ny = g.ny; k.nz = g.nz;
+    k.z_base = g.z_base; k.z_end = g.z_end; k.kv0 = g.kv0; k.kv1 = g.kv1; k.kc_off = g.kc_off;
     k.TXq = g.TX / 4; k.TY = g.TY; k.LZ = g.LZ; k.PX = g.PX; k.PY = g.PY; k.ntx = g.ntx; k.nty = g.nty; k.ntz = g.ntz;
     k.c0 = V(g.c[0]); k.c1 = V(g.c[1]); k.c2 = V(g.c[2]); k.c3 = V(g.c[3]); k.c4 = V(g.c[4]); k.c5 = V(g.c[5]); k.c6 = V(g.c[6]);
     k.w = V(g.w);
     k.fast_div = (std::fabs(g.c[3]) >= 0x1p-400 && std::fabs(g.c[3]) <= 0x1p400) ? 1 : 0;
-    k.nxc = g.nx / 2; k.nyc = g.ny / 2; k.nzc = g.nz / 2;
+    k.nxc = g.nx / 2; k.nyc = g.ny / 2; k.nzc = g.nzc;
     const int64_t nc = int64_t(k.nxc) * k.nyc * k.nzc;
     k.cvec_bytes = unsigned(nc * int64_t(sizeof(V)));
     k.cmap_bytes = unsigned(nc * 4);

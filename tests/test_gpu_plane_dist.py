@@ -1,0 +1,75 @@
+"""The plane-pipelined slab runner (omg_pdist_*, csrc/dist.hip): all ranks of a 1-D decomposition in one process
+on one GPU — the launches and exchanges of the multi-GPU schedule with device copies in place of RCCL — against
+the single-GPU hierarchy: the iterate bit for bit, for 1, 2, 4 and 8 slabs; and a one-rank RCCL communicator
+through the real collective calls."""
+import numpy as np
+import pytest
+
+from openmg_amd import _hip, _hip_dist, operators
+
+pytestmark = pytest.mark.gpu
+
+
+def problem(shape, grids):
+    from test_gpu_plane import hierarchy                # plain 2x2x2 aggregation for any even shape
+    A, R = hierarchy(shape, grids)
+    rng = np.random.default_rng(31)
+    return A, R, A[0] @ rng.random(A[0].shape[0]), rng.standard_normal(A[0].shape[0])
+
+
+def slabs(A, R, shape, n_ranks, n_dist, b, x0):
+    """n_dist distributed levels, the rest replicated; every rank loaded with its planes."""
+    shapes = [tuple(s >> l for s in shape) for l in range(len(A))]
+    coef = [_hip_dist.star_coefficients(A[l], shapes[l]) for l in range(n_dist)]
+    w = float(R[0].data[0])
+    ranks = []
+    per = b.size // n_ranks
+    for r in range(n_ranks):
+        tail = _hip.Hierarchy(A[n_dist:], R[n_dist:], smoother="colour")
+        d = _hip_dist.PlaneDistRank(r, n_ranks, shape, coef, w, tail)
+        d.load(b[r * per:(r + 1) * per], None if x0 is None else x0[r * per:(r + 1) * per])
+        ranks.append(d)
+    return ranks
+
+
+@pytest.mark.parametrize("shape,grids,n_dist", [((32, 32, 32), 4, 2), ((64, 32, 48), 4, 2), ((32, 16, 16), 3, 1), ((64, 64, 64), 5, 3)])
+def test_plane_slabs_have_the_bits_of_the_single_gpu_cycle(shape, grids, n_dist):
+    A, R, b, x0 = problem(shape, grids)
+    with _hip.Hierarchy(A, R, smoother="colour") as h:
+        assert all(h.level_flags(l)["plane"] for l in range(len(R)))
+        h.resident_load(b, x0)
+        want_norms = [h.resident_cycle(1, 1) for _ in range(3)]
+        want = h.resident_fetch()
+    for n_ranks in (1, 2, 4, 8):
+        if (shape[0] >> (n_dist - 1)) // n_ranks < 2:
+            continue                                   # every distributed level needs two planes per rank
+        g = _hip_dist.PlaneDistGroup(slabs(A, R, shape, n_ranks, n_dist, b, x0))
+        try:
+            norms = g.cycles(2) + g.cycles(1)
+            got = np.concatenate([r.fetch() for r in g.ranks])
+        finally:
+            g.close()
+        assert np.array_equal(got, want), (shape, n_ranks, int(np.sum(got != want)))
+        np.testing.assert_allclose(norms, want_norms, rtol=1e-13)
+
+
+def test_one_rank_through_the_rccl_calls():
+    """A one-rank communicator: omg_pdist_cycles runs the schedule's RCCL path (all-gather of the level below the
+    slabs, all-reduce of the norm are skipped for one rank; connect / load / cycles / fetch are the calls bench.py
+    makes per rank)."""
+    shape, grids, n_dist = (32, 32, 32), 4, 2
+    A, R, b, x0 = problem(shape, grids)
+    with _hip.Hierarchy(A, R, smoother="colour") as h:
+        h.resident_load(b)
+        want_norms = [h.resident_cycle(1, 1) for _ in range(3)]
+        want = h.resident_fetch()
+    (d,) = slabs(A, R, shape, 1, n_dist, b, None)
+    try:
+        d.connect(_hip_dist.rccl_unique_id())
+        assert d.rccl_ranks() == 1
+        d.load(b)
+        norms = d.cycles(3)
+        assert np.array_equal(d.fetch(), want)
+        np.testing.assert_allclose(norms, want_norms, rtol=1e-13)
+    finally:
+        d.close()
