@@ -350,11 +350,18 @@ int omg_pdist_create(int rank, int n_ranks, int nx, int ny, int nz_global, int n
                      omg_pdist **out);
 int omg_pdist_destroy(omg_pdist *d);
 int omg_pdist_set_tail(omg_pdist *d, omg_hierarchy *tail);
-int omg_pdist_connect(omg_pdist *d, const void *unique_id128);
+/* two communicators: the cycle's, and one for the exchanges that run on a second stream beside the coarser levels */
+int omg_pdist_connect(omg_pdist *d, const void *unique_id128, const void *unique_id128_side);
 int omg_pdist_rccl_ranks(omg_pdist *d, int *count);
 int omg_pdist_load(omg_pdist *d, const double *b_local, const double *x0_local /* NULL = zeros */);   /* collective */
 int omg_pdist_fetch(omg_pdist *d, double *x_local);
 int omg_pdist_sync(omg_pdist *d);
+/* omg_pdist_trace(1): the stream writes a progress word (pinned host memory) between the phases of a cycle;
+ * omg_pdist_progress reads it without synchronising: (cycle << 16) | (level << 8) | phase, phase 1 halo of x, 2 halo of
+ * b, 3 down pass, 4 halo of x for the up pass, 5 gather + replicated tail, 6 halo of the correction, 7 up pass —
+ * what a rank reports when a collective never completes (bench.py's preflight).                                   */
+int omg_pdist_trace(omg_pdist *d, int enable);
+int omg_pdist_progress(omg_pdist *d, unsigned *word);
 int omg_pdist_cycles(omg_pdist *d, int n_cycles, double *norms /* nullable */);                         /* collective */
 /* all ranks in one process on one GPU, device copies in place of RCCL (verification) */
 int omg_pdist_group_create(int n, omg_pdist **ranks, omg_pdist_group **out);

@@ -107,11 +107,13 @@ SIGNATURES = {
     "omg_pdist_create": (_I, [_I, _I, _I, _I, _I, _I, _P, _D, _PP]),
     "omg_pdist_destroy": (_I, [_P]),
     "omg_pdist_set_tail": (_I, [_P, _P]),
-    "omg_pdist_connect": (_I, [_P, _P]),
+    "omg_pdist_connect": (_I, [_P, _P, _P]),
     "omg_pdist_rccl_ranks": (_I, [_P, _IP]),
     "omg_pdist_load": (_I, [_P, _P, _P]),
     "omg_pdist_fetch": (_I, [_P, _P]),
     "omg_pdist_sync": (_I, [_P]),
+    "omg_pdist_trace": (_I, [_P, _I]),
+    "omg_pdist_progress": (_I, [_P, ctypes.POINTER(ctypes.c_uint)]),
     "omg_pdist_cycles": (_I, [_P, _I, _P]),
     "omg_pdist_group_create": (_I, [_I, _P, _PP]),
     "omg_pdist_group_destroy": (_I, [_P]),

@@ -214,9 +214,12 @@ class PlaneDistRank:
         self.n_local = nx * ny * (nz // int(n_ranks))
         check(lib().omg_pdist_set_tail(self._h, tail._h))
 
-    def connect(self, unique_id):
-        buf = ctypes.create_string_buffer(bytes(unique_id), 128)
-        check(lib().omg_pdist_connect(self._h, buf))
+    def connect(self, unique_id, unique_id_side):
+        """Two RCCL bootstrap ids (rccl_unique_id() twice on rank 0, broadcast): the cycle's communicator and the
+        one of the exchanges that run on the second stream."""
+        a = ctypes.create_string_buffer(bytes(unique_id), 128)
+        b = ctypes.create_string_buffer(bytes(unique_id_side), 128)
+        check(lib().omg_pdist_connect(self._h, a, b))
 
     def rccl_ranks(self):
         n = ctypes.c_int(0)
@@ -235,6 +238,19 @@ class PlaneDistRank:
 
     def sync(self):
         check(lib().omg_pdist_sync(self._h))
+
+    PHASES = {0: "not started", 1: "halo exchange of x", 2: "halo exchange of the right-hand side", 3: "down pass",
+              4: "halo exchange of x for the up pass", 5: "gather + replicated tail", 6: "halo exchange of the correction",
+              7: "up pass"}
+
+    def trace(self, enable=True):
+        check(lib().omg_pdist_trace(self._h, 1 if enable else 0))
+
+    def progress(self):
+        """(cycle, level, last phase the DEVICE has completed) — read without synchronising."""
+        w = ctypes.c_uint(0)
+        check(lib().omg_pdist_progress(self._h, ctypes.byref(w)))
+        return w.value >> 16, (w.value >> 8) & 0xFF, self.PHASES.get(w.value & 0xFF, "phase %d" % (w.value & 0xFF))
 
     def cycles(self, n_cycles):
         norms = (ctypes.c_double * max(int(n_cycles), 1))()

@@ -866,7 +866,27 @@ struct PlaneDist {
     DevBuf<double> nat;                       // host I/O staging (owned planes, natural order)
     hipStream_t own = nullptr, stream = nullptr;
     ncclComm_t comm = nullptr;
+    // The ghost planes of x for a level's UP pass are exchanged right after its DOWN pass, on a second stream (and
+    // a communicator of its own), while the coarser levels run: two events per level order the streams.
+    hipStream_t side_own = nullptr, side = nullptr;
+    ncclComm_t comm_side = nullptr;
+    std::vector<hipEvent_t> ev_down, ev_halo;
+    // progress of the DEVICE through a cycle, for a caller whose collective never completes (bench.py's preflight):
+    // a word in pinned host memory the stream writes between the phases — (cycle << 16) | (level << 8) | phase,
+    // phase 1 halo x, 2 halo b, 3 down pass, 4 halo x (for the up pass), 5 gather + tail, 6 halo of the correction,
+    // 7 up pass, 8 norm; only while tracing is on (omg_pdist_trace)
+    uint32_t *progress = nullptr;
+    bool trace = false;
+    uint32_t cycle_no = 0;
+    void mark(int level, int phase) {
+        if (trace && progress) (void)hipStreamWriteValue32(stream, progress, (cycle_no << 16) | (uint32_t(level) << 8) | uint32_t(phase), 0);
+    }
     ~PlaneDist() {
+        if (progress) (void)hipHostFree(progress);
+        for (hipEvent_t e : ev_down) (void)hipEventDestroy(e);
+        for (hipEvent_t e : ev_halo) (void)hipEventDestroy(e);
+        if (comm_side) (void)g_rccl.CommDestroy(comm_side);
+        if (side_own) (void)hipStreamDestroy(side_own);
         if (comm) (void)g_rccl.CommDestroy(comm);
         if (own) (void)hipStreamDestroy(own);
     }
@@ -893,9 +913,12 @@ struct PDExchange {
     bool loopback = false;
 
     // ghost planes of a plane-major vector of level l (both colours): `count` planes from either neighbour
-    void halo(int l, int which /* 0 x (current), 1 b */, int count) {
+    bool exchanges() const { return loopback ? ranks.size() > 1 : ranks[0]->n_ranks > 1; }
+    void halo(int l, int which /* 0 x (current), 1 b */, int count, bool on_side = false) {
         for (PlaneDist *d : ranks) {
             PDLevel &L = d->lv[l];
+            const hipStream_t st = on_side ? d->side : d->stream;
+            const ncclComm_t cm = on_side ? d->comm_side : d->comm;
             if (!loopback && d->n_ranks > 1) OMG_NCCL(g_rccl.GroupStart());
             for (int colour = 0; colour < 2; ++colour) {
                 double *mine = (which == 0 ? L.xp : L.b.p) + (colour ? L.n_ext / 2 : 0);
@@ -910,22 +933,22 @@ struct PDExchange {
                         PlaneDist *o = ranks[d->rank - 1];
                         PDLevel &O = o->lv[l];
                         const double *src = (which == 0 ? O.xp : O.b.p) + (colour ? O.n_ext / 2 : 0) + int64_t(PD_GHOST + O.nzo - count) * O.pc;
-                        OMG_HIP(hipMemcpyAsync(recv_lo, src, cnt * sizeof(double), hipMemcpyDeviceToDevice, d->stream));
+                        OMG_HIP(hipMemcpyAsync(recv_lo, src, cnt * sizeof(double), hipMemcpyDeviceToDevice, st));
                     }
                     if (d->rank + 1 < d->n_ranks) {
                         PlaneDist *o = ranks[d->rank + 1];
                         PDLevel &O = o->lv[l];
                         const double *src = (which == 0 ? O.xp : O.b.p) + (colour ? O.n_ext / 2 : 0) + int64_t(PD_GHOST) * O.pc;
-                        OMG_HIP(hipMemcpyAsync(recv_hi, src, cnt * sizeof(double), hipMemcpyDeviceToDevice, d->stream));
+                        OMG_HIP(hipMemcpyAsync(recv_hi, src, cnt * sizeof(double), hipMemcpyDeviceToDevice, st));
                     }
                 } else if (d->n_ranks > 1) {
                     if (d->rank + 1 < d->n_ranks) {
-                        OMG_NCCL(g_rccl.Send(send_up, cnt, ncclDouble, d->rank + 1, d->comm, d->stream));
-                        OMG_NCCL(g_rccl.Recv(recv_hi, cnt, ncclDouble, d->rank + 1, d->comm, d->stream));
+                        OMG_NCCL(g_rccl.Send(send_up, cnt, ncclDouble, d->rank + 1, cm, st));
+                        OMG_NCCL(g_rccl.Recv(recv_hi, cnt, ncclDouble, d->rank + 1, cm, st));
                     }
                     if (d->rank > 0) {
-                        OMG_NCCL(g_rccl.Send(send_dn, cnt, ncclDouble, d->rank - 1, d->comm, d->stream));
-                        OMG_NCCL(g_rccl.Recv(recv_lo, cnt, ncclDouble, d->rank - 1, d->comm, d->stream));
+                        OMG_NCCL(g_rccl.Send(send_dn, cnt, ncclDouble, d->rank - 1, cm, st));
+                        OMG_NCCL(g_rccl.Recv(recv_lo, cnt, ncclDouble, d->rank - 1, cm, st));
                     }
                 }
             }
@@ -985,18 +1008,37 @@ struct PDExchange {
         }
     }
     // one V(1,1) cycle; the norm's squares of every rank in its norm2 (level-0 up pass partials summed)
+    void mark(int level, int phase) {
+        for (PlaneDist *d : ranks) d->mark(level, phase);
+    }
     void cycle() {
         const int nd = (int)ranks[0]->lv.size();
+        for (PlaneDist *d : ranks) ++d->cycle_no;
         halo(0, 0, 3);
+        mark(0, 1);
         for (int l = 0; l < nd; ++l) {
-            if (l > 0) halo(l, 1, 2);
+            if (l > 0) { halo(l, 1, 2); mark(l, 2); }
             down(l);
-            halo(l, 0, 3);                                        // for the up pass (nothing before it reads these planes)
+            mark(l, 3);
+            // the ghost planes for the up pass: on the side stream, beside the coarser levels (nothing before the up
+            // pass reads or writes them, nor the planes they are copied from)
+            if (!exchanges()) continue;                           // one slab: no neighbour, no second stream
+            for (PlaneDist *d : ranks) {
+                OMG_HIP(hipEventRecord(d->ev_down[size_t(l)], d->stream));
+                OMG_HIP(hipStreamWaitEvent(d->side, d->ev_down[size_t(l)], 0));
+            }
+            halo(l, 0, 3, true);
+            for (PlaneDist *d : ranks) OMG_HIP(hipEventRecord(d->ev_halo[size_t(l)], d->side));
         }
         tail_solve();
+        mark(nd, 5);
         for (int l = nd - 1; l >= 0; --l) {
-            if (l + 1 < nd) halo(l + 1, 0, 2);                    // ghost planes of the correction
+            if (l + 1 < nd) { halo(l + 1, 0, 2); mark(l, 6); }    // ghost planes of the correction
+            if (exchanges())
+                for (PlaneDist *d : ranks) OMG_HIP(hipStreamWaitEvent(d->stream, d->ev_halo[size_t(l)], 0));
+            mark(l, 4);
             up(l, nullptr);
+            mark(l, 7);
         }
         for (PlaneDist *d : ranks) launch_sum(d->lv[0].plan.partials.p, d->lv[0].plan.g.n_wg, d->norm2.p, d->stream);
     }
@@ -1025,7 +1067,16 @@ std::unique_ptr<PlaneDist> pd_create(int rank, int n_ranks, int nx, int ny, int 
     d->n_ranks = n_ranks;
     OMG_HIP(hipStreamCreateWithFlags(&d->own, hipStreamNonBlocking));
     d->stream = d->own;
+    OMG_HIP(hipStreamCreateWithFlags(&d->side_own, hipStreamNonBlocking));
+    d->side = d->side_own;
     d->lv.resize(size_t(n_levels));
+    for (int l = 0; l < n_levels; ++l) {
+        hipEvent_t a, b;
+        OMG_HIP(hipEventCreateWithFlags(&a, hipEventDisableTiming));
+        OMG_HIP(hipEventCreateWithFlags(&b, hipEventDisableTiming));
+        d->ev_down.push_back(a);
+        d->ev_halo.push_back(b);
+    }
     int lx = nx, ly = ny, lz = nz_global / n_ranks;
     for (int l = 0; l < n_levels; ++l) {
         PDLevel &L = d->lv[size_t(l)];
@@ -1064,6 +1115,8 @@ std::unique_ptr<PlaneDist> pd_create(int rank, int n_ranks, int nx, int ny, int 
     d->full_x.alloc(size_t(cplane * lz * n_ranks));
     d->norm2.alloc(1);
     d->norms.alloc(64);
+    OMG_HIP(hipHostMalloc(reinterpret_cast<void **>(&d->progress), sizeof(uint32_t), hipHostMallocDefault));
+    *d->progress = 0;
     d->nat.alloc(size_t(int64_t(nx) * ny * (nz_global / n_ranks)));
     OMG_HIP(hipStreamSynchronize(d->stream));
     return d;
@@ -1434,13 +1487,15 @@ int omg_pdist_set_tail(omg_pdist *d, omg_hierarchy *tail) {
     });
 }
 
-int omg_pdist_connect(omg_pdist *d, const void *unique_id128) {
+int omg_pdist_connect(omg_pdist *d, const void *unique_id128, const void *unique_id128_side) {
     return guarded([&] {
-        OMG_REQUIRE(d && d->d && unique_id128, "null argument");
+        OMG_REQUIRE(d && d->d && unique_id128 && unique_id128_side, "null argument");
         g_rccl.load();
         ncclUniqueId id;
         std::memcpy(&id, unique_id128, sizeof(id));
         OMG_NCCL(g_rccl.CommInitRank(&d->d->comm, d->d->n_ranks, id, d->d->rank));
+        std::memcpy(&id, unique_id128_side, sizeof(id));
+        OMG_NCCL(g_rccl.CommInitRank(&d->d->comm_side, d->d->n_ranks, id, d->d->rank));
     });
 }
 
@@ -1495,8 +1550,25 @@ int omg_pdist_fetch(omg_pdist *d, double *x_local) {
     });
 }
 
+/* Tracing on: the stream writes a progress word between the phases of a cycle; omg_pdist_progress reads it WITHOUT
+ * synchronising — (cycle << 16) | (level << 8) | phase (1 halo x, 2 halo b, 3 down pass, 4 halo x for the up pass,
+ * 5 gather + replicated tail, 6 halo of the correction, 7 up pass): where the device is when a collective hangs. */
+int omg_pdist_trace(omg_pdist *d, int enable) {
+    return guarded([&] { OMG_REQUIRE(d && d->d, "null"); d->d->trace = enable != 0; });
+}
+int omg_pdist_progress(omg_pdist *d, unsigned *word) {
+    return guarded([&] {
+        OMG_REQUIRE(d && d->d && word, "null");
+        *word = d->d->progress ? *reinterpret_cast<volatile uint32_t *>(d->d->progress) : 0u;
+    });
+}
+
 int omg_pdist_sync(omg_pdist *d) {
-    return guarded([&] { OMG_REQUIRE(d && d->d, "null"); OMG_HIP(hipStreamSynchronize(d->d->stream)); });
+    return guarded([&] {
+        OMG_REQUIRE(d && d->d, "null");
+        OMG_HIP(hipStreamSynchronize(d->d->stream));
+        OMG_HIP(hipStreamSynchronize(d->d->side));
+    });
 }
 
 /* n_cycles V(1,1) cycles, every cycle's global residual norm computed and returned; collective. */
@@ -1530,6 +1602,7 @@ int omg_pdist_group_create(int n, omg_pdist **ranks, omg_pdist_group **out) {
             OMG_REQUIRE(ranks[r] && ranks[r]->d && ranks[r]->d->rank == r && ranks[r]->d->n_ranks == n, "ranks must be 0 .. n-1 of an n-rank decomposition");
             OMG_HIP(hipStreamSynchronize(ranks[r]->d->stream));
             ranks[r]->d->stream = ranks[0]->d->own;
+            ranks[r]->d->side = ranks[0]->d->side_own;
             g->ranks.push_back(ranks[r]);
         }
         *out = g.release();

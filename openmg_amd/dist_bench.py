@@ -34,6 +34,114 @@ def _bench_identity():
     return mod.kernel_source_hash(), mod.git_head()
 
 
+def plane_levels(shape, world, n_dist):
+    """How many levels the plane-pipelined slab runner can distribute (0: not applicable): the first n_dist - 1
+    levels, as long as every one of them has even extents and at least two planes per rank."""
+    n = 0
+    nz, ny, nx = shape
+    for _ in range(max(0, n_dist - 1)):
+        if nz % world or (nz // world) % 2 or (nz // world) < 2 or ny % 2 or nx % 2:
+            break
+        n += 1
+        nz, ny, nx = nz // 2, ny // 2, nx // 2
+    return n
+
+
+def main_plane(args, rank, world, shape, grids, n_levels, all_gather, td, torch, watchdog):
+    """The 7-point red-black cycle as plane-pipelined passes on slabs with ghost planes (omg_pdist_*)."""
+    import numpy as np
+    from . import _hip, _hip_dist, dist, operators, preflight
+    t_setup = time.perf_counter()
+    lo = rank * (shape[0] // world) * shape[1] * shape[2]
+    hi = lo + (shape[0] // world) * shape[1] * shape[2]
+    A_rows = dist.stencil_rows(shape, lo, hi)
+    n_glob = shape[0] * shape[1] * shape[2]
+    u = np.random.default_rng(12345).random(n_glob)
+    b_loc = A_rows @ u
+    nnz_loc, n_loc = A_rows.nnz, hi - lo
+    del u, A_rows
+    # level l of the hierarchy is lap3(shape / 2^l) / 16^l exactly (tests/test_gpu_parity.py); the levels below the
+    # slabs run replicated as an ordinary hierarchy on the gathered right-hand side
+    coef = [[v / 16.0 ** l for v in (-1.0, -1.0, -1.0, 6.0, -1.0, -1.0, -1.0)] for l in range(n_levels)]
+    tshape = tuple(s >> n_levels for s in shape)
+    tgrids = grids - n_levels
+    At = operators.stencil_poisson(tshape) / 16.0 ** n_levels
+    Rt = operators.restrictionList(tshape, tgrids - 2, 8) if tgrids >= 2 else []
+    tail = _hip.Hierarchy(operators.coeffecientList(At, Rt), Rt, smoother=args.smoother)
+    r = _hip_dist.PlaneDistRank(rank, world, shape, coef, 0.125, tail)
+    ident = [(_hip_dist.rccl_unique_id(), _hip_dist.rccl_unique_id()) if rank == 0 else None]
+    td.broadcast_object_list(ident, src=0)
+    r.connect(*ident[0])
+    r.load(b_loc)
+    setup_s = time.perf_counter() - t_setup
+    # ONE checked cycle: every rank's norm under a deadline, compared with rank 0's; a rank that hangs says where
+    r.trace(True)
+    first_norm = preflight.run(rank, world, lambda: r.cycles(1)[0], all_gather, min(120.0, max(20.0, args.watchdog / 4.0)),
+                               where=lambda: "cycle %d, level %d, last completed phase: %s" % r.progress())
+    r.trace(False)
+    for _ in range(args.warmup):
+        r.cycles(1)
+    times = []
+    for _ in range(max(1, getattr(args, "repeats", 1))):
+        r.sync()
+        torch.cuda.synchronize()
+        td.barrier()
+        t0 = time.perf_counter()
+        region_norms = r.cycles(args.steps)              # K cycles back to back, every cycle's global norm computed
+        r.sync()
+        torch.cuda.synchronize()
+        td.barrier()
+        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+        td.all_reduce(t, op=td.ReduceOp.MAX)             # the slowest rank's time
+        times.append(float(t[0]))
+    elapsed = statistics.median(times)
+    norm = r.cycles(1)[0]
+    rccl_ranks = r.rccl_ranks()
+    if rank == 0:
+        equiv = n_glob / float(256 ** 3)
+        # per cycle a rank's two fine-grid passes move (DESIGN.md section 5a) 3 w per owned unknown + (w + 4) per coarse one, each
+        n_c = n_loc // 8
+        pass_bytes = 3 * 8 * n_loc + n_c * (8 + 4)
+        src_sha, head = _bench_identity()
+        out = {
+            "metric": "V-cycles/sec (256^3-unknown equivalents), 3-D 7-point Poisson, weak scaling",
+            "value": round(args.steps / elapsed * equiv, 3),
+            "unit": "256^3-equivalent V-cycles/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": "3-D 7-point Poisson %s, %d-grid V(1,1) cycle, red-black Gauss-Seidel, fp64, 1-D slabs over %d GPUs: "
+                                   "plane-pipelined passes on slabs with ghost planes, RCCL exchanges of whole planes"
+                                   % ("x".join(map(str, shape)), grids, world),
+                       "unknowns": n_glob, "unknowns_per_gpu": n_loc, "nnz_per_gpu": nnz_loc, "grids": grids,
+                       "distributed_grids": n_levels, "replicated_tail_grids": tgrids, "runner": "plane slabs (omg_pdist)",
+                       "rccl_ranks": rccl_ranks, "repeats": len(times), "preflight_norm": first_norm,
+                       "kernel_src_sha": src_sha, "git_head": head,
+                       "ms_per_step_all": [round(1e3 * t / args.steps, 4) for t in times],
+                       "pre": 1, "post": 1, "cycles_per_s": round(args.steps / elapsed, 3),
+                       "final_residual_norm": norm, "norms_last_region_tail": region_norms[-3:],
+                       "setup_s": round(setup_s, 2)},
+            # a LOWER bound of the fine-grid passes' rate: the bytes both of rank 0's fine-grid passes have to move per
+            # cycle over the WHOLE cycle's time (exchanges, coarser levels and the replicated tail included)
+            "roofline": {"bound": "hbm", "kernel": "rank 0's two fine-grid plane passes per cycle (bytes needed / whole cycle time: a lower bound)",
+                         "achieved": round(2 * pass_bytes / (elapsed / args.steps) / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
+                         "frac": round(2 * pass_bytes / (elapsed / args.steps) / 1e9 / 8000.0, 4), "traffic": None,
+                         "bytes_per_launch": pass_bytes},
+            "cpu_baseline": None,
+        }
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+        print(json.dumps(out))
+        sys.stdout.flush()
+    r.close()
+    tail.close()
+    watchdog.cancel()
+    td.barrier()
+    td.destroy_process_group()
+    return 0
+
+
 def main(args):
     import datetime
     import threading
@@ -81,6 +189,12 @@ def main(args):
     # levels 0..n_dist-2 are smoothed across ranks; level n_dist-1 and everything below it run
     # replicated on every rank as an ordinary single-GPU hierarchy (dist.make_tail)
     n_dist = max(2, min(args.dist_grids, grids))
+    # constant-coefficient 7-point stencil, red-black, fp64: the plane-pipelined slab runner (OMG_DIST_PLANE=0: the
+    # set-by-set runner with one exchange per colour below)
+    n_plane = plane_levels(shape, world, n_dist)
+    if (args.stencil == "7pt" and args.smoother == "colour" and args.dtype == "f64" and n_plane >= 1
+            and os.environ.get("OMG_DIST_PLANE", "1") != "0"):
+        return main_plane(args, rank, world, shape, grids, n_plane, all_gather, td, torch, watchdog)
     part = dist.SlabPartition(shape, world, n_dist)
     lo, hi = part.rows(0, rank)
     w = 8 if args.dtype == "f64" else 4

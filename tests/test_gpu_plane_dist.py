@@ -65,7 +65,7 @@ def test_one_rank_through_the_rccl_calls():
         want = h.resident_fetch()
     (d,) = slabs(A, R, shape, 1, n_dist, b, None)
     try:
-        d.connect(_hip_dist.rccl_unique_id())
+        d.connect(_hip_dist.rccl_unique_id(), _hip_dist.rccl_unique_id())
         assert d.rccl_ranks() == 1
         d.load(b)
         norms = d.cycles(3)
