@@ -250,3 +250,49 @@ def test_bench_overlap_autotune_candidates():
     c = dist_bench.overlap_candidates(rows)
     assert [t for _, t in c] == [0, 16777216, 2097152, 1 << 62]
     assert dist_bench.overlap_candidates([4096]) == [("all levels", 0), ("none", 1 << 62)]
+
+
+def _preflight_ranks(world, fault, fault_rank, timeout_s):
+    import subprocess
+    import sys
+    port = _free_port()
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "preflight_worker.py")
+    procs = [subprocess.Popen([sys.executable, worker, str(r), str(world), str(port), fault, str(fault_rank), str(timeout_s)],
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(world)]
+    out = []
+    for p in procs:
+        try:
+            o, e = p.communicate(timeout=180)
+        except subprocess.TimeoutExpired:                     # pragma: no cover - the failure this test exists for
+            p.kill()
+            o, e = p.communicate()
+        out.append((p.returncode, o, e))
+    return out
+
+
+def test_preflight_healthy_ranks_agree_and_return_the_norm():
+    res = _preflight_ranks(2, "none", -1, 60.0)
+    for rank, (code, o, e) in enumerate(res):
+        assert code == 0, e
+        assert "rank %d norm 3" % rank in o
+
+
+def test_preflight_stalled_rank_ends_every_rank_with_a_diagnosis():
+    """one rank never reaches the exchange.  Every rank must END (non-zero) within the deadline
+    and say where it was: the stalled one inside its cycle, the other inside the collective waiting for it."""
+    from openmg_amd import preflight
+    res = _preflight_ranks(2, "stall", 1, 6.0)
+    for rank, (code, o, e) in enumerate(res):
+        assert code == preflight.EXIT_TIMEOUT, (rank, code, e)
+        assert "preflight: rank %d of 2 did not finish one cycle within 6 s: inside the cycle" % rank in e, e
+        assert "device progress: level 0" in e
+    assert "in the all-reduce of the norm" in res[0][2]       # rank 0 got as far as the collective
+    assert "exchanging the ghost planes" in res[1][2]         # rank 1 never did
+
+
+def test_preflight_norm_mismatch_between_ranks_is_fatal():
+    from openmg_amd import preflight
+    res = _preflight_ranks(2, "mismatch", 1, 60.0)
+    for rank, (code, o, e) in enumerate(res):
+        assert code == preflight.EXIT_MISMATCH, (rank, code, e)
+        assert "differ between ranks after one cycle" in e and "[1]" in e
