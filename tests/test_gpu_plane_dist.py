@@ -73,3 +73,37 @@ def test_one_rank_through_the_rccl_calls():
         np.testing.assert_allclose(norms, want_norms, rtol=1e-13)
     finally:
         d.close()
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_slabs_at_the_bench_shapes_have_the_bits_of_one_slab(world):
+    """bench.py --gpus 8: (512, 512, 512), three slab levels of 64 / 32 / 16 planes per rank above a replicated 64^3
+    hierarchy (--gpus 2 and 4: dist_bench.SHAPES).  Too large for the oracle: the size-independent property is that
+    the decomposition does not change a bit — the slabs with ghost planes against ONE slab holding every plane,
+    same launches otherwise."""
+    from openmg_amd import dist_bench
+    shape, n_levels, tail_grids = dist_bench.SHAPES[world], 3, 4
+    assert dist_bench.plane_levels(shape, world, 4) == n_levels
+    coef = [[v / 16.0 ** l for v in (-1.0, -1.0, -1.0, 6.0, -1.0, -1.0, -1.0)] for l in range(n_levels)]
+    tshape = tuple(s >> n_levels for s in shape)
+    At = operators.stencil_poisson(tshape) / 16.0 ** n_levels
+    Rt = operators.restrictionList(tshape, tail_grids - 2, 8)
+    At = operators.coeffecientList(At, Rt)
+    b = np.random.default_rng(5).random(shape[0] * shape[1] * shape[2])
+    out = {}
+    for n_ranks in (1, world):
+        per = b.size // n_ranks
+        ranks = []
+        for r in range(n_ranks):
+            d = _hip_dist.PlaneDistRank(r, n_ranks, shape, coef, 0.125, _hip.Hierarchy(At, Rt, smoother="colour"))
+            d.load(b[r * per:(r + 1) * per])
+            ranks.append(d)
+        g = _hip_dist.PlaneDistGroup(ranks)
+        try:
+            norms = g.cycles(2)
+            out[n_ranks] = (norms, np.concatenate([r.fetch() for r in g.ranks]))
+        finally:
+            g.close()
+    assert np.array_equal(out[1][1], out[world][1])
+    np.testing.assert_allclose(out[1][0], out[world][0], rtol=1e-13)     # per-slab partial sums, added in rank order
+    assert out[1][0][1] < out[1][0][0]                  # and the norm goes down
