@@ -905,6 +905,10 @@ __global__ void pd_scatter_kernel(const double *__restrict__ nat, double *__rest
 }
 __global__ void pd_add_kernel(double *acc, const double *v) { *acc += *v; }
 __global__ void pd_sqrt_kernel(const double *v, double *out) { *out = sqrt(*v); }
+__global__ void pd_sqrt_batch_kernel(double *v, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) v[i] = sqrt(v[i]);
+}
 
 // The schedule over a set of ranks: ONE rank with RCCL exchanges, or all of them in one process with device copies
 // in their place (loopback group: the same launches in the same order per rank).
@@ -1011,7 +1015,7 @@ struct PDExchange {
     void mark(int level, int phase) {
         for (PlaneDist *d : ranks) d->mark(level, phase);
     }
-    void cycle() {
+    void cycle(double *squares_out = nullptr /* one rank only: where its sum of squares goes instead of norm2 */) {
         const int nd = (int)ranks[0]->lv.size();
         for (PlaneDist *d : ranks) ++d->cycle_no;
         halo(0, 0, 3);
@@ -1040,7 +1044,16 @@ struct PDExchange {
             up(l, nullptr);
             mark(l, 7);
         }
-        for (PlaneDist *d : ranks) launch_sum(d->lv[0].plan.partials.p, d->lv[0].plan.g.n_wg, d->norm2.p, d->stream);
+        for (PlaneDist *d : ranks)
+            launch_sum(d->lv[0].plan.partials.p, d->lv[0].plan.g.n_wg, squares_out ? squares_out : d->norm2.p, d->stream);
+    }
+    // a batch of cycles of ONE rank: slot k holds this rank's squares of cycle k; one all-reduce for all of them
+    // (nothing on the device waits for a norm, so none is needed inside a cycle), then the roots in place
+    void norms_of_batch(double *slots, int n) {
+        PlaneDist *d = ranks[0];
+        if (d->n_ranks > 1) OMG_NCCL(g_rccl.AllReduce(slots, slots, size_t(n), ncclDouble, ncclSum, d->comm, d->stream));
+        hipLaunchKernelGGL(pd_sqrt_batch_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, d->stream, slots, n);
+        OMG_HIP(hipGetLastError());
     }
     // ||b - A x|| of the cycle just run into out (device) on every rank
     void norm(double *const *out_per_rank) {
@@ -1582,11 +1595,8 @@ int omg_pdist_cycles(omg_pdist *d, int n_cycles, double *norms) {
         if (dd->norms.n < size_t(n_cycles)) dd->norms.alloc(size_t(n_cycles));
         PDExchange ex;
         ex.ranks = {dd};
-        for (int k = 0; k < n_cycles; ++k) {
-            ex.cycle();
-            double *out = dd->norms.p + k;
-            ex.norm(&out);
-        }
+        for (int k = 0; k < n_cycles; ++k) ex.cycle(dd->norms.p + k);
+        ex.norms_of_batch(dd->norms.p, n_cycles);
         if (norms) OMG_HIP(hipMemcpyAsync(norms, dd->norms.p, size_t(n_cycles) * sizeof(double), hipMemcpyDeviceToHost, dd->stream));
         OMG_HIP(hipStreamSynchronize(dd->stream));
     });
