@@ -362,7 +362,25 @@ int omg_pdist_sync(omg_pdist *d);
  * what a rank reports when a collective never completes (bench.py's preflight).                                   */
 int omg_pdist_trace(omg_pdist *d, int enable);
 int omg_pdist_progress(omg_pdist *d, unsigned *word);
-int omg_pdist_cycles(omg_pdist *d, int n_cycles, double *norms /* nullable */);                         /* collective */
+int omg_pdist_cycles(omg_pdist *d, int n_cycles, double *norms /* nullable */);
+
+/* ---- peer mode: the slab exchanges as stores into the neighbours' memory over xGMI peer mappings ------------------
+ * (no reference counterpart: openmg is single-process.)  The passes write their boundary planes straight into the
+ * neighbours' ghost planes, raise a flag there when all their workgroups are done, and wait for their neighbours'
+ * flags before reading a ghost plane: no exchange launches inside a cycle.  Setup: every rank exports
+ * omg_pdist_p2p_handle_count() IPC handles of 64 bytes (omg_pdist_p2p_handles), the control plane hands them round,
+ * every rank opens every other rank's (omg_pdist_p2p_open; ranks of one process: omg_pdist_p2p_local), then
+ * omg_pdist_p2p_enable(mode) — 1: the passes wait themselves (one GPU per rank); 2: one-workgroup wait launches
+ * (ranks sharing a GPU); 0: back to RCCL.  Every distributed level needs >= 4 planes per rank.  A wait that gives up
+ * (OMG_P2P_SPIN polls, default 2^21) sets bit 0 of omg_pdist_p2p_status and lets the device run on.
+ * omg_pdist_cycles_squares: the cycles without the norm's collective — this rank's sums of squared residuals. */
+int omg_pdist_p2p_handle_count(omg_pdist *d, int *count);
+int omg_pdist_p2p_handles(omg_pdist *d, void *handles64, int capacity);
+int omg_pdist_p2p_open(omg_pdist *d, int peer_rank, const void *handles64, int count);
+int omg_pdist_p2p_local(omg_pdist *d, omg_pdist *other);
+int omg_pdist_p2p_enable(omg_pdist *d, int mode);
+int omg_pdist_p2p_status(omg_pdist *d, unsigned *status);
+int omg_pdist_cycles_squares(omg_pdist *d, int n_cycles, double *squares);                         /* collective */
 /* all ranks in one process on one GPU, device copies in place of RCCL (verification) */
 int omg_pdist_group_create(int n, omg_pdist **ranks, omg_pdist_group **out);
 int omg_pdist_group_destroy(omg_pdist_group *g);

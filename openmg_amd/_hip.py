@@ -108,6 +108,13 @@ SIGNATURES = {
     "omg_pdist_destroy": (_I, [_P]),
     "omg_pdist_set_tail": (_I, [_P, _P]),
     "omg_pdist_connect": (_I, [_P, _P, _P]),
+    "omg_pdist_p2p_handle_count": (_I, [_P, _P]),
+    "omg_pdist_p2p_handles": (_I, [_P, _P, _I]),
+    "omg_pdist_p2p_open": (_I, [_P, _I, _P, _I]),
+    "omg_pdist_p2p_local": (_I, [_P, _P]),
+    "omg_pdist_p2p_enable": (_I, [_P, _I]),
+    "omg_pdist_p2p_status": (_I, [_P, _P]),
+    "omg_pdist_cycles_squares": (_I, [_P, _I, _P]),
     "omg_pdist_rccl_ranks": (_I, [_P, _IP]),
     "omg_pdist_load": (_I, [_P, _P, _P]),
     "omg_pdist_fetch": (_I, [_P, _P]),

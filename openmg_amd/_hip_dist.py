@@ -252,10 +252,49 @@ class PlaneDistRank:
         check(lib().omg_pdist_progress(self._h, ctypes.byref(w)))
         return w.value >> 16, (w.value >> 8) & 0xFF, self.PHASES.get(w.value & 0xFF, "phase %d" % (w.value & 0xFF))
 
-    def cycles(self, n_cycles):
+    def cycles(self, n_cycles, reduce=None):
+        """n cycles -> every cycle's global residual norm.  reduce (peer mode without a communicator): a callable
+        taking this rank's list of squared-residual sums and returning the sums over all ranks."""
         norms = (ctypes.c_double * max(int(n_cycles), 1))()
-        check(lib().omg_pdist_cycles(self._h, int(n_cycles), norms))
-        return [float(norms[k]) for k in range(int(n_cycles))]
+        if reduce is None:
+            check(lib().omg_pdist_cycles(self._h, int(n_cycles), norms))
+            out = [float(norms[k]) for k in range(int(n_cycles))]
+        else:
+            check(lib().omg_pdist_cycles_squares(self._h, int(n_cycles), norms))
+            out = [float(v) ** 0.5 for v in reduce([float(norms[k]) for k in range(int(n_cycles))])]
+        if self.p2p_mode:
+            status = self.p2p_status()
+            if status:
+                raise RuntimeError("rank %d: a wait for a neighbour's flag gave up (status %d): the peer-store exchanges "
+                                   "did not complete; the results of this batch are not valid" % (self.rank, status))
+        return out
+
+    # ---- peer mode (include/openmg_hip.h: omg_pdist_p2p_*) ----
+    p2p_mode = 0
+
+    def p2p_handles(self):
+        """bytes: this rank's IPC handles, for the other ranks' p2p_open."""
+        n = ctypes.c_int(0)
+        check(lib().omg_pdist_p2p_handle_count(self._h, ctypes.byref(n)))
+        buf = ctypes.create_string_buffer(64 * n.value)
+        check(lib().omg_pdist_p2p_handles(self._h, buf, n.value))
+        return bytes(buf.raw)
+
+    def p2p_open(self, peer_rank, handles):
+        buf = ctypes.create_string_buffer(bytes(handles), len(handles))
+        check(lib().omg_pdist_p2p_open(self._h, int(peer_rank), buf, len(handles) // 64))
+
+    def p2p_local(self, other):
+        check(lib().omg_pdist_p2p_local(self._h, other._h))
+
+    def p2p_enable(self, mode):
+        check(lib().omg_pdist_p2p_enable(self._h, int(mode)))
+        self.p2p_mode = int(mode)
+
+    def p2p_status(self):
+        v = ctypes.c_uint(0)
+        check(lib().omg_pdist_p2p_status(self._h, ctypes.byref(v)))
+        return v.value
 
     def close(self):
         if getattr(self, "_h", None):
@@ -272,8 +311,16 @@ class PlaneDistRank:
 class PlaneDistGroup:
     """All ranks of a plane-slab decomposition in one process on one GPU (device copies in place of RCCL)."""
 
-    def __init__(self, ranks):
+    def __init__(self, ranks, p2p=0):
+        """p2p 1 / 2: the ranks store into each other's vectors (peer mode; 2: with wait launches) instead of copies."""
         self.ranks = list(ranks)
+        if p2p:
+            for a in self.ranks:
+                for b in self.ranks:
+                    if a is not b:
+                        a.p2p_local(b)
+            for a in self.ranks:
+                a.p2p_enable(p2p)
         arr = (ctypes.c_void_p * len(self.ranks))(*[r._h for r in self.ranks])
         g = ctypes.c_void_p()
         check(lib().omg_pdist_group_create(len(self.ranks), arr, ctypes.byref(g)))
@@ -282,6 +329,9 @@ class PlaneDistGroup:
     def cycles(self, n_cycles):
         norms = (ctypes.c_double * max(int(n_cycles), 1))()
         check(lib().omg_pdist_group_cycles(self._g, int(n_cycles), norms))
+        for r in self.ranks:
+            if r.p2p_mode and r.p2p_status():
+                raise RuntimeError("rank %d: a wait for a neighbour's flag gave up" % r.rank)
         return [float(norms[k]) for k in range(int(n_cycles))]
 
     def close(self):

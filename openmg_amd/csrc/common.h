@@ -511,6 +511,25 @@ struct PlanePlan {
     // behind `ghost` ghost planes; first / last: the slab holds the global grid's first / last plane (its outer
     // ghost planes do not exist and stay zero).  The coarse slab has `ghost_c` ghost planes of its own.
     void build_slab(int nx, int ny, int nz_own, int ghost, int ghost_c, bool first, bool last, const double (&c)[7], double w);
+    // Slab neighbours reached by peer stores over xGMI (dist.hip, p2p mode): a pass writes its first / last planes of
+    // x_new (and, going down, of the coarse right-hand side) straight into the neighbours' ghost planes, raises a
+    // flag in each neighbour's memory when ALL its workgroups have done so, and — before it reads a ghost plane —
+    // waits for the flags its neighbours' producing passes raise in its own memory.  Index 0: rank - 1, 1: rank + 1.
+    struct Peer {
+        V *x[2] = {nullptr, nullptr};             // the neighbour's vector in the role of this pass's x_new (null: no neighbour)
+        V *bc[2] = {nullptr, nullptr};            // down: its coarse right-hand side (null: none, or not exchanged)
+        int64_t shift = 0, cshift = 0;            // slots per slab: my slot + shift = the same cell in rank - 1's slab, - shift: rank + 1's
+        int planes = 0, cplanes = 0;              // boundary planes written there
+        int zc_lo = 0, zc_hi = 0;                 // my owned coarse planes [zc_lo, zc_hi) of the extended coarse slab
+        const uint32_t *wait_flag[4] = {nullptr, nullptr, nullptr, nullptr};   // in MY memory (null: nothing to wait for)
+        uint32_t wait_seq[4] = {0, 0, 0, 0};      // ... until it holds at least this (wrapping compare)
+        bool fused_wait = true;                   // the pass waits itself (false: the caller has launched wait_kernel)
+        uint32_t *done = nullptr;                 // my workgroup counter (zero between launches)
+        uint32_t *flag[2] = {nullptr, nullptr};   // in the NEIGHBOURS' memory
+        uint32_t seq = 0;                         // what is stored there
+        uint32_t *status = nullptr;               // my error word: bit 0 = a wait gave up
+        uint32_t spin = 1u << 21;                 // polls before a wait gives up
+    };
     struct Coarse {
         const int32_t *map = nullptr; // coarse natural index -> slot in the coarse ordering (null: identity)
         V *b = nullptr;               // down: coarse right-hand side
@@ -520,9 +539,9 @@ struct PlanePlan {
         const V *e = nullptr;         // up: coarse correction
     };
     // x_zero: x_old is known to be zero and is not read
-    void down(const V *x_old, V *x_new, const V *b, bool x_zero, const Coarse &c, hipStream_t s) const;
+    void down(const V *x_old, V *x_new, const V *b, bool x_zero, const Coarse &c, hipStream_t s, const Peer *peer = nullptr) const;
     // out (nullable): block partials of the squared residual norm, g.n_wg doubles
-    void up(const V *x_old, V *x_new, const V *b, const Coarse &c, double *out, hipStream_t s) const;
+    void up(const V *x_old, V *x_new, const V *b, const Coarse &c, double *out, hipStream_t s, const Peer *peer = nullptr) const;
 };
 
 }  // namespace omg

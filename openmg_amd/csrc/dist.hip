@@ -854,8 +854,35 @@ struct PDLevel {
     DevBuf<int32_t> cmap;                     // coarse slab (natural, extended) -> slot in the next level's ordering (not the last level)
 };
 
+// ---- peer mode: the exchanges as stores into the neighbours' memory (xGMI peer mappings) ----------------------
+// Flags live in each rank's own memory and are written by the others: flag (slot, from) of a rank, from = 0: by
+// rank - 1, 1: by rank + 1.  Values only grow: cycle numbers (PF_DOWN/PF_UP/PF_GATHER), batch numbers (the rest).
+constexpr int PD_FLAGS = 256;
+constexpr int PF_DOWN = 0;                    // + level: the neighbour's down pass of cycle c has written its boundary planes here
+constexpr int PF_UP = 8;                      // + level: ... its up pass
+constexpr int PF_PRIME = 16;                  // the ghost planes a batch of cycles starts from have been written
+constexpr int PF_READY = 17;                  // the neighbour's stream has reached the start of the batch
+constexpr int PF_GATHER = 64;                 // + source rank (no direction): its planes of the tail's right-hand side
+constexpr int PD_STATUS = PD_FLAGS, PD_DONE = PD_FLAGS + 1, PD_COUNT = PD_FLAGS + 8;   // local words behind the flags
+inline int pf(int slot, int from) { return slot * 2 + from; }
+
+struct PDPeer {                               // another rank's buffers as this process addresses them
+    std::vector<double *> x, tmp, b;          // per distributed level
+    double *full_b[2] = {nullptr, nullptr};
+    uint32_t *flags = nullptr;
+    std::vector<void *> mapped;               // hipIpcOpenMemHandle results (closed with the rank)
+};
+
 struct PlaneDist {
     int rank = 0, n_ranks = 1;
+    int p2p = 0;                              // 0: RCCL / loopback copies; 1: peer stores, the passes wait themselves; 2: ... wait launches
+    uint32_t spin = 1u << 21;
+    std::vector<PDPeer> peers;                // by rank (own entry unused)
+    DevBuf<uint32_t> flags;                   // PD_FLAGS flags + status + counters
+    DevBuf<double> full_b2;                   // the gathered right-hand side of odd cycles (a rank may still be reading the even one)
+    DevBuf<double *> ag_dst[2];               // per parity: where every rank wants my planes
+    DevBuf<uint32_t *> ag_flag;
+    uint32_t batch_no = 0;
     std::vector<PDLevel> lv;
     // the level below the last distributed one: every rank's planes of its right-hand side / of the correction in
     // natural order with ghost planes (cb, ce), and the whole of them for the replicated tail (full_b, full_x)
@@ -882,6 +909,8 @@ struct PlaneDist {
         if (trace && progress) (void)hipStreamWriteValue32(stream, progress, (cycle_no << 16) | (uint32_t(level) << 8) | uint32_t(phase), 0);
     }
     ~PlaneDist() {
+        for (PDPeer &p : peers)
+            for (void *m : p.mapped) (void)hipIpcCloseMemHandle(m);
         if (progress) (void)hipHostFree(progress);
         for (hipEvent_t e : ev_down) (void)hipEventDestroy(e);
         for (hipEvent_t e : ev_halo) (void)hipEventDestroy(e);
@@ -908,6 +937,68 @@ __global__ void pd_sqrt_kernel(const double *v, double *out) { *out = sqrt(*v); 
 __global__ void pd_sqrt_batch_kernel(double *v, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) v[i] = sqrt(v[i]);
+}
+
+// peer mode's own launches (the passes themselves store and wait in plane.hip)
+__device__ __forceinline__ void pd_spin(const uint32_t *flag, uint32_t seq, uint32_t *status, uint32_t spin) {
+    for (uint32_t n = 0;; ++n) {
+        if (int32_t(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - seq) >= 0) break;
+        if (n >= spin) { __hip_atomic_fetch_or(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
+        __builtin_amdgcn_s_sleep(16);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+}
+// thread i waits for flags[first + i * stride] (i < count)
+__global__ void pd_wait_kernel(const uint32_t *flags, int first, int stride, int count, uint32_t seq, uint32_t *status, uint32_t spin) {
+    if (int(threadIdx.x) < count) pd_spin(flags + first + int(threadIdx.x) * stride, seq, status, spin);
+}
+__global__ void pd_signal_kernel(uint32_t *f0, uint32_t *f1, uint32_t seq) {
+    if (f0) __hip_atomic_store(f0, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (f1) __hip_atomic_store(f1, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+struct PDPush {
+    const double *src[4];
+    double *dst[4];
+    int64_t n[4];                             // doubles (even)
+    int nseg;
+    uint32_t *counter, *flag;
+    uint32_t seq;
+};
+// copies the segments into another rank's memory, then raises the flag there (the last workgroup does)
+__global__ __launch_bounds__(256) void pd_push_kernel(const PDPush a) {
+    typedef double v2d __attribute__((ext_vector_type(2)));
+    for (int g = 0; g < a.nseg; ++g) {
+        const v2d *s = reinterpret_cast<const v2d *>(a.src[g]);
+        v2d *d = reinterpret_cast<v2d *>(a.dst[g]);
+        const int64_t n = a.n[g] / 2;
+        for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) d[i] = s[i];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t before = __hip_atomic_fetch_add(a.counter, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        if (before == gridDim.x - 1) {
+            __hip_atomic_store(a.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+            __hip_atomic_store(a.flag, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+// my planes of the tail's right-hand side into every rank's gathered vector (blockIdx.y = destination rank)
+__global__ __launch_bounds__(256) void pd_gather_kernel(const double *src, int64_t n, double *const *dst, uint32_t *const *flag, uint32_t *counters, uint32_t seq) {
+    const int r = int(blockIdx.y);
+    double *d = dst[r];
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) d[i] = src[i];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t before = __hip_atomic_fetch_add(counters + r, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        if (before == gridDim.x - 1) {
+            __hip_atomic_store(counters + r, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+            __hip_atomic_store(flag[r], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
 }
 
 // The schedule over a set of ranks: ONE rank with RCCL exchanges, or all of them in one process with device copies
@@ -962,7 +1053,57 @@ struct PDExchange {
     // loopback: all ranks of a group share one stream order only per rank; a copy must not start before the
     // source rank's producing kernel has finished -> the group runs on ONE stream (set at creation)
 
-    void down(int l) {
+    bool p2p() const { return ranks[0]->p2p != 0; }
+    // peer mode: what a pass of level l (down or up, cycle c) stores into its neighbours and waits for
+    PlanePlan<double>::Peer peer_of(PlaneDist *d, int l, bool going_down, bool first_of_batch) const {
+        PDLevel &L = d->lv[l];
+        const int nd = (int)d->lv.size();
+        const bool last = l + 1 == nd;
+        const uint32_t c = d->cycle_no;
+        PlanePlan<double>::Peer p;
+        p.planes = 3;
+        p.shift = int64_t(L.nzo) * L.pc;
+        if (going_down && !last) {
+            const PDLevel &C = d->lv[l + 1];
+            p.cplanes = 2;
+            p.cshift = int64_t(C.nzo) * C.pc;
+            p.zc_lo = PD_GHOST;
+            p.zc_hi = PD_GHOST + C.nzo;
+        }
+        const bool new_is_tmp = L.tp == L.tmp.p;
+        for (int i = 0; i < 2; ++i) {
+            const int nb = d->rank + (i ? 1 : -1);
+            if (nb < 0 || nb >= d->n_ranks) continue;
+            const PDPeer &P = d->peers[size_t(nb)];
+            p.x[i] = new_is_tmp ? P.tmp[size_t(l)] : P.x[size_t(l)];
+            if (going_down && !last) p.bc[i] = P.b[size_t(l) + 1];
+            // (I am rank - 1's NEXT neighbour and rank + 1's PREVIOUS one)
+            p.flag[i] = P.flags + pf((going_down ? PF_DOWN : PF_UP) + l, i ? 0 : 1);
+            if (going_down) {
+                if (l == 0) {
+                    p.wait_flag[i] = d->flags.p + pf(first_of_batch ? PF_PRIME : PF_UP, i);
+                    p.wait_seq[i] = first_of_batch ? d->batch_no : c - 1;
+                } else {
+                    p.wait_flag[i] = d->flags.p + pf(PF_DOWN + l - 1, i);
+                    p.wait_seq[i] = c;
+                }
+            } else {
+                p.wait_flag[i] = d->flags.p + pf(PF_DOWN + l, i);
+                p.wait_seq[i] = c;
+                if (!last) {
+                    p.wait_flag[2 + i] = d->flags.p + pf(PF_UP + l + 1, i);
+                    p.wait_seq[2 + i] = c;
+                }
+            }
+        }
+        p.fused_wait = d->p2p == 1;
+        p.done = d->flags.p + PD_DONE;
+        p.status = d->flags.p + PD_STATUS;
+        p.seq = c;
+        p.spin = d->spin;
+        return p;
+    }
+    void down(int l, bool first_of_batch = false) {
         for (PlaneDist *d : ranks) {
             PDLevel &L = d->lv[l];
             const bool last = l + 1 == (int)d->lv.size();
@@ -970,7 +1111,12 @@ struct PDExchange {
             c.map = last ? nullptr : L.cmap.p;
             c.b = last ? d->cb.p : d->lv[l + 1].b.p;
             c.x = nullptr;                                        // the level below takes its iterate as zero
-            L.plan.down(L.xp, L.tp, L.b.p, l > 0, c, d->stream);
+            if (d->p2p) {
+                const PlanePlan<double>::Peer p = peer_of(d, l, true, first_of_batch);
+                L.plan.down(L.xp, L.tp, L.b.p, l > 0, c, d->stream, &p);
+            } else {
+                L.plan.down(L.xp, L.tp, L.b.p, l > 0, c, d->stream);
+            }
             std::swap(L.xp, L.tp);
         }
     }
@@ -981,17 +1127,86 @@ struct PDExchange {
             PlanePlan<double>::Coarse c;
             c.map = last ? nullptr : L.cmap.p;
             c.e = last ? d->ce.p : d->lv[l + 1].xp;
-            L.plan.up(L.xp, L.tp, L.b.p, c, l == 0 ? (partials ? partials : L.plan.partials.p) : nullptr, d->stream);
+            double *out = l == 0 ? (partials ? partials : L.plan.partials.p) : nullptr;
+            if (d->p2p) {
+                const PlanePlan<double>::Peer p = peer_of(d, l, false, false);
+                L.plan.up(L.xp, L.tp, L.b.p, c, out, d->stream, &p);
+            } else {
+                L.plan.up(L.xp, L.tp, L.b.p, c, out, d->stream);
+            }
             std::swap(L.xp, L.tp);
         }
+    }
+    // peer mode, once per batch of cycles: the ghost planes of b and of the incoming x, handed over only when the
+    // neighbour's stream has reached its own batch start (it may have been loading new vectors until then)
+    void prime() {
+        for (PlaneDist *d : ranks) ++d->batch_no;
+        for (PlaneDist *d : ranks) {
+            uint32_t *f[2] = {nullptr, nullptr};
+            for (int i = 0; i < 2; ++i) {
+                const int nb = d->rank + (i ? 1 : -1);
+                if (nb >= 0 && nb < d->n_ranks) f[i] = d->peers[size_t(nb)].flags + pf(PF_READY, i ? 0 : 1);
+            }
+            hipLaunchKernelGGL(pd_signal_kernel, dim3(1), dim3(1), 0, d->stream, f[0], f[1], d->batch_no);
+        }
+        for (PlaneDist *d : ranks) wait_neighbours(d, PF_READY, d->batch_no);
+        for (PlaneDist *d : ranks) {
+            PDLevel &L = d->lv[0];
+            const bool cur_is_x = L.xp == L.x.p;
+            for (int i = 0; i < 2; ++i) {
+                const int nb = d->rank + (i ? 1 : -1);
+                if (nb < 0 || nb >= d->n_ranks) continue;
+                const PDPeer &P = d->peers[size_t(nb)];
+                double *px = cur_is_x ? P.x[0] : P.tmp[0], *pb = P.b[0];
+                PDPush a;
+                a.nseg = 4;
+                for (int colour = 0; colour < 2; ++colour) {
+                    const int64_t half = colour ? L.n_ext / 2 : 0;
+                    // to rank + 1: my last owned planes -> its lower ghosts; to rank - 1: my first owned planes -> its upper ghosts
+                    const int64_t from_x = half + int64_t(i ? PD_GHOST + L.nzo - 3 : PD_GHOST) * L.pc, to_x = half + int64_t(i ? PD_GHOST - 3 : PD_GHOST + L.nzo) * L.pc;
+                    const int64_t from_b = half + int64_t(i ? PD_GHOST + L.nzo - 2 : PD_GHOST) * L.pc, to_b = half + int64_t(i ? PD_GHOST - 2 : PD_GHOST + L.nzo) * L.pc;
+                    a.src[colour] = L.xp + from_x; a.dst[colour] = px + to_x; a.n[colour] = 3 * L.pc;
+                    a.src[2 + colour] = L.b.p + from_b; a.dst[2 + colour] = pb + to_b; a.n[2 + colour] = 2 * L.pc;
+                }
+                a.counter = d->flags.p + PD_DONE + 1 + i;
+                a.flag = P.flags + pf(PF_PRIME, i ? 0 : 1);
+                a.seq = d->batch_no;
+                const int64_t bytes = 5 * L.pc * 2 * 8;
+                const unsigned blocks = unsigned(std::max<int64_t>(1, std::min<int64_t>(64, bytes / 32768)));
+                hipLaunchKernelGGL(pd_push_kernel, dim3(blocks), dim3(256), 0, d->stream, a);
+            }
+        }
+        OMG_HIP(hipGetLastError());
+    }
+    void wait_neighbours(PlaneDist *d, int slot, uint32_t seq) {
+        const bool lo = d->rank > 0, hi = d->rank + 1 < d->n_ranks;
+        if (!lo && !hi) return;
+        hipLaunchKernelGGL(pd_wait_kernel, dim3(1), dim3(64), 0, d->stream, d->flags.p, pf(slot, lo ? 0 : 1), 1, (lo && hi) ? 2 : 1, seq,
+                           d->flags.p + PD_STATUS, d->spin);
+    }
+    // peer mode: every rank's planes of the tail's right-hand side stored into every rank's gathered vector
+    void gather_p2p() {
+        for (PlaneDist *d : ranks) {
+            const int64_t own = int64_t(d->cnx) * d->cny * d->cnzo;
+            const int par = int(d->cycle_no & 1u);
+            const unsigned blocks = unsigned(std::max<int64_t>(1, std::min<int64_t>(16, own * 8 / 16384)));
+            hipLaunchKernelGGL(pd_gather_kernel, dim3(blocks, unsigned(d->n_ranks)), dim3(256), 0, d->stream,
+                               d->cb.p + int64_t(PD_GHOST) * d->cnx * d->cny, own, d->ag_dst[par].p, d->ag_flag.p, d->flags.p + PD_COUNT, d->cycle_no);
+        }
+        for (PlaneDist *d : ranks)
+            hipLaunchKernelGGL(pd_wait_kernel, dim3(1), dim3(unsigned((d->n_ranks + 63) / 64 * 64)), 0, d->stream, d->flags.p, PF_GATHER * 2, 1, d->n_ranks,
+                               d->cycle_no, d->flags.p + PD_STATUS, d->spin);
+        OMG_HIP(hipGetLastError());
     }
     // right-hand side of the level below the slabs: gathered, solved by the replicated tail, the slab's planes
     // (and ghosts) of the correction taken out of it
     void tail_solve() {
+        if (p2p()) gather_p2p();
         for (PlaneDist *d : ranks) {
             const int64_t plane = int64_t(d->cnx) * d->cny, own = plane * d->cnzo;
             const double *mine = d->cb.p + int64_t(PD_GHOST) * plane;
-            if (loopback) {
+            if (d->p2p) {
+            } else if (loopback) {
                 for (PlaneDist *o : ranks)
                     OMG_HIP(hipMemcpyAsync(o->full_b.p + int64_t(d->rank) * own, mine, size_t(own) * sizeof(double), hipMemcpyDeviceToDevice, d->stream));
             } else if (d->n_ranks > 1) {
@@ -1002,7 +1217,8 @@ struct PDExchange {
         }
         for (PlaneDist *d : ranks) {
             const int64_t plane = int64_t(d->cnx) * d->cny;
-            if (omg_hierarchy_cycle_dev(d->tail, d->full_b.p, d->full_x.p, 1, 1, d->stream) != OMG_OK)
+            const double *gathered = (d->p2p && (d->cycle_no & 1u)) ? d->full_b2.p : d->full_b.p;
+            if (omg_hierarchy_cycle_dev(d->tail, gathered, d->full_x.p, 1, 1, d->stream) != OMG_OK)
                 throw Error(OMG_ERR_HIP, std::string("replicated tail cycle: ") + omg_last_error());
             // planes [k0 - ghost, k0 + own + ghost) of the correction, clipped to the grid (the rest stays zero)
             const int64_t k0 = int64_t(d->rank) * d->cnzo, nzg = int64_t(d->n_ranks) * d->cnzo;
@@ -1015,9 +1231,20 @@ struct PDExchange {
     void mark(int level, int phase) {
         for (PlaneDist *d : ranks) d->mark(level, phase);
     }
-    void cycle(double *squares_out = nullptr /* one rank only: where its sum of squares goes instead of norm2 */) {
+    void cycle(double *squares_out = nullptr /* one rank only: where its sum of squares goes instead of norm2 */, bool first_of_batch = false) {
         const int nd = (int)ranks[0]->lv.size();
         for (PlaneDist *d : ranks) ++d->cycle_no;
+        if (p2p()) {
+            // peer mode: no exchange launches — the passes store into their neighbours and wait for them (prime() has
+            // run before the batch's first cycle)
+            for (int l = 0; l < nd; ++l) { down(l, first_of_batch); mark(l, 3); }
+            tail_solve();
+            mark(nd, 5);
+            for (int l = nd - 1; l >= 0; --l) { up(l, nullptr); mark(l, 7); }
+            for (PlaneDist *d : ranks)
+                launch_sum(d->lv[0].plan.partials.p, d->lv[0].plan.g.n_wg, squares_out ? squares_out : d->norm2.p, d->stream);
+            return;
+        }
         halo(0, 0, 3);
         mark(0, 1);
         for (int l = 0; l < nd; ++l) {
@@ -1128,6 +1355,11 @@ std::unique_ptr<PlaneDist> pd_create(int rank, int n_ranks, int nx, int ny, int 
     d->full_x.alloc(size_t(cplane * lz * n_ranks));
     d->norm2.alloc(1);
     d->norms.alloc(64);
+    d->flags.alloc(size_t(PD_COUNT + std::max(n_ranks, 8)));
+    d->flags.zero(d->stream);
+    d->full_b2.alloc(size_t(cplane * lz * n_ranks));
+    d->peers.resize(size_t(n_ranks));
+    if (const char *e = getenv("OMG_P2P_SPIN")) d->spin = uint32_t(std::max(1L, atol(e)));
     OMG_HIP(hipHostMalloc(reinterpret_cast<void **>(&d->progress), sizeof(uint32_t), hipHostMallocDefault));
     *d->progress = 0;
     d->nat.alloc(size_t(int64_t(nx) * ny * (nz_global / n_ranks)));
@@ -1520,6 +1752,126 @@ int omg_pdist_rccl_ranks(omg_pdist *d, int *count) {
     });
 }
 
+/* ---- peer mode (xGMI peer stores instead of RCCL launches) ------------------------------------------------------
+ * Every rank exports IPC handles of the buffers its neighbours store into (omg_pdist_p2p_handles: 3 + 3 per level
+ * handles of 64 bytes: flags, the two gathered right-hand sides, then x / tmp / b of every level), the control plane
+ * hands them round, every rank opens every other rank's (omg_pdist_p2p_open; same process: omg_pdist_p2p_local),
+ * then omg_pdist_p2p_enable(mode): 1 = the passes wait for their neighbours' flags themselves (one GPU per rank),
+ * 2 = a one-workgroup wait launch before each pass (ranks that share a GPU: a pass that waited itself would hold the
+ * compute units the neighbour's pass needs), 0 = back to RCCL.  Needs >= 4 planes per rank on every level. */
+static void pd_own_buffers(PlaneDist *d, std::vector<void *> &out) {
+    out = {d->flags.p, d->full_b.p, d->full_b2.p};
+    for (PDLevel &L : d->lv) { out.push_back(L.x.p); out.push_back(L.tmp.p); out.push_back(L.b.p); }
+}
+static void pd_attach(PlaneDist *d, int peer_rank, const std::vector<void *> &bufs) {
+    PDPeer &P = d->peers[size_t(peer_rank)];
+    P.flags = static_cast<uint32_t *>(bufs[0]);
+    P.full_b[0] = static_cast<double *>(bufs[1]);
+    P.full_b[1] = static_cast<double *>(bufs[2]);
+    P.x.clear(); P.tmp.clear(); P.b.clear();
+    for (size_t l = 0; l < d->lv.size(); ++l) {
+        P.x.push_back(static_cast<double *>(bufs[3 + 3 * l]));
+        P.tmp.push_back(static_cast<double *>(bufs[4 + 3 * l]));
+        P.b.push_back(static_cast<double *>(bufs[5 + 3 * l]));
+    }
+}
+
+int omg_pdist_p2p_handle_count(omg_pdist *d, int *count) {
+    return guarded([&] {
+        OMG_REQUIRE(d && d->d && count, "null argument");
+        *count = 3 + 3 * int(d->d->lv.size());
+    });
+}
+
+int omg_pdist_p2p_handles(omg_pdist *d, void *handles64, int capacity) {
+    return guarded([&] {
+        OMG_REQUIRE(d && d->d && handles64, "null argument");
+        static_assert(sizeof(hipIpcMemHandle_t) == 64, "IPC handle size");
+        std::vector<void *> bufs;
+        pd_own_buffers(d->d.get(), bufs);
+        OMG_REQUIRE(capacity >= int(bufs.size()), "handle buffer too small");
+        OMG_HIP(hipStreamSynchronize(d->d->stream));
+        for (size_t i = 0; i < bufs.size(); ++i) {
+            hipIpcMemHandle_t h;
+            OMG_HIP(hipIpcGetMemHandle(&h, static_cast<char *>(bufs[i]) - DEVBUF_SLACK));     // (the allocation's base)
+            std::memcpy(static_cast<char *>(handles64) + 64 * i, &h, 64);
+        }
+    });
+}
+
+int omg_pdist_p2p_open(omg_pdist *d, int peer_rank, const void *handles64, int count) {
+    return guarded([&] {
+        OMG_REQUIRE(d && d->d && handles64, "null argument");
+        PlaneDist *dd = d->d.get();
+        OMG_REQUIRE(peer_rank >= 0 && peer_rank < dd->n_ranks && peer_rank != dd->rank, "bad peer rank");
+        OMG_REQUIRE(count == 3 + 3 * int(dd->lv.size()), "handle count does not match the levels");
+        PDPeer &P = dd->peers[size_t(peer_rank)];
+        OMG_REQUIRE(P.mapped.empty(), "peer already opened");
+        std::vector<void *> bufs;
+        for (int i = 0; i < count; ++i) {
+            hipIpcMemHandle_t h;
+            std::memcpy(&h, static_cast<const char *>(handles64) + 64 * i, 64);
+            void *base = nullptr;
+            OMG_HIP(hipIpcOpenMemHandle(&base, h, hipIpcMemLazyEnablePeerAccess));
+            P.mapped.push_back(base);
+            bufs.push_back(static_cast<char *>(base) + DEVBUF_SLACK);
+        }
+        pd_attach(dd, peer_rank, bufs);
+    });
+}
+
+int omg_pdist_p2p_local(omg_pdist *d, omg_pdist *other) {
+    return guarded([&] {
+        OMG_REQUIRE(d && d->d && other && other->d, "null argument");
+        OMG_REQUIRE(other->d->n_ranks == d->d->n_ranks && other->d->lv.size() == d->d->lv.size() && other->d->rank != d->d->rank,
+                    "not another rank of the same decomposition");
+        std::vector<void *> bufs;
+        pd_own_buffers(other->d.get(), bufs);
+        pd_attach(d->d.get(), other->d->rank, bufs);
+    });
+}
+
+int omg_pdist_p2p_enable(omg_pdist *d, int mode) {
+    return guarded([&] {
+        OMG_REQUIRE(d && d->d && mode >= 0 && mode <= 2, "bad argument");
+        PlaneDist *dd = d->d.get();
+        if (mode == 0) { dd->p2p = 0; return; }
+        for (const PDLevel &L : dd->lv) OMG_REQUIRE(L.nzo >= 4, "peer mode needs at least four planes per rank on every distributed level");
+        const int64_t own = int64_t(dd->cnx) * dd->cny * dd->cnzo;
+        std::vector<double *> dst[2];
+        std::vector<uint32_t *> fl;
+        for (int r = 0; r < dd->n_ranks; ++r) {
+            const bool self = r == dd->rank;
+            if (!self) OMG_REQUIRE(dd->peers[size_t(r)].flags, "peer mode: a rank's buffers have not been opened");
+            dst[0].push_back((self ? dd->full_b.p : dd->peers[size_t(r)].full_b[0]) + int64_t(dd->rank) * own);
+            dst[1].push_back((self ? dd->full_b2.p : dd->peers[size_t(r)].full_b[1]) + int64_t(dd->rank) * own);
+            fl.push_back((self ? dd->flags.p : dd->peers[size_t(r)].flags) + PF_GATHER * 2 + dd->rank);
+        }
+        OMG_REQUIRE(PF_GATHER * 2 + dd->n_ranks <= PD_FLAGS, "too many ranks for the flag table");
+        for (int par = 0; par < 2; ++par) {
+            dd->ag_dst[par].alloc(dst[par].size());
+            dd->ag_dst[par].upload(dst[par].data(), dst[par].size(), dd->stream);
+        }
+        dd->ag_flag.alloc(fl.size());
+        dd->ag_flag.upload(fl.data(), fl.size(), dd->stream);
+        OMG_HIP(hipStreamSynchronize(dd->stream));
+        dd->p2p = mode;
+    });
+}
+
+/* bit 0: a wait for a neighbour's flag gave up since the last call (the results since then are not to be used) */
+int omg_pdist_p2p_status(omg_pdist *d, unsigned *status) {
+    return guarded([&] {
+        OMG_REQUIRE(d && d->d && status, "null argument");
+        PlaneDist *dd = d->d.get();
+        uint32_t v = 0;
+        OMG_HIP(hipMemcpyAsync(&v, dd->flags.p + PD_STATUS, 4, hipMemcpyDeviceToHost, dd->stream));
+        OMG_HIP(hipMemsetAsync(dd->flags.p + PD_STATUS, 0, 4, dd->stream));
+        OMG_HIP(hipStreamSynchronize(dd->stream));
+        *status = v;
+    });
+}
+
 static void pd_put(PlaneDist *d, const double *host, double *ext) {
     PDLevel &L = d->lv[0];
     const int64_t n = int64_t(L.nx) * L.ny * L.nzo;
@@ -1541,7 +1893,7 @@ int omg_pdist_load(omg_pdist *d, const double *b_local, const double *x0_local) 
         PlaneDist *dd = d->d.get();
         pd_put(dd, b_local, dd->lv[0].b.p);
         pd_put(dd, x0_local, dd->lv[0].xp);
-        if (dd->comm && dd->n_ranks > 1) {
+        if (dd->comm && dd->n_ranks > 1 && !dd->p2p) {            // (peer mode hands the ghost planes over at every batch start)
             PDExchange ex;
             ex.ranks = {dd};
             ex.halo(0, 1, 2);
@@ -1585,22 +1937,29 @@ int omg_pdist_sync(omg_pdist *d) {
 }
 
 /* n_cycles V(1,1) cycles, every cycle's global residual norm computed and returned; collective. */
-int omg_pdist_cycles(omg_pdist *d, int n_cycles, double *norms) {
+static int pd_cycles(omg_pdist *d, int n_cycles, double *norms, bool squares_only) {
     return guarded([&] {
         OMG_REQUIRE(d && d->d && n_cycles >= 0, "bad argument");
         PlaneDist *dd = d->d.get();
         OMG_REQUIRE(dd->tail, "omg_pdist_set_tail has not been called");
-        OMG_REQUIRE(dd->n_ranks == 1 || dd->comm, "omg_pdist_connect has not been called");
+        OMG_REQUIRE(dd->n_ranks == 1 || dd->comm || (dd->p2p && squares_only), "omg_pdist_connect has not been called");
         if (n_cycles == 0) return;
         if (dd->norms.n < size_t(n_cycles)) dd->norms.alloc(size_t(n_cycles));
         PDExchange ex;
         ex.ranks = {dd};
-        for (int k = 0; k < n_cycles; ++k) ex.cycle(dd->norms.p + k);
-        ex.norms_of_batch(dd->norms.p, n_cycles);
+        if (dd->p2p) ex.prime();
+        for (int k = 0; k < n_cycles; ++k) ex.cycle(dd->norms.p + k, k == 0);
+        if (squares_only) { OMG_REQUIRE(norms, "null argument"); }
+        else ex.norms_of_batch(dd->norms.p, n_cycles);
         if (norms) OMG_HIP(hipMemcpyAsync(norms, dd->norms.p, size_t(n_cycles) * sizeof(double), hipMemcpyDeviceToHost, dd->stream));
         OMG_HIP(hipStreamSynchronize(dd->stream));
     });
 }
+
+int omg_pdist_cycles(omg_pdist *d, int n_cycles, double *norms) { return pd_cycles(d, n_cycles, norms, false); }
+/* The same cycles; squares[k] = THIS rank's sum of squared residuals after cycle k — no collective (peer mode without
+ * a communicator: the caller adds the ranks' values and takes the root). */
+int omg_pdist_cycles_squares(omg_pdist *d, int n_cycles, double *squares) { return pd_cycles(d, n_cycles, squares, true); }
 
 /* All ranks of a decomposition in ONE process on one GPU: the same launches per rank, device copies in place of
  * the RCCL exchanges (verification of the schedule without several GPUs).  The ranks run on rank 0's stream. */
@@ -1636,10 +1995,12 @@ int omg_pdist_group_cycles(omg_pdist_group *g, int n_cycles, double *norms) {
         if (n_cycles == 0) return;
         PlaneDist *z = ex.ranks[0];
         if (z->norms.n < size_t(n_cycles) * ex.ranks.size()) z->norms.alloc(size_t(n_cycles) * ex.ranks.size());
-        ex.halo(0, 1, 2);                                     // ghost planes of the right-hand side
+        for (PlaneDist *r : ex.ranks) OMG_REQUIRE(r->p2p == z->p2p, "the ranks of a group must all be in the same mode");
+        if (ex.p2p()) ex.prime();
+        else ex.halo(0, 1, 2);                                // ghost planes of the right-hand side
         std::vector<double *> outs(ex.ranks.size());
         for (int k = 0; k < n_cycles; ++k) {
-            ex.cycle();
+            ex.cycle(nullptr, k == 0);
             for (size_t r = 0; r < ex.ranks.size(); ++r) outs[r] = z->norms.p + size_t(k) * ex.ranks.size() + r;
             ex.norm(outs.data());
         }

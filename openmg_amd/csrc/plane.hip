@@ -147,6 +147,15 @@ struct PlaneKArgs {
     int first_end;
     const V *ec;
     double *partials;
+    // slab neighbours (PEER kernels; PlanePlan::Peer)
+    V *peer_x[2], *peer_bc[2];
+    int peer_shift, peer_cshift, peer_planes, peer_cplanes, zc_lo, zc_hi;
+    const uint32_t *wait_flag[4];
+    uint32_t wait_seq[4];
+    int fused_wait;
+    uint32_t *done, *peer_flag[2];
+    uint32_t flag_seq, spin;
+    uint32_t *status;
 #ifdef OMG_PLANE_STAMPS
     unsigned long long *stamps;      // diagnostic build: per workgroup and wave, cycles spent waiting for loads / computing / at the barrier
     int dbg;                         // ... OMG_PLANE_DBG bits: 1 no x stores, 2 no coarse stores, 4 x taken as zero (wrong results, timing only)
@@ -225,7 +234,50 @@ __device__ __forceinline__ Inline<V> in_line(int rule, const P2<V> &O, V nb) {
     return r;
 }
 
+// Wait until a flag another GPU (or another process's kernel) stores into this GPU's memory holds at least seq
+// (wrapping compare): system-scope loads, a bounded number of them — a wait that gives up sets bit 0 of *status
+// and lets the caller run on (its results are then wrong and the host says so) instead of hanging the device.
+__device__ __forceinline__ void peer_wait(const uint32_t *flag, uint32_t seq, uint32_t *status, uint32_t spin) {
+    if (!flag) return;
+    for (uint32_t n = 0;; ++n) {
+        const uint32_t v = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (int32_t(v - seq) >= 0) break;
+        if (n >= spin) {
+            if (status) __hip_atomic_fetch_or(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            break;
+        }
+        __builtin_amdgcn_s_sleep(16);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");      // what the flag's writer stored before it: not from this CU's L1 / this XCD's L2
+}
+// the pass's workgroups are counted at its end; the last one tells the neighbours
+__device__ __forceinline__ void peer_done(uint32_t *done, uint32_t n_wg, uint32_t *const (&flag)[2], uint32_t seq) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");      // every thread: its stores into the neighbours' memory are out
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t before = __hip_atomic_fetch_add(done, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        if (before == n_wg - 1) {
+            __hip_atomic_store(done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+            for (int i = 0; i < 2; ++i)
+                if (flag[i]) __hip_atomic_store(flag[i], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+// (one workgroup; the caller's stream then launches the pass: for neighbours that share this GPU, where a pass
+// that waited itself would hold the compute units the neighbour's pass needs)
+__global__ void plane_wait_kernel(const uint32_t *f0, const uint32_t *f1, const uint32_t *f2, const uint32_t *f3,
+                                  uint32_t s0, uint32_t s1, uint32_t s2, uint32_t s3, uint32_t *status, uint32_t spin) {
+    if (threadIdx.x == 0) {
+        peer_wait(f0, s0, status, spin);
+        peer_wait(f1, s1, status, spin);
+        peer_wait(f2, s2, status, spin);
+        peer_wait(f3, s3, status, spin);
+    }
+}
+
 // MODE 0: down (sweep, residual, restriction), 1: up (prolongation, sweep, optionally the norm)
+// PEER: a slab with neighbours reached by peer stores (PlanePlan::Peer).
 // XZ (down): x_old is zero and is not read.
 // Every load of the loop is UNCONDITIONAL (a lane that needs nothing asks for an offset behind the buffer,
 // which costs no memory traffic) and is committed at the top of the NEXT step: a load inside a branch is
@@ -234,7 +286,7 @@ __device__ __forceinline__ Inline<V> in_line(int rule, const P2<V> &O, V nb) {
 // LA: how many steps ahead a step's loads are requested (2: two sets of registers in flight — the vector
 // memory pipe then streams while a step computes and waits at its barrier; the loop runs two steps per
 // iteration so that every register has a fixed role and the step's parity is a compile-time constant).
-template <typename V, int MODE, bool NORM, bool XZ, int LA>
+template <typename V, int MODE, bool NORM, bool XZ, int LA, bool PEER = false>
 __global__ __launch_bounds__(512) void plane_kernel(const PlaneKArgs<V> a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char plane_smem[];
     V *const lds = reinterpret_cast<V *>(plane_smem);
@@ -312,7 +364,42 @@ __global__ __launch_bounds__(512) void plane_kernel(const PlaneKArgs<V> a) {
     const int row_a = 1 + 2 * py, col = 2 + 2 * px;
     const int idx[2] = {row_a * S + col, (row_a + 1) * S + col};
     for (int i = t; i < 6 * BUF; i += int(blockDim.x)) lds[i] = V(0);
+    if (PEER && a.fused_wait && t == 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) peer_wait(a.wait_flag[i], a.wait_seq[i], a.status, a.spin);
+    }
     __syncthreads();
+    // the neighbours' vectors (a missing neighbour: an empty range, its stores are dropped)
+    const __amdgpu_buffer_rsrc_t pw0 = __builtin_amdgcn_make_buffer_rsrc(PEER && a.peer_x[0] ? a.peer_x[0] : a.x_new, 0, PEER && a.peer_x[0] ? a.vec_bytes : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t pw1 = __builtin_amdgcn_make_buffer_rsrc(PEER && a.peer_x[1] ? a.peer_x[1] : a.x_new, 0, PEER && a.peer_x[1] ? a.vec_bytes : 0u, 0x00020000);
+    // plane k (uniform) of colour-offset slot `base` (+ lb[l]): to the neighbours whose ghost planes it is
+    auto peer_store = [&](int k, int base, const P2<V> (&v)[2]) {
+        if (k < a.z_base + a.peer_planes) {
+#pragma unroll
+            for (int l = 0; l < 2; ++l)
+                if (vl[l] && vx0) bstore2(pw0, (base + a.peer_shift + lb[l]) * int(sizeof(V)), v[l], vx1);
+        }
+        if (k >= a.z_end - a.peer_planes) {
+#pragma unroll
+            for (int l = 0; l < 2; ++l)
+                if (vl[l] && vx0) bstore2(pw1, (base - a.peer_shift + lb[l]) * int(sizeof(V)), v[l], vx1);
+        }
+    };
+    int CO_kc = 0;                   // coarse plane (extended slab) of the pending coarse pair
+    auto coarse_store = [&](const v2i &sl, const P2<V> &co, const P2<V> &cx) {
+        if (sl.x >= 0) { a.bc[sl.x] = co.x; if (a.xc) a.xc[sl.x] = cx.x; }
+        if (sl.y >= 0) { a.bc[sl.y] = co.y; if (a.xc) a.xc[sl.y] = cx.y; }
+        if (PEER) {
+            if (a.peer_bc[0] && CO_kc < a.zc_lo + a.peer_cplanes) {
+                if (sl.x >= 0) a.peer_bc[0][sl.x + a.peer_cshift] = co.x;
+                if (sl.y >= 0) a.peer_bc[0][sl.y + a.peer_cshift] = co.y;
+            }
+            if (a.peer_bc[1] && CO_kc >= a.zc_hi - a.peer_cplanes) {
+                if (sl.x >= 0) a.peer_bc[1][sl.x - a.peer_cshift] = co.x;
+                if (sl.y >= 0) a.peer_bc[1][sl.y - a.peer_cshift] = co.y;
+            }
+        }
+    };
 
     const P2<V> zero2 = {V(0), V(0)};
     P2<V> XR[3][2], XB[5][2], BR[3][2], BB[2], LXB[LA][2], LXR[LA][2], LBR[LA][2], LBB[LA][2], RB[2];
@@ -440,8 +527,7 @@ __global__ __launch_bounds__(512) void plane_kernel(const PlaneKArgs<V> a) {
             if (a.dbg & 2) co_pending = false;
 #endif
             if (co_pending) {
-                if (SLo.x >= 0) { a.bc[SLo.x] = CO.x; if (a.xc) a.xc[SLo.x] = CX.x; }
-                if (SLo.y >= 0) { a.bc[SLo.y] = CO.y; if (a.xc) a.xc[SLo.y] = CX.y; }
+                coarse_store(SLo, CO, CX);
                 co_pending = false;
             }
         }
@@ -485,6 +571,7 @@ __global__ __launch_bounds__(512) void plane_kernel(const PlaneKArgs<V> a) {
 #pragma unroll
                 for (int l = 0; l < 2; ++l)
                     if (vl[l] && vx0) bstore2(ws, ((s - 1) * ps + lb[l]) * int(sizeof(V)), XR[1][l], vx1);
+                if (PEER) peer_store(s - 1, (s - 1) * ps, XR[1]);
             }
             PLANE_STAMP(st_B)
             // C: black sweep of plane s - 1, and the residual of the rows it has just relaxed
@@ -530,6 +617,7 @@ __global__ __launch_bounds__(512) void plane_kernel(const PlaneKArgs<V> a) {
 #pragma unroll
                 for (int l = 0; l < 2; ++l)
                     if (vl[l] && vx0) bstore2(ws, (a.nr + (s - 2) * ps + lb[l]) * int(sizeof(V)), XB[3][l], vx1);
+                if (PEER) peer_store(s - 2, a.nr + (s - 2) * ps, XB[3]);
             }
             PLANE_STAMP(st_C)
             // D: residual of the red rows of plane s - 2
@@ -567,6 +655,7 @@ __global__ __launch_bounds__(512) void plane_kernel(const PlaneKArgs<V> a) {
                     if (inner && s - 2 >= z0 && s - 2 < z1) {
                         CO = ACC;
                         SLo = SLd;
+                        CO_kc = ((s - 2) >> 1) + a.kc_off;
                         // the coarse level's first relaxation of a zero iterate, spelled like row_epilogue's
                         CX.x = (a.cdiag && SLd.x >= 0 && SLd.x < a.first_end) ? V(0) + (ACC.x - V(0)) / DG.x : V(0);
                         CX.y = (a.cdiag && SLd.y >= 0 && SLd.y < a.first_end) ? V(0) + (ACC.y - V(0)) / DG.y : V(0);
@@ -621,10 +710,7 @@ __global__ __launch_bounds__(512) void plane_kernel(const PlaneKArgs<V> a) {
         o[0] = st_mem; o[1] = st_cmp; o[2] = st_bar; o[3] = unsigned(z1 + 2 - s0); o[4] = st_top; o[5] = st_B; o[6] = st_C;
     }
 #endif
-    if (MODE == 0 && co_pending) {
-        if (SLo.x >= 0) { a.bc[SLo.x] = CO.x; if (a.xc) a.xc[SLo.x] = CX.x; }
-        if (SLo.y >= 0) { a.bc[SLo.y] = CO.y; if (a.xc) a.xc[SLo.y] = CX.y; }
-    }
+    if (MODE == 0 && co_pending) coarse_store(SLo, CO, CX);
     if (NORM) {
         // fixed order: lanes of a wave (shuffle tree), then the waves in turn
 #pragma unroll
@@ -637,6 +723,7 @@ __global__ __launch_bounds__(512) void plane_kernel(const PlaneKArgs<V> a) {
             a.partials[blockIdx.x] = tot;
         }
     }
+    if (PEER) peer_done(a.done, gridDim.x, a.peer_flag, a.flag_seq);
 }
 
 // ---- host: does the level qualify, and how is it tiled -----------------------------------------------
@@ -963,43 +1050,69 @@ void allow_lds(K kernel, size_t bytes) {
 
 }  // namespace
 
+// the neighbours of a slab into the kernel's arguments; the wait as a launch of its own where asked for
 template <typename V>
-void PlanePlan<V>::down(const V *x_old, V *x_new, const V *b, bool x_zero, const Coarse &c, hipStream_t s) const {
+void peer_args(PlaneKArgs<V> &k, const typename PlanePlan<V>::Peer &p, hipStream_t s) {
+    for (int i = 0; i < 2; ++i) { k.peer_x[i] = p.x[i]; k.peer_bc[i] = p.bc[i]; k.peer_flag[i] = p.flag[i]; }
+    k.peer_shift = int(p.shift); k.peer_cshift = int(p.cshift);
+    k.peer_planes = p.planes; k.peer_cplanes = p.cplanes; k.zc_lo = p.zc_lo; k.zc_hi = p.zc_hi;
+    for (int i = 0; i < 4; ++i) { k.wait_flag[i] = p.wait_flag[i]; k.wait_seq[i] = p.wait_seq[i]; }
+    k.fused_wait = p.fused_wait ? 1 : 0;
+    k.done = p.done; k.flag_seq = p.seq; k.status = p.status; k.spin = p.spin;
+    OMG_REQUIRE(p.done, "plane pass with neighbours: no workgroup counter");
+    if (!p.fused_wait && (p.wait_flag[0] || p.wait_flag[1] || p.wait_flag[2] || p.wait_flag[3])) {
+        hipLaunchKernelGGL(plane_wait_kernel, dim3(1), dim3(64), 0, s, p.wait_flag[0], p.wait_flag[1], p.wait_flag[2], p.wait_flag[3],
+                           p.wait_seq[0], p.wait_seq[1], p.wait_seq[2], p.wait_seq[3], p.status, p.spin);
+        OMG_HIP(hipGetLastError());
+    }
+}
+
+template <typename K, typename V>
+void launch_plane(K kernel, const PlaneGeom &g, const PlaneKArgs<V> &k, hipStream_t s) {
+    allow_lds(kernel, g.lds_bytes);
+    hipLaunchKernelGGL(kernel, dim3(unsigned(g.n_wg)), dim3(unsigned(g.threads)), g.lds_bytes, s, k);
+    OMG_HIP(hipGetLastError());
+}
+
+template <typename V>
+void PlanePlan<V>::down(const V *x_old, V *x_new, const V *b, bool x_zero, const Coarse &c, hipStream_t s, const Peer *peer) const {
     PlaneKArgs<V> k = plane_args<V>(g, x_old, x_new, b, c);
     k.x_zero = x_zero ? 1 : 0;
 #ifdef OMG_PLANE_STAMPS
     DevBuf<unsigned long long> sb;
     stamps_begin(k, g, sb);
 #endif
-    if (x_zero) {
-        allow_lds(plane_kernel<V, 0, false, true, PLANE_LA>, g.lds_bytes);
-        hipLaunchKernelGGL((plane_kernel<V, 0, false, true, PLANE_LA>), dim3(unsigned(g.n_wg)), dim3(unsigned(g.threads)), g.lds_bytes, s, k);
+    if (peer) {
+        peer_args<V>(k, *peer, s);
+        if (x_zero) launch_plane(plane_kernel<V, 0, false, true, PLANE_LA, true>, g, k, s);
+        else launch_plane(plane_kernel<V, 0, false, false, PLANE_LA, true>, g, k, s);
+    } else if (x_zero) {
+        launch_plane(plane_kernel<V, 0, false, true, PLANE_LA>, g, k, s);
     } else {
-        allow_lds(plane_kernel<V, 0, false, false, PLANE_LA>, g.lds_bytes);
-        hipLaunchKernelGGL((plane_kernel<V, 0, false, false, PLANE_LA>), dim3(unsigned(g.n_wg)), dim3(unsigned(g.threads)), g.lds_bytes, s, k);
+        launch_plane(plane_kernel<V, 0, false, false, PLANE_LA>, g, k, s);
     }
-    OMG_HIP(hipGetLastError());
 #ifdef OMG_PLANE_STAMPS
     stamps_end("down", g, sb, s);
 #endif
 }
 
 template <typename V>
-void PlanePlan<V>::up(const V *x_old, V *x_new, const V *b, const Coarse &c, double *out, hipStream_t s) const {
+void PlanePlan<V>::up(const V *x_old, V *x_new, const V *b, const Coarse &c, double *out, hipStream_t s, const Peer *peer) const {
     PlaneKArgs<V> k = plane_args<V>(g, x_old, x_new, b, c);
     k.partials = out;
 #ifdef OMG_PLANE_STAMPS
     DevBuf<unsigned long long> sb;
     stamps_begin(k, g, sb);
 #endif
-    if (out) {
-        allow_lds(plane_kernel<V, 1, true, false, PLANE_LA>, g.lds_bytes);
-        hipLaunchKernelGGL((plane_kernel<V, 1, true, false, PLANE_LA>), dim3(unsigned(g.n_wg)), dim3(unsigned(g.threads)), g.lds_bytes, s, k);
+    if (peer) {
+        peer_args<V>(k, *peer, s);
+        if (out) launch_plane(plane_kernel<V, 1, true, false, PLANE_LA, true>, g, k, s);
+        else launch_plane(plane_kernel<V, 1, false, false, PLANE_LA, true>, g, k, s);
+    } else if (out) {
+        launch_plane(plane_kernel<V, 1, true, false, PLANE_LA>, g, k, s);
     } else {
-        allow_lds(plane_kernel<V, 1, false, false, PLANE_LA>, g.lds_bytes);
-        hipLaunchKernelGGL((plane_kernel<V, 1, false, false, PLANE_LA>), dim3(unsigned(g.n_wg)), dim3(unsigned(g.threads)), g.lds_bytes, s, k);
+        launch_plane(plane_kernel<V, 1, false, false, PLANE_LA>, g, k, s);
     }
-    OMG_HIP(hipGetLastError());
 #ifdef OMG_PLANE_STAMPS
     stamps_end("up", g, sb, s);
 #endif

@@ -107,3 +107,81 @@ def test_slabs_at_the_bench_shapes_have_the_bits_of_one_slab(world):
     assert np.array_equal(out[1][1], out[world][1])
     np.testing.assert_allclose(out[1][0], out[world][0], rtol=1e-13)     # per-slab partial sums, added in rank order
     assert out[1][0][1] < out[1][0][0]                  # and the norm goes down
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+@pytest.mark.parametrize("shape,grids,n_dist", [((32, 32, 32), 4, 1), ((64, 32, 48), 4, 2), ((64, 64, 64), 5, 3)])
+def test_peer_store_slabs_have_the_bits_of_the_single_gpu_cycle(shape, grids, n_dist, mode):
+    """Peer mode (omg_pdist_p2p_*): the passes store their boundary planes into the neighbours' ghost planes and wait
+    for each other's flags; no exchange launches.  All ranks in one process, so the peers are plain pointers."""
+    A, R, b, x0 = problem(shape, grids)
+    with _hip.Hierarchy(A, R, smoother="colour") as h:
+        h.resident_load(b, x0)
+        want_norms = [h.resident_cycle(1, 1) for _ in range(4)]
+        want = h.resident_fetch()
+    for n_ranks in (1, 2, 4, 8):
+        if (shape[0] >> (n_dist - 1)) // n_ranks < 4:
+            continue                                   # peer mode: four planes per rank on every distributed level
+        g = _hip_dist.PlaneDistGroup(slabs(A, R, shape, n_ranks, n_dist, b, x0), p2p=mode)
+        try:
+            norms = g.cycles(3) + g.cycles(1)          # (two batches: the ghost planes are handed over again)
+            got = np.concatenate([r.fetch() for r in g.ranks])
+        finally:
+            g.close()
+        assert np.array_equal(got, want), (shape, n_ranks, int(np.sum(got != want)))
+        np.testing.assert_allclose(norms, want_norms, rtol=1e-13)
+
+
+def test_peer_store_wait_gives_up_instead_of_hanging():
+    """A rank whose neighbour never writes: the wait is bounded, the status word says so, the device is not hung."""
+    import os
+    shape, grids, n_dist = (32, 32, 32), 4, 1
+    A, R, b, x0 = problem(shape, grids)
+    os.environ["OMG_P2P_SPIN"] = "2000"
+    try:
+        ranks = slabs(A, R, shape, 2, n_dist, b, x0)
+    finally:
+        del os.environ["OMG_P2P_SPIN"]
+    try:
+        ranks[0].p2p_local(ranks[1])
+        ranks[0].p2p_enable(2)
+        with pytest.raises(RuntimeError, match="gave up"):
+            ranks[0].cycles(1, reduce=lambda v: v)     # rank 1 never runs: its READY flag never comes
+        assert ranks[0].p2p_status() == 0              # (cleared by the read above)
+    finally:
+        for r in ranks:
+            r.close()
+
+
+@pytest.mark.parametrize("world,shape,grids,n_dist", [(2, (32, 32, 32), 4, 2), (4, (64, 32, 48), 4, 2)])
+def test_peer_stores_between_processes(tmp_path, world, shape, grids, n_dist):
+    """Real concurrency: one PROCESS per rank (all on this GPU), hipIpc mappings of each other's vectors and flags,
+    gloo only as the control plane.  The iterate must have the bits of the single-GPU cycle."""
+    import os
+    import socket
+    import subprocess
+    import sys
+    A, R, b, x0 = problem(shape, grids)
+    with _hip.Hierarchy(A, R, smoother="colour") as h:
+        h.resident_load(b, x0)
+        want_norms = [h.resident_cycle(1, 1) for _ in range(3)]
+        want = h.resident_fetch()
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "p2p_worker.py")
+    procs = [subprocess.Popen([sys.executable, worker, str(r), str(world), str(port), str(tmp_path), "x".join(map(str, shape)), str(grids), str(n_dist)],
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(world)]
+    for r, p in enumerate(procs):
+        try:
+            o, e = p.communicate(timeout=240)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        assert p.returncode == 0, (r, e[-3000:])
+    got = np.concatenate([np.load(os.path.join(str(tmp_path), "rank%d.npz" % r))["x"] for r in range(world)])
+    assert np.array_equal(got, want), int(np.sum(got != want))
+    for r in range(world):
+        np.testing.assert_allclose(np.load(os.path.join(str(tmp_path), "rank%d.npz" % r))["norms"], want_norms, rtol=1e-13)
