@@ -90,21 +90,26 @@ __device__ __forceinline__ void lds_put(V *p, const P2<V> &v) {
     q.y = v.y;
     *reinterpret_cast<typename VecOf<V>::type *>(p) = q;
 }
+// AUX: the store's cache policy bits (gfx950: 1 = sc0, 2 = nt, 16 = sc1; sc0 | sc1 = written through at system scope)
+template <int AUX = PLANE_STORE_AUX>
 __device__ __forceinline__ void bstore2(__amdgpu_buffer_rsrc_t rs, int off, const P2<double> &v, bool both) {
     if (both) {
         const v2u lo = __builtin_bit_cast(v2u, v.x), hi = __builtin_bit_cast(v2u, v.y);
-        __builtin_amdgcn_raw_buffer_store_b128(v4u{lo.x, lo.y, hi.x, hi.y}, rs, off, 0, PLANE_STORE_AUX);
+        __builtin_amdgcn_raw_buffer_store_b128(v4u{lo.x, lo.y, hi.x, hi.y}, rs, off, 0, AUX);
     } else {
-        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, v.x), rs, off, 0, PLANE_STORE_AUX);
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, v.x), rs, off, 0, AUX);
     }
 }
+template <int AUX = PLANE_STORE_AUX>
 __device__ __forceinline__ void bstore2(__amdgpu_buffer_rsrc_t rs, int off, const P2<float> &v, bool both) {
     if (both) {
-        __builtin_amdgcn_raw_buffer_store_b64(v2u{__builtin_bit_cast(unsigned, v.x), __builtin_bit_cast(unsigned, v.y)}, rs, off, 0, PLANE_STORE_AUX);
+        __builtin_amdgcn_raw_buffer_store_b64(v2u{__builtin_bit_cast(unsigned, v.x), __builtin_bit_cast(unsigned, v.y)}, rs, off, 0, AUX);
     } else {
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v.x), rs, off, 0, PLANE_STORE_AUX);
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v.x), rs, off, 0, AUX);
     }
 }
+constexpr int PEER_PLANES = 3, PEER_CPLANES = 2;   // boundary planes of x / of the coarse right-hand side a neighbour takes (a chunk holds at least four planes)
+constexpr int PEER_AUX = 1 | 16;     // stores into a neighbour's memory: through this GPU's caches, acknowledged when they are out
 template <typename V>
 __device__ __forceinline__ void store2(V *p, const P2<V> &v, bool both) {
     if (both) {
@@ -149,7 +154,7 @@ struct PlaneKArgs {
     double *partials;
     // slab neighbours (PEER kernels; PlanePlan::Peer)
     V *peer_x[2], *peer_bc[2];
-    int peer_shift, peer_cshift, peer_planes, peer_cplanes, zc_lo, zc_hi;
+    int peer_shift, peer_cshift;
     const uint32_t *wait_flag[4];
     uint32_t wait_seq[4];
     int fused_wait;
@@ -251,16 +256,18 @@ __device__ __forceinline__ void peer_wait(const uint32_t *flag, uint32_t seq, ui
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");      // what the flag's writer stored before it: not from this CU's L1 / this XCD's L2
 }
 // the pass's workgroups are counted at its end; the last one tells the neighbours
+// (The stores into the neighbours are write-through — PEER_AUX — so "out" is their acknowledgement: a wait for the
+// wave's outstanding stores, NOT a release fence at system scope, which would also write this XCD's whole L2 back —
+// the pass's own 134 MB of stores — once per workgroup: measured +30 us per pass.)
 __device__ __forceinline__ void peer_done(uint32_t *done, uint32_t n_wg, uint32_t *const (&flag)[2], uint32_t seq) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");      // every thread: its stores into the neighbours' memory are out
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");         // every wave: s_waitcnt vmcnt(0)
     __syncthreads();
     if (threadIdx.x == 0) {
-        const uint32_t before = __hip_atomic_fetch_add(done, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t before = __hip_atomic_fetch_add(done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (before == n_wg - 1) {
             __hip_atomic_store(done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
             for (int i = 0; i < 2; ++i)
-                if (flag[i]) __hip_atomic_store(flag[i], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                if (flag[i]) __hip_atomic_store(flag[i], seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
 }
@@ -369,34 +376,47 @@ __global__ __launch_bounds__(512) void plane_kernel(const PlaneKArgs<V> a) {
         for (int i = 0; i < 4; ++i) peer_wait(a.wait_flag[i], a.wait_seq[i], a.status, a.spin);
     }
     __syncthreads();
-    // the neighbours' vectors (a missing neighbour: an empty range, its stores are dropped)
-    const __amdgpu_buffer_rsrc_t pw0 = __builtin_amdgcn_make_buffer_rsrc(PEER && a.peer_x[0] ? a.peer_x[0] : a.x_new, 0, PEER && a.peer_x[0] ? a.vec_bytes : 0u, 0x00020000);
-    const __amdgpu_buffer_rsrc_t pw1 = __builtin_amdgcn_make_buffer_rsrc(PEER && a.peer_x[1] ? a.peer_x[1] : a.x_new, 0, PEER && a.peer_x[1] ? a.vec_bytes : 0u, 0x00020000);
-    // plane k (uniform) of colour-offset slot `base` (+ lb[l]): to the neighbours whose ghost planes it is
+    // ONE scalar says what this workgroup owes the neighbours (everything else about them is fetched from the
+    // kernel's arguments only in the steps that store there: the loop has no scalar registers to spare, and an
+    // argument it has to re-read costs a scalar-load round trip per step): bit 0 / 1: its chunk holds the slab's
+    // first / last planes and rank - 1 / rank + 1 exists; bits 2 / 3: ... and takes the coarse right-hand side
+    int pside = 0;
+    if (PEER) {
+        const bool lo = z0 < a.z_base + 2 * PEER_CPLANES, hi = z1 > a.z_end - 2 * PEER_CPLANES;    // (a short chunk may be the second of them)
+        pside = (lo && a.peer_x[0] ? 1 : 0) | (hi && a.peer_x[1] ? 2 : 0) | (lo && a.peer_bc[0] ? 4 : 0) | (hi && a.peer_bc[1] ? 8 : 0);
+    }
+    // plane k (uniform) of colour-offset slot `base` (+ lb[l]): to the neighbours whose ghost planes it is.  The
+    // neighbour's buffer descriptor is made HERE, in the few steps that use it (the asm keeps it from being hoisted
+    // out of the loop): kept live over the loop it does not fit the scalar registers any more, moves into vector
+    // registers, and every store becomes a loop over the lanes' "different" descriptors (+5 us per pass).
+    // A missing neighbour: an empty range, its stores are dropped.
     auto peer_store = [&](int k, int base, const P2<V> (&v)[2]) {
-        if (k < a.z_base + a.peer_planes) {
+#pragma unroll
+        for (int side = 0; side < 2; ++side) {
+            const bool hit = side == 0 ? (pside & 1) && k < z0 + PEER_PLANES && k < a.z_base + PEER_PLANES
+                                       : (pside & 2) && k >= z1 - PEER_PLANES && k >= a.z_end - PEER_PLANES;
+            if (!hit) continue;
+            V *px = a.peer_x[side];
+            asm volatile("" : "+s"(px));
+            const __amdgpu_buffer_rsrc_t pw = __builtin_amdgcn_make_buffer_rsrc(px ? px : a.x_new, 0, px ? a.vec_bytes : 0u, 0x00020000);
+            const int sh = side == 0 ? a.peer_shift : -a.peer_shift;
 #pragma unroll
             for (int l = 0; l < 2; ++l)
-                if (vl[l] && vx0) bstore2(pw0, (base + a.peer_shift + lb[l]) * int(sizeof(V)), v[l], vx1);
-        }
-        if (k >= a.z_end - a.peer_planes) {
-#pragma unroll
-            for (int l = 0; l < 2; ++l)
-                if (vl[l] && vx0) bstore2(pw1, (base - a.peer_shift + lb[l]) * int(sizeof(V)), v[l], vx1);
+                if (vl[l] && vx0) bstore2<PEER_AUX>(pw, (base + sh + lb[l]) * int(sizeof(V)), v[l], vx1);
         }
     };
-    int CO_kc = 0;                   // coarse plane (extended slab) of the pending coarse pair
-    auto coarse_store = [&](const v2i &sl, const P2<V> &co, const P2<V> &cx) {
+    int CO_side = 0;                 // the pending coarse pair is also rank - 1's (1) / rank + 1's (2) ghost
+    auto coarse_store = [&](const v2i &sl, const P2<V> &co, const P2<V> &cx, auto PB) {
         if (sl.x >= 0) { a.bc[sl.x] = co.x; if (a.xc) a.xc[sl.x] = cx.x; }
         if (sl.y >= 0) { a.bc[sl.y] = co.y; if (a.xc) a.xc[sl.y] = cx.y; }
-        if (PEER) {
-            if (a.peer_bc[0] && CO_kc < a.zc_lo + a.peer_cplanes) {
-                if (sl.x >= 0) a.peer_bc[0][sl.x + a.peer_cshift] = co.x;
-                if (sl.y >= 0) a.peer_bc[0][sl.y + a.peer_cshift] = co.y;
+        if (PEER && decltype(PB)::value) {
+            if (CO_side & 1) {
+                if (sl.x >= 0) __hip_atomic_store(a.peer_bc[0] + (sl.x + a.peer_cshift), co.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                if (sl.y >= 0) __hip_atomic_store(a.peer_bc[0] + (sl.y + a.peer_cshift), co.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             }
-            if (a.peer_bc[1] && CO_kc >= a.zc_hi - a.peer_cplanes) {
-                if (sl.x >= 0) a.peer_bc[1][sl.x - a.peer_cshift] = co.x;
-                if (sl.y >= 0) a.peer_bc[1][sl.y - a.peer_cshift] = co.y;
+            if (CO_side & 2) {
+                if (sl.x >= 0) __hip_atomic_store(a.peer_bc[1] + (sl.x - a.peer_cshift), co.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                if (sl.y >= 0) __hip_atomic_store(a.peer_bc[1] + (sl.y - a.peer_cshift), co.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             }
         }
     };
@@ -461,7 +481,11 @@ __global__ __launch_bounds__(512) void plane_kernel(const PlaneKArgs<V> a) {
 #define PLANE_STAMP(acc)
 #endif
     // one step; PARC: the parity of s as a type (s0 is even)
-    auto step = [&](auto PARC, const int s) {
+    // PB (PEER kernels): the step may hold planes the neighbours take — only those steps carry the peer stores;
+    // the others are the code of a pass without neighbours
+    static_assert(!(PEER && LA == 2), "the two-step loop has no boundary steps");
+    auto step = [&](auto PARC, const int s, auto PB) {
+        constexpr bool PEER_STEP = PEER && decltype(PB)::value;
         const int par = PARC;                            // (a compile-time constant after inlining when LA == 2)
         const int set = LA == 2 ? par : 0;               // the registers this step's loads arrive in, and its requests go to
         // The step's loads are taken HERE, behind the barrier — not where the compiler would sink the copies
@@ -527,7 +551,7 @@ __global__ __launch_bounds__(512) void plane_kernel(const PlaneKArgs<V> a) {
             if (a.dbg & 2) co_pending = false;
 #endif
             if (co_pending) {
-                coarse_store(SLo, CO, CX);
+                coarse_store(SLo, CO, CX, PB);
                 co_pending = false;
             }
         }
@@ -571,7 +595,6 @@ __global__ __launch_bounds__(512) void plane_kernel(const PlaneKArgs<V> a) {
 #pragma unroll
                 for (int l = 0; l < 2; ++l)
                     if (vl[l] && vx0) bstore2(ws, ((s - 1) * ps + lb[l]) * int(sizeof(V)), XR[1][l], vx1);
-                if (PEER) peer_store(s - 1, (s - 1) * ps, XR[1]);
             }
             PLANE_STAMP(st_B)
             // C: black sweep of plane s - 1, and the residual of the rows it has just relaxed
@@ -617,7 +640,6 @@ __global__ __launch_bounds__(512) void plane_kernel(const PlaneKArgs<V> a) {
 #pragma unroll
                 for (int l = 0; l < 2; ++l)
                     if (vl[l] && vx0) bstore2(ws, (a.nr + (s - 2) * ps + lb[l]) * int(sizeof(V)), XB[3][l], vx1);
-                if (PEER) peer_store(s - 2, a.nr + (s - 2) * ps, XB[3]);
             }
             PLANE_STAMP(st_C)
             // D: residual of the red rows of plane s - 2
@@ -655,7 +677,8 @@ __global__ __launch_bounds__(512) void plane_kernel(const PlaneKArgs<V> a) {
                     if (inner && s - 2 >= z0 && s - 2 < z1) {
                         CO = ACC;
                         SLo = SLd;
-                        CO_kc = ((s - 2) >> 1) + a.kc_off;
+                        if (PEER) CO_side = (((pside & 4) && s - 2 < z0 + 2 * PEER_CPLANES && s - 2 < a.z_base + 2 * PEER_CPLANES) ? 1 : 0) |
+                                            (((pside & 8) && s - 2 >= z1 - 2 * PEER_CPLANES && s - 2 >= a.z_end - 2 * PEER_CPLANES) ? 2 : 0);
                         // the coarse level's first relaxation of a zero iterate, spelled like row_epilogue's
                         CX.x = (a.cdiag && SLd.x >= 0 && SLd.x < a.first_end) ? V(0) + (ACC.x - V(0)) / DG.x : V(0);
                         CX.y = (a.cdiag && SLd.y >= 0 && SLd.y < a.first_end) ? V(0) + (ACC.y - V(0)) / DG.y : V(0);
@@ -692,17 +715,23 @@ __global__ __launch_bounds__(512) void plane_kernel(const PlaneKArgs<V> a) {
                 lds_put(W3 + idx[l], XB[2][l]);
             }
         }
+        if (PEER_STEP && inner && (((pside & 1) && s < z0 + PEER_PLANES + 2) || ((pside & 2) && s >= z1 - PEER_PLANES + 1))) {
+            // (ONE uniform branch per step, taken by the few steps that hold a neighbour's ghost planes: red of
+            // plane s - 1 and black of plane s - 2, final since the previous step and still in their registers)
+            if (s - 1 >= z0 && s - 1 < z1) peer_store(s - 1, (s - 1) * ps, XR[1]);
+            if (s - 2 >= z0 && s - 2 < z1) peer_store(s - 2, a.nr + (s - 2) * ps, XB[3]);
+        }
         PLANE_STAMP(st_cmp)
         __syncthreads();
         PLANE_STAMP(st_bar)
     };
     if (LA == 2) {
         for (int s = s0; s <= z1 + 1; s += 2) {          // s0 even, z1 + 1 odd: whole pairs of steps
-            step(std::integral_constant<int, 0>(), s);
-            step(std::integral_constant<int, 1>(), s + 1);
+            step(std::integral_constant<int, 0>(), s, std::false_type());
+            step(std::integral_constant<int, 1>(), s + 1, std::false_type());
         }
     } else {
-        for (int s = s0; s <= z1 + 1; ++s) step(s & 1, s);
+        for (int s = s0; s <= z1 + 1; ++s) step(s & 1, s, std::integral_constant<bool, PEER>());
     }
 #ifdef OMG_PLANE_STAMPS
     if ((t & 63) == 0) {
@@ -710,7 +739,7 @@ __global__ __launch_bounds__(512) void plane_kernel(const PlaneKArgs<V> a) {
         o[0] = st_mem; o[1] = st_cmp; o[2] = st_bar; o[3] = unsigned(z1 + 2 - s0); o[4] = st_top; o[5] = st_B; o[6] = st_C;
     }
 #endif
-    if (MODE == 0 && co_pending) coarse_store(SLo, CO, CX);
+    if (MODE == 0 && co_pending) coarse_store(SLo, CO, CX, std::true_type());
     if (NORM) {
         // fixed order: lanes of a wave (shuffle tree), then the waves in turn
 #pragma unroll
@@ -1055,7 +1084,7 @@ template <typename V>
 void peer_args(PlaneKArgs<V> &k, const typename PlanePlan<V>::Peer &p, hipStream_t s) {
     for (int i = 0; i < 2; ++i) { k.peer_x[i] = p.x[i]; k.peer_bc[i] = p.bc[i]; k.peer_flag[i] = p.flag[i]; }
     k.peer_shift = int(p.shift); k.peer_cshift = int(p.cshift);
-    k.peer_planes = p.planes; k.peer_cplanes = p.cplanes; k.zc_lo = p.zc_lo; k.zc_hi = p.zc_hi;
+    OMG_REQUIRE(p.planes == PEER_PLANES && (p.cplanes == PEER_CPLANES || (!p.bc[0] && !p.bc[1])), "plane pass with neighbours: three planes of x, two of the coarse right-hand side");
     for (int i = 0; i < 4; ++i) { k.wait_flag[i] = p.wait_flag[i]; k.wait_seq[i] = p.wait_seq[i]; }
     k.fused_wait = p.fused_wait ? 1 : 0;
     k.done = p.done; k.flag_seq = p.seq; k.status = p.status; k.spin = p.spin;

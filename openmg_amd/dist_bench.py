@@ -79,6 +79,56 @@ def main_plane(args, rank, world, shape, grids, n_levels, all_gather, td, torch,
     first_norm = preflight.run(rank, world, lambda: r.cycles(1)[0], all_gather, min(120.0, max(20.0, args.watchdog / 4.0)),
                                where=lambda: "cycle %d, level %d, last completed phase: %s" % r.progress())
     r.trace(False)
+    # Peer mode (xGMI peer stores fused into the passes, no exchange launches): tried when every level has four planes
+    # per rank, kept only if EVERY rank could map every other rank's buffers and one checked cycle from the same start
+    # gives the norm the RCCL cycle gave; otherwise the RCCL exchanges stay.  OMG_DIST_P2P=0: not tried; =1: tried
+    # with one rank too.
+    exchange = "RCCL grouped send/recv of ghost planes"
+    p2p_note = "not tried"
+    want = os.environ.get("OMG_DIST_P2P", "auto")
+    if want != "0" and (world > 1 or want == "1") and all((shape[0] >> l) // world >= 4 for l in range(n_levels)):
+        def agree(ok):
+            return all(all_gather(bool(ok)))
+        try:
+            mine = r.p2p_handles()
+        except Exception as e:                                  # noqa: BLE001 - any failure means "stay with RCCL"
+            mine, p2p_note = None, "export failed on rank %d: %s" % (rank, e)
+        handles = all_gather(mine)
+        ok = all(h is not None for h in handles)
+        if ok:
+            try:
+                for peer in range(world):
+                    if peer != rank:
+                        r.p2p_open(peer, handles[peer])
+                r.p2p_enable(1)
+            except Exception as e:                              # noqa: BLE001
+                ok, p2p_note = False, "mapping failed on rank %d: %s" % (rank, e)
+        if agree(ok):
+            r.load(b_loc)
+            try:
+                r.trace(True)
+                peer_norm = preflight.run(rank, world, lambda: r.cycles(1)[0], all_gather, min(120.0, max(20.0, args.watchdog / 4.0)),
+                                          where=lambda: "peer mode, cycle %d, level %d, last completed phase: %s" % r.progress())
+                r.trace(False)
+                ok = abs(peer_norm - first_norm) <= 1e-12 * abs(first_norm)
+                if not ok:
+                    p2p_note = "norm after one cycle %.17g, RCCL cycle gave %.17g" % (peer_norm, first_norm)
+            except RuntimeError as e:
+                ok, p2p_note = False, str(e)
+            if agree(ok):
+                exchange = "peer stores into the neighbours' ghost planes (xGMI), flags, no exchange launches"
+                p2p_note = "checked against the RCCL cycle: same norm on every rank"
+            else:
+                r.p2p_enable(0)
+                notes = [n for n in all_gather(p2p_note) if n != "not tried"]
+                p2p_note = "rejected: " + (notes[0] if notes else "another rank failed")
+        else:
+            r.p2p_enable(0)
+            notes = [n for n in all_gather(p2p_note) if n != "not tried"]
+            p2p_note = "unavailable: " + (notes[0] if notes else "another rank failed")
+        # the same start for the timed run whatever was tried
+        r.load(b_loc)
+        r.cycles(1)
     for _ in range(args.warmup):
         r.cycles(1)
     times = []
@@ -112,10 +162,11 @@ def main_plane(args, rank, world, shape, grids, n_levels, all_gather, td, torch,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": "3-D 7-point Poisson %s, %d-grid V(1,1) cycle, red-black Gauss-Seidel, fp64, 1-D slabs over %d GPUs: "
-                                   "plane-pipelined passes on slabs with ghost planes, RCCL exchanges of whole planes"
+                                   "plane-pipelined passes on slabs with ghost planes, whole ghost planes exchanged"
                                    % ("x".join(map(str, shape)), grids, world),
                        "unknowns": n_glob, "unknowns_per_gpu": n_loc, "nnz_per_gpu": nnz_loc, "grids": grids,
                        "distributed_grids": n_levels, "replicated_tail_grids": tgrids, "runner": "plane slabs (omg_pdist)",
+                       "exchange": exchange, "peer_mode": p2p_note,
                        "rccl_ranks": rccl_ranks, "repeats": len(times), "preflight_norm": first_norm,
                        "kernel_src_sha": src_sha, "git_head": head,
                        "ms_per_step_all": [round(1e3 * t / args.steps, 4) for t in times],

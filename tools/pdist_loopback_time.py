@@ -1,6 +1,7 @@
 """Per-rank device time of the plane-slab cycle at the --gpus N bench shape, measured on ONE GPU: all N slabs in a
 loopback group on one stream (exchanges are device copies), time / N.  What is left to add for N GPUs is the
 exchange latency (tools/exchange_probe.py), not device work."""
+import os
 import sys
 import time
 
@@ -23,7 +24,7 @@ def main():
             d = _hip_dist.PlaneDistRank(r, world, shape, coef, 0.125, _hip.Hierarchy(At, Rt, smoother="colour"))
             d.load(b[r * per:(r + 1) * per])
             ranks.append(d)
-        g = _hip_dist.PlaneDistGroup(ranks)
+        g = _hip_dist.PlaneDistGroup(ranks, p2p=int(os.environ.get("OMG_LOOPBACK_P2P", "0")))
         g.cycles(3)
         t = time.perf_counter()
         n = 20
