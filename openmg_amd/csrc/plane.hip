@@ -293,8 +293,12 @@ __global__ void plane_wait_kernel(const uint32_t *f0, const uint32_t *f1, const 
 // LA: how many steps ahead a step's loads are requested (2: two sets of registers in flight — the vector
 // memory pipe then streams while a step computes and waits at its barrier; the loop runs two steps per
 // iteration so that every register has a fixed role and the step's parity is a compile-time constant).
-template <typename V, int MODE, bool NORM, bool XZ, int LA, bool PEER = false>
-__global__ __launch_bounds__(512) void plane_kernel(const PlaneKArgs<V> a) {
+// MAXT: the largest workgroup the instantiation is launched with (small tiles: more registers per lane, which LA = 2 needs)
+template <typename V, int MODE, bool NORM, bool XZ, int LA, bool PEER = false, int MAXT = 512>
+__global__ __launch_bounds__(MAXT) void plane_kernel(const PlaneKArgs<V> a) {
+#ifdef OMG_PLANE_STAMPS
+    const unsigned long long st_entry = __builtin_amdgcn_s_memtime();
+#endif
     extern __shared__ __attribute__((aligned(16))) unsigned char plane_smem[];
     V *const lds = reinterpret_cast<V *>(plane_smem);
     __shared__ double s_red[8];
@@ -737,6 +741,7 @@ __global__ __launch_bounds__(512) void plane_kernel(const PlaneKArgs<V> a) {
     if ((t & 63) == 0) {
         unsigned long long *o = a.stamps + (size_t(blockIdx.x) * 8 + (t >> 6)) * 8;
         o[0] = st_mem; o[1] = st_cmp; o[2] = st_bar; o[3] = unsigned(z1 + 2 - s0); o[4] = st_top; o[5] = st_B; o[6] = st_C;
+        o[7] = __builtin_amdgcn_s_memtime() - st_entry;
     }
 #endif
     if (MODE == 0 && co_pending) coarse_store(SLo, CO, CX, std::true_type());
@@ -753,6 +758,198 @@ __global__ __launch_bounds__(512) void plane_kernel(const PlaneKArgs<V> a) {
         }
     }
     if (PEER) peer_done(a.done, gridDim.x, a.peer_flag, a.flag_seq);
+}
+
+// ---- small levels: a block of the grid per workgroup, whole in LDS ----------------------------------------------
+// A level of <= 64^3 cells is pure latency for the marching kernel above: LZ + 4 = 6 dependent steps of one wave each
+// (load round trip, red chain -> black chain -> residual chain, barrier), 12-15 us per pass whatever the size
+// (profiles/r03_small_levels.txt).  Here a workgroup takes a BX x BY x BZ block with a ring of two cells, loads it
+// ONCE (all its loads in flight together), and walks the pass's stages over the whole block at a time:
+//   down (the level's iterate is zero: every level below the finest on the way down): red sweep on block + 2,
+//        black sweep on block + 1, residual on the block, the eight residuals of a coarse cell -> coarse b;
+//   up:  x + w e on block + 2, red sweep on block + 1, black sweep on the block.
+// The ring is relaxed redundantly (same operations on the same operands as the owning block: same bits); every
+// row is the marching kernel's chain — slots -K, -J, -I, diagonal, +I, +J, +K from +0, x + (b - s) / a_ii, cells
+// outside the grid as zeros — so the two kernels are interchangeable bit for bit (tests/test_gpu_plane.py).
+template <typename V>
+struct BlockKArgs {
+    const V *x_old;
+    V *x_new;
+    const V *b;
+    int nx, ny, nz, nr;
+    int nbx, nby;
+    V c0, c1, c2, c3, c4, c5, c6, w;
+    int fast_div;
+    int nxc, nyc;
+    const int32_t *cmap;
+    V *bc;
+    const V *ec;
+};
+
+__device__ __forceinline__ double block_quotient(double n, double c, double r, bool fast) {
+    if (fast && plain_numerator(n)) {
+        const double q0 = n * r;
+        return fma(fma(-c, q0, n), r, q0);
+    }
+    return n / c;
+}
+__device__ __forceinline__ float block_quotient(float n, float c, float, bool) { return n / c; }
+
+// BX, BY, BZ as template parameters: every index of the stages is then a division by a constant and every loop has a
+// known trip count (with run-time block extents the integer divisions alone cost more than the marching kernel)
+template <typename V, int MODE, int BX, int BY, int BZ>
+__global__ __launch_bounds__(256) void block_kernel(const BlockKArgs<V> a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char plane_smem[];
+    constexpr int EX = BX + 4, EY = BY + 4, EZ = BZ + 4, vol = EX * EY * EZ;
+    constexpr int NT = vol >= 1024 ? 256 : 128;       // the launch's workgroup size (choose_block)
+    V *const X = reinterpret_cast<V *>(plane_smem);
+    V *const B = X + vol;
+    V *const E = B + vol;                             // up: the coarse correction under the block + 2 region; down: the block's residuals
+    const int t = int(threadIdx.x);
+    const int bi = int(blockIdx.x) % a.nbx, bj = (int(blockIdx.x) / a.nbx) % a.nby, bk = int(blockIdx.x) / (a.nbx * a.nby);
+    const int i0 = bi * BX - 2, j0 = bj * BY - 2, k0 = bk * BZ - 2;            // grid coordinates of LDS cell (0, 0, 0): even
+    constexpr int CX = EX / 2, CY = EY / 2, CZ = EZ / 2;                      // coarse cells under the LDS region
+    constexpr int hx = BX / 2, hy = BY / 2, hz = BZ / 2;                      // ... under the block
+    const int ci0 = i0 >> 1, cj0 = j0 >> 1, ck0 = k0 >> 1;
+    const int nzc = a.nz >> 1;
+    const V rc3 = refined_rcp(a.c3);
+    const bool fast = a.fast_div != 0;
+    auto slot_of = [&](int gi, int gj, int gk) { return (((gi + gj + gk) & 1) ? a.nr : 0) + (((gk * a.ny + gj) * a.nx + gi) >> 1); };
+    auto in_grid = [&](int gi, int gj, int gk) { return gi >= 0 && gi < a.nx && gj >= 0 && gj < a.ny && gk >= 0 && gk < a.nz; };
+
+    // ALL the block's loads are requested before the first one is used (a load per loop iteration with its consumer
+    // in the same iteration is a memory round trip per iteration: 11 of them for a 16 x 8 x 8 block)
+    constexpr int NL = (vol + NT - 1) / NT, NC = MODE == 1 ? (CX * CY * CZ + NT - 1) / NT : (hx * hy * hz + NT - 1) / NT;
+    int cs[NC];                                      // coarse slots: up: of the cells under block + 2; down: of the block's coarse cells
+#pragma unroll
+    for (int n = 0; n < NC; ++n) {
+        const int c = t + n * NT;
+        int I, J, K;
+        bool ok;
+        if (MODE == 1) {
+            I = ci0 + c % CX; J = cj0 + (c / CX) % CY; K = ck0 + c / (CX * CY);
+            ok = c < CX * CY * CZ && I >= 0 && J >= 0 && K >= 0;
+        } else {
+            I = (bi * BX >> 1) + c % hx; J = (bj * BY >> 1) + (c / hx) % hy; K = (bk * BZ >> 1) + c / (hx * hy);
+            ok = c < hx * hy * hz;
+        }
+        ok = ok && I < a.nxc && J < a.nyc && K < nzc;
+        const int ce = (K * a.nyc + J) * a.nxc + I;
+        cs[n] = ok ? (a.cmap ? a.cmap[ce] : ce) : -1;
+    }
+    V xv[NL], bv[NL];
+#pragma unroll
+    for (int n = 0; n < NL; ++n) {
+        const int c = t + n * NT;
+        const int gi = i0 + c % EX, gj = j0 + (c / EX) % EY, gk = k0 + c / (EX * EY);
+        const bool ok = c < vol && in_grid(gi, gj, gk);
+        const int slot = ok ? slot_of(gi, gj, gk) : 0;
+        bv[n] = a.b[slot];
+        xv[n] = MODE == 1 ? a.x_old[slot] : V(0);
+        if (!ok) { bv[n] = V(0); xv[n] = V(0); }      // cells outside the grid are zeros and stay so
+    }
+    if (MODE == 1) {
+        V ev[NC];
+#pragma unroll
+        for (int n = 0; n < NC; ++n) ev[n] = a.ec[cs[n] >= 0 ? cs[n] : 0];
+#pragma unroll
+        for (int n = 0; n < NC; ++n)
+            if (t + n * NT < CX * CY * CZ) E[t + n * NT] = cs[n] >= 0 ? ev[n] : V(0);
+    }
+#pragma unroll
+    for (int n = 0; n < NL; ++n)
+        if (t + n * NT < vol) { X[t + n * NT] = xv[n]; B[t + n * NT] = bv[n]; }
+    __syncthreads();
+    if (MODE == 1) {
+        // openmg/__init__.py:214,220: x + R^T e — the product rounded, then added
+#pragma unroll
+        for (int n = 0; n < NL; ++n) {
+            const int c = t + n * NT;
+            const int li = c % EX, lj = (c / EX) % EY, lk = c / (EX * EY);
+            if (c < vol && in_grid(i0 + li, j0 + lj, k0 + lk))
+                X[c] = xv[n] + madd(a.w, E[((lk >> 1) * CY + (lj >> 1)) * CX + (li >> 1)], V(0));
+        }
+        __syncthreads();
+    }
+    auto row = [&](int c) -> V {
+        V s = madd(a.c0, X[c - EX * EY], V(0));
+        s = madd(a.c1, X[c - EX], s);
+        s = madd(a.c2, X[c - 1], s);
+        s = madd(a.c3, X[c], s);
+        s = madd(a.c4, X[c + 1], s);
+        s = madd(a.c5, X[c + EX], s);
+        return madd(a.c6, X[c + EX * EY], s);
+    };
+    // cells of one colour inside the block widened by RING, clipped to the grid
+    auto sweep = [&](int colour, auto RING, auto FROM_ZERO) {
+        constexpr int ring = decltype(RING)::value;
+        constexpr int wx = BX + 2 * ring, wy = BY + 2 * ring, wz = BZ + 2 * ring, off = 2 - ring;
+        // a thread takes PAIRS of cells along x and relaxes the one of the sweep's colour
+        constexpr int np = wx / 2 * wy * wz, NI = (np + NT - 1) / NT;
+#pragma unroll
+        for (int n = 0; n < NI; ++n) {
+            const int p = t + n * NT;
+            const int pj = (p / (wx / 2)) % wy, pk = p / (wx / 2 * wy);
+            const int lj = off + pj, lk = off + pk;
+            // off + i0 + j + k parity: i0, j0, k0 are even, so the grid parity is the local one
+            const int li = off + 2 * (p % (wx / 2)) + ((off + lj + lk + colour) & 1);
+            const int gi = i0 + li, gj = j0 + lj, gk = k0 + lk;
+            if (p >= np || !in_grid(gi, gj, gk)) continue;
+            const int l = (lk * EY + lj) * EX + li;
+            // (FROM_ZERO: the first sweep of a zero iterate — the chain over zeros is +0 exactly, and the region's
+            // outermost cells have no neighbours in LDS to read)
+            const V sum = decltype(FROM_ZERO)::value ? V(0) : row(l);
+            // openmg/solvers.py:68   x[i] = x[i] + (b[i] - Aix) / A[i, i]
+            X[l] = X[l] + block_quotient(B[l] - sum, a.c3, rc3, fast);
+        }
+    };
+    typedef std::integral_constant<int, 0> R0;
+    typedef std::integral_constant<int, 1> R1;
+    typedef std::integral_constant<int, 2> R2;
+    constexpr int NB = (BX * BY * BZ + NT - 1) / NT;
+    if (MODE == 0) {
+        sweep(0, R2(), std::true_type());
+        __syncthreads();
+        sweep(1, R1(), std::false_type());
+        __syncthreads();
+        // the block's cells: the new iterate out, the residual kept for the restriction
+#pragma unroll
+        for (int n = 0; n < NB; ++n) {
+            const int c = t + n * NT;
+            const int li = 2 + c % BX, lj = 2 + (c / BX) % BY, lk = 2 + c / (BX * BY);
+            const int gi = i0 + li, gj = j0 + lj, gk = k0 + lk;
+            if (c >= BX * BY * BZ || gi >= a.nx || gj >= a.ny || gk >= a.nz) continue;
+            const int l = (lk * EY + lj) * EX + li;
+            E[c] = B[l] - row(l);
+            a.x_new[slot_of(gi, gj, gk)] = X[l];
+        }
+        __syncthreads();
+        // openmg/__init__.py:210: a coarse cell's eight fine residuals in column order
+#pragma unroll
+        for (int n = 0; n < NC; ++n) {
+            const int c = t + n * NT;
+            if (cs[n] < 0) continue;
+            const int I = c % hx, J = (c / hx) % hy, K = c / (hx * hy);
+            V acc = V(0);
+#pragma unroll
+            for (int d = 0; d < 8; ++d)
+                acc = madd(a.w, E[((2 * K + (d >> 2)) * BY + 2 * J + ((d >> 1) & 1)) * BX + 2 * I + (d & 1)], acc);
+            a.bc[cs[n]] = acc;
+        }
+    } else {
+        sweep(0, R1(), std::false_type());
+        __syncthreads();
+        sweep(1, R0(), std::false_type());
+        __syncthreads();
+#pragma unroll
+        for (int n = 0; n < NB; ++n) {
+            const int c = t + n * NT;
+            const int li = 2 + c % BX, lj = 2 + (c / BX) % BY, lk = 2 + c / (BX * BY);
+            const int gi = i0 + li, gj = j0 + lj, gk = k0 + lk;
+            if (c >= BX * BY * BZ || gi >= a.nx || gj >= a.ny || gk >= a.nz) continue;
+            a.x_new[slot_of(gi, gj, gk)] = X[(lk * EY + lj) * EX + li];
+        }
+    }
 }
 
 // ---- host: does the level qualify, and how is it tiled -----------------------------------------------
@@ -1059,13 +1256,16 @@ inline void stamps_end(const char *what, const PlaneGeom &g, DevBuf<unsigned lon
     OMG_HIP(hipStreamSynchronize(s));
     std::vector<unsigned long long> hst(buf.n);
     OMG_HIP(hipMemcpy(hst.data(), buf.p, buf.n * 8, hipMemcpyDeviceToHost));
-    double m = 0, c = 0, b = 0, steps = 0, tp = 0, sB = 0, sC = 0;
+    double m = 0, c = 0, b = 0, steps = 0, tp = 0, sB = 0, sC = 0, tot = 0, nw = 0;
     const int waves = g.threads / 64;
     for (int w = 0; w < g.n_wg; ++w)
         for (int v = 0; v < waves; ++v) {
             const unsigned long long *o = &hst[(size_t(w) * 8 + v) * 8];
             m += o[0]; c += o[1]; b += o[2]; steps += o[3]; tp += o[4]; sB += o[5]; sC += o[6];
+            tot += o[7]; nw += 1;
         }
+    fprintf(stderr, "[plane stamps] %-5s ... per wave: %.1f steps, %.0f cycles entry to last step's end, %.0f of them outside the steps (100 MHz counter)\n",
+            what, steps / nw, tot / nw, (tot - m - c - b - tp - sB - sC) / nw);
     fprintf(stderr, "[plane stamps] %-5s n %dx%dx%d wg %d thr %d: cycles per step and wave: wait-for-loads %.0f | top (shift, issue loads + stores) %.0f | B %.0f | C %.0f | D + rest %.0f | barrier %.0f\n",
             what, g.nx, g.ny, g.nz, g.n_wg, g.threads, m / steps, tp / steps, sB / steps, sC / steps, c / steps, b / steps);
 }
@@ -1096,6 +1296,67 @@ void peer_args(PlaneKArgs<V> &k, const typename PlanePlan<V>::Peer &p, hipStream
     }
 }
 
+// small levels (whole grids of at most 64^3 cells): block_kernel
+struct BlockGeom {
+    int shape, BX, BY, BZ, nbx, nby, nbz, threads;
+    size_t lds;
+};
+inline bool block_level(const PlaneGeom &g) {
+    static const int on = [] { const char *e = getenv("OMG_PLANE_BLOCK"); return e ? atoi(e) : 1; }();
+    return on && g.z_base == 0 && g.z_end == g.nz && g.kv0 == 0 && g.kv1 == g.nz && int64_t(g.nx) * g.ny * g.nz <= int64_t(64) * 64 * 64;
+}
+// the block extents block_kernel is instantiated for, largest first
+constexpr int BLOCK_SHAPES[4][3] = {{16, 8, 8}, {8, 8, 8}, {8, 4, 4}, {4, 4, 4}};
+inline BlockGeom choose_block(const PlaneGeom &g, size_t value_bytes) {
+    BlockGeom k;
+    int pick = 3;
+    // enough workgroups to spread over the chip, from the largest block (least ring per cell) down
+    for (int i = 0; i < 4; ++i) {
+        const int64_t n = int64_t((g.nx + BLOCK_SHAPES[i][0] - 1) / BLOCK_SHAPES[i][0]) * ((g.ny + BLOCK_SHAPES[i][1] - 1) / BLOCK_SHAPES[i][1]) *
+                          ((g.nz + BLOCK_SHAPES[i][2] - 1) / BLOCK_SHAPES[i][2]);
+        if (n >= 128) { pick = i; break; }
+    }
+    k.shape = pick;
+    k.BX = BLOCK_SHAPES[pick][0]; k.BY = BLOCK_SHAPES[pick][1]; k.BZ = BLOCK_SHAPES[pick][2];
+    k.nbx = (g.nx + k.BX - 1) / k.BX; k.nby = (g.ny + k.BY - 1) / k.BY; k.nbz = (g.nz + k.BZ - 1) / k.BZ;
+    const size_t vol = size_t(k.BX + 4) * size_t(k.BY + 4) * size_t(k.BZ + 4);
+    k.threads = vol >= 1024 ? 256 : 128;
+    k.lds = (2 * vol + std::max(size_t(k.BX) * k.BY * k.BZ, vol / 8)) * value_bytes;
+    return k;
+}
+template <typename V, int MODE, int S>
+void launch_block_shape(const BlockGeom &k, const BlockKArgs<V> &a, hipStream_t s) {
+    auto kernel = block_kernel<V, MODE, BLOCK_SHAPES[S][0], BLOCK_SHAPES[S][1], BLOCK_SHAPES[S][2]>;
+    allow_lds(kernel, k.lds);
+    hipLaunchKernelGGL(kernel, dim3(unsigned(k.nbx * k.nby * k.nbz)), dim3(unsigned(k.threads)), k.lds, s, a);
+}
+template <typename V, int MODE>
+void launch_block(const PlaneGeom &g, const V *x_old, V *x_new, const V *b, const typename PlanePlan<V>::Coarse &c, hipStream_t s) {
+    const BlockGeom k = choose_block(g, sizeof(V));
+    BlockKArgs<V> a;
+    std::memset(&a, 0, sizeof(a));
+    a.x_old = x_old; a.x_new = x_new; a.b = b;
+    a.nx = g.nx; a.ny = g.ny; a.nz = g.nz; a.nr = int(int64_t(g.nx) * g.ny * g.nz / 2);
+    a.nbx = k.nbx; a.nby = k.nby;
+    a.c0 = V(g.c[0]); a.c1 = V(g.c[1]); a.c2 = V(g.c[2]); a.c3 = V(g.c[3]); a.c4 = V(g.c[4]); a.c5 = V(g.c[5]); a.c6 = V(g.c[6]);
+    a.w = V(g.w);
+    a.fast_div = (std::fabs(g.c[3]) >= 0x1p-400 && std::fabs(g.c[3]) <= 0x1p400) ? 1 : 0;
+    a.nxc = g.nx / 2; a.nyc = g.ny / 2;
+    a.cmap = c.map; a.bc = c.b; a.ec = c.e;
+    switch (k.shape) {
+        case 0: launch_block_shape<V, MODE, 0>(k, a, s); break;
+        case 1: launch_block_shape<V, MODE, 1>(k, a, s); break;
+        case 2: launch_block_shape<V, MODE, 2>(k, a, s); break;
+        default: launch_block_shape<V, MODE, 3>(k, a, s); break;
+    }
+    OMG_HIP(hipGetLastError());
+}
+
+inline bool small_tile(const PlaneGeom &g) {
+    static const int on = [] { const char *e = getenv("OMG_PLANE_LA2"); return e ? atoi(e) : 1; }();
+    return on && g.threads <= 128;
+}
+
 template <typename K, typename V>
 void launch_plane(K kernel, const PlaneGeom &g, const PlaneKArgs<V> &k, hipStream_t s) {
     allow_lds(kernel, g.lds_bytes);
@@ -1111,10 +1372,16 @@ void PlanePlan<V>::down(const V *x_old, V *x_new, const V *b, bool x_zero, const
     DevBuf<unsigned long long> sb;
     stamps_begin(k, g, sb);
 #endif
-    if (peer) {
+    if (!peer && x_zero && !c.x && !c.diag && block_level(g)) {
+        launch_block<V, 0>(g, x_old, x_new, b, c, s);
+    } else if (peer) {
         peer_args<V>(k, *peer, s);
         if (x_zero) launch_plane(plane_kernel<V, 0, false, true, PLANE_LA, true>, g, k, s);
         else launch_plane(plane_kernel<V, 0, false, false, PLANE_LA, true>, g, k, s);
+    } else if (small_tile(g)) {
+        // latency-bound small levels: loads two steps ahead (the registers are there for workgroups this small)
+        if (x_zero) launch_plane(plane_kernel<V, 0, false, true, 2, false, 128>, g, k, s);
+        else launch_plane(plane_kernel<V, 0, false, false, 2, false, 128>, g, k, s);
     } else if (x_zero) {
         launch_plane(plane_kernel<V, 0, false, true, PLANE_LA>, g, k, s);
     } else {
@@ -1133,10 +1400,14 @@ void PlanePlan<V>::up(const V *x_old, V *x_new, const V *b, const Coarse &c, dou
     DevBuf<unsigned long long> sb;
     stamps_begin(k, g, sb);
 #endif
-    if (peer) {
+    if (!peer && !out && block_level(g)) {
+        launch_block<V, 1>(g, x_old, x_new, b, c, s);
+    } else if (peer) {
         peer_args<V>(k, *peer, s);
         if (out) launch_plane(plane_kernel<V, 1, true, false, PLANE_LA, true>, g, k, s);
         else launch_plane(plane_kernel<V, 1, false, false, PLANE_LA, true>, g, k, s);
+    } else if (small_tile(g) && !out) {
+        launch_plane(plane_kernel<V, 1, false, false, 2, false, 128>, g, k, s);
     } else if (out) {
         launch_plane(plane_kernel<V, 1, true, false, PLANE_LA>, g, k, s);
     } else {
