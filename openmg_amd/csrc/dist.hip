@@ -1364,6 +1364,19 @@ std::unique_ptr<PlaneDist> pd_create(int rank, int n_ranks, int nx, int ny, int 
     *d->progress = 0;
     d->nat.alloc(size_t(int64_t(nx) * ny * (nz_global / n_ranks)));
     OMG_HIP(hipStreamSynchronize(d->stream));
+    {
+        // the finest slab's tiling: measured on its own (zero) vectors
+        PDLevel &L = d->lv[0];
+        const bool last = n_levels == 1;
+        PlanePlan<double>::Coarse c;
+        c.map = last ? nullptr : L.cmap.p;
+        c.b = last ? d->cb.p : d->lv[1].b.p;
+        c.e = last ? d->ce.p : d->lv[1].xp;
+        L.plan.tune(L.xp, L.tp, L.b.p, c, d->stream);
+        L.x.zero(d->stream); L.tmp.zero(d->stream);
+        if (last) d->cb.zero(d->stream); else d->lv[1].b.zero(d->stream);
+        OMG_HIP(hipStreamSynchronize(d->stream));
+    }
     return d;
 }
 

@@ -735,7 +735,18 @@ __global__ __launch_bounds__(MAXT) void plane_kernel(const PlaneKArgs<V> a) {
             step(std::integral_constant<int, 1>(), s + 1, std::false_type());
         }
     } else {
-        for (int s = s0; s <= z1 + 1; ++s) step(s & 1, s, std::integral_constant<bool, PEER>());
+        if (MODE == 1 && !PEER) {
+            // two steps per iteration: the step's parity — which neighbour an in-line pair takes, which coarse plane
+            // a fine one lies over — is a compile-time constant in each copy (s0 is even, the step count too): 9 us of
+            // 124 for the fine level's up pass.  (The down pass and the passes with neighbours run out of registers
+            // that way: 20-100 bytes of scratch per lane and +16 us.)
+            for (int s = s0; s <= z1 + 1; s += 2) {
+                step(std::integral_constant<int, 0>(), s, std::false_type());
+                step(std::integral_constant<int, 1>(), s + 1, std::false_type());
+            }
+        } else {
+            for (int s = s0; s <= z1 + 1; ++s) step(s & 1, s, std::integral_constant<bool, PEER>());
+        }
     }
 #ifdef OMG_PLANE_STAMPS
     if ((t & 63) == 0) {
@@ -961,7 +972,12 @@ int env_int3(const char *name, int out[3]) {
 
 inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
-void choose_tiles(PlaneGeom &g, size_t value_bytes) {
+// model 0: one workgroup per CU, cost ~ rounds x steps x (threads + a fixed per-step price).
+// model 1: the CU's four SIMDs evenly loaded — a workgroup of 6 waves costs a step what one of 8 does (two of its
+// SIMDs carry two waves), and several small workgroups share a CU.  Neither predicts the other's winner
+// (256^3: 64 x 32 x 32 at 132 us against 128 x 22 x 26 at 122 us per down pass; other shapes the other way):
+// PlanePlan::tune() times both on the level's own vectors.
+void choose_tiles(PlaneGeom &g, size_t value_bytes, int model = 0) {
     const int nzo = g.z_end - g.z_base;             // planes the launch relaxes
     auto set = [&](int TX, int TY, int LZ) {
         g.TX = TX; g.TY = TY; g.LZ = LZ;
@@ -994,8 +1010,18 @@ void choose_tiles(PlaneGeom &g, size_t value_bytes) {
             for (int ntz = 1; ntz <= nzo / 2; ++ntz) {
                 const int LZ = round_up((nzo + ntz - 1) / ntz, 2);
                 if ((nzo + LZ - 1) / LZ != ntz) continue;
-                const double rounds = std::ceil(double(ntx) * nty * ntz / 256.0);
-                const double cost = rounds * (LZ + 4) * (thr + 192.0);
+                double cost;
+                if (model == 0) {
+                    const double rounds = std::ceil(double(ntx) * nty * ntz / 256.0);
+                    cost = rounds * (LZ + 4) * (thr + 192.0);
+                } else {
+                    const int waves = thr / 64;
+                    const size_t lds = size_t(6) * size_t(TY + 10) * size_t(TX / 2 + 8) * value_bytes;
+                    const int per_cu = std::max(1, std::min(8 / waves, int(size_t(160) * 1024 / lds)));
+                    const int simd = (waves * per_cu + 3) / 4;
+                    const double rounds = std::ceil(double(ntx) * nty * ntz / (256.0 * per_cu));
+                    cost = rounds * (LZ + 4) * (256.0 * simd + 192.0);
+                }
                 if (cost < best) { best = cost; bx = TX; by = TY; bz = LZ; }
             }
         }
@@ -1155,6 +1181,47 @@ void PlanePlan<V>::build_slab(int nx, int ny, int nz_own, int ghost, int ghost_c
     partials.alloc(size_t(g.n_wg) + SUM_FOLD);
 }
 
+// Times the candidate tilings on the caller's vectors (their contents are destroyed; zeros are a fair input) and
+// keeps the fastest.  Large levels only: a few launches, ~3 ms.
+template <typename V>
+void PlanePlan<V>::tune(V *x, V *tmp, const V *b, const Coarse &c, hipStream_t s) {
+    {
+        const char *e = getenv("OMG_PLANE_TUNE");
+        int forced[3];
+        if ((e && e[0] == '0') || env_int3("OMG_PLANE_TILE", forced)) return;
+    }
+    if (int64_t(g.nx) * g.ny * (g.z_end - g.z_base) < (int64_t(1) << 21)) return;
+    PlaneGeom cand[2] = {g, g};
+    choose_tiles(cand[1], sizeof(V), 1);
+    if (cand[1].TX == g.TX && cand[1].TY == g.TY && cand[1].LZ == g.LZ) return;
+    if (cand[1].TX <= 0 || cand[1].threads > 512) return;
+    partials.alloc(size_t(std::max(cand[0].n_wg, cand[1].n_wg)) + SUM_FOLD);
+    hipEvent_t e0, e1;
+    OMG_HIP(hipEventCreate(&e0));
+    OMG_HIP(hipEventCreate(&e1));
+    float best = 0.0f;
+    int pick = 0;
+    for (int i = 0; i < 2; ++i) {
+        g = cand[i];
+        down(x, tmp, b, false, c, s);                             // (not timed: the kernel's first launch)
+        up(tmp, x, b, c, partials.p, s);
+        OMG_HIP(hipEventRecord(e0, s));
+        for (int r = 0; r < 2; ++r) {
+            down(x, tmp, b, false, c, s);
+            up(tmp, x, b, c, partials.p, s);
+        }
+        OMG_HIP(hipEventRecord(e1, s));
+        OMG_HIP(hipEventSynchronize(e1));
+        float ms = 0.0f;
+        OMG_HIP(hipEventElapsedTime(&ms, e0, e1));
+        if (i == 0 || ms < best) { best = ms; pick = i; }
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    g = cand[pick];
+    partials.alloc(size_t(g.n_wg) + SUM_FOLD);
+}
+
 template <typename V>
 HostCsr PlanePlan<V>::operator_csr() const {
     const int64_t nx = g.nx, ny = g.ny, nz = g.nz, n = nx * ny * nz, sj = nx, sk = nx * ny;
@@ -1303,7 +1370,8 @@ struct BlockGeom {
 };
 inline bool block_level(const PlaneGeom &g) {
     static const int on = [] { const char *e = getenv("OMG_PLANE_BLOCK"); return e ? atoi(e) : 1; }();
-    return on && g.z_base == 0 && g.z_end == g.nz && g.kv0 == 0 && g.kv1 == g.nz && int64_t(g.nx) * g.ny * g.nz <= int64_t(64) * 64 * 64;
+    static const int64_t cells = [] { const char *e = getenv("OMG_PLANE_BLOCK_CELLS"); return e ? atoll(e) : int64_t(64) * 64 * 64; }();
+    return on && g.z_base == 0 && g.z_end == g.nz && g.kv0 == 0 && g.kv1 == g.nz && int64_t(g.nx) * g.ny * g.nz <= cells;
 }
 // the block extents block_kernel is instantiated for, largest first
 constexpr int BLOCK_SHAPES[4][3] = {{16, 8, 8}, {8, 8, 8}, {8, 4, 4}, {4, 4, 4}};
