@@ -294,7 +294,9 @@ __global__ void plane_wait_kernel(const uint32_t *f0, const uint32_t *f1, const 
 // memory pipe then streams while a step computes and waits at its barrier; the loop runs two steps per
 // iteration so that every register has a fixed role and the step's parity is a compile-time constant).
 // MAXT: the largest workgroup the instantiation is launched with (small tiles: more registers per lane, which LA = 2 needs)
-template <typename V, int MODE, bool NORM, bool XZ, int LA, bool PEER = false, int MAXT = 512>
+// FIRST (down): the coarse level's initial iterate is written too (zeros, or its first relaxation where a diagonal
+// is given) — not needed when the coarse level's own down pass takes its iterate as zero, the usual case
+template <typename V, int MODE, bool NORM, bool XZ, int LA, bool PEER = false, int MAXT = 512, bool FIRST = false>
 __global__ __launch_bounds__(MAXT) void plane_kernel(const PlaneKArgs<V> a) {
 #ifdef OMG_PLANE_STAMPS
     const unsigned long long st_entry = __builtin_amdgcn_s_memtime();
@@ -411,8 +413,8 @@ __global__ __launch_bounds__(MAXT) void plane_kernel(const PlaneKArgs<V> a) {
     };
     int CO_side = 0;                 // the pending coarse pair is also rank - 1's (1) / rank + 1's (2) ghost
     auto coarse_store = [&](const v2i &sl, const P2<V> &co, const P2<V> &cx, auto PB) {
-        if (sl.x >= 0) { a.bc[sl.x] = co.x; if (a.xc) a.xc[sl.x] = cx.x; }
-        if (sl.y >= 0) { a.bc[sl.y] = co.y; if (a.xc) a.xc[sl.y] = cx.y; }
+        if (sl.x >= 0) { a.bc[sl.x] = co.x; if (FIRST && a.xc) a.xc[sl.x] = cx.x; }
+        if (sl.y >= 0) { a.bc[sl.y] = co.y; if (FIRST && a.xc) a.xc[sl.y] = cx.y; }
         if (PEER && decltype(PB)::value) {
             if (CO_side & 1) {
                 if (sl.x >= 0) __hip_atomic_store(a.peer_bc[0] + (sl.x + a.peer_cshift), co.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -516,7 +518,7 @@ __global__ __launch_bounds__(MAXT) void plane_kernel(const PlaneKArgs<V> a) {
             // after it for the coarse diagonal there
             const v2i sl = slots_commit(SLt, SLt_kc, true);
             SLd.x = par ? SLd.x : sl.x; SLd.y = par ? SLd.y : sl.y;
-            DG.x = par ? DGt.x : DG.x; DG.y = par ? DGt.y : DG.y;
+            if (FIRST) { DG.x = par ? DGt.x : DG.x; DG.y = par ? DGt.y : DG.y; }
         }
 #pragma unroll
         for (int l = 0; l < 2; ++l) {
@@ -541,7 +543,7 @@ __global__ __launch_bounds__(MAXT) void plane_kernel(const PlaneKArgs<V> a) {
         } else {
             SLt_kc = (s - 1) >> 1;                                // the coarse plane finished by step s + 2
             SLt = slots_request(SLt_kc, par != 0);
-            DGt = coarse_vals((par || !a.cdiag) ? v2i{-1, -1} : SLd);
+            if (FIRST) DGt = coarse_vals((par || !a.cdiag) ? v2i{-1, -1} : SLd);
         }
 #pragma unroll
         for (int l = 0; l < 2; ++l) {
@@ -684,8 +686,10 @@ __global__ __launch_bounds__(MAXT) void plane_kernel(const PlaneKArgs<V> a) {
                         if (PEER) CO_side = (((pside & 4) && s - 2 < z0 + 2 * PEER_CPLANES && s - 2 < a.z_base + 2 * PEER_CPLANES) ? 1 : 0) |
                                             (((pside & 8) && s - 2 >= z1 - 2 * PEER_CPLANES && s - 2 >= a.z_end - 2 * PEER_CPLANES) ? 2 : 0);
                         // the coarse level's first relaxation of a zero iterate, spelled like row_epilogue's
-                        CX.x = (a.cdiag && SLd.x >= 0 && SLd.x < a.first_end) ? V(0) + (ACC.x - V(0)) / DG.x : V(0);
-                        CX.y = (a.cdiag && SLd.y >= 0 && SLd.y < a.first_end) ? V(0) + (ACC.y - V(0)) / DG.y : V(0);
+                        if (FIRST) {
+                            CX.x = (a.cdiag && SLd.x >= 0 && SLd.x < a.first_end) ? V(0) + (ACC.x - V(0)) / DG.x : V(0);
+                            CX.y = (a.cdiag && SLd.y >= 0 && SLd.y < a.first_end) ? V(0) + (ACC.y - V(0)) / DG.y : V(0);
+                        }
                         co_pending = true;
                     }
                 }
@@ -735,7 +739,7 @@ __global__ __launch_bounds__(MAXT) void plane_kernel(const PlaneKArgs<V> a) {
             step(std::integral_constant<int, 1>(), s + 1, std::false_type());
         }
     } else {
-        if (MODE == 1 && !PEER) {
+        if (!PEER && !FIRST) {
             // two steps per iteration: the step's parity — which neighbour an in-line pair takes, which coarse plane
             // a fine one lies over — is a compile-time constant in each copy (s0 is even, the step count too): 9 us of
             // 124 for the fine level's up pass.  (The down pass and the passes with neighbours run out of registers
@@ -1446,6 +1450,9 @@ void PlanePlan<V>::down(const V *x_old, V *x_new, const V *b, bool x_zero, const
         peer_args<V>(k, *peer, s);
         if (x_zero) launch_plane(plane_kernel<V, 0, false, true, PLANE_LA, true>, g, k, s);
         else launch_plane(plane_kernel<V, 0, false, false, PLANE_LA, true>, g, k, s);
+    } else if (c.x || c.diag) {
+        if (x_zero) launch_plane(plane_kernel<V, 0, false, true, PLANE_LA, false, 512, true>, g, k, s);
+        else launch_plane(plane_kernel<V, 0, false, false, PLANE_LA, false, 512, true>, g, k, s);
     } else if (small_tile(g)) {
         // latency-bound small levels: loads two steps ahead (the registers are there for workgroups this small)
         if (x_zero) launch_plane(plane_kernel<V, 0, false, true, 2, false, 128>, g, k, s);
