@@ -739,14 +739,15 @@ __global__ __launch_bounds__(MAXT) void plane_kernel(const PlaneKArgs<V> a) {
             step(std::integral_constant<int, 1>(), s + 1, std::false_type());
         }
     } else {
-        if (!PEER && !FIRST) {
+        // (with neighbours, the finest level's two passes run out of registers that way: 16-68 bytes of scratch per lane)
+        constexpr bool PAIRS = !FIRST && !(PEER && (NORM || (MODE == 0 && !XZ)));
+        if (PAIRS) {
             // two steps per iteration: the step's parity — which neighbour an in-line pair takes, which coarse plane
-            // a fine one lies over — is a compile-time constant in each copy (s0 is even, the step count too): 9 us of
-            // 124 for the fine level's up pass.  (The down pass and the passes with neighbours run out of registers
-            // that way: 20-100 bytes of scratch per lane and +16 us.)
+            // a fine one lies over — is a compile-time constant in each copy (s0 is even, the step count too): 10 us of
+            // 117 / 124 for the fine level's down / up pass.
             for (int s = s0; s <= z1 + 1; s += 2) {
-                step(std::integral_constant<int, 0>(), s, std::false_type());
-                step(std::integral_constant<int, 1>(), s + 1, std::false_type());
+                step(std::integral_constant<int, 0>(), s, std::integral_constant<bool, PEER>());
+                step(std::integral_constant<int, 1>(), s + 1, std::integral_constant<bool, PEER>());
             }
         } else {
             for (int s = s0; s <= z1 + 1; ++s) step(s & 1, s, std::integral_constant<bool, PEER>());
