@@ -541,7 +541,7 @@ struct PlanePlan {
     // x_zero: x_old is known to be zero and is not read
     // Large levels: times the candidate tilings on these vectors (contents destroyed) and keeps the fastest
     // (OMG_PLANE_TUNE=0 / OMG_PLANE_TILE: no timing).
-    void tune(V *x, V *tmp, const V *b, const Coarse &c, hipStream_t s);
+    void tune(V *x, V *tmp, const V *b, const Coarse &c, hipStream_t s, bool finest = true);
     void down(const V *x_old, V *x_new, const V *b, bool x_zero, const Coarse &c, hipStream_t s, const Peer *peer = nullptr) const;
     // out (nullable): block partials of the squared residual norm, g.n_wg doubles
     void up(const V *x_old, V *x_new, const V *b, const Coarse &c, double *out, hipStream_t s, const Peer *peer = nullptr) const;

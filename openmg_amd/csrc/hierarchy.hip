@@ -787,16 +787,17 @@ std::unique_ptr<Hier<V>> create(int n_levels, const omg_csr *A, const omg_csr *R
         L.xp = L.x.p;
         L.tp = L.tmp.p;
     }
-    if (n_levels >= 2 && h->lv[0].plane && h->lv[0].tmp.p) {
-        // the finest level's tiling: measured, not modelled (plane.hip choose_tiles)
-        SetupTimer tm("plane tiling of the finest level");
-        Level<V> &L = h->lv[0], &C = h->lv[1];
+    for (int l = 0; l + 1 < n_levels; ++l) {
+        // the large levels' tilings: measured, not modelled (plane.hip choose_tiles; tune() skips the small ones)
+        if (!h->lv[l].plane || !h->lv[l].tmp.p) continue;
+        SetupTimer tm("plane tiling of a large level");
+        Level<V> &L = h->lv[l], &C = h->lv[l + 1];
         L.x.zero(h->stream); L.tmp.zero(h->stream); L.b.zero(h->stream); C.x.zero(h->stream);
         typename PlanePlan<V>::Coarse c;
         c.map = L.r_out.p;
         c.b = C.b.p;
         c.e = C.xp;
-        L.plane->tune(L.xp, L.tp, L.b.p, c, h->stream);
+        L.plane->tune(L.xp, L.tp, L.b.p, c, h->stream, l == 0);
         OMG_HIP(hipStreamSynchronize(h->stream));
     }
     { SetupTimer tm("wait for the coarse factorisation"); inverter.join(); }

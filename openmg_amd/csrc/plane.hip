@@ -535,6 +535,14 @@ __global__ __launch_bounds__(MAXT) void plane_kernel(const PlaneKArgs<V> a) {
             BR[0][l] = clean(LBR[set][l]);
             BB[l] = clean(LBB[set][l]);
         }
+        if (PEER_STEP && inner && (((pside & 1) && s < z0 + PEER_PLANES + 2) || ((pside & 2) && s >= z1 - PEER_PLANES + 1))) {
+            // ONE uniform branch per step, taken by the few steps that hold a neighbour's ghost planes: red of plane
+            // s - 1 and black of plane s - 2, final since the previous step.  HERE — the last step's loads are consumed,
+            // this step's not yet requested — the fewest registers are live (at the step's end the branch cost the
+            // kernels with neighbours their two-steps-per-iteration form).
+            if (s - 1 >= z0 && s - 1 < z1) peer_store(s - 1, (s - 1) * ps, XR[1]);
+            if (s - 2 >= z0 && s - 2 < z1) peer_store(s - 2, a.nr + (s - 2) * ps, XB[3]);
+        }
         if (MODE == 1) {
             E0.x = par ? E1n.x : E0.x; E0.y = par ? E1n.y : E0.y;
             SLt_kc = (s >> 1) + 2;
@@ -722,12 +730,6 @@ __global__ __launch_bounds__(MAXT) void plane_kernel(const PlaneKArgs<V> a) {
                 lds_put(W2 + idx[l], XR[0][l]);
                 lds_put(W3 + idx[l], XB[2][l]);
             }
-        }
-        if (PEER_STEP && inner && (((pside & 1) && s < z0 + PEER_PLANES + 2) || ((pside & 2) && s >= z1 - PEER_PLANES + 1))) {
-            // (ONE uniform branch per step, taken by the few steps that hold a neighbour's ghost planes: red of
-            // plane s - 1 and black of plane s - 2, final since the previous step and still in their registers)
-            if (s - 1 >= z0 && s - 1 < z1) peer_store(s - 1, (s - 1) * ps, XR[1]);
-            if (s - 2 >= z0 && s - 2 < z1) peer_store(s - 2, a.nr + (s - 2) * ps, XB[3]);
         }
         PLANE_STAMP(st_cmp)
         __syncthreads();
@@ -1189,7 +1191,7 @@ void PlanePlan<V>::build_slab(int nx, int ny, int nz_own, int ghost, int ghost_c
 // Times the candidate tilings on the caller's vectors (their contents are destroyed; zeros are a fair input) and
 // keeps the fastest.  Large levels only: a few launches, ~3 ms.
 template <typename V>
-void PlanePlan<V>::tune(V *x, V *tmp, const V *b, const Coarse &c, hipStream_t s) {
+void PlanePlan<V>::tune(V *x, V *tmp, const V *b, const Coarse &c, hipStream_t s, bool finest) {
     {
         const char *e = getenv("OMG_PLANE_TUNE");
         int forced[3];
@@ -1208,12 +1210,13 @@ void PlanePlan<V>::tune(V *x, V *tmp, const V *b, const Coarse &c, hipStream_t s
     int pick = 0;
     for (int i = 0; i < 2; ++i) {
         g = cand[i];
-        down(x, tmp, b, false, c, s);                             // (not timed: the kernel's first launch)
-        up(tmp, x, b, c, partials.p, s);
+        // (the finest level's passes read the iterate and square the residual; the others' start from zero)
+        down(x, tmp, b, !finest, c, s);                           // (not timed: the kernel's first launch)
+        up(tmp, x, b, c, finest ? partials.p : nullptr, s);
         OMG_HIP(hipEventRecord(e0, s));
         for (int r = 0; r < 2; ++r) {
-            down(x, tmp, b, false, c, s);
-            up(tmp, x, b, c, partials.p, s);
+            down(x, tmp, b, !finest, c, s);
+            up(tmp, x, b, c, finest ? partials.p : nullptr, s);
         }
         OMG_HIP(hipEventRecord(e1, s));
         OMG_HIP(hipEventSynchronize(e1));
