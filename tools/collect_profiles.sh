@@ -10,7 +10,10 @@ cd "$root"
 last() { tail -1 "$1" > "$2"; }
 timeout 600 python bench.py > $out/bench.log 2>$out/bench.err; last $out/bench.log $out/${p}_bench.json
 timeout 300 python bench.py --no-cpu --no-plain --no-lex --dtype f32 > $out/f32.log 2>/dev/null; last $out/f32.log $out/${p}_bench_f32.json
-timeout 300 python bench.py --dist 1 --no-cpu > $out/dist1.log 2>/dev/null; last $out/dist1.log $out/${p}_bench_dist1.json
+OMG_DIST_P2P=0 timeout 300 python bench.py --dist 1 --no-cpu > $out/dist1.log 2>/dev/null; last $out/dist1.log $out/${p}_bench_dist1.json
+OMG_DIST_P2P=1 timeout 300 python bench.py --dist 1 --no-cpu > $out/dist1p.log 2>/dev/null; last $out/dist1p.log $out/${p}_bench_dist1_peer.json
+PYTHONPATH=$root timeout 300 python tools/exchange_probe.py > $out/${p}_exchange_probe.txt 2>/dev/null
+( for m in 0 1; do echo "OMG_LOOPBACK_P2P=$m (0: device copies in place of RCCL, 1: peer stores between the slabs)"; OMG_LOOPBACK_P2P=$m PYTHONPATH=$root timeout 300 python tools/pdist_loopback_time.py 1 2 4 8 2>/dev/null | grep world; done ) > $out/${p}_slab_loopback.txt
 timeout 600 python tools/run_configs.py > $out/${p}_configs.txt 2>&1
 timeout 900 python tools/config3_single.py 512 6 > $out/${p}_config3_single_gpu.txt 2>&1
 timeout 600 python tools/config4_probe.py --size 256 > $out/${p}_config4_256_fp32.txt 2>&1
@@ -25,10 +28,13 @@ timeout 300 rocprofv3 --kernel-trace --output-format csv -d $out/cyc -o c -- pyt
 python3 $root/tools/cycle_timeline.py $out/cyc/c_kernel_trace.csv -3 > $out/${p}_bench_cycle_timeline.txt 2>&1
 timeout 300 rocprofv3 --kernel-trace --output-format csv -d $out/lex -o l -- python3 $root/tools/run_configs.py 0 4 5 > /dev/null 2>&1
 python3 $root/tools/march_trace.py $out/lex/l_kernel_trace.csv > $out/${p}_march_by_level.txt 2>&1
+for m in 0 1; do PYTHONPATH=$root timeout 200 rocprofv3 --kernel-trace --output-format csv -d $out/peer$m -o p -- python3 $root/tools/prof_pdist.py $m 20 > /dev/null 2>&1; done
+python3 $root/tools/peer_mode_table.py $out/peer0 $out/peer1 > $out/${p}_peer_mode.txt 2>&1
+python3 $root/tools/level_times.py $out/cyc/c_kernel_trace.csv > $out/${p}_level_times.txt 2>&1
 cd "$root"
 PASSES="1 2 4 5 6 7" bash tools/pmc_plane.sh gpurun_out/fin/pmc > $out/pmc.log 2>&1
 python tools/pmc_any.py gpurun_out/fin/pmc > $out/${p}_pmc_plane_kernels.txt 2>&1
 python tools/pmc_plane_json.py gpurun_out/fin/pmc $out/${p}_bench.json $out/${p}_pmc_plane_down.json \
   "tools/pmc_plane.sh passes 6 and 7 (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, --kernel-include-regex plane_kernel, tools/prof_cycle.py --steps 2), table in profiles/${p}_pmc_plane_kernels.txt" > $out/pmc_json.log 2>&1
-rm -rf $out/trace $out/cyc $out/lex $out/pmc
+rm -rf $out/trace $out/cyc $out/lex $out/pmc $out/peer0 $out/peer1
 ls -la $out
