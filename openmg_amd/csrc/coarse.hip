@@ -220,16 +220,21 @@ __global__ __launch_bounds__(SINE_THREADS) void sine_solve_kernel(const V *__res
             v4d acc[E / 16];
 #pragma unroll
             for (int ib = 0; ib < E / 16; ++ib) acc[ib] = v4d{0.0, 0.0, 0.0, 0.0};
-#pragma unroll 1
-            for (int ks = 0; ks < k_steps; ++ks) {
-                const int k = 4 * ks + k4;
-                const double bv = (live && k < ne) ? sine_buf[bs + k * stride] : 0.0;
+            // all the operands first (E / 4 steps whatever the extent: the tables are zero beyond it), then the chain of
+            // matrix instructions: the LDS round trips overlap instead of one per step
+            double bvs[E / 4], avs[E / 16][E / 4];
 #pragma unroll
-                for (int ib = 0; ib < E / 16; ++ib) {
-                    const double av = S[(16 * ib + c16) * E + (k < E ? k : 0)];     // rows and columns beyond ne are zeros
-                    acc[ib] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc[ib], 0, 0, 0);
-                }
+            for (int ks = 0; ks < E / 4; ++ks) {
+                const int k = 4 * ks + k4;
+                bvs[ks] = (live && k < ne) ? sine_buf[bs + k * stride] : 0.0;
+#pragma unroll
+                for (int ib = 0; ib < E / 16; ++ib) avs[ib][ks] = S[(16 * ib + c16) * E + k];
             }
+#pragma unroll
+            for (int ks = 0; ks < E / 4; ++ks)
+#pragma unroll
+                for (int ib = 0; ib < E / 16; ++ib)
+                    if (ks < k_steps) acc[ib] = __builtin_amdgcn_mfma_f64_16x16x4f64(avs[ib][ks], bvs[ks], acc[ib], 0, 0, 0);
             // (the wave has read all it needs of its 16 lines: LDS operations of a wave complete in order)
             if (live) {
 #pragma unroll

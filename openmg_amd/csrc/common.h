@@ -492,6 +492,9 @@ struct PlaneGeom {
     size_t lds_bytes = 0;
     double c[7] = {0, 0, 0, 0, 0, 0, 0};   // -K, -J, -I, diagonal, +I, +J, +K
     double w = 0.0;                   // the restriction's weight
+    // small levels (set when the plan is built, from OMG_PLANE_BLOCK / OMG_PLANE_BLOCK_CELLS / OMG_PLANE_LA2):
+    bool block = false;               // whole grid of <= 64^3 cells: block_kernel where the pass allows it
+    bool la2 = true;                  // marching kernel with two steps of lookahead for workgroups of <= 128 threads
 };
 template <typename V>
 struct PlanePlan {

@@ -405,7 +405,8 @@ __global__ __launch_bounds__(MAXT) void plane_kernel(const PlaneKArgs<V> a) {
             V *px = a.peer_x[side];
             asm volatile("" : "+s"(px));
             const __amdgpu_buffer_rsrc_t pw = __builtin_amdgcn_make_buffer_rsrc(px ? px : a.x_new, 0, px ? a.vec_bytes : 0u, 0x00020000);
-            const int sh = side == 0 ? a.peer_shift : -a.peer_shift;
+            int sh = side == 0 ? a.peer_shift : -a.peer_shift;
+            asm volatile("" : "+s"(sh));                            // (... nor the addresses computed ahead of the branch)
 #pragma unroll
             for (int l = 0; l < 2; ++l)
                 if (vl[l] && vx0) bstore2<PEER_AUX>(pw, (base + sh + lb[l]) * int(sizeof(V)), v[l], vx1);
@@ -416,13 +417,15 @@ __global__ __launch_bounds__(MAXT) void plane_kernel(const PlaneKArgs<V> a) {
         if (sl.x >= 0) { a.bc[sl.x] = co.x; if (FIRST && a.xc) a.xc[sl.x] = cx.x; }
         if (sl.y >= 0) { a.bc[sl.y] = co.y; if (FIRST && a.xc) a.xc[sl.y] = cx.y; }
         if (PEER && decltype(PB)::value) {
-            if (CO_side & 1) {
-                if (sl.x >= 0) __hip_atomic_store(a.peer_bc[0] + (sl.x + a.peer_cshift), co.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                if (sl.y >= 0) __hip_atomic_store(a.peer_bc[0] + (sl.y + a.peer_cshift), co.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            }
-            if (CO_side & 2) {
-                if (sl.x >= 0) __hip_atomic_store(a.peer_bc[1] + (sl.x - a.peer_cshift), co.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                if (sl.y >= 0) __hip_atomic_store(a.peer_bc[1] + (sl.y - a.peer_cshift), co.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+#pragma unroll
+            for (int side = 0; side < 2; ++side) {
+                if (!(CO_side & (1 << side))) continue;
+                // (pointer and shift pinned inside the branch, as in peer_store: nothing of it is computed ahead)
+                V *pb = a.peer_bc[side];
+                int sh = side == 0 ? a.peer_cshift : -a.peer_cshift;
+                asm volatile("" : "+s"(pb), "+s"(sh));
+                if (sl.x >= 0) __hip_atomic_store(pb + (sl.x + sh), co.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                if (sl.y >= 0) __hip_atomic_store(pb + (sl.y + sh), co.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             }
         }
     };
@@ -742,7 +745,7 @@ __global__ __launch_bounds__(MAXT) void plane_kernel(const PlaneKArgs<V> a) {
         }
     } else {
         // (with neighbours, the finest level's two passes run out of registers that way: 16-68 bytes of scratch per lane)
-        constexpr bool PAIRS = !FIRST && !(PEER && (NORM || (MODE == 0 && !XZ)));
+        constexpr bool PAIRS = !FIRST && !(PEER && MODE == 0 && !XZ);
         if (PAIRS) {
             // two steps per iteration: the step's parity — which neighbour an in-line pair takes, which coarse plane
             // a fine one lies over — is a compile-time constant in each copy (s0 is even, the step count too): 10 us of
@@ -979,6 +982,14 @@ int env_int3(const char *name, int out[3]) {
 
 inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
+// (decided once per plan, so that a process can hold hierarchies built with different switches: the tests do)
+inline void small_level_switches(PlaneGeom &g) {
+    auto env = [](const char *name, long long dflt) { const char *e = getenv(name); return e && e[0] ? atoll(e) : dflt; };
+    const bool whole = g.z_base == 0 && g.z_end == g.nz && g.kv0 == 0 && g.kv1 == g.nz;
+    g.block = env("OMG_PLANE_BLOCK", 1) != 0 && whole && int64_t(g.nx) * g.ny * g.nz <= env("OMG_PLANE_BLOCK_CELLS", int64_t(64) * 64 * 64);
+    g.la2 = env("OMG_PLANE_LA2", 1) != 0;
+}
+
 // model 0: one workgroup per CU, cost ~ rounds x steps x (threads + a fixed per-step price).
 // model 1: the CU's four SIMDs evenly loaded — a workgroup of 6 waves costs a step what one of 8 does (two of its
 // SIMDs carry two waves), and several small workgroups share a CU.  Neither predicts the other's winner
@@ -1164,6 +1175,7 @@ bool PlanePlan<V>::build(const omg_csr &A, const omg_csr &R, Ordering &ord) {
     g.w = double(V(w));
     g.z_base = 0; g.z_end = g.nz; g.kv0 = 0; g.kv1 = g.nz; g.kc_off = 0; g.nzc = g.nz / 2;
     choose_tiles(g, sizeof(V));
+    small_level_switches(g);
     if (g.TX <= 0 || g.threads > 512) return false;
     partials.alloc(size_t(g.n_wg) + SUM_FOLD);
     return true;
@@ -1184,6 +1196,7 @@ void PlanePlan<V>::build_slab(int nx, int ny, int nz_own, int ghost, int ghost_c
     g.kc_off = ghost_c - ghost / 2;
     OMG_REQUIRE(uint64_t(nx) * ny * g.nz * sizeof(V) < (uint64_t(1) << 31), "plane slab: vector exceeds 2 GiB");
     choose_tiles(g, sizeof(V));
+    small_level_switches(g);
     OMG_REQUIRE(g.TX > 0 && g.threads <= 512, "plane slab: no tiling");
     partials.alloc(size_t(g.n_wg) + SUM_FOLD);
 }
@@ -1376,11 +1389,7 @@ struct BlockGeom {
     int shape, BX, BY, BZ, nbx, nby, nbz, threads;
     size_t lds;
 };
-inline bool block_level(const PlaneGeom &g) {
-    static const int on = [] { const char *e = getenv("OMG_PLANE_BLOCK"); return e ? atoi(e) : 1; }();
-    static const int64_t cells = [] { const char *e = getenv("OMG_PLANE_BLOCK_CELLS"); return e ? atoll(e) : int64_t(64) * 64 * 64; }();
-    return on && g.z_base == 0 && g.z_end == g.nz && g.kv0 == 0 && g.kv1 == g.nz && int64_t(g.nx) * g.ny * g.nz <= cells;
-}
+inline bool block_level(const PlaneGeom &g) { return g.block; }
 // the block extents block_kernel is instantiated for, largest first
 constexpr int BLOCK_SHAPES[4][3] = {{16, 8, 8}, {8, 8, 8}, {8, 4, 4}, {4, 4, 4}};
 inline BlockGeom choose_block(const PlaneGeom &g, size_t value_bytes) {
@@ -1428,10 +1437,7 @@ void launch_block(const PlaneGeom &g, const V *x_old, V *x_new, const V *b, cons
     OMG_HIP(hipGetLastError());
 }
 
-inline bool small_tile(const PlaneGeom &g) {
-    static const int on = [] { const char *e = getenv("OMG_PLANE_LA2"); return e ? atoi(e) : 1; }();
-    return on && g.threads <= 128;
-}
+inline bool small_tile(const PlaneGeom &g) { return g.la2 && g.threads <= 128; }
 
 template <typename K, typename V>
 void launch_plane(K kernel, const PlaneGeom &g, const PlaneKArgs<V> &k, hipStream_t s) {

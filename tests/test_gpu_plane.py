@@ -240,3 +240,25 @@ def test_plane_full_size_properties():
         h.use_plane(False)
         norms3, x3 = run(h, b, 1, 1, 3)
         assert np.array_equal(x3, x) and close(norms3, norms)
+
+
+@pytest.mark.parametrize("shape,grids", [((48, 40, 72), 4), ((64, 64, 64), 5), ((16, 24, 20), 3)])
+def test_small_level_kernels_are_interchangeable_bit_for_bit(monkeypatch, shape, grids):
+    """Levels of <= 64^3 cells below the finest: the block-in-LDS kernel (default), the marching kernel with two
+    steps of lookahead, the marching kernel with one — and the set schedule: one iterate."""
+    A, R = hierarchy(shape, grids, scale=0.61)
+    rng = np.random.default_rng(21)
+    b = rng.standard_normal(A[0].shape[0])
+    x0 = rng.standard_normal(A[0].shape[0])
+    results = {}
+    for name, env in (("sets", {"OMG_PLANE": "0"}), ("block", {}), ("march la2", {"OMG_PLANE_BLOCK": "0"}),
+                      ("march la1", {"OMG_PLANE_BLOCK": "0", "OMG_PLANE_LA2": "0"})):
+        for k in ("OMG_PLANE", "OMG_PLANE_BLOCK", "OMG_PLANE_LA2"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        with _hip.Hierarchy(A, R, smoother="colour") as h:
+            results[name] = run(h, b, 1, 1, 3, x0)
+    for name in ("block", "march la2", "march la1"):
+        assert np.array_equal(results[name][1], results["sets"][1]), (name, int(np.sum(results[name][1] != results["sets"][1])))
+        assert close(results[name][0], results["sets"][0])

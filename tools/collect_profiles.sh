@@ -1,6 +1,7 @@
 #!/bin/bash
 # Everything under profiles/rNN_* from ONE gpurun call (run from the repository root on the GPU box):
-#     OMG_GIT_HEAD=$(git rev-parse HEAD) gpurun -- 'bash tools/collect_profiles.sh r03'
+#     gpurun -- "OMG_GIT_HEAD=$(git rev-parse HEAD) bash tools/collect_profiles.sh r03"
+# (the variable goes INSIDE the command: gpurun does not forward the caller's environment, and the box has no .git)
 # writes gpurun_out/fin/<prefix>_*; copy what is to be judged into profiles/.
 p=${1:-r03}
 root=$(cd "$(dirname "$0")/.." && pwd)
@@ -8,6 +9,13 @@ out=$root/gpurun_out/fin
 rm -rf "$out"; mkdir -p "$out"
 cd "$root"
 last() { tail -1 "$1" > "$2"; }
+# the PMC passes first: the bench line quotes their traffic (profiles/${p}_pmc_plane_down.json) while the kernel sources hash to it
+timeout 300 python bench.py --no-cpu --no-plain --no-lex --no-sets > $out/quick.log 2>/dev/null; last $out/quick.log $out/quick.json
+PASSES="1 2 4 5 6 7" bash tools/pmc_plane.sh gpurun_out/fin/pmc > $out/pmc.log 2>&1
+python tools/pmc_any.py gpurun_out/fin/pmc > $out/${p}_pmc_plane_kernels.txt 2>&1
+python tools/pmc_plane_json.py gpurun_out/fin/pmc $out/quick.json $out/${p}_pmc_plane_down.json \
+  "tools/pmc_plane.sh passes 6 and 7 (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, --kernel-include-regex plane_kernel, tools/prof_cycle.py --steps 2), table in profiles/${p}_pmc_plane_kernels.txt" > $out/pmc_json.log 2>&1
+cp $out/${p}_pmc_plane_down.json $root/profiles/${p}_pmc_plane_down.json
 timeout 600 python bench.py > $out/bench.log 2>$out/bench.err; last $out/bench.log $out/${p}_bench.json
 timeout 300 python bench.py --no-cpu --no-plain --no-lex --dtype f32 > $out/f32.log 2>/dev/null; last $out/f32.log $out/${p}_bench_f32.json
 OMG_DIST_P2P=0 timeout 300 python bench.py --dist 1 --no-cpu > $out/dist1.log 2>/dev/null; last $out/dist1.log $out/${p}_bench_dist1.json
@@ -32,9 +40,5 @@ for m in 0 1; do PYTHONPATH=$root timeout 200 rocprofv3 --kernel-trace --output-
 python3 $root/tools/peer_mode_table.py $out/peer0 $out/peer1 > $out/${p}_peer_mode.txt 2>&1
 python3 $root/tools/level_times.py $out/cyc/c_kernel_trace.csv > $out/${p}_level_times.txt 2>&1
 cd "$root"
-PASSES="1 2 4 5 6 7" bash tools/pmc_plane.sh gpurun_out/fin/pmc > $out/pmc.log 2>&1
-python tools/pmc_any.py gpurun_out/fin/pmc > $out/${p}_pmc_plane_kernels.txt 2>&1
-python tools/pmc_plane_json.py gpurun_out/fin/pmc $out/${p}_bench.json $out/${p}_pmc_plane_down.json \
-  "tools/pmc_plane.sh passes 6 and 7 (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, --kernel-include-regex plane_kernel, tools/prof_cycle.py --steps 2), table in profiles/${p}_pmc_plane_kernels.txt" > $out/pmc_json.log 2>&1
 rm -rf $out/trace $out/cyc $out/lex $out/pmc $out/peer0 $out/peer1
 ls -la $out
