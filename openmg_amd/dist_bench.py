@@ -126,24 +126,47 @@ def main_plane(args, rank, world, shape, grids, n_levels, all_gather, td, torch,
             r.p2p_enable(0)
             notes = [n for n in all_gather(p2p_note) if n != "not tried"]
             p2p_note = "unavailable: " + (notes[0] if notes else "another rank failed")
-        # the same start for the timed run whatever was tried
+    def timed_run():
+        """From the loaded right-hand side: one cycle, the warm-up, the timed regions -> (times, every norm in order)."""
         r.load(b_loc)
-        r.cycles(1)
-    for _ in range(args.warmup):
-        r.cycles(1)
-    times = []
-    for _ in range(max(1, getattr(args, "repeats", 1))):
-        r.sync()
-        torch.cuda.synchronize()
-        td.barrier()
-        t0 = time.perf_counter()
-        region_norms = r.cycles(args.steps)              # K cycles back to back, every cycle's global norm computed
-        r.sync()
-        torch.cuda.synchronize()
-        td.barrier()
-        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
-        td.all_reduce(t, op=td.ReduceOp.MAX)             # the slowest rank's time
-        times.append(float(t[0]))
+        trajectory = r.cycles(1)
+        for _ in range(args.warmup):
+            trajectory += r.cycles(1)
+        times_ = []
+        for _ in range(max(1, getattr(args, "repeats", 1))):
+            r.sync()
+            torch.cuda.synchronize()
+            td.barrier()
+            t0 = time.perf_counter()
+            region = r.cycles(args.steps)                # K cycles back to back, every cycle's global norm computed
+            r.sync()
+            torch.cuda.synchronize()
+            td.barrier()
+            t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+            td.all_reduce(t, op=td.ReduceOp.MAX)         # the slowest rank's time
+            times_.append(float(t[0]))
+            trajectory += region
+        return times_, trajectory
+
+    times, trajectory = timed_run()
+    if r.p2p_mode:
+        # every norm of the timed peer-mode run against the same cycles over RCCL (untimed): a hand-over that went
+        # wrong once in hundreds of cycles must not survive into the reported number
+        r.p2p_enable(0)
+        r.load(b_loc)
+        check = []
+        while len(check) < len(trajectory):
+            check += r.cycles(min(args.steps, len(trajectory) - len(check)))
+        same = all(abs(a - c) <= 1e-11 * abs(c) for a, c in zip(trajectory, check))
+        if all(all_gather(bool(same))):
+            p2p_note += "; all %d norms of the timed run equal the same cycles' over RCCL" % len(trajectory)
+        else:
+            bad = next(k for k, (a, c) in enumerate(zip(trajectory, check)) if not abs(a - c) <= 1e-11 * abs(c)) if not same else -1
+            p2p_note = "rejected AFTER the timed run (rank %d: first differing cycle %d): the reported run is the RCCL one" % (rank, bad)
+            p2p_note = next(n for n in all_gather(p2p_note) if n.startswith("rejected"))
+            exchange = "RCCL grouped send/recv of ghost planes"
+            times, trajectory = timed_run()
+    region_norms = trajectory[-args.steps:]
     elapsed = statistics.median(times)
     norm = r.cycles(1)[0]
     rccl_ranks = r.rccl_ranks()
