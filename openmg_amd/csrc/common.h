@@ -456,6 +456,8 @@ struct MarchPlan {
     DevBuf<uint32_t> codes;           // [tile][group][lane]: the pattern codes of the lane's rows of four consecutive steps
     DevBuf<V> coef;                   // [pattern][8]: -K, -J, -I, diagonal, +I, +J, +K, unused
     DevBuf<uint32_t> sync;            // ticket, finished tiles, error flag
+    DevBuf<int32_t> order;            // ticket -> tile: along the wavefront (anti-diagonals of the tile grid), so that the
+                                      // tiles holding a CU are the ones next to run (empty: tickets are tile numbers)
     DevBuf<V> faceJ, faceK;           // [tile][line of the +J / +K face][row]: hand-over slots, unset (a marker NaN) between sweeps
     // false: the operator is not such a stencil (the caller keeps the level schedule)
     bool build(const omg_csr &A, hipStream_t s);

@@ -52,6 +52,7 @@ struct MarchArgs {
     const V *b;
     const uint32_t *codes;
     const V *coef;
+    const int32_t *order;
     uint32_t *sync;
     V *faceJ, *faceK;
     long long *dbg;      // OMG_MARCH_DEBUG=1: per tile start, end, time in face waits, polls (wall_clock64 ticks)
@@ -177,23 +178,28 @@ __global__ __launch_bounds__(128) void march_gs_kernel(MarchArgs<V> a) {
     __shared__ int s_ready, s_taken;           // blocks the computing wave has put into the ring / the storing wave has taken out
     const int lane = threadIdx.x & 63;
     const bool storer = threadIdx.x >= 64;
-    if (threadIdx.x == 0) {
-        // tiles are numbered by a ticket: whatever order the workgroups start in, the tiles a tile
-        // takes faces from (lower numbers) have started
-        const unsigned t = __hip_atomic_fetch_add(a.sync + 0, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s_tile = (int)t;
-        // every tile has its ticket: the counter is left as the next sweep expects it
-        if ((int)t == a.n_tiles - 1) store_through(a.sync + 0, 0u);
-        s_ready = 0;
-        s_taken = 0;
-    }
     for (int q = threadIdx.x; q < a.n_pat * 8; q += 128) {
         V c = a.coef[q];
         if ((q & 7) == 7) c = refined_rcp(a.coef[q - 4]);
         s_coef[q] = c;
     }
+    // A workgroup is a WORKER: it takes tiles by ticket until none is left.  Tickets run along the wavefront (a.order:
+    // anti-diagonals of the tile grid), so the tiles a tile takes faces from (earlier tickets) are done or in some
+    // worker's hands, and with about one worker per CU the tiles that hold a CU are the ones next to run.  (With every
+    // tile a workgroup of its own, 512 of them were resident two to a CU from the start — in tile-number order the
+    // first sixteen tile rows — polling beside the few that could run: a tile took 98 us instead of 62, a hop 13.7
+    // instead of 9, and a tile of row 18 that could have run at 250 us found no CU before 340.)
+    for (;;) {
+    __syncthreads();                                   // (the previous tile's last use of the LDS flags and rings)
+    if (threadIdx.x == 0) {
+        const unsigned t = __hip_atomic_fetch_add(a.sync + 0, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_tile = int(t) < a.n_tiles ? (a.order ? a.order[t] : (int)t) : -1;
+        s_ready = 0;
+        s_taken = 0;
+    }
     __syncthreads();
     const int tile = __builtin_amdgcn_readfirstlane(s_tile);
+    if (tile < 0) break;
     const int TJ = a.TJ, TK = 64 / TJ;
     const int J = tile % a.ntj, K = tile / a.ntj;
     const int jj = lane % TJ, kk = lane / TJ;
@@ -287,8 +293,7 @@ __global__ __launch_bounds__(128) void march_gs_kernel(MarchArgs<V> a) {
             a.dbg[8 * tile + 5] = wall_clock64();
             a.dbg[8 * tile + 6] = t_wait;
         }
-        return;
-    }
+    } else {
     long long t_ring = 0;
 
     const unsigned vec_bytes = unsigned(a.n) * unsigned(sizeof(V));
@@ -496,6 +501,16 @@ __global__ __launch_bounds__(128) void march_gs_kernel(MarchArgs<V> a) {
         a.dbg[8 * tile + 3] = spins;
         a.dbg[8 * tile + 4] = t_ring;
     }
+    }   // computing wave
+    }   // next tile
+    // the last worker out leaves the counters as the next sweep expects them
+    if (threadIdx.x == 0) {
+        const unsigned d = __hip_atomic_fetch_add(a.sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (d == gridDim.x - 1) {
+            store_through(a.sync + 1, 0u);
+            store_through(a.sync + 0, 0u);
+        }
+    }
 }
 
 template <typename V>
@@ -636,6 +651,18 @@ bool MarchPlan<V>::build(const omg_csr &A, hipStream_t s) {
     std::vector<V> cf(size_t(g.n_pat) * 8, V(0));
     for (int q = 0; q < g.n_pat; ++q)
         for (int e = 0; e < 7; ++e) cf[size_t(q) * 8 + e] = V(pats[q][e]);
+    {
+        std::vector<int32_t> ord;
+        ord.reserve(size_t(g.n_tiles));
+        for (int d = 0; d <= g.ntj + g.ntk - 2; ++d)
+            for (int K = std::max(0, d - (g.ntj - 1)); K <= std::min(d, g.ntk - 1); ++K) ord.push_back(K * g.ntj + (d - K));
+        const char *e = getenv("OMG_MARCH_ORDER");
+        if (!(e && e[0] == '0')) {
+            order.alloc(ord.size());
+            order.upload(ord.data(), ord.size(), s);
+            OMG_HIP(hipStreamSynchronize(s));
+        }
+    }
     codes.alloc(words.size());
     coef.alloc(cf.size());
     sync.alloc(SYNC_WORDS);
@@ -655,7 +682,7 @@ bool MarchPlan<V>::build(const omg_csr &A, hipStream_t s) {
 template <typename V>
 void MarchPlan<V>::sweep(V *x, const V *b, hipStream_t s) const {
     MarchArgs<V> a;
-    a.x = x; a.b = b; a.codes = codes.p; a.coef = coef.p; a.sync = sync.p;
+    a.x = x; a.b = b; a.codes = codes.p; a.coef = coef.p; a.sync = sync.p; a.order = order.p;
     a.nx = g.nx; a.ny = g.ny; a.nz = g.nz; a.TJ = g.TJ; a.ntj = g.ntj; a.n_tiles = g.n_tiles;
     a.T = g.T; a.n_grp = g.n_grp; a.n_pat = g.n_pat; a.n = g.nx * g.ny * g.nz;
     a.faceJ = faceJ.p; a.faceK = faceK.p;
@@ -664,9 +691,21 @@ void MarchPlan<V>::sweep(V *x, const V *b, hipStream_t s) const {
     DevBuf<long long> dbg;
     a.dbg = nullptr;
     if (debug) { dbg.alloc(size_t(8) * g.n_tiles); dbg.zero(s); a.dbg = dbg.p; }
-    const dim3 grid((unsigned)g.n_tiles);
-    if (steps == 4) hipLaunchKernelGGL((march_gs_kernel<V, 4>), grid, dim3(128), 0, s, a);
-    else hipLaunchKernelGGL((march_gs_kernel<V, 8>), grid, dim3(128), 0, s, a);
+    // workers: one per CU (a pad of dynamic LDS keeps a second one off the CU), each taking tiles until none is left
+    static const int workers = [] { const char *e = getenv("OMG_MARCH_WORKERS"); return e ? atoi(e) : 256; }();
+    const bool persistent = workers > 0 && g.n_tiles > workers;
+    const dim3 grid((unsigned)(persistent ? workers : g.n_tiles));
+    const size_t pad = persistent ? size_t(56) * 1024 : 0;
+    if (pad) {
+        static bool allowed = false;                          // (per instantiation of sweep<V>)
+        if (!allowed) {
+            OMG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(march_gs_kernel<V, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, int(pad)));
+            OMG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(march_gs_kernel<V, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, int(pad)));
+            allowed = true;
+        }
+    }
+    if (steps == 4) hipLaunchKernelGGL((march_gs_kernel<V, 4>), grid, dim3(128), pad, s, a);
+    else hipLaunchKernelGGL((march_gs_kernel<V, 8>), grid, dim3(128), pad, s, a);
     OMG_HIP(hipGetLastError());
     if (debug) {
         std::vector<long long> h(size_t(8) * g.n_tiles);
