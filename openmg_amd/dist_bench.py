@@ -69,14 +69,32 @@ def main_plane(args, rank, world, shape, grids, n_levels, all_gather, td, torch,
     Rt = operators.restrictionList(tshape, tgrids - 2, 8) if tgrids >= 2 else []
     tail = _hip.Hierarchy(operators.coeffecientList(At, Rt), Rt, smoother=args.smoother)
     r = _hip_dist.PlaneDistRank(rank, world, shape, coef, 0.125, tail)
-    ident = [(_hip_dist.rccl_unique_id(), _hip_dist.rccl_unique_id()) if rank == 0 else None]
-    td.broadcast_object_list(ident, src=0)
-    r.connect(*ident[0])
+    # OMG_DIST_SHARED_GPU=1: every rank on GPU 0 — a REHEARSAL of the multi-process path (launcher, rendezvous, preflight,
+    # hipIpc peer mappings, flags between processes) where there is one GPU; RCCL cannot put two ranks on one device, so
+    # the exchanges are peer stores with wait launches and the norms are added over gloo.  Not a scaling measurement.
+    shared = os.environ.get("OMG_DIST_SHARED_GPU", "0") == "1" and world > 1
+
+    def reduce(squares):
+        t = torch.tensor(squares, dtype=torch.float64)
+        td.all_reduce(t)
+        return [float(v) for v in t]
+
+    run_cycles = (lambda n: r.cycles(n, reduce)) if shared else r.cycles
+    if shared:
+        handles = all_gather(r.p2p_handles())
+        for peer in range(world):
+            if peer != rank:
+                r.p2p_open(peer, handles[peer])
+        r.p2p_enable(2)
+    else:
+        ident = [(_hip_dist.rccl_unique_id(), _hip_dist.rccl_unique_id()) if rank == 0 else None]
+        td.broadcast_object_list(ident, src=0)
+        r.connect(*ident[0])
     r.load(b_loc)
     setup_s = time.perf_counter() - t_setup
     # ONE checked cycle: every rank's norm under a deadline, compared with rank 0's; a rank that hangs says where
     r.trace(True)
-    first_norm = preflight.run(rank, world, lambda: r.cycles(1)[0], all_gather, min(120.0, max(20.0, args.watchdog / 4.0)),
+    first_norm = preflight.run(rank, world, lambda: run_cycles(1)[0], all_gather, min(120.0, max(20.0, args.watchdog / 4.0)),
                                where=lambda: "cycle %d, level %d, last completed phase: %s" % r.progress())
     r.trace(False)
     # Peer mode (xGMI peer stores fused into the passes, no exchange launches): tried when every level has four planes
@@ -86,7 +104,10 @@ def main_plane(args, rank, world, shape, grids, n_levels, all_gather, td, torch,
     exchange = "RCCL grouped send/recv of ghost planes"
     p2p_note = "not tried"
     want = os.environ.get("OMG_DIST_P2P", "auto")
-    if want != "0" and (world > 1 or want == "1") and all((shape[0] >> l) // world >= 4 for l in range(n_levels)):
+    if shared:
+        exchange = "peer stores between PROCESSES SHARING ONE GPU (hipIpc mappings, wait launches): a rehearsal, not a scaling measurement"
+        p2p_note = "required (no RCCL between ranks on one device)"
+    elif want != "0" and (world > 1 or want == "1") and all((shape[0] >> l) // world >= 4 for l in range(n_levels)):
         def agree(ok):
             return all(all_gather(bool(ok)))
         try:
@@ -129,16 +150,16 @@ def main_plane(args, rank, world, shape, grids, n_levels, all_gather, td, torch,
     def timed_run():
         """From the loaded right-hand side: one cycle, the warm-up, the timed regions -> (times, every norm in order)."""
         r.load(b_loc)
-        trajectory = r.cycles(1)
+        trajectory = run_cycles(1)
         for _ in range(args.warmup):
-            trajectory += r.cycles(1)
+            trajectory += run_cycles(1)
         times_ = []
         for _ in range(max(1, getattr(args, "repeats", 1))):
             r.sync()
             torch.cuda.synchronize()
             td.barrier()
             t0 = time.perf_counter()
-            region = r.cycles(args.steps)                # K cycles back to back, every cycle's global norm computed
+            region = run_cycles(args.steps)              # K cycles back to back, every cycle's global norm computed
             r.sync()
             torch.cuda.synchronize()
             td.barrier()
@@ -149,7 +170,7 @@ def main_plane(args, rank, world, shape, grids, n_levels, all_gather, td, torch,
         return times_, trajectory
 
     times, trajectory = timed_run()
-    if r.p2p_mode:
+    if r.p2p_mode and not shared:
         # every norm of the timed peer-mode run against the same cycles over RCCL (untimed): a hand-over that went
         # wrong once in hundreds of cycles must not survive into the reported number
         r.p2p_enable(0)
@@ -168,7 +189,7 @@ def main_plane(args, rank, world, shape, grids, n_levels, all_gather, td, torch,
             times, trajectory = timed_run()
     region_norms = trajectory[-args.steps:]
     elapsed = statistics.median(times)
-    norm = r.cycles(1)[0]
+    norm = run_cycles(1)[0]
     rccl_ranks = r.rccl_ranks()
     if rank == 0:
         equiv = n_glob / float(256 ** 3)
@@ -189,7 +210,7 @@ def main_plane(args, rank, world, shape, grids, n_levels, all_gather, td, torch,
                                    % ("x".join(map(str, shape)), grids, world),
                        "unknowns": n_glob, "unknowns_per_gpu": n_loc, "nnz_per_gpu": nnz_loc, "grids": grids,
                        "distributed_grids": n_levels, "replicated_tail_grids": tgrids, "runner": "plane slabs (omg_pdist)",
-                       "exchange": exchange, "peer_mode": p2p_note,
+                       "exchange": exchange, "peer_mode": p2p_note, "ranks_share_one_gpu": bool(shared),
                        "rccl_ranks": rccl_ranks, "repeats": len(times), "preflight_norm": first_norm,
                        "kernel_src_sha": src_sha, "git_head": head,
                        "ms_per_step_all": [round(1e3 * t / args.steps, 4) for t in times],
@@ -244,6 +265,8 @@ def main(args):
     from . import _hip, _hip_dist, dist
 
     _hip.require_gpu()
+    if os.environ.get("OMG_DIST_SHARED_GPU", "0") == "1":
+        local = 0                                             # (rehearsal on one GPU: main_plane)
     torch.cuda.set_device(local)
     _hip_dist.set_device(local)
     # control plane (ids, barriers, timing max) over gloo; the data plane is RCCL inside

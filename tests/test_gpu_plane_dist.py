@@ -185,3 +185,23 @@ def test_peer_stores_between_processes(tmp_path, world, shape, grids, n_dist):
     assert np.array_equal(got, want), int(np.sum(got != want))
     for r in range(world):
         np.testing.assert_allclose(np.load(os.path.join(str(tmp_path), "rank%d.npz" % r))["norms"], want_norms, rtol=1e-13)
+
+
+def test_bench_gpus_2_rehearsal_on_one_gpu():
+    """`bench.py --gpus 2` end to end with both rank processes on this GPU (OMG_DIST_SHARED_GPU=1): the launcher, the
+    gloo rendezvous, the preflight cycle, hipIpc mappings between the ranks, peer-store exchanges, the JSON line."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, OMG_DIST_SHARED_GPU="1")
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--no-cpu", "--size", "64", "--steps", "4",
+                        "--warmup", "1", "--repeats", "1"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-3000:]
+    d = json.loads(p.stdout.strip().splitlines()[-1])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0 and d["steps"] == 4
+    c = d["config"]
+    assert c["ranks_share_one_gpu"] is True and c["runner"].startswith("plane slabs")
+    tail = c["norms_last_region_tail"]
+    assert all(np.isfinite(tail)) and tail[-1] < tail[0]
