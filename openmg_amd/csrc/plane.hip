@@ -21,6 +21,14 @@
 // workgroup waits for another; everything is out of place (x_old read, x_new written by the owner).
 // All global traffic of a step is issued at its top (the loads the NEXT step consumes, the stores
 // of what the previous step finished), so the one wait per step finds them done.
+//
+// What else lives here:
+//   * instantiations: PEER — a slab whose neighbours are reached by peer stores (PlanePlan::Peer, dist.hip); FIRST —
+//     the coarse level's first relaxation is written too (only when that level does not start from zero); MAXT /
+//     LA = 2 — small workgroups with two steps of lookahead; the loop runs two steps per iteration where the
+//     registers allow it, so that the step's parity is a compile-time constant;
+//   * block_kernel — levels of <= 64^3 cells below the finest: a block of the grid per workgroup, whole in LDS;
+//   * choose_tiles (two cost models) and PlanePlan::tune, which times their winners on the level's own vectors.
 #include <algorithm>
 #include <atomic>
 #include <cmath>
@@ -35,8 +43,8 @@ namespace {
 
 // cache policy of the x_new stores: 0 = plain; 16 = sc1 (write-through: the lines leave the XCD's L2 while the
 // kernel runs instead of in one write-back at its end — the 5-6 us gap behind every level-0 pass in the
-// trace); measured at 256^3: 134.6 / 124.2 us per pass and 388 us per cycle with sc1, 132.8 / 123.0 and 387
-// plain, nt (2) 131.6 / 124.4 and 389 — no difference worth a policy
+// trace); measured at 256^3 over whole cycles: plain 3276 V-cycles/s, nt (2) 3304, sc1 3254, sc0 | sc1 3136 —
+// no difference worth a policy
 #ifndef PLANE_STORE_AUX
 #define PLANE_STORE_AUX 0
 #endif
