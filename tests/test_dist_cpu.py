@@ -296,3 +296,18 @@ def test_preflight_norm_mismatch_between_ranks_is_fatal():
     for rank, (code, o, e) in enumerate(res):
         assert code == preflight.EXIT_MISMATCH, (rank, code, e)
         assert "differ between ranks after one cycle" in e and "[1]" in e
+
+
+def test_plane_levels_of_the_bench_shapes():
+    """Which levels bench.py --gpus N hands to the plane-slab runner: every one needs an even number (>= 2) of planes
+    per rank and even extents; the three bench shapes give three slab levels above a replicated 64^3 (N = 8) tail."""
+    from openmg_amd import dist_bench
+    for world, shape in dist_bench.SHAPES.items():
+        if world == 1:
+            continue
+        assert dist_bench.plane_levels(shape, world, 4) == 3, (world, shape)
+    assert dist_bench.plane_levels((512, 512, 512), 8, 7) == 6          # 64, 32, 16, 8, 4, 2 planes per rank: all n_dist - 1 levels
+    assert dist_bench.plane_levels((512, 512, 512), 8, 8) == 6          # ... and ONE plane per rank is not a slab
+    assert dist_bench.plane_levels((24, 16, 16), 4, 4) == 1             # 6 planes per rank, then 3: odd
+    assert dist_bench.plane_levels((20, 16, 16), 8, 4) == 0             # 20 planes do not divide over 8 ranks
+    assert dist_bench.plane_levels((32, 30, 32), 2, 4) == 1             # 30 lines, then 15: odd extents stop it
