@@ -116,6 +116,14 @@ __device__ __forceinline__ void bstore2(__amdgpu_buffer_rsrc_t rs, int off, cons
         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v.x), rs, off, 0, AUX);
     }
 }
+template <int AUX>
+__device__ __forceinline__ void bstore1(__amdgpu_buffer_rsrc_t rs, int off, double v) {
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, v), rs, off, 0, AUX);
+}
+template <int AUX>
+__device__ __forceinline__ void bstore1(__amdgpu_buffer_rsrc_t rs, int off, float v) {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs, off, 0, AUX);
+}
 constexpr int PEER_PLANES = 3, PEER_CPLANES = 2;   // boundary planes of x / of the coarse right-hand side a neighbour takes (a chunk holds at least four planes)
 constexpr int PEER_AUX = 1 | 16;     // stores into a neighbour's memory: through this GPU's caches, acknowledged when they are out
 template <typename V>
@@ -432,8 +440,11 @@ __global__ __launch_bounds__(MAXT) void plane_kernel(const PlaneKArgs<V> a) {
                 V *pb = a.peer_bc[side];
                 int sh = side == 0 ? a.peer_cshift : -a.peer_cshift;
                 asm volatile("" : "+s"(pb), "+s"(sh));
-                if (sl.x >= 0) __hip_atomic_store(pb + (sl.x + sh), co.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                if (sl.y >= 0) __hip_atomic_store(pb + (sl.y + sh), co.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                // (through a buffer descriptor with 32-bit offsets, like the planes of x: 64-bit addresses per value
+                // cost this kernel forty registers)
+                const __amdgpu_buffer_rsrc_t pwb = __builtin_amdgcn_make_buffer_rsrc(pb, 0, a.cvec_bytes, 0x00020000);
+                bstore1<PEER_AUX>(pwb, sl.x >= 0 ? (sl.x + sh) * int(sizeof(V)) : OOB, co.x);
+                bstore1<PEER_AUX>(pwb, sl.y >= 0 ? (sl.y + sh) * int(sizeof(V)) : OOB, co.y);
             }
         }
     };
