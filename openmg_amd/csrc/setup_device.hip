@@ -325,7 +325,7 @@ template <bool FILL, int CAP>
 __global__ __launch_bounds__(RAP_WAVES * 64) void rap_aggregation_kernel(
     int64_t nc, const int32_t *rp, const int32_t *ri, const double *rv, const int32_t *ap, const int32_t *ai,
     const double *av, const int32_t *owner, const double *weight, int32_t *row_len, const int32_t *cp, int32_t *ci,
-    double *cv) {
+    double *cv, int32_t *stash_i, double *stash_v, int stash_k, int32_t *overflow) {
     __shared__ int s_key[RAP_WAVES][CAP];
     __shared__ double s_val[RAP_WAVES][CAP];
     __shared__ unsigned long long s_sort[RAP_WAVES][CAP / 2];     // (J << 32 | j) of the kept columns, then ranked
@@ -426,14 +426,36 @@ __global__ __launch_bounds__(RAP_WAVES * 64) void rap_aggregation_kernel(
         }
         const bool keep = head && sum != 0.0;
         const unsigned long long mask = __ballot(keep);
-        if (FILL && keep) {
+        if (keep) {
             const int pos = out_count + __popcll(mask & ((1ull << lane) - 1ull));
-            ci[dst0 + pos] = int32_t(J);
-            cv[dst0 + pos] = sum;
+            if (FILL) {
+                ci[dst0 + pos] = int32_t(J);
+                cv[dst0 + pos] = sum;
+            } else if (pos < stash_k) {
+                // the counting pass keeps what it has computed, stash_k entries per row: if every row fits, the second
+                // pass is a copy (rap_rows_kernel) instead of the same computation again
+                stash_i[I * stash_k + pos] = int32_t(J);
+                stash_v[I * stash_k + pos] = sum;
+            }
         }
         out_count += __popcll(mask);
     }
-    if (!FILL && lane == 0) row_len[I] = out_count;
+    if (!FILL && lane == 0) {
+        row_len[I] = out_count;
+        if (out_count > stash_k) atomicOr(overflow, 1);
+    }
+}
+
+// the rows the counting pass has kept, into CSR order (a lane per row: a few tens of contiguous bytes each way)
+__global__ void rap_rows_kernel(int64_t nc, int k, const int32_t *cp, const int32_t *si, const double *sv, int32_t *ci, double *cv) {
+    for (int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r < nc; r += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t src = r * k, dst = cp[r];
+        const int len = cp[r + 1] - cp[r];
+        for (int e = 0; e < len; ++e) {
+            ci[dst + e] = si[src + e];
+            cv[dst + e] = sv[src + e];
+        }
+    }
 }
 
 // true: C = (R A) R^T by the fused kernel; false: the operands do not qualify (the caller takes the two products)
@@ -444,11 +466,11 @@ bool rap_aggregation(const DevMat &R, const DevMat &A, omg_csr_result &C, hipStr
     }
     const int64_t nc = R.n_rows, n = A.n_rows;
     if (nc == 0 || n == 0 || R.nnz == 0) return false;
-    DevBuf<int32_t> owner(n), seen(n), flag(2);
+    DevBuf<int32_t> owner(n), seen(n), flag(3);
     DevBuf<double> weight(n);
     OMG_HIP(hipMemsetAsync(owner.p, 0xff, size_t(n) * sizeof(int32_t), s));
     OMG_HIP(hipMemsetAsync(seen.p, 0, size_t(n) * sizeof(int32_t), s));
-    OMG_HIP(hipMemsetAsync(flag.p, 0, 2 * sizeof(int32_t), s));
+    OMG_HIP(hipMemsetAsync(flag.p, 0, 3 * sizeof(int32_t), s));
     hipLaunchKernelGGL(column_owner_kernel, dim3(grid1d(nc)), dim3(256), 0, s, nc, R.indptr.p, R.indices.p, R.data.p, owner.p,
                        weight.p, seen.p);
     hipLaunchKernelGGL(rap_check_kernel, dim3(grid1d(n)), dim3(256), 0, s, n, nc, seen.p, A.indptr.p, A.indices.p, R.indptr.p,
@@ -464,10 +486,16 @@ bool rap_aggregation(const DevMat &R, const DevMat &A, omg_csr_result &C, hipStr
     const dim3 grid(unsigned((nc + RAP_WAVES - 1) / RAP_WAVES)), block(RAP_WAVES * 64);
     // the hash table is sized by the longest aggregate (the compaction walks every slot)
     const int cap = h_flag[1] <= 64 ? 128 : h_flag[1] <= 128 ? 256 : RAP_CAP;
+    // what the counting pass keeps per row: about a fine row's length, which is what a Galerkin row of a grid stencil
+    // under 2^d aggregation has (7 -> 8, 27 -> 32 entries; longer rows: the second pass computes again)
+    const int stash_k = std::min(32, ((int(h_flag[1]) + 7) / 8 + 7) / 8 * 8);
+    DevBuf<int32_t> stash_i(size_t(nc) * size_t(stash_k));
+    DevBuf<double> stash_v(size_t(nc) * size_t(stash_k));
     auto pass = [&](bool fill) {
 #define OMG_RAP_LAUNCH(F, CAPV)                                                                                              \
         hipLaunchKernelGGL((rap_aggregation_kernel<F, CAPV>), grid, block, 0, s, nc, R.indptr.p, R.indices.p, R.data.p,        \
-                           A.indptr.p, A.indices.p, A.data.p, owner.p, weight.p, row_len.p, C.indptr.p, C.indices.p, C.data.p)
+                           A.indptr.p, A.indices.p, A.data.p, owner.p, weight.p, row_len.p, C.indptr.p, C.indices.p, C.data.p,  \
+                           stash_i.p, stash_v.p, stash_k, flag.p + 2)
         if (fill) { if (cap == 128) OMG_RAP_LAUNCH(true, 128); else if (cap == 256) OMG_RAP_LAUNCH(true, 256); else OMG_RAP_LAUNCH(true, RAP_CAP); }
         else { if (cap == 128) OMG_RAP_LAUNCH(false, 128); else if (cap == 256) OMG_RAP_LAUNCH(false, 256); else OMG_RAP_LAUNCH(false, RAP_CAP); }
 #undef OMG_RAP_LAUNCH
@@ -477,7 +505,11 @@ bool rap_aggregation(const DevMat &R, const DevMat &A, omg_csr_result &C, hipStr
     C.nnz = device_row_pointers(nc, row_len.p, C.indptr.p, s);
     C.indices.alloc(std::max<int64_t>(C.nnz, 1));
     C.data.alloc(std::max<int64_t>(C.nnz, 1));
-    pass(true);
+    int32_t overflow = 0;
+    OMG_HIP(hipMemcpyAsync(&overflow, flag.p + 2, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    OMG_HIP(hipStreamSynchronize(s));
+    if (overflow) pass(true);                                        // some row is longer than the stash: the computation again
+    else hipLaunchKernelGGL(rap_rows_kernel, dim3(grid1d(nc)), dim3(256), 0, s, nc, stash_k, C.indptr.p, stash_i.p, stash_v.p, C.indices.p, C.data.p);
     OMG_HIP(hipGetLastError());
     OMG_HIP(hipStreamSynchronize(s));
     return true;
