@@ -374,6 +374,7 @@ int omg_pdist_cycles(omg_pdist *d, int n_cycles, double *norms /* nullable */);
  * (ranks sharing a GPU); 0: back to RCCL.  Every distributed level needs >= 4 planes per rank.  A wait that gives up
  * (OMG_P2P_SPIN polls, default 2^21) sets bit 0 of omg_pdist_p2p_status and lets the device run on.
  * omg_pdist_cycles_squares: the cycles without the norm's collective — this rank's sums of squared residuals. */
+int omg_peer_access(int device, int peer_device, int *can);     /* hipDeviceCanAccessPeer (same device: 1): ask before mapping */
 int omg_pdist_p2p_handle_count(omg_pdist *d, int *count);
 int omg_pdist_p2p_handles(omg_pdist *d, void *handles64, int capacity);
 int omg_pdist_p2p_open(omg_pdist *d, int peer_rank, const void *handles64, int count);

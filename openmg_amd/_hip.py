@@ -108,6 +108,7 @@ SIGNATURES = {
     "omg_pdist_destroy": (_I, [_P]),
     "omg_pdist_set_tail": (_I, [_P, _P]),
     "omg_pdist_connect": (_I, [_P, _P, _P]),
+    "omg_peer_access": (_I, [_I, _I, _P]),
     "omg_pdist_p2p_handle_count": (_I, [_P, _P]),
     "omg_pdist_p2p_handles": (_I, [_P, _P, _I]),
     "omg_pdist_p2p_open": (_I, [_P, _I, _P, _I]),

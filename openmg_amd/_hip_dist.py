@@ -7,6 +7,13 @@ import scipy.sparse as sp
 from ._hip import DistLevelView, as_csr, check, csr_view, dtype_code, lib, smoother_code, vec
 
 
+def peer_access(device, peer_device):
+    """Can `device` address `peer_device`'s memory?  (asked before peer mode maps anything)"""
+    can = ctypes.c_int(0)
+    check(lib().omg_peer_access(int(device), int(peer_device), ctypes.byref(can)))
+    return bool(can.value)
+
+
 def set_device(device):
     check(lib().omg_set_device(int(device)))
 

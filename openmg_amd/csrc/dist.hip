@@ -1789,6 +1789,19 @@ static void pd_attach(PlaneDist *d, int peer_rank, const std::vector<void *> &bu
     }
 }
 
+/* Can `device` address `peer_device`'s memory (hipDeviceCanAccessPeer; the same device: yes)?  Asked BEFORE peer mode
+ * is tried: a store through a mapping the hardware cannot serve is a memory fault, not an error code. */
+int omg_peer_access(int device, int peer_device, int *can) {
+    return guarded([&] {
+        OMG_REQUIRE(can, "null argument");
+        *can = 0;
+        if (device == peer_device) { *can = 1; return; }
+        int c = 0;
+        OMG_HIP(hipDeviceCanAccessPeer(&c, device, peer_device));
+        *can = c;
+    });
+}
+
 int omg_pdist_p2p_handle_count(omg_pdist *d, int *count) {
     return guarded([&] {
         OMG_REQUIRE(d && d->d && count, "null argument");

@@ -110,8 +110,13 @@ def main_plane(args, rank, world, shape, grids, n_levels, all_gather, td, torch,
     elif want != "0" and (world > 1 or want == "1") and all((shape[0] >> l) // world >= 4 for l in range(n_levels)):
         def agree(ok):
             return all(all_gather(bool(ok)))
+        devices = all_gather(int(torch.cuda.current_device()))
         try:
-            mine = r.p2p_handles()
+            # (asked first: a store through a mapping the hardware cannot serve is a memory fault, not an exception)
+            reach = all(_hip_dist.peer_access(devices[rank], devices[peer]) for peer in range(world) if peer != rank)
+            mine = r.p2p_handles() if reach else None
+            if not reach:
+                p2p_note = "rank %d's GPU cannot address every other rank's memory (hipDeviceCanAccessPeer)" % rank
         except Exception as e:                                  # noqa: BLE001 - any failure means "stay with RCCL"
             mine, p2p_note = None, "export failed on rank %d: %s" % (rank, e)
         handles = all_gather(mine)
