@@ -57,27 +57,32 @@ template <typename T>
 struct DevBuf {
     T *p = nullptr;
     size_t n = 0;
+    size_t shift = 0;
     DevBuf() = default;
     explicit DevBuf(size_t count) { alloc(count); }
     DevBuf(const DevBuf &) = delete;
     DevBuf &operator=(const DevBuf &) = delete;
-    DevBuf(DevBuf &&o) noexcept : p(o.p), n(o.n) { o.p = nullptr; o.n = 0; }
+    DevBuf(DevBuf &&o) noexcept : p(o.p), n(o.n), shift(o.shift) { o.p = nullptr; o.n = 0; o.shift = 0; }
     DevBuf &operator=(DevBuf &&o) noexcept {
-        if (this != &o) { release(); p = o.p; n = o.n; o.p = nullptr; o.n = 0; }
+        if (this != &o) { release(); p = o.p; n = o.n; shift = o.shift; o.p = nullptr; o.n = 0; o.shift = 0; }
         return *this;
     }
     ~DevBuf() { release(); }
-    void alloc(size_t count) {
+    // shift (bytes, a multiple of 64): the vector starts that much further into its allocation — large vectors that a
+    // kernel streams side by side are staggered so that they do not walk the memory channels in lockstep
+    void alloc(size_t count, size_t shift_bytes = 0) {
         release();
         n = count;
         char *raw = nullptr;
-        OMG_HIP(hipMalloc(reinterpret_cast<void **>(&raw), count * sizeof(T) + 2 * DEVBUF_SLACK));
-        p = reinterpret_cast<T *>(raw + DEVBUF_SLACK);
+        OMG_HIP(hipMalloc(reinterpret_cast<void **>(&raw), count * sizeof(T) + 2 * DEVBUF_SLACK + shift_bytes));
+        shift = shift_bytes;
+        p = reinterpret_cast<T *>(raw + DEVBUF_SLACK + shift_bytes);
     }
     void release() {
-        if (p) (void)hipFree(reinterpret_cast<char *>(p) - DEVBUF_SLACK);
+        if (p) (void)hipFree(reinterpret_cast<char *>(p) - DEVBUF_SLACK - shift);
         p = nullptr;
         n = 0;
+        shift = 0;
     }
     void upload(const T *host, size_t count, hipStream_t s) {
         if (count) OMG_HIP(hipMemcpyAsync(p, host, count * sizeof(T), hipMemcpyHostToDevice, s));
@@ -87,6 +92,16 @@ struct DevBuf {
     }
     void zero(hipStream_t s) { if (n) OMG_HIP(hipMemsetAsync(p, 0, n * sizeof(T), s)); }
 };
+
+// The vectors a plane pass streams side by side (x_old, x_new, b: plane.hip) start k * 256 bytes into their allocations
+// (hipMalloc returns them all at the same offset of a 2 MiB page, so at every index they would otherwise sit on the
+// same memory channel): measured at 256^3 over five processes each, down pass 103.4-104.1 us in four of five with
+// 256 bytes against 106-111 us (two populations) with 0, 128, 512, 1 Ki, 2 Ki, 4 Ki, 64 Ki or 1 Mi.  OMG_VEC_STAGGER
+// overrides the 256.
+inline size_t vector_stagger(int k) {
+    static const long bytes = [] { const char *e = getenv("OMG_VEC_STAGGER"); return e ? atol(e) : 256L; }();
+    return size_t(bytes > 0 ? bytes : 0) / 64 * 64 * size_t(k);
+}
 
 // ---- host-side CSR (setup only) -----------------------------------------------------
 // Allocator whose construct() default-initialises: resize() of a vector of ints / doubles then

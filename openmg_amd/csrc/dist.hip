@@ -1327,7 +1327,7 @@ std::unique_ptr<PlaneDist> pd_create(int rank, int n_ranks, int nx, int ny, int 
         double c[7];
         for (int e = 0; e < 7; ++e) c[e] = coef7[7 * l + e];
         L.plan.build_slab(lx, ly, lz, PD_GHOST, PD_GHOST, rank == 0, rank == n_ranks - 1, c, w);
-        L.x.alloc(size_t(L.n_ext)); L.tmp.alloc(size_t(L.n_ext)); L.b.alloc(size_t(L.n_ext));
+        L.x.alloc(size_t(L.n_ext)); L.tmp.alloc(size_t(L.n_ext), vector_stagger(1)); L.b.alloc(size_t(L.n_ext), vector_stagger(2));
         L.x.zero(d->stream); L.tmp.zero(d->stream); L.b.zero(d->stream);
         L.xp = L.x.p; L.tp = L.tmp.p;
         lx /= 2; ly /= 2; lz /= 2;
@@ -1772,9 +1772,14 @@ int omg_pdist_rccl_ranks(omg_pdist *d, int *count) {
  * then omg_pdist_p2p_enable(mode): 1 = the passes wait for their neighbours' flags themselves (one GPU per rank),
  * 2 = a one-workgroup wait launch before each pass (ranks that share a GPU: a pass that waited itself would hold the
  * compute units the neighbour's pass needs), 0 = back to RCCL.  Needs >= 4 planes per rank on every level. */
-static void pd_own_buffers(PlaneDist *d, std::vector<void *> &out) {
+// (with how far each vector starts into its allocation: common.h vector_stagger — the same on every rank)
+static void pd_own_buffers(PlaneDist *d, std::vector<void *> &out, std::vector<size_t> *shift = nullptr) {
     out = {d->flags.p, d->full_b.p, d->full_b2.p};
-    for (PDLevel &L : d->lv) { out.push_back(L.x.p); out.push_back(L.tmp.p); out.push_back(L.b.p); }
+    if (shift) *shift = {d->flags.shift, d->full_b.shift, d->full_b2.shift};
+    for (PDLevel &L : d->lv) {
+        out.push_back(L.x.p); out.push_back(L.tmp.p); out.push_back(L.b.p);
+        if (shift) { shift->push_back(L.x.shift); shift->push_back(L.tmp.shift); shift->push_back(L.b.shift); }
+    }
 }
 static void pd_attach(PlaneDist *d, int peer_rank, const std::vector<void *> &bufs) {
     PDPeer &P = d->peers[size_t(peer_rank)];
@@ -1814,12 +1819,13 @@ int omg_pdist_p2p_handles(omg_pdist *d, void *handles64, int capacity) {
         OMG_REQUIRE(d && d->d && handles64, "null argument");
         static_assert(sizeof(hipIpcMemHandle_t) == 64, "IPC handle size");
         std::vector<void *> bufs;
-        pd_own_buffers(d->d.get(), bufs);
+        std::vector<size_t> shift;
+        pd_own_buffers(d->d.get(), bufs, &shift);
         OMG_REQUIRE(capacity >= int(bufs.size()), "handle buffer too small");
         OMG_HIP(hipStreamSynchronize(d->d->stream));
         for (size_t i = 0; i < bufs.size(); ++i) {
             hipIpcMemHandle_t h;
-            OMG_HIP(hipIpcGetMemHandle(&h, static_cast<char *>(bufs[i]) - DEVBUF_SLACK));     // (the allocation's base)
+            OMG_HIP(hipIpcGetMemHandle(&h, static_cast<char *>(bufs[i]) - DEVBUF_SLACK - shift[i]));     // (the allocation's base)
             std::memcpy(static_cast<char *>(handles64) + 64 * i, &h, 64);
         }
     });
@@ -1833,14 +1839,16 @@ int omg_pdist_p2p_open(omg_pdist *d, int peer_rank, const void *handles64, int c
         OMG_REQUIRE(count == 3 + 3 * int(dd->lv.size()), "handle count does not match the levels");
         PDPeer &P = dd->peers[size_t(peer_rank)];
         OMG_REQUIRE(P.mapped.empty(), "peer already opened");
-        std::vector<void *> bufs;
+        std::vector<void *> bufs, own;
+        std::vector<size_t> shift;
+        pd_own_buffers(dd, own, &shift);                      // (the peer's vectors sit in their allocations as mine do)
         for (int i = 0; i < count; ++i) {
             hipIpcMemHandle_t h;
             std::memcpy(&h, static_cast<const char *>(handles64) + 64 * i, 64);
             void *base = nullptr;
             OMG_HIP(hipIpcOpenMemHandle(&base, h, hipIpcMemLazyEnablePeerAccess));
             P.mapped.push_back(base);
-            bufs.push_back(static_cast<char *>(base) + DEVBUF_SLACK);
+            bufs.push_back(static_cast<char *>(base) + DEVBUF_SLACK + shift[size_t(i)]);
         }
         pd_attach(dd, peer_rank, bufs);
     });

@@ -678,6 +678,7 @@ void ensure_format(Hier<V> *h, int l) {
 template <typename V>
 void ensure_format(const Hier<V> *h, int l) { ensure_format(const_cast<Hier<V> *>(h), l); }
 
+
 template <typename V>
 std::unique_ptr<Hier<V>> create(int n_levels, const omg_csr *A, const omg_csr *R, int smoother,
                                 double omega) {
@@ -778,12 +779,12 @@ std::unique_ptr<Hier<V>> create(int n_levels, const omg_csr *A, const omg_csr *R
                 L.r_out.upload(co.inv.data(), co.inv.size(), h->stream);
                 OMG_HIP(hipStreamSynchronize(h->stream));
             }
-            if (L.plane) L.tmp.alloc(L.n);
+            if (L.plane) L.tmp.alloc(L.n, vector_stagger(1));
             if (L.plane && !getenv_flag0("OMG_PLANE_LAZY")) L.format_pending = true;
             else build_format(h.get(), l, A[l], R[l]);
         }
         L.x.alloc(std::max<int64_t>(L.n, 1));
-        L.b.alloc(std::max<int64_t>(L.n, 1));
+        L.b.alloc(std::max<int64_t>(L.n, 1), L.plane ? vector_stagger(2) : 0);
         L.xp = L.x.p;
         L.tp = L.tmp.p;
     }

@@ -41,12 +41,12 @@
 namespace omg {
 namespace {
 
-// cache policy of the x_new stores: 0 = plain; 16 = sc1 (write-through: the lines leave the XCD's L2 while the
+// cache policy of the x_new stores: 0 = plain; 2 = nt; 16 = sc1 (write-through: the lines leave the XCD's L2 while the
 // kernel runs instead of in one write-back at its end — the 5-6 us gap behind every level-0 pass in the
-// trace); measured at 256^3 over whole cycles: plain 3276 V-cycles/s, nt (2) 3304, sc1 3254, sc0 | sc1 3136 —
-// no difference worth a policy
+// trace); measured at 256^3 over whole cycles: plain 3276 V-cycles/s, nt 3304, sc1 3254, sc0 | sc1 3136; plain and
+// nt interleaved in one call, three times: nt ahead by 0.3-0.7 % each time (down pass -1 to -2 us): nt it is
 #ifndef PLANE_STORE_AUX
-#define PLANE_STORE_AUX 0
+#define PLANE_STORE_AUX 2
 #endif
 typedef unsigned v2u __attribute__((ext_vector_type(2)));
 typedef unsigned v4u __attribute__((ext_vector_type(4)));
