@@ -108,7 +108,8 @@ __device__ __forceinline__ void bstore2(__amdgpu_buffer_rsrc_t rs, int off, cons
         __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, v.x), rs, off, 0, AUX);
     }
 }
-template <int AUX = PLANE_STORE_AUX>
+// (float: plain stores — with nt the fp32 cycle dropped from 4890 to 4480 V-cycles/s; its stores are 8 bytes a lane)
+template <int AUX = 0>
 __device__ __forceinline__ void bstore2(__amdgpu_buffer_rsrc_t rs, int off, const P2<float> &v, bool both) {
     if (both) {
         __builtin_amdgcn_raw_buffer_store_b64(v2u{__builtin_bit_cast(unsigned, v.x), __builtin_bit_cast(unsigned, v.y)}, rs, off, 0, AUX);
