@@ -30,9 +30,12 @@
 //   * block_kernel — levels of <= 64^3 cells below the finest: a block of the grid per workgroup, whole in LDS;
 //   * choose_tiles (two cost models) and PlanePlan::tune, which times their winners on the level's own vectors.
 #include <algorithm>
+#include <array>
 #include <atomic>
 #include <cmath>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <thread>
 #include <type_traits>
 
@@ -141,6 +144,9 @@ __device__ __forceinline__ void store2(V *p, const P2<V> &v, bool both) {
 
 #ifndef PLANE_LA
 #define PLANE_LA 1
+#endif
+#ifndef PLANE_WAVE_SYNC
+#define PLANE_WAVE_SYNC 1            // 0: a workgroup barrier per step
 #endif
 constexpr int OOB = 0x7FFFFFF0;      // a byte offset behind every vector: the buffer's range check answers 0
 
@@ -321,6 +327,8 @@ __global__ __launch_bounds__(MAXT) void plane_kernel(const PlaneKArgs<V> a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char plane_smem[];
     V *const lds = reinterpret_cast<V *>(plane_smem);
     __shared__ double s_red[8];
+    __shared__ int s_step[8];            // per wave: steps finished (PLANE_WAVE_SYNC)
+    if (threadIdx.x < 8) s_step[threadIdx.x] = 0;
 
     const int PX = a.PX, PY = a.PY;
     const int S = 2 * PX + 4;                        // LDS row: guard pair, PX pairs, guard pair
@@ -755,7 +763,23 @@ __global__ __launch_bounds__(MAXT) void plane_kernel(const PlaneKArgs<V> a) {
             }
         }
         PLANE_STAMP(st_cmp)
-        __syncthreads();
+        if (PLANE_WAVE_SYNC) {
+            // A wave reads only LDS cells written by threads t +- 1 and t +- PX, i.e. by the waves within
+            // (PX + 63) / 64 of it: instead of a barrier of the whole workgroup — where eight waves waited for the
+            // slowest at every step: 1440 of a step's 7700 cycles — it publishes its progress and waits for those
+            // neighbours'.  The images are double buffered, so one wait per step covers both hazards: what a neighbour
+            // wrote for step s + 1 is there, and what it read for step s it has read.
+            const int cnt = s - s0 + 1, w = t >> 6, nw = int(blockDim.x) >> 6, reach = (PX + 63) >> 6;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            if ((t & 63) == 0) {
+                __hip_atomic_store(&s_step[w], cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                for (int o = max(0, w - reach); o <= min(nw - 1, w + reach); ++o)
+                    while (__hip_atomic_load(&s_step[o], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < cnt) __builtin_amdgcn_s_sleep(1);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        } else {
+            __syncthreads();
+        }
         PLANE_STAMP(st_bar)
     };
     if (LA == 2) {
@@ -1235,6 +1259,20 @@ void PlanePlan<V>::tune(V *x, V *tmp, const V *b, const Coarse &c, hipStream_t s
     choose_tiles(cand[1], sizeof(V), 1);
     if (cand[1].TX == g.TX && cand[1].TY == g.TY && cand[1].LZ == g.LZ) return;
     if (cand[1].TX <= 0 || cand[1].threads > 512) return;
+    // One decision per process and shape: the norm's partial sums follow the tiles, and two hierarchies of one process
+    // must not differ in its last bit because a timing came out the other way (where the candidates are close).
+    static std::mutex mu;
+    static std::map<std::array<int, 8>, int> decided;
+    const std::array<int, 8> key = {g.nx, g.ny, g.nz, g.z_base, g.z_end, int(sizeof(V)), finest ? 1 : 0, g.kv1 - g.kv0};
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        const auto it = decided.find(key);
+        if (it != decided.end()) {
+            g = cand[it->second];
+            partials.alloc(size_t(g.n_wg) + SUM_FOLD);
+            return;
+        }
+    }
     partials.alloc(size_t(std::max(cand[0].n_wg, cand[1].n_wg)) + SUM_FOLD);
     hipEvent_t e0, e1;
     OMG_HIP(hipEventCreate(&e0));
@@ -1259,6 +1297,10 @@ void PlanePlan<V>::tune(V *x, V *tmp, const V *b, const Coarse &c, hipStream_t s
     }
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        pick = decided.emplace(key, pick).first->second;
+    }
     g = cand[pick];
     partials.alloc(size_t(g.n_wg) + SUM_FOLD);
 }
