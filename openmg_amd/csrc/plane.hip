@@ -763,7 +763,8 @@ __global__ __launch_bounds__(MAXT) void plane_kernel(const PlaneKArgs<V> a) {
             }
         }
         PLANE_STAMP(st_cmp)
-        if (PLANE_WAVE_SYNC) {
+        // (double only: the fp32 passes were 10 % slower with it — 70 / 75.5 us against 63.5 / 68 with the barrier)
+        if (PLANE_WAVE_SYNC && sizeof(V) == 8) {
             // A wave reads only LDS cells written by threads t +- 1 and t +- PX, i.e. by the waves within
             // (PX + 63) / 64 of it: instead of a barrier of the whole workgroup — where eight waves waited for the
             // slowest at every step: 1440 of a step's 7700 cycles — it publishes its progress and waits for those
