@@ -95,7 +95,8 @@ def test_parity_ordering_is_the_greedy_colouring(monkeypatch):
             assert h.level_flags(0)["plane"] and h.level_sets(0) == 2
 
 
-@pytest.mark.parametrize("tile", ["4,2,2", "8,4,2", "8,2,4", "12,6,4", "16,8,8", "64,32,32", "32,8,2"])
+@pytest.mark.parametrize("tile", ["4,2,2", "8,4,2", "8,2,4", "12,6,4", "16,8,8", "64,32,32", "32,8,2",
+                                  "256,2,4", "128,22,26"])     # 66 threads per row: a wave's LDS neighbours are two waves away
 def test_plane_tilings_agree(monkeypatch, tile):
     """Every tiling — rings, partial tiles at the grid's edges, chunks of two planes — is the same
     arithmetic: same bits as the set schedule."""
