@@ -61,10 +61,11 @@ def kernel_source_hash():
 
 
 def git_head():
-    """Commit of the sources this line was measured on: OMG_GIT_HEAD (the GPU boxes have no .git) or git itself."""
-    head = os.environ.get("OMG_GIT_HEAD")
-    if head:
-        return head
+    """Commit of the sources this line was measured on: OMG_GIT_HEAD — its PRESENCE means "resolved", even empty (the
+    GPU boxes have no .git; no rank of a multi-GPU run forks git from a process that has initialised the GPU) — or
+    git itself."""
+    if "OMG_GIT_HEAD" in os.environ:
+        return os.environ["OMG_GIT_HEAD"] or None
     try:
         import subprocess
         return subprocess.check_output(["git", "-C", ROOT, "rev-parse", "HEAD"], text=True, stderr=subprocess.DEVNULL).strip()
@@ -301,6 +302,7 @@ def main():
     ap.add_argument("--no-plain", action="store_true", help="skip the plain-CSR (OMG_COMPRESS=0) leg")
     ap.add_argument("--no-sets", action="store_true", help="skip the set-by-set schedule (OMG_PLANE=0) leg")
     ap.add_argument("--no-lex", action="store_true", help="skip the leg with the reference's lexicographic Gauss-Seidel")
+    ap.add_argument("--no-dropin", action="store_true", help="skip the legs through the Python drop-in (mgCycle per call, mgSolve end to end)")
     ap.add_argument("--dist", type=int, default=0, help="force the multi-GPU code path even with one rank (debug)")
     ap.add_argument("--watchdog", type=int, default=900, help="multi-GPU: abort after this many seconds")
     ap.add_argument("--overlap", type=int, default=1,
@@ -421,7 +423,51 @@ def main():
                                       "nnz": fmt_cov["nnz"], "OMG_COMPRESS": os.environ.get("OMG_COMPRESS", "15 (default)")},
                     "rows_covered": rows_c, "nnz_covered": nnz_c, "fused_last_set": h.level_fused(0),
                     "level0_kernels": kernels}
+    # The reference's OWN parameter dict: preIterations 1, postIterations 0 (openmg/__init__.py:22-23), same hierarchy
+    # and loop: the up pass then runs without its relaxation (prolongation + correction + the norm's squares).
+    default_cycle = None
+    if plane and args.smoother == "colour":
+        h.resident_load(b)
+        t_d, _, n_d = timed_regions(h, syncer(h), args.steps, min(args.warmup, 3), min(repeats, 3), 1, 0, ())
+        e_d = statistics.median(t_d)
+        default_cycle = {"what": "same hierarchy and timed loop with the reference's default sweep counts V(1,0) "
+                                 "(openmg/__init__.py:22-23), red-black ordering, plane passes",
+                         "vcycles_per_s": round(args.steps / e_d, 3), "ms_per_step": round(1e3 * e_d / args.steps, 4),
+                         "ms_per_step_all": [round(1e3 * t / args.steps, 4) for t in t_d],
+                         "plane": bool(h.level_flags(0)["plane"]), "norms_last_region_tail": n_d[-3:]}
     h.close()
+
+    # What a caller of the DROP-IN pays (north star: "openmg.mg_cycle(A, b, ...) is a drop-in"): mgCycle is handed the
+    # A / R lists and host vectors on every call (openmg/__init__.py:151), mgSolve builds the hierarchy itself (:103-109).
+    dropin = None
+    if not args.no_dropin and args.smoother == "colour":
+        import numpy as np
+        import openmg_amd
+        A0, b_h, R_l, A_l = _PROBLEM[(args.size, args.grids)][:4]
+        prm = {"coarsestLevel": len(R_l), "preIterations": 1, "postIterations": 1, "smoother": "colour",
+               "dtype": np_dtype}
+        t0 = time.perf_counter()
+        x_d, info_d = openmg_amd.mgCycle(A_l, b_h, 0, R_l, prm)                  # first call: uploads the hierarchy
+        first_s = time.perf_counter() - t0
+        calls = []
+        for _ in range(4):
+            t0 = time.perf_counter()
+            x_d, info_d = openmg_amd.mgCycle(A_l, b_h, 0, R_l, prm, initial=x_d)
+            calls.append(time.perf_counter() - t0)
+        openmg_amd.clear_cache()
+        p_s = {"problemShape": (args.size,) * 3, "gridLevels": args.grids - 1, "cycles": 20, "threshold": 0,
+               "preIterations": 1, "postIterations": 1, "smoother": "colour", "dtype": np_dtype, "giveInfo": True}
+        t0 = time.perf_counter()
+        u_s, info_s = openmg_amd.mgSolve(A0, b_h, p_s)
+        solve_s = time.perf_counter() - t0
+        dropin = {"what": "openmg_amd.mgCycle(A, b, 0, R, parameters, initial) with the A / R lists and host vectors per call "
+                          "(cached device hierarchy, every byte of the lists checksummed per call, b and x over PCIe), and "
+                          "openmg_amd.mgSolve(A_in, b, parameters) for 20 cycles including its whole setup",
+                  "mgcycle_first_call_s": round(first_s, 3),
+                  "mgcycle_call_ms": round(1e3 * statistics.median(calls), 2),
+                  "mgcycle_call_ms_all": [round(1e3 * t, 2) for t in calls],
+                  "mgcycle_norm": info_d["norm"],
+                  "mgsolve_20_cycles_s": round(solve_s, 3), "mgsolve_norm": info_s["norm"], "mgsolve_cycles": info_s["cycle"]}
 
     def leg(env, smoother, what, reps, want_spmv):
         """The same problem and timed loop under other switches."""
@@ -531,6 +577,8 @@ def main():
                    "generate_s": round(generate_s, 2),
                    "kernel_src_sha": src_sha, "git_head": os.environ.get("OMG_GIT_HEAD") or None},
         "roofline": roofline,
+        "default_cycle": default_cycle,
+        "dropin": dropin,
         "set_schedule": set_path,
         "csr_path": csr_path,
         "reference_smoother": lex_path,

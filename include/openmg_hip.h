@@ -242,6 +242,12 @@ int omg_csr_result_free(omg_csr_result *res);
 int omg_restriction(int dim, const int64_t *shape, int32_t *indptr, int32_t *indices,
                     double *data, int64_t *n_rows, int64_t *nnz);
 
+/* Host-side helper of the mgCycle binding (no reference counterpart, no device involved): mgCycle(A, b, level, R,
+ * parameters, initial) — openmg/__init__.py:151 — is handed the operator lists on EVERY call; the binding keeps the
+ * device hierarchy between calls and recognises the lists by a checksum of every byte (an operator edited in place
+ * must not meet a stale device copy).  64-bit digest of buf[0..bytes), chunks hashed on all host threads.           */
+int omg_host_checksum(const void *buf, int64_t bytes, uint64_t *out);
+
 /* ---- multi-GPU: one process per GPU, 1-D slabs, RCCL halo exchange ---------------------------
  * No reference counterpart (the reference is single-threaded): the same
  * mgCycle (openmg/__init__.py:151-236) run on a row-partitioned hierarchy.  Each rank owns a

@@ -66,21 +66,11 @@ def _dtype_of(parameters):
 _cache = {}
 _CACHE_SLOTS = 2
 
-try:
-    from xxhash import xxh64_intdigest as _digest
-except ImportError:                                   # pragma: no cover - xxhash ships with the image
-    import zlib
-
-    def _digest(buf):
-        return zlib.crc32(buf)
-
-
 def _array_checksum(a):
-    """Checksum of the WHOLE array (xxhash runs at several GB/s: a 256^3 operator costs ~0.3 s per
-    mgCycle call, small next to the 0.4 GB it then ships over PCIe) — an in-place edit of a few
-    entries of a large operator must not hit the stale device copy."""
-    a = np.ascontiguousarray(a).reshape(-1)
-    return _digest(a.view(np.uint8))
+    """Checksum of the WHOLE array — an in-place edit of a few entries of a large operator must not hit
+    the stale device copy.  omg_host_checksum hashes 4 MiB chunks on all host threads (one Python thread
+    with xxhash: ~5 GB/s under the interpreter lock, 0.3 s per mgCycle call for a 256^3 operator)."""
+    return _hip.host_checksum(np.asarray(a))
 
 
 _csr_of = {}          # id(non-CSR sparse member) -> (weak reference, checksum of its own arrays, its CSR form)
@@ -90,8 +80,12 @@ def _as_csr_cached(M):
     """CSR form of a sparse member, converted once while the member lives and keeps its content."""
     if sp.isspmatrix_csr(M):
         return M
-    src = tuple(_array_checksum(getattr(M, name)) for name in ("data", "indices", "indptr", "row", "col", "offsets")
-                if isinstance(getattr(M, name, None), np.ndarray))
+    arrays = [getattr(M, name) for name in ("data", "indices", "indptr", "row", "col", "offsets")
+              if isinstance(getattr(M, name, None), np.ndarray)]
+    if not arrays or any(a.dtype.kind == "O" for a in arrays):
+        # LIL (object arrays of Python lists), DOK: no flat buffers to checksum — converted on every call (ADVICE r3)
+        return sp.csr_matrix(M)
+    src = tuple(_array_checksum(a) for a in arrays)
     entry = _csr_of.get(id(M))
     if entry is not None and entry[0]() is M and entry[1] == src:
         return entry[2]

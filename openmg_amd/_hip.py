@@ -95,6 +95,7 @@ SIGNATURES = {
     "omg_csr_result_fetch": (_I, [_P, _P, _P, _P]),
     "omg_csr_result_free": (_I, [_P]),
     "omg_restriction": (_I, [_I, _I64P, _P, _P, _P, _I64P, _I64P]),
+    "omg_host_checksum": (_I, [_P, ctypes.c_int64, ctypes.POINTER(ctypes.c_uint64)]),
     "omg_dist_create": (_I, [_I, _I, _I, _P, _CSR, _I64P, _I, _D, _PP]),
     "omg_dist_create_ex": (_I, [_I, _I, _I, _P, _CSR, _I64P, _I, _D, _I, _PP]),
     "omg_dist_destroy": (_I, [_P]),
@@ -210,6 +211,14 @@ def dtype_code(dtype):
     raise ValueError("dtype must be float64 or float32, not %r" % (dtype,))
 
 
+def host_checksum(a):
+    """64-bit digest of every byte of a NumPy array (omg_host_checksum: all host threads, no device)."""
+    a = np.ascontiguousarray(a)
+    out = ctypes.c_uint64(0)
+    check(lib().omg_host_checksum(a.ctypes.data, a.nbytes, ctypes.byref(out)))
+    return out.value
+
+
 def as_csr(A):
     """CSR with int32 index arrays / float64 data; stored column order is kept as is."""
     if not sp.isspmatrix_csr(A):
@@ -301,6 +310,12 @@ class Hierarchy:
         check(lib().omg_solve(self._h, b.ctypes.data, x.ctypes.data, int(pre), int(post), int(max_cycles),
                               float(threshold), ctypes.byref(cycles), ctypes.byref(norm)))
         return cycles.value, norm.value
+
+    def cycle_dev(self, b_dev, x_dev, pre, post, hip_stream=None):
+        """One cycle from a zero iterate on DEVICE vectors (addresses of level-0 doubles in natural numbering):
+        omg_hierarchy_cycle_dev, enqueued on `hip_stream` (None: the hierarchy's own), no host synchronisation."""
+        check(lib().omg_hierarchy_cycle_dev(self._h, ctypes.c_void_p(int(b_dev)), ctypes.c_void_p(int(x_dev)), int(pre), int(post),
+                                            ctypes.c_void_p(hip_stream or 0)))
 
     # -- resident ------------------------------------------------------------------------
     def resident_load(self, b, x0=None):

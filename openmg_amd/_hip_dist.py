@@ -269,11 +269,11 @@ class PlaneDistRank:
         else:
             check(lib().omg_pdist_cycles_squares(self._h, int(n_cycles), norms))
             out = [float(v) ** 0.5 for v in reduce([float(norms[k]) for k in range(int(n_cycles))])]
-        if self.p2p_mode:
-            status = self.p2p_status()
-            if status:
-                raise RuntimeError("rank %d: a wait for a neighbour's flag gave up (status %d): the peer-store exchanges "
-                                   "did not complete; the results of this batch are not valid" % (self.rank, status))
+        status = self.p2p_status()
+        if status:
+            raise RuntimeError("rank %d: a bounded wait inside a pass gave up (status %d: bit 0 a neighbour's flag — the "
+                               "peer-store exchanges did not complete —, bit 1 a neighbouring wave of a workgroup); the "
+                               "results of this batch are not valid" % (self.rank, status))
         return out
 
     # ---- peer mode (include/openmg_hip.h: omg_pdist_p2p_*) ----
@@ -337,8 +337,8 @@ class PlaneDistGroup:
         norms = (ctypes.c_double * max(int(n_cycles), 1))()
         check(lib().omg_pdist_group_cycles(self._g, int(n_cycles), norms))
         for r in self.ranks:
-            if r.p2p_mode and r.p2p_status():
-                raise RuntimeError("rank %d: a wait for a neighbour's flag gave up" % r.rank)
+            if r.p2p_status():
+                raise RuntimeError("rank %d: a bounded wait inside a pass gave up" % r.rank)
         return [float(norms[k]) for k in range(int(n_cycles))]
 
     def close(self):

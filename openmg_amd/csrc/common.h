@@ -517,6 +517,10 @@ template <typename V>
 struct PlanePlan {
     PlaneGeom g;
     DevBuf<double> partials;          // one per workgroup (+ SUM_FOLD): the up pass's share of ||b - A x||^2
+    // device word (not owned; null: none) in which a pass records that it gave up a bounded wait: bit 0 a neighbour
+    // GPU's flag (Peer::status overrides it), bit 1 a neighbouring wave of its own workgroup.  Whoever reads results
+    // back looks at it (hierarchy.hip check_march, omg_pdist_p2p_status)
+    uint32_t *status = nullptr;
     // false: the level does not qualify (the caller keeps the set-by-set schedule; ord untouched).  A, R:
     // the caller's CSR in natural numbering.  true: ord = the level's colour ordering, written in closed
     // form (parity colours, red first — what the greedy colouring of such a stencil gives, without its
@@ -562,9 +566,13 @@ struct PlanePlan {
     // Large levels: times the candidate tilings on these vectors (contents destroyed) and keeps the fastest
     // (OMG_PLANE_TUNE=0 / OMG_PLANE_TILE: no timing).
     void tune(V *x, V *tmp, const V *b, const Coarse &c, hipStream_t s, bool finest = true);
-    void down(const V *x_old, V *x_new, const V *b, bool x_zero, const Coarse &c, hipStream_t s, const Peer *peer = nullptr) const;
+    // sweep = false: the pass without its relaxation (a cycle with preIterations = 0 / postIterations = 0): down then
+    // leaves x_new untouched (the iterate stays in x_old), up writes x_new = x_old + R^T e
+    void down(const V *x_old, V *x_new, const V *b, bool x_zero, const Coarse &c, hipStream_t s, const Peer *peer = nullptr,
+              bool sweep = true) const;
     // out (nullable): block partials of the squared residual norm, g.n_wg doubles
-    void up(const V *x_old, V *x_new, const V *b, const Coarse &c, double *out, hipStream_t s, const Peer *peer = nullptr) const;
+    void up(const V *x_old, V *x_new, const V *b, const Coarse &c, double *out, hipStream_t s, const Peer *peer = nullptr,
+            bool sweep = true) const;
 };
 
 }  // namespace omg

@@ -1357,6 +1357,7 @@ std::unique_ptr<PlaneDist> pd_create(int rank, int n_ranks, int nx, int ny, int 
     d->norms.alloc(64);
     d->flags.alloc(size_t(PD_COUNT + std::max(n_ranks, 8)));
     d->flags.zero(d->stream);
+    for (PDLevel &L : d->lv) L.plan.status = d->flags.p + PD_STATUS;       // (bit 1: a wave gave up waiting for its neighbour wave)
     d->full_b2.alloc(size_t(cplane * lz * n_ranks));
     d->peers.resize(size_t(n_ranks));
     if (const char *e = getenv("OMG_P2P_SPIN")) d->spin = uint32_t(std::max(1L, atol(e)));
@@ -1893,7 +1894,8 @@ int omg_pdist_p2p_enable(omg_pdist *d, int mode) {
     });
 }
 
-/* bit 0: a wait for a neighbour's flag gave up since the last call (the results since then are not to be used) */
+/* bit 0: a wait for a neighbour's flag gave up since the last call (the results since then are not to be used);
+ * bit 1: a wave of a pass gave up waiting for a neighbouring wave of its own workgroup */
 int omg_pdist_p2p_status(omg_pdist *d, unsigned *status) {
     return guarded([&] {
         OMG_REQUIRE(d && d->d && status, "null argument");

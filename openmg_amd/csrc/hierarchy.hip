@@ -86,6 +86,7 @@ struct Hier {
     std::vector<Level<V>> lv;
     CoarseSolver<V> coarse;   // direct solve of the coarsest operator (common.h)
     DevBuf<double> norm_dev;
+    DevBuf<uint32_t> plane_status; // PlanePlan::status of every plane level: bit 1 = a wave gave up waiting for its neighbour wave
     DevBuf<double> norms_dev;      // omg_resident_cycles: one norm per cycle of the batch
     DevBuf<double> batch_partials; // ... and the block partials of up to 64 deferred norms
     int smoother = OMG_SMOOTH_GS_LEX;
@@ -375,10 +376,13 @@ void coarse_solve_level(Hier<V> *h) {
 // What a cycle leaves of the entry level's residual norm (openmg/__init__.py:227)
 enum NormState { NORM_NONE = 0, NORM_LAST_SET = 1, NORM_PLANE = 2 };
 
-// Do both halves of a cycle over this level run as plane-pipelined launches?
+// Do both halves of a cycle over this level run as plane-pipelined launches?  (Any sweep counts: with
+// pre = 0 or post = 0 — the reference's default is V(1,0), openmg/__init__.py:22-23 — the pass runs
+// without its relaxation.)
 template <typename V>
 bool use_plane(const Hier<V> *h, const Level<V> &L, int pre, int post) {
-    return L.plane && pre >= 1 && post >= 1 && !h->no_plane;
+    (void)pre; (void)post;
+    return L.plane && !h->no_plane;
 }
 
 // openmg/__init__.py:199-234 with the dead work removed: R[l]*b (:205-206) is computed by the
@@ -403,7 +407,7 @@ int cycle_body(Hier<V> *h, int l, int pre, int post, bool want_norm = false, dou
     Level<V> &C = h->lv[l + 1];
     // OMG_PLANE_HALVES=1|2 (debugging, not under hipGraph): only the down / only the up pass plane-pipelined
     static const int halves = [] { const char *e = getenv("OMG_PLANE_HALVES"); return (e && (e[0] == '1' || e[0] == '2')) ? e[0] - '0' : 3; }();
-    if (use_plane(h, L, pre, post) && halves == 2 && !x_zero) {
+    if (use_plane(h, L, pre, post) && halves == 2 && !x_zero && pre >= 1 && post >= 1) {
         const bool res_done = smooth_level(h, l, pre, FUSE_RESIDUAL, nullptr, first_done);
         residual_level(h, l, L.r.p, res_done);
         if (l + 1 < last) ensure_format(h, l + 1);
@@ -420,7 +424,7 @@ int cycle_body(Hier<V> *h, int l, int pre, int post, bool want_norm = false, dou
             return smooth_level(h, l, post - 1, want_norm ? FUSE_NORM : FUSE_NONE, nullptr, false, post_slot) ? NORM_LAST_SET : NORM_NONE;
         return out ? NORM_PLANE : NORM_NONE;
     }
-    if (use_plane(h, L, pre, post) && halves == 1) {
+    if (use_plane(h, L, pre, post) && halves == 1 && pre >= 1 && post >= 1) {
         if (pre > 1) smooth_level(h, l, pre - 1, FUSE_NONE, nullptr, first_done);
         if (l + 1 < last) ensure_format(h, l + 1);
         const bool child_first = l + 1 < last && first_sweep_in_restrict(h, C, pre);
@@ -440,7 +444,7 @@ int cycle_body(Hier<V> *h, int l, int pre, int post, bool want_norm = false, dou
         // :201 all but the last pre-smoothing sweep set by set (in place); the last one inside the down pass
         if (pre > 1) smooth_level(h, l, pre - 1, FUSE_NONE, nullptr, first_done);
         const bool child_plane = l + 1 < last && use_plane(h, C, pre, post);
-        const bool child_zero = child_plane && pre == 1 && halves == 3;       // the child's down pass never reads its zero iterate
+        const bool child_zero = child_plane && pre <= 1 && halves == 3;       // the child's down pass never reads its zero iterate
         if (l + 1 < last && !child_zero) ensure_format(h, l + 1);
         const bool child_first = l + 1 < last && !child_zero && first_sweep_in_restrict(h, C, pre);
         typename PlanePlan<V>::Coarse c;
@@ -449,17 +453,19 @@ int cycle_body(Hier<V> *h, int l, int pre, int post, bool want_norm = false, dou
         c.x = (l + 1 < last && !child_zero) ? C.xp : nullptr;
         c.diag = child_first ? C.diag.p : nullptr;
         c.first_end = child_first ? int(C.A.sets[1]) : 0;
+        // (pre = 0: the child's down pass does not write its iterate either, and its up pass reads it)
+        if (child_zero && pre == 0) OMG_HIP(hipMemsetAsync(C.xp, 0, size_t(C.n) * sizeof(V), h->stream));
         {
             Prof<V> p(h, l, 5);
-            L.plane->down(L.xp, L.tp, L.b.p, x_zero, c, h->stream);      // :201 (last sweep), :209, :210
+            L.plane->down(L.xp, L.tp, L.b.p, x_zero, c, h->stream, nullptr, pre >= 1);      // :201 (last sweep), :209, :210
         }
-        std::swap(L.xp, L.tp);
+        if (pre >= 1) std::swap(L.xp, L.tp);
         cycle_body(h, l + 1, pre, post, false, nullptr, child_first, nullptr, child_zero);   // :213
         c.e = C.xp;
-        double *out = (want_norm && post == 1) ? (post_slot ? post_slot : L.plane->partials.p) : nullptr;
+        double *out = (want_norm && post <= 1) ? (post_slot ? post_slot : L.plane->partials.p) : nullptr;
         {
             Prof<V> p(h, l, 6);
-            L.plane->up(L.xp, L.tp, L.b.p, c, out, h->stream);           // :214, :220/:224, first sweep of :216-222 (, :227)
+            L.plane->up(L.xp, L.tp, L.b.p, c, out, h->stream, nullptr, post >= 1);           // :214, :220/:224, first sweep of :216-222 (, :227)
         }
         std::swap(L.xp, L.tp);
         if (post > 1)
@@ -519,11 +525,26 @@ void load_vec(Hier<V> *h, int l, const double *host, V *dst) {
 // The wavefront sweeps give up waiting for a face after a bounded number of polls instead of
 // hanging the device; whoever reads results back asks whether that has happened.
 template <typename V>
-void check_march(Hier<V> *h) {
+void check_plane_status(Hier<V> *h, uint32_t st) {
+    if (!st) return;
+    OMG_HIP(hipMemsetAsync(h->plane_status.p, 0, sizeof(st), h->stream));
+    throw Error(OMG_ERR_HIP, "a plane-pipelined pass gave up waiting for a neighbouring wave of its workgroup (status " +
+                             std::to_string(st) + "): the results since the last read-back are not valid");
+}
+
+// (have_plane_status: the caller has already copied the plane passes' status word back with its own results)
+template <typename V>
+void check_march(Hier<V> *h, bool have_plane_status = false, uint32_t plane_st = 0) {
     for (Level<V> &L : h->lv)
         if (L.march && L.march->timed_out(h->stream))
             throw Error(OMG_ERR_HIP, "lexicographic wavefront sweep timed out waiting for a neighbouring tile's face; the iterate and "
                                      "the hand-over slots of this hierarchy are no longer consistent: destroy it and build a new one");
+    // the plane passes' waves wait for their neighbour waves a bounded number of polls (plane.hip WAVE_SYNC_SPIN)
+    if (h->plane_status.p && !have_plane_status) {
+        OMG_HIP(hipMemcpyAsync(&plane_st, h->plane_status.p, sizeof(plane_st), hipMemcpyDeviceToHost, h->stream));
+        OMG_HIP(hipStreamSynchronize(h->stream));
+    }
+    check_plane_status(h, plane_st);
 }
 
 template <typename V>
@@ -543,9 +564,11 @@ void fetch_vec(Hier<V> *h, int l, const V *src, double *host) {
 template <typename V>
 double read_norm(Hier<V> *h) {
     double v = 0.0;
+    uint32_t st = 0;
     OMG_HIP(hipMemcpyAsync(&v, h->norm_dev.p, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    if (h->plane_status.p) OMG_HIP(hipMemcpyAsync(&st, h->plane_status.p, sizeof(st), hipMemcpyDeviceToHost, h->stream));
     OMG_HIP(hipStreamSynchronize(h->stream));
-    check_march(h);
+    check_march(h, true, st);
     return v;
 }
 
@@ -749,6 +772,8 @@ std::unique_ptr<Hier<V>> create(int n_levels, const omg_csr *A, const omg_csr *R
             std::unique_ptr<PlanePlan<V>> plan(new PlanePlan<V>);
             L.march.reset();
             if (plan->build(A[l], R[l], L.ord)) {
+                if (!h->plane_status.p) { h->plane_status.alloc(1); h->plane_status.zero(h->stream); }
+                plan->status = h->plane_status.p;
                 L.plane = std::move(plan);
                 // OMG_PLANE_CHECK_ORDER=1 (tests): the closed-form ordering is the greedy colouring's
                 if (getenv_flag("OMG_PLANE_CHECK_ORDER")) {
@@ -1070,21 +1095,25 @@ int omg_hierarchy_cycle_dev(omg_hierarchy *h, const double *b_dev, double *x_dev
                 else launch_gather<double, V>(b_dev, perm, L.b.p, L.n, hh->stream);
                 bool first = false, zero_in = false;
                 if (hh->lv.size() > 1) {
-                    // x starts from zero: the first relaxation launch is a pointwise b / diag (restrict_level)
-                    if (!L.diag.p && pre > 0 && !getenv_flag("OMG_NO_FIRST_SWEEP")) {
-                        L.diag.alloc(std::max<int64_t>(L.n, 1));
-                        launch_diagonal(L.A, L.diag.p, hh->stream);
-                    }
                     zero_in = use_plane(hh, L, pre, post) && pre == 1;     // the down pass does not read a zero iterate
-                    if (!zero_in) ensure_format(hh, 0);
-                    first = !zero_in && first_sweep_in_restrict(hh, L, pre);
-                    if (zero_in) {
-                        // nothing to write
-                    } else if (first) {
-                        const bool jac = hh->smoother == OMG_SMOOTH_JACOBI;
-                        launch_first_relaxation<V>(L.b.p, L.diag.p, L.xp, L.n, jac ? L.n : L.A.sets[1], jac, hh->omega, hh->stream);
-                    } else {
-                        OMG_HIP(hipMemsetAsync(L.xp, 0, L.n * sizeof(V), hh->stream));
+                    if (!zero_in) {
+                        // x starts from zero: the first relaxation launch is a pointwise b / diag (restrict_level).  The
+                        // diagonal comes from the row-kernel format, which a plane level builds on first use: BEFORE it
+                        // (with the format still pending the diagonal stayed uninitialised)
+                        if (pre > 0) {
+                            ensure_format(hh, 0);
+                            if (!L.diag.p && !getenv_flag("OMG_NO_FIRST_SWEEP")) {
+                                L.diag.alloc(std::max<int64_t>(L.n, 1));
+                                launch_diagonal(L.A, L.diag.p, hh->stream);
+                            }
+                        }
+                        first = pre > 0 && first_sweep_in_restrict(hh, L, pre);
+                        if (first) {
+                            const bool jac = hh->smoother == OMG_SMOOTH_JACOBI;
+                            launch_first_relaxation<V>(L.b.p, L.diag.p, L.xp, L.n, jac ? L.n : L.A.sets[1], jac, hh->omega, hh->stream);
+                        } else {
+                            OMG_HIP(hipMemsetAsync(L.xp, 0, L.n * sizeof(V), hh->stream));
+                        }
                     }
                 }
                 cycle_body(hh, 0, pre, post, false, nullptr, first, nullptr, zero_in);
@@ -1140,7 +1169,7 @@ int omg_resident_cycles(omg_hierarchy *h, int pre, int post, int n_cycles, doubl
             if (n_cycles == 0) return;
             if (hh->norms_dev.n < size_t(n_cycles)) hh->norms_dev.alloc(size_t(n_cycles));
             const bool single = hh->lv.size() == 1;
-            if (!single && use_plane(hh, hh->lv[0], pre, post) && post == 1) {
+            if (!single && use_plane(hh, hh->lv[0], pre, post) && post <= 1) {
                 // every cycle's up pass leaves its workgroup partials in a slot of the batch buffer; one
                 // launch per chunk adds the slots up (the additions of launch_sum_sqrt: same bits as
                 // omg_resident_cycle)

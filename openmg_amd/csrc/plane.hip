@@ -148,6 +148,7 @@ __device__ __forceinline__ void store2(V *p, const P2<V> &v, bool both) {
 #ifndef PLANE_WAVE_SYNC
 #define PLANE_WAVE_SYNC 1            // 0: a workgroup barrier per step
 #endif
+constexpr unsigned WAVE_SYNC_SPIN = 1u << 22;     // polls of a neighbour wave's step count (~0.1 us each) before a wave gives up
 constexpr int OOB = 0x7FFFFFF0;      // a byte offset behind every vector: the buffer's range check answers 0
 
 template <typename V>
@@ -319,7 +320,10 @@ __global__ void plane_wait_kernel(const uint32_t *f0, const uint32_t *f1, const 
 // MAXT: the largest workgroup the instantiation is launched with (small tiles: more registers per lane, which LA = 2 needs)
 // FIRST (down): the coarse level's initial iterate is written too (zeros, or its first relaxation where a diagonal
 // is given) — not needed when the coarse level's own down pass takes its iterate as zero, the usual case
-template <typename V, int MODE, bool NORM, bool XZ, int LA, bool PEER = false, int MAXT = 512, bool FIRST = false>
+// SWEEP = false: the pass without its relaxation — a cycle with preIterations = 0 (down: residual of the iterate as
+// it is + restriction; x_new is not written) or postIterations = 0, the reference's default (openmg/__init__.py:22-23;
+// up: x_new = x_old + R^T e and the squares of ITS residual): the same pipeline, stages B and C form no quotient
+template <typename V, int MODE, bool NORM, bool XZ, int LA, bool PEER = false, int MAXT = 512, bool FIRST = false, bool SWEEP = true>
 __global__ __launch_bounds__(MAXT) void plane_kernel(const PlaneKArgs<V> a) {
 #ifdef OMG_PLANE_STAMPS
     const unsigned long long st_entry = __builtin_amdgcn_s_memtime();
@@ -608,7 +612,7 @@ __global__ __launch_bounds__(MAXT) void plane_kernel(const PlaneKArgs<V> a) {
             const V *const E3 = lds + (2 * 2 + par) * BUF;        // black, new, plane s - 2
             const bool pvB = s >= a.kv0 && s < a.kv1, pvC = s - 1 >= a.kv0 && s - 1 < a.kv1, pvD = s - 2 >= a.kv0 && s - 2 < a.kv1;
             // B: red sweep of plane s
-            {
+            if (SWEEP) {
                 const P2<V> jm = lds_pair(E1 + idx[0] - S), jp = lds_pair(E1 + idx[1] + S);
                 const P2<V> o0 = XB[1][0], o1 = XB[1][1];
                 V num[4], quo[4];
@@ -634,7 +638,7 @@ __global__ __launch_bounds__(MAXT) void plane_kernel(const PlaneKArgs<V> a) {
                     XR[0][l].y = act[2 * l + 1] ? XR[0][l].y + quo[2 * l + 1] : V(0);
                 }
             }
-            if (inner && s - 1 >= z0 && s - 1 < z1) {
+            if ((SWEEP || MODE == 1) && inner && s - 1 >= z0 && s - 1 < z1) {
                 // red of plane s - 1 became final in the previous step (stored here, not at the top: the
                 // vector memory pipe is busy with the step's loads there)
 #pragma unroll
@@ -665,9 +669,15 @@ __global__ __launch_bounds__(MAXT) void plane_kernel(const PlaneKArgs<V> a) {
                     act[2 * l] = pvC && vl[l] && vx0;
                     act[2 * l + 1] = pvC && vl[l] && vx1;
                 }
-                quotients(num, act, a.c3, rc3, fast, quo);
+                if (SWEEP) quotients(num, act, a.c3, rc3, fast, quo);
 #pragma unroll
                 for (int l = 0; l < 2; ++l) {
+                    if (!SWEEP) {
+                        // the row's residual with the iterate as it is: the chain above IS a residual pass's
+                        rb[l].x = act[2 * l] ? num[2 * l] : V(0);
+                        rb[l].y = act[2 * l + 1] ? num[2 * l + 1] : V(0);
+                        continue;
+                    }
                     const P2<V> Bv = BB[l], Kp = XR[0][l];
                     const V nx_ = act[2 * l] ? XB[2][l].x + quo[2 * l] : V(0);
                     const V ny_ = act[2 * l + 1] ? XB[2][l].y + quo[2 * l + 1] : V(0);
@@ -680,7 +690,7 @@ __global__ __launch_bounds__(MAXT) void plane_kernel(const PlaneKArgs<V> a) {
                     XB[2][l].y = ny_;
                 }
             }
-            if (inner && s - 2 >= z0 && s - 2 < z1) {
+            if ((SWEEP || MODE == 1) && inner && s - 2 >= z0 && s - 2 < z1) {
                 // black of plane s - 2 became final in the previous step
 #pragma unroll
                 for (int l = 0; l < 2; ++l)
@@ -774,8 +784,16 @@ __global__ __launch_bounds__(MAXT) void plane_kernel(const PlaneKArgs<V> a) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             if ((t & 63) == 0) {
                 __hip_atomic_store(&s_step[w], cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                // a bounded wait, like the peer waits and the wavefront sweep's polls: a wave that never arrives (it
+                // cannot, short of a fault) sets bit 1 of *status — the host raises — instead of hanging the queue
                 for (int o = max(0, w - reach); o <= min(nw - 1, w + reach); ++o)
-                    while (__hip_atomic_load(&s_step[o], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < cnt) __builtin_amdgcn_s_sleep(1);
+                    for (unsigned polls = 0; __hip_atomic_load(&s_step[o], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < cnt; ++polls) {
+                        if (polls >= WAVE_SYNC_SPIN) {
+                            if (a.status) __hip_atomic_fetch_or(a.status, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            break;
+                        }
+                        __builtin_amdgcn_s_sleep(1);
+                    }
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         } else {
@@ -863,7 +881,8 @@ __device__ __forceinline__ float block_quotient(float n, float c, float, bool) {
 
 // BX, BY, BZ as template parameters: every index of the stages is then a division by a constant and every loop has a
 // known trip count (with run-time block extents the integer divisions alone cost more than the marching kernel)
-template <typename V, int MODE, int BX, int BY, int BZ>
+// SWEEP = false: the pass of a cycle without pre- / post-smoothing (down: the residual of a zero iterate is b itself)
+template <typename V, int MODE, int BX, int BY, int BZ, bool SWEEP = true>
 __global__ __launch_bounds__(256) void block_kernel(const BlockKArgs<V> a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char plane_smem[];
     constexpr int EX = BX + 4, EY = BY + 4, EZ = BZ + 4, vol = EX * EY * EZ;
@@ -974,10 +993,12 @@ __global__ __launch_bounds__(256) void block_kernel(const BlockKArgs<V> a) {
     typedef std::integral_constant<int, 2> R2;
     constexpr int NB = (BX * BY * BZ + NT - 1) / NT;
     if (MODE == 0) {
-        sweep(0, R2(), std::true_type());
-        __syncthreads();
-        sweep(1, R1(), std::false_type());
-        __syncthreads();
+        if (SWEEP) {
+            sweep(0, R2(), std::true_type());
+            __syncthreads();
+            sweep(1, R1(), std::false_type());
+            __syncthreads();
+        }
         // the block's cells: the new iterate out, the residual kept for the restriction
 #pragma unroll
         for (int n = 0; n < NB; ++n) {
@@ -987,7 +1008,7 @@ __global__ __launch_bounds__(256) void block_kernel(const BlockKArgs<V> a) {
             if (c >= BX * BY * BZ || gi >= a.nx || gj >= a.ny || gk >= a.nz) continue;
             const int l = (lk * EY + lj) * EX + li;
             E[c] = B[l] - row(l);
-            a.x_new[slot_of(gi, gj, gk)] = X[l];
+            if (SWEEP) a.x_new[slot_of(gi, gj, gk)] = X[l];
         }
         __syncthreads();
         // openmg/__init__.py:210: a coarse cell's eight fine residuals in column order
@@ -1003,10 +1024,12 @@ __global__ __launch_bounds__(256) void block_kernel(const BlockKArgs<V> a) {
             a.bc[cs[n]] = acc;
         }
     } else {
-        sweep(0, R1(), std::false_type());
-        __syncthreads();
-        sweep(1, R0(), std::false_type());
-        __syncthreads();
+        if (SWEEP) {
+            sweep(0, R1(), std::false_type());
+            __syncthreads();
+            sweep(1, R0(), std::false_type());
+            __syncthreads();
+        }
 #pragma unroll
         for (int n = 0; n < NB; ++n) {
             const int c = t + n * NT;
@@ -1371,7 +1394,7 @@ HostCsr PlanePlan<V>::restriction_csr() const {
 namespace {
 
 template <typename V>
-PlaneKArgs<V> plane_args(const PlaneGeom &g, const V *x_old, V *x_new, const V *b, const typename PlanePlan<V>::Coarse &c) {
+PlaneKArgs<V> plane_args(const PlaneGeom &g, const V *x_old, V *x_new, const V *b, const typename PlanePlan<V>::Coarse &c, uint32_t *status) {
     PlaneKArgs<V> k;
     std::memset(&k, 0, sizeof(k));
     const int64_t n = int64_t(g.nx) * g.ny * g.nz;
@@ -1390,6 +1413,7 @@ PlaneKArgs<V> plane_args(const PlaneGeom &g, const V *x_old, V *x_new, const V *
     k.cmap_bytes = unsigned(nc * 4);
     k.cmap = c.map;
     k.bc = c.b; k.xc = c.x; k.cdiag = c.diag; k.first_end = c.first_end; k.ec = c.e;
+    k.status = status;
     return k;
 }
 
@@ -1472,13 +1496,13 @@ inline BlockGeom choose_block(const PlaneGeom &g, size_t value_bytes) {
     k.lds = (2 * vol + std::max(size_t(k.BX) * k.BY * k.BZ, vol / 8)) * value_bytes;
     return k;
 }
-template <typename V, int MODE, int S>
+template <typename V, int MODE, int S, bool SWEEP>
 void launch_block_shape(const BlockGeom &k, const BlockKArgs<V> &a, hipStream_t s) {
-    auto kernel = block_kernel<V, MODE, BLOCK_SHAPES[S][0], BLOCK_SHAPES[S][1], BLOCK_SHAPES[S][2]>;
+    auto kernel = block_kernel<V, MODE, BLOCK_SHAPES[S][0], BLOCK_SHAPES[S][1], BLOCK_SHAPES[S][2], SWEEP>;
     allow_lds(kernel, k.lds);
     hipLaunchKernelGGL(kernel, dim3(unsigned(k.nbx * k.nby * k.nbz)), dim3(unsigned(k.threads)), k.lds, s, a);
 }
-template <typename V, int MODE>
+template <typename V, int MODE, bool SWEEP = true>
 void launch_block(const PlaneGeom &g, const V *x_old, V *x_new, const V *b, const typename PlanePlan<V>::Coarse &c, hipStream_t s) {
     const BlockGeom k = choose_block(g, sizeof(V));
     BlockKArgs<V> a;
@@ -1492,10 +1516,10 @@ void launch_block(const PlaneGeom &g, const V *x_old, V *x_new, const V *b, cons
     a.nxc = g.nx / 2; a.nyc = g.ny / 2;
     a.cmap = c.map; a.bc = c.b; a.ec = c.e;
     switch (k.shape) {
-        case 0: launch_block_shape<V, MODE, 0>(k, a, s); break;
-        case 1: launch_block_shape<V, MODE, 1>(k, a, s); break;
-        case 2: launch_block_shape<V, MODE, 2>(k, a, s); break;
-        default: launch_block_shape<V, MODE, 3>(k, a, s); break;
+        case 0: launch_block_shape<V, MODE, 0, SWEEP>(k, a, s); break;
+        case 1: launch_block_shape<V, MODE, 1, SWEEP>(k, a, s); break;
+        case 2: launch_block_shape<V, MODE, 2, SWEEP>(k, a, s); break;
+        default: launch_block_shape<V, MODE, 3, SWEEP>(k, a, s); break;
     }
     OMG_HIP(hipGetLastError());
 }
@@ -1510,14 +1534,20 @@ void launch_plane(K kernel, const PlaneGeom &g, const PlaneKArgs<V> &k, hipStrea
 }
 
 template <typename V>
-void PlanePlan<V>::down(const V *x_old, V *x_new, const V *b, bool x_zero, const Coarse &c, hipStream_t s, const Peer *peer) const {
-    PlaneKArgs<V> k = plane_args<V>(g, x_old, x_new, b, c);
+void PlanePlan<V>::down(const V *x_old, V *x_new, const V *b, bool x_zero, const Coarse &c, hipStream_t s, const Peer *peer, bool sweep) const {
+    PlaneKArgs<V> k = plane_args<V>(g, x_old, x_new, b, c, status);
     k.x_zero = x_zero ? 1 : 0;
 #ifdef OMG_PLANE_STAMPS
     DevBuf<unsigned long long> sb;
     stamps_begin(k, g, sb);
 #endif
-    if (!peer && x_zero && !c.x && !c.diag && block_level(g)) {
+    if (!sweep) {
+        // preIterations = 0: residual of the iterate as it is + restriction; x_new is not written
+        OMG_REQUIRE(!peer, "plane pass without its sweep: not built for slabs with neighbours");
+        if (x_zero && !c.x && !c.diag && block_level(g)) launch_block<V, 0, false>(g, x_old, x_new, b, c, s);
+        else if (x_zero) launch_plane(plane_kernel<V, 0, false, true, PLANE_LA, false, 512, true, false>, g, k, s);
+        else launch_plane(plane_kernel<V, 0, false, false, PLANE_LA, false, 512, true, false>, g, k, s);
+    } else if (!peer && x_zero && !c.x && !c.diag && block_level(g)) {
         launch_block<V, 0>(g, x_old, x_new, b, c, s);
     } else if (peer) {
         peer_args<V>(k, *peer, s);
@@ -1541,14 +1571,20 @@ void PlanePlan<V>::down(const V *x_old, V *x_new, const V *b, bool x_zero, const
 }
 
 template <typename V>
-void PlanePlan<V>::up(const V *x_old, V *x_new, const V *b, const Coarse &c, double *out, hipStream_t s, const Peer *peer) const {
-    PlaneKArgs<V> k = plane_args<V>(g, x_old, x_new, b, c);
+void PlanePlan<V>::up(const V *x_old, V *x_new, const V *b, const Coarse &c, double *out, hipStream_t s, const Peer *peer, bool sweep) const {
+    PlaneKArgs<V> k = plane_args<V>(g, x_old, x_new, b, c, status);
     k.partials = out;
 #ifdef OMG_PLANE_STAMPS
     DevBuf<unsigned long long> sb;
     stamps_begin(k, g, sb);
 #endif
-    if (!peer && !out && block_level(g)) {
+    if (!sweep) {
+        // postIterations = 0 (the reference's default): x_new = x_old + R^T e (+ the squares of its residual)
+        OMG_REQUIRE(!peer, "plane pass without its sweep: not built for slabs with neighbours");
+        if (!out && block_level(g)) launch_block<V, 1, false>(g, x_old, x_new, b, c, s);
+        else if (out) launch_plane(plane_kernel<V, 1, true, false, PLANE_LA, false, 512, false, false>, g, k, s);
+        else launch_plane(plane_kernel<V, 1, false, false, PLANE_LA, false, 512, false, false>, g, k, s);
+    } else if (!peer && !out && block_level(g)) {
         launch_block<V, 1>(g, x_old, x_new, b, c, s);
     } else if (peer) {
         peer_args<V>(k, *peer, s);

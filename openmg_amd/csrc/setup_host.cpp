@@ -857,3 +857,73 @@ template struct DevCsrT<double>;
 template struct DevCsrT<float>;
 
 }  // namespace omg
+
+namespace omg {
+// ---- host-side checksum of a caller's array (no device involved) -----------------------------------------
+// openmg_amd.mgCycle receives the A and R lists on every call (openmg/__init__.py:151) and keys its cache of device
+// hierarchies on a checksum of EVERY byte of them.  One Python thread hashes ~5 GB/s (1.9 GB at 256^3: 0.3 s per
+// call, and the xxhash module holds the interpreter lock, so a thread pool does not help); here the buffer is cut
+// into 4 MiB chunks hashed on as many threads as the host has (xxh64's four-lane stripe loop per chunk: 32 bytes
+// per iteration, bound by memory bandwidth) and the chunk digests are folded in order.
+namespace {
+inline uint64_t rotl64(uint64_t v, int r) { return (v << r) | (v >> (64 - r)); }
+constexpr uint64_t CK_P1 = 0x9E3779B185EBCA87ull, CK_P2 = 0xC2B2AE3D27D4EB4Full, CK_P3 = 0x165667B19E3779F9ull,
+                   CK_P4 = 0x85EBCA77C2B2AE63ull, CK_P5 = 0x27D4EB2F165667C5ull;
+inline uint64_t ck_round(uint64_t acc, uint64_t lane) { return rotl64(acc + lane * CK_P2, 31) * CK_P1; }
+inline uint64_t ck_avalanche(uint64_t h) {
+    h ^= h >> 33; h *= CK_P2; h ^= h >> 29; h *= CK_P3; h ^= h >> 32;
+    return h;
+}
+uint64_t chunk_hash(const unsigned char *p, size_t n, uint64_t seed) {
+    uint64_t a0 = seed + CK_P1 + CK_P2, a1 = seed + CK_P2, a2 = seed, a3 = seed - CK_P1;
+    size_t i = 0;
+    for (; i + 32 <= n; i += 32) {
+        uint64_t w[4];
+        std::memcpy(w, p + i, 32);
+        a0 = ck_round(a0, w[0]); a1 = ck_round(a1, w[1]); a2 = ck_round(a2, w[2]); a3 = ck_round(a3, w[3]);
+    }
+    uint64_t h = rotl64(a0, 1) + rotl64(a1, 7) + rotl64(a2, 12) + rotl64(a3, 18);
+    h = (h ^ ck_round(0, a0)) * CK_P1 + CK_P4;
+    h = (h ^ ck_round(0, a1)) * CK_P1 + CK_P4;
+    h = (h ^ ck_round(0, a2)) * CK_P1 + CK_P4;
+    h = (h ^ ck_round(0, a3)) * CK_P1 + CK_P4;
+    h += uint64_t(n);
+    for (; i < n; ++i) h = rotl64(h ^ (uint64_t(p[i]) * CK_P5), 11) * CK_P1;
+    return ck_avalanche(h);
+}
+}  // namespace
+
+uint64_t host_checksum(const void *buf, int64_t bytes) {
+    const unsigned char *p = static_cast<const unsigned char *>(buf);
+    constexpr int64_t CH = int64_t(4) << 20;
+    const int64_t n_chunks = std::max<int64_t>(1, (bytes + CH - 1) / CH);
+    std::vector<uint64_t> dig(size_t(n_chunks), 0);
+    const unsigned hw = std::max(1u, std::min(64u, std::thread::hardware_concurrency()));
+    const int nt = (int)std::max<int64_t>(1, std::min<int64_t>(hw, n_chunks / 4));
+    std::atomic<int64_t> next(0);
+    auto work = [&] {
+        for (;;) {
+            const int64_t c = next.fetch_add(1);
+            if (c >= n_chunks) return;
+            const int64_t lo = c * CH, hi = std::min(bytes, lo + CH);
+            dig[size_t(c)] = chunk_hash(p + lo, size_t(std::max<int64_t>(0, hi - lo)), uint64_t(c));
+        }
+    };
+    std::vector<std::thread> th;
+    for (int t = 1; t < nt; ++t) th.emplace_back(work);
+    work();
+    for (auto &q : th) q.join();
+    return chunk_hash(reinterpret_cast<const unsigned char *>(dig.data()), dig.size() * 8, uint64_t(bytes));
+}
+
+}  // namespace omg
+
+extern "C" int omg_host_checksum(const void *buf, int64_t bytes, uint64_t *out) {
+    if (!out || bytes < 0 || (!buf && bytes > 0)) {
+        omg::set_last_error("omg_host_checksum: null / negative argument");
+        return OMG_ERR_INVALID;
+    }
+    *out = omg::host_checksum(buf, bytes);
+    return OMG_OK;
+}
+

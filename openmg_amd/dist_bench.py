@@ -25,13 +25,14 @@ def overlap_candidates(level_rows):
 
 
 def _bench_identity():
-    """(hash of the kernel sources, commit) as bench.py reports them."""
+    """(hash of the kernel sources, commit) as bench.py reports them.  The commit is what bench.py resolved BEFORE
+    anything initialised the GPU and exported as OMG_GIT_HEAD (empty: no .git): a rank never forks git."""
     import importlib.util
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     spec = importlib.util.spec_from_file_location("_omg_bench", os.path.join(root, "bench.py"))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
-    return mod.kernel_source_hash(), mod.git_head()
+    return mod.kernel_source_hash(), (os.environ.get("OMG_GIT_HEAD") or None)
 
 
 def plane_levels(shape, world, n_dist):
@@ -152,29 +153,65 @@ def main_plane(args, rank, world, shape, grids, n_levels, all_gather, td, torch,
             r.p2p_enable(0)
             notes = [n for n in all_gather(p2p_note) if n != "not tried"]
             p2p_note = "unavailable: " + (notes[0] if notes else "another rank failed")
+    class CyclesFailed(RuntimeError):
+        """Some rank's cycles raised inside a timed run; raised on EVERY rank at the same point."""
+
     def timed_run():
-        """From the loaded right-hand side: one cycle, the warm-up, the timed regions -> (times, every norm in order)."""
+        """From the loaded right-hand side: one cycle, the warm-up, the timed regions -> (times, every norm in order).
+        A rank whose cycles raise (a peer-store wait that gave up) keeps making the same collectives as the others and
+        tells them through the reductions, so that all ranks leave together (CyclesFailed) instead of one crashing and
+        the others waiting for the watchdog."""
+        failed = [0.0]
+
+        def cycles(n):
+            if failed[0]:
+                return [float("nan")] * n
+            try:
+                return run_cycles(n)
+            except RuntimeError as e:
+                sys.stderr.write("bench.py rank %d: cycles raised inside the timed run: %s\n" % (rank, e))
+                failed[0] = 1.0
+                return [float("nan")] * n
+
+        def anyone_failed(extra=0.0):
+            t = torch.tensor([extra, failed[0]], dtype=torch.float64)
+            td.all_reduce(t, op=td.ReduceOp.MAX)         # the slowest rank's time; whether any rank failed
+            return float(t[0]), bool(t[1])
+
         r.load(b_loc)
-        trajectory = run_cycles(1)
+        trajectory = cycles(1)
         for _ in range(args.warmup):
-            trajectory += run_cycles(1)
+            trajectory += cycles(1)
+        if anyone_failed()[1]:
+            raise CyclesFailed("warm-up")
         times_ = []
         for _ in range(max(1, getattr(args, "repeats", 1))):
             r.sync()
             torch.cuda.synchronize()
             td.barrier()
             t0 = time.perf_counter()
-            region = run_cycles(args.steps)              # K cycles back to back, every cycle's global norm computed
+            region = cycles(args.steps)                  # K cycles back to back, every cycle's global norm computed
             r.sync()
             torch.cuda.synchronize()
             td.barrier()
-            t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
-            td.all_reduce(t, op=td.ReduceOp.MAX)         # the slowest rank's time
-            times_.append(float(t[0]))
+            slowest, bad = anyone_failed(time.perf_counter() - t0)
+            if bad:
+                raise CyclesFailed("timed region")
+            times_.append(slowest)
             trajectory += region
         return times_, trajectory
 
-    times, trajectory = timed_run()
+    try:
+        times, trajectory = timed_run()
+    except CyclesFailed as e:
+        if not (r.p2p_mode and not shared):
+            raise
+        # peer mode gave up somewhere: every rank is here (the failure was agreed inside timed_run); the RCCL
+        # exchanges are the checked fallback
+        r.p2p_enable(0)
+        exchange = "RCCL grouped send/recv of ghost planes"
+        p2p_note = "rejected DURING the timed run (%s): the reported run is the RCCL one" % e
+        times, trajectory = timed_run()
     if r.p2p_mode and not shared:
         # every norm of the timed peer-mode run against the same cycles over RCCL (untimed): a hand-over that went
         # wrong once in hundreds of cycles must not survive into the reported number

@@ -22,9 +22,15 @@ def run(rank, world, one_cycle, all_gather, timeout_s, where=None, rtol=1e-12, d
     def body():
         try:
             box["stage"] = "inside the cycle"
-            box["norm"] = float(one_cycle())
+            # A cycle that RAISES on this rank (a peer-store wait that gave up, a HIP error) must not leave the other
+            # ranks alone in the gather below: every rank makes the same sequence of collectives, the failing one
+            # contributes (False, message), and every rank then raises the same RuntimeError.
+            try:
+                mine = (True, float(one_cycle()))
+            except Exception as e:                      # noqa: BLE001 - told to every rank below
+                mine = (False, "%s: %s" % (type(e).__name__, e))
             box["stage"] = "waiting for the other ranks' norms (the cycle of THIS rank has completed)"
-            box["all"] = all_gather(box["norm"])
+            box["all"] = all_gather(mine)
             box["stage"] = "done"
         except BaseException as e:                      # reported by the caller's thread
             box["error"] = e
@@ -46,7 +52,10 @@ def run(rank, world, one_cycle, all_gather, timeout_s, where=None, rtol=1e-12, d
         return None
     if "error" in box:
         raise box["error"]
-    norms = [float(v) for v in box["all"]]
+    failed = [(r, v[1]) for r, v in enumerate(box["all"]) if not v[0]]
+    if failed:
+        raise RuntimeError("preflight: the checked cycle raised on rank(s) %s" % "; ".join("%d (%s)" % f for f in failed))
+    norms = [float(v[1]) for v in box["all"]]
     ref = norms[0]
     bad = [r for r, v in enumerate(norms) if not math.isfinite(v) or abs(v - ref) > rtol * abs(ref)]
     if bad or not math.isfinite(ref):
@@ -55,4 +64,4 @@ def run(rank, world, one_cycle, all_gather, timeout_s, where=None, rtol=1e-12, d
         sys.stderr.flush()
         die(EXIT_MISMATCH)
         return None
-    return box["norm"]
+    return norms[rank]

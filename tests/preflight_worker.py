@@ -27,6 +27,8 @@ def main():
         v = float(t.item())
         if fault == "mismatch" and rank == fault_rank:
             v *= 1.0 + 1e-6
+        if fault == "raise" and rank == fault_rank:
+            raise RuntimeError("a peer-store wait gave up (injected)")     # AFTER the cycle's own collectives, as on the device
         return v
 
     def gather(v):
@@ -34,7 +36,14 @@ def main():
         td.all_gather_object(out, v)
         return out
 
-    norm = preflight.run(rank, world, one_cycle, gather, timeout_s, where=lambda: progress["at"])
+    try:
+        norm = preflight.run(rank, world, one_cycle, gather, timeout_s, where=lambda: progress["at"])
+    except RuntimeError as e:
+        # what dist_bench does with a peer-mode cycle that raised: every rank agrees on the fallback
+        agreed = gather(False)
+        print("rank %d fallback agreed by %d ranks after: %s" % (rank, len(agreed), e))
+        sys.stdout.flush()
+        os._exit(0)
     print("rank %d norm %.17g" % (rank, norm))
     sys.stdout.flush()
     os._exit(0)                                               # no destroy: nothing left to wait for

@@ -298,6 +298,16 @@ def test_preflight_norm_mismatch_between_ranks_is_fatal():
         assert "differ between ranks after one cycle" in e and "[1]" in e
 
 
+def test_preflight_cycle_that_raises_on_one_rank_reaches_every_rank():
+    """a cycle that raises on ONE rank (a peer-store wait that gave up) used to skip the gather the other
+    ranks were in, and the collectives paired up out of step.  Now every rank makes the same collectives, learns of
+    the failure, raises the same error — and the agreed fallback that follows runs on all of them."""
+    res = _preflight_ranks(2, "raise", 1, 60.0)
+    for rank, (code, o, e) in enumerate(res):
+        assert code == 0, (rank, code, e)
+        assert "rank %d fallback agreed by 2 ranks after: preflight: the checked cycle raised on rank(s) 1 (RuntimeError: a peer-store wait gave up (injected))" % rank in o, o
+
+
 def test_plane_levels_of_the_bench_shapes():
     """Which levels bench.py --gpus N hands to the plane-slab runner: every one needs an even number (>= 2) of planes
     per rank and even extents; the three bench shapes give three slab levels above a replicated 64^3 (N = 8) tail."""

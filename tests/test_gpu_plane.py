@@ -75,14 +75,67 @@ def test_plane_passes_have_the_bits_of_the_set_schedule(shape, grids):
             ref = run(h, b, pre, post, 3, x0)
             assert np.array_equal(got[1], ref[1]), (shape, pre, post, int(np.sum(got[1] != ref[1])))
             assert close(got[0], ref[0]), (got[0], ref[0])
-        # sweep counts the plane passes do not cover fall back to the set schedule by themselves
-        h.use_plane(True)
-        for pre, post in ((1, 0), (0, 1)):
-            got = run(h, b, pre, post, 2, x0)
-            h.use_plane(False)
-            ref = run(h, b, pre, post, 2, x0)
+        # cycles without pre- or post-smoothing — V(1,0) is the reference's default (openmg/__init__.py:22-23) —
+        # stay on the plane passes: the same launches without their relaxation stages
+        for pre, post in ((1, 0), (0, 1), (2, 0), (0, 2), (0, 0)):
             h.use_plane(True)
-            assert got[0] == ref[0] and np.array_equal(got[1], ref[1])
+            assert h.level_flags(0)["plane"]
+            got = run(h, b, pre, post, 3, x0)
+            batch = None
+            if post <= 1:
+                h.resident_load(b, x0)
+                batch = h.resident_cycles(pre, post, 3)
+                assert batch == got[0] and np.array_equal(h.resident_fetch(), got[1])
+            h.use_plane(False)
+            ref = run(h, b, pre, post, 3, x0)
+            assert np.array_equal(got[1], ref[1]), (shape, pre, post, int(np.sum(got[1] != ref[1])))
+            assert close(got[0], ref[0]), (pre, post, got[0], ref[0])
+
+
+def test_default_cycle_against_the_oracle():
+    """The reference's own parameter dict — preIterations 1, postIterations 0 (openmg/__init__.py:22-23) — and
+    V(0,1), on the plane passes against the CPU restatement of mgCycle with the red-black ordering."""
+    shape = (32, 32, 32)
+    A0 = operators.stencil_poisson(shape)
+    b = A0 @ np.random.default_rng(12345).random(A0.shape[0])
+    R = operators.restrictionList(shape, 2, 8)
+    A = operators.coeffecientList(A0, R)
+    Ro = orc.restriction_list(shape, 2, 8)
+    Ao = orc.coefficient_list(A0, Ro)
+    sm = orc.make_smoother("colour", Ao)
+    for pre, post in ((1, 0), (0, 1)):
+        p = {"preIterations": pre, "postIterations": post, "coarsestLevel": len(Ro)}
+        with _hip.Hierarchy(A, R, smoother="colour") as h:
+            assert all(h.level_flags(l)["plane"] for l in range(len(R)))
+            h.resident_load(b)
+            xo = None
+            for _ in range(3):
+                norm = h.resident_cycle(pre, post)
+                xo, info = orc.mg_cycle(Ao, b, 0, Ro, p, initial=xo, smoother=sm)
+                assert abs(norm - info["norm"]) <= 1e-10 * info["norm"]
+            np.testing.assert_allclose(h.resident_fetch(), xo, rtol=1e-9, atol=1e-12)
+
+
+@pytest.mark.parametrize("pre,post", [(1, 1), (2, 1), (1, 0), (2, 2), (0, 1), (3, 0)])
+def test_device_pointer_cycle_on_a_plane_level(pre, post):
+    """omg_hierarchy_cycle_dev (the multi-GPU runner's replicated tail) on a plane-qualified hierarchy whose
+    row-kernel format is still pending: every sweep count gives what omg_vcycle gives from a zero iterate
+    (the diagonal of the first relaxation was formed before the format existed)."""
+    import torch
+    shape = (16, 16, 16)
+    A, R = hierarchy(shape, 3)
+    b = A[0] @ np.random.default_rng(11).random(A[0].shape[0])
+    with _hip.Hierarchy(A, R, smoother="colour") as h:
+        x = np.zeros(b.size)
+        h.vcycle(b, x, pre, post)
+    with _hip.Hierarchy(A, R, smoother="colour") as h:
+        assert h.level_flags(0)["plane"]
+        bd = torch.tensor(b, dtype=torch.float64, device="cuda")
+        xd = torch.full_like(bd, float("nan"))
+        torch.cuda.synchronize()
+        h.cycle_dev(bd.data_ptr(), xd.data_ptr(), pre, post)
+        h.sync()
+        assert np.array_equal(xd.cpu().numpy(), x), (pre, post)
 
 
 def test_parity_ordering_is_the_greedy_colouring(monkeypatch):
