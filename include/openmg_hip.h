@@ -145,6 +145,13 @@ int omg_format_selftest(const omg_csr *A, int dtype, int64_t *out);
  * *norm (nullable) = ||b - A[level] uOut||_2 (:227), 0 when level is the coarsest (:232). */
 int omg_vcycle(omg_hierarchy *h, int level, const double *b, double *x,
                int pre, int post, double *norm);
+/* The same cycle with the reference's in-place pre-smoother made explicit (Q2): gaussSeidel writes x[i] of the
+ * caller's `initial` (openmg/solvers.py:68) and returns the same object (:75), so after mgCycle the array passed as
+ * `initial` holds the PRE-SMOOTHED iterate (openmg/__init__.py:201) while uOut is a new array (:220 / :224).
+ * x_in: initial iterate (NULL: zeros, :191-192; nothing is uploaded); x_out: uOut; x_pre (nullable): the iterate
+ * after the pre-smoothing sweeps of `level` (equal to x_in when pre = 0).  One call, each vector over PCIe once. */
+int omg_vcycle_ex(omg_hierarchy *h, int level, const double *b, const double *x_in, double *x_out, double *x_pre,
+                  int pre, int post, double *norm);
 
 /* replaces: the cycle loop of openmg.mgSolve — openmg/__init__.py:112-138.  At least one
  * cycle, then until cycle >= max_cycles (if max_cycles > 0) or norm < threshold (if

@@ -223,21 +223,27 @@ def mgCycle(A, b, level, R, parameters, initial=None):
         # the reference's `else` branch (:229-234): direct solve with A[level], norm 0
         return solvers.coarseSolve(A[level], b), {"norm": 0}
     hierarchy = _hierarchy_for(A, R, coarsest + 1, code, omega, _dtype_of(parameters))
-    x = np.zeros(b.size) if initial is None else np.array(np.asarray(initial, dtype=np.float64).reshape(-1), order="C")
     if parameters.get("verbose", False):
         for l in range(level, coarsest):
             print(l * " " + "calling mgCycle at level %i" % l)
         print(coarsest * " " + "direct solving at level %i" % coarsest)
     pre = parameters["preIterations"]
-    if (pre > 0 and isinstance(initial, np.ndarray) and initial.dtype == np.float64 and initial.flags.writeable
-            and initial.size == b.size and np.shares_memory(initial, initial.reshape(-1))):
+    x_in = None if initial is None else np.ascontiguousarray(np.asarray(initial, dtype=np.float64).reshape(-1))
+    x = np.empty(b.size)                    # uOut is a new array (openmg/__init__.py:220 / :224)
+    in_place = (pre > 0 and isinstance(initial, np.ndarray) and initial.dtype == np.float64 and initial.flags.writeable
+                and initial.size == b.size and np.shares_memory(initial, initial.reshape(-1)))
+    if in_place and np.shares_memory(x_in, initial):
         # Q2: the reference's pre-smoother works IN PLACE on the caller's `initial`
         # (openmg/__init__.py:201 -> solvers.py:68,75): after the call it holds the pre-smoothed
-        # iterate, uOut is a new array.  Same sweeps on the device (same bits as inside the cycle).
-        smoothed = x.copy()
-        hierarchy.smooth(level, b, smoothed, pre)
+        # iterate.  The device hands that iterate back from the same cycle (omg_vcycle_ex): x_in is read
+        # before x_pre is written, so the two may be the caller's one buffer.
+        norm = hierarchy.vcycle_ex(b, x_in, x, x_in, pre, parameters["postIterations"], level=level)
+    elif in_place:
+        smoothed = np.empty(b.size)
+        norm = hierarchy.vcycle_ex(b, x_in, x, smoothed, pre, parameters["postIterations"], level=level)
         initial.reshape(-1)[:] = smoothed
-    norm = hierarchy.vcycle(b, x, pre, parameters["postIterations"], level=level)
+    else:
+        norm = hierarchy.vcycle_ex(b, x_in, x, None, pre, parameters["postIterations"], level=level)
     return x, {"norm": norm}
 
 

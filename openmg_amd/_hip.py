@@ -71,6 +71,7 @@ SIGNATURES = {
     "omg_hierarchy_format_info": (_I, [_P, _I, _I, _I, _I64P]),
     "omg_format_selftest": (_I, [_CSR, _I, _I64P]),
     "omg_vcycle": (_I, [_P, _I, _P, _P, _I, _I, _DP]),
+    "omg_vcycle_ex": (_I, [_P, _I, _P, _P, _P, _P, _I, _I, _DP]),
     "omg_solve": (_I, [_P, _P, _P, _I, _I, _I, _D, _IP, _DP]),
     "omg_resident_load": (_I, [_P, _P, _P]),
     "omg_resident_cycle": (_I, [_P, _I, _I, _DP]),
@@ -299,6 +300,18 @@ class Hierarchy:
         assert x.dtype == np.float64 and x.flags.c_contiguous and x.size == n
         norm = ctypes.c_double(0.0)
         check(lib().omg_vcycle(self._h, level, b.ctypes.data, x.ctypes.data, int(pre), int(post), ctypes.byref(norm)))
+        return norm.value
+
+    def vcycle_ex(self, b, x_in, x_out, x_pre, pre, post, level=0):
+        """omg_vcycle_ex: x_in (None: zeros) -> x_out; x_pre (None: not wanted) receives the iterate after the
+        pre-smoothing sweeps (the reference's in-place smoother overwrites `initial` with it).  Returns the norm."""
+        n = self.sizes[level]
+        b = vec(b, n)
+        for a in (x_in, x_out, x_pre):
+            assert a is None or (a.dtype == np.float64 and a.flags.c_contiguous and a.size == n)
+        norm = ctypes.c_double(0.0)
+        check(lib().omg_vcycle_ex(self._h, level, b.ctypes.data, None if x_in is None else x_in.ctypes.data, x_out.ctypes.data,
+                                  None if x_pre is None else x_pre.ctypes.data, int(pre), int(post), ctypes.byref(norm)))
         return norm.value
 
     def solve(self, b, x, pre, post, max_cycles, threshold):

@@ -87,6 +87,9 @@ struct Hier {
     CoarseSolver<V> coarse;   // direct solve of the coarsest operator (common.h)
     DevBuf<double> norm_dev;
     DevBuf<uint32_t> plane_status; // PlanePlan::status of every plane level: bit 1 = a wave gave up waiting for its neighbour wave
+    // omg_vcycle_ex: cycle_body leaves a copy of level pre_level's iterate after its pre-smoothing here (-1: nowhere)
+    DevBuf<V> pre_buf;
+    int pre_level = -1;
     DevBuf<double> norms_dev;      // omg_resident_cycles: one norm per cycle of the batch
     DevBuf<double> batch_partials; // ... and the block partials of up to 64 deferred norms
     int smoother = OMG_SMOOTH_GS_LEX;
@@ -460,6 +463,7 @@ int cycle_body(Hier<V> *h, int l, int pre, int post, bool want_norm = false, dou
             L.plane->down(L.xp, L.tp, L.b.p, x_zero, c, h->stream, nullptr, pre >= 1);      // :201 (last sweep), :209, :210
         }
         if (pre >= 1) std::swap(L.xp, L.tp);
+        if (l == h->pre_level) OMG_HIP(hipMemcpyAsync(h->pre_buf.p, L.xp, size_t(L.n) * sizeof(V), hipMemcpyDeviceToDevice, h->stream));
         cycle_body(h, l + 1, pre, post, false, nullptr, child_first, nullptr, child_zero);   // :213
         c.e = C.xp;
         double *out = (want_norm && post <= 1) ? (post_slot ? post_slot : L.plane->partials.p) : nullptr;
@@ -473,6 +477,7 @@ int cycle_body(Hier<V> *h, int l, int pre, int post, bool want_norm = false, dou
         return out ? NORM_PLANE : NORM_NONE;
     }
     const bool res_done = smooth_level(h, l, pre, FUSE_RESIDUAL, pre_slot, first_done);   // :201 (+ last set's share of :209)
+    if (l == h->pre_level) OMG_HIP(hipMemcpyAsync(h->pre_buf.p, L.xp, size_t(L.n) * sizeof(V), hipMemcpyDeviceToDevice, h->stream));
     residual_level(h, l, L.r.p, res_done);                          // :209
     // :210, and the coarse cycle's initial=None -> zeros (:191-192) cleared by the same launch —
     // or already relaxed once (first_sweep_in_restrict)
@@ -1069,6 +1074,47 @@ int omg_vcycle(omg_hierarchy *h, int level, const double *b, double *x, int pre,
                 nv = read_norm(hh);
             }
             fetch_vec<V>(hh, level, L.xp, x);
+            if (norm) *norm = nv;
+        });
+    });
+}
+
+int omg_vcycle_ex(omg_hierarchy *h, int level, const double *b, const double *x_in, double *x_out, double *x_pre,
+                  int pre, int post, double *norm) {
+    return guarded([&] {
+        with(h, [&](auto *hh) {
+            using V = value_of<decltype(hh)>;
+            check_level(hh, level);
+            OMG_REQUIRE(b && x_out, "b / x_out is null");
+            OMG_REQUIRE(pre >= 0 && post >= 0, "negative sweep count");
+            auto &L = hh->lv[level];
+            const int last = (int)hh->lv.size() - 1;
+            hh->resident = false;
+            load_vec(hh, level, b, L.b.p);
+            if (x_in) load_vec(hh, level, x_in, L.xp);
+            else OMG_HIP(hipMemsetAsync(L.xp, 0, size_t(L.n) * sizeof(V), hh->stream));
+            const bool want_pre = x_pre && level < last && pre > 0;
+            if (want_pre) {
+                if (hh->pre_buf.n < size_t(L.n)) hh->pre_buf.alloc(size_t(L.n));
+                hh->pre_level = level;
+            }
+            int part = NORM_NONE;
+            try {
+                part = cycle_body(hh, level, pre, post, level < last);
+            } catch (...) {
+                hh->pre_level = -1;
+                throw;
+            }
+            hh->pre_level = -1;
+            double nv = 0.0;
+            if (level < last) {
+                finish_norm(hh, level, part);
+                nv = read_norm(hh);
+            }
+            fetch_vec<V>(hh, level, L.xp, x_out);
+            if (want_pre) fetch_vec<V>(hh, level, hh->pre_buf.p, x_pre);
+            else if (x_pre && x_in) { if (x_pre != x_in) std::memcpy(x_pre, x_in, size_t(L.n) * sizeof(double)); }
+            else if (x_pre) std::memset(x_pre, 0, size_t(L.n) * sizeof(double));
             if (norm) *norm = nv;
         });
     });

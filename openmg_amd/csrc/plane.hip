@@ -1179,7 +1179,8 @@ bool PlanePlan<V>::build(const omg_csr &A, const omg_csr &R, Ordering &ord) {
     const int64_t nxc = nx / 2, nyc = ny / 2, nzc = nz / 2;
     if (R.n_cols != n || R.n_rows != nxc * nyc * nzc || R.nnz != n) return false;
     const double w = R.nnz ? R.data[0] : 0.0;
-    const unsigned hw = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+    // (memory-bound: the scan reads every byte of the operator once; 64 threads on a many-core host: 64 -> ~15 ms at 256^3)
+    const unsigned hw = std::max(1u, std::min(64u, std::thread::hardware_concurrency()));
     const int nt = (int)std::min<int64_t>(hw, std::max<int64_t>(1, n / 65536));
     std::atomic<bool> ok(true);
     auto scan = [&](int tnum) {

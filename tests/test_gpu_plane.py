@@ -121,7 +121,13 @@ def test_device_pointer_cycle_on_a_plane_level(pre, post):
     """omg_hierarchy_cycle_dev (the multi-GPU runner's replicated tail) on a plane-qualified hierarchy whose
     row-kernel format is still pending: every sweep count gives what omg_vcycle gives from a zero iterate
     (the diagonal of the first relaxation was formed before the format existed)."""
-    import torch
+    import ctypes
+    # device vectors from the HIP runtime libopenmg_hip.so itself is linked against (NOT torch: it ships a second
+    # copy of the runtime, and two of them in one process end in a double free at interpreter exit)
+    hip = ctypes.CDLL("libamdhip64.so.7")
+    hip.hipMalloc.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t]
+    hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+    hip.hipFree.argtypes = [ctypes.c_void_p]
     shape = (16, 16, 16)
     A, R = hierarchy(shape, 3)
     b = A[0] @ np.random.default_rng(11).random(A[0].shape[0])
@@ -130,12 +136,18 @@ def test_device_pointer_cycle_on_a_plane_level(pre, post):
         h.vcycle(b, x, pre, post)
     with _hip.Hierarchy(A, R, smoother="colour") as h:
         assert h.level_flags(0)["plane"]
-        bd = torch.tensor(b, dtype=torch.float64, device="cuda")
-        xd = torch.full_like(bd, float("nan"))
-        torch.cuda.synchronize()
-        h.cycle_dev(bd.data_ptr(), xd.data_ptr(), pre, post)
-        h.sync()
-        assert np.array_equal(xd.cpu().numpy(), x), (pre, post)
+        bd, xd = ctypes.c_void_p(), ctypes.c_void_p()
+        assert hip.hipMalloc(ctypes.byref(bd), b.nbytes) == 0 and hip.hipMalloc(ctypes.byref(xd), b.nbytes) == 0
+        try:
+            got = np.full(b.size, np.nan)
+            assert hip.hipMemcpy(bd, b.ctypes.data, b.nbytes, 1) == 0 and hip.hipMemcpy(xd, got.ctypes.data, b.nbytes, 1) == 0
+            h.cycle_dev(bd.value, xd.value, pre, post)
+            h.sync()
+            assert hip.hipMemcpy(got.ctypes.data, xd, b.nbytes, 2) == 0
+        finally:
+            hip.hipFree(bd)
+            hip.hipFree(xd)
+        assert np.array_equal(got, x), (pre, post)
 
 
 def test_parity_ordering_is_the_greedy_colouring(monkeypatch):
