@@ -133,6 +133,9 @@ struct Ordering {
 };
 
 // setup_host.cpp
+// Touch every page of a freshly allocated host buffer that is about to RECEIVE a large device-to-host copy, on many
+// threads: the copy into untouched pages of a new NumPy array runs at page-fault speed (175 MB in 33 ms, measured)
+void prefault_host(void *p, size_t bytes);
 void validate_csr(const omg_csr &A, const char *what);
 // Smallest row whose stored diagonal entries are missing or sum to zero; -1 if none.
 int64_t first_row_without_diagonal(const omg_csr &A);
@@ -480,6 +483,10 @@ struct MarchPlan {
     bool timed_out(hipStream_t s) const;                 // (synchronises) some sweep gave up waiting for a face
 };
 
+// Is R the plain 2 x 2 x 2 aggregation of an nx x ny x nz grid (openmg/operators.py:73-84: eight entries per coarse
+// cell in (dk, dj, di) order, ONE weight, ascending columns)?  w: that weight.  Host scan on many threads.
+bool is_plain_aggregation(const omg_csr &R, int64_t nx, int64_t ny, int64_t nz, double &w);   // (stencil27.hip)
+
 // ---- plane-pipelined red-black passes of grid stencils (plane.hip) -----------------------------
 // A V(1,1) cycle over a red-black ordered level streams x and b through HBM eight times (red
 // sweep, black sweep + residual, red residual, restriction; prolongation, red, black + norm, red
@@ -573,6 +580,64 @@ struct PlanePlan {
     // out (nullable): block partials of the squared residual norm, g.n_wg doubles
     void up(const V *x_old, V *x_new, const V *b, const Coarse &c, double *out, hipStream_t s, const Peer *peer = nullptr,
             bool sweep = true) const;
+};
+
+// ---- 27-point grid stencils with per-row coefficients: BASELINE configs[4] (stencil27.hip) ----------------
+// A level whose operator holds, in every row, exactly the in-grid neighbours of a 27-point stencil on a
+// lexicographically numbered grid of even extents (columns ascending: slot s = 9 (dz + 1) + 3 (dy + 1) + dx + 1) with
+// ARBITRARY coefficients, restricted by the plain 2 x 2 x 2 aggregation, smoothed with the 8-colour Gauss-Seidel the
+// greedy colouring finds on it (colour = (i & 1) + 2 (j & 1) + 4 (k & 1): the octant of a cell inside its aggregate).
+// In that ordering each colour's part of a level vector is indexed by the AGGREGATE (I, J, K) = (i, j, k) >> 1, so
+//   * a row's 27 operands are unit-stride runs of eight "coarse-shaped" arrays at shifts of -1 / 0 / +1 aggregates,
+//   * the restriction (openmg/__init__.py:210) and the prolongation (:214) are element-wise over the eight arrays,
+//   * colours 2m and 2m + 1 (x even / x odd of one line) depend on each other only inside their own grid line,
+// and the set-by-set schedule (8 launches per sweep, a 4-byte gather + a 4-byte coefficient load per stored entry)
+// becomes 4 launches per sweep that stream the coefficients — held per colour and wave in [slot][lane] tiles of
+// 16-byte accesses — once each:
+//   sweep_pair    colours (2m, 2m + 1), out of place (x_old only read); the last pair also leaves the residuals of
+//                 its rows (their sweep is final), the first sweep of a batched cycle also squares the residuals
+//                 with respect to x_old — the PREVIOUS cycle's norm (openmg/__init__.py:227) for free;
+//   residual      b - A x of the other six colours fused with the restriction (r never exists in HBM), or squared
+//                 for the norm;
+//   prolong       x += R^T e.
+// Every row is summed as the row kernels sum a row of 27 stored entries — four fma chains, entry e to chain e & 3,
+// ((s0 + s1) + s2) + s3 — with an absent neighbour as an explicit zero coefficient: the level's row-kernel format is
+// built from that PADDED operator (27 entries in every row), so the set-by-set schedule of the same hierarchy
+// (omg_hierarchy_use_plane(0)) produces the same bits.
+struct S27Geom {
+    int nx = 0, ny = 0, nz = 0;       // cells (even)
+    int hx = 0, hy = 0, hz = 0;       // aggregates per line / lines per plane / planes
+    int64_t na = 0;                   // aggregates = rows per colour
+    int rg = 0;                       // aggregates per lane (16-byte accesses: 4 floats, 2 doubles; 4 doubles for long lines)
+    int L = 0, G = 0;                 // lanes per grid line, lines per wave
+    int64_t nl = 0, ng = 0;           // lines per colour; waves (line groups) per colour
+    int n_wg = 0;                     // workgroups of four waves
+    double w = 0.0;                   // the restriction's weight
+};
+template <typename V>
+struct Stencil27Plan {
+    S27Geom g;
+    DevBuf<V> coef;                   // [colour][wave group][slot][lane][rg]
+    DevBuf<V> res67;                  // residuals of colours 6 and 7, left by a sweep's last pair launch
+    DevBuf<double> partials;          // 4 segments of n_wg block partials (+ SUM_FOLD): squared residuals
+    bool have67 = false;              // res67 / segment 3 belong to the current iterate
+    // false: the level does not qualify (ord untouched).  A, R: the caller's CSR in natural numbering.
+    bool build(const omg_csr &A, const omg_csr &R, Ordering &ord, hipStream_t s);
+    // One sweep x_old -> x_new.  x_zero: x_old is zero and is not read.  norm_old (nullable: 4 n_wg doubles): also
+    // the squares of b - A x_old.  last: leave the residuals of colours 6, 7 (res67) and, with norm_new (nullable,
+    // same shape; only segment 3 is written), their squares.
+    void sweep(const V *x_old, V *x_new, const V *b, bool x_zero, double *norm_old, bool last, double *norm_new, hipStream_t s);
+    // coarse right-hand side = R (b - A x) (cmap: coarse natural index -> slot in the coarse ordering, null: identity).
+    // use67: the residuals of colours 6, 7 are taken from res67.
+    void residual_restrict(const V *x, const V *b, bool use67, const int32_t *cmap, V *bc, hipStream_t s);
+    // squares of b - A x into segment 0 of `out` (4 n_wg doubles; segments 1, 2 are cleared, segment 3 too unless
+    // use67: then it holds the squares of colours 6, 7 already)
+    void norm(const V *x, const V *b, bool use67, double *out, hipStream_t s);
+    void prolong(V *x, const V *e, const int32_t *cmap, hipStream_t s);
+    // The operator the row kernels' format of this level is built from: every row with all 27 slots, an absent
+    // neighbour as a zero entry on the row's own column (doubles of the stored V); and the aggregation.
+    HostCsr operator_csr(hipStream_t s) const;
+    HostCsr restriction_csr() const;
 };
 
 }  // namespace omg

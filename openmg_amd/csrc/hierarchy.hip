@@ -69,6 +69,9 @@ struct Level {
     // of a V(pre >= 1, post >= 1) cycle is one plane-pipelined launch (common.h PlanePlan), out of place
     // between x and tmp
     std::unique_ptr<PlanePlan<V>> plane;
+    // 27-point grid stencil with per-row coefficients under the 2x2x2 aggregation, 8-colour Gauss-Seidel (BASELINE
+    // configs[4]): the cycle over this level runs the octant-layout kernels of stencil27.hip (common.h Stencil27Plan)
+    std::unique_ptr<Stencil27Plan<V>> s27;
     // A plane level's cycle never touches the row-kernel format of A and R (nor r, the block partials, the
     // sweep plan): they are built on first use — by a cycle with pre = 0 or post = 0, a single-level
     // operation, a format query — from the operator the plan describes (ensure_format; OMG_PLANE_LAZY=0: at creation)
@@ -377,7 +380,13 @@ void coarse_solve_level(Hier<V> *h) {
 }
 
 // What a cycle leaves of the entry level's residual norm (openmg/__init__.py:227)
-enum NormState { NORM_NONE = 0, NORM_LAST_SET = 1, NORM_PLANE = 2 };
+enum NormState { NORM_NONE = 0, NORM_LAST_SET = 1, NORM_PLANE = 2, NORM_S27 = 3 };
+
+// Does the cycle over this level run the 27-point kernels of stencil27.hip?  (Switched with the plane passes.)
+template <typename V>
+bool use_s27(const Hier<V> *h, const Level<V> &L) {
+    return L.s27 && !h->no_plane;
+}
 
 // Do both halves of a cycle over this level run as plane-pipelined launches?  (Any sweep counts: with
 // pre = 0 or post = 0 — the reference's default is V(1,0), openmg/__init__.py:22-23 — the pass runs
@@ -408,6 +417,43 @@ int cycle_body(Hier<V> *h, int l, int pre, int post, bool want_norm = false, dou
     }
     Level<V> &L = h->lv[l];
     Level<V> &C = h->lv[l + 1];
+    if (use_s27(h, L)) {
+        // 27-point per-row-coefficient level (stencil27.hip): sweeps as four pair launches, out of place; the last
+        // pre-smoothing sweep leaves the residuals of its final rows, the others' are formed inside the restriction
+        Stencil27Plan<V> &P = *L.s27;
+        const bool child_fused = l + 1 < last && (use_s27(h, C) || use_plane(h, C, pre, post));
+        const bool child_zero = child_fused && pre >= 1;       // such a child's first sweep never reads its zero iterate
+        bool zero_now = x_zero;
+        if (x_zero && pre == 0) {
+            OMG_HIP(hipMemsetAsync(L.xp, 0, size_t(L.n) * sizeof(V), h->stream));
+            zero_now = false;
+        }
+        for (int it = 0; it < pre; ++it) {                      // :201
+            Prof<V> p(h, l, 0);
+            P.sweep(L.xp, L.tp, L.b.p, zero_now, (it == 0 && !zero_now) ? pre_slot : nullptr, it + 1 == pre, nullptr, h->stream);
+            std::swap(L.xp, L.tp);
+            zero_now = false;
+        }
+        if (l == h->pre_level) OMG_HIP(hipMemcpyAsync(h->pre_buf.p, L.xp, size_t(L.n) * sizeof(V), hipMemcpyDeviceToDevice, h->stream));
+        if (l + 1 < last && !child_zero) OMG_HIP(hipMemsetAsync(C.xp, 0, size_t(C.n) * sizeof(V), h->stream));   // :191-192
+        {
+            Prof<V> p(h, l, 1);
+            P.residual_restrict(L.xp, L.b.p, pre >= 1, L.r_out.p, C.b.p, h->stream);                  // :209, :210
+        }
+        cycle_body(h, l + 1, pre, post, false, nullptr, false, nullptr, child_zero);                   // :213
+        {
+            Prof<V> p(h, l, 3);
+            P.prolong(L.xp, C.xp, L.r_out.p, h->stream);                                               // :214, :220 / :224
+        }
+        double *nslot = want_norm ? (post_slot ? post_slot : P.partials.p) : nullptr;
+        for (int it = 0; it < post; ++it) {                     // :216-222
+            Prof<V> p(h, l, 0);
+            const bool fin = it + 1 == post && want_norm;
+            P.sweep(L.xp, L.tp, L.b.p, false, nullptr, fin, fin ? nslot : nullptr, h->stream);
+            std::swap(L.xp, L.tp);
+        }
+        return want_norm ? NORM_S27 : NORM_NONE;
+    }
     // OMG_PLANE_HALVES=1|2 (debugging, not under hipGraph): only the down / only the up pass plane-pipelined
     static const int halves = [] { const char *e = getenv("OMG_PLANE_HALVES"); return (e && (e[0] == '1' || e[0] == '2')) ? e[0] - '0' : 3; }();
     if (use_plane(h, L, pre, post) && halves == 2 && !x_zero && pre >= 1 && post >= 1) {
@@ -449,7 +495,7 @@ int cycle_body(Hier<V> *h, int l, int pre, int post, bool want_norm = false, dou
         const bool child_plane = l + 1 < last && use_plane(h, C, pre, post);
         const bool child_zero = child_plane && pre <= 1 && halves == 3;       // the child's down pass never reads its zero iterate
         if (l + 1 < last && !child_zero) ensure_format(h, l + 1);
-        const bool child_first = l + 1 < last && !child_zero && first_sweep_in_restrict(h, C, pre);
+        const bool child_first = l + 1 < last && !child_zero && !use_s27(h, C) && first_sweep_in_restrict(h, C, pre);
         typename PlanePlan<V>::Coarse c;
         c.map = L.r_out.p;
         c.b = C.b.p;
@@ -481,9 +527,9 @@ int cycle_body(Hier<V> *h, int l, int pre, int post, bool want_norm = false, dou
     residual_level(h, l, L.r.p, res_done);                          // :209
     // :210, and the coarse cycle's initial=None -> zeros (:191-192) cleared by the same launch —
     // or already relaxed once (first_sweep_in_restrict)
-    const bool child_zero = l + 1 < last && use_plane(h, C, pre, post) && pre == 1 && halves == 3;
-    if (l + 1 < last && !child_zero) ensure_format(h, l + 1);
-    const bool child_first = l + 1 < last && !child_zero && first_sweep_in_restrict(h, C, pre);
+    const bool child_zero = l + 1 < last && ((use_plane(h, C, pre, post) && pre == 1 && halves == 3) || (use_s27(h, C) && pre >= 1));
+    if (l + 1 < last && !child_zero && !use_s27(h, C)) ensure_format(h, l + 1);
+    const bool child_first = l + 1 < last && !child_zero && !use_s27(h, C) && first_sweep_in_restrict(h, C, pre);
     restrict_level<V>(h, l, L.r.p, C.b.p, (l + 1 < last && !child_zero) ? C.xp : nullptr, child_first);
     cycle_body(h, l + 1, pre, post, false, nullptr, child_first, nullptr, child_zero);   // :213
     prolong_add_level<V>(h, l, C.xp, L.xp);                         // :214, :220/:224
@@ -498,6 +544,15 @@ void finish_norm(Hier<V> *h, int l, int state, double *out = nullptr) {
     if (state == NORM_PLANE) {
         Level<V> &L = h->lv[l];
         launch_sum_sqrt(L.plane->partials.p, L.plane->g.n_wg, out ? out : h->norm_dev.p, h->stream);
+    } else if (state == NORM_S27) {
+        // the rows the last post-smoothing launch made final have left their squares (segment 3); the others' now
+        Level<V> &L = h->lv[l];
+        Stencil27Plan<V> &P = *L.s27;
+        {
+            Prof<V> p(h, l, 4);
+            P.norm(L.xp, L.b.p, P.have67, P.partials.p, h->stream);
+        }
+        launch_sum_sqrt(P.partials.p, int64_t(4) * P.g.n_wg, out ? out : h->norm_dev.p, h->stream);
     } else {
         norm_level<V>(h, l, nullptr, state == NORM_LAST_SET, out);
     }
@@ -698,8 +753,11 @@ template <typename V>
 void ensure_format(Hier<V> *h, int l) {
     if (l < 0 || l >= (int)h->lv.size() || !h->lv[l].format_pending) return;
     Level<V> &L = h->lv[l];
-    SetupTimer tm("plane level: row-kernel format on first use");
-    const HostCsr A = L.plane->operator_csr(), R = L.plane->restriction_csr();
+    SetupTimer tm("plane / 27-point level: row-kernel format on first use");
+    // (a 27-point level: from the operator PADDED to 27 entries per row, so that the row kernels associate every row's
+    // sum as the kernels of stencil27.hip do)
+    const HostCsr A = L.s27 ? L.s27->operator_csr(h->stream) : L.plane->operator_csr();
+    const HostCsr R = L.s27 ? L.s27->restriction_csr() : L.plane->restriction_csr();
     L.format_pending = false;
     build_format(h, l, view(A), view(R));
 }
@@ -788,6 +846,16 @@ std::unique_ptr<Hier<V>> create(int n_levels, const omg_csr *A, const omg_csr *R
                 }
                 continue;
             }
+            std::unique_ptr<Stencil27Plan<V>> s27(new Stencil27Plan<V>);
+            if (s27->build(A[l], R[l], L.ord, h->stream)) {
+                L.s27 = std::move(s27);
+                if (getenv_flag("OMG_PLANE_CHECK_ORDER")) {
+                    const Ordering g = make_ordering(A[l], smoother);
+                    OMG_REQUIRE(g.sets == L.ord.sets && g.perm == L.ord.perm && g.inv == L.ord.inv,
+                                "internal: the octant ordering differs from the greedy colouring");
+                }
+                continue;
+            }
         }
         SetupTimer tm("ordering (colouring / level schedule / wavefront plan)");
         order_level(L, A[l], smoother, h->stream);
@@ -810,7 +878,9 @@ std::unique_ptr<Hier<V>> create(int n_levels, const omg_csr *A, const omg_csr *R
                 OMG_HIP(hipStreamSynchronize(h->stream));
             }
             if (L.plane) L.tmp.alloc(L.n, vector_stagger(1));
-            if (L.plane && !getenv_flag0("OMG_PLANE_LAZY")) L.format_pending = true;
+            if (L.s27) L.tmp.alloc(L.n);
+            if ((L.plane || L.s27) && !getenv_flag0("OMG_PLANE_LAZY")) L.format_pending = true;
+            else if (L.s27) { L.format_pending = true; ensure_format(h.get(), l); }      // (from the padded operator)
             else build_format(h.get(), l, A[l], R[l]);
         }
         L.x.alloc(std::max<int64_t>(L.n, 1));
@@ -988,7 +1058,8 @@ int omg_hierarchy_level_flags(const omg_hierarchy *h, int level, int *flags) {
                      ((smoothed && hh->lv[level].scatter_prolong) ? OMG_LEVEL_SCATTER_PROLONG : 0) |
                      ((smoothed && hh->lv[level].A.all_union()) ? OMG_LEVEL_UNION_WALK : 0) |
                      ((smoothed && hh->lv[level].march) ? OMG_LEVEL_MARCH : 0) |
-                     ((smoothed && hh->lv[level].plane && !hh->no_plane) ? OMG_LEVEL_PLANE : 0);
+                     ((smoothed && hh->lv[level].plane && !hh->no_plane) ? OMG_LEVEL_PLANE : 0) |
+                     ((smoothed && hh->lv[level].s27 && !hh->no_plane) ? OMG_LEVEL_STENCIL27 : 0);
         });
     });
 }
@@ -1141,7 +1212,7 @@ int omg_hierarchy_cycle_dev(omg_hierarchy *h, const double *b_dev, double *x_dev
                 else launch_gather<double, V>(b_dev, perm, L.b.p, L.n, hh->stream);
                 bool first = false, zero_in = false;
                 if (hh->lv.size() > 1) {
-                    zero_in = use_plane(hh, L, pre, post) && pre == 1;     // the down pass does not read a zero iterate
+                    zero_in = (use_plane(hh, L, pre, post) && pre == 1) || (use_s27(hh, L) && pre >= 1);   // the down pass / first sweep does not read a zero iterate
                     if (!zero_in) {
                         // x starts from zero: the first relaxation launch is a pointwise b / diag (restrict_level).  The
                         // diagonal comes from the row-kernel format, which a plane level builds on first use: BEFORE it
@@ -1227,6 +1298,35 @@ int omg_resident_cycles(omg_hierarchy *h, int pre, int post, int n_cycles, doubl
                     for (int j = 0; j < cnt; ++j) {
                         const int st = cycle_body(hh, 0, pre, post, true, nullptr, false, hh->batch_partials.p + size_t(j) * size_t(nb));
                         OMG_REQUIRE(st == NORM_PLANE, "internal: plane-pipelined cycle without its norm partials");
+                    }
+                    launch_sum_batch(hh->batch_partials.p, nb, nb, cnt, hh->norms_dev.p + k0, true, hh->stream);
+                }
+                if (norms) OMG_HIP(hipMemcpyAsync(norms, hh->norms_dev.p, size_t(n_cycles) * sizeof(double), hipMemcpyDeviceToHost, hh->stream));
+                OMG_HIP(hipStreamSynchronize(hh->stream));
+                check_march(hh);
+                return;
+            }
+            if (!single && use_s27(hh, hh->lv[0])) {
+                // 27-point level: with pre >= 1 the first sweep of cycle j + 1 also squares the residuals with respect
+                // to the iterate it starts from — cycle j's norm (openmg/__init__.py:227) without another pass over
+                // the operator; the last cycle of a chunk (and every cycle when pre = 0) runs the norm kernel
+                constexpr int CHUNK = 64;
+                using V = value_of<decltype(hh)>;
+                auto &L0 = hh->lv[0];
+                Stencil27Plan<V> &P = *L0.s27;
+                const int64_t nb = int64_t(4) * P.g.n_wg;
+                if (hh->batch_partials.n < size_t(CHUNK) * size_t(nb)) hh->batch_partials.alloc(size_t(CHUNK) * size_t(nb));
+                for (int k0 = 0; k0 < n_cycles; k0 += CHUNK) {
+                    const int cnt = std::min(CHUNK, n_cycles - k0);
+                    for (int j = 0; j < cnt; ++j) {
+                        double *slot_prev = (pre >= 1 && j > 0) ? hh->batch_partials.p + size_t(j - 1) * size_t(nb) : nullptr;
+                        double *slot_this = hh->batch_partials.p + size_t(j) * size_t(nb);
+                        const bool own_norm = j + 1 == cnt || pre == 0;
+                        cycle_body(hh, 0, pre, post, own_norm, slot_prev, false, own_norm ? slot_this : nullptr);
+                        if (own_norm) {
+                            Prof<V> p(hh, 0, 4);
+                            P.norm(L0.xp, L0.b.p, P.have67, slot_this, hh->stream);
+                        }
                     }
                     launch_sum_batch(hh->batch_partials.p, nb, nb, cnt, hh->norms_dev.p + k0, true, hh->stream);
                 }

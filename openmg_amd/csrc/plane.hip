@@ -1185,14 +1185,20 @@ bool PlanePlan<V>::build(const omg_csr &A, const omg_csr &R, Ordering &ord) {
     std::atomic<bool> ok(true);
     auto scan = [&](int tnum) {
         const int64_t lo = n * tnum / nt, hi = n * (tnum + 1) / nt;
+        int64_t i = lo % nx, jl = (lo / nx) % ny, kl = lo / sk;
+        const int64_t off7[7] = {-sk, -sj, -1, 0, 1, sj, sk};
         for (int64_t r = lo; r < hi; ++r) {
-            const int64_t i = r % nx, jl = (r / nx) % ny, kl = r / sk;
+            if (r > lo && ++i == nx) {                    // (the cell's coordinates, carried along instead of divided out)
+                i = 0;
+                if (++jl == ny) { jl = 0; ++kl; }
+            }
             const bool present[7] = {kl > 0, jl > 0, i > 0, true, i + 1 < nx, jl + 1 < ny, kl + 1 < nz};
             int64_t p = A.indptr[r];
             const int64_t pe = A.indptr[r + 1];
             for (int e = 0; e < 7; ++e) {
                 if (!present[e]) continue;
-                if (p >= pe || slot_of(r, A.indices[p]) != e || A.data[p] != c[e]) { ok = false; return; }
+                // (the column itself: slot_of() costs three integer divisions per ENTRY — the scan was bound by them, not by memory)
+                if (p >= pe || int64_t(A.indices[p]) != r + off7[e] || A.data[p] != c[e]) { ok = false; return; }
                 ++p;
             }
             if (p != pe) { ok = false; return; }

@@ -893,6 +893,26 @@ uint64_t chunk_hash(const unsigned char *p, size_t n, uint64_t seed) {
 }
 }  // namespace
 
+void prefault_host(void *p, size_t bytes) {
+    if (bytes < (size_t(8) << 20)) return;
+    volatile unsigned char *c = static_cast<volatile unsigned char *>(p);
+    constexpr size_t PAGE = 4096;
+    const size_t pages = (bytes + PAGE - 1) / PAGE;
+    const unsigned hw = std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
+    const int nt = (int)std::max<size_t>(1, std::min<size_t>(hw, pages / 1024));
+    auto work = [&](int t) {
+        const size_t lo = pages * size_t(t) / size_t(nt), hi = pages * size_t(t + 1) / size_t(nt);
+        for (size_t q = lo; q < hi; ++q) {
+            const size_t off = q * PAGE;
+            c[off] = 0;                                       // (the buffer is an OUTPUT: its contents are about to be overwritten)
+        }
+    };
+    std::vector<std::thread> th;
+    for (int t = 1; t < nt; ++t) th.emplace_back(work, t);
+    work(0);
+    for (auto &q : th) q.join();
+}
+
 uint64_t host_checksum(const void *buf, int64_t bytes) {
     const unsigned char *p = static_cast<const unsigned char *>(buf);
     constexpr int64_t CH = int64_t(4) << 20;

@@ -1,0 +1,797 @@
+// 27-point grid stencils with per-row coefficients (common.h Stencil27Plan) — gfx950 only.
+//
+// BASELINE configs[4]: the Q1 stiffness operator of -div(kappa grad u) and its Galerkin products, fp32, 8-colour
+// Gauss-Seidel.  The octant colouring (colour = (i & 1) + 2 (j & 1) + 4 (k & 1), what the greedy colouring finds)
+// puts cell (i, j, k) of colour c at slot c na + a, a = ((k >> 1) hy + (j >> 1)) hx + (i >> 1): every colour's part
+// of a level vector is a grid of AGGREGATES.  For a cell with parity bit p along an axis and a neighbour at offset
+// d in {-1, 0, +1} along it, the neighbour's bit is p ^ (d != 0) and its aggregate index moves by (p + d) >> 1 — all
+// compile-time facts of (colour, slot), so a row's 27 operands are 27 unit-stride vector loads.
+//
+// Thread mapping: a wave owns G = 64 / L whole grid LINES of one colour (L = lanes per line, a lane RG consecutive
+// aggregates of its line: 16-byte accesses), so the only dependency inside a pair of colours (2m, 2m + 1) — the two
+// in-line neighbours — is a neighbouring element of the same lane or the neighbouring LANE (one wave shuffle); no
+// workgroup ever waits for another.  The coefficients are stored for exactly that mapping: [colour][wave][slot][lane][RG].
+//
+// Arithmetic: the row kernels' (csr_kernels.hip) for a row of 27 stored entries — four fma chains, entry e to chain
+// e & 3, ((s0 + s1) + s2) + s3, x + (b - sum) / a_ii — on the operator PADDED with explicit zeros for the neighbours
+// a boundary row lacks (common.h): same bits as the set-by-set schedule of the same hierarchy.
+#include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <cstring>
+#include <thread>
+#include <type_traits>
+
+#include "common.h"
+
+namespace omg {
+
+bool is_plain_aggregation(const omg_csr &R, int64_t nx, int64_t ny, int64_t nz, double &w) {
+    const int64_t n = nx * ny * nz, sj = nx, sk = nx * ny;
+    const int64_t nxc = nx / 2, nyc = ny / 2, nzc = nz / 2;
+    if ((nx & 1) || (ny & 1) || (nz & 1) || R.n_cols != n || R.n_rows != nxc * nyc * nzc || R.nnz != n || n == 0) return false;
+    w = R.data[0];
+    const double w0 = w;
+    const unsigned hw = std::max(1u, std::min(64u, std::thread::hardware_concurrency()));
+    const int nt = (int)std::min<int64_t>(hw, std::max<int64_t>(1, R.n_rows / 8192));
+    std::atomic<bool> ok(true);
+    auto scan = [&](int tnum) {
+        const int64_t clo = R.n_rows * tnum / nt, chi = R.n_rows * (tnum + 1) / nt;
+        for (int64_t cr = clo; cr < chi; ++cr) {
+            const int64_t I = cr % nxc, J = (cr / nxc) % nyc, K = cr / (nxc * nyc);
+            int64_t p = R.indptr[cr];
+            if (R.indptr[cr + 1] - p != 8) { ok = false; return; }
+            for (int dk = 0; dk < 2; ++dk)
+                for (int dj = 0; dj < 2; ++dj)
+                    for (int di = 0; di < 2; ++di, ++p) {
+                        const int64_t f = (2 * K + dk) * sk + (2 * J + dj) * sj + 2 * I + di;
+                        if (R.indices[p] != f || R.data[p] != w0) { ok = false; return; }
+                    }
+        }
+    };
+    std::vector<std::thread> th;
+    for (int tnum = 1; tnum < nt; ++tnum) th.emplace_back(scan, tnum);
+    scan(0);
+    for (auto &q : th) q.join();
+    return ok;
+}
+
+namespace {
+
+typedef unsigned v2u __attribute__((ext_vector_type(2)));
+typedef unsigned v4u __attribute__((ext_vector_type(4)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+constexpr int S27_OOB = 0x7FFFFFF0;       // byte offset behind every buffer: the range check answers 0 / drops the store
+
+__device__ __forceinline__ double madd(double v, double x, double acc) { return fma(v, x, acc); }
+__device__ __forceinline__ float madd(float v, float x, float acc) { return fmaf(v, x, acc); }
+
+// RG consecutive values of a buffer, starting at element `idx` (any 4-byte aligned offset; outside the buffer: zeros)
+template <typename V, int RG>
+struct Vec {
+    V v[RG];
+};
+__device__ __forceinline__ Vec<float, 4> ldv(__amdgpu_buffer_rsrc_t rs, int idx, Vec<float, 4> *) {
+    const v4f q = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rs, idx * 4, 0, 0));
+    return {{q.x, q.y, q.z, q.w}};
+}
+__device__ __forceinline__ Vec<double, 2> ldv(__amdgpu_buffer_rsrc_t rs, int idx, Vec<double, 2> *) {
+    const v4u q = __builtin_amdgcn_raw_buffer_load_b128(rs, idx * 8, 0, 0);
+    return {{__builtin_bit_cast(double, v2u{q.x, q.y}), __builtin_bit_cast(double, v2u{q.z, q.w})}};
+}
+// element-wise masked store (mask bit r: element r is a row of the grid)
+__device__ __forceinline__ void stv(__amdgpu_buffer_rsrc_t rs, int idx, const Vec<float, 4> &x, unsigned mask) {
+    if (mask == 0xFu) {
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, v4f{x.v[0], x.v[1], x.v[2], x.v[3]}), rs, idx * 4, 0, 0);
+    } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if ((mask >> r) & 1u) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, x.v[r]), rs, (idx + r) * 4, 0, 0);
+    }
+}
+__device__ __forceinline__ void stv(__amdgpu_buffer_rsrc_t rs, int idx, const Vec<double, 2> &x, unsigned mask) {
+    if (mask == 0x3u) {
+        const v2u lo = __builtin_bit_cast(v2u, x.v[0]), hi = __builtin_bit_cast(v2u, x.v[1]);
+        __builtin_amdgcn_raw_buffer_store_b128(v4u{lo.x, lo.y, hi.x, hi.y}, rs, idx * 8, 0, 0);
+    } else {
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+            if ((mask >> r) & 1u) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, x.v[r]), rs, (idx + r) * 8, 0, 0);
+    }
+}
+
+template <typename V>
+struct S27KArgs {
+    const V *coef;                   // [8][ng][27][64 RG]
+    const V *x_old;
+    V *x_new;                        // sweep: the iterate being written; residual / prolong: unused / the iterate
+    const V *b;
+    V *res;                          // [2][na]: residuals of colours 6, 7
+    const V *e;                      // prolong: coarse correction
+    V *bc;                           // restrict: coarse right-hand side
+    const int32_t *cmap;             // coarse natural index -> slot (null: identity)
+    double *part_a, *part_b;         // block partials: sweep: old-residual squares / new-residual squares; residual: squares
+    int hx, hy, L, G;
+    int na, nl, ng;                  // rows per colour, lines per colour, waves per colour
+    unsigned vec_bytes, coef_bytes;  // 8 na sizeof(V); bytes of ONE colour's coefficients
+    V w;
+};
+
+// the neighbour of a cell with parity bits (px, py, pz) at slot s: its colour and the shift of its aggregate
+struct Nb {
+    int colour, si, sj, sk;
+};
+__host__ __device__ constexpr Nb neighbour(int px, int py, int pz, int s) {
+    const int dx = s % 3 - 1, dy = (s / 3) % 3 - 1, dz = s / 9 - 1;
+    // (p + d) >> 1 with an arithmetic shift: p = 0: -1 -> -1, +1 -> 0; p = 1: -1 -> 0, +1 -> +1
+    const int si = (px + dx) < 0 ? -1 : (px + dx) >> 1, sj = (py + dy) < 0 ? -1 : (py + dy) >> 1, sk = (pz + dz) < 0 ? -1 : (pz + dz) >> 1;
+    return Nb{(px ^ (dx != 0 ? 1 : 0)) | ((py ^ (dy != 0 ? 1 : 0)) << 1) | ((pz ^ (dz != 0 ? 1 : 0)) << 2), si, sj, sk};
+}
+
+template <typename V, int RG>
+struct Lane {
+    int line, i0, a0, cbase;         // grid line of the colour, first aggregate in the line, a0 = line hx + i0, first coefficient
+    unsigned mask;                   // bit r: aggregate i0 + r exists
+    int lane;
+};
+template <typename V, int RG>
+__device__ __forceinline__ Lane<V, RG> lane_of(const S27KArgs<V> &a) {
+    Lane<V, RG> t;
+    const int wave = int(blockIdx.x) * 4 + (int(threadIdx.x) >> 6);
+    t.lane = int(threadIdx.x) & 63;
+    const int lw = t.lane / a.L;                      // line of the wave
+    t.line = wave * a.G + lw;
+    t.i0 = (t.lane - lw * a.L) * RG;
+    const bool live = wave < a.ng && lw < a.G && t.line < a.nl;
+    t.a0 = t.line * a.hx + t.i0;
+    t.cbase = (wave * 27 * 64 + t.lane) * RG;
+    t.mask = 0u;
+#pragma unroll
+    for (int r = 0; r < RG; ++r)
+        if (live && t.i0 + r < a.hx) t.mask |= 1u << r;
+    if (wave >= a.ng) t.cbase = S27_OOB / int(sizeof(V));          // (a launch is padded to whole workgroups)
+    return t;
+}
+
+template <typename V>
+struct Chains4 {
+    V s[4];
+    __device__ __forceinline__ void clear() { s[0] = s[1] = s[2] = s[3] = V(0); }
+    __device__ __forceinline__ V total() const { return ((s[0] + s[1]) + s[2]) + s[3]; }
+};
+
+__device__ __forceinline__ void add_sq(double &sq, double r) { sq = fma(r, r, sq); }
+
+// between two groups of slots: no load of the next group is issued before the fmas of this one (a compiler fence for
+// memory operations — the machine scheduler's own barrier alone left all 54 loads of a row pair at the top — and a
+// scheduling barrier)
+// ... and the lane's two base indices pass through an empty asm, so that no ADDRESS of the next group is computed
+// ahead of it either (54 offsets with their selects were live at once)
+// ... and the group's accumulators too: its fmas are then in front of the fence, not sunk behind the next loads
+template <typename C>
+__device__ __forceinline__ void pin_chains(C &c) {
+    asm volatile("" : "+v"(c.s[0]), "+v"(c.s[1]), "+v"(c.s[2]), "+v"(c.s[3]));
+}
+__device__ __forceinline__ void group_fence(int &a0, int &cbase) {
+    asm volatile("" : "+v"(a0), "+v"(cbase) : : "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// fixed order: lanes of a wave (shuffle tree), then the four waves in turn
+__device__ __forceinline__ void block_partial(double sq, double *out) {
+    __shared__ double s_red[4];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) sq += __shfl_down(sq, off, 64);
+    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = sq;
+    __syncthreads();
+    if (threadIdx.x == 0) out[blockIdx.x] = ((s_red[0] + s_red[1]) + s_red[2]) + s_red[3];
+}
+
+// ---- one sweep launch: colours (2 PAIR, 2 PAIR + 1) ---------------------------------------------------------------
+// XZ: x_old is zero and not read.  NOLD: also the squares of b - A x_old (both colours) -> part_a.  LAST (PAIR == 3):
+// the residuals of both colours with the FINAL iterate -> res, their squares -> part_b when it is given.
+// The 27 slots of a row are taken in groups of SG: the group's coefficient and operand loads are issued together,
+// then its fmas; a scheduling barrier between the groups keeps the compiler from hoisting every load of the unrolled
+// row to the top (54 sixteen-byte loads in flight: 256 registers and scratch).
+constexpr int SG = 9;
+template <typename V, int RG, int PAIR, bool XZ, bool NOLD, bool LAST>
+__global__ __launch_bounds__(256, NOLD ? 1 : 2) void s27_sweep_kernel(const S27KArgs<V> a) {
+    static_assert(!LAST || PAIR == 3, "only the last pair's rows are final when their launch ends");
+    static_assert(!(XZ && NOLD), "a zero iterate has no predecessor cycle");
+    typedef Vec<V, RG> VR;
+    constexpr int CA = 2 * PAIR, CB = CA + 1, PY = PAIR & 1, PZ = PAIR >> 1;
+    Lane<V, RG> tt = lane_of<V, RG>(a);
+    const Lane<V, RG> &t = tt;
+    const int lhx = a.hx, lhyhx = a.hx * a.hy;
+    const __amdgpu_buffer_rsrc_t xo = __builtin_amdgcn_make_buffer_rsrc(const_cast<V *>(a.x_old), 0, XZ ? 0u : a.vec_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t xn = __builtin_amdgcn_make_buffer_rsrc(a.x_new, 0, a.vec_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t bs = __builtin_amdgcn_make_buffer_rsrc(const_cast<V *>(a.b), 0, a.vec_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ka = __builtin_amdgcn_make_buffer_rsrc(const_cast<V *>(a.coef + size_t(CA) * (a.coef_bytes / sizeof(V))), 0, a.coef_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t kb = __builtin_amdgcn_make_buffer_rsrc(const_cast<V *>(a.coef + size_t(CB) * (a.coef_bytes / sizeof(V))), 0, a.coef_bytes, 0x00020000);
+    const int ok = t.mask ? 1 : 0;                     // (a lane without rows asks for nothing)
+    constexpr int NONE = S27_OOB / int(sizeof(V));
+    auto cload = [&](const __amdgpu_buffer_rsrc_t &rs, int s) -> VR { return ldv(rs, ok ? t.cbase + s * 64 * RG : NONE, (VR *)nullptr); };
+    // operand of a slot: current = x_new for colours already relaxed in this sweep (< CA), x_old otherwise
+    auto operand = [&](const __amdgpu_buffer_rsrc_t &rs, const Nb &nb) -> VR {
+        return ldv(rs, ok ? nb.colour * a.na + t.a0 + nb.sk * lhyhx + nb.sj * lhx + nb.si : NONE, (VR *)nullptr);
+    };
+    double sq_old = 0.0, sq_new = 0.0;
+    Chains4<V> acc[RG], aold[RG];
+
+    // ---- colour CA (x even) ----
+    VR xa = {}, ba = ldv(bs, ok ? CA * a.na + t.a0 : NONE, (VR *)nullptr);
+    if (!XZ) xa = ldv(xo, ok ? CA * a.na + t.a0 : NONE, (VR *)nullptr);
+#pragma unroll
+    for (int r = 0; r < RG; ++r) { acc[r].clear(); aold[r].clear(); }
+    VR diag_a = {};
+#pragma unroll
+    for (int g0 = 0; g0 < 27; g0 += SG) {
+        VR c[SG], x[SG], xold[SG];
+#pragma unroll
+        for (int u = 0; u < SG; ++u) {
+            const int s = g0 + u;
+            const Nb nb = neighbour(0, PY, PZ, s);
+            const bool from_new = nb.colour < CA;
+            if (XZ && !from_new && s != 13) continue;  // (c * 0 leaves a chain as it is; the coefficient is not even loaded)
+            c[u] = cload(ka, s);
+            if (s == 13) { diag_a = c[u]; x[u] = xa; xold[u] = xa; continue; }
+            x[u] = operand(from_new ? xn : xo, nb);
+            if (NOLD) xold[u] = from_new ? operand(xo, nb) : x[u];
+        }
+#pragma unroll
+        for (int u = 0; u < SG; ++u) {
+            const int s = g0 + u;
+            const Nb nb = neighbour(0, PY, PZ, s);
+            if (XZ && !(nb.colour < CA)) continue;     // (slot 13 too: x_i = 0)
+#pragma unroll
+            for (int r = 0; r < RG; ++r) {
+                acc[r].s[s & 3] = madd(c[u].v[r], x[u].v[r], acc[r].s[s & 3]);
+                if (NOLD) aold[r].s[s & 3] = madd(c[u].v[r], xold[u].v[r], aold[r].s[s & 3]);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < RG; ++r) { pin_chains(acc[r]); if (NOLD) pin_chains(aold[r]); }
+        group_fence(tt.a0, tt.cbase);
+    }
+    VR na_;                                            // the relaxed values of colour CA
+#pragma unroll
+    for (int r = 0; r < RG; ++r) {
+        // openmg/solvers.py:68   x[i] = x[i] + (b[i] - Aix) / A[i, i]
+        const V v = xa.v[r] + (ba.v[r] - acc[r].total()) / diag_a.v[r];
+        na_.v[r] = ((t.mask >> r) & 1u) ? v : V(0);
+        if (NOLD && ((t.mask >> r) & 1u)) add_sq(sq_old, double(ba.v[r] - aold[r].total()));
+    }
+    // the in-line neighbours of colour CB: aggregate i + 1 of this lane or the next lane's first; of colour CA's
+    // residual: aggregate i - 1 of this lane or the previous lane's last (a line's first / last: no such cell, zero
+    // coefficient — whatever finite value the neighbouring lane holds)
+    const V na_next = __shfl_down(na_.v[0], 1, 64);
+
+    // ---- colour CB (x odd) ----
+    VR xb = {}, bb = ldv(bs, ok ? CB * a.na + t.a0 : NONE, (VR *)nullptr);
+    if (!XZ) xb = ldv(xo, ok ? CB * a.na + t.a0 : NONE, (VR *)nullptr);
+#pragma unroll
+    for (int r = 0; r < RG; ++r) { acc[r].clear(); aold[r].clear(); }
+    VR diag_b = {};
+    V keep1[RG];                                       // LAST: chain 1 in front of slot 13
+#pragma unroll
+    for (int r = 0; r < RG; ++r) keep1[r] = V(0);
+#pragma unroll
+    for (int g0 = 0; g0 < 27; g0 += SG) {
+        VR c[SG], x[SG], xold[SG];
+#pragma unroll
+        for (int u = 0; u < SG; ++u) {
+            const int s = g0 + u;
+            const Nb nb = neighbour(1, PY, PZ, s);
+            const bool in_line = s == 12 || s == 14;   // colour CA of the own line: relaxed above
+            const bool from_new = nb.colour < CA;
+            if (XZ && !from_new && !in_line && s != 13) continue;
+            c[u] = cload(kb, s);
+            if (s == 13) { diag_b = c[u]; x[u] = xb; xold[u] = xb; }
+            else if (s == 12) { x[u] = na_; xold[u] = xa; }          // dx = -1: the same aggregate's colour CA cell
+            else if (s == 14) {                                        // dx = +1: the next aggregate's
+#pragma unroll
+                for (int r = 0; r + 1 < RG; ++r) x[u].v[r] = na_.v[r + 1];
+                x[u].v[RG - 1] = na_next;
+                if (NOLD) xold[u] = operand(xo, nb);
+            } else {
+                x[u] = operand(from_new ? xn : xo, nb);
+                if (NOLD) xold[u] = from_new ? operand(xo, nb) : x[u];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < SG; ++u) {
+            const int s = g0 + u;
+            const Nb nb = neighbour(1, PY, PZ, s);
+            const bool in_line = s == 12 || s == 14;
+            if (XZ && !(nb.colour < CA) && !in_line) continue;
+            if (LAST && s == 13) {
+#pragma unroll
+                for (int r = 0; r < RG; ++r) keep1[r] = acc[r].s[1];
+            }
+#pragma unroll
+            for (int r = 0; r < RG; ++r) {
+                acc[r].s[s & 3] = madd(c[u].v[r], x[u].v[r], acc[r].s[s & 3]);
+                if (NOLD) aold[r].s[s & 3] = madd(c[u].v[r], xold[u].v[r], aold[r].s[s & 3]);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < RG; ++r) { pin_chains(acc[r]); if (NOLD) pin_chains(aold[r]); }
+        group_fence(tt.a0, tt.cbase);
+    }
+    VR nb_;
+#pragma unroll
+    for (int r = 0; r < RG; ++r) {
+        const V v = xb.v[r] + (bb.v[r] - acc[r].total()) / diag_b.v[r];
+        nb_.v[r] = ((t.mask >> r) & 1u) ? v : V(0);
+        if (NOLD && ((t.mask >> r) & 1u)) add_sq(sq_old, double(bb.v[r] - aold[r].total()));
+    }
+    stv(xn, CA * a.na + t.a0, na_, t.mask);
+    stv(xn, CB * a.na + t.a0, nb_, t.mask);
+
+    if (LAST) {
+        // The rows of colours 6 and 7 are final: their residuals with the new iterate, as a residual pass would form
+        // them — the same chains, with the operands that have changed since the row was relaxed.
+        // Colour 7 (CB): only its own value (slot 13, chain 1): chain 1 again from slot 13 on.
+        const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(a.res, 0, unsigned(2 * size_t(a.na) * sizeof(V)), 0x00020000);
+        VR rb;
+        {
+            V c1[RG];
+#pragma unroll
+            for (int r = 0; r < RG; ++r) c1[r] = madd(diag_b.v[r], nb_.v[r], keep1[r]);
+            VR c[3], x[3];
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+                const Nb nb = neighbour(1, PY, PZ, 17 + 4 * u);
+                c[u] = cload(kb, 17 + 4 * u);
+                x[u] = operand(xn, nb);                   // (colours 0 .. 5: relaxed by the earlier launches of this sweep)
+            }
+#pragma unroll
+            for (int u = 0; u < 3; ++u)
+#pragma unroll
+                for (int r = 0; r < RG; ++r) c1[r] = madd(c[u].v[r], x[u].v[r], c1[r]);
+#pragma unroll
+            for (int r = 0; r < RG; ++r) {
+                const V tot = ((acc[r].s[0] + c1[r]) + acc[r].s[2]) + acc[r].s[3];
+                rb.v[r] = ((t.mask >> r) & 1u) ? bb.v[r] - tot : V(0);
+            }
+        }
+        group_fence(tt.a0, tt.cbase);
+        // Colour 6 (CA): its own value (slot 13) and its two in-line neighbours of colour 7 (slots 12, 14): the whole
+        // row again (its coefficients come from L2 this time)
+        const V nb_prev = __shfl_up(nb_.v[RG - 1], 1, 64);
+        VR ra;
+        {
+#pragma unroll
+            for (int r = 0; r < RG; ++r) acc[r].clear();
+#pragma unroll
+            for (int g0 = 0; g0 < 27; g0 += SG) {
+                VR c[SG], x[SG];
+#pragma unroll
+                for (int u = 0; u < SG; ++u) {
+                    const int s = g0 + u;
+                    const Nb nb = neighbour(0, PY, PZ, s);
+                    c[u] = cload(ka, s);
+                    if (s == 13) x[u] = na_;
+                    else if (s == 14) x[u] = nb_;          // dx = +1: the same aggregate's colour 7 cell
+                    else if (s == 12) {                    // dx = -1: the previous aggregate's
+#pragma unroll
+                        for (int r = 1; r < RG; ++r) x[u].v[r] = nb_.v[r - 1];
+                        x[u].v[0] = nb_prev;
+                    } else x[u] = operand(xn, nb);
+                }
+#pragma unroll
+                for (int u = 0; u < SG; ++u)
+#pragma unroll
+                    for (int r = 0; r < RG; ++r) acc[r].s[(g0 + u) & 3] = madd(c[u].v[r], x[u].v[r], acc[r].s[(g0 + u) & 3]);
+#pragma unroll
+                for (int r = 0; r < RG; ++r) pin_chains(acc[r]);
+                group_fence(tt.a0, tt.cbase);
+            }
+#pragma unroll
+            for (int r = 0; r < RG; ++r) ra.v[r] = ((t.mask >> r) & 1u) ? ba.v[r] - acc[r].total() : V(0);
+        }
+        stv(rr, t.a0, ra, t.mask);
+        stv(rr, a.na + t.a0, rb, t.mask);
+        if (a.part_b) {
+#pragma unroll
+            for (int r = 0; r < RG; ++r) { add_sq(sq_new, double(ra.v[r])); add_sq(sq_new, double(rb.v[r])); }
+        }
+    }
+    if (NOLD) block_partial(sq_old, a.part_a);
+    if (LAST && a.part_b) block_partial(sq_new, a.part_b);
+}
+
+// ---- residual of the colours [0, NC) (NC = 6: those of colours 6, 7 are read from res), then ----------------------
+// MODE 0: the restriction, openmg/__init__.py:210 — a coarse cell's eight fine residuals in R's column order, which
+//         IS the colour order — into the coarse right-hand side;  MODE 1: their squares -> part_a (NC colours only).
+// The colours are a run-time loop (the colour is wave-uniform: its neighbour table is scalar arithmetic), the 27 slots
+// of a row unrolled in groups of SG like the sweep's.
+template <typename V, int RG, int NC, int MODE>
+__global__ __launch_bounds__(256, 2) void s27_residual_kernel(const S27KArgs<V> a) {
+    typedef Vec<V, RG> VR;
+    Lane<V, RG> tt = lane_of<V, RG>(a);
+    const Lane<V, RG> &t = tt;
+    const int lhx = a.hx, lhyhx = a.hx * a.hy;
+    const __amdgpu_buffer_rsrc_t xs = __builtin_amdgcn_make_buffer_rsrc(const_cast<V *>(a.x_old), 0, a.vec_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t bs = __builtin_amdgcn_make_buffer_rsrc(const_cast<V *>(a.b), 0, a.vec_bytes, 0x00020000);
+    const int ok = t.mask ? 1 : 0;
+    constexpr int NONE = S27_OOB / int(sizeof(V));
+    V rsum[RG];                                        // MODE 0: the restriction's running chain
+#pragma unroll
+    for (int r = 0; r < RG; ++r) rsum[r] = V(0);
+    double sq = 0.0;
+#pragma unroll 1
+    for (int c = 0; c < NC; ++c) {
+        const int px = c & 1, py = (c >> 1) & 1, pz = c >> 2;
+        const __amdgpu_buffer_rsrc_t kc = __builtin_amdgcn_make_buffer_rsrc(const_cast<V *>(a.coef + size_t(c) * (a.coef_bytes / sizeof(V))), 0, a.coef_bytes, 0x00020000);
+        const VR bv = ldv(bs, ok ? c * a.na + t.a0 : NONE, (VR *)nullptr);
+        Chains4<V> acc[RG];
+#pragma unroll
+        for (int r = 0; r < RG; ++r) acc[r].clear();
+#pragma unroll
+        for (int g0 = 0; g0 < 27; g0 += SG) {
+            VR cf[SG], x[SG];
+#pragma unroll
+            for (int u = 0; u < SG; ++u) {
+                const int s = g0 + u;
+                const Nb nb = neighbour(px, py, pz, s);
+                cf[u] = ldv(kc, ok ? t.cbase + s * 64 * RG : NONE, (VR *)nullptr);
+                x[u] = ldv(xs, ok ? nb.colour * a.na + t.a0 + nb.sk * lhyhx + nb.sj * lhx + nb.si : NONE, (VR *)nullptr);
+            }
+#pragma unroll
+            for (int u = 0; u < SG; ++u)
+#pragma unroll
+                for (int r = 0; r < RG; ++r) acc[r].s[(g0 + u) & 3] = madd(cf[u].v[r], x[u].v[r], acc[r].s[(g0 + u) & 3]);
+#pragma unroll
+            for (int r = 0; r < RG; ++r) pin_chains(acc[r]);
+            group_fence(tt.a0, tt.cbase);
+        }
+#pragma unroll
+        for (int r = 0; r < RG; ++r) {
+            const V res = ((t.mask >> r) & 1u) ? bv.v[r] - acc[r].total() : V(0);
+            if (MODE == 1) add_sq(sq, double(res));
+            else rsum[r] = madd(a.w, res, rsum[r]);
+        }
+    }
+    if (MODE == 0) {
+        if (NC < 8) {
+            const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(a.res, 0, unsigned(2 * size_t(a.na) * sizeof(V)), 0x00020000);
+            const VR r6 = ldv(rr, ok ? t.a0 : NONE, (VR *)nullptr), r7 = ldv(rr, ok ? a.na + t.a0 : NONE, (VR *)nullptr);
+#pragma unroll
+            for (int r = 0; r < RG; ++r) rsum[r] = madd(a.w, r7.v[r], madd(a.w, r6.v[r], rsum[r]));
+        }
+#pragma unroll
+        for (int r = 0; r < RG; ++r) {
+            if (!((t.mask >> r) & 1u)) continue;
+            const int ca = t.a0 + r;                   // the coarse cell's natural index IS the aggregate's
+            a.bc[a.cmap ? a.cmap[ca] : ca] = rsum[r];
+        }
+    } else {
+        block_partial(sq, a.part_a);
+    }
+}
+
+// x += R^T e, openmg/__init__.py:214,220 — the product rounded, then added (ROW_SCATTER's two roundings)
+template <typename V, int RG>
+__global__ __launch_bounds__(256) void s27_prolong_kernel(const S27KArgs<V> a) {
+    typedef Vec<V, RG> VR;
+    const Lane<V, RG> t = lane_of<V, RG>(a);
+    if (!t.mask) return;
+    const __amdgpu_buffer_rsrc_t xs = __builtin_amdgcn_make_buffer_rsrc(a.x_new, 0, a.vec_bytes, 0x00020000);
+    VR e;
+#pragma unroll
+    for (int r = 0; r < RG; ++r) e.v[r] = ((t.mask >> r) & 1u) ? a.e[a.cmap ? a.cmap[t.a0 + r] : t.a0 + r] : V(0);
+    VR x[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) x[c] = ldv(xs, c * a.na + t.a0, (VR *)nullptr);
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+#pragma unroll
+        for (int r = 0; r < RG; ++r) x[c].v[r] = x[c].v[r] + madd(a.w, e.v[r], V(0));
+        stv(xs, c * a.na + t.a0, x[c], t.mask);
+    }
+}
+
+// ---- setup: the caller's CSR (natural numbering) -> the wave-tiled coefficient array; every row checked ----------
+// err: 0 fine, otherwise 1 + the first offending row (any of them)
+template <typename V>
+__global__ __launch_bounds__(256) void s27_build_kernel(const int32_t *indptr, const int32_t *indices, const double *data,
+                                                        int nx, int ny, int nz, int L, int G, int RG, int64_t ng, V *coef, unsigned long long *err) {
+    const int64_t n = int64_t(nx) * ny * nz;
+    const int64_t row = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    if (row >= n) return;
+    const int i = int(row % nx), j = int((row / nx) % ny), k = int(row / (int64_t(nx) * ny));
+    const int hy = ny / 2;
+    const int c = (i & 1) | ((j & 1) << 1) | ((k & 1) << 2);
+    const int64_t line = int64_t(k >> 1) * hy + (j >> 1);
+    const int64_t wave = line / G;
+    const int lane = int(line - wave * G) * L + (i >> 1) / RG, r = (i >> 1) % RG;
+    V *out = coef + ((size_t(c) * size_t(ng) + size_t(wave)) * 27 * 64 + size_t(lane)) * size_t(RG) + size_t(r);
+    int64_t p = indptr[row];
+    const int64_t pe = indptr[row + 1];
+    bool bad = false;
+    for (int s = 0; s < 27; ++s) {
+        const int dx = s % 3 - 1, dy = (s / 3) % 3 - 1, dz = s / 9 - 1;
+        const bool present = i + dx >= 0 && i + dx < nx && j + dy >= 0 && j + dy < ny && k + dz >= 0 && k + dz < nz;
+        V v = V(0);
+        if (present) {
+            if (p < pe && int64_t(indices[p]) == row + (int64_t(dz) * ny + dy) * nx + dx) {
+                v = V(data[p]);
+                const double back = double(v);
+                if (!(back - back == 0.0)) bad = true;                 // not finite (as V)
+                if (s == 13 && !(back != 0.0)) bad = true;             // a zero diagonal
+                ++p;
+            } else {
+                bad = true;
+            }
+        }
+        out[size_t(s) * 64 * size_t(RG)] = v;
+    }
+    if (p != pe) bad = true;
+    if (bad) atomicMin(err, (unsigned long long)(row + 1));
+}
+
+template <typename V>
+S27KArgs<V> base_args(const Stencil27Plan<V> &P) {
+    S27KArgs<V> k;
+    std::memset(&k, 0, sizeof(k));
+    const S27Geom &g = P.g;
+    k.coef = P.coef.p;
+    k.res = P.res67.p;
+    k.hx = g.hx; k.hy = g.hy; k.L = g.L; k.G = g.G;
+    k.na = int(g.na); k.nl = int(g.nl); k.ng = int(g.ng);
+    k.vec_bytes = unsigned(size_t(8) * size_t(g.na) * sizeof(V));
+    k.coef_bytes = unsigned(size_t(g.ng) * 27 * 64 * size_t(g.rg) * sizeof(V));
+    k.w = V(g.w);
+    return k;
+}
+
+template <typename K, typename V>
+void launch_s27(K kernel, const S27Geom &g, const S27KArgs<V> &k, hipStream_t s) {
+    hipLaunchKernelGGL(kernel, dim3(unsigned(g.n_wg)), dim3(256), 0, s, k);
+    OMG_HIP(hipGetLastError());
+}
+
+template <typename V, int RG, int PAIR>
+void launch_pair(const S27Geom &g, const S27KArgs<V> &k, bool x_zero, bool nold, bool last, hipStream_t s) {
+    if (PAIR == 3 && last) {
+        if (x_zero) launch_s27(s27_sweep_kernel<V, RG, 3, true, false, true>, g, k, s);
+        else if (nold) launch_s27(s27_sweep_kernel<V, RG, 3, false, true, true>, g, k, s);
+        else launch_s27(s27_sweep_kernel<V, RG, 3, false, false, true>, g, k, s);
+    } else {
+        if (x_zero) launch_s27(s27_sweep_kernel<V, RG, PAIR, true, false, false>, g, k, s);
+        else if (nold) launch_s27(s27_sweep_kernel<V, RG, PAIR, false, true, false>, g, k, s);
+        else launch_s27(s27_sweep_kernel<V, RG, PAIR, false, false, false>, g, k, s);
+    }
+}
+
+template <typename V, int RG>
+void sweep_rg(const Stencil27Plan<V> &P, const V *x_old, V *x_new, const V *b, bool x_zero, double *norm_old, bool last, double *norm_new,
+              hipStream_t s) {
+    S27KArgs<V> k = base_args(P);
+    k.x_old = x_old; k.x_new = x_new; k.b = b;
+    const int nw = P.g.n_wg;
+    k.part_b = (last && norm_new) ? norm_new + 3 * size_t(nw) : nullptr;
+    k.part_a = norm_old;                      launch_pair<V, RG, 0>(P.g, k, x_zero, norm_old != nullptr, false, s);
+    k.part_a = norm_old ? norm_old + nw : nullptr;     launch_pair<V, RG, 1>(P.g, k, x_zero, norm_old != nullptr, false, s);
+    k.part_a = norm_old ? norm_old + 2 * size_t(nw) : nullptr; launch_pair<V, RG, 2>(P.g, k, x_zero, norm_old != nullptr, false, s);
+    k.part_a = norm_old ? norm_old + 3 * size_t(nw) : nullptr; launch_pair<V, RG, 3>(P.g, k, x_zero, norm_old != nullptr, last, s);
+}
+
+template <typename V, int RG>
+void residual_rg(const Stencil27Plan<V> &P, const V *x, const V *b, bool use67, int mode, const int32_t *cmap, V *bc, double *out, hipStream_t s) {
+    S27KArgs<V> k = base_args(P);
+    k.x_old = x; k.b = b; k.cmap = cmap; k.bc = bc; k.part_a = out;
+    if (mode == 0) {
+        if (use67) launch_s27(s27_residual_kernel<V, RG, 6, 0>, P.g, k, s);
+        else launch_s27(s27_residual_kernel<V, RG, 8, 0>, P.g, k, s);
+    } else {
+        if (use67) launch_s27(s27_residual_kernel<V, RG, 6, 1>, P.g, k, s);
+        else launch_s27(s27_residual_kernel<V, RG, 8, 1>, P.g, k, s);
+    }
+}
+
+// RG by value type: 16-byte accesses (4 floats, 2 doubles)
+template <typename V> constexpr int rg_small() { return sizeof(V) == 4 ? 4 : 2; }
+
+}  // namespace
+
+template <typename V>
+bool Stencil27Plan<V>::build(const omg_csr &A, const omg_csr &R, Ordering &ord, hipStream_t s) {
+    {
+        const char *e = getenv("OMG_STENCIL27");
+        if (e && e[0] == '0') return false;
+    }
+    const int64_t n = A.n_rows;
+    if (n < 64 || n != A.n_cols || (n & 7)) return false;
+    auto has = [&](int64_t r, int64_t c) {
+        for (int64_t p = A.indptr[r]; p < A.indptr[r + 1]; ++p)
+            if (A.indices[p] == c) return true;
+        return false;
+    };
+    // the grid, read off the couplings (as PlanePlan::build does)
+    int64_t nx = n;
+    for (int64_t r = 1; r < n; ++r)
+        if (!has(r, r - 1)) { nx = r; break; }
+    if (nx < 2 || n % nx) return false;
+    const int64_t lines = n / nx;
+    int64_t ny = lines;
+    for (int64_t q = 1; q < lines; ++q)
+        if (!has(q * nx, (q - 1) * nx)) { ny = q; break; }
+    if (lines % ny) return false;
+    const int64_t nz = lines / ny;
+    if ((nx & 1) || (ny & 1) || (nz & 1) || ny < 2 || nz < 2) return false;
+    // every row holds exactly its in-grid neighbours: the entry count is then (3 nx - 2)(3 ny - 2)(3 nz - 2)
+    if (A.nnz != (3 * nx - 2) * (3 * ny - 2) * (3 * nz - 2)) return false;
+    // a 27-point row next to the grid's corner: the diagonal neighbour must be there (a 7-point operator is not this)
+    if (!has(nx * ny + nx + 1, 0)) return false;
+    double w = 0.0;
+    if (!is_plain_aggregation(R, nx, ny, nz, w)) return false;
+    S27Geom q;
+    q.nx = int(nx); q.ny = int(ny); q.nz = int(nz);
+    q.hx = q.nx / 2; q.hy = q.ny / 2; q.hz = q.nz / 2;
+    q.na = int64_t(q.hx) * q.hy * q.hz;
+    q.rg = rg_small<V>();
+    if (q.hx > 64 * q.rg) return false;                          // a grid line must fit one wave (nx <= 512 in float, 256 in double)
+    q.L = (q.hx + q.rg - 1) / q.rg;
+    q.G = 64 / q.L;
+    q.nl = int64_t(q.hy) * q.hz;
+    q.ng = (q.nl + q.G - 1) / q.G;
+    q.n_wg = int((q.ng + 3) / 4);
+    q.w = double(V(w));
+    const uint64_t coef_colour_bytes = uint64_t(q.ng) * 27 * 64 * uint64_t(q.rg) * sizeof(V);
+    if (uint64_t(n) * sizeof(V) >= (uint64_t(1) << 31) || coef_colour_bytes >= (uint64_t(1) << 31)) return false;
+    // the operator onto the device as it is, every row checked and scattered into the tiles there
+    require_device();
+    {
+        SetupTimer tm("27-point level: upload CSR, check + tile the coefficients on the device");
+        DevBuf<int32_t> d_ptr(size_t(n) + 1), d_idx(size_t(std::max<int64_t>(A.nnz, 1)));
+        DevBuf<double> d_val(size_t(std::max<int64_t>(A.nnz, 1)));
+        DevBuf<unsigned long long> d_err(1);
+        OMG_HIP(hipMemcpyAsync(d_ptr.p, A.indptr, (size_t(n) + 1) * sizeof(int32_t), hipMemcpyHostToDevice, s));
+        OMG_HIP(hipMemcpyAsync(d_idx.p, A.indices, size_t(A.nnz) * sizeof(int32_t), hipMemcpyHostToDevice, s));
+        OMG_HIP(hipMemcpyAsync(d_val.p, A.data, size_t(A.nnz) * sizeof(double), hipMemcpyHostToDevice, s));
+        OMG_HIP(hipMemsetAsync(d_err.p, 0xFF, sizeof(unsigned long long), s));
+        coef.alloc(size_t(8) * size_t(q.ng) * 27 * 64 * size_t(q.rg));
+        coef.zero(s);
+        hipLaunchKernelGGL(s27_build_kernel<V>, dim3(unsigned((n + 255) / 256)), dim3(256), 0, s, d_ptr.p, d_idx.p, d_val.p, q.nx, q.ny, q.nz,
+                           q.L, q.G, q.rg, q.ng, coef.p, d_err.p);
+        OMG_HIP(hipGetLastError());
+        unsigned long long err = 0;
+        OMG_HIP(hipMemcpyAsync(&err, d_err.p, sizeof(err), hipMemcpyDeviceToHost, s));
+        OMG_HIP(hipStreamSynchronize(s));
+        if (err != ~0ull) { coef.release(); return false; }
+    }
+    g = q;
+    res67.alloc(size_t(2) * size_t(g.na));
+    partials.alloc(size_t(4) * size_t(g.n_wg) + SUM_FOLD);
+    partials.zero(s);
+    have67 = false;
+    // the ordering: colour = octant, inside a colour the aggregates in natural order (what the greedy colouring of
+    // such an operator gives: every lower-numbered neighbour of a cell lies in another octant position)
+    ord = Ordering();
+    ord.identity = false;
+    ord.sets.resize(9);
+    for (int c = 0; c <= 8; ++c) ord.sets[size_t(c)] = int64_t(c) * g.na;
+    ord.perm.resize(size_t(n));
+    ord.inv.resize(size_t(n));
+    {
+        const unsigned hw = std::max(1u, std::min(64u, std::thread::hardware_concurrency()));
+        const int nt = (int)std::min<int64_t>(hw, std::max<int64_t>(1, n / 65536));
+        auto fill = [&](int tnum) {
+            const int64_t lo = n * tnum / nt, hi = n * (tnum + 1) / nt;
+            for (int64_t r = lo; r < hi; ++r) {
+                const int64_t i = r % nx, j = (r / nx) % ny, k = r / (nx * ny);
+                const int64_t c = (i & 1) | ((j & 1) << 1) | ((k & 1) << 2);
+                const int64_t slot = c * g.na + ((k >> 1) * g.hy + (j >> 1)) * g.hx + (i >> 1);
+                ord.inv[size_t(r)] = int32_t(slot);
+                ord.perm[size_t(slot)] = int32_t(r);
+            }
+        };
+        std::vector<std::thread> th;
+        for (int tnum = 1; tnum < nt; ++tnum) th.emplace_back(fill, tnum);
+        fill(0);
+        for (auto &t2 : th) t2.join();
+    }
+    return true;
+}
+
+template <typename V>
+void Stencil27Plan<V>::sweep(const V *x_old, V *x_new, const V *b, bool x_zero, double *norm_old, bool last, double *norm_new, hipStream_t s) {
+    sweep_rg<V, rg_small<V>()>(*this, x_old, x_new, b, x_zero, norm_old, last, norm_new, s);
+    have67 = last;
+}
+
+template <typename V>
+void Stencil27Plan<V>::residual_restrict(const V *x, const V *b, bool use67, const int32_t *cmap, V *bc, hipStream_t s) {
+    OMG_REQUIRE(!use67 || have67, "internal: residuals of colours 6, 7 asked for but not there");
+    residual_rg<V, rg_small<V>()>(*this, x, b, use67, 0, cmap, bc, nullptr, s);
+}
+
+template <typename V>
+void Stencil27Plan<V>::norm(const V *x, const V *b, bool use67, double *out, hipStream_t s) {
+    OMG_REQUIRE(!use67 || have67, "internal: squares of colours 6, 7 asked for but not there");
+    const size_t nw = size_t(g.n_wg);
+    OMG_HIP(hipMemsetAsync(out + nw, 0, (use67 ? 2 : 3) * nw * sizeof(double), s));
+    residual_rg<V, rg_small<V>()>(*this, x, b, use67, 1, nullptr, nullptr, out, s);
+}
+
+template <typename V>
+void Stencil27Plan<V>::prolong(V *x, const V *e, const int32_t *cmap, hipStream_t s) {
+    S27KArgs<V> k = base_args(*this);
+    k.x_new = x; k.e = e; k.cmap = cmap;
+    launch_s27(s27_prolong_kernel<V, rg_small<V>()>, g, k, s);
+    have67 = false;
+}
+
+template <typename V>
+HostCsr Stencil27Plan<V>::operator_csr(hipStream_t s) const {
+    const int64_t nx = g.nx, ny = g.ny, nz = g.nz, n = nx * ny * nz;
+    std::vector<V> host(coef.n);
+    OMG_HIP(hipMemcpyAsync(host.data(), coef.p, coef.n * sizeof(V), hipMemcpyDeviceToHost, s));
+    OMG_HIP(hipStreamSynchronize(s));
+    HostCsr A;
+    A.n_rows = A.n_cols = n;
+    A.nnz = 27 * n;
+    A.indptr.resize(size_t(n) + 1);
+    A.indices.resize(size_t(A.nnz));
+    A.data.resize(size_t(A.nnz));
+    const unsigned hw = std::max(1u, std::min(64u, std::thread::hardware_concurrency()));
+    const int nt = (int)std::min<int64_t>(hw, std::max<int64_t>(1, n / 16384));
+    auto fill = [&](int tnum) {
+        const int64_t lo = n * tnum / nt, hi = n * (tnum + 1) / nt;
+        for (int64_t row = lo; row < hi; ++row) {
+            const int i = int(row % nx), j = int((row / nx) % ny), k = int(row / (nx * ny));
+            const int c = (i & 1) | ((j & 1) << 1) | ((k & 1) << 2);
+            const int64_t line = int64_t(k >> 1) * g.hy + (j >> 1), wave = line / g.G;
+            const int lane = int(line - wave * g.G) * g.L + (i >> 1) / g.rg, r = (i >> 1) % g.rg;
+            const V *in = host.data() + ((size_t(c) * size_t(g.ng) + size_t(wave)) * 27 * 64 + size_t(lane)) * size_t(g.rg) + size_t(r);
+            A.indptr[size_t(row)] = int32_t(27 * row);
+            for (int sl = 0; sl < 27; ++sl) {
+                const int dx = sl % 3 - 1, dy = (sl / 3) % 3 - 1, dz = sl / 9 - 1;
+                const bool present = i + dx >= 0 && i + dx < nx && j + dy >= 0 && j + dy < ny && k + dz >= 0 && k + dz < nz;
+                // an absent neighbour: an explicit zero on the row's own column (it adds +0 to the diagonal's sum)
+                A.indices[size_t(27 * row + sl)] = int32_t(present ? row + (int64_t(dz) * ny + dy) * nx + dx : row);
+                A.data[size_t(27 * row + sl)] = present ? double(in[size_t(sl) * 64 * size_t(g.rg)]) : 0.0;
+            }
+        }
+    };
+    std::vector<std::thread> th;
+    for (int tnum = 1; tnum < nt; ++tnum) th.emplace_back(fill, tnum);
+    fill(0);
+    for (auto &t2 : th) t2.join();
+    A.indptr[size_t(n)] = int32_t(27 * n);
+    return A;
+}
+
+template <typename V>
+HostCsr Stencil27Plan<V>::restriction_csr() const {
+    const int64_t nx = g.nx, ny = g.ny, nz = g.nz, n = nx * ny * nz, sj = nx, sk = nx * ny;
+    const int64_t nxc = nx / 2, nyc = ny / 2, nc = nxc * nyc * (nz / 2);
+    HostCsr R;
+    R.n_rows = nc;
+    R.n_cols = n;
+    R.nnz = n;
+    R.indptr.resize(size_t(nc) + 1);
+    R.indices.resize(size_t(n));
+    R.data.resize(size_t(n));
+    for (int64_t cr = 0; cr <= nc; ++cr) R.indptr[size_t(cr)] = int32_t(8 * cr);
+    for (int64_t cr = 0; cr < nc; ++cr) {
+        const int64_t I = cr % nxc, J = (cr / nxc) % nyc, K = cr / (nxc * nyc);
+        int64_t p = 8 * cr;
+        for (int dk = 0; dk < 2; ++dk)
+            for (int dj = 0; dj < 2; ++dj)
+                for (int di = 0; di < 2; ++di, ++p) {
+                    R.indices[size_t(p)] = int32_t((2 * K + dk) * sk + (2 * J + dj) * sj + 2 * I + di);
+                    R.data[size_t(p)] = g.w;
+                }
+    }
+    return R;
+}
+
+template struct Stencil27Plan<double>;
+template struct Stencil27Plan<float>;
+
+}  // namespace omg

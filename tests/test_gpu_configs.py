@@ -62,6 +62,7 @@ def test_config4_27_point_variable_coefficient_vcycle_fp64_against_oracle(n):
     # every cycle's norm, through the resident interface, with the device-built Galerkin operators
     with _hip.Hierarchy(info["A"], info["R"], smoother="colour") as h:
         assert h.level_sets(0) == 8 and h.level_sets(1) == 8
+        assert h.level_flags(0)["stencil27"] and h.level_flags(1)["stencil27"]       # the kernels of stencil27.hip
         h.resident_load(b)
         for k in range(3):
             assert rel(h.resident_cycle(1, 1), norms_o[k]) < NORM_RTOL, k
@@ -87,6 +88,7 @@ def test_config4_27_point_variable_coefficient_vcycle_fp32_against_fp64_oracle(n
     A = operators.coeffecientList(A0, R)
     with _hip.Hierarchy(A, R, smoother="colour", dtype="float32") as h:
         assert h.device_dtype() == np.dtype(np.float32) and h.level_sets(0) == 8
+        assert h.level_flags(0)["stencil27"] and h.level_flags(1)["stencil27"]       # the kernels of stencil27.hip
         h.resident_load(b)
         norms = [h.resident_cycle(1, 1) for _ in range(3)]
         x = h.resident_fetch()
