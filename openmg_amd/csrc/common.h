@@ -517,6 +517,7 @@ struct PlaneGeom {
     double c[7] = {0, 0, 0, 0, 0, 0, 0};   // -K, -J, -I, diagonal, +I, +J, +K
     double w = 0.0;                   // the restriction's weight
     // small levels (set when the plan is built, from OMG_PLANE_BLOCK / OMG_PLANE_BLOCK_CELLS / OMG_PLANE_LA2):
+    bool dim2 = false;                // nz == 1: a 2-D grid (five-point stencil, 2 x 2 aggregation): tile2d_kernel
     bool block = false;               // whole grid of <= 64^3 cells: block_kernel where the pass allows it
     bool la2 = true;                  // marching kernel with two steps of lookahead for workgroups of <= 128 threads
 };

@@ -495,7 +495,7 @@ int cycle_body(Hier<V> *h, int l, int pre, int post, bool want_norm = false, dou
         const bool child_plane = l + 1 < last && use_plane(h, C, pre, post);
         const bool child_zero = child_plane && pre <= 1 && halves == 3;       // the child's down pass never reads its zero iterate
         if (l + 1 < last && !child_zero) ensure_format(h, l + 1);
-        const bool child_first = l + 1 < last && !child_zero && !use_s27(h, C) && first_sweep_in_restrict(h, C, pre);
+        const bool child_first = l + 1 < last && !child_zero && !use_s27(h, C) && !L.plane->g.dim2 && first_sweep_in_restrict(h, C, pre);
         typename PlanePlan<V>::Coarse c;
         c.map = L.r_out.p;
         c.b = C.b.p;

@@ -1041,6 +1041,165 @@ __global__ __launch_bounds__(256) void block_kernel(const BlockKArgs<V> a) {
     }
 }
 
+// ---- 2-D levels (five-point stencils, 2 x 2 aggregation): a tile of the grid per workgroup, whole in LDS ---------
+// BASELINE configs[1]'s grids (1024^2 and its Galerkin products).  A 2-D level has nothing to march along, so each half
+// of the cycle is one launch of independent tiles: the workgroup loads its BX x BY cells with a ring of three (x; b: two),
+// relaxes red on tile + 2 and black on tile + 1 redundantly — the same operations on the same operands as the owning
+// tiles, so no workgroup waits for another —, and finishes on the tile itself:
+//   down: x_new out, residual, the four residuals of a coarse cell in R's column order -> coarse right-hand side;
+//   up:   the tile's x is x_old + w e first (openmg/__init__.py:214,220); x_new out; optionally the residual's squares.
+// A row is the row kernels' chain over the five slots in column order (-J, -I, diagonal, +I, +J) from +0, a cell outside
+// the grid a zero value, and the same quotient: the bits of the set-by-set schedule (tests/test_gpu_plane2d.py).
+template <typename V>
+struct Tile2KArgs {
+    const V *x_old;
+    V *x_new;
+    const V *b;
+    int nx, ny, nr;
+    int nbx;
+    V c1, c2, c3, c4, c5, w;
+    int fast_div;
+    int nxc, nyc;
+    const int32_t *cmap;
+    V *bc;
+    const V *ec;
+    double *partials;
+};
+
+template <typename V, int MODE, bool XZ, bool NORM, bool SWEEP, int BX, int BY>
+__global__ __launch_bounds__(256) void tile2d_kernel(const Tile2KArgs<V> a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char plane_smem[];
+    constexpr int EX = BX + 6, EY = BY + 6, vol = EX * EY, NT = 256;
+    V *const X = reinterpret_cast<V *>(plane_smem);
+    V *const B = X + vol;
+    V *const E = B + vol;                                                  // up: coarse correction under the region; down / norm: the tile's residuals
+    __shared__ double s_red[NT / 64];
+    const int t = int(threadIdx.x);
+    const int bi = int(blockIdx.x) % a.nbx, bj = int(blockIdx.x) / a.nbx;
+    const int i0 = bi * BX - 3, j0 = bj * BY - 3;                          // grid coordinates of LDS cell (0, 0): odd
+    const V rc3 = refined_rcp(a.c3);
+    const bool fast = a.fast_div != 0;
+    auto slot_of = [&](int gi, int gj) { return (((gi + gj) & 1) ? a.nr : 0) + ((gj * a.nx + gi) >> 1); };
+    auto in_grid = [&](int gi, int gj) { return gi >= 0 && gi < a.nx && gj >= 0 && gj < a.ny; };
+    // all loads requested before the first is used
+    constexpr int NL = (vol + NT - 1) / NT;
+    V xv[NL], bv[NL];
+#pragma unroll
+    for (int n = 0; n < NL; ++n) {
+        const int c = t + n * NT;
+        const int gi = i0 + c % EX, gj = j0 + c / EX;
+        const bool ok = c < vol && in_grid(gi, gj);
+        const int slot = ok ? slot_of(gi, gj) : 0;
+        bv[n] = a.b[slot];
+        xv[n] = XZ ? V(0) : a.x_old[slot];
+        if (!ok) { bv[n] = V(0); xv[n] = V(0); }                           // cells outside the grid are zeros and stay so
+    }
+    if (MODE == 1) {
+        // the coarse cells under the region: LDS cell (li, lj) lies over coarse cell ((i0 + li) >> 1, (j0 + lj) >> 1), i0, j0 odd
+        constexpr int NC = (((EX + 1) / 2 + 1) * ((EY + 1) / 2 + 1) + NT - 1) / NT;
+        constexpr int CW = (EX + 1) / 2 + 1, CH = (EY + 1) / 2 + 1;
+        const int ci0 = (i0 - 1) / 2, cj0 = (j0 - 1) / 2;                  // floor(i0 / 2), floor(j0 / 2): i0, j0 are odd
+#pragma unroll
+        for (int n = 0; n < NC; ++n) {
+            const int c = t + n * NT;
+            const int I = ci0 + c % CW, J = cj0 + c / CW;
+            const bool ok = c < CW * CH && I >= 0 && J >= 0 && I < a.nxc && J < a.nyc;
+            const int ce = J * a.nxc + I;
+            const V ev = ok ? a.ec[a.cmap ? a.cmap[ce] : ce] : V(0);
+            if (c < CW * CH) E[c] = ev;
+        }
+        __syncthreads();
+        // openmg/__init__.py:214,220: x + R^T e — the product rounded, then added
+#pragma unroll
+        for (int n = 0; n < NL; ++n) {
+            const int c = t + n * NT;
+            const int gi = i0 + c % EX, gj = j0 + c / EX;
+            if (c < vol && in_grid(gi, gj)) xv[n] = xv[n] + madd(a.w, E[((gj >> 1) - cj0) * CW + ((gi >> 1) - ci0)], V(0));
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int n = 0; n < NL; ++n)
+        if (t + n * NT < vol) { X[t + n * NT] = xv[n]; B[t + n * NT] = bv[n]; }
+    __syncthreads();
+    auto row = [&](int c) -> V {
+        V s = madd(a.c1, X[c - EX], V(0));
+        s = madd(a.c2, X[c - 1], s);
+        s = madd(a.c3, X[c], s);
+        s = madd(a.c4, X[c + 1], s);
+        return madd(a.c5, X[c + EX], s);
+    };
+    // cells of one colour inside the tile widened by RING (<= 2), clipped to the grid
+    auto sweep = [&](int colour, auto RING) {
+        constexpr int ring = decltype(RING)::value;
+        constexpr int wx = BX + 2 * ring, wy = BY + 2 * ring, off = 3 - ring;
+        constexpr int np = wx / 2 * wy, NI = (np + NT - 1) / NT;
+#pragma unroll
+        for (int n = 0; n < NI; ++n) {
+            const int p = t + n * NT;
+            const int lj = off + p / (wx / 2);
+            // i0, j0 are odd: grid parity of LDS cell (li, lj) = (li + lj) & 1
+            const int li = off + 2 * (p % (wx / 2)) + ((off + lj + colour) & 1);
+            const int gi = i0 + li, gj = j0 + lj;
+            if (p >= np || !in_grid(gi, gj)) continue;
+            const int l = lj * EX + li;
+            // openmg/solvers.py:68   x[i] = x[i] + (b[i] - Aix) / A[i, i]
+            X[l] = X[l] + block_quotient(B[l] - row(l), a.c3, rc3, fast);
+        }
+    };
+    if (SWEEP) {
+        sweep(0, std::integral_constant<int, 2>());
+        __syncthreads();
+        sweep(1, std::integral_constant<int, 1>());
+        __syncthreads();
+    }
+    constexpr int NB = (BX * BY + NT - 1) / NT;
+    double sq = 0.0;
+#pragma unroll
+    for (int n = 0; n < NB; ++n) {
+        const int c = t + n * NT;
+        const int li = 3 + c % BX, lj = 3 + c / BX;
+        const int gi = i0 + li, gj = j0 + lj;
+        if (c >= BX * BY || gi >= a.nx || gj >= a.ny) continue;
+        const int l = lj * EX + li;
+        if (SWEEP || MODE == 1) a.x_new[slot_of(gi, gj)] = X[l];
+        if (MODE == 0 || NORM) {
+            const V res = B[l] - row(l);
+            if (MODE == 0) E[c] = res;
+            if (NORM) sq = fma(double(res), double(res), sq);
+        }
+    }
+    if (MODE == 0) {
+        __syncthreads();
+        // openmg/__init__.py:210: a coarse cell's four fine residuals in column order
+        constexpr int hx = BX / 2, hy = BY / 2, NCC = (hx * hy + NT - 1) / NT;
+#pragma unroll
+        for (int n = 0; n < NCC; ++n) {
+            const int c = t + n * NT;
+            const int I = c % hx, J = c / hx;
+            const int GI = (bi * BX >> 1) + I, GJ = (bj * BY >> 1) + J;
+            if (c >= hx * hy || GI >= a.nxc || GJ >= a.nyc) continue;
+            V acc = V(0);
+#pragma unroll
+            for (int d = 0; d < 4; ++d) acc = madd(a.w, E[(2 * J + (d >> 1)) * BX + 2 * I + (d & 1)], acc);
+            const int ce = GJ * a.nxc + GI;
+            a.bc[a.cmap ? a.cmap[ce] : ce] = acc;
+        }
+    }
+    if (NORM) {
+        // fixed order: lanes of a wave (shuffle tree), then the waves in turn
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) sq += __shfl_down(sq, off, 64);
+        if ((t & 63) == 0) s_red[t >> 6] = sq;
+        __syncthreads();
+        if (t == 0) {
+            double tot = 0.0;
+            for (int wv = 0; wv < NT / 64; ++wv) tot += s_red[wv];
+            a.partials[blockIdx.x] = tot;
+        }
+    }
+}
+
 // ---- host: does the level qualify, and how is it tiled -----------------------------------------------
 int env_int3(const char *name, int out[3]) {
     const char *e = getenv(name);
@@ -1115,6 +1274,24 @@ void choose_tiles(PlaneGeom &g, size_t value_bytes, int model = 0) {
     set(bx, by, bz);
 }
 
+// 2-D levels: the tile shapes tile2d_kernel is instantiated for, largest first; the largest that still gives 128 workgroups
+constexpr int TILE2_SHAPES[3][2] = {{64, 32}, {32, 16}, {16, 8}};
+void choose_tile2d(PlaneGeom &g, size_t value_bytes) {
+    int pick = 2;
+    for (int i = 0; i < 3; ++i) {
+        const int64_t n = int64_t((g.nx + TILE2_SHAPES[i][0] - 1) / TILE2_SHAPES[i][0]) * ((g.ny + TILE2_SHAPES[i][1] - 1) / TILE2_SHAPES[i][1]);
+        if (n >= 128) { pick = i; break; }
+    }
+    g.block = false;
+    g.TX = TILE2_SHAPES[pick][0]; g.TY = TILE2_SHAPES[pick][1]; g.LZ = 1;
+    g.ntx = (g.nx + g.TX - 1) / g.TX; g.nty = (g.ny + g.TY - 1) / g.TY; g.ntz = 1;
+    g.n_wg = g.ntx * g.nty;
+    g.threads = 256;
+    const size_t vol = size_t(g.TX + 6) * size_t(g.TY + 6);
+    g.lds_bytes = (2 * vol + std::max(size_t(g.TX) * g.TY, size_t(g.TX / 2 + 4) * size_t(g.TY / 2 + 4))) * value_bytes;
+    (void)pick;
+}
+
 }  // namespace
 
 template <typename V>
@@ -1142,7 +1319,13 @@ bool PlanePlan<V>::build(const omg_csr &A, const omg_csr &R, Ordering &ord) {
         if (!has(q * nx, (q - 1) * nx)) { ny = q; break; }
     if (lines % ny) return false;
     const int64_t nz = lines / ny;
-    if ((nx & 1) || (ny & 1) || (nz & 1) || ny < 2 || nz < 2) return false;
+    // nz == 1: a 2-D grid (five-point stencil, 2 x 2 aggregation): tile2d_kernel instead of the marching kernel
+    const bool dim2 = nz == 1;
+    if ((nx & 1) || (ny & 1) || (!dim2 && (nz & 1)) || ny < 2) return false;
+    {
+        const char *e = getenv("OMG_PLANE_2D");
+        if (dim2 && e && e[0] == '0') return false;
+    }
     const int64_t sj = nx, sk = nx * ny;
     // (the ordering — two colours by parity, red first — is WRITTEN below once the level has qualified: it is
     // what the greedy smallest-free-colour pass in natural order finds on such a stencil, every lower
@@ -1170,13 +1353,15 @@ bool PlanePlan<V>::build(const omg_csr &A, const omg_csr &R, Ordering &ord) {
                 if (!havec[sl]) { havec[sl] = true; c[sl] = A.data[p]; }
             }
         }
+        if (dim2) havec[0] = havec[6] = true;               // (no such slots: their coefficients stay 0)
         for (int e = 0; e < 7; ++e)
             if (!havec[e]) return false;
         if (!(std::fabs(c[3]) > 0.0) || !std::isfinite(c[3])) return false;
     }
     // every row: exactly its in-grid neighbours, in slot (= column) order, with those coefficients (as V
     // they are what the device format holds); its slot in the ordering; and R's row of every coarse cell
-    const int64_t nxc = nx / 2, nyc = ny / 2, nzc = nz / 2;
+    const int64_t nxc = nx / 2, nyc = ny / 2, nzc = dim2 ? 1 : nz / 2;
+    const int per = dim2 ? 4 : 8;                            // fine cells of an aggregate
     if (R.n_cols != n || R.n_rows != nxc * nyc * nzc || R.nnz != n) return false;
     const double w = R.nnz ? R.data[0] : 0.0;
     // (memory-bound: the scan reads every byte of the operator once; 64 threads on a many-core host: 64 -> ~15 ms at 256^3)
@@ -1207,8 +1392,8 @@ bool PlanePlan<V>::build(const omg_csr &A, const omg_csr &R, Ordering &ord) {
         for (int64_t cr = clo; cr < chi; ++cr) {
             const int64_t I = cr % nxc, J = (cr / nxc) % nyc, K = cr / (nxc * nyc);
             int64_t p = R.indptr[cr];
-            if (R.indptr[cr + 1] - p != 8) { ok = false; return; }
-            for (int dk = 0; dk < 2; ++dk)
+            if (R.indptr[cr + 1] - p != per) { ok = false; return; }
+            for (int dk = 0; dk < (dim2 ? 1 : 2); ++dk)
                 for (int dj = 0; dj < 2; ++dj)
                     for (int di = 0; di < 2; ++di, ++p) {
                         const int64_t f = (2 * K + dk) * sk + (2 * J + dj) * sj + 2 * I + di;
@@ -1249,9 +1434,14 @@ bool PlanePlan<V>::build(const omg_csr &A, const omg_csr &R, Ordering &ord) {
     for (int e = 0; e < 7; ++e) g.c[e] = double(V(c[e]));
     g.w = double(V(w));
     g.z_base = 0; g.z_end = g.nz; g.kv0 = 0; g.kv1 = g.nz; g.kc_off = 0; g.nzc = g.nz / 2;
-    choose_tiles(g, sizeof(V));
-    small_level_switches(g);
-    if (g.TX <= 0 || g.threads > 512) return false;
+    g.dim2 = dim2;
+    if (dim2) {
+        choose_tile2d(g, sizeof(V));
+    } else {
+        choose_tiles(g, sizeof(V));
+        small_level_switches(g);
+        if (g.TX <= 0 || g.threads > 512) return false;
+    }
     partials.alloc(size_t(g.n_wg) + SUM_FOLD);
     return true;
 }
@@ -1376,7 +1566,8 @@ HostCsr PlanePlan<V>::operator_csr() const {
 template <typename V>
 HostCsr PlanePlan<V>::restriction_csr() const {
     const int64_t nx = g.nx, ny = g.ny, nz = g.nz, n = nx * ny * nz, sj = nx, sk = nx * ny;
-    const int64_t nxc = nx / 2, nyc = ny / 2, nc = nxc * nyc * (nz / 2);
+    const int per = g.dim2 ? 4 : 8;
+    const int64_t nxc = nx / 2, nyc = ny / 2, nc = nxc * nyc * (g.dim2 ? 1 : nz / 2);
     HostCsr R;
     R.n_rows = nc;
     R.n_cols = n;
@@ -1384,11 +1575,11 @@ HostCsr PlanePlan<V>::restriction_csr() const {
     R.indptr.resize(size_t(nc) + 1);
     R.indices.resize(size_t(n));
     R.data.resize(size_t(n));
-    for (int64_t cr = 0; cr <= nc; ++cr) R.indptr[size_t(cr)] = int32_t(8 * cr);
+    for (int64_t cr = 0; cr <= nc; ++cr) R.indptr[size_t(cr)] = int32_t(per * cr);
     for (int64_t cr = 0; cr < nc; ++cr) {
         const int64_t I = cr % nxc, J = (cr / nxc) % nyc, K = cr / (nxc * nyc);
-        int64_t p = 8 * cr;
-        for (int dk = 0; dk < 2; ++dk)
+        int64_t p = per * cr;
+        for (int dk = 0; dk < (g.dim2 ? 1 : 2); ++dk)
             for (int dj = 0; dj < 2; ++dj)
                 for (int di = 0; di < 2; ++di, ++p) {
                     R.indices[size_t(p)] = int32_t((2 * K + dk) * sk + (2 * J + dj) * sj + 2 * I + di);
@@ -1531,6 +1722,30 @@ void launch_block(const PlaneGeom &g, const V *x_old, V *x_new, const V *b, cons
     OMG_HIP(hipGetLastError());
 }
 
+
+template <typename V, int MODE, bool XZ, bool NORM, bool SWEEP>
+void launch_tile2d(const PlaneGeom &g, const V *x_old, V *x_new, const V *b, const typename PlanePlan<V>::Coarse &c, double *out, hipStream_t s) {
+    Tile2KArgs<V> a;
+    std::memset(&a, 0, sizeof(a));
+    a.x_old = x_old; a.x_new = x_new; a.b = b;
+    a.nx = g.nx; a.ny = g.ny; a.nr = int(int64_t(g.nx) * g.ny / 2);
+    a.nbx = g.ntx;
+    a.c1 = V(g.c[1]); a.c2 = V(g.c[2]); a.c3 = V(g.c[3]); a.c4 = V(g.c[4]); a.c5 = V(g.c[5]);
+    a.w = V(g.w);
+    a.fast_div = (std::fabs(g.c[3]) >= 0x1p-400 && std::fabs(g.c[3]) <= 0x1p400) ? 1 : 0;
+    a.nxc = g.nx / 2; a.nyc = g.ny / 2;
+    a.cmap = c.map; a.bc = c.b; a.ec = c.e;
+    a.partials = out;
+    auto go = [&](auto kernel) {
+        allow_lds(kernel, g.lds_bytes);
+        hipLaunchKernelGGL(kernel, dim3(unsigned(g.n_wg)), dim3(256), g.lds_bytes, s, a);
+    };
+    if (g.TX == 64) go(tile2d_kernel<V, MODE, XZ, NORM, SWEEP, 64, 32>);
+    else if (g.TX == 32) go(tile2d_kernel<V, MODE, XZ, NORM, SWEEP, 32, 16>);
+    else go(tile2d_kernel<V, MODE, XZ, NORM, SWEEP, 16, 8>);
+    OMG_HIP(hipGetLastError());
+}
+
 inline bool small_tile(const PlaneGeom &g) { return g.la2 && g.threads <= 128; }
 
 template <typename K, typename V>
@@ -1548,7 +1763,17 @@ void PlanePlan<V>::down(const V *x_old, V *x_new, const V *b, bool x_zero, const
     DevBuf<unsigned long long> sb;
     stamps_begin(k, g, sb);
 #endif
-    if (!sweep) {
+    if (g.dim2) {
+        OMG_REQUIRE(!peer && !c.diag, "2-D plane level: no slab neighbours, no fused first relaxation of the coarse level");
+        if (c.x) OMG_HIP(hipMemsetAsync(c.x, 0, size_t(g.nx / 2) * size_t(g.ny / 2) * sizeof(V), s));      // (coarse zero iterate, :191-192)
+        if (sweep) {
+            if (x_zero) launch_tile2d<V, 0, true, false, true>(g, x_old, x_new, b, c, nullptr, s);
+            else launch_tile2d<V, 0, false, false, true>(g, x_old, x_new, b, c, nullptr, s);
+        } else {
+            if (x_zero) launch_tile2d<V, 0, true, false, false>(g, x_old, x_new, b, c, nullptr, s);
+            else launch_tile2d<V, 0, false, false, false>(g, x_old, x_new, b, c, nullptr, s);
+        }
+    } else if (!sweep) {
         // preIterations = 0: residual of the iterate as it is + restriction; x_new is not written
         OMG_REQUIRE(!peer, "plane pass without its sweep: not built for slabs with neighbours");
         if (x_zero && !c.x && !c.diag && block_level(g)) launch_block<V, 0, false>(g, x_old, x_new, b, c, s);
@@ -1585,7 +1810,16 @@ void PlanePlan<V>::up(const V *x_old, V *x_new, const V *b, const Coarse &c, dou
     DevBuf<unsigned long long> sb;
     stamps_begin(k, g, sb);
 #endif
-    if (!sweep) {
+    if (g.dim2) {
+        OMG_REQUIRE(!peer, "2-D plane level: no slab neighbours");
+        if (sweep) {
+            if (out) launch_tile2d<V, 1, false, true, true>(g, x_old, x_new, b, c, out, s);
+            else launch_tile2d<V, 1, false, false, true>(g, x_old, x_new, b, c, nullptr, s);
+        } else {
+            if (out) launch_tile2d<V, 1, false, true, false>(g, x_old, x_new, b, c, out, s);
+            else launch_tile2d<V, 1, false, false, false>(g, x_old, x_new, b, c, nullptr, s);
+        }
+    } else if (!sweep) {
         // postIterations = 0 (the reference's default): x_new = x_old + R^T e (+ the squares of its residual)
         OMG_REQUIRE(!peer, "plane pass without its sweep: not built for slabs with neighbours");
         if (!out && block_level(g)) launch_block<V, 1, false>(g, x_old, x_new, b, c, s);

@@ -305,11 +305,11 @@ __global__ __launch_bounds__(256, NOLD ? 1 : 2) void s27_sweep_kernel(const S27K
             const int s = g0 + u;
             const Nb nb = neighbour(1, PY, PZ, s);
             const bool in_line = s == 12 || s == 14;
-            if (XZ && !(nb.colour < CA) && !in_line) continue;
-            if (LAST && s == 13) {
+            if (LAST && s == 13) {                     // (before the skip below: with XZ slot 13 itself adds nothing)
 #pragma unroll
                 for (int r = 0; r < RG; ++r) keep1[r] = acc[r].s[1];
             }
+            if (XZ && !(nb.colour < CA) && !in_line) continue;
 #pragma unroll
             for (int r = 0; r < RG; ++r) {
                 acc[r].s[s & 3] = madd(c[u].v[r], x[u].v[r], acc[r].s[s & 3]);
