@@ -283,6 +283,83 @@ def pmc_traffic(name, bytes_per_launch, w):
     return None, None
 
 
+def config4_leg(size, grids, steps, warmup, repeats, sync_of):
+    """BASELINE configs[4]'s per-GPU workload on ONE GPU: 27-point variable-coefficient operator (Q1 stiffness of
+    -div(kappa grad u), kappa = exp(U(-1,1) ln 10) per cell, default_rng(2024): SURVEY 8(d)), fp32 levels, Galerkin
+    products rebuilt on the device, 8-colour Gauss-Seidel V(1,1) — the same timed loop as the headline: regions of
+    `steps` batched cycles, every cycle's norm computed."""
+    import numpy as np
+    from openmg_amd import _hip, operators
+    shape = (size,) * 3
+    t0 = time.perf_counter()
+    A0 = operators.stencil27_variable(shape)
+    b = A0 @ np.random.default_rng(12345).random(A0.shape[0])
+    t1 = time.perf_counter()
+    R = operators.restrictionList(shape, grids - 2, 8)
+    A = operators.coeffecientList(A0, R)                        # Galerkin products on the device
+    t2 = time.perf_counter()
+    h = _hip.Hierarchy(A, R, smoother="colour", dtype="float32")
+    t3 = time.perf_counter()
+    h.resident_load(b)
+    n, nnz, w = A0.shape[0], A0.nnz, 4
+    fused = bool(h.level_flags(0)["stencil27"])
+    times, prof, norms = timed_regions(h, sync_of(h), steps, warmup, repeats, 1, 1, ("smoother_set_sweep",))
+    e = statistics.median(times)
+    cnt, ms = prof["smoother_set_sweep"]
+    out = {"what": "BASELINE configs[4] per GPU: 3-D 27-point variable-coefficient Poisson %d^3, %d grids, fp32 levels, Galerkin products "
+                   "on the device, 8-colour Gauss-Seidel V(1,1); same timed loop as `value` (batched cycles, every norm computed)" % (size, len(A)),
+           "vcycles_per_s": round(steps / e, 3), "ms_per_step": round(1e3 * e / steps, 4),
+           "ms_per_step_all": [round(1e3 * t / steps, 4) for t in times], "dtype": "f32",
+           "unknowns": n, "nnz": nnz, "stencil27_kernels": fused, "level_flags": [h.level_flags(l) for l in range(len(A) - 1)],
+           "generate_s": round(t1 - t0, 2), "rap_s": round(t2 - t1, 2), "hierarchy_s": round(t3 - t2, 2),
+           "norms_last_region_tail": norms[-3:]}
+    if fused and cnt:
+        # the dominant kernel: one smoothing sweep of the fine grid = four pair launches of stencil27.hip.  Bytes it has
+        # to move: the 27 coefficients of every row once (27 w n), b read and x written once (2 w n), and the iterate
+        # read once per launch (every launch needs every colour's neighbours: 4 w n)
+        sweep_bytes = (27 + 2 + 4) * w * n
+        us = 1e3 * ms / cnt
+        out["roofline"] = {"bound": "hbm", "kernel": "s27_sweep_kernel x 4 (one 8-colour Gauss-Seidel sweep of the fine grid, stencil27.hip)",
+                           "achieved": round(sweep_bytes / us / 1e3, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": round(sweep_bytes / us / 1e3 / HBM_PEAK_GBS, 4), "traffic": None,
+                           "bytes_per_sweep": sweep_bytes, "avg_sweep_us": round(us, 2), "sweeps_timed": cnt,
+                           "bytes_definition": "27 coefficients per row (27 w n) + b read, x written (2 w n) + the iterate read once per launch (4 w n)",
+                           "csr_equiv_bytes": (w + 4) * nnz + 4 * (n + 8) + 3 * w * n + 8 * w * n,
+                           "csr_equiv_GBps": round(((w + 4) * nnz + 4 * (n + 8) + 3 * w * n + 8 * w * n) / us / 1e3, 1)}
+    # the whole level-0 kernel table (untimed region)
+    h.profile_enable(True)
+    for _ in range(min(steps, 10)):
+        h.resident_cycle(1, 1, want_norm=True)
+    tab = h.profile_read()
+    h.profile_enable(False)
+    out["level0_kernels"] = {k: {"launches_per_cycle": c / min(steps, 10), "avg_us": round(1e3 * m / c, 2)} for k, (c, m) in tab.items() if c}
+    h.close()
+    return out
+
+
+def config1_leg(steps, warmup, repeats, sync_of):
+    """BASELINE configs[1]: 2-D 5-point Poisson 1024^2, 4 grids, fp64: weighted Jacobi (the smoother the config names)
+    and red-black Gauss-Seidel (fused tile passes), V(1,1), same timed loop."""
+    import numpy as np
+    from openmg_amd import _hip, operators
+    shape = (1024, 1024)
+    A0 = operators.stencil_poisson(shape)
+    b = A0 @ np.random.default_rng(12345).random(A0.shape[0])
+    R = operators.restrictionList(shape, 2, 8)
+    A = operators.coeffecientList(A0, R)
+    out = {"what": "BASELINE configs[1]: 2-D 5-point Poisson 1024^2, 4 grids, fp64, V(1,1); same timed loop as `value`"}
+    for name, smoother, kw in (("weighted_jacobi", "jacobi", {"omega": 2.0 / 3.0}), ("red_black", "colour", {})):
+        h = _hip.Hierarchy(A, R, smoother=smoother, **kw)
+        h.resident_load(b)
+        times, _, norms = timed_regions(h, sync_of(h), steps * 4, warmup, repeats, 1, 1, ())
+        e = statistics.median(times)
+        out[name] = {"vcycles_per_s": round(steps * 4 / e, 1), "ms_per_step": round(1e3 * e / (steps * 4), 4),
+                     "plane_levels": [bool(h.level_flags(l)["plane"]) for l in range(len(A) - 1)],
+                     "norms_last_region_tail": norms[-2:]}
+        h.close()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -303,6 +380,9 @@ def main():
     ap.add_argument("--no-sets", action="store_true", help="skip the set-by-set schedule (OMG_PLANE=0) leg")
     ap.add_argument("--no-lex", action="store_true", help="skip the leg with the reference's lexicographic Gauss-Seidel")
     ap.add_argument("--no-dropin", action="store_true", help="skip the legs through the Python drop-in (mgCycle per call, mgSolve end to end)")
+    ap.add_argument("--no-config4", action="store_true", help="skip the configs[4] leg (27-point variable-coefficient, fp32, 256^3)")
+    ap.add_argument("--no-config1", action="store_true", help="skip the configs[1] leg (2-D 1024^2)")
+    ap.add_argument("--config4-size", type=int, default=256)
     ap.add_argument("--dist", type=int, default=0, help="force the multi-GPU code path even with one rank (debug)")
     ap.add_argument("--watchdog", type=int, default=900, help="multi-GPU: abort after this many seconds")
     ap.add_argument("--overlap", type=int, default=1,
@@ -523,6 +603,14 @@ def main():
                        "as the smoother; grid star stencils run a sweep as one wavefront launch (march.hip, "
                        "OMG_MARCH=0: one launch per level set), bit-identical either way", min(repeats, 3), False)
 
+    config4 = None
+    if not args.no_config4 and args.dtype == "f64" and args.smoother == "colour":
+        _PROBLEM.clear()                               # (the 256^3 7-point operator: 1.9 GB of host memory)
+        config4 = config4_leg(args.config4_size, args.grids, max(5, args.steps // 2), 3, min(repeats, 3), syncer)
+    config1 = None
+    if not args.no_config1 and args.dtype == "f64" and args.smoother == "colour":
+        config1 = config1_leg(args.steps, 3, min(repeats, 3), syncer)
+
     cpu = None
     if not args.no_cpu:
         rate, dt, cpu_spmv = cpu_baseline(args.cpu_size, args.grids, args.cpu_cycles)
@@ -579,6 +667,8 @@ def main():
         "roofline": roofline,
         "default_cycle": default_cycle,
         "dropin": dropin,
+        "config4": config4,
+        "config1": config1,
         "set_schedule": set_path,
         "csr_path": csr_path,
         "reference_smoother": lex_path,

@@ -63,6 +63,16 @@ typedef unsigned v4u __attribute__((ext_vector_type(4)));
 typedef float v4f __attribute__((ext_vector_type(4)));
 typedef float v2f __attribute__((ext_vector_type(2)));
 
+// tuning switches (A/B builds: make EXTRA=-DS27_...)
+#ifndef S27_COEF_AUX
+#define S27_COEF_AUX 0                    // cache policy of the coefficient loads (gfx950: 1 = sc0, 2 = nt, 16 = sc1): they are read once
+#endif
+#ifndef S27_SG
+#define S27_SG 9                          // slots per load group
+#endif
+#ifndef S27_WAVES
+#define S27_WAVES 2                       // launch bound: waves per SIMD the sweep / residual kernels are compiled for
+#endif
 constexpr int S27_OOB = 0x7FFFFFF0;       // byte offset behind every buffer: the range check answers 0 / drops the store
 
 __device__ __forceinline__ double madd(double v, double x, double acc) { return fma(v, x, acc); }
@@ -73,12 +83,14 @@ template <typename V, int RG>
 struct Vec {
     V v[RG];
 };
+template <int AUX = 0>
 __device__ __forceinline__ Vec<float, 4> ldv(__amdgpu_buffer_rsrc_t rs, int idx, Vec<float, 4> *) {
-    const v4f q = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rs, idx * 4, 0, 0));
+    const v4f q = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rs, idx * 4, 0, AUX));
     return {{q.x, q.y, q.z, q.w}};
 }
+template <int AUX = 0>
 __device__ __forceinline__ Vec<double, 2> ldv(__amdgpu_buffer_rsrc_t rs, int idx, Vec<double, 2> *) {
-    const v4u q = __builtin_amdgcn_raw_buffer_load_b128(rs, idx * 8, 0, 0);
+    const v4u q = __builtin_amdgcn_raw_buffer_load_b128(rs, idx * 8, 0, AUX);
     return {{__builtin_bit_cast(double, v2u{q.x, q.y}), __builtin_bit_cast(double, v2u{q.z, q.w})}};
 }
 // element-wise masked store (mask bit r: element r is a row of the grid)
@@ -195,9 +207,9 @@ __device__ __forceinline__ void block_partial(double sq, double *out) {
 // The 27 slots of a row are taken in groups of SG: the group's coefficient and operand loads are issued together,
 // then its fmas; a scheduling barrier between the groups keeps the compiler from hoisting every load of the unrolled
 // row to the top (54 sixteen-byte loads in flight: 256 registers and scratch).
-constexpr int SG = 9;
+constexpr int SG = S27_SG;
 template <typename V, int RG, int PAIR, bool XZ, bool NOLD, bool LAST>
-__global__ __launch_bounds__(256, NOLD ? 1 : 2) void s27_sweep_kernel(const S27KArgs<V> a) {
+__global__ __launch_bounds__(256, NOLD ? 1 : S27_WAVES) void s27_sweep_kernel(const S27KArgs<V> a) {
     static_assert(!LAST || PAIR == 3, "only the last pair's rows are final when their launch ends");
     static_assert(!(XZ && NOLD), "a zero iterate has no predecessor cycle");
     typedef Vec<V, RG> VR;
@@ -212,7 +224,7 @@ __global__ __launch_bounds__(256, NOLD ? 1 : 2) void s27_sweep_kernel(const S27K
     const __amdgpu_buffer_rsrc_t kb = __builtin_amdgcn_make_buffer_rsrc(const_cast<V *>(a.coef + size_t(CB) * (a.coef_bytes / sizeof(V))), 0, a.coef_bytes, 0x00020000);
     const int ok = t.mask ? 1 : 0;                     // (a lane without rows asks for nothing)
     constexpr int NONE = S27_OOB / int(sizeof(V));
-    auto cload = [&](const __amdgpu_buffer_rsrc_t &rs, int s) -> VR { return ldv(rs, ok ? t.cbase + s * 64 * RG : NONE, (VR *)nullptr); };
+    auto cload = [&](const __amdgpu_buffer_rsrc_t &rs, int s) -> VR { return ldv<S27_COEF_AUX>(rs, ok ? t.cbase + s * 64 * RG : NONE, (VR *)nullptr); };
     // operand of a slot: current = x_new for colours already relaxed in this sweep (< CA), x_old otherwise
     auto operand = [&](const __amdgpu_buffer_rsrc_t &rs, const Nb &nb) -> VR {
         return ldv(rs, ok ? nb.colour * a.na + t.a0 + nb.sk * lhyhx + nb.sj * lhx + nb.si : NONE, (VR *)nullptr);
@@ -232,6 +244,7 @@ __global__ __launch_bounds__(256, NOLD ? 1 : 2) void s27_sweep_kernel(const S27K
 #pragma unroll
         for (int u = 0; u < SG; ++u) {
             const int s = g0 + u;
+            if (s >= 27) continue;
             const Nb nb = neighbour(0, PY, PZ, s);
             const bool from_new = nb.colour < CA;
             if (XZ && !from_new && s != 13) continue;  // (c * 0 leaves a chain as it is; the coefficient is not even loaded)
@@ -243,6 +256,7 @@ __global__ __launch_bounds__(256, NOLD ? 1 : 2) void s27_sweep_kernel(const S27K
 #pragma unroll
         for (int u = 0; u < SG; ++u) {
             const int s = g0 + u;
+            if (s >= 27) continue;
             const Nb nb = neighbour(0, PY, PZ, s);
             if (XZ && !(nb.colour < CA)) continue;     // (slot 13 too: x_i = 0)
 #pragma unroll
@@ -283,6 +297,7 @@ __global__ __launch_bounds__(256, NOLD ? 1 : 2) void s27_sweep_kernel(const S27K
 #pragma unroll
         for (int u = 0; u < SG; ++u) {
             const int s = g0 + u;
+            if (s >= 27) continue;
             const Nb nb = neighbour(1, PY, PZ, s);
             const bool in_line = s == 12 || s == 14;   // colour CA of the own line: relaxed above
             const bool from_new = nb.colour < CA;
@@ -303,6 +318,7 @@ __global__ __launch_bounds__(256, NOLD ? 1 : 2) void s27_sweep_kernel(const S27K
 #pragma unroll
         for (int u = 0; u < SG; ++u) {
             const int s = g0 + u;
+            if (s >= 27) continue;
             const Nb nb = neighbour(1, PY, PZ, s);
             const bool in_line = s == 12 || s == 14;
             if (LAST && s == 13) {                     // (before the skip below: with XZ slot 13 itself adds nothing)
@@ -371,6 +387,9 @@ __global__ __launch_bounds__(256, NOLD ? 1 : 2) void s27_sweep_kernel(const S27K
 #pragma unroll
                 for (int u = 0; u < SG; ++u) {
                     const int s = g0 + u;
+                if (s >= 27) continue;
+                    if (s >= 27) continue;
+            if (s >= 27) continue;
                     const Nb nb = neighbour(0, PY, PZ, s);
                     c[u] = cload(ka, s);
                     if (s == 13) x[u] = na_;
@@ -382,9 +401,11 @@ __global__ __launch_bounds__(256, NOLD ? 1 : 2) void s27_sweep_kernel(const S27K
                     } else x[u] = operand(xn, nb);
                 }
 #pragma unroll
-                for (int u = 0; u < SG; ++u)
+                for (int u = 0; u < SG; ++u) {
+                    if (g0 + u >= 27) continue;
 #pragma unroll
                     for (int r = 0; r < RG; ++r) acc[r].s[(g0 + u) & 3] = madd(c[u].v[r], x[u].v[r], acc[r].s[(g0 + u) & 3]);
+                }
 #pragma unroll
                 for (int r = 0; r < RG; ++r) pin_chains(acc[r]);
                 group_fence(tt.a0, tt.cbase);
@@ -409,7 +430,7 @@ __global__ __launch_bounds__(256, NOLD ? 1 : 2) void s27_sweep_kernel(const S27K
 // The colours are a run-time loop (the colour is wave-uniform: its neighbour table is scalar arithmetic), the 27 slots
 // of a row unrolled in groups of SG like the sweep's.
 template <typename V, int RG, int NC, int MODE>
-__global__ __launch_bounds__(256, 2) void s27_residual_kernel(const S27KArgs<V> a) {
+__global__ __launch_bounds__(256, S27_WAVES) void s27_residual_kernel(const S27KArgs<V> a) {
     typedef Vec<V, RG> VR;
     Lane<V, RG> tt = lane_of<V, RG>(a);
     const Lane<V, RG> &t = tt;
@@ -436,14 +457,18 @@ __global__ __launch_bounds__(256, 2) void s27_residual_kernel(const S27KArgs<V> 
 #pragma unroll
             for (int u = 0; u < SG; ++u) {
                 const int s = g0 + u;
+                if (s >= 27) continue;
+            if (s >= 27) continue;
                 const Nb nb = neighbour(px, py, pz, s);
-                cf[u] = ldv(kc, ok ? t.cbase + s * 64 * RG : NONE, (VR *)nullptr);
+                cf[u] = ldv<S27_COEF_AUX>(kc, ok ? t.cbase + s * 64 * RG : NONE, (VR *)nullptr);
                 x[u] = ldv(xs, ok ? nb.colour * a.na + t.a0 + nb.sk * lhyhx + nb.sj * lhx + nb.si : NONE, (VR *)nullptr);
             }
 #pragma unroll
-            for (int u = 0; u < SG; ++u)
+            for (int u = 0; u < SG; ++u) {
+                if (g0 + u >= 27) continue;
 #pragma unroll
                 for (int r = 0; r < RG; ++r) acc[r].s[(g0 + u) & 3] = madd(cf[u].v[r], x[u].v[r], acc[r].s[(g0 + u) & 3]);
+            }
 #pragma unroll
             for (int r = 0; r < RG; ++r) pin_chains(acc[r]);
             group_fence(tt.a0, tt.cbase);

@@ -257,10 +257,13 @@ def test_eight_rank_slabs_are_bit_identical_to_one_gpu(monkeypatch, shape, grids
     np.testing.assert_allclose(nd, n1, rtol=1e-13)
 
 
-def test_eight_rank_slabs_27_point_fp32_and_oracle():
+def test_eight_rank_slabs_27_point_fp32_and_oracle(monkeypatch):
     """configs[4]'s operator over 8 slabs in fp32 (bit-identical to the one-GPU fp32 hierarchy)
     and in fp64 against the oracle's cycle (1e-10 on the norm): the 8-colour schedule with one
-    message per (neighbour, colour) produces the reference's iterate."""
+    message per (neighbour, colour) produces the reference's iterate.  (The slab runner sums a row as it is stored;
+    the one-GPU comparator therefore runs without the 27-point kernels, which pad boundary rows to 27 entries and
+    so associate THEIR sums differently — OMG_STENCIL27=0; every interior row has the same bits either way.)"""
+    monkeypatch.setenv("OMG_STENCIL27", "0")
     shape, grids = (32, 32, 32), 3
     A0 = operators.stencil27_variable(shape)
     b = A0 @ np.random.default_rng(12345).random(A0.shape[0])

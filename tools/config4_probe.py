@@ -24,11 +24,23 @@ def main():
     ap.add_argument("--grids", type=int, default=5)
     ap.add_argument("--dtype", default="float32")
     ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--cache", default="", help="directory to keep the generated operator in between runs (A/B builds)")
     args = ap.parse_args()
     shape = (args.size,) * 3
     w = 4 if args.dtype == "float32" else 8
     t = time.perf_counter()
-    A0 = operators.stencil27_variable(shape)                  # Q1 stiffness, kappa per cell, default_rng(2024)
+    A0 = None
+    if args.cache:
+        import scipy.sparse as sp
+        base = os.path.join(args.cache, "cfg4_%d" % args.size)
+        if os.path.exists(base + "_data.npy"):
+            A0 = sp.csr_matrix((np.load(base + "_data.npy"), np.load(base + "_indices.npy"), np.load(base + "_indptr.npy")),
+                               shape=(args.size ** 3,) * 2)
+    if A0 is None:
+        A0 = operators.stencil27_variable(shape)              # Q1 stiffness, kappa per cell, default_rng(2024)
+        if args.cache:
+            os.makedirs(args.cache, exist_ok=True)
+            np.save(base + "_data.npy", A0.data); np.save(base + "_indices.npy", A0.indices); np.save(base + "_indptr.npy", A0.indptr)
     t_gen = time.perf_counter() - t
     b = A0 @ np.random.default_rng(2).random(A0.shape[0])
     t = time.perf_counter()
