@@ -609,10 +609,11 @@ struct S27Geom {
     int nx = 0, ny = 0, nz = 0;       // cells (even)
     int hx = 0, hy = 0, hz = 0;       // aggregates per line / lines per plane / planes
     int64_t na = 0;                   // aggregates = rows per colour
-    int rg = 0;                       // aggregates per lane (16-byte accesses: 4 floats, 2 doubles; 4 doubles for long lines)
+    int rg = 0;                       // aggregates per lane (16-byte accesses: 4 floats, 2 doubles; fewer on small levels)
     int L = 0, G = 0;                 // lanes per grid line, lines per wave
     int64_t nl = 0, ng = 0;           // lines per colour; waves (line groups) per colour
-    int n_wg = 0;                     // workgroups of four waves
+    int wpb = 4;                      // waves per workgroup (1 on small levels)
+    int n_wg = 0;                     // workgroups
     double w = 0.0;                   // the restriction's weight
 };
 template <typename V>

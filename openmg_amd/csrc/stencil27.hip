@@ -65,10 +65,11 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 
 // tuning switches (A/B builds: make EXTRA=-DS27_...)
 #ifndef S27_COEF_AUX
-#define S27_COEF_AUX 0                    // cache policy of the coefficient loads (gfx950: 1 = sc0, 2 = nt, 16 = sc1): they are read once
+#define S27_COEF_AUX 2                    // cache policy of the coefficient loads (gfx950: 1 = sc0, 2 = nt, 16 = sc1): they are read once; nt
+                                          // keeps them from evicting the iterate from L2 (256^3 fp32 sweep: 447 -> 419 us)
 #endif
 #ifndef S27_SG
-#define S27_SG 9                          // slots per load group
+#define S27_SG 14                         // slots per load group (measured: 5: 462 us per sweep, 9: 419, 14: 399, 18: 419, 27: 449)
 #endif
 #ifndef S27_WAVES
 #define S27_WAVES 2                       // launch bound: waves per SIMD the sweep / residual kernels are compiled for
@@ -93,6 +94,19 @@ __device__ __forceinline__ Vec<double, 2> ldv(__amdgpu_buffer_rsrc_t rs, int idx
     const v4u q = __builtin_amdgcn_raw_buffer_load_b128(rs, idx * 8, 0, AUX);
     return {{__builtin_bit_cast(double, v2u{q.x, q.y}), __builtin_bit_cast(double, v2u{q.z, q.w})}};
 }
+template <int AUX = 0>
+__device__ __forceinline__ Vec<float, 2> ldv(__amdgpu_buffer_rsrc_t rs, int idx, Vec<float, 2> *) {
+    const v2f q = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(rs, idx * 4, 0, AUX));
+    return {{q.x, q.y}};
+}
+template <int AUX = 0>
+__device__ __forceinline__ Vec<float, 1> ldv(__amdgpu_buffer_rsrc_t rs, int idx, Vec<float, 1> *) {
+    return {{__builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, idx * 4, 0, AUX))}};
+}
+template <int AUX = 0>
+__device__ __forceinline__ Vec<double, 1> ldv(__amdgpu_buffer_rsrc_t rs, int idx, Vec<double, 1> *) {
+    return {{__builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs, idx * 8, 0, AUX))}};
+}
 // element-wise masked store (mask bit r: element r is a row of the grid)
 __device__ __forceinline__ void stv(__amdgpu_buffer_rsrc_t rs, int idx, const Vec<float, 4> &x, unsigned mask) {
     if (mask == 0xFu) {
@@ -112,6 +126,22 @@ __device__ __forceinline__ void stv(__amdgpu_buffer_rsrc_t rs, int idx, const Ve
         for (int r = 0; r < 2; ++r)
             if ((mask >> r) & 1u) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, x.v[r]), rs, (idx + r) * 8, 0, 0);
     }
+}
+
+__device__ __forceinline__ void stv(__amdgpu_buffer_rsrc_t rs, int idx, const Vec<float, 2> &x, unsigned mask) {
+    if (mask == 0x3u) {
+        __builtin_amdgcn_raw_buffer_store_b64(v2u{__builtin_bit_cast(unsigned, x.v[0]), __builtin_bit_cast(unsigned, x.v[1])}, rs, idx * 4, 0, 0);
+    } else {
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+            if ((mask >> r) & 1u) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, x.v[r]), rs, (idx + r) * 4, 0, 0);
+    }
+}
+__device__ __forceinline__ void stv(__amdgpu_buffer_rsrc_t rs, int idx, const Vec<float, 1> &x, unsigned mask) {
+    if (mask & 1u) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, x.v[0]), rs, idx * 4, 0, 0);
+}
+__device__ __forceinline__ void stv(__amdgpu_buffer_rsrc_t rs, int idx, const Vec<double, 1> &x, unsigned mask) {
+    if (mask & 1u) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, x.v[0]), rs, idx * 8, 0, 0);
 }
 
 template <typename V>
@@ -151,7 +181,7 @@ struct Lane {
 template <typename V, int RG>
 __device__ __forceinline__ Lane<V, RG> lane_of(const S27KArgs<V> &a) {
     Lane<V, RG> t;
-    const int wave = int(blockIdx.x) * 4 + (int(threadIdx.x) >> 6);
+    const int wave = int(blockIdx.x) * (int(blockDim.x) >> 6) + (int(threadIdx.x) >> 6);     // (workgroups of four waves, or of one on small levels)
     t.lane = int(threadIdx.x) & 63;
     const int lw = t.lane / a.L;                      // line of the wave
     t.line = wave * a.G + lw;
@@ -191,11 +221,13 @@ __device__ __forceinline__ void group_fence(int &a0, int &cbase) {
     __builtin_amdgcn_sched_barrier(0);
 }
 
-// fixed order: lanes of a wave (shuffle tree), then the four waves in turn
+// fixed order: lanes of a wave (shuffle tree), then the workgroup's waves in turn
 __device__ __forceinline__ void block_partial(double sq, double *out) {
     __shared__ double s_red[4];
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) sq += __shfl_down(sq, off, 64);
+    if (threadIdx.x < 4) s_red[threadIdx.x] = 0.0;
+    __syncthreads();
     if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = sq;
     __syncthreads();
     if (threadIdx.x == 0) out[blockIdx.x] = ((s_red[0] + s_red[1]) + s_red[2]) + s_red[3];
@@ -575,7 +607,7 @@ S27KArgs<V> base_args(const Stencil27Plan<V> &P) {
 
 template <typename K, typename V>
 void launch_s27(K kernel, const S27Geom &g, const S27KArgs<V> &k, hipStream_t s) {
-    hipLaunchKernelGGL(kernel, dim3(unsigned(g.n_wg)), dim3(256), 0, s, k);
+    hipLaunchKernelGGL(kernel, dim3(unsigned(g.n_wg)), dim3(unsigned(64 * g.wpb)), 0, s, k);
     OMG_HIP(hipGetLastError());
 }
 
@@ -618,8 +650,15 @@ void residual_rg(const Stencil27Plan<V> &P, const V *x, const V *b, bool use67, 
     }
 }
 
-// RG by value type: 16-byte accesses (4 floats, 2 doubles)
-template <typename V> constexpr int rg_small() { return sizeof(V) == 4 ? 4 : 2; }
+// RG: 16-byte accesses (4 floats, 2 doubles) on the large levels, fewer aggregates per lane — more waves — on the small ones
+template <typename V> constexpr int rg_max() { return sizeof(V) == 4 ? 4 : 2; }
+template <typename V, typename F>
+void with_rg(int rg, F &&f) {
+    if (rg == 1) f(std::integral_constant<int, 1>());
+    else if (rg == 2) f(std::integral_constant<int, 2>());
+    else if (sizeof(V) == 4) f(std::integral_constant<int, rg_max<V>()>());
+    else f(std::integral_constant<int, 2>());
+}
 
 }  // namespace
 
@@ -658,13 +697,27 @@ bool Stencil27Plan<V>::build(const omg_csr &A, const omg_csr &R, Ordering &ord, 
     q.nx = int(nx); q.ny = int(ny); q.nz = int(nz);
     q.hx = q.nx / 2; q.hy = q.ny / 2; q.hz = q.nz / 2;
     q.na = int64_t(q.hx) * q.hy * q.hz;
-    q.rg = rg_small<V>();
+    q.rg = rg_max<V>();
     if (q.hx > 64 * q.rg) return false;                          // a grid line must fit one wave (nx <= 512 in float, 256 in double)
-    q.L = (q.hx + q.rg - 1) / q.rg;
-    q.G = 64 / q.L;
     q.nl = int64_t(q.hy) * q.hz;
-    q.ng = (q.nl + q.G - 1) / q.G;
-    q.n_wg = int((q.ng + 3) / 4);
+    {
+        // small levels: fewer aggregates per lane and one-wave workgroups, so that the launch still spreads over the chip
+        const char *e = getenv("OMG_S27_RG");
+        const int forced = e ? atoi(e) : 0;
+        for (;;) {
+            q.L = (q.hx + q.rg - 1) / q.rg;
+            q.G = 64 / q.L;
+            q.ng = (q.nl + q.G - 1) / q.G;
+            if (forced == 1 || forced == 2 || forced == 4) {
+                if (q.rg == forced || q.rg == 1 || forced > rg_max<V>()) break;
+            } else if (q.ng >= 1024 || q.rg == 1) {
+                break;
+            }
+            q.rg /= 2;
+        }
+    }
+    q.wpb = q.ng >= 1024 ? 4 : 1;
+    q.n_wg = int((q.ng + q.wpb - 1) / q.wpb);
     q.w = double(V(w));
     const uint64_t coef_colour_bytes = uint64_t(q.ng) * 27 * 64 * uint64_t(q.rg) * sizeof(V);
     if (uint64_t(n) * sizeof(V) >= (uint64_t(1) << 31) || coef_colour_bytes >= (uint64_t(1) << 31)) return false;
@@ -725,14 +778,14 @@ bool Stencil27Plan<V>::build(const omg_csr &A, const omg_csr &R, Ordering &ord, 
 
 template <typename V>
 void Stencil27Plan<V>::sweep(const V *x_old, V *x_new, const V *b, bool x_zero, double *norm_old, bool last, double *norm_new, hipStream_t s) {
-    sweep_rg<V, rg_small<V>()>(*this, x_old, x_new, b, x_zero, norm_old, last, norm_new, s);
+    with_rg<V>(g.rg, [&](auto RGC) { sweep_rg<V, decltype(RGC)::value>(*this, x_old, x_new, b, x_zero, norm_old, last, norm_new, s); });
     have67 = last;
 }
 
 template <typename V>
 void Stencil27Plan<V>::residual_restrict(const V *x, const V *b, bool use67, const int32_t *cmap, V *bc, hipStream_t s) {
     OMG_REQUIRE(!use67 || have67, "internal: residuals of colours 6, 7 asked for but not there");
-    residual_rg<V, rg_small<V>()>(*this, x, b, use67, 0, cmap, bc, nullptr, s);
+    with_rg<V>(g.rg, [&](auto RGC) { residual_rg<V, decltype(RGC)::value>(*this, x, b, use67, 0, cmap, bc, nullptr, s); });
 }
 
 template <typename V>
@@ -740,14 +793,14 @@ void Stencil27Plan<V>::norm(const V *x, const V *b, bool use67, double *out, hip
     OMG_REQUIRE(!use67 || have67, "internal: squares of colours 6, 7 asked for but not there");
     const size_t nw = size_t(g.n_wg);
     OMG_HIP(hipMemsetAsync(out + nw, 0, (use67 ? 2 : 3) * nw * sizeof(double), s));
-    residual_rg<V, rg_small<V>()>(*this, x, b, use67, 1, nullptr, nullptr, out, s);
+    with_rg<V>(g.rg, [&](auto RGC) { residual_rg<V, decltype(RGC)::value>(*this, x, b, use67, 1, nullptr, nullptr, out, s); });
 }
 
 template <typename V>
 void Stencil27Plan<V>::prolong(V *x, const V *e, const int32_t *cmap, hipStream_t s) {
     S27KArgs<V> k = base_args(*this);
     k.x_new = x; k.e = e; k.cmap = cmap;
-    launch_s27(s27_prolong_kernel<V, rg_small<V>()>, g, k, s);
+    with_rg<V>(g.rg, [&](auto RGC) { launch_s27(s27_prolong_kernel<V, decltype(RGC)::value>, g, k, s); });
     have67 = false;
 }
 
