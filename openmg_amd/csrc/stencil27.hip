@@ -270,6 +270,9 @@ __global__ __launch_bounds__(256, NOLD ? 1 : S27_WAVES) void s27_sweep_kernel(co
 #pragma unroll
     for (int r = 0; r < RG; ++r) { acc[r].clear(); aold[r].clear(); }
     VR diag_a = {};
+    V pre_a[3][RG], a3[RG];                            // LAST: colour CA's chains 0, 1, 2 in front of slots 12, 13, 14; its chain 3
+#pragma unroll
+    for (int r = 0; r < RG; ++r) pre_a[0][r] = pre_a[1][r] = pre_a[2][r] = a3[r] = V(0);
 #pragma unroll
     for (int g0 = 0; g0 < 27; g0 += SG) {
         VR c[SG], x[SG], xold[SG];
@@ -290,6 +293,10 @@ __global__ __launch_bounds__(256, NOLD ? 1 : S27_WAVES) void s27_sweep_kernel(co
             const int s = g0 + u;
             if (s >= 27) continue;
             const Nb nb = neighbour(0, PY, PZ, s);
+            if (LAST && (s == 12 || s == 13 || s == 14)) {      // (before the skip below) chains 0, 1, 2 in front of slots 12, 13, 14
+#pragma unroll
+                for (int r = 0; r < RG; ++r) pre_a[s - 12][r] = acc[r].s[s & 3];
+            }
             if (XZ && !(nb.colour < CA)) continue;     // (slot 13 too: x_i = 0)
 #pragma unroll
             for (int r = 0; r < RG; ++r) {
@@ -308,6 +315,7 @@ __global__ __launch_bounds__(256, NOLD ? 1 : S27_WAVES) void s27_sweep_kernel(co
         const V v = xa.v[r] + (ba.v[r] - acc[r].total()) / diag_a.v[r];
         na_.v[r] = ((t.mask >> r) & 1u) ? v : V(0);
         if (NOLD && ((t.mask >> r) & 1u)) add_sq(sq_old, double(ba.v[r] - aold[r].total()));
+        if (LAST) a3[r] = acc[r].s[3];
     }
     // the in-line neighbours of colour CB: aggregate i + 1 of this lane or the next lane's first; of colour CA's
     // residual: aggregate i - 1 of this lane or the previous lane's last (a line's first / last: no such cell, zero
@@ -406,44 +414,37 @@ __global__ __launch_bounds__(256, NOLD ? 1 : S27_WAVES) void s27_sweep_kernel(co
             }
         }
         group_fence(tt.a0, tt.cbase);
-        // Colour 6 (CA): its own value (slot 13) and its two in-line neighbours of colour 7 (slots 12, 14): the whole
-        // row again (its coefficients come from L2 this time)
+        // Colour 6 (CA): its own value (slot 13) and its two in-line neighbours of colour 7 (slots 12, 14) have changed
+        // since its rows were relaxed: chains 0, 1, 2 again from those slots on (their prefixes and chain 3 were kept),
+        // the nine later coefficients and operands loaded again (operands: what the sweep itself used)
         const V nb_prev = __shfl_up(nb_.v[RG - 1], 1, 64);
         VR ra;
         {
+            V ch[3][RG];
+            const VR c12 = cload(ka, 12), c14 = cload(ka, 14);
 #pragma unroll
-            for (int r = 0; r < RG; ++r) acc[r].clear();
+            for (int r = 0; r < RG; ++r) {
+                const V x12 = r ? nb_.v[r - 1] : nb_prev;                    // dx = -1: the previous aggregate's colour 7 cell
+                ch[0][r] = madd(c12.v[r], x12, pre_a[0][r]);
+                ch[1][r] = madd(diag_a.v[r], na_.v[r], pre_a[1][r]);
+                ch[2][r] = madd(c14.v[r], nb_.v[r], pre_a[2][r]);            // dx = +1: the same aggregate's
+            }
+            VR c[9], x[9];
 #pragma unroll
-            for (int g0 = 0; g0 < 27; g0 += SG) {
-                VR c[SG], x[SG];
-#pragma unroll
-                for (int u = 0; u < SG; ++u) {
-                    const int s = g0 + u;
-                if (s >= 27) continue;
-                    if (s >= 27) continue;
-            if (s >= 27) continue;
-                    const Nb nb = neighbour(0, PY, PZ, s);
-                    c[u] = cload(ka, s);
-                    if (s == 13) x[u] = na_;
-                    else if (s == 14) x[u] = nb_;          // dx = +1: the same aggregate's colour 7 cell
-                    else if (s == 12) {                    // dx = -1: the previous aggregate's
-#pragma unroll
-                        for (int r = 1; r < RG; ++r) x[u].v[r] = nb_.v[r - 1];
-                        x[u].v[0] = nb_prev;
-                    } else x[u] = operand(xn, nb);
-                }
-#pragma unroll
-                for (int u = 0; u < SG; ++u) {
-                    if (g0 + u >= 27) continue;
-#pragma unroll
-                    for (int r = 0; r < RG; ++r) acc[r].s[(g0 + u) & 3] = madd(c[u].v[r], x[u].v[r], acc[r].s[(g0 + u) & 3]);
-                }
-#pragma unroll
-                for (int r = 0; r < RG; ++r) pin_chains(acc[r]);
-                group_fence(tt.a0, tt.cbase);
+            for (int u = 0; u < 9; ++u) {
+                const int sl = 16 + 4 * (u / 3) + (u % 3);                   // 16, 17, 18, 20, 21, 22, 24, 25, 26
+                c[u] = cload(ka, sl);
+                x[u] = operand(xn, neighbour(0, PY, PZ, sl));                // (colours 0 .. 5)
             }
 #pragma unroll
-            for (int r = 0; r < RG; ++r) ra.v[r] = ((t.mask >> r) & 1u) ? ba.v[r] - acc[r].total() : V(0);
+            for (int u = 0; u < 9; ++u)
+#pragma unroll
+                for (int r = 0; r < RG; ++r) ch[u % 3][r] = madd(c[u].v[r], x[u].v[r], ch[u % 3][r]);
+#pragma unroll
+            for (int r = 0; r < RG; ++r) {
+                const V tot = ((ch[0][r] + ch[1][r]) + ch[2][r]) + a3[r];
+                ra.v[r] = ((t.mask >> r) & 1u) ? ba.v[r] - tot : V(0);
+            }
         }
         stv(rr, t.a0, ra, t.mask);
         stv(rr, a.na + t.a0, rb, t.mask);
