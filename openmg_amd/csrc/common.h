@@ -136,6 +136,11 @@ struct Ordering {
 // Touch every page of a freshly allocated host buffer that is about to RECEIVE a large device-to-host copy, on many
 // threads: the copy into untouched pages of a new NumPy array runs at page-fault speed (175 MB in 33 ms, measured)
 void prefault_host(void *p, size_t bytes);
+// Large device-to-host copy into PAGEABLE memory (a caller's NumPy array): the runtime's own path ran at 5-12 GB/s
+// (175 MB in 33 ms).  Here: chunks through two pinned staging buffers (kept for the process), the copy of chunk i + 1
+// over PCIe while several host threads move chunk i into the destination.  Synchronous: returns when `host` is
+// complete; everything enqueued on `s` before the call is waited for.  (setup_host.cpp)
+void download_staged(void *host, const void *dev, size_t bytes, hipStream_t s);
 void validate_csr(const omg_csr &A, const char *what);
 // Smallest row whose stored diagonal entries are missing or sum to zero; -1 if none.
 int64_t first_row_without_diagonal(const omg_csr &A);

@@ -629,13 +629,9 @@ int omg_csr_result_fetch(omg_csr_result *res, int32_t *indptr, int32_t *indices,
     return guarded([&] {
         OMG_REQUIRE(res && indptr, "null argument");
         OMG_REQUIRE(res->nnz == 0 || (indices && data), "null output array");
-        prefault_host(indptr, size_t(res->n_rows + 1) * sizeof(int32_t));
-        prefault_host(indices, size_t(res->nnz) * sizeof(int32_t));
-        prefault_host(data, size_t(res->nnz) * sizeof(double));
-        res->indptr.download(indptr, res->n_rows + 1, nullptr);
-        res->indices.download(indices, res->nnz, nullptr);
-        res->data.download(data, res->nnz, nullptr);
-        OMG_HIP(hipStreamSynchronize(nullptr));
+        download_staged(indptr, res->indptr.p, size_t(res->n_rows + 1) * sizeof(int32_t), nullptr);
+        download_staged(indices, res->indices.p, size_t(res->nnz) * sizeof(int32_t), nullptr);
+        download_staged(data, res->data.p, size_t(res->nnz) * sizeof(double), nullptr);
         delete res;
     });
 }
@@ -667,13 +663,9 @@ int omg_restriction(int dim, const int64_t *shape, int32_t *indptr, int32_t *ind
                            shape[0], dim >= 2 ? shape[1] : 1, dim >= 3 ? shape[2] : 1, rows, dp.p,
                            di.p, dv.p);
         OMG_HIP(hipGetLastError());
-        prefault_host(indptr, size_t(n + 1) * sizeof(int32_t));
-        prefault_host(indices, size_t(rows * per) * sizeof(int32_t));
-        prefault_host(data, size_t(rows * per) * sizeof(double));
-        dp.download(indptr, rows + 1, st.s);
-        di.download(indices, rows * per, st.s);
-        dv.download(data, rows * per, st.s);
-        OMG_HIP(hipStreamSynchronize(st.s));
+        download_staged(indptr, dp.p, size_t(rows + 1) * sizeof(int32_t), st.s);
+        download_staged(indices, di.p, size_t(rows * per) * sizeof(int32_t), st.s);
+        download_staged(data, dv.p, size_t(rows * per) * sizeof(double), st.s);
         for (int64_t r = rows + 1; r <= n; ++r) indptr[r] = (int32_t)(rows * per);   // trailing empty rows
         *n_rows = n;
         *nnz = rows * per;

@@ -4,6 +4,7 @@
 #include <atomic>
 #include <cstring>
 #include <string>
+#include <mutex>
 #include <thread>
 #include <unordered_map>
 #include <type_traits>
@@ -911,6 +912,48 @@ void prefault_host(void *p, size_t bytes) {
     for (int t = 1; t < nt; ++t) th.emplace_back(work, t);
     work(0);
     for (auto &q : th) q.join();
+}
+
+void download_staged(void *host, const void *dev, size_t bytes, hipStream_t s) {
+    constexpr size_t CH = size_t(32) << 20;
+    if (bytes < (size_t(8) << 20)) {
+        if (bytes) OMG_HIP(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, s));
+        OMG_HIP(hipStreamSynchronize(s));
+        return;
+    }
+    // two pinned buffers and their events, made once per process and shared (one copy at a time)
+    static std::mutex mu;
+    static void *pin[2] = {nullptr, nullptr};
+    static hipEvent_t ev[2] = {nullptr, nullptr};
+    std::lock_guard<std::mutex> lock(mu);
+    if (!pin[0]) {
+        for (int i = 0; i < 2; ++i) {
+            OMG_HIP(hipHostMalloc(&pin[i], CH, hipHostMallocDefault));
+            OMG_HIP(hipEventCreateWithFlags(&ev[i], hipEventDisableTiming));
+        }
+    }
+    const size_t n_chunks = (bytes + CH - 1) / CH;
+    const unsigned hw = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+    auto issue = [&](size_t c) {
+        const size_t off = c * CH, len = std::min(CH, bytes - off);
+        OMG_HIP(hipMemcpyAsync(pin[c & 1], static_cast<const char *>(dev) + off, len, hipMemcpyDeviceToHost, s));
+        OMG_HIP(hipEventRecord(ev[c & 1], s));
+    };
+    issue(0);
+    for (size_t c = 0; c < n_chunks; ++c) {
+        if (c + 1 < n_chunks) issue(c + 1);                    // (buffer (c + 1) & 1 was emptied in the previous iteration)
+        OMG_HIP(hipEventSynchronize(ev[c & 1]));
+        const size_t off = c * CH, len = std::min(CH, bytes - off);
+        const int nt = (int)std::max<size_t>(1, std::min<size_t>(hw, len >> 20));
+        auto work = [&](int t) {
+            const size_t lo = len * size_t(t) / size_t(nt), hi = len * size_t(t + 1) / size_t(nt);
+            std::memcpy(static_cast<char *>(host) + off + lo, static_cast<const char *>(pin[c & 1]) + lo, hi - lo);
+        };
+        std::vector<std::thread> th;
+        for (int t = 1; t < nt; ++t) th.emplace_back(work, t);
+        work(0);
+        for (auto &q : th) q.join();
+    }
 }
 
 uint64_t host_checksum(const void *buf, int64_t bytes) {
