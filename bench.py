@@ -326,9 +326,17 @@ def config4_leg(size, grids, steps, warmup, repeats, sync_of):
         # read once per launch (every launch needs every colour's neighbours: 4 w n)
         sweep_bytes = (27 + 2 + 4) * w * n
         us = 1e3 * ms / cnt
+        traffic, traffic_src = None, None
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r04_pmc_s27_sweep.json")))
+            if pmc.get("kernel_src_sha") == kernel_source_hash() and size == 256:
+                traffic = pmc["traffic_bytes"]
+                traffic_src = "NOT measured in this run: rocprofv3 --pmc passes of the same build, " + pmc["source"]
+        except (OSError, KeyError, ValueError):
+            pass
         out["roofline"] = {"bound": "hbm", "kernel": "s27_sweep_kernel x 4 (one 8-colour Gauss-Seidel sweep of the fine grid, stencil27.hip)",
                            "achieved": round(sweep_bytes / us / 1e3, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": round(sweep_bytes / us / 1e3 / HBM_PEAK_GBS, 4), "traffic": None,
+                           "frac": round(sweep_bytes / us / 1e3 / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                            "bytes_per_sweep": sweep_bytes, "avg_sweep_us": round(us, 2), "sweeps_timed": cnt,
                            "bytes_definition": "27 coefficients per row (27 w n) + b read, x written (2 w n) + the iterate read once per launch (4 w n)",
                            "csr_equiv_bytes": (w + 4) * nnz + 4 * (n + 8) + 3 * w * n + 8 * w * n,
@@ -480,7 +488,7 @@ def main():
         # (DESIGN.md §5): per fine unknown 3 w (x read, b read, x written), per coarse unknown w (its right-hand
         # side) + 4 (its slot in the coarse ordering).  The operator itself costs nothing: seven coefficients.
         bytes_roof = fmt_b["plane_down"]
-        traffic, traffic_src = pmc_traffic("r03_pmc_plane_down.json", bytes_roof, w)
+        traffic, traffic_src = pmc_traffic("r04_pmc_plane_down.json", bytes_roof, w)
         achieved = bytes_roof / avg_s / 1e9
         roofline = {"bound": "hbm", "kernel": "plane_kernel<down>: fine-grid red-black sweep + residual + restriction in one launch (plane.hip)",
                     "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -489,7 +497,7 @@ def main():
                     "bytes_definition": "per fine unknown: x read, b read, x written (3 w); per coarse unknown: right-hand side written (w) "
                                         "+ its slot in the coarse ordering read (4)",
                     "avg_launch_us": round(avg_s * 1e6, 2), "avg_launch_us_source": "hipEvents on the kernel's own stream inside the timed regions; "
-                                                                                  "rocprofv3's duration of the same kernel: profiles/r03_bench_kernel_stats*.txt",
+                                                                                  "rocprofv3's duration of the same kernel: profiles/r04_bench_kernel_stats*.txt",
                     "launches_timed": launches,
                     "csr_equiv_bytes": int(csr_b["plane_down"]), "csr_equiv_GBps": round(csr_b["plane_down"] / avg_s / 1e9, 1),
                     "tiling": h.plane_info(0),

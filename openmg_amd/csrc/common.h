@@ -508,6 +508,7 @@ bool is_plain_aggregation(const omg_csr &R, int64_t nx, int64_t ny, int64_t nz, 
 // chain in stored (= slot) order as in the row kernels — an absent neighbour is 0 * c, which leaves
 // the chain as it is — and the same division, so the iterate has the bits of the set-by-set
 // schedule (tests/test_gpu_plane.py; OMG_PLANE=0 switches the path off).
+constexpr int PLANE_EDGE = 4;         // planes at either end of a slab that the EDGE launch of a split pass covers
 struct PlaneGeom {
     int nx = 0, ny = 0, nz = 0;       // cells per line, lines per plane, planes (all even)
     int hx = 0;                       // cells of one colour per line = nx / 2
@@ -581,11 +582,24 @@ struct PlanePlan {
     void tune(V *x, V *tmp, const V *b, const Coarse &c, hipStream_t s, bool finest = true);
     // sweep = false: the pass without its relaxation (a cycle with preIterations = 0 / postIterations = 0): down then
     // leaves x_new untouched (the iterate stays in x_old), up writes x_new = x_old + R^T e
+    // part: a pass as TWO launches (slabs with RCCL exchanges, dist.hip): PART_EDGE = the slab's first and last PLANE_EDGE
+    // planes — what the neighbours are waiting for — as two short chunks, PART_INNER = the planes between them; the two
+    // write disjoint planes and may run side by side on two streams.
+    enum { PART_ALL = 0, PART_EDGE = 1, PART_INNER = 2 };
+    // (PLANE_EDGE = 4 planes at either end: the three planes of x and the two coarse planes a neighbour takes)
+    bool can_split() const {
+        return !g.dim2 && !g.block && !(g.la2 && g.threads <= 128) && (g.z_end - g.z_base) >= 3 * PLANE_EDGE;
+    }
+    // workgroups = norm partials of a pass made of the two launches
+    int split_partials() const {
+        const int nzo = g.z_end - g.z_base;
+        return nzo >= 3 * PLANE_EDGE ? g.ntx * g.nty * (2 + (nzo - 2 * PLANE_EDGE + g.LZ - 1) / g.LZ) : g.n_wg;
+    }
     void down(const V *x_old, V *x_new, const V *b, bool x_zero, const Coarse &c, hipStream_t s, const Peer *peer = nullptr,
-              bool sweep = true) const;
+              bool sweep = true, int part = PART_ALL) const;
     // out (nullable): block partials of the squared residual norm, g.n_wg doubles
     void up(const V *x_old, V *x_new, const V *b, const Coarse &c, double *out, hipStream_t s, const Peer *peer = nullptr,
-            bool sweep = true) const;
+            bool sweep = true, int part = PART_ALL) const;
 };
 
 // ---- 27-point grid stencils with per-row coefficients: BASELINE configs[4] (stencil27.hip) ----------------

@@ -898,6 +898,14 @@ struct PlaneDist {
     hipStream_t side_own = nullptr, side = nullptr;
     ncclComm_t comm_side = nullptr;
     std::vector<hipEvent_t> ev_down, ev_halo;
+    // Split passes (round 4): a pass of a slab level runs as TWO launches — the z chunks that hold the slab's first and
+    // last planes on the side stream, followed there by the exchanges of what they produced, and the other chunks on the
+    // main stream beside them — so that an exchange is on the critical path only for as long as it outlasts the inner
+    // chunks.  ev_main[l][0 / 1]: the main stream has everything the down / up pass of level l reads; ev_edge[l][0 / 1]:
+    // the side stream has run the pass's edge chunks and the exchanges behind them.
+    std::vector<hipEvent_t> ev_main[2], ev_edge[2];
+    bool split = [] { const char *e = getenv("OMG_PDIST_SPLIT"); return !(e && e[0] == '0'); }();   // (and every level's tiling must have inner chunks)
+    bool x0_posted = false;                   // the ghost planes of x for the next cycle's first pass are already on their way (ev_edge[1][0])
     // progress of the DEVICE through a cycle, for a caller whose collective never completes (bench.py's preflight):
     // a word in pinned host memory the stream writes between the phases — (cycle << 16) | (level << 8) | phase,
     // phase 1 halo x, 2 halo b, 3 down pass, 4 halo x (for the up pass), 5 gather + tail, 6 halo of the correction,
@@ -914,6 +922,10 @@ struct PlaneDist {
         if (progress) (void)hipHostFree(progress);
         for (hipEvent_t e : ev_down) (void)hipEventDestroy(e);
         for (hipEvent_t e : ev_halo) (void)hipEventDestroy(e);
+        for (int i = 0; i < 2; ++i) {
+            for (hipEvent_t e : ev_main[i]) (void)hipEventDestroy(e);
+            for (hipEvent_t e : ev_edge[i]) (void)hipEventDestroy(e);
+        }
         if (comm_side) (void)g_rccl.CommDestroy(comm_side);
         if (side_own) (void)hipStreamDestroy(side_own);
         if (comm) (void)g_rccl.CommDestroy(comm);
@@ -1103,7 +1115,9 @@ struct PDExchange {
         p.spin = d->spin;
         return p;
     }
-    void down(int l, bool first_of_batch = false) {
+    // part: PlanePlan::PART_ALL, or one of the two launches of a split pass (the EDGE launch goes to the side stream;
+    // the vectors are swapped once, after the pass's last launch has been enqueued: swap)
+    void down(int l, bool first_of_batch = false, int part = PlanePlan<double>::PART_ALL, bool swap = true, bool on_side = false) {
         for (PlaneDist *d : ranks) {
             PDLevel &L = d->lv[l];
             const bool last = l + 1 == (int)d->lv.size();
@@ -1115,12 +1129,12 @@ struct PDExchange {
                 const PlanePlan<double>::Peer p = peer_of(d, l, true, first_of_batch);
                 L.plan.down(L.xp, L.tp, L.b.p, l > 0, c, d->stream, &p);
             } else {
-                L.plan.down(L.xp, L.tp, L.b.p, l > 0, c, d->stream);
+                L.plan.down(L.xp, L.tp, L.b.p, l > 0, c, (on_side || part == PlanePlan<double>::PART_EDGE) ? d->side : d->stream, nullptr, true, part);
             }
-            std::swap(L.xp, L.tp);
+            if (swap) std::swap(L.xp, L.tp);
         }
     }
-    void up(int l, double *partials) {
+    void up(int l, double *partials, int part = PlanePlan<double>::PART_ALL, bool swap = true, bool on_side = false) {
         for (PlaneDist *d : ranks) {
             PDLevel &L = d->lv[l];
             const bool last = l + 1 == (int)d->lv.size();
@@ -1132,10 +1146,88 @@ struct PDExchange {
                 const PlanePlan<double>::Peer p = peer_of(d, l, false, false);
                 L.plan.up(L.xp, L.tp, L.b.p, c, out, d->stream, &p);
             } else {
-                L.plan.up(L.xp, L.tp, L.b.p, c, out, d->stream);
+                L.plan.up(L.xp, L.tp, L.b.p, c, out, (on_side || part == PlanePlan<double>::PART_EDGE) ? d->side : d->stream, nullptr, true, part);
             }
-            std::swap(L.xp, L.tp);
+            if (swap) std::swap(L.xp, L.tp);
         }
+    }
+    // split passes: main -> side ("the pass's inputs are complete") and side -> main ("edge chunks and exchanges done")
+    void main_to_side(int l, int up_) {
+        for (PlaneDist *d : ranks) {
+            OMG_HIP(hipEventRecord(d->ev_main[up_][size_t(l)], d->stream));
+            OMG_HIP(hipStreamWaitEvent(d->side, d->ev_main[up_][size_t(l)], 0));
+        }
+    }
+    void side_done(int l, int up_) {
+        for (PlaneDist *d : ranks) OMG_HIP(hipEventRecord(d->ev_edge[up_][size_t(l)], d->side));
+    }
+    void main_waits_side(int l, int up_) {
+        for (PlaneDist *d : ranks) OMG_HIP(hipStreamWaitEvent(d->stream, d->ev_edge[up_][size_t(l)], 0));
+    }
+    bool split() const {
+        if (!exchanges()) return false;                           // one slab: no neighbour, nothing to overlap
+        for (PlaneDist *d : ranks)
+            if (!d->split) return false;
+        return true;
+    }
+    // a level too thin for two launches runs its whole pass where the edge chunks would run
+    bool two_launches(int l) const {
+        for (PlaneDist *d : ranks)
+            if (!d->lv[size_t(l)].plan.can_split()) return false;
+        return true;
+    }
+    // One V(1,1) cycle with split passes.  Per pass: side stream: edge chunks, then the exchanges of what they produced
+    // (ghost planes of the new iterate for this level's own up pass / for the finer level's; ghost planes of the coarse
+    // right-hand side for the next level's down pass) — main stream: the inner chunks meanwhile.  Left on the critical
+    // path: the tail's all-gather, and whatever part of an exchange outlasts its pass's inner chunks.
+    void cycle_split(double *squares_out) {
+        typedef PlanePlan<double> PP;
+        const int nd = (int)ranks[0]->lv.size();
+        // the ghost planes of x the first pass reads: posted behind the previous cycle's last edge launch, or (first
+        // cycle after a load) exchanged here
+        bool posted = true;
+        for (PlaneDist *d : ranks) posted = posted && d->x0_posted;
+        if (posted) main_waits_side(0, 1);
+        else halo(0, 0, 3);
+        mark(0, 1);
+        for (int l = 0; l < nd; ++l) {
+            if (l > 0) main_waits_side(l - 1, 0);                 // ghost planes of this level's right-hand side
+            main_to_side(l, 0);
+            if (two_launches(l)) {
+                down(l, false, PP::PART_EDGE, false);
+                down(l, false, PP::PART_INNER, true);             // (swapped: the exchanges below send the NEW iterate)
+            } else {
+                down(l, false, PP::PART_ALL, true, true);
+            }
+            halo(l, 0, 3, true);                                  // for this level's up pass
+            if (l + 1 < nd) halo(l + 1, 1, 2, true);              // for the next level's down pass
+            side_done(l, 0);
+            mark(l, 3);
+        }
+        main_waits_side(nd - 1, 0);                               // the tail gathers ALL of the last level's coarse right-hand side
+        tail_solve();
+        mark(nd, 5);
+        for (int l = nd - 1; l >= 0; --l) {
+            main_waits_side(l, 0);                                // ghost planes of the iterate the down pass left
+            if (l + 1 < nd) main_waits_side(l + 1, 1);            // ... and of the correction
+            mark(l, 4);
+            main_to_side(l, 1);
+            if (two_launches(l)) {
+                up(l, nullptr, PP::PART_EDGE, false);
+                up(l, nullptr, PP::PART_INNER, true);
+            } else {
+                up(l, nullptr, PP::PART_ALL, true, true);
+            }
+            halo(l, 0, l > 0 ? 2 : 3, true);                      // the correction's ghost planes for level l - 1 / the next cycle's first pass
+            side_done(l, 1);
+            mark(l, 7);
+        }
+        for (PlaneDist *d : ranks) d->x0_posted = true;
+        main_waits_side(0, 1);                                    // (the edge chunks' share of the norm's partials)
+        const bool two0 = two_launches(0);
+        for (PlaneDist *d : ranks)
+            launch_sum(d->lv[0].plan.partials.p, two0 ? d->lv[0].plan.split_partials() : d->lv[0].plan.g.n_wg, squares_out ? squares_out : d->norm2.p,
+                       d->stream);
     }
     // peer mode, once per batch of cycles: the ghost planes of b and of the incoming x, handed over only when the
     // neighbour's stream has reached its own batch start (it may have been loading new vectors until then)
@@ -1245,6 +1337,7 @@ struct PDExchange {
                 launch_sum(d->lv[0].plan.partials.p, d->lv[0].plan.g.n_wg, squares_out ? squares_out : d->norm2.p, d->stream);
             return;
         }
+        if (split()) { cycle_split(squares_out); return; }
         halo(0, 0, 3);
         mark(0, 1);
         for (int l = 0; l < nd; ++l) {
@@ -1307,7 +1400,13 @@ std::unique_ptr<PlaneDist> pd_create(int rank, int n_ranks, int nx, int ny, int 
     d->n_ranks = n_ranks;
     OMG_HIP(hipStreamCreateWithFlags(&d->own, hipStreamNonBlocking));
     d->stream = d->own;
-    OMG_HIP(hipStreamCreateWithFlags(&d->side_own, hipStreamNonBlocking));
+    {
+        // the side stream carries the edge chunks of split passes and the exchanges behind them: ahead of the main
+        // stream's inner chunks when both have workgroups to place
+        int least = 0, greatest = 0;
+        OMG_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        OMG_HIP(hipStreamCreateWithPriority(&d->side_own, hipStreamNonBlocking, greatest));
+    }
     d->side = d->side_own;
     d->lv.resize(size_t(n_levels));
     for (int l = 0; l < n_levels; ++l) {
@@ -1316,6 +1415,13 @@ std::unique_ptr<PlaneDist> pd_create(int rank, int n_ranks, int nx, int ny, int 
         OMG_HIP(hipEventCreateWithFlags(&b, hipEventDisableTiming));
         d->ev_down.push_back(a);
         d->ev_halo.push_back(b);
+        for (int i = 0; i < 2; ++i) {
+            hipEvent_t m, e;
+            OMG_HIP(hipEventCreateWithFlags(&m, hipEventDisableTiming));
+            OMG_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            d->ev_main[i].push_back(m);
+            d->ev_edge[i].push_back(e);
+        }
     }
     int lx = nx, ly = ny, lz = nz_global / n_ranks;
     for (int l = 0; l < n_levels; ++l) {
@@ -1927,6 +2033,7 @@ int omg_pdist_load(omg_pdist *d, const double *b_local, const double *x0_local) 
     return guarded([&] {
         OMG_REQUIRE(d && d->d && b_local, "null argument");
         PlaneDist *dd = d->d.get();
+        dd->x0_posted = false;                                    // (the next cycle exchanges the ghost planes of the new iterate itself)
         pd_put(dd, b_local, dd->lv[0].b.p);
         pd_put(dd, x0_local, dd->lv[0].xp);
         if (dd->comm && dd->n_ranks > 1 && !dd->p2p) {            // (peer mode hands the ghost planes over at every batch start)

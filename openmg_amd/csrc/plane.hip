@@ -164,6 +164,11 @@ struct PlaneKArgs {
     // zeros and stay zeros); a whole grid: 0, nz, 0, nz.  kc_off: coarse plane of fine plane k = (k >> 1) + kc_off
     int z_base, z_end, kv0, kv1, kc_off;
     int TXq, TY, LZ, PX, PY, ntx, nty, ntz;
+    // the z chunks of this launch: chunk i = planes [zc_base + i zc_stride, + zc_len) clipped to zc_end.  A whole pass:
+    // z_base, LZ, LZ, z_end.  A pass made of two launches (PlanePlan::PART_*): the EDGE launch has two short chunks — the
+    // slab's first and last PLANE_EDGE planes —, the INNER launch chunks of LZ planes between them; the norm's partial of a
+    // workgroup then goes to slot part_slot0 + its number (the two launches fill one array)
+    int zc_base, zc_stride, zc_len, zc_end, part_slot0;
     V c0, c1, c2, c3, c4, c5, c6, w;
     int x_zero;
     int fast_div;                    // the diagonal's exponent is within 2^-400 .. 2^400 (quotients())
@@ -348,7 +353,7 @@ __global__ __launch_bounds__(MAXT) void plane_kernel(const PlaneKArgs<V> a) {
     const int nxy = a.ntx * a.nty;
     const int tz = L / nxy, rem = L - tz * nxy;
     const int ty = rem / a.ntx, tx = rem - ty * a.ntx;
-    const int z0 = a.z_base + tz * a.LZ, z1 = min(a.z_end, z0 + a.LZ);
+    const int z0 = a.zc_base + tz * a.zc_stride, z1 = min(a.zc_end, z0 + a.zc_len);
     const int q = tx * a.TXq + px - 1;               // pair index in the line
     const int ja = ty * a.TY + 2 * py - 4;           // the thread's lines ja (even), ja + 1
     const bool vx0 = live && q >= 0 && 2 * q < a.hx, vx1 = live && q >= 0 && 2 * q + 1 < a.hx;
@@ -838,7 +843,7 @@ __global__ __launch_bounds__(MAXT) void plane_kernel(const PlaneKArgs<V> a) {
         if (t == 0) {
             double tot = 0.0;
             for (int wv = 0; wv < int(blockDim.x) >> 6; ++wv) tot += s_red[wv];
-            a.partials[blockIdx.x] = tot;
+            a.partials[a.part_slot0 + int(blockIdx.x)] = tot;
         }
     }
     if (PEER) peer_done(a.done, gridDim.x, a.peer_flag, a.flag_seq);
@@ -1463,7 +1468,7 @@ void PlanePlan<V>::build_slab(int nx, int ny, int nz_own, int ghost, int ghost_c
     choose_tiles(g, sizeof(V));
     small_level_switches(g);
     OMG_REQUIRE(g.TX > 0 && g.threads <= 512, "plane slab: no tiling");
-    partials.alloc(size_t(g.n_wg) + SUM_FOLD);
+    partials.alloc(size_t(std::max(g.n_wg, split_partials())) + SUM_FOLD);
 }
 
 // Times the candidate tilings on the caller's vectors (their contents are destroyed; zeros are a fair input) and
@@ -1490,11 +1495,11 @@ void PlanePlan<V>::tune(V *x, V *tmp, const V *b, const Coarse &c, hipStream_t s
         const auto it = decided.find(key);
         if (it != decided.end()) {
             g = cand[it->second];
-            partials.alloc(size_t(g.n_wg) + SUM_FOLD);
+            partials.alloc(size_t(std::max(g.n_wg, split_partials())) + SUM_FOLD);
             return;
         }
     }
-    partials.alloc(size_t(std::max(cand[0].n_wg, cand[1].n_wg)) + SUM_FOLD);
+    partials.alloc(size_t(std::max(std::max(cand[0].n_wg, cand[1].n_wg), split_partials())) + SUM_FOLD);
     hipEvent_t e0, e1;
     OMG_HIP(hipEventCreate(&e0));
     OMG_HIP(hipEventCreate(&e1));
@@ -1523,7 +1528,7 @@ void PlanePlan<V>::tune(V *x, V *tmp, const V *b, const Coarse &c, hipStream_t s
         pick = decided.emplace(key, pick).first->second;
     }
     g = cand[pick];
-    partials.alloc(size_t(g.n_wg) + SUM_FOLD);
+    partials.alloc(size_t(std::max(g.n_wg, split_partials())) + SUM_FOLD);
 }
 
 template <typename V>
@@ -1612,6 +1617,7 @@ PlaneKArgs<V> plane_args(const PlaneGeom &g, const V *x_old, V *x_new, const V *
     k.cmap = c.map;
     k.bc = c.b; k.xc = c.x; k.cdiag = c.diag; k.first_end = c.first_end; k.ec = c.e;
     k.status = status;
+    k.zc_base = g.z_base; k.zc_stride = g.LZ; k.zc_len = g.LZ; k.zc_end = g.z_end; k.part_slot0 = 0;
     return k;
 }
 
@@ -1748,17 +1754,33 @@ void launch_tile2d(const PlaneGeom &g, const V *x_old, V *x_new, const V *b, con
 
 inline bool small_tile(const PlaneGeom &g) { return g.la2 && g.threads <= 128; }
 
+// part (PlanePlan::PART_*): the whole pass, or only the slab's first and last PLANE_EDGE planes, or only the planes between
+template <typename V>
+int plane_part(const PlaneGeom &g, PlaneKArgs<V> &k, int part) {
+    const int nxy = g.ntx * g.nty, nzo = g.z_end - g.z_base;
+    if (part == 0) return g.n_wg;
+    if (part == 1) {
+        k.zc_base = g.z_base; k.zc_stride = nzo - PLANE_EDGE; k.zc_len = PLANE_EDGE; k.zc_end = g.z_end; k.part_slot0 = 0;
+        return 2 * nxy;
+    }
+    k.zc_base = g.z_base + PLANE_EDGE; k.zc_stride = g.LZ; k.zc_len = g.LZ; k.zc_end = g.z_end - PLANE_EDGE; k.part_slot0 = 2 * nxy;
+    return nxy * ((nzo - 2 * PLANE_EDGE + g.LZ - 1) / g.LZ);
+}
 template <typename K, typename V>
-void launch_plane(K kernel, const PlaneGeom &g, const PlaneKArgs<V> &k, hipStream_t s) {
+void launch_plane(K kernel, const PlaneGeom &g, const PlaneKArgs<V> &k, hipStream_t s, int n_wg = -1) {
+    if (n_wg == 0) return;
     allow_lds(kernel, g.lds_bytes);
-    hipLaunchKernelGGL(kernel, dim3(unsigned(g.n_wg)), dim3(unsigned(g.threads)), g.lds_bytes, s, k);
+    hipLaunchKernelGGL(kernel, dim3(unsigned(n_wg < 0 ? g.n_wg : n_wg)), dim3(unsigned(g.threads)), g.lds_bytes, s, k);
     OMG_HIP(hipGetLastError());
 }
 
 template <typename V>
-void PlanePlan<V>::down(const V *x_old, V *x_new, const V *b, bool x_zero, const Coarse &c, hipStream_t s, const Peer *peer, bool sweep) const {
+void PlanePlan<V>::down(const V *x_old, V *x_new, const V *b, bool x_zero, const Coarse &c, hipStream_t s, const Peer *peer, bool sweep, int part) const {
     PlaneKArgs<V> k = plane_args<V>(g, x_old, x_new, b, c, status);
     k.x_zero = x_zero ? 1 : 0;
+    OMG_REQUIRE(part == 0 || (!peer && sweep && !g.dim2 && !block_level(g) && !c.x && !c.diag && !small_tile(g)),
+                "a pass in two launches: slabs' marching passes only");
+    const int wgs = plane_part(g, k, part);
 #ifdef OMG_PLANE_STAMPS
     DevBuf<unsigned long long> sb;
     stamps_begin(k, g, sb);
@@ -1793,9 +1815,9 @@ void PlanePlan<V>::down(const V *x_old, V *x_new, const V *b, bool x_zero, const
         if (x_zero) launch_plane(plane_kernel<V, 0, false, true, 2, false, 128>, g, k, s);
         else launch_plane(plane_kernel<V, 0, false, false, 2, false, 128>, g, k, s);
     } else if (x_zero) {
-        launch_plane(plane_kernel<V, 0, false, true, PLANE_LA>, g, k, s);
+        launch_plane(plane_kernel<V, 0, false, true, PLANE_LA>, g, k, s, wgs);
     } else {
-        launch_plane(plane_kernel<V, 0, false, false, PLANE_LA>, g, k, s);
+        launch_plane(plane_kernel<V, 0, false, false, PLANE_LA>, g, k, s, wgs);
     }
 #ifdef OMG_PLANE_STAMPS
     stamps_end("down", g, sb, s);
@@ -1803,9 +1825,12 @@ void PlanePlan<V>::down(const V *x_old, V *x_new, const V *b, bool x_zero, const
 }
 
 template <typename V>
-void PlanePlan<V>::up(const V *x_old, V *x_new, const V *b, const Coarse &c, double *out, hipStream_t s, const Peer *peer, bool sweep) const {
+void PlanePlan<V>::up(const V *x_old, V *x_new, const V *b, const Coarse &c, double *out, hipStream_t s, const Peer *peer, bool sweep, int part) const {
     PlaneKArgs<V> k = plane_args<V>(g, x_old, x_new, b, c, status);
     k.partials = out;
+    OMG_REQUIRE(part == 0 || (!peer && sweep && !g.dim2 && !block_level(g) && !(small_tile(g) && !out)),
+                "a pass in two launches: slabs' marching passes only");
+    const int wgs = plane_part(g, k, part);
 #ifdef OMG_PLANE_STAMPS
     DevBuf<unsigned long long> sb;
     stamps_begin(k, g, sb);
@@ -1834,9 +1859,9 @@ void PlanePlan<V>::up(const V *x_old, V *x_new, const V *b, const Coarse &c, dou
     } else if (small_tile(g) && !out) {
         launch_plane(plane_kernel<V, 1, false, false, 2, false, 128>, g, k, s);
     } else if (out) {
-        launch_plane(plane_kernel<V, 1, true, false, PLANE_LA>, g, k, s);
+        launch_plane(plane_kernel<V, 1, true, false, PLANE_LA>, g, k, s, wgs);
     } else {
-        launch_plane(plane_kernel<V, 1, false, false, PLANE_LA>, g, k, s);
+        launch_plane(plane_kernel<V, 1, false, false, PLANE_LA>, g, k, s, wgs);
     }
 #ifdef OMG_PLANE_STAMPS
     stamps_end("up", g, sb, s);
