@@ -904,7 +904,10 @@ struct PlaneDist {
     // chunks.  ev_main[l][0 / 1]: the main stream has everything the down / up pass of level l reads; ev_edge[l][0 / 1]:
     // the side stream has run the pass's edge chunks and the exchanges behind them.
     std::vector<hipEvent_t> ev_main[2], ev_edge[2];
-    bool split = [] { const char *e = getenv("OMG_PDIST_SPLIT"); return !(e && e[0] == '0'); }();   // (and every level's tiling must have inner chunks)
+    // OMG_PDIST_SPLIT=1 (or 2: even without neighbours).  OFF by default: measured on one GPU (tools/pdist_split_cost.py,
+    // profiles/r04_pdist_split_cost.txt) the two launches + their stream hand-overs cost a rank ~27 us of device time per
+    // pass, ~165 us per cycle — more than the ~120 us of exchange latency and wire time they can hide at N = 8.
+    bool split = [] { const char *e = getenv("OMG_PDIST_SPLIT"); return e && (e[0] == '1' || e[0] == '2'); }();
     bool x0_posted = false;                   // the ghost planes of x for the next cycle's first pass are already on their way (ev_edge[1][0])
     // progress of the DEVICE through a cycle, for a caller whose collective never completes (bench.py's preflight):
     // a word in pinned host memory the stream writes between the phases — (cycle << 16) | (level << 8) | phase,
@@ -1165,7 +1168,10 @@ struct PDExchange {
         for (PlaneDist *d : ranks) OMG_HIP(hipStreamWaitEvent(d->stream, d->ev_edge[up_][size_t(l)], 0));
     }
     bool split() const {
-        if (!exchanges()) return false;                           // one slab: no neighbour, nothing to overlap
+        // (OMG_PDIST_SPLIT=2: also with ONE slab — no neighbour, no exchange: what the two-launch schedule costs a rank
+        // in device time, measurable on one GPU)
+        static const bool force = [] { const char *e = getenv("OMG_PDIST_SPLIT"); return e && e[0] == '2'; }();
+        if (!exchanges() && !force) return false;                 // one slab: no neighbour, nothing to overlap
         for (PlaneDist *d : ranks)
             if (!d->split) return false;
         return true;

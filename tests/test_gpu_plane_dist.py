@@ -53,6 +53,29 @@ def test_plane_slabs_have_the_bits_of_the_single_gpu_cycle(shape, grids, n_dist)
         np.testing.assert_allclose(norms, want_norms, rtol=1e-13)
 
 
+@pytest.mark.parametrize("mode", ["1", "2"])
+def test_split_passes_have_the_bits_of_whole_passes(monkeypatch, mode):
+    """OMG_PDIST_SPLIT: every slab pass as two launches — the slab's first and last four planes on the (priority) side
+    stream with the exchanges behind them, the planes between on the main stream (off by default: it costs a rank more
+    device time than the exchanges it hides).  Same bits; 2: also for a single slab."""
+    monkeypatch.setenv("OMG_PDIST_SPLIT", mode)
+    shape, grids, n_dist = (64, 32, 48), 4, 2
+    A, R, b, x0 = problem(shape, grids)
+    with _hip.Hierarchy(A, R, smoother="colour") as h:
+        h.resident_load(b, x0)
+        want_norms = [h.resident_cycle(1, 1) for _ in range(4)]
+        want = h.resident_fetch()
+    for n_ranks in (1, 2, 4):
+        g = _hip_dist.PlaneDistGroup(slabs(A, R, shape, n_ranks, n_dist, b, x0))
+        try:
+            norms = g.cycles(3) + g.cycles(1)
+            got = np.concatenate([r.fetch() for r in g.ranks])
+        finally:
+            g.close()
+        assert np.array_equal(got, want), (mode, n_ranks, int(np.sum(got != want)))
+        np.testing.assert_allclose(norms, want_norms, rtol=1e-13)
+
+
 def test_one_rank_through_the_rccl_calls():
     """A one-rank communicator: omg_pdist_cycles runs the schedule's RCCL path (all-gather of the level below the
     slabs, all-reduce of the norm are skipped for one rank; connect / load / cycles / fetch are the calls bench.py
