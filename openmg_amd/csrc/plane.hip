@@ -1227,7 +1227,8 @@ inline void small_level_switches(PlaneGeom &g) {
 // SIMDs carry two waves), and several small workgroups share a CU.  Neither predicts the other's winner
 // (256^3: 64 x 32 x 32 at 132 us against 128 x 22 x 26 at 122 us per down pass; other shapes the other way):
 // PlanePlan::tune() times both on the level's own vectors.
-void choose_tiles(PlaneGeom &g, size_t value_bytes, int model = 0) {
+// `more` (nullable): the best few tilings of the model beyond the winner, best first (PlanePlan::tune times them too)
+void choose_tiles(PlaneGeom &g, size_t value_bytes, int model = 0, std::vector<std::array<int, 3>> *more = nullptr, int keep = 0) {
     const int nzo = g.z_end - g.z_base;             // planes the launch relaxes
     auto set = [&](int TX, int TY, int LZ) {
         g.TX = TX; g.TY = TY; g.LZ = LZ;
@@ -1246,8 +1247,7 @@ void choose_tiles(PlaneGeom &g, size_t value_bytes, int model = 0) {
     // Few, fat workgroups: one per CU (256), each as large a tile as its registers hold (<= 512 threads of
     // two lines x four cells), the z chunk as long as the count allows.  cost ~ rounds of workgroups x
     // steps x (threads + a fixed per-step price).
-    double best = 1e300;
-    int bx = 0, by = 0, bz = 0;
+    std::vector<std::pair<double, std::array<int, 3>>> all;
     for (int ntx = 1; ntx <= (g.nx + 3) / 4; ++ntx) {
         const int TX = round_up((g.nx + ntx - 1) / ntx, 4);
         if ((g.nx + TX - 1) / TX != ntx) continue;
@@ -1272,11 +1272,15 @@ void choose_tiles(PlaneGeom &g, size_t value_bytes, int model = 0) {
                     const double rounds = std::ceil(double(ntx) * nty * ntz / (256.0 * per_cu));
                     cost = rounds * (LZ + 4) * (256.0 * simd + 192.0);
                 }
-                if (cost < best) { best = cost; bx = TX; by = TY; bz = LZ; }
+                all.push_back({cost, {TX, TY, LZ}});
             }
         }
     }
-    set(bx, by, bz);
+    if (all.empty()) { g.TX = 0; return; }
+    std::stable_sort(all.begin(), all.end(), [](const auto &u, const auto &v) { return u.first < v.first; });
+    set(all[0].second[0], all[0].second[1], all[0].second[2]);
+    if (more)
+        for (size_t i = 1; i < all.size() && int(more->size()) < keep; ++i) more->push_back(all[i].second);
 }
 
 // 2-D levels: the tile shapes tile2d_kernel is instantiated for, largest first; the largest that still gives 128 workgroups
@@ -1480,32 +1484,68 @@ void PlanePlan<V>::tune(V *x, V *tmp, const V *b, const Coarse &c, hipStream_t s
         int forced[3];
         if ((e && e[0] == '0') || env_int3("OMG_PLANE_TILE", forced)) return;
     }
-    if (int64_t(g.nx) * g.ny * (g.z_end - g.z_base) < (int64_t(1) << 21)) return;
-    PlaneGeom cand[2] = {g, g};
-    choose_tiles(cand[1], sizeof(V), 1);
-    if (cand[1].TX == g.TX && cand[1].TY == g.TY && cand[1].LZ == g.LZ) return;
-    if (cand[1].TX <= 0 || cand[1].threads > 512) return;
+    if (g.dim2 || int64_t(g.nx) * g.ny * (g.z_end - g.z_base) < (int64_t(1) << 21)) return;
+    // Candidates: the winner of either cost model and the next few of each (OMG_PLANE_TUNE_K per model, default 0: measured in round 4, profiles/r04_plane_tune_candidates.txt: none beat the winners) —
+    // neither model predicts the other's winner, nor always the fastest tiling; all are TIMED on the level's own vectors.
+    static const int keep = [] { const char *e = getenv("OMG_PLANE_TUNE_K"); return e ? std::max(0, atoi(e)) : 0; }();
+    static const bool debug = [] { const char *e = getenv("OMG_PLANE_TUNE_DEBUG"); return e && e[0] == '1'; }();
+    std::vector<PlaneGeom> cand;
+    {
+        std::vector<std::array<int, 3>> more0, more1;
+        PlaneGeom g0 = g, g1 = g;
+        choose_tiles(g0, sizeof(V), 0, &more0, keep);
+        choose_tiles(g1, sizeof(V), 1, &more1, keep);
+        auto add = [&](const PlaneGeom &q) {
+            if (q.TX <= 0 || q.threads > 512) return;
+            for (const PlaneGeom &c : cand)
+                if (c.TX == q.TX && c.TY == q.TY && c.LZ == q.LZ) return;
+            cand.push_back(q);
+        };
+        add(g);
+        add(g0);
+        add(g1);
+        auto from = [&](const std::array<int, 3> &t) {
+            PlaneGeom q = g;
+            q.TX = t[0]; q.TY = t[1]; q.LZ = t[2];
+            q.PX = q.TX / 4 + 2; q.PY = q.TY / 2 + 4;
+            const int nzo = q.z_end - q.z_base;
+            q.ntx = (q.nx + q.TX - 1) / q.TX; q.nty = (q.ny + q.TY - 1) / q.TY; q.ntz = (nzo + q.LZ - 1) / q.LZ;
+            q.n_wg = q.ntx * q.nty * q.ntz;
+            q.threads = round_up(q.PX * q.PY, 64);
+            q.lds_bytes = size_t(6) * size_t(2 * q.PY + 2) * size_t(2 * q.PX + 4) * sizeof(V);
+            return q;
+        };
+        for (const auto &t : more0) add(from(t));
+        for (const auto &t : more1) add(from(t));
+    }
+    if (cand.size() < 2) return;
     // One decision per process and shape: the norm's partial sums follow the tiles, and two hierarchies of one process
     // must not differ in its last bit because a timing came out the other way (where the candidates are close).
     static std::mutex mu;
-    static std::map<std::array<int, 8>, int> decided;
+    static std::map<std::array<int, 8>, std::array<int, 3>> decided;
     const std::array<int, 8> key = {g.nx, g.ny, g.nz, g.z_base, g.z_end, int(sizeof(V)), finest ? 1 : 0, g.kv1 - g.kv0};
+    auto adopt = [&](const std::array<int, 3> &t) {
+        for (const PlaneGeom &c : cand)
+            if (c.TX == t[0] && c.TY == t[1] && c.LZ == t[2]) { g = c; break; }
+        partials.alloc(size_t(std::max(g.n_wg, split_partials())) + SUM_FOLD);
+    };
     {
         std::lock_guard<std::mutex> lock(mu);
         const auto it = decided.find(key);
         if (it != decided.end()) {
-            g = cand[it->second];
-            partials.alloc(size_t(std::max(g.n_wg, split_partials())) + SUM_FOLD);
+            adopt(it->second);
             return;
         }
     }
-    partials.alloc(size_t(std::max(std::max(cand[0].n_wg, cand[1].n_wg), split_partials())) + SUM_FOLD);
+    int max_wg = 0;
+    for (const PlaneGeom &c : cand) max_wg = std::max(max_wg, c.n_wg);
+    partials.alloc(size_t(std::max(max_wg, split_partials())) + SUM_FOLD);
     hipEvent_t e0, e1;
     OMG_HIP(hipEventCreate(&e0));
     OMG_HIP(hipEventCreate(&e1));
     float best = 0.0f;
-    int pick = 0;
-    for (int i = 0; i < 2; ++i) {
+    size_t pick = 0;
+    for (size_t i = 0; i < cand.size(); ++i) {
         g = cand[i];
         // (the finest level's passes read the iterate and square the residual; the others' start from zero)
         down(x, tmp, b, !finest, c, s);                           // (not timed: the kernel's first launch)
@@ -1519,16 +1559,19 @@ void PlanePlan<V>::tune(V *x, V *tmp, const V *b, const Coarse &c, hipStream_t s
         OMG_HIP(hipEventSynchronize(e1));
         float ms = 0.0f;
         OMG_HIP(hipEventElapsedTime(&ms, e0, e1));
+        if (debug)
+            fprintf(stderr, "[plane tune] %dx%dx%d%s: tile %3d x %3d x %3d  %4d workgroups of %3d threads  %7.1f us per down + up\n", g.nx, g.ny, g.nz,
+                    finest ? " (finest)" : "", g.TX, g.TY, g.LZ, g.n_wg, g.threads, 1e3 * ms / 2);
         if (i == 0 || ms < best) { best = ms; pick = i; }
     }
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
+    std::array<int, 3> chosen = {cand[pick].TX, cand[pick].TY, cand[pick].LZ};
     {
         std::lock_guard<std::mutex> lock(mu);
-        pick = decided.emplace(key, pick).first->second;
+        chosen = decided.emplace(key, chosen).first->second;
     }
-    g = cand[pick];
-    partials.alloc(size_t(std::max(g.n_wg, split_partials())) + SUM_FOLD);
+    adopt(chosen);
 }
 
 template <typename V>
