@@ -229,7 +229,7 @@ def mgCycle(A, b, level, R, parameters, initial=None):
         print(coarsest * " " + "direct solving at level %i" % coarsest)
     pre = parameters["preIterations"]
     x_in = None if initial is None else np.ascontiguousarray(np.asarray(initial, dtype=np.float64).reshape(-1))
-    x = _hip.out_array(b.size, np.float64)  # uOut is a new array (openmg/__init__.py:220 / :224)
+    x = np.empty(b.size)                    # uOut is a new array (openmg/__init__.py:220 / :224)
     in_place = (pre > 0 and isinstance(initial, np.ndarray) and initial.dtype == np.float64 and initial.flags.writeable
                 and initial.size == b.size and np.shares_memory(initial, initial.reshape(-1)))
     if in_place and np.shares_memory(x_in, initial):

@@ -4,7 +4,6 @@ There is deliberately NO fallback: if the shared library is missing, or no MI355
 visible when a compute entry point is called, an exception is raised.
 """
 import ctypes
-import mmap
 import os
 
 import numpy as np
@@ -213,18 +212,6 @@ def dtype_code(dtype):
     raise ValueError("dtype must be float64 or float32, not %r" % (dtype,))
 
 
-def out_array(count, dtype):
-    """A fresh array the library is about to fill.  Large ones come from an anonymous mapping made with MAP_POPULATE:
-    the pages of a new np.empty are faulted in one by one by whoever writes them first (175 MB: 75 ms on the GPU boxes,
-    measured with tools/hostmem_probe.py), populated in one call they cost 9 ms."""
-    dtype = np.dtype(dtype)
-    nbytes = int(count) * dtype.itemsize
-    if nbytes < (8 << 20) or not hasattr(mmap, "MAP_POPULATE"):
-        return np.empty(int(count), dtype=dtype)
-    m = mmap.mmap(-1, nbytes, flags=mmap.MAP_PRIVATE | mmap.MAP_ANONYMOUS | mmap.MAP_POPULATE)
-    return np.frombuffer(m, dtype=dtype, count=int(count))          # (the array keeps the mapping alive)
-
-
 def host_checksum(a):
     """64-bit digest of every byte of a NumPy array (omg_host_checksum: all host threads, no device)."""
     a = np.ascontiguousarray(a)
@@ -364,7 +351,7 @@ class Hierarchy:
         return [float(norms[k]) for k in range(int(n_cycles))]
 
     def resident_fetch(self):
-        x = out_array(self.sizes[0], np.float64)
+        x = np.empty(self.sizes[0], dtype=np.float64)
         check(lib().omg_resident_fetch(self._h, x.ctypes.data))
         return x
 
@@ -557,9 +544,9 @@ def _product(fn, X, Y):
     nr, nc, nnz = ctypes.c_int64(0), ctypes.c_int64(0), ctypes.c_int64(0)
     check(fn(ctypes.byref(vx), ctypes.byref(vy), ctypes.byref(res), ctypes.byref(nr),
              ctypes.byref(nc), ctypes.byref(nnz)))
-    indptr = out_array(nr.value + 1, np.int32)
-    indices = out_array(max(nnz.value, 0), np.int32)
-    data = out_array(max(nnz.value, 0), np.float64)
+    indptr = np.empty(nr.value + 1, dtype=np.int32)
+    indices = np.empty(max(nnz.value, 0), dtype=np.int32)
+    data = np.empty(max(nnz.value, 0), dtype=np.float64)
     check(lib().omg_csr_result_fetch(res, indptr.ctypes.data, indices.ctypes.data, data.ctypes.data))
     return sp.csr_matrix((data, indices, indptr), shape=(nr.value, nc.value))
 
@@ -581,9 +568,9 @@ def restriction(shape):
     N = int(np.prod(shape))
     n = N // (2 ** dim)
     arr = (ctypes.c_int64 * dim)(*shape)
-    indptr = out_array(n + 1, np.int32)
-    indices = out_array(n * (2 ** dim), np.int32)
-    data = out_array(n * (2 ** dim), np.float64)
+    indptr = np.empty(n + 1, dtype=np.int32)
+    indices = np.empty(n * (2 ** dim), dtype=np.int32)
+    data = np.empty(n * (2 ** dim), dtype=np.float64)
     nr, nnz = ctypes.c_int64(0), ctypes.c_int64(0)
     check(lib().omg_restriction(dim, arr, indptr.ctypes.data, indices.ctypes.data, data.ctypes.data,
                                 ctypes.byref(nr), ctypes.byref(nnz)))
