@@ -524,6 +524,8 @@ struct PlaneGeom {
     double w = 0.0;                   // the restriction's weight
     // small levels (set when the plan is built, from OMG_PLANE_BLOCK / OMG_PLANE_BLOCK_CELLS / OMG_PLANE_LA2):
     bool dim2 = false;                // nz == 1: a 2-D grid (five-point stencil, 2 x 2 aggregation): tile2d_kernel
+    bool jacobi = false;              // ... smoothed with weighted Jacobi (weight omega) in its natural ordering instead of red-black
+    double omega = 1.0;
     bool block = false;               // whole grid of <= 64^3 cells: block_kernel where the pass allows it
     bool la2 = true;                  // marching kernel with two steps of lookahead for workgroups of <= 128 threads
 };
@@ -539,7 +541,8 @@ struct PlanePlan {
     // the caller's CSR in natural numbering.  true: ord = the level's colour ordering, written in closed
     // form (parity colours, red first — what the greedy colouring of such a stencil gives, without its
     // sequential pass over the rows).
-    bool build(const omg_csr &A, const omg_csr &R, Ordering &ord);
+    // jacobi: the level is smoothed with weighted Jacobi (2-D levels only): natural ordering, one set.
+    bool build(const omg_csr &A, const omg_csr &R, Ordering &ord, bool jacobi = false, double omega = 1.0);
     // The operator and the restriction the plan stands for, as the caller's CSR had them (natural numbering,
     // ascending columns; doubles — of the rounded coefficients for a float plan): what the row kernels'
     // format of a plane level is built from when something asks for it (hierarchy.hip ensure_format).

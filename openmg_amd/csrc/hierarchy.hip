@@ -831,16 +831,17 @@ std::unique_ptr<Hier<V>> create(int n_levels, const omg_csr *A, const omg_csr *R
     for (int l = 0; l + 1 < n_levels; ++l) {
         Lv &L = h->lv[l];
         L.n = A[l].n_rows;
-        if (smoother == OMG_SMOOTH_GS_COLOUR) {
+        if (smoother == OMG_SMOOTH_GS_COLOUR || smoother == OMG_SMOOTH_JACOBI) {
             SetupTimer tp("plane-pipelined passes: does the level qualify (+ its parity ordering)");
             std::unique_ptr<PlanePlan<V>> plan(new PlanePlan<V>);
             L.march.reset();
-            if (plan->build(A[l], R[l], L.ord)) {
+            // (weighted Jacobi: 2-D levels only — BASELINE configs[1] — in their natural ordering)
+            if (plan->build(A[l], R[l], L.ord, smoother == OMG_SMOOTH_JACOBI, omega)) {
                 if (!h->plane_status.p) { h->plane_status.alloc(1); h->plane_status.zero(h->stream); }
                 plan->status = h->plane_status.p;
                 L.plane = std::move(plan);
                 // OMG_PLANE_CHECK_ORDER=1 (tests): the closed-form ordering is the greedy colouring's
-                if (getenv_flag("OMG_PLANE_CHECK_ORDER")) {
+                if (getenv_flag("OMG_PLANE_CHECK_ORDER") && smoother == OMG_SMOOTH_GS_COLOUR) {
                     const Ordering g = make_ordering(A[l], smoother);
                     OMG_REQUIRE(g.sets == L.ord.sets && g.perm == L.ord.perm && g.inv == L.ord.inv,
                                 "internal: the parity ordering differs from the greedy colouring");
@@ -848,7 +849,7 @@ std::unique_ptr<Hier<V>> create(int n_levels, const omg_csr *A, const omg_csr *R
                 continue;
             }
             std::unique_ptr<Stencil27Plan<V>> s27(new Stencil27Plan<V>);
-            if (s27->build(A[l], R[l], L.ord, h->stream)) {
+            if (smoother == OMG_SMOOTH_GS_COLOUR && s27->build(A[l], R[l], L.ord, h->stream)) {
                 L.s27 = std::move(s27);
                 if (getenv_flag("OMG_PLANE_CHECK_ORDER")) {
                     const Ordering g = make_ordering(A[l], smoother);

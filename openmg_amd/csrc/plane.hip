@@ -1062,7 +1062,7 @@ struct Tile2KArgs {
     const V *b;
     int nx, ny, nr;
     int nbx;
-    V c1, c2, c3, c4, c5, w;
+    V c1, c2, c3, c4, c5, w, omega;
     int fast_div;
     int nxc, nyc;
     const int32_t *cmap;
@@ -1071,20 +1071,24 @@ struct Tile2KArgs {
     double *partials;
 };
 
-template <typename V, int MODE, bool XZ, bool NORM, bool SWEEP, int BX, int BY>
+// JAC: weighted Jacobi (the smoother BASELINE configs[1] names) instead of red-black Gauss-Seidel: the level keeps its
+// natural ordering; one out-of-place sweep over tile + 1 (x_new in a second LDS image), x + omega ((b - A x) / a_ii)
+// spelled like the row kernels' ROW_JACOBI
+template <typename V, int MODE, bool XZ, bool NORM, bool SWEEP, int BX, int BY, bool JAC = false>
 __global__ __launch_bounds__(256) void tile2d_kernel(const Tile2KArgs<V> a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char plane_smem[];
     constexpr int EX = BX + 6, EY = BY + 6, vol = EX * EY, NT = 256;
     V *const X = reinterpret_cast<V *>(plane_smem);
     V *const B = X + vol;
-    V *const E = B + vol;                                                  // up: coarse correction under the region; down / norm: the tile's residuals
+    V *const XN = B + vol;                                                 // JAC: the relaxed values (tile + 1); otherwise X itself
+    V *const E = JAC ? XN + vol : XN;                                      // up: coarse correction under the region; down / norm: the tile's residuals
     __shared__ double s_red[NT / 64];
     const int t = int(threadIdx.x);
     const int bi = int(blockIdx.x) % a.nbx, bj = int(blockIdx.x) / a.nbx;
     const int i0 = bi * BX - 3, j0 = bj * BY - 3;                          // grid coordinates of LDS cell (0, 0): odd
     const V rc3 = refined_rcp(a.c3);
     const bool fast = a.fast_div != 0;
-    auto slot_of = [&](int gi, int gj) { return (((gi + gj) & 1) ? a.nr : 0) + ((gj * a.nx + gi) >> 1); };
+    auto slot_of = [&](int gi, int gj) { return JAC ? gj * a.nx + gi : (((gi + gj) & 1) ? a.nr : 0) + ((gj * a.nx + gi) >> 1); };
     auto in_grid = [&](int gi, int gj) { return gi >= 0 && gi < a.nx && gj >= 0 && gj < a.ny; };
     // all loads requested before the first is used
     constexpr int NL = (vol + NT - 1) / NT;
@@ -1127,13 +1131,14 @@ __global__ __launch_bounds__(256) void tile2d_kernel(const Tile2KArgs<V> a) {
     for (int n = 0; n < NL; ++n)
         if (t + n * NT < vol) { X[t + n * NT] = xv[n]; B[t + n * NT] = bv[n]; }
     __syncthreads();
-    auto row = [&](int c) -> V {
-        V s = madd(a.c1, X[c - EX], V(0));
-        s = madd(a.c2, X[c - 1], s);
-        s = madd(a.c3, X[c], s);
-        s = madd(a.c4, X[c + 1], s);
-        return madd(a.c5, X[c + EX], s);
+    auto row_of = [&](const V *Y, int c) -> V {
+        V s = madd(a.c1, Y[c - EX], V(0));
+        s = madd(a.c2, Y[c - 1], s);
+        s = madd(a.c3, Y[c], s);
+        s = madd(a.c4, Y[c + 1], s);
+        return madd(a.c5, Y[c + EX], s);
     };
+    auto row = [&](int c) -> V { return row_of(X, c); };
     // cells of one colour inside the tile widened by RING (<= 2), clipped to the grid
     auto sweep = [&](int colour, auto RING) {
         constexpr int ring = decltype(RING)::value;
@@ -1152,7 +1157,24 @@ __global__ __launch_bounds__(256) void tile2d_kernel(const Tile2KArgs<V> a) {
             X[l] = X[l] + block_quotient(B[l] - row(l), a.c3, rc3, fast);
         }
     };
-    if (SWEEP) {
+    const V *Y = X;                                                        // the iterate the tile is finished from
+    if (SWEEP && JAC) {
+        // one weighted-Jacobi sweep over tile + 1, out of place (cells outside the grid stay zero)
+        constexpr int wx = BX + 2, wy = BY + 2, np = wx * wy, NI = (np + NT - 1) / NT;
+        for (int i = t; i < vol; i += NT) XN[i] = V(0);
+        __syncthreads();
+#pragma unroll
+        for (int n = 0; n < NI; ++n) {
+            const int p = t + n * NT;
+            const int li = 2 + p % wx, lj = 2 + p / wx;
+            const int gi = i0 + li, gj = j0 + lj;
+            if (p >= np || !in_grid(gi, gj)) continue;
+            const int l = lj * EX + li;
+            XN[l] = X[l] + a.omega * block_quotient(B[l] - row(l), a.c3, rc3, fast);
+        }
+        __syncthreads();
+        Y = XN;
+    } else if (SWEEP) {
         sweep(0, std::integral_constant<int, 2>());
         __syncthreads();
         sweep(1, std::integral_constant<int, 1>());
@@ -1167,9 +1189,9 @@ __global__ __launch_bounds__(256) void tile2d_kernel(const Tile2KArgs<V> a) {
         const int gi = i0 + li, gj = j0 + lj;
         if (c >= BX * BY || gi >= a.nx || gj >= a.ny) continue;
         const int l = lj * EX + li;
-        if (SWEEP || MODE == 1) a.x_new[slot_of(gi, gj)] = X[l];
+        if (SWEEP || MODE == 1) a.x_new[slot_of(gi, gj)] = Y[l];
         if (MODE == 0 || NORM) {
-            const V res = B[l] - row(l);
+            const V res = B[l] - row_of(Y, l);
             if (MODE == 0) E[c] = res;
             if (NORM) sq = fma(double(res), double(res), sq);
         }
@@ -1297,14 +1319,14 @@ void choose_tile2d(PlaneGeom &g, size_t value_bytes) {
     g.n_wg = g.ntx * g.nty;
     g.threads = 256;
     const size_t vol = size_t(g.TX + 6) * size_t(g.TY + 6);
-    g.lds_bytes = (2 * vol + std::max(size_t(g.TX) * g.TY, size_t(g.TX / 2 + 4) * size_t(g.TY / 2 + 4))) * value_bytes;
+    g.lds_bytes = ((g.jacobi ? 3 : 2) * vol + std::max(size_t(g.TX) * g.TY, size_t(g.TX / 2 + 4) * size_t(g.TY / 2 + 4))) * value_bytes;
     (void)pick;
 }
 
 }  // namespace
 
 template <typename V>
-bool PlanePlan<V>::build(const omg_csr &A, const omg_csr &R, Ordering &ord) {
+bool PlanePlan<V>::build(const omg_csr &A, const omg_csr &R, Ordering &ord, bool jacobi, double omega) {
     {
         const char *e = getenv("OMG_PLANE");
         if (e && e[0] == '0') return false;
@@ -1331,6 +1353,7 @@ bool PlanePlan<V>::build(const omg_csr &A, const omg_csr &R, Ordering &ord) {
     // nz == 1: a 2-D grid (five-point stencil, 2 x 2 aggregation): tile2d_kernel instead of the marching kernel
     const bool dim2 = nz == 1;
     if ((nx & 1) || (ny & 1) || (!dim2 && (nz & 1)) || ny < 2) return false;
+    if (jacobi && !dim2) return false;                 // weighted Jacobi: the 2-D tile passes only
     {
         const char *e = getenv("OMG_PLANE_2D");
         if (dim2 && e && e[0] == '0') return false;
@@ -1418,6 +1441,10 @@ bool PlanePlan<V>::build(const omg_csr &A, const omg_csr &R, Ordering &ord) {
     }
     if (!ok) return false;
     ord = Ordering();
+    if (jacobi) {
+        ord.identity = true;                           // one set, natural numbering
+        ord.sets = {0, n};
+    } else {
     ord.identity = false;
     ord.sets = {0, n / 2, n};
     ord.perm.resize(size_t(n));
@@ -1437,6 +1464,7 @@ bool PlanePlan<V>::build(const omg_csr &A, const omg_csr &R, Ordering &ord) {
         fill(0);
         for (auto &q : th) q.join();
     }
+    }
     // (a float level holds the rounded coefficients: every entry with one value rounds to one value)
     g = PlaneGeom();
     g.nx = (int)nx; g.ny = (int)ny; g.nz = (int)nz; g.hx = (int)(nx / 2);
@@ -1444,6 +1472,8 @@ bool PlanePlan<V>::build(const omg_csr &A, const omg_csr &R, Ordering &ord) {
     g.w = double(V(w));
     g.z_base = 0; g.z_end = g.nz; g.kv0 = 0; g.kv1 = g.nz; g.kc_off = 0; g.nzc = g.nz / 2;
     g.dim2 = dim2;
+    g.jacobi = jacobi;
+    g.omega = jacobi ? double(V(omega)) : 1.0;
     if (dim2) {
         choose_tile2d(g, sizeof(V));
     } else {
@@ -1781,6 +1811,7 @@ void launch_tile2d(const PlaneGeom &g, const V *x_old, V *x_new, const V *b, con
     a.nbx = g.ntx;
     a.c1 = V(g.c[1]); a.c2 = V(g.c[2]); a.c3 = V(g.c[3]); a.c4 = V(g.c[4]); a.c5 = V(g.c[5]);
     a.w = V(g.w);
+    a.omega = V(g.omega);
     a.fast_div = (std::fabs(g.c[3]) >= 0x1p-400 && std::fabs(g.c[3]) <= 0x1p400) ? 1 : 0;
     a.nxc = g.nx / 2; a.nyc = g.ny / 2;
     a.cmap = c.map; a.bc = c.b; a.ec = c.e;
@@ -1789,9 +1820,15 @@ void launch_tile2d(const PlaneGeom &g, const V *x_old, V *x_new, const V *b, con
         allow_lds(kernel, g.lds_bytes);
         hipLaunchKernelGGL(kernel, dim3(unsigned(g.n_wg)), dim3(256), g.lds_bytes, s, a);
     };
-    if (g.TX == 64) go(tile2d_kernel<V, MODE, XZ, NORM, SWEEP, 64, 32>);
-    else if (g.TX == 32) go(tile2d_kernel<V, MODE, XZ, NORM, SWEEP, 32, 16>);
-    else go(tile2d_kernel<V, MODE, XZ, NORM, SWEEP, 16, 8>);
+    if (g.jacobi) {
+        if (g.TX == 64) go(tile2d_kernel<V, MODE, XZ, NORM, SWEEP, 64, 32, true>);
+        else if (g.TX == 32) go(tile2d_kernel<V, MODE, XZ, NORM, SWEEP, 32, 16, true>);
+        else go(tile2d_kernel<V, MODE, XZ, NORM, SWEEP, 16, 8, true>);
+    } else {
+        if (g.TX == 64) go(tile2d_kernel<V, MODE, XZ, NORM, SWEEP, 64, 32>);
+        else if (g.TX == 32) go(tile2d_kernel<V, MODE, XZ, NORM, SWEEP, 32, 16>);
+        else go(tile2d_kernel<V, MODE, XZ, NORM, SWEEP, 16, 8>);
+    }
     OMG_HIP(hipGetLastError());
 }
 

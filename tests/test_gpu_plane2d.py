@@ -113,3 +113,36 @@ def test_config1_full_size_properties():
         h.use_plane(False)
         norms3, x3 = run(h, b, 1, 1, 3)
         assert np.array_equal(x3, x) and close(norms3, norms)
+
+
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+@pytest.mark.parametrize("shape,grids", [((16, 16), 3), ((64, 64), 4), ((10, 22), 2), ((128, 256), 4), ((70, 98), 2)])
+def test_2d_weighted_jacobi_tile_passes_have_the_bits_of_the_set_schedule(shape, grids, dtype):
+    """Weighted Jacobi (the smoother BASELINE configs[1] names) on the same fused tile passes, natural ordering."""
+    A, R = hierarchy(shape, grids, scale=0.83)
+    rng = np.random.default_rng(19)
+    b = rng.standard_normal(A[0].shape[0])
+    x0 = rng.standard_normal(A[0].shape[0])
+    if dtype == "float32":
+        b, x0 = b.astype(np.float32).astype(np.float64), x0.astype(np.float32).astype(np.float64)
+    with _hip.Hierarchy(A, R, smoother="jacobi", omega=2.0 / 3.0, dtype=dtype) as h:
+        assert h.level_flags(0)["plane"] and h.level_sets(0) == 1, shape
+        for pre, post in ((1, 1), (2, 1), (1, 2), (1, 0), (0, 1)):
+            h.use_plane(True)
+            got = run(h, b, pre, post, 3, x0)
+            h.resident_load(b, x0)
+            batch = h.resident_cycles(pre, post, 3)
+            xb = h.resident_fetch()
+            h.use_plane(False)
+            ref = run(h, b, pre, post, 3, x0)
+            assert np.array_equal(got[1], ref[1]), (shape, dtype, pre, post, int(np.sum(got[1] != ref[1])))
+            assert close(got[0], ref[0], 1e-12), (pre, post, got[0], ref[0])
+            assert np.array_equal(xb, got[1]) and batch == got[0]
+
+
+def test_3d_jacobi_keeps_the_set_schedule():
+    A0 = operators.stencil_poisson((8, 8, 8))
+    R = operators.restrictionList((8, 8, 8), 0, 4)
+    A = operators.coeffecientList(A0, R)
+    with _hip.Hierarchy(A, R, smoother="jacobi", omega=0.7) as h:
+        assert not h.level_flags(0)["plane"]
