@@ -470,9 +470,15 @@ def main():
     # sits in HBM for the cycle, 20 back-to-back launches in one hipEvent bracket (untimed region).
     spmv_ms = h.spmv_time(20)
     spmv_csr = spmv_bytes(n, nnz, w)
-    fmt_all = h.format_info(0, "A")
-    spmv_fmt = fmt_all["format_bytes"] + 2 * w * n              # operator in its device format + x read + y written
-    fine_spmv = {"kernel": "y = A x, all rows of the fine grid (%s)" % kernel_name(fmt_all, "ROW_SPMV", h.level_flags(0)["union_walk"]),
+    if plane:
+        # a plane level applies its operator matrix-free, like its cycle does: x read once, y written once
+        spmv_fmt = 2 * w * n
+        spmv_kernel = "y = A x, all rows of the fine grid (plane_spmv_kernel: matrix-free, the level's seven coefficients)"
+    else:
+        fmt_all = h.format_info(0, "A")
+        spmv_fmt = fmt_all["format_bytes"] + 2 * w * n          # operator in its device format + x read + y written
+        spmv_kernel = "y = A x, all rows of the fine grid (%s)" % kernel_name(fmt_all, "ROW_SPMV", h.level_flags(0)["union_walk"])
+    fine_spmv = {"kernel": spmv_kernel,
                  "avg_launch_us": round(spmv_ms * 1e3, 2),
                  "bytes_per_launch": spmv_fmt, "achieved": round(spmv_fmt / spmv_ms / 1e6, 1),
                  "frac": round(spmv_fmt / spmv_ms / 1e6 / HBM_PEAK_GBS, 4),

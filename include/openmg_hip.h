@@ -206,6 +206,11 @@ int omg_level_smooth(omg_hierarchy *h, int level, const double *b, double *x, in
 /* replaces: tools.getresidual(b, A[l], x, N) — openmg/tools.py:12-15 (+ norm, __init__.py:227). */
 int omg_level_residual(omg_hierarchy *h, int level, const double *b, const double *x,
                        double *r, double *norm /* nullable */);
+/* replaces: tools.flexibleMmult(A[level], x) — openmg/tools.py:26 (csr_matvec) — on the operator as the hierarchy
+ * holds it: a plane level (constant-coefficient grid stencil, red-black) applies it matrix-free, any other level walks
+ * its device format; the same bits either way.                                                                        */
+int omg_level_spmv(omg_hierarchy *h, int level, const double *x, double *y);
+
 /* replaces: flexibleMmult(R[l], residual) — openmg/__init__.py:210. */
 int omg_level_restrict(omg_hierarchy *h, int level, const double *fine, double *coarse);
 /* replaces: uApx + flexibleMmult(R[l].transpose(), coarseCorrection) — openmg/__init__.py:214,220,224. */

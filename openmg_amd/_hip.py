@@ -83,6 +83,7 @@ SIGNATURES = {
     "omg_profile_read": (_I, [_P, _I64P, _DP]),
     "omg_level_smooth": (_I, [_P, _I, _P, _P, _I]),
     "omg_level_residual": (_I, [_P, _I, _P, _P, _P, _DP]),
+    "omg_level_spmv": (_I, [_P, _I, _P, _P]),
     "omg_level_restrict": (_I, [_P, _I, _P, _P]),
     "omg_level_prolong_add": (_I, [_P, _I, _P, _P]),
     "omg_coarse_solve": (_I, [_P, _P, _P]),
@@ -455,6 +456,14 @@ class Hierarchy:
             return r, norm.value
         check(lib().omg_level_residual(self._h, level, b.ctypes.data, x.ctypes.data, r.ctypes.data, None))
         return r
+
+    def spmv(self, level, x):
+        """A[level] x on the operator as the hierarchy holds it (omg_level_spmv)."""
+        n = self.sizes[level]
+        x = vec(x, n)
+        y = np.empty(n)
+        check(lib().omg_level_spmv(self._h, level, x.ctypes.data, y.ctypes.data))
+        return y
 
     def restrict(self, level, fine):
         fine = vec(fine, self.sizes[level])

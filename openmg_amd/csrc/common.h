@@ -543,6 +543,8 @@ struct PlanePlan {
     // sequential pass over the rows).
     // jacobi: the level is smoothed with weighted Jacobi (2-D levels only): natural ordering, one set.
     bool build(const omg_csr &A, const omg_csr &R, Ordering &ord, bool jacobi = false, double omega = 1.0);
+    // y = A x of the whole level (colour-ordered vectors), matrix-free; the bits of the row kernels' SpMV
+    void spmv(const V *x, V *y, hipStream_t s) const;
     // The operator and the restriction the plan stands for, as the caller's CSR had them (natural numbering,
     // ascending columns; doubles — of the rounded coefficients for a float plan): what the row kernels'
     // format of a plane level is built from when something asks for it (hierarchy.hip ensure_format).

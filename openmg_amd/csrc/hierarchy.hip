@@ -1389,16 +1389,23 @@ int omg_resident_spmv_time(omg_hierarchy *h, int reps, double *avg_ms) {
             check_level(hh, 0);
             OMG_REQUIRE(hh->resident && reps > 0 && avg_ms, "nothing resident / bad argument");
             OMG_REQUIRE(hh->lv.size() > 1, "single-level hierarchy has no smoothed operator");
-            ensure_format(hh, 0);
             auto &L = hh->lv[0];
+            // a plane level (red-black ordered constant-coefficient stencil): matrix-free, like its cycle; y = the level's
+            // scratch vector.  Anything else: the row kernels on the operator as it sits in HBM.
+            const bool mf = use_plane(hh, L, 1, 1) && !L.plane->g.jacobi;
+            if (!mf) ensure_format(hh, 0);
             RowArgsT<V> a;
-            a.x = L.xp; a.y = L.r.p;
-            launch_rows(L.A, ROW_SPMV, -1, a, hh->stream);              // warm-up
+            a.x = L.xp; a.y = mf ? L.tp : L.r.p;
+            auto once = [&] {
+                if (mf) L.plane->spmv(L.xp, L.tp, hh->stream);
+                else launch_rows(L.A, ROW_SPMV, -1, a, hh->stream);
+            };
+            once();                                                     // warm-up
             hipEvent_t e0, e1;
             OMG_HIP(hipEventCreate(&e0));
             OMG_HIP(hipEventCreate(&e1));
             OMG_HIP(hipEventRecord(e0, hh->stream));
-            for (int i = 0; i < reps; ++i) launch_rows(L.A, ROW_SPMV, -1, a, hh->stream);
+            for (int i = 0; i < reps; ++i) once();
             OMG_HIP(hipEventRecord(e1, hh->stream));
             OMG_HIP(hipEventSynchronize(e1));
             float ms = 0.f;
@@ -1530,6 +1537,31 @@ int omg_level_residual(omg_hierarchy *h, int level, const double *b, const doubl
                 residual_level<V>(hh, level, L.r.p);
             }
             fetch_vec<V>(hh, level, L.r.p, r);
+        });
+    });
+}
+
+int omg_level_spmv(omg_hierarchy *h, int level, const double *x, double *y) {
+    return guarded([&] {
+        with(h, [&](auto *hh) {
+            using V = value_of<decltype(hh)>;
+            check_level(hh, level);
+            OMG_REQUIRE(level < (int)hh->lv.size() - 1, "use omg_spmv for the coarsest operator");
+            OMG_REQUIRE(x && y, "null vector");
+            auto &L = hh->lv[level];
+            hh->resident = false;
+            load_vec(hh, level, x, L.xp);
+            const bool mf = use_plane(hh, L, 1, 1) && !L.plane->g.jacobi;
+            if (mf) {
+                L.plane->spmv(L.xp, L.tp, hh->stream);
+                fetch_vec<V>(hh, level, L.tp, y);
+            } else {
+                ensure_format(hh, level);
+                RowArgsT<V> a;
+                a.x = L.xp; a.y = L.r.p;
+                launch_rows(L.A, ROW_SPMV, -1, a, hh->stream);
+                fetch_vec<V>(hh, level, L.r.p, y);
+            }
         });
     });
 }

@@ -849,6 +849,57 @@ __global__ __launch_bounds__(MAXT) void plane_kernel(const PlaneKArgs<V> a) {
     if (PEER) peer_done(a.done, gridDim.x, a.peer_flag, a.flag_seq);
 }
 
+// ---- y = A x of a plane level, matrix-free (the "fine-grid SpMV" of BASELINE's metric on the default path) -----------
+// A thread forms one PAIR (h = 2q, 2q + 1) of one colour of one grid line: the row kernels' chain over the seven slots in
+// column order from +0, a neighbour outside the grid a zero value — the bits of rows_*_kernel<ROW_SPMV> on the same
+// operator.  Six 16-byte loads and one store per pair; x is read once from HBM (the neighbours come out of L2).
+template <typename V>
+struct PlaneSpmvArgs {
+    const V *x;
+    V *y;
+    unsigned vec_bytes;
+    int nr, hx, ny, nz, hq;              // first black slot; pairs per half line = (hx + 1) / 2
+    V c0, c1, c2, c3, c4, c5, c6;
+};
+template <typename V>
+__global__ __launch_bounds__(256) void plane_spmv_kernel(const PlaneSpmvArgs<V> a) {
+    const int64_t t = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    const int64_t per_colour = int64_t(a.hq) * a.ny * a.nz;
+    if (t >= 2 * per_colour) return;
+    const int colour = t >= per_colour ? 1 : 0;
+    const int64_t u = t - colour * per_colour;
+    const int q = int(u % a.hq);
+    const int line = int(u / a.hq), j = line % a.ny, k = line / a.ny;
+    const int h = 2 * q;
+    const bool two = h + 1 < a.hx;
+    const int p = (j + k) & 1;
+    const __amdgpu_buffer_rsrc_t xs = __builtin_amdgcn_make_buffer_rsrc(const_cast<V *>(a.x), 0, a.vec_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ys = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, a.vec_bytes, 0x00020000);
+    const int same = colour ? a.nr : 0, other = colour ? 0 : a.nr;
+    const int lb = line * a.hx + h;                              // the pair's place in a colour's run
+    const int ps = a.ny * a.hx;
+    auto pair_at = [&](int base, bool ok) -> P2<V> {
+        P2<V> r = bload2(xs, ok ? (base + lb) * int(sizeof(V)) : OOB, V(0));
+        if (!two) r.y = V(0);
+        return r;
+    };
+    const P2<V> D = pair_at(same, true);
+    const P2<V> Km = pair_at(other - ps, k > 0), Kp = pair_at(other + ps, k + 1 < a.nz);
+    const P2<V> Jm = pair_at(other - a.hx, j > 0), Jp = pair_at(other + a.hx, j + 1 < a.ny);
+    const P2<V> O = pair_at(other, true);
+    // the in-line neighbours (plane.hip, top): rule 0: i - 1 at h - 1, i + 1 at h of the other colour; rule 1: at h, h + 1
+    const int rule = colour ? 1 - p : p;
+    const int nbh = rule ? h + 2 : h - 1;
+    const V nb = bload1(xs, (nbh >= 0 && nbh < a.hx) ? (other + line * a.hx + nbh) * int(sizeof(V)) : OOB, V(0));
+    const Inline<V> n = in_line(rule, O, nb);
+    PlaneKArgs<V> c;                                              // (chain_head / chain_tail take the coefficients from there)
+    c.c0 = a.c0; c.c1 = a.c1; c.c2 = a.c2; c.c3 = a.c3; c.c4 = a.c4; c.c5 = a.c5; c.c6 = a.c6;
+    P2<V> out;
+    out.x = chain_tail(c, chain_head(c, Km.x, Jm.x, n.imx), D.x, n.ipx, Jp.x, Kp.x);
+    out.y = chain_tail(c, chain_head(c, Km.y, Jm.y, n.imy), D.y, n.ipy, Jp.y, Kp.y);
+    bstore2<0>(ys, (same + lb) * int(sizeof(V)), out, two);
+}
+
 // ---- small levels: a block of the grid per workgroup, whole in LDS ----------------------------------------------
 // A level of <= 64^3 cells is pure latency for the marching kernel above: LZ + 4 = 6 dependent steps of one wave each
 // (load round trip, red chain -> black chain -> residual chain, barrier), 12-15 us per pass whatever the size
@@ -1946,6 +1997,21 @@ void PlanePlan<V>::up(const V *x_old, V *x_new, const V *b, const Coarse &c, dou
 #ifdef OMG_PLANE_STAMPS
     stamps_end("up", g, sb, s);
 #endif
+}
+
+template <typename V>
+void PlanePlan<V>::spmv(const V *x, V *y, hipStream_t s) const {
+    OMG_REQUIRE(!g.jacobi && g.z_base == 0 && g.z_end == g.nz, "matrix-free SpMV: whole red-black ordered grids only");
+    PlaneSpmvArgs<V> a;
+    std::memset(&a, 0, sizeof(a));
+    const int64_t n = int64_t(g.nx) * g.ny * g.nz;
+    a.x = x; a.y = y;
+    a.vec_bytes = unsigned(n * int64_t(sizeof(V)));
+    a.nr = int(n / 2); a.hx = g.hx; a.ny = g.ny; a.nz = g.nz; a.hq = (g.hx + 1) / 2;
+    a.c0 = V(g.c[0]); a.c1 = V(g.c[1]); a.c2 = V(g.c[2]); a.c3 = V(g.c[3]); a.c4 = V(g.c[4]); a.c5 = V(g.c[5]); a.c6 = V(g.c[6]);
+    const int64_t threads = 2 * int64_t(a.hq) * g.ny * g.nz;
+    hipLaunchKernelGGL(plane_spmv_kernel<V>, dim3(unsigned((threads + 255) / 256)), dim3(256), 0, s, a);
+    OMG_HIP(hipGetLastError());
 }
 
 template struct PlanePlan<double>;

@@ -150,6 +150,23 @@ def test_device_pointer_cycle_on_a_plane_level(pre, post):
         assert np.array_equal(got, x), (pre, post)
 
 
+@pytest.mark.parametrize("shape", [(16, 16, 16), (8, 12, 20), (10, 8, 6), (12, 20, 34), (4, 4, 4)])
+def test_matrix_free_spmv_of_a_plane_level(shape):
+    """omg_level_spmv on a plane level (plane_spmv_kernel) against the row kernels on the same operator — same bits —
+    and against SciPy's csr_matvec (openmg/tools.py:26)."""
+    A, R = hierarchy(shape, 2, scale=0.77)
+    x = np.random.default_rng(4).standard_normal(A[0].shape[0])
+    for dtype in ("float64", "float32"):
+        xx = x if dtype == "float64" else x.astype(np.float32).astype(np.float64)
+        with _hip.Hierarchy(A, R, smoother="colour", dtype=dtype) as h:
+            assert h.level_flags(0)["plane"]
+            got = h.spmv(0, xx)
+            h.use_plane(False)
+            ref = h.spmv(0, xx)
+        assert np.array_equal(got, ref), (shape, dtype, int(np.sum(got != ref)))
+        np.testing.assert_allclose(got, A[0] @ xx, rtol=1e-13 if dtype == "float64" else 1e-5, atol=1e-12 if dtype == "float64" else 1e-5)
+
+
 def test_parity_ordering_is_the_greedy_colouring(monkeypatch):
     """A level that qualifies gets its red-black ordering in closed form instead of the sequential greedy
     pass; OMG_PLANE_CHECK_ORDER=1 makes the library compare the two (sets, perm, inv) at creation."""
