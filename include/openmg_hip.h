@@ -89,6 +89,18 @@ int omg_hierarchy_create(int n_levels, const omg_csr *A, const omg_csr *R,
 #define OMG_DTYPE_F32 1
 int omg_hierarchy_create_ex(int n_levels, const omg_csr *A, const omg_csr *R, int smoother,
                             double omega, int dtype, omg_hierarchy **out);
+/* replaces: the setup of openmg.mgSolve — operators.restrictionList(problemShape, ...) + operators.coeffecientList(A_in, R)
+ * (openmg/__init__.py:103-109) — and omg_hierarchy_create_ex in ONE call that keeps everything on the device: A_in is
+ * uploaded once, every R[l] is built and every Galerkin product (R A) R^T formed in HBM, every smoothed level is
+ * qualified there for a fused path (plane passes, 2-D tile passes, 27-point kernels; the grid is the caller's
+ * problemShape = shape[0..dim-1], dim 2 or 3, shape[0] == shape[dim-1], extents divisible by 2^n_restrictions), and only
+ * the coarsest operator visits the host (its factorisation).  n_restrictions: len(restrictionList(...)) by the
+ * reference's depth rule (the caller applies it: it needs the shapes only).  If some level does not qualify its operators
+ * are fetched and the hierarchy is built the ordinary way: the same object either way.  The lists mgSolve returns in
+ * infoDict['A'], ['R'] are NOT kept: a caller with giveInfo takes the ordinary route.                                  */
+int omg_hierarchy_create_from_fine(const omg_csr *A_in, int dim, const int64_t *shape, int n_restrictions, int smoother, double omega,
+                                   int dtype, omg_hierarchy **out);
+
 int omg_hierarchy_dtype(const omg_hierarchy *h, int *dtype);
 int omg_hierarchy_destroy(omg_hierarchy *h);
 /* Run on a caller-owned hipStream_t instead of the hierarchy's own stream (NULL = own). */

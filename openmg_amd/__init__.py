@@ -150,17 +150,25 @@ def mgSolve(A_in, b, parameters):
     dense = parameters["dense"]
     code, omega = _smoother_of(parameters)
 
-    R = operators.restrictionList(problemShape, parameters["coarsestLevel"], parameters["minSize"],
-                                  dense=dense, verbose=verbose)
-    parameters["coarsestLevel"] = len(R)
-    A = operators.coeffecientList(A_in, R, dense=dense, verbose=verbose)
-
     pre, post = parameters["preIterations"], parameters["postIterations"]
-    hierarchy = _hip.Hierarchy(A, R, smoother=code, omega=omega, dtype=_dtype_of(parameters))
+    n_fused = _device_setup_depth(A_in, problemShape, parameters)
+    if n_fused:
+        # nobody asked for the operator lists (giveInfo off): restrictions, Galerkin products and the levels' qualification
+        # for the fused paths stay in HBM (omg_hierarchy_create_from_fine); same hierarchy, same results
+        R = A = None
+        parameters["coarsestLevel"] = n_fused
+        hierarchy = _hip.Hierarchy.from_fine(A_in, problemShape, n_fused, smoother=code, omega=omega, dtype=_dtype_of(parameters))
+    else:
+        R = operators.restrictionList(problemShape, parameters["coarsestLevel"], parameters["minSize"],
+                                      dense=dense, verbose=verbose)
+        parameters["coarsestLevel"] = len(R)
+        A = operators.coeffecientList(A_in, R, dense=dense, verbose=verbose)
+        hierarchy = _hip.Hierarchy(A, R, smoother=code, omega=omega, dtype=_dtype_of(parameters))
+    depth = parameters["coarsestLevel"]
     try:
         hierarchy.resident_load(np.asarray(b, dtype=np.float64).reshape(-1))
         if verbose:
-            _announce_descent(len(R))
+            _announce_descent(depth)
         norm = hierarchy.resident_cycle(pre, post)
         cycle = 1
         if verbose:
@@ -181,7 +189,7 @@ def mgSolve(A_in, b, parameters):
         while not finished():
             if verbose:
                 print("cycle %i < cycles %i" % (cycle, parameters["cycles"]))
-                _announce_descent(len(R))
+                _announce_descent(depth)
             cycle += 1
             norm = hierarchy.resident_cycle(pre, post)
             if verbose:
@@ -196,6 +204,44 @@ def mgSolve(A_in, b, parameters):
     if parameters["giveInfo"]:
         return result, infoDict
     return result
+
+
+def _device_setup_depth(A_in, problemShape, parameters):
+    """How many restrictions operators.restrictionList would build (openmg/operators.py:128-141) when mgSolve's whole
+    setup can stay on the device — 0 when it cannot: the caller wants the lists (giveInfo), the dense path, progress
+    messages, or the shape is not one whose restriction is the plain aggregation at every level (2-D / 3-D, first and
+    last extent equal, extents even on every restricted level) — then the ordinary route runs (and raises what the
+    reference raises)."""
+    if parameters.get("giveInfo") or parameters.get("dense") or parameters.get("verbose") or not sp.issparse(A_in):
+        return 0
+    try:
+        shape = tuple(int(s) for s in problemShape)
+    except TypeError:
+        return 0
+    dim = len(shape)
+    if dim not in (2, 3) or shape[0] != shape[-1] or min(shape) < 2:
+        return 0
+    if int(np.prod(shape)) != A_in.shape[0] or A_in.shape[0] != A_in.shape[1]:
+        return 0
+
+    def rows_of(level):                 # rows of restriction(shape // 2**level), or None where the reference's quirks start
+        ext = [s // 2 ** level for s in shape]
+        if any(e < 2 or e % 2 for e in ext):
+            return None
+        return int(np.prod(ext)) // 2 ** dim
+
+    first = rows_of(0)
+    if first is None or first in (0, 1):
+        return 0
+    n = 1
+    for level in range(1, parameters["coarsestLevel"] + 1):
+        rows = rows_of(level)
+        if rows is None or rows in (0, 1):
+            return 0                    # (the reference raises or truncates here: let the ordinary route do that)
+        if rows <= parameters["minSize"]:
+            break
+        n += 1
+    return n
 
 
 def _announce_descent(depth):

@@ -57,6 +57,7 @@ SIGNATURES = {
     "omg_set_device": (_I, [_I]),
     "omg_hierarchy_create": (_I, [_I, _CSR, _CSR, _I, _D, _PP]),
     "omg_hierarchy_create_ex": (_I, [_I, _CSR, _CSR, _I, _D, _I, _PP]),
+    "omg_hierarchy_create_from_fine": (_I, [_CSR, _I, _I64P, _I, _I, _D, _I, _PP]),
     "omg_hierarchy_dtype": (_I, [_P, _IP]),
     "omg_hierarchy_destroy": (_I, [_P]),
     "omg_hierarchy_set_stream": (_I, [_P, _P]),
@@ -275,6 +276,27 @@ class Hierarchy:
         self._h = h
         # the device copy is complete; the host copies are only kept for .sizes
         self._A = self._R = None
+
+    @classmethod
+    def from_fine(cls, A_in, shape, n_restrictions, smoother="gs", omega=1.0, dtype="float64"):
+        """mgSolve's setup on the device (omg_hierarchy_create_from_fine): restrictions, Galerkin products and the
+        qualification of the levels all in HBM; len(sizes) = n_restrictions + 1."""
+        self = cls.__new__(cls)
+        A0 = as_csr(A_in)
+        shape = tuple(int(s) for s in shape)
+        arr = (ctypes.c_int64 * len(shape))(*shape)
+        self.smoother = smoother_code(smoother)
+        self.omega = float(omega)
+        self.dtype = dtype_code(dtype)
+        self.n_levels = int(n_restrictions) + 1
+        self.sizes = [A0.shape[0] // (2 ** len(shape)) ** l for l in range(self.n_levels)]
+        h = ctypes.c_void_p()
+        v = csr_view(A0)
+        check(lib().omg_hierarchy_create_from_fine(ctypes.byref(v), len(shape), arr, int(n_restrictions), self.smoother, self.omega,
+                                                   self.dtype, ctypes.byref(h)))
+        self._h = h
+        self._A = self._R = None
+        return self
 
     def close(self):
         if getattr(self, "_h", None):

@@ -130,7 +130,14 @@ struct Ordering {
     std::vector<int32_t> perm, inv;
     std::vector<int64_t> sets;
     bool identity = true;
+    // A closed-form ordering of an nx x ny x nz grid whose host arrays have not been written (setup on the device):
+    // 2 = red-black by parity (plane levels), 8 = octants (27-point levels); materialise_ordering() fills perm / inv
+    int closed_form = 0, cf_nx = 0, cf_ny = 0, cf_nz = 0;
 };
+void materialise_ordering(Ordering &ord);                     // (setup_host.cpp) no-op unless perm / inv are pending
+// perm (slot -> natural row) of a closed-form ordering, and for a coarse level with such an ordering the map natural
+// index -> slot, written on the device (setup_device.hip)
+void fill_ordering_device(int kind, int nx, int ny, int nz, int32_t *perm, int32_t *inv, hipStream_t s);
 
 // setup_host.cpp
 // Touch every page of a freshly allocated host buffer that is about to RECEIVE a large device-to-host copy, on many
@@ -488,6 +495,21 @@ struct MarchPlan {
     bool timed_out(hipStream_t s) const;                 // (synchronises) some sweep gave up waiting for a face
 };
 
+// ---- setup that stays on the device (round 4: omg_hierarchy_create_from_fine) -----------------------------------
+// A plain device CSR (double values, natural numbering): what the Galerkin chain leaves per level.
+struct DevCsrPlain {
+    int64_t n_rows = 0, n_cols = 0, nnz = 0;
+    DevBuf<int32_t> indptr, indices;
+    DevBuf<double> data;
+};
+// operators.restrictionList + coeffecientList (openmg/operators.py:92-141, 144-188) without the host in between: A[0] =
+// the caller's operator uploaded once, R[l] built on the device (omg_restriction's kernel), A[l + 1] = (R[l] A[l]) R[l]^T
+// by omg_rap's kernels, everything left in HBM.  n_restrictions operators R are made (the caller has applied the
+// reference's depth rule).  (setup_device.hip)
+void galerkin_chain_device(const omg_csr &A0, int dim, const int64_t *shape, int n_restrictions, std::vector<DevCsrPlain> &A,
+                           std::vector<DevCsrPlain> &R, hipStream_t s);
+HostCsr download_csr(const DevCsrPlain &M, hipStream_t s);
+
 // Is R the plain 2 x 2 x 2 aggregation of an nx x ny x nz grid (openmg/operators.py:73-84: eight entries per coarse
 // cell in (dk, dj, di) order, ONE weight, ascending columns)?  w: that weight.  Host scan on many threads.
 bool is_plain_aggregation(const omg_csr &R, int64_t nx, int64_t ny, int64_t nz, double &w);   // (stencil27.hip)
@@ -543,6 +565,11 @@ struct PlanePlan {
     // sequential pass over the rows).
     // jacobi: the level is smoothed with weighted Jacobi (2-D levels only): natural ordering, one set.
     bool build(const omg_csr &A, const omg_csr &R, Ordering &ord, bool jacobi = false, double omega = 1.0);
+    // The same qualification for an operator that is already in HBM, on a grid the caller knows (nz = 1: 2-D), restricted by
+    // the plain aggregation with weight w: the rows are checked by a kernel.  ord gets its sets only (perm / inv empty:
+    // Ordering::parity_pending; the device copies of perm and of the coarse slot map are made by fill_parity_maps).
+    bool build_device(const DevCsrPlain &A, int nx, int ny, int nz, double w, Ordering &ord, bool jacobi, double omega, hipStream_t s);
+    bool finish_geometry(int64_t nx, int64_t ny, int64_t nz, const double (&c)[7], double w, bool jacobi, double omega);
     // y = A x of the whole level (colour-ordered vectors), matrix-free; the bits of the row kernels' SpMV
     void spmv(const V *x, V *y, hipStream_t s) const;
     // The operator and the restriction the plan stands for, as the caller's CSR had them (natural numbering,
@@ -649,6 +676,8 @@ struct Stencil27Plan {
     bool have67 = false;              // res67 / segment 3 belong to the current iterate
     // false: the level does not qualify (ord untouched).  A, R: the caller's CSR in natural numbering.
     bool build(const omg_csr &A, const omg_csr &R, Ordering &ord, hipStream_t s);
+    // ... for an operator already in HBM on a known grid, restricted by the plain aggregation with weight w
+    bool build_device(const DevCsrPlain &A, int nx, int ny, int nz, double w, Ordering &ord, hipStream_t s);
     // One sweep x_old -> x_new.  x_zero: x_old is zero and is not read.  norm_old (nullable: 4 n_wg doubles): also
     // the squares of b - A x_old.  last: leave the residuals of colours 6, 7 (res67) and, with norm_new (nullable,
     // same shape; only segment 3 is written), their squares.

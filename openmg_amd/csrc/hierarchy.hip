@@ -755,6 +755,8 @@ void ensure_format(Hier<V> *h, int l) {
     if (l < 0 || l >= (int)h->lv.size() || !h->lv[l].format_pending) return;
     Level<V> &L = h->lv[l];
     SetupTimer tm("plane / 27-point level: row-kernel format on first use");
+    materialise_ordering(L.ord);                                   // (a hierarchy set up on the device keeps its closed-form
+    if (l + 1 < (int)h->lv.size()) materialise_ordering(h->lv[l + 1].ord);   //  orderings as device arrays only until here)
     // (a 27-point level: from the operator PADDED to 27 entries per row, so that the row kernels associate every row's
     // sum as the kernels of stencil27.hip do)
     const HostCsr A = L.s27 ? L.s27->operator_csr(h->stream) : L.plane->operator_csr();
@@ -909,6 +911,149 @@ std::unique_ptr<Hier<V>> create(int n_levels, const omg_csr *A, const omg_csr *R
     return h;
 }
 
+// mgSolve's setup (openmg/__init__.py:103-109) without the host in between: restrictionList + coeffecientList on the
+// device (galerkin_chain_device), every smoothed level qualified THERE for a fused path (plane passes / 2-D tile passes /
+// 27-point kernels) — the grid is the caller's problemShape —, orderings and slot maps written by kernels.  What comes
+// back to the host: the coarsest operator (a few thousand entries) for its factorisation.  A hierarchy with a level
+// that does not qualify takes the ordinary route (its operators are fetched once): the result is the same object.
+template <typename V>
+std::unique_ptr<Hier<V>> create_from_fine(const omg_csr &A0, int dim, const int64_t *shape, int n_restrictions, int smoother, double omega) {
+    using H = Hier<V>;
+    using Lv = Level<V>;
+    OMG_REQUIRE(dim >= 2 && dim <= 3 && shape && n_restrictions >= 1, "device setup: 2-D / 3-D grids, at least one restriction");
+    OMG_REQUIRE(smoother >= OMG_SMOOTH_GS_LEX && smoother <= OMG_SMOOTH_JACOBI, "unknown smoother");
+    validate_csr(A0, "A_in");
+    OMG_REQUIRE(A0.n_rows == A0.n_cols, "A_in must be square");
+    // the reference's restriction is the plain aggregation when its quirky second-axis offset shape[0] (Q6) equals the
+    // true one: first and last extent equal
+    OMG_REQUIRE(shape[0] == shape[dim - 1], "device setup: first and last extent must be equal");
+    require_device();
+    std::unique_ptr<H> h(new H);
+    h->smoother = smoother;
+    h->omega = omega;
+    OMG_HIP(hipStreamCreateWithFlags(&h->own, hipStreamNonBlocking));
+    h->stream = h->own;
+    h->norm_dev.alloc(1);
+    std::vector<DevCsrPlain> dA, dR;
+    galerkin_chain_device(A0, dim, shape, n_restrictions, dA, dR, h->stream);
+    const int n_levels = n_restrictions + 1;
+    h->lv.resize(size_t(n_levels));
+    const double w = 1.0 / double(1 << dim);
+    auto dims = [&](int l, int &nx, int &ny, int &nz) {
+        nx = int(shape[dim - 1] >> l);
+        ny = int(shape[dim - 2] >> l);
+        nz = dim == 3 ? int(shape[0] >> l) : 1;
+    };
+    bool all = smoother == OMG_SMOOTH_GS_COLOUR || (smoother == OMG_SMOOTH_JACOBI && dim == 2);
+    for (int l = 0; all && l + 1 < n_levels; ++l) {
+        Lv &L = h->lv[size_t(l)];
+        L.n = dA[size_t(l)].n_rows;
+        int nx, ny, nz;
+        dims(l, nx, ny, nz);
+        SetupTimer tp("device setup: does the level qualify for a fused path");
+        std::unique_ptr<PlanePlan<V>> plan(new PlanePlan<V>);
+        if (plan->build_device(dA[size_t(l)], nx, ny, nz, w, L.ord, smoother == OMG_SMOOTH_JACOBI, omega, h->stream)) {
+            if (!h->plane_status.p) { h->plane_status.alloc(1); h->plane_status.zero(h->stream); }
+            plan->status = h->plane_status.p;
+            L.plane = std::move(plan);
+            continue;
+        }
+        std::unique_ptr<Stencil27Plan<V>> s27(new Stencil27Plan<V>);
+        if (smoother == OMG_SMOOTH_GS_COLOUR && dim == 3 && s27->build_device(dA[size_t(l)], nx, ny, nz, w, L.ord, h->stream)) {
+            L.s27 = std::move(s27);
+            continue;
+        }
+        all = false;
+    }
+    if (!all) {
+        // some level needs the host's orderings and codings: fetch the operators once, then the ordinary route
+        SetupTimer tm("device setup: a level does not qualify: operators fetched, ordinary route");
+        std::vector<HostCsr> hA, hR;
+        for (auto &M : dA) hA.push_back(download_csr(M, h->stream));
+        for (auto &M : dR) hR.push_back(download_csr(M, h->stream));
+        dA.clear();
+        dR.clear();
+        std::vector<omg_csr> vA, vR;
+        for (auto &M : hA) vA.push_back(view(M));
+        for (auto &M : hR) vR.push_back(view(M));
+        h.reset();
+        return create<V>(n_levels, vA.data(), vR.data(), smoother, omega);
+    }
+    // the coarsest operator: to the host for its factorisation (helper thread, as in create())
+    int device = 0;
+    OMG_HIP(hipGetDevice(&device));
+    HostCsr Ac = download_csr(dA.back(), h->stream);
+    {
+        Lv &L = h->lv.back();
+        L.n = Ac.n_rows;
+        L.ord.identity = true;
+        L.ord.sets = {0, L.n};
+    }
+    check_diagonal(view(Ac), n_levels - 1);
+    int inv_code = OMG_OK;
+    std::string inv_msg;
+    std::thread inverter([&] {
+        hipStream_t s = nullptr;
+        SetupTimer tm("coarse factorisation (helper thread)");
+        try {
+            OMG_HIP(hipSetDevice(device));
+            OMG_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+            Lv &L = h->lv.back();
+            L.A.upload(Ac, L.ord.sets, s);
+            h->coarse.build(Ac, s);
+        } catch (const Error &e) {
+            inv_code = e.code;
+            inv_msg = e.what();
+        } catch (const std::exception &e) {
+            inv_code = OMG_ERR_HIP;
+            inv_msg = e.what();
+        }
+        if (s) { (void)hipStreamSynchronize(s); (void)hipStreamDestroy(s); }
+    });
+    struct Joiner { std::thread &t; ~Joiner() { if (t.joinable()) t.join(); } } joiner{inverter};
+    dA.clear();                                                    // (the fused paths hold what they need of the operators)
+    dR.clear();
+    for (int l = 0; l < n_levels; ++l) {
+        Lv &L = h->lv[size_t(l)];
+        if (!L.ord.identity) {
+            // slot -> natural row, for the gathers at the host boundary: written by a kernel
+            L.perm.alloc(L.n);
+            fill_ordering_device(L.ord.closed_form, L.ord.cf_nx, L.ord.cf_ny, L.ord.cf_nz, L.perm.p, nullptr, h->stream);
+        }
+        if (l + 1 < n_levels) {
+            const Ordering &co = h->lv[size_t(l) + 1].ord;
+            if (!co.identity) {
+                L.r_out.alloc(size_t(h->lv[size_t(l) + 1].n));
+                fill_ordering_device(co.closed_form, co.cf_nx, co.cf_ny, co.cf_nz, nullptr, L.r_out.p, h->stream);
+            }
+            if (L.plane) L.tmp.alloc(L.n, vector_stagger(1));
+            if (L.s27) L.tmp.alloc(L.n);
+            L.format_pending = true;
+        }
+        L.x.alloc(std::max<int64_t>(L.n, 1));
+        L.b.alloc(std::max<int64_t>(L.n, 1), L.plane ? vector_stagger(2) : 0);
+        L.xp = L.x.p;
+        L.tp = L.tmp.p;
+    }
+    OMG_HIP(hipStreamSynchronize(h->stream));
+    for (int l = 0; l + 1 < n_levels; ++l) {
+        if (!h->lv[size_t(l)].plane || !h->lv[size_t(l)].tmp.p) continue;
+        SetupTimer tm("plane tiling of a large level");
+        Level<V> &L = h->lv[size_t(l)], &C = h->lv[size_t(l) + 1];
+        L.x.zero(h->stream); L.tmp.zero(h->stream); L.b.zero(h->stream); C.x.zero(h->stream);
+        typename PlanePlan<V>::Coarse c;
+        c.map = L.r_out.p;
+        c.b = C.b.p;
+        c.e = C.xp;
+        L.plane->tune(L.xp, L.tp, L.b.p, c, h->stream, l == 0);
+        OMG_HIP(hipStreamSynchronize(h->stream));
+    }
+    { SetupTimer tm("wait for the coarse factorisation"); inverter.join(); }
+    if (inv_code != OMG_OK) throw Error(inv_code, inv_msg);
+    OMG_HIP(hipStreamSynchronize(h->stream));
+    return h;
+}
+
 // A throw-away single operator for the standalone entry points.
 struct OneShot {
     DevCsr A;
@@ -991,6 +1136,19 @@ int omg_hierarchy_create_ex(int n_levels, const omg_csr *A, const omg_csr *R, in
 int omg_hierarchy_create(int n_levels, const omg_csr *A, const omg_csr *R, int smoother,
                          double omega, omg_hierarchy **out) {
     return omg_hierarchy_create_ex(n_levels, A, R, smoother, omega, OMG_DTYPE_F64, out);
+}
+
+int omg_hierarchy_create_from_fine(const omg_csr *A_in, int dim, const int64_t *shape, int n_restrictions, int smoother, double omega,
+                                   int dtype, omg_hierarchy **out) {
+    return guarded([&] {
+        OMG_REQUIRE(out && A_in, "null argument");
+        *out = nullptr;
+        OMG_REQUIRE(dtype == OMG_DTYPE_F64 || dtype == OMG_DTYPE_F32, "unknown dtype");
+        std::unique_ptr<omg_hierarchy> h(new omg_hierarchy);
+        if (dtype == OMG_DTYPE_F32) h->f = create_from_fine<float>(*A_in, dim, shape, n_restrictions, smoother, omega);
+        else h->d = create_from_fine<double>(*A_in, dim, shape, n_restrictions, smoother, omega);
+        *out = h.release();
+    });
 }
 
 int omg_hierarchy_dtype(const omg_hierarchy *h, int *dtype) {

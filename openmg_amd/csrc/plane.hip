@@ -1516,6 +1516,13 @@ bool PlanePlan<V>::build(const omg_csr &A, const omg_csr &R, Ordering &ord, bool
         for (auto &q : th) q.join();
     }
     }
+    return finish_geometry(nx, ny, nz, c, w, jacobi, omega);
+}
+
+// the plan of a whole nx x ny x nz grid (nz = 1: 2-D) with these coefficients
+template <typename V>
+bool PlanePlan<V>::finish_geometry(int64_t nx, int64_t ny, int64_t nz, const double (&c)[7], double w, bool jacobi, double omega) {
+    const bool dim2 = nz == 1;
     // (a float level holds the rounded coefficients: every entry with one value rounds to one value)
     g = PlaneGeom();
     g.nx = (int)nx; g.ny = (int)ny; g.nz = (int)nz; g.hx = (int)(nx / 2);
@@ -1534,6 +1541,104 @@ bool PlanePlan<V>::build(const omg_csr &A, const omg_csr &R, Ordering &ord, bool
     }
     partials.alloc(size_t(g.n_wg) + SUM_FOLD);
     return true;
+}
+
+namespace {
+// every row of a device CSR: exactly its in-grid neighbours of the 5 / 7-point stencil in slot order with the level's
+// ONE coefficient per slot?  err: 0, or 1 + the smallest offending row
+__global__ __launch_bounds__(256) void plane_check_kernel(const int32_t *indptr, const int32_t *indices, const double *data, int nx, int ny, int nz,
+                                                          double c0, double c1, double c2, double c3, double c4, double c5, double c6,
+                                                          unsigned long long *err) {
+    const int64_t n = int64_t(nx) * ny * nz, sj = nx, sk = int64_t(nx) * ny;
+    const int64_t r = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    if (r >= n) return;
+    const int64_t i = r % nx, j = (r / nx) % ny, k = r / sk;
+    const bool present[7] = {k > 0, j > 0, i > 0, true, i + 1 < nx, j + 1 < ny, k + 1 < nz};
+    const int64_t off[7] = {-sk, -sj, -1, 0, 1, sj, sk};
+    const double c[7] = {c0, c1, c2, c3, c4, c5, c6};
+    int64_t p = indptr[r];
+    const int64_t pe = indptr[r + 1];
+    bool bad = false;
+    for (int e = 0; e < 7; ++e) {
+        if (!present[e]) continue;
+        if (p >= pe || int64_t(indices[p]) != r + off[e] || data[p] != c[e]) { bad = true; break; }
+        ++p;
+    }
+    if (bad || p != pe) atomicMin(err, (unsigned long long)(r + 1));
+}
+}  // namespace
+
+template <typename V>
+bool PlanePlan<V>::build_device(const DevCsrPlain &A, int nx, int ny, int nz, double w, Ordering &ord, bool jacobi, double omega, hipStream_t s) {
+    {
+        const char *e = getenv("OMG_PLANE");
+        if (e && e[0] == '0') return false;
+    }
+    const int64_t n = int64_t(nx) * ny * nz;
+    const bool dim2 = nz == 1;
+    if (n < 8 || n != A.n_rows || n != A.n_cols || uint64_t(n) * sizeof(V) >= (uint64_t(1) << 31)) return false;
+    if ((nx & 1) || (ny & 1) || (!dim2 && (nz & 1)) || ny < 2) return false;
+    if (jacobi && !dim2) return false;
+    {
+        const char *e = getenv("OMG_PLANE_2D");
+        if (dim2 && e && e[0] == '0') return false;
+    }
+    const int64_t want = dim2 ? 5 * n - 2 * nx - 2 * ny : 7 * n - 2 * (int64_t(nx) * ny + int64_t(ny) * nz + int64_t(nx) * nz);
+    if (A.nnz != want) return false;
+    // the coefficients: from cell (1, 1, 1) (an interior row when every extent is >= 3), the first and the last row
+    const int64_t sj = nx, sk = int64_t(nx) * ny;
+    bool havec[7] = {false, false, false, false, false, false, false};
+    double c[7] = {0, 0, 0, 0, 0, 0, 0};
+    const int64_t probe = std::min<int64_t>(n - 1, sk + sj + 1);
+    for (int64_t r : {probe, int64_t(0), n - 1}) {
+        int32_t pp[2];
+        OMG_HIP(hipMemcpyAsync(pp, A.indptr.p + r, sizeof(pp), hipMemcpyDeviceToHost, s));
+        OMG_HIP(hipStreamSynchronize(s));
+        const int len = pp[1] - pp[0];
+        if (len < 1 || len > 7) return false;
+        int32_t idx[7];
+        double val[7];
+        OMG_HIP(hipMemcpyAsync(idx, A.indices.p + pp[0], size_t(len) * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+        OMG_HIP(hipMemcpyAsync(val, A.data.p + pp[0], size_t(len) * sizeof(double), hipMemcpyDeviceToHost, s));
+        OMG_HIP(hipStreamSynchronize(s));
+        const int64_t i = r % nx, jl = (r / nx) % ny, kl = r / sk;
+        for (int q = 0; q < len; ++q) {
+            const int64_t off = int64_t(idx[q]) - r;
+            int sl = -1;
+            if (off == 0) sl = 3;
+            else if (off == -1 && i > 0) sl = 2;
+            else if (off == 1 && i + 1 < nx) sl = 4;
+            else if (off == -sj && jl > 0) sl = 1;
+            else if (off == sj && jl + 1 < ny) sl = 5;
+            else if (off == -sk && kl > 0) sl = 0;
+            else if (off == sk && kl + 1 < nz) sl = 6;
+            if (sl < 0) return false;
+            if (!havec[sl]) { havec[sl] = true; c[sl] = val[q]; }
+        }
+    }
+    if (dim2) havec[0] = havec[6] = true;
+    for (int e = 0; e < 7; ++e)
+        if (!havec[e]) return false;
+    if (!(std::fabs(c[3]) > 0.0) || !std::isfinite(c[3])) return false;
+    DevBuf<unsigned long long> d_err(1);
+    OMG_HIP(hipMemsetAsync(d_err.p, 0xFF, sizeof(unsigned long long), s));
+    hipLaunchKernelGGL(plane_check_kernel, dim3(unsigned((n + 255) / 256)), dim3(256), 0, s, A.indptr.p, A.indices.p, A.data.p, nx, ny, nz,
+                       c[0], c[1], c[2], c[3], c[4], c[5], c[6], d_err.p);
+    OMG_HIP(hipGetLastError());
+    unsigned long long err = 0;
+    OMG_HIP(hipMemcpyAsync(&err, d_err.p, sizeof(err), hipMemcpyDeviceToHost, s));
+    OMG_HIP(hipStreamSynchronize(s));
+    if (err != ~0ull) return false;
+    ord = Ordering();
+    if (jacobi) {
+        ord.identity = true;
+        ord.sets = {0, n};
+    } else {
+        ord.identity = false;
+        ord.sets = {0, n / 2, n};
+        ord.closed_form = 2; ord.cf_nx = nx; ord.cf_ny = ny; ord.cf_nz = nz;     // perm / inv: on the device (fill_ordering_device), on the host on demand
+    }
+    return finish_geometry(nx, ny, nz, c, w, jacobi, omega);
 }
 
 template <typename V>

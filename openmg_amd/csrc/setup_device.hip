@@ -25,11 +25,7 @@ struct omg_csr_result {
 
 namespace {
 
-struct DevMat {            // plain device CSR without row blocks
-    int64_t n_rows = 0, n_cols = 0, nnz = 0;
-    DevBuf<int32_t> indptr, indices;
-    DevBuf<double> data;
-};
+typedef DevCsrPlain DevMat;   // plain device CSR without row blocks (common.h)
 
 void upload(DevMat &M, const omg_csr &A, hipStream_t s) {
     M.n_rows = A.n_rows; M.n_cols = A.n_cols; M.nnz = A.nnz;
@@ -549,6 +545,91 @@ __global__ void restriction_kernel(int dim, int64_t s0, int64_t s1, int64_t s2, 
         }
     }
 }
+
+// perm[slot] = natural row, inv[row] = slot of a closed-form ordering (either pointer may be null)
+__global__ void ordering_fill_kernel(int kind, int nx, int ny, int nz, int32_t *perm, int32_t *inv) {
+    const int64_t n = int64_t(nx) * ny * nz;
+    for (int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r < n; r += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t i = r % nx, j = (r / nx) % ny, k = r / (int64_t(nx) * ny);
+        int64_t slot;
+        if (kind == 2) {
+            slot = (((i + j + k) & 1) ? n / 2 : 0) + r / 2;
+        } else {
+            const int64_t c = (i & 1) | ((j & 1) << 1) | ((k & 1) << 2), na = n / 8;
+            slot = c * na + ((k >> 1) * (ny / 2) + (j >> 1)) * (nx / 2) + (i >> 1);
+        }
+        if (inv) inv[r] = int32_t(slot);
+        if (perm) perm[slot] = int32_t(r);
+    }
+}
+
+}  // namespace
+
+namespace omg {
+
+void fill_ordering_device(int kind, int nx, int ny, int nz, int32_t *perm, int32_t *inv, hipStream_t s) {
+    const int64_t n = int64_t(nx) * ny * nz;
+    hipLaunchKernelGGL(ordering_fill_kernel, dim3(grid1d(n)), dim3(256), 0, s, kind, nx, ny, nz, perm, inv);
+    OMG_HIP(hipGetLastError());
+}
+
+HostCsr download_csr(const DevCsrPlain &M, hipStream_t s) {
+    HostCsr H;
+    H.n_rows = M.n_rows; H.n_cols = M.n_cols; H.nnz = M.nnz;
+    H.indptr.resize(size_t(M.n_rows) + 1);
+    H.indices.resize(size_t(M.nnz));
+    H.data.resize(size_t(M.nnz));
+    download_staged(H.indptr.data(), M.indptr.p, (size_t(M.n_rows) + 1) * sizeof(int32_t), s);
+    download_staged(H.indices.data(), M.indices.p, size_t(M.nnz) * sizeof(int32_t), s);
+    download_staged(H.data.data(), M.data.p, size_t(M.nnz) * sizeof(double), s);
+    return H;
+}
+
+void galerkin_chain_device(const omg_csr &A0, int dim, const int64_t *shape, int n_restrictions, std::vector<DevCsrPlain> &A,
+                           std::vector<DevCsrPlain> &R, hipStream_t s) {
+    OMG_REQUIRE(dim >= 1 && dim <= 3 && n_restrictions >= 1, "bad argument");
+    A.clear();
+    R.clear();
+    A.resize(size_t(n_restrictions) + 1);
+    R.resize(size_t(n_restrictions));
+    { SetupTimer tm("device setup: upload the fine operator"); upload(A[0], A0, s); OMG_HIP(hipStreamSynchronize(s)); }
+    int64_t ext[3] = {1, 1, 1};
+    for (int d = 0; d < dim; ++d) ext[d] = shape[d];
+    for (int l = 0; l < n_restrictions; ++l) {
+        int64_t N = 1;
+        for (int d = 0; d < dim; ++d) {
+            OMG_REQUIRE(ext[d] >= 2 && !(ext[d] & 1), "device setup needs even extents on every level");
+            N *= ext[d];
+        }
+        OMG_REQUIRE(N == A[size_t(l)].n_rows, "problemShape does not match the operator");
+        const int per = 1 << dim;
+        const int64_t rows = N / per;
+        DevCsrPlain &Rl = R[size_t(l)];
+        Rl.n_rows = rows; Rl.n_cols = N; Rl.nnz = N;
+        Rl.indptr.alloc(size_t(rows) + 1);
+        Rl.indices.alloc(size_t(N));
+        Rl.data.alloc(size_t(N));
+        hipLaunchKernelGGL(restriction_kernel, dim3(grid1d(rows + 1)), dim3(256), 0, s, dim, ext[0], dim >= 2 ? ext[1] : 1, dim >= 3 ? ext[2] : 1,
+                           rows, Rl.indptr.p, Rl.indices.p, Rl.data.p);
+        OMG_HIP(hipGetLastError());
+        SetupTimer tm("device setup: Galerkin product of a level");
+        omg_csr_result C;
+        if (!rap_aggregation(Rl, A[size_t(l)], C, s)) {
+            DevMat Rt, RA;
+            device_transpose(Rl, Rt, s);
+            omg_csr_result T;
+            spgemm(Rl, A[size_t(l)], T, s);
+            as_devmat(std::move(T), RA);
+            spgemm(RA, Rt, C, s);
+        }
+        as_devmat(std::move(C), A[size_t(l) + 1]);
+        for (int d = 0; d < dim; ++d) ext[d] /= 2;
+    }
+}
+
+}  // namespace omg
+
+namespace {
 
 template <typename F>
 int guarded(F &&f) {

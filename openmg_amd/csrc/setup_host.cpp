@@ -894,6 +894,31 @@ uint64_t chunk_hash(const unsigned char *p, size_t n, uint64_t seed) {
 }
 }  // namespace
 
+void materialise_ordering(Ordering &ord) {
+    if (!ord.closed_form || !ord.perm.empty()) return;
+    const int64_t nx = ord.cf_nx, ny = ord.cf_ny, nz = ord.cf_nz, n = nx * ny * nz;
+    ord.perm.resize(size_t(n));
+    ord.inv.resize(size_t(n));
+    const unsigned hw = std::max(1u, std::min(64u, std::thread::hardware_concurrency()));
+    const int nt = (int)std::min<int64_t>(hw, std::max<int64_t>(1, n / 65536));
+    const int kind = ord.closed_form;
+    auto fill = [&](int tnum) {
+        const int64_t lo = n * tnum / nt, hi = n * (tnum + 1) / nt;
+        for (int64_t r = lo; r < hi; ++r) {
+            const int64_t i = r % nx, j = (r / nx) % ny, k = r / (nx * ny);
+            int64_t slot;
+            if (kind == 2) slot = (((i + j + k) & 1) ? n / 2 : 0) + r / 2;
+            else slot = ((i & 1) | ((j & 1) << 1) | ((k & 1) << 2)) * (n / 8) + ((k >> 1) * (ny / 2) + (j >> 1)) * (nx / 2) + (i >> 1);
+            ord.inv[size_t(r)] = int32_t(slot);
+            ord.perm[size_t(slot)] = int32_t(r);
+        }
+    };
+    std::vector<std::thread> th;
+    for (int tnum = 1; tnum < nt; ++tnum) th.emplace_back(fill, tnum);
+    fill(0);
+    for (auto &q : th) q.join();
+}
+
 void prefault_host(void *p, size_t bytes) {
     if (bytes < (size_t(8) << 20)) return;
     volatile unsigned char *c = static_cast<volatile unsigned char *>(p);

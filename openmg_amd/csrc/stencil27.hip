@@ -694,6 +694,34 @@ bool Stencil27Plan<V>::build(const omg_csr &A, const omg_csr &R, Ordering &ord, 
     if (!has(nx * ny + nx + 1, 0)) return false;
     double w = 0.0;
     if (!is_plain_aggregation(R, nx, ny, nz, w)) return false;
+    // the operator onto the device as it is, every row checked and scattered into the tiles there
+    require_device();
+    DevCsrPlain D;
+    {
+        SetupTimer tm("27-point level: upload CSR");
+        D.n_rows = D.n_cols = n; D.nnz = A.nnz;
+        D.indptr.alloc(size_t(n) + 1);
+        D.indices.alloc(size_t(std::max<int64_t>(A.nnz, 1)));
+        D.data.alloc(size_t(std::max<int64_t>(A.nnz, 1)));
+        OMG_HIP(hipMemcpyAsync(D.indptr.p, A.indptr, (size_t(n) + 1) * sizeof(int32_t), hipMemcpyHostToDevice, s));
+        OMG_HIP(hipMemcpyAsync(D.indices.p, A.indices, size_t(A.nnz) * sizeof(int32_t), hipMemcpyHostToDevice, s));
+        OMG_HIP(hipMemcpyAsync(D.data.p, A.data, size_t(A.nnz) * sizeof(double), hipMemcpyHostToDevice, s));
+        OMG_HIP(hipStreamSynchronize(s));
+    }
+    if (!build_device(D, int(nx), int(ny), int(nz), w, ord, s)) return false;
+    materialise_ordering(ord);
+    return true;
+}
+
+template <typename V>
+bool Stencil27Plan<V>::build_device(const DevCsrPlain &A, int nx, int ny, int nz, double w, Ordering &ord, hipStream_t s) {
+    {
+        const char *e = getenv("OMG_STENCIL27");
+        if (e && e[0] == '0') return false;
+    }
+    const int64_t n = int64_t(nx) * ny * nz;
+    if (n < 64 || n != A.n_rows || n != A.n_cols || (nx & 1) || (ny & 1) || (nz & 1) || ny < 2 || nz < 2) return false;
+    if (A.nnz != (3 * int64_t(nx) - 2) * (3 * int64_t(ny) - 2) * (3 * int64_t(nz) - 2)) return false;
     S27Geom q;
     q.nx = int(nx); q.ny = int(ny); q.nz = int(nz);
     q.hx = q.nx / 2; q.hy = q.ny / 2; q.hz = q.nz / 2;
@@ -722,20 +750,13 @@ bool Stencil27Plan<V>::build(const omg_csr &A, const omg_csr &R, Ordering &ord, 
     q.w = double(V(w));
     const uint64_t coef_colour_bytes = uint64_t(q.ng) * 27 * 64 * uint64_t(q.rg) * sizeof(V);
     if (uint64_t(n) * sizeof(V) >= (uint64_t(1) << 31) || coef_colour_bytes >= (uint64_t(1) << 31)) return false;
-    // the operator onto the device as it is, every row checked and scattered into the tiles there
-    require_device();
     {
-        SetupTimer tm("27-point level: upload CSR, check + tile the coefficients on the device");
-        DevBuf<int32_t> d_ptr(size_t(n) + 1), d_idx(size_t(std::max<int64_t>(A.nnz, 1)));
-        DevBuf<double> d_val(size_t(std::max<int64_t>(A.nnz, 1)));
+        SetupTimer tm("27-point level: check + tile the coefficients on the device");
         DevBuf<unsigned long long> d_err(1);
-        OMG_HIP(hipMemcpyAsync(d_ptr.p, A.indptr, (size_t(n) + 1) * sizeof(int32_t), hipMemcpyHostToDevice, s));
-        OMG_HIP(hipMemcpyAsync(d_idx.p, A.indices, size_t(A.nnz) * sizeof(int32_t), hipMemcpyHostToDevice, s));
-        OMG_HIP(hipMemcpyAsync(d_val.p, A.data, size_t(A.nnz) * sizeof(double), hipMemcpyHostToDevice, s));
         OMG_HIP(hipMemsetAsync(d_err.p, 0xFF, sizeof(unsigned long long), s));
         coef.alloc(size_t(8) * size_t(q.ng) * 27 * 64 * size_t(q.rg));
         coef.zero(s);
-        hipLaunchKernelGGL(s27_build_kernel<V>, dim3(unsigned((n + 255) / 256)), dim3(256), 0, s, d_ptr.p, d_idx.p, d_val.p, q.nx, q.ny, q.nz,
+        hipLaunchKernelGGL(s27_build_kernel<V>, dim3(unsigned((n + 255) / 256)), dim3(256), 0, s, A.indptr.p, A.indices.p, A.data.p, q.nx, q.ny, q.nz,
                            q.L, q.G, q.rg, q.ng, coef.p, d_err.p);
         OMG_HIP(hipGetLastError());
         unsigned long long err = 0;
@@ -749,31 +770,13 @@ bool Stencil27Plan<V>::build(const omg_csr &A, const omg_csr &R, Ordering &ord, 
     partials.zero(s);
     have67 = false;
     // the ordering: colour = octant, inside a colour the aggregates in natural order (what the greedy colouring of
-    // such an operator gives: every lower-numbered neighbour of a cell lies in another octant position)
+    // such an operator gives: every lower-numbered neighbour of a cell lies in another octant position); its host
+    // arrays are written on demand (materialise_ordering)
     ord = Ordering();
     ord.identity = false;
     ord.sets.resize(9);
     for (int c = 0; c <= 8; ++c) ord.sets[size_t(c)] = int64_t(c) * g.na;
-    ord.perm.resize(size_t(n));
-    ord.inv.resize(size_t(n));
-    {
-        const unsigned hw = std::max(1u, std::min(64u, std::thread::hardware_concurrency()));
-        const int nt = (int)std::min<int64_t>(hw, std::max<int64_t>(1, n / 65536));
-        auto fill = [&](int tnum) {
-            const int64_t lo = n * tnum / nt, hi = n * (tnum + 1) / nt;
-            for (int64_t r = lo; r < hi; ++r) {
-                const int64_t i = r % nx, j = (r / nx) % ny, k = r / (nx * ny);
-                const int64_t c = (i & 1) | ((j & 1) << 1) | ((k & 1) << 2);
-                const int64_t slot = c * g.na + ((k >> 1) * g.hy + (j >> 1)) * g.hx + (i >> 1);
-                ord.inv[size_t(r)] = int32_t(slot);
-                ord.perm[size_t(slot)] = int32_t(r);
-            }
-        };
-        std::vector<std::thread> th;
-        for (int tnum = 1; tnum < nt; ++tnum) th.emplace_back(fill, tnum);
-        fill(0);
-        for (auto &t2 : th) t2.join();
-    }
+    ord.closed_form = 8; ord.cf_nx = nx; ord.cf_ny = ny; ord.cf_nz = nz;
     return true;
 }
 
