@@ -48,7 +48,7 @@ def test_device_setup_gives_the_hierarchy_of_the_host_route(name, make, shape, l
     assert np.array_equal(x_dev, x_host), (name, int(np.sum(x_dev != x_host)))
     # the handle itself: which path each level takes, and the single-level entry points that build the row-kernel
     # format on first use from the closed-form orderings
-    with _hip.Hierarchy.from_fine(A0, shape, levels, smoother=smoother, omega=p.get("omega", 1.0), dtype=dtype) as h, \\
+    with _hip.Hierarchy.from_fine(A0, shape, levels, smoother=smoother, omega=p.get("omega", 1.0), dtype=dtype) as h, \
             _hip.Hierarchy(info["A"], info["R"], smoother=smoother, omega=p.get("omega", 1.0), dtype=dtype) as g:
         assert h.sizes == g.sizes
         for l in range(levels):
