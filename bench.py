@@ -302,11 +302,11 @@ def config4_leg(size, grids, steps, warmup, repeats, sync_of):
     A0 = operators.stencil27_variable(shape)
     b = A0 @ np.random.default_rng(12345).random(A0.shape[0])
     t1 = time.perf_counter()
-    R = operators.restrictionList(shape, grids - 2, 8)
-    A = operators.coeffecientList(A0, R)                        # Galerkin products on the device
-    t2 = time.perf_counter()
-    h = _hip.Hierarchy(A, R, smoother="colour", dtype="float32")
-    t3 = time.perf_counter()
+    # restrictions, Galerkin products (rebuilt on the device: configs[4]) and the levels' 27-point tiles, all in HBM
+    # (omg_hierarchy_create_from_fine: what mgSolve runs when nobody asks for the operator lists)
+    h = _hip.Hierarchy.from_fine(A0, shape, grids - 1, smoother="colour", dtype="float32")
+    t3 = t2 = time.perf_counter()
+    A = [None] * grids
     h.resident_load(b)
     n, nnz, w = A0.shape[0], A0.nnz, 4
     fused = bool(h.level_flags(0)["stencil27"])
@@ -318,7 +318,7 @@ def config4_leg(size, grids, steps, warmup, repeats, sync_of):
            "vcycles_per_s": round(steps / e, 3), "ms_per_step": round(1e3 * e / steps, 4),
            "ms_per_step_all": [round(1e3 * t / steps, 4) for t in times], "dtype": "f32",
            "unknowns": n, "nnz": nnz, "stencil27_kernels": fused, "level_flags": [h.level_flags(l) for l in range(len(A) - 1)],
-           "generate_s": round(t1 - t0, 2), "rap_s": round(t2 - t1, 2), "hierarchy_s": round(t3 - t2, 2),
+           "generate_s": round(t1 - t0, 2), "device_setup_s": round(t3 - t1, 2),
            "norms_last_region_tail": norms[-3:]}
     if fused and cnt:
         # the dominant kernel: one smoothing sweep of the fine grid = four pair launches of stencil27.hip.  Bytes it has
@@ -557,18 +557,26 @@ def main():
             calls.append(time.perf_counter() - t0)
         openmg_amd.clear_cache()
         p_s = {"problemShape": (args.size,) * 3, "gridLevels": args.grids - 1, "cycles": 20, "threshold": 0,
-               "preIterations": 1, "postIterations": 1, "smoother": "colour", "dtype": np_dtype, "giveInfo": True}
+               "preIterations": 1, "postIterations": 1, "smoother": "colour", "dtype": np_dtype}
         t0 = time.perf_counter()
-        u_s, info_s = openmg_amd.mgSolve(A0, b_h, p_s)
+        u_s = openmg_amd.mgSolve(A0, b_h, dict(p_s))                           # what a caller writes: setup stays on the device
         solve_s = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        u_i, info_s = openmg_amd.mgSolve(A0, b_h, dict(p_s, giveInfo=True))    # ... asking for the R / A lists: through the host
+        solve_info_s = time.perf_counter() - t0
+        same = bool(np.array_equal(u_s, u_i))
         dropin = {"what": "openmg_amd.mgCycle(A, b, 0, R, parameters, initial) with the A / R lists and host vectors per call "
                           "(cached device hierarchy, every byte of the lists checksummed per call, b and x over PCIe), and "
-                          "openmg_amd.mgSolve(A_in, b, parameters) for 20 cycles including its whole setup",
+                          "openmg_amd.mgSolve(A_in, b, parameters) for 20 cycles including its whole setup: on the device "
+                          "(omg_hierarchy_create_from_fine) when the caller does not ask for the operator lists, through host "
+                          "lists with giveInfo",
                   "mgcycle_first_call_s": round(first_s, 3),
                   "mgcycle_call_ms": round(1e3 * statistics.median(calls), 2),
                   "mgcycle_call_ms_all": [round(1e3 * t, 2) for t in calls],
                   "mgcycle_norm": info_d["norm"],
-                  "mgsolve_20_cycles_s": round(solve_s, 3), "mgsolve_norm": info_s["norm"], "mgsolve_cycles": info_s["cycle"]}
+                  "mgsolve_20_cycles_s": round(solve_s, 3), "mgsolve_20_cycles_giveinfo_s": round(solve_info_s, 3),
+                  "mgsolve_same_iterate_both_routes": same,
+                  "mgsolve_norm": info_s["norm"], "mgsolve_cycles": info_s["cycle"]}
 
     def leg(env, smoother, what, reps, want_spmv):
         """The same problem and timed loop under other switches."""
