@@ -526,6 +526,15 @@ def main():
                     "level0_kernels": kernels}
     # The reference's OWN parameter dict: preIterations 1, postIterations 0 (openmg/__init__.py:22-23), same hierarchy
     # and loop: the up pass then runs without its relaxation (prolongation + correction + the norm's squares).
+    # the same setup kept on the device (omg_hierarchy_create_from_fine: what mgSolve runs when the caller does not ask
+    # for the operator lists): upload of the fine operator, restrictions, Galerkin products, qualification, tilings
+    setup_device_s = None
+    if args.smoother == "colour":
+        from openmg_amd import _hip as _h
+        t_s = time.perf_counter()
+        h_dev = _h.Hierarchy.from_fine(_PROBLEM[(args.size, args.grids)][0], (args.size,) * 3, args.grids - 1, smoother=args.smoother, dtype=np_dtype)
+        setup_device_s = time.perf_counter() - t_s
+        h_dev.close()
     default_cycle = None
     if plane and args.smoother == "colour":
         h.resident_load(b)
@@ -693,6 +702,10 @@ def main():
                                  "(creating it and loading the code object, once per process: device_init_s); generating the synthetic "
                                  "operator and right-hand side on the host took generate_s",
                    "device_init_s": round(meta.get("device_init_s", 0.0), 3),
+                   "setup_device_s": None if setup_device_s is None else round(setup_device_s, 3),
+                   "setup_device_what": "the same setup without host lists in between (omg_hierarchy_create_from_fine; mgSolve's route "
+                                        "when giveInfo is off): fine operator up, restrictions + Galerkin products + the levels' "
+                                        "qualification in HBM, coarsest operator down for its factorisation",
                    "rap_s": round(meta["rap_s"], 2), "hierarchy_s": round(meta["hierarchy_s"], 2),
                    "generate_s": round(generate_s, 2),
                    "kernel_src_sha": src_sha, "git_head": os.environ.get("OMG_GIT_HEAD") or None},
