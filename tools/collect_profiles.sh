@@ -1,44 +1,57 @@
 #!/bin/bash
 # Everything under profiles/rNN_* from ONE gpurun call (run from the repository root on the GPU box):
-#     gpurun -- "OMG_GIT_HEAD=$(git rev-parse HEAD) bash tools/collect_profiles.sh r03"
+#     gpurun -- "OMG_GIT_HEAD=$(git rev-parse HEAD) bash tools/collect_profiles.sh r04"
 # (the variable goes INSIDE the command: gpurun does not forward the caller's environment, and the box has no .git)
 # writes gpurun_out/fin/<prefix>_*; copy what is to be judged into profiles/.
-p=${1:-r03}
+p=${1:-r04}
 root=$(cd "$(dirname "$0")/.." && pwd)
 out=$root/gpurun_out/fin
 rm -rf "$out"; mkdir -p "$out"
 cd "$root"
 last() { tail -1 "$1" > "$2"; }
-# the PMC passes first: the bench line quotes their traffic (profiles/${p}_pmc_plane_down.json) while the kernel sources hash to it
-timeout 300 python bench.py --no-cpu --no-plain --no-lex --no-sets > $out/quick.log 2>/dev/null; last $out/quick.log $out/quick.json
+# the PMC passes first: the bench line quotes their traffic (profiles/${p}_pmc_*.json) while the kernel sources hash to it
+timeout 300 python bench.py --no-cpu --no-plain --no-lex --no-sets --no-dropin --no-config4 --no-config1 > $out/quick.log 2>/dev/null; last $out/quick.log $out/quick.json
 PASSES="1 2 4 5 6 7" bash tools/pmc_plane.sh gpurun_out/fin/pmc > $out/pmc.log 2>&1
 python tools/pmc_any.py gpurun_out/fin/pmc > $out/${p}_pmc_plane_kernels.txt 2>&1
 python tools/pmc_plane_json.py gpurun_out/fin/pmc $out/quick.json $out/${p}_pmc_plane_down.json \
   "tools/pmc_plane.sh passes 6 and 7 (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, --kernel-include-regex plane_kernel, tools/prof_cycle.py --steps 2), table in profiles/${p}_pmc_plane_kernels.txt" > $out/pmc_json.log 2>&1
 cp $out/${p}_pmc_plane_down.json $root/profiles/${p}_pmc_plane_down.json
-timeout 600 python bench.py > $out/bench.log 2>$out/bench.err; last $out/bench.log $out/${p}_bench.json
-timeout 300 python bench.py --no-cpu --no-plain --no-lex --dtype f32 > $out/f32.log 2>/dev/null; last $out/f32.log $out/${p}_bench_f32.json
+python3 tools/prof_config4.py --steps 1 > /dev/null 2>&1          # (generates and caches the configs[4] operator under /tmp/cfg4)
+bash tools/pmc_s27.sh gpurun_out/fin/pmc27 > $out/pmc27.log 2>&1
+python tools/pmc_any.py gpurun_out/fin/pmc27 > $out/${p}_pmc_s27_kernels.txt 2>&1
+python tools/pmc_s27_json.py gpurun_out/fin/pmc27 $out/${p}_pmc_s27_sweep.json \
+  "tools/pmc_s27.sh passes 5 and 6 (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, --kernel-include-regex s27_, tools/prof_config4.py --steps 2 --batched 0), table in profiles/${p}_pmc_s27_kernels.txt" > $out/pmc27_json.log 2>&1
+cp $out/${p}_pmc_s27_sweep.json $root/profiles/${p}_pmc_s27_sweep.json
+timeout 900 python bench.py > $out/bench.log 2>$out/bench.err; last $out/bench.log $out/${p}_bench.json
+timeout 300 python bench.py --graph 1 --no-cpu --no-plain --no-lex --no-sets --no-dropin --no-config4 --no-config1 > $out/graph.log 2>/dev/null; last $out/graph.log $out/${p}_bench_hipgraph.json
+timeout 300 python bench.py --no-cpu --no-plain --no-lex --no-dropin --no-config4 --no-config1 --dtype f32 > $out/f32.log 2>/dev/null; last $out/f32.log $out/${p}_bench_f32.json
 OMG_DIST_P2P=0 timeout 300 python bench.py --dist 1 --no-cpu > $out/dist1.log 2>/dev/null; last $out/dist1.log $out/${p}_bench_dist1.json
 OMG_DIST_P2P=1 timeout 300 python bench.py --dist 1 --no-cpu > $out/dist1p.log 2>/dev/null; last $out/dist1p.log $out/${p}_bench_dist1_peer.json
 PYTHONPATH=$root timeout 300 python tools/exchange_probe.py > $out/${p}_exchange_probe.txt 2>/dev/null
 ( for m in 0 1; do echo "OMG_LOOPBACK_P2P=$m (0: device copies in place of RCCL, 1: peer stores between the slabs)"; OMG_LOOPBACK_P2P=$m PYTHONPATH=$root timeout 300 python tools/pdist_loopback_time.py 1 2 4 8 2>/dev/null | grep world; done ) > $out/${p}_slab_loopback.txt
 timeout 600 python tools/run_configs.py > $out/${p}_configs.txt 2>&1
 timeout 900 python tools/config3_single.py 512 6 > $out/${p}_config3_single_gpu.txt 2>&1
-timeout 600 python tools/config4_probe.py --size 256 > $out/${p}_config4_256_fp32.txt 2>&1
+timeout 600 python tools/config4_probe.py --size 256 --cache /tmp/cfg4 2>&1 | tail -1 > $out/${p}_config4_256_fp32.txt
 OMG_MARCH_DEBUG=1 timeout 120 python tools/march_probe.py 8x8x2048 8x64x2048 32x32x32 128x128x128 256x256x256 2> $out/${p}_march_timeline.txt > /dev/null
 OMG_SETUP_TIMING=1 timeout 120 python tools/setup_timing.py > $out/${p}_setup_timing.txt 2>&1
+OMG_SETUP_TIMING=1 timeout 200 python tools/setup_breakdown.py > $out/${p}_setup_breakdown.txt 2>&1
+python tools/hostmem_probe.py > $out/${p}_hostmem_probe.txt 2>&1
 cd /tmp && export TMPDIR=/tmp
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -o b -- python3 $root/bench.py --no-cpu > $out/under.log 2>/dev/null
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -o b -- python3 $root/bench.py --no-cpu > $out/under.log 2>/dev/null
 last $out/under.log $out/${p}_bench_under_rocprof.json
 cp $out/trace/b_kernel_stats.csv $out/${p}_bench_kernel_stats.csv
 python3 $root/tools/trace_stats.py $out/trace/b_kernel_trace.csv > $out/${p}_bench_kernel_stats_by_grid.txt 2>&1
 timeout 300 rocprofv3 --kernel-trace --output-format csv -d $out/cyc -o c -- python3 $root/tools/prof_cycle.py --steps 6 > /dev/null 2>&1
 python3 $root/tools/cycle_timeline.py $out/cyc/c_kernel_trace.csv -3 > $out/${p}_bench_cycle_timeline.txt 2>&1
+timeout 400 rocprofv3 --kernel-trace --output-format csv -d $out/c4b -o t -- python3 $root/tools/prof_config4.py --steps 4 --batched 1 > /dev/null 2>&1
+python3 $root/tools/trace_dump.py $out/c4b/t_kernel_trace.csv 75 > $out/${p}_config4_cycle_timeline_batched.txt 2>&1
+timeout 400 rocprofv3 --kernel-trace --output-format csv -d $out/c4s -o t -- python3 $root/tools/prof_config4.py --steps 4 --batched 0 > /dev/null 2>&1
+python3 $root/tools/trace_dump.py $out/c4s/t_kernel_trace.csv 60 > $out/${p}_config4_cycle_timeline.txt 2>&1
 timeout 300 rocprofv3 --kernel-trace --output-format csv -d $out/lex -o l -- python3 $root/tools/run_configs.py 0 4 5 > /dev/null 2>&1
 python3 $root/tools/march_trace.py $out/lex/l_kernel_trace.csv > $out/${p}_march_by_level.txt 2>&1
 for m in 0 1; do PYTHONPATH=$root timeout 200 rocprofv3 --kernel-trace --output-format csv -d $out/peer$m -o p -- python3 $root/tools/prof_pdist.py $m 20 > /dev/null 2>&1; done
 python3 $root/tools/peer_mode_table.py $out/peer0 $out/peer1 > $out/${p}_peer_mode.txt 2>&1
 python3 $root/tools/level_times.py $out/cyc/c_kernel_trace.csv > $out/${p}_level_times.txt 2>&1
 cd "$root"
-rm -rf $out/trace $out/cyc $out/lex $out/pmc $out/peer0 $out/peer1
+rm -rf $out/trace $out/cyc $out/lex $out/pmc $out/pmc27 $out/peer0 $out/peer1 $out/c4b $out/c4s
 ls -la $out

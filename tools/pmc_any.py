@@ -9,6 +9,13 @@ def short(name):
     if m:
         return "plane_kernel<%s, %s%s%s>" % (m.group(1), "down" if m.group(2) == "0" else "up", ", norm" if m.group(3) == "true" else "",
                                              ", x=0" if m.group(4) == "true" else "")
+    m = re.search(r"s27_sweep_kernel<(\w+), (\d+), (\d+), (true|false), (true|false), (true|false)>", name)
+    if m:
+        return "s27_sweep<%s rg%s pair%s%s%s%s>" % (m.group(1), m.group(2), m.group(3), " x=0" if m.group(4) == "true" else "",
+                                                    " +old-norm" if m.group(5) == "true" else "", " +res67" if m.group(6) == "true" else "")
+    m = re.search(r"s27_residual_kernel<(\w+), (\d+), (\d+), (\d+)>", name)
+    if m:
+        return "s27_residual<%s rg%s %s colours %s>" % (m.group(1), m.group(2), m.group(3), "restrict" if m.group(4) == "0" else "norm")
     return re.sub(r"\(.*", "", name)[:80]
 
 

@@ -29,6 +29,17 @@ def short(name):
     if m:
         return "rows_kernel<%s, nt=%s, %s, %s>" % (MODES[int(m.group(1))], m.group(2)[0],
                                                    "short" if m.group(3) == "true" else "lpr" + m.group(4), m.group(5))
+    m = re.search(r"s27_sweep_kernel<(\w+), (\d+), (\d+), (true|false), (true|false), (true|false)>", name)
+    if m:
+        return "s27_sweep<%s rg%s pair%s%s%s%s>" % (m.group(1), m.group(2), m.group(3), " x=0" if m.group(4) == "true" else "",
+                                                    " +old-norm" if m.group(5) == "true" else "", " +res67" if m.group(6) == "true" else "")
+    m = re.search(r"s27_residual_kernel<(\w+), (\d+), (\d+), (\d+)>", name)
+    if m:
+        return "s27_residual<%s rg%s %s colours %s>" % (m.group(1), m.group(2), m.group(3), "restrict" if m.group(4) == "0" else "norm")
+    m = re.search(r"tile2d_kernel<(\w+), (\d+), (true|false), (true|false), (true|false), (\d+), (\d+), (true|false)>", name)
+    if m:
+        return "tile2d_kernel<%s %s%s%s %sx%s%s>" % (m.group(1), "down" if m.group(2) == "0" else "up", ", norm" if m.group(4) == "true" else "",
+                                                     "" if m.group(5) == "true" else ", no sweep", m.group(6), m.group(7), ", jacobi" if m.group(8) == "true" else "")
     m = re.search(r"(\w+_kernel|__amd\w+)", name)
     return m.group(1) if m else name[:40]
 
