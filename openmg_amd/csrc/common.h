@@ -77,6 +77,17 @@ struct DevBuf {
         OMG_HIP(hipMalloc(reinterpret_cast<void **>(&raw), count * sizeof(T) + 2 * DEVBUF_SLACK + shift_bytes));
         shift = shift_bytes;
         p = reinterpret_cast<T *>(raw + DEVBUF_SLACK + shift_bytes);
+        // OMG_POISON=1 (tests): fresh device memory holds NaN patterns instead of whatever the allocator hands out (zeros
+        // in a young process, anything later) — a kernel that reads what nobody wrote shows in the results
+        // (OMG_POISON=2: only the slack around the arrays; 3: only the arrays)
+        static const int poison = [] { const char *e = getenv("OMG_POISON"); return e ? atoi(e) : 0; }();
+        if (poison == 1) OMG_HIP(hipMemset(raw, 0xFF, count * sizeof(T) + 2 * DEVBUF_SLACK + shift_bytes));
+        if (poison == 2) {
+            OMG_HIP(hipMemset(raw, 0xFF, DEVBUF_SLACK + shift_bytes));
+            OMG_HIP(hipMemset(raw + DEVBUF_SLACK + shift_bytes + count * sizeof(T), 0xFF, DEVBUF_SLACK));
+        }
+        if (poison == 3 && count) OMG_HIP(hipMemset(p, 0xFF, count * sizeof(T)));
+        if (poison) OMG_HIP(hipDeviceSynchronize());      // (the fill is in place before any stream writes the array)
     }
     void release() {
         if (p) (void)hipFree(reinterpret_cast<char *>(p) - DEVBUF_SLACK - shift);

@@ -889,8 +889,13 @@ std::unique_ptr<Hier<V>> create(int n_levels, const omg_csr *A, const omg_csr *R
         }
         L.x.alloc(std::max<int64_t>(L.n, 1));
         L.b.alloc(std::max<int64_t>(L.n, 1), L.plane ? vector_stagger(2) : 0);
+        // (finite from the start: the 27-point sweeps multiply the slot of a neighbour that does not exist — a zero
+        // coefficient — with whatever the vectors hold at the index the slot's shift lands on)
+        L.x.zero(h->stream);
+        L.tmp.zero(h->stream);
         L.xp = L.x.p;
         L.tp = L.tmp.p;
+        if (SetupTimer::on() && l == 0) fprintf(stderr, "[omg setup] level 0 vectors at x %p  tmp %p  b %p\n", (void *)L.x.p, (void *)L.tmp.p, (void *)L.b.p);
     }
     for (int l = 0; l + 1 < n_levels; ++l) {
         // the large levels' tilings: measured, not modelled (plane.hip choose_tiles; tune() skips the small ones)
@@ -1032,8 +1037,13 @@ std::unique_ptr<Hier<V>> create_from_fine(const omg_csr &A0, int dim, const int6
         }
         L.x.alloc(std::max<int64_t>(L.n, 1));
         L.b.alloc(std::max<int64_t>(L.n, 1), L.plane ? vector_stagger(2) : 0);
+        // (finite from the start: the 27-point sweeps multiply the slot of a neighbour that does not exist — a zero
+        // coefficient — with whatever the vectors hold at the index the slot's shift lands on)
+        L.x.zero(h->stream);
+        L.tmp.zero(h->stream);
         L.xp = L.x.p;
         L.tp = L.tmp.p;
+        if (SetupTimer::on() && l == 0) fprintf(stderr, "[omg setup] level 0 vectors at x %p  tmp %p  b %p\n", (void *)L.x.p, (void *)L.tmp.p, (void *)L.b.p);
     }
     OMG_HIP(hipStreamSynchronize(h->stream));
     for (int l = 0; l + 1 < n_levels; ++l) {

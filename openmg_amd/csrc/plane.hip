@@ -72,8 +72,11 @@ template <> struct VecOf<float> {
     typedef type gtype __attribute__((aligned(4)));
 };
 
+#ifndef PLANE_LOAD_AUX
+#define PLANE_LOAD_AUX 0             // cache policy of the passes' vector loads (experiments: 2 = nt)
+#endif
 __device__ __forceinline__ P2<double> bload2(__amdgpu_buffer_rsrc_t rs, int off, double) {
-    const v4u q = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0);
+    const v4u q = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, PLANE_LOAD_AUX);
     return {__builtin_bit_cast(double, v2u{q.x, q.y}), __builtin_bit_cast(double, v2u{q.z, q.w})};
 }
 __device__ __forceinline__ P2<float> bload2(__amdgpu_buffer_rsrc_t rs, int off, float) {
@@ -234,16 +237,16 @@ __device__ __forceinline__ bool plain_numerator(double v) {
     return e - 623u <= 800u || v == 0.0;
 }
 __device__ __forceinline__ bool plain_numerator(float) { return false; }
-// q[i] = n[i] / c for the lanes' four numerators; act[i]: the lane uses quotient i
+// q[i] = n[i] / c for the lanes' four numerators (every lane's: a cell outside the grid has a finite numerator like any other)
 template <typename V>
-__device__ __forceinline__ void quotients(const V (&n)[4], const bool (&act)[4], V c, V r, bool fast, V (&q)[4]) {
+__device__ __forceinline__ void quotients(const V (&n)[4], V c, V r, bool fast, V (&q)[4]) {
     if (sizeof(V) == 8 && fast) {
         bool bad = false;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const V q0 = n[i] * r;
             q[i] = madd(madd(-c, q0, n[i]), r, q0);
-            bad = bad || (act[i] && !plain_numerator(n[i]));
+            bad = bad || !plain_numerator(n[i]);
         }
         if (__builtin_amdgcn_ballot_w64(bad) == 0) return;
     }
@@ -328,8 +331,14 @@ __global__ void plane_wait_kernel(const uint32_t *f0, const uint32_t *f1, const 
 // SWEEP = false: the pass without its relaxation — a cycle with preIterations = 0 (down: residual of the iterate as
 // it is + restriction; x_new is not written) or postIterations = 0, the reference's default (openmg/__init__.py:22-23;
 // up: x_new = x_old + R^T e and the squares of ITS residual): the same pipeline, stages B and C form no quotient
-template <typename V, int MODE, bool NORM, bool XZ, int LA, bool PEER = false, int MAXT = 512, bool FIRST = false, bool SWEEP = true>
+// MIRROR (up, whole grids): the march runs from the grid's LAST plane to its first — plane index and coarse plane index
+// mirrored where global memory is addressed, the two k neighbours exchanged in the row chains, the in-line rule's parity
+// flipped (nz is even) — so that the pass starts where the down pass before it ended and ends where the next cycle's
+// down pass starts: what those passes touched last is the likeliest to be still in the memory-side cache.  A sweep of
+// one colour does not depend on the order of its cells: the same bits in x; the norm's squares are added in another order.
+template <typename V, int MODE, bool NORM, bool XZ, int LA, bool PEER = false, int MAXT = 512, bool FIRST = false, bool SWEEP = true, bool MIRROR = false>
 __global__ __launch_bounds__(MAXT) void plane_kernel(const PlaneKArgs<V> a) {
+    static_assert(!MIRROR || (MODE == 1 && !PEER && !FIRST && !XZ), "mirrored march: up passes of whole grids");
 #ifdef OMG_PLANE_STAMPS
     const unsigned long long st_entry = __builtin_amdgcn_s_memtime();
 #endif
@@ -368,39 +377,97 @@ __global__ __launch_bounds__(MAXT) void plane_kernel(const PlaneKArgs<V> a) {
     const __amdgpu_buffer_rsrc_t es = __builtin_amdgcn_make_buffer_rsrc(const_cast<V *>(MODE == 1 ? a.ec : a.cdiag), 0, a.cvec_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t ms = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t *>(a.cmap), 0, a.cmap_bytes, 0x00020000);
 
-    // a pair of the level vector: colour (0 red, 1 black), plane k, line ja + l; 0 outside the grid
-    auto fetch = [&](const __amdgpu_buffer_rsrc_t &rs, int colour, int k, int l) -> P2<V> {
-        const bool ok = vl[l] && vx0 && k >= a.kv0 && k < a.kv1;
-        // (a pair's second value is cleared where it is TAKEN — clean() — not here: a select on the loaded
-        // register would be the load's first consumer, in the step that issues it)
-        return bload2(rs, ok ? ((colour ? a.nr : 0) + k * ps + lb[l]) * int(sizeof(V)) : OOB, V(0));
+    // ---- cells outside the grid ------------------------------------------------------------------------------------
+    // Nothing in the loop is masked per lane.  A thread relaxes all its cells; for a cell outside the grid that gives a
+    // finite value nobody may use, so the couplings of the cells INSIDE to such cells are switched off instead: per-lane
+    // copies of the four coefficients that can point outside, zero where they do (a zero coefficient times a finite
+    // value adds +-0 to a chain that started from +0 — the bits of the same chain over a neighbour that holds zero).
+    // The OLD values of the cells outside are exact zeros as before (loads from behind the buffer), nothing of them is
+    // stored (offsets behind the buffer again), their residuals end in coarse slots that do not exist, their squares are
+    // dropped at the end.  PLANES outside the grid are uniform: a scalar branch clears them after stages B and C.
+    // (ja and ny are even: a thread's two lines are in the grid together)
+    constexpr int W = int(sizeof(V));
+    const bool vcell = vl[0] && vx0;
+    V c1a = ja > 0 ? a.c1 : V(0);                    // line ja: its -J neighbour is the thread above's second line
+    V c5b = ja + 2 < a.ny ? a.c5 : V(0);             // line ja + 1: its +J neighbour is the thread below's first line
+    V c2x = q > 0 ? a.c2 : V(0);                     // first value under rule 0: -I is the left thread's second value
+    V c4x = 2 * q + 1 < a.hx ? a.c4 : V(0);          // first value under rule 1: +I is the other colour's second value (outside in the last pair of a line of odd hx)
+    V c4y = 2 * q + 2 < a.hx ? a.c4 : V(0);          // second value under rule 1: +I is the right thread's first value
+    // byte offsets of the thread's pairs within a plane of one colour: loads (every cell of the grid), stores (the tile's own cells)
+    unsigned lbo[2] = {vcell ? unsigned(lb[0] * W) : unsigned(OOB), vcell ? unsigned(lb[1] * W) : unsigned(OOB)};
+    unsigned lso[2] = {(vcell && inner) ? unsigned(lb[0] * W) : unsigned(OOB), (vcell && inner) ? unsigned(lb[1] * W) : unsigned(OOB)};
+    // (opaque from here on: kept in registers, not re-derived from the conditions inside the loop)
+    asm volatile("" : "+v"(c1a), "+v"(c5b), "+v"(c2x), "+v"(c4x), "+v"(c4y));
+    asm volatile("" : "+v"(lbo[0]), "+v"(lbo[1]), "+v"(lso[0]), "+v"(lso[1]));
+    const bool oddx = (a.hx & 1) != 0;               // the last pair of a line holds one value: its store is a single one
+
+    // the chain of a row: the seven slots in column order from +0, the lane's coefficient where the neighbour may be outside.
+    // l: the thread's line, v: first / second value of the pair, rule: see in_line()
+    auto head = [&](int l, int v, int rule, V km, V jm, V im) -> V {
+        V sum = madd(a.c0, km, V(0));
+        sum = madd(l == 0 ? c1a : a.c1, jm, sum);
+        return madd((v == 0 && rule == 0) ? c2x : a.c2, im, sum);
     };
-    auto clean = [&](const P2<V> &r) -> P2<V> { return {r.x, vx1 ? r.y : V(0)}; };
+    auto tail = [&](int l, int v, int rule, V sum, V d, V ip, V jp, V kp) -> V {
+        sum = madd(a.c3, d, sum);
+        sum = madd(rule == 0 ? a.c4 : (v == 0 ? c4x : c4y), ip, sum);
+        sum = madd(l == 1 ? c5b : a.c5, jp, sum);
+        return madd(a.c6, kp, sum);
+    };
+
+    // a pair of the level vector: colour (0 red, 1 black), plane k (uniform), line ja + l; 0 outside the grid
+    auto zphys = [&](int k) -> int { return MIRROR ? a.nz - 1 - k : k; };          // the plane a march index stands for
+    auto zcphys = [&](int kc) -> int { return MIRROR ? a.nzc - 1 - kc : kc; };
+    auto plane_off = [&](int colour, int k) -> unsigned {
+        return (k >= a.kv0 && k < a.kv1) ? unsigned(((colour ? a.nr : 0) + zphys(k) * ps) * W) : unsigned(OOB);
+    };
+    // (the plane's part of the offset as ONE scalar value — the asm keeps the compiler from branching around its select)
+    auto fetch = [&](const __amdgpu_buffer_rsrc_t &rs, int colour, int k, int l) -> P2<V> {
+        unsigned po = plane_off(colour, k);
+        asm volatile("" : "+s"(po));
+        return bload2(rs, int(lbo[l] + po), V(0));
+    };
+    auto fetch_at = [&](const __amdgpu_buffer_rsrc_t &rs, unsigned po, int l) -> P2<V> { return bload2(rs, int(lbo[l] + po), V(0)); };
     auto fetch_x = [&](int colour, int k, int l) -> P2<V> {
         if (XZ) return {V(0), V(0)};
         return fetch(xs, colour, k, l);
     };
-    // the coarse cells (2q, J, kc), (2q + 1, J, kc) of this thread, J = ja / 2: slots in the coarse ordering
-    const bool vcoarse = vl[0] && vx0;
+    // (a line of odd hx: the pair as two stores, the second one dropped where the line has ended)
+    constexpr int XAUX = sizeof(V) == 8 ? PLANE_STORE_AUX : 0;
+    auto put_pair = [&](const __amdgpu_buffer_rsrc_t &rs, unsigned off, const P2<V> &v) {
+        if (oddx) {
+            bstore1<XAUX>(rs, int(off), v.x);
+            bstore1<XAUX>(rs, int(vx1 ? off + unsigned(W) : unsigned(OOB)), v.y);
+        } else {
+            bstore2(rs, int(off), v, true);
+        }
+    };
+    // the coarse cells (2q, J, kc), (2q + 1, J, kc) of this thread, J = ja / 2, as BYTE offsets into the coarse vectors
+    // (>= OOB: none — the cell or the plane is outside, or, going down, the thread is in the tile's ring and stores nothing)
+    const bool vcoarse = vcell && (MODE == 1 || inner);
     const int cbase = (ja >> 1) * a.nxc + 2 * q;
+    unsigned cb4 = vcoarse ? unsigned(cbase * 4) : unsigned(OOB);
+    unsigned lmx = vcoarse ? 0u : unsigned(OOB), lmy = (vcoarse && vx1) ? 0u : unsigned(OOB);
+    asm volatile("" : "+v"(cb4), "+v"(lmx), "+v"(lmy));
+    const v2u none = {unsigned(OOB), unsigned(OOB)};
     // ... in two halves, so that the load has no consumer in the step that issues it: the request
-    // (raw words of the slot map; nothing is fetched for a lane that needs none) and, a step later, the slots
+    // (raw words of the slot map; nothing is fetched for a lane that needs none) and, a step later, the offsets
     auto slots_request = [&](int kc, bool want) -> v2u {
         kc += a.kc_off;
-        const bool ok = want && a.cmap && vcoarse && kc >= 0 && kc < a.nzc;
-        return __builtin_amdgcn_raw_buffer_load_b64(ms, ok ? (kc * a.nyc * a.nxc + cbase) * 4 : OOB, 0, 0);   // (second word unused when !vx1)
+        const bool ok = want && a.cmap && kc >= 0 && kc < a.nzc;
+        return __builtin_amdgcn_raw_buffer_load_b64(ms, int(cb4 + (ok ? unsigned(zcphys(kc) * a.nyc * a.nxc * 4) : unsigned(OOB))), 0, 0);   // (second word unused when !vx1)
     };
-    auto slots_commit = [&](const v2u &m, int kc, bool want) -> v2i {
+    auto slots_commit = [&](const v2u &m, int kc, bool want) -> v2u {
         kc += a.kc_off;
-        const bool ok = want && vcoarse && kc >= 0 && kc < a.nzc;
-        const int cn = kc * a.nyc * a.nxc + cbase;
-        const int s0_ = a.cmap ? int(m.x) : cn, s1_ = a.cmap ? int(m.y) : cn + 1;
-        return v2i{ok ? s0_ : -1, (ok && vx1) ? s1_ : -1};
+        const bool ok = want && kc >= 0 && kc < a.nzc;
+        const unsigned u = ok ? 0u : unsigned(OOB), cn = ok ? unsigned(zcphys(kc) * a.nyc * a.nxc * W) : 0u;
+        // (no slot map: the coarse level in natural order.  cb4 of a lane without coarse cells is an offset behind the
+        // buffers already, and stays one under the masks)
+        const unsigned s0_ = a.cmap ? m.x * unsigned(W) : cn + cb4 * unsigned(W / 4), s1_ = a.cmap ? m.y * unsigned(W) : cn + cb4 * unsigned(W / 4) + unsigned(W);
+        return v2u{s0_ | lmx | u, s1_ | lmy | u};
     };
-    auto coarse_slots = [&](int kc) -> v2i { return slots_commit(slots_request(kc, true), kc, true); };
-    auto coarse_vals = [&](const v2i &sl) -> P2<V> {
-        return {bload1(es, sl.x >= 0 ? sl.x * int(sizeof(V)) : OOB, V(0)), bload1(es, sl.y >= 0 ? sl.y * int(sizeof(V)) : OOB, V(0))};
-    };
+    auto coarse_slots = [&](int kc) -> v2u { return slots_commit(slots_request(kc, true), kc, true); };
+    auto coarse_vals = [&](const v2u &sl) -> P2<V> { return {bload1(es, int(sl.x), V(0)), bload1(es, int(sl.y), V(0))}; };
     auto prolonged = [&](const P2<V> &x, const P2<V> &e) -> P2<V> {
         // openmg/__init__.py:214,220: x + R^T e — the product rounded, then added (ROW_SCATTER's two roundings)
         return {x.x + madd(a.w, e.x, V(0)), x.y + madd(a.w, e.y, V(0))};
@@ -447,9 +514,16 @@ __global__ __launch_bounds__(MAXT) void plane_kernel(const PlaneKArgs<V> a) {
         }
     };
     int CO_side = 0;                 // the pending coarse pair is also rank - 1's (1) / rank + 1's (2) ghost
-    auto coarse_store = [&](const v2i &sl, const P2<V> &co, const P2<V> &cx, auto PB) {
-        if (sl.x >= 0) { a.bc[sl.x] = co.x; if (FIRST && a.xc) a.xc[sl.x] = cx.x; }
-        if (sl.y >= 0) { a.bc[sl.y] = co.y; if (FIRST && a.xc) a.xc[sl.y] = cx.y; }
+    // (the coarse right-hand side through a descriptor too: a slot that is none is an offset behind it, no branch)
+    const __amdgpu_buffer_rsrc_t bcs = __builtin_amdgcn_make_buffer_rsrc(a.bc, 0, a.bc ? a.cvec_bytes : 0u, 0x00020000);
+    auto coarse_store = [&](const v2u &sl, const P2<V> &co, const P2<V> &cx, auto PB) {
+        bstore1<0>(bcs, int(sl.x), co.x);
+        bstore1<0>(bcs, int(sl.y), co.y);
+        if (FIRST && a.xc) {
+            const __amdgpu_buffer_rsrc_t xcs = __builtin_amdgcn_make_buffer_rsrc(a.xc, 0, a.cvec_bytes, 0x00020000);
+            bstore1<0>(xcs, int(sl.x), cx.x);
+            bstore1<0>(xcs, int(sl.y), cx.y);
+        }
         if (PEER && decltype(PB)::value) {
 #pragma unroll
             for (int side = 0; side < 2; ++side) {
@@ -461,8 +535,8 @@ __global__ __launch_bounds__(MAXT) void plane_kernel(const PlaneKArgs<V> a) {
                 // (through a buffer descriptor with 32-bit offsets, like the planes of x: 64-bit addresses per value
                 // cost this kernel forty registers)
                 const __amdgpu_buffer_rsrc_t pwb = __builtin_amdgcn_make_buffer_rsrc(pb, 0, a.cvec_bytes, 0x00020000);
-                bstore1<PEER_AUX>(pwb, sl.x >= 0 ? (sl.x + sh) * int(sizeof(V)) : OOB, co.x);
-                bstore1<PEER_AUX>(pwb, sl.y >= 0 ? (sl.y + sh) * int(sizeof(V)) : OOB, co.y);
+                bstore1<PEER_AUX>(pwb, sl.x < unsigned(OOB) ? int(sl.x) + sh * W : OOB, co.x);
+                bstore1<PEER_AUX>(pwb, sl.y < unsigned(OOB) ? int(sl.y) + sh * W : OOB, co.y);
             }
         }
     };
@@ -480,21 +554,20 @@ __global__ __launch_bounds__(MAXT) void plane_kernel(const PlaneKArgs<V> a) {
     }
     P2<V> ACC = zero2;               // down: the restriction's running chain
     P2<V> CO = zero2, CX = zero2;    // ... a finished coarse pair waiting for its store: right-hand side, first iterate
-    v2i SLd = {-1, -1}, SLo = {-1, -1};
+    v2u SLd = none, SLo = none;
     v2u SLt = {0u, 0u};              // SLt, DGt, Et: requested in one step, committed at the top of the next
     int SLt_kc = -1;
     P2<V> DG = zero2, DGt = zero2;   // ... the coarse diagonal at those slots
-    bool co_pending = false;
     P2<V> E0 = zero2, E1n = zero2, Et = zero2;   // up: coarse correction of coarse planes s >> 1 and (s >> 1) + 1
-    v2i SLn = {-1, -1};
-    double sq = 0.0;
+    v2u SLn = none;
+    double sq = 0.0, sqy = 0.0;      // squares of the pairs' first / second values (every lane's; the lanes that count are picked at the end)
 
     // ---- prologue: the state step s0 = z0 - 2 expects ---------------------------------------------
     const int s0 = z0 - 2;
     {
         P2<V> em = zero2;
         if (MODE == 1) {
-            const v2i sl0 = coarse_slots(s0 >> 1), slm = coarse_slots((s0 >> 1) - 1);
+            const v2u sl0 = coarse_slots(s0 >> 1), slm = coarse_slots((s0 >> 1) - 1);
             SLt_kc = (s0 >> 1) + 1;
             SLt = slots_request(SLt_kc, true);        // committed to SLn at the top of the first step
             E0 = coarse_vals(sl0);
@@ -502,8 +575,8 @@ __global__ __launch_bounds__(MAXT) void plane_kernel(const PlaneKArgs<V> a) {
         }
 #pragma unroll
         for (int l = 0; l < 2; ++l) {
-            XB[0][l] = clean(fetch_x(1, s0, l));     // becomes XB[1] at the first shift
-            XB[1][l] = clean(fetch_x(1, s0 - 1, l)); // becomes XB[2]
+            XB[0][l] = fetch_x(1, s0, l);            // becomes XB[1] at the first shift
+            XB[1][l] = fetch_x(1, s0 - 1, l);        // becomes XB[2]
             if (MODE == 1) {
                 XB[0][l] = prolonged(XB[0][l], E0);
                 XB[1][l] = prolonged(XB[1][l], em);
@@ -530,6 +603,37 @@ __global__ __launch_bounds__(MAXT) void plane_kernel(const PlaneKArgs<V> a) {
     // PB (PEER kernels): the step may hold planes the neighbours take — only those steps carry the peer stores;
     // the others are the code of a pass without neighbours
     static_assert(!(PEER && LA == 2), "the two-step loop has no boundary steps");
+    // The waves of a workgroup, step by step.  A wave reads only LDS cells written by threads t +- 1 and t +- PX, i.e. by
+    // the waves within (PX + 63) / 64 of it: instead of a barrier of the whole workgroup — where eight waves waited for the
+    // slowest at every step — it PUBLISHES its progress once it has written the next step's images and needs nothing of
+    // this step's any more (stage D's operands are taken first), and AWAITS those neighbours' progress only where the
+    // next step first reads an image: stage D, the restriction and the next step's top (loads taken, requests issued)
+    // lie between the two, so a neighbour that is a little behind costs nothing.  The images are double buffered: one
+    // count per step covers both hazards — what a neighbour wrote for step s + 1 is there, and what it read for step s it
+    // has read.  (double only: the fp32 passes were 10 % slower with it than with the barrier.)
+    constexpr bool WSYNC = PLANE_WAVE_SYNC && sizeof(V) == 8;
+    int n_waves = int(blockDim.x) >> 6;
+    asm volatile("" : "+s"(n_waves));                    // (not re-read from the dispatch packet in every step)
+    const int my_wave = t >> 6, reach = (PX + 63) >> 6;
+    auto publish = [&](int cnt) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if ((t & 63) == 0) __hip_atomic_store(&s_step[my_wave], cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
+    auto await = [&](int cnt) {
+        if ((t & 63) == 0) {
+            // a bounded wait, like the peer waits and the wavefront sweep's polls: a wave that never arrives (it
+            // cannot, short of a fault) sets bit 1 of *status — the host raises — instead of hanging the queue
+            for (int o = max(0, my_wave - reach); o <= min(n_waves - 1, my_wave + reach); ++o)
+                for (unsigned polls = 0; __hip_atomic_load(&s_step[o], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < cnt; ++polls) {
+                    if (polls >= WAVE_SYNC_SPIN) {
+                        if (a.status) __hip_atomic_fetch_or(a.status, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    };
     auto step = [&](auto PARC, const int s, auto PB) {
         constexpr bool PEER_STEP = PEER && decltype(PB)::value;
         const int par = PARC;                            // (a compile-time constant after inlining when LA == 2)
@@ -551,12 +655,12 @@ __global__ __launch_bounds__(MAXT) void plane_kernel(const PlaneKArgs<V> a) {
             // commit what the previous step requested: an even step asked for the next coarse plane's values,
             // an odd one for the slots of the one after
             E1n.x = par ? Et.x : E1n.x; E1n.y = par ? Et.y : E1n.y;
-            const v2i sl = slots_commit(SLt, SLt_kc, true);
+            const v2u sl = slots_commit(SLt, SLt_kc, true);
             SLn.x = par ? SLn.x : sl.x; SLn.y = par ? SLn.y : sl.y;
         } else {
             // an odd step asked for the slots of the coarse plane finished two steps later, the even step
             // after it for the coarse diagonal there
-            const v2i sl = slots_commit(SLt, SLt_kc, true);
+            const v2u sl = slots_commit(SLt, SLt_kc, true);
             SLd.x = par ? SLd.x : sl.x; SLd.y = par ? SLd.y : sl.y;
             if (FIRST) { DG.x = par ? DGt.x : DG.x; DG.y = par ? DGt.y : DG.y; }
         }
@@ -566,14 +670,14 @@ __global__ __launch_bounds__(MAXT) void plane_kernel(const PlaneKArgs<V> a) {
             XR[2][l] = XR[1][l]; XR[1][l] = XR[0][l];
             BR[2][l] = BR[1][l]; BR[1][l] = BR[0][l];
             if (MODE == 1) {
-                XB[0][l] = prolonged(clean(LXB[set][l]), par ? E1n : E0);     // plane s + 1: coarse plane (s + 1) >> 1
-                XR[0][l] = prolonged(clean(LXR[set][l]), E0);                 // plane s
+                XB[0][l] = prolonged(LXB[set][l], par ? E1n : E0);            // plane s + 1: coarse plane (s + 1) >> 1
+                XR[0][l] = prolonged(LXR[set][l], E0);                        // plane s
             } else {
-                XB[0][l] = clean(LXB[set][l]);
-                XR[0][l] = clean(LXR[set][l]);
+                XB[0][l] = LXB[set][l];
+                XR[0][l] = LXR[set][l];
             }
-            BR[0][l] = clean(LBR[set][l]);
-            BB[l] = clean(LBB[set][l]);
+            BR[0][l] = LBR[set][l];
+            BB[l] = LBB[set][l];
         }
         if (PEER_STEP && inner && (((pside & 1) && s < z0 + PEER_PLANES + 2) || ((pside & 2) && s >= z1 - PEER_PLANES + 1))) {
             // ONE uniform branch per step, taken by the few steps that hold a neighbour's ghost planes: red of plane
@@ -587,137 +691,163 @@ __global__ __launch_bounds__(MAXT) void plane_kernel(const PlaneKArgs<V> a) {
             E0.x = par ? E1n.x : E0.x; E0.y = par ? E1n.y : E0.y;
             SLt_kc = (s >> 1) + 2;
             SLt = slots_request(SLt_kc, par != 0);
-            Et = coarse_vals(par ? v2i{-1, -1} : SLn);            // coarse plane (s >> 1) + 1, slots committed above
+            Et = coarse_vals(par ? none : SLn);                   // coarse plane (s >> 1) + 1, slots committed above
         } else {
             SLt_kc = (s - 1) >> 1;                                // the coarse plane finished by step s + 2
             SLt = slots_request(SLt_kc, par != 0);
-            if (FIRST) DGt = coarse_vals((par || !a.cdiag) ? v2i{-1, -1} : SLd);
+            if (FIRST) DGt = coarse_vals((par || !a.cdiag) ? none : SLd);
         }
+        {
+            unsigned pXB = plane_off(1, s + LA + 1), pR = plane_off(0, s + LA), pBB = plane_off(1, s + LA - 1);
+            asm volatile("" : "+s"(pXB), "+s"(pR), "+s"(pBB));
 #pragma unroll
-        for (int l = 0; l < 2; ++l) {
-            LXB[set][l] = fetch_x(1, s + LA + 1, l);
-            LXR[set][l] = fetch_x(0, s + LA, l);
-            LBR[set][l] = fetch(bs, 0, s + LA, l);
-            LBB[set][l] = fetch(bs, 1, s + LA - 1, l);
-        }
-        if (MODE == 0) {
-#ifdef OMG_PLANE_STAMPS
-            if (a.dbg & 2) co_pending = false;
-#endif
-            if (co_pending) {
-                coarse_store(SLo, CO, CX, PB);
-                co_pending = false;
+            for (int l = 0; l < 2; ++l) {
+                LXB[set][l] = XZ ? zero2 : fetch_at(xs, pXB, l);
+                LXR[set][l] = XZ ? zero2 : fetch_at(xs, pR, l);
+                LBR[set][l] = fetch_at(bs, pR, l);
+                LBB[set][l] = fetch_at(bs, pBB, l);
             }
+        }
+        // the coarse pair the previous (odd) step finished (uniform)
+        if (MODE == 0 && !par && s - 3 >= z0 && s - 3 < z1) {
+#ifdef OMG_PLANE_STAMPS
+            if (!(a.dbg & 2))
+#endif
+            coarse_store(SLo, CO, CX, PB);
         }
 
         PLANE_STAMP(st_top)
+        // the images this step reads are complete, and the neighbours have read the ones it overwrites (see `publish` below)
+        if (WSYNC) await(s - s0);
+        PLANE_STAMP(st_bar)
+        P2<V> d_jm = zero2, d_jp = zero2;                         // stage D's values from the images, taken before they are handed over
+        V d_nb[2] = {V(0), V(0)};
+        P2<V> rb[2] = {zero2, zero2};                             // stage C's residuals (black rows of plane s - 1)
         if (live) {
             const V *const E1 = lds + (0 * 2 + par) * BUF;        // black, old, plane s
             const V *const E2 = lds + (1 * 2 + par) * BUF;        // red, new, plane s - 1
             const V *const E3 = lds + (2 * 2 + par) * BUF;        // black, new, plane s - 2
-            const bool pvB = s >= a.kv0 && s < a.kv1, pvC = s - 1 >= a.kv0 && s - 1 < a.kv1, pvD = s - 2 >= a.kv0 && s - 2 < a.kv1;
+            const bool pvB = s >= a.kv0 && s < a.kv1, pvC = s - 1 >= a.kv0 && s - 1 < a.kv1;
             // B: red sweep of plane s
             if (SWEEP) {
                 const P2<V> jm = lds_pair(E1 + idx[0] - S), jp = lds_pair(E1 + idx[1] + S);
                 const P2<V> o0 = XB[1][0], o1 = XB[1][1];
                 V num[4], quo[4];
-                bool act[4];
 #pragma unroll
                 for (int l = 0; l < 2; ++l) {
-                    const int rule = (l + s) & 1;
+                    const int rule = (l + par + (MIRROR ? 1 : 0)) & 1;    // (par, not s: a constant in the two-steps form)
                     const P2<V> O = l ? o1 : o0, Ojm = l ? o0 : jm, Ojp = l ? jp : o1;
                     const Inline<V> n = in_line(rule, O, E1[idx[l] + (rule ? 2 : -1)]);
-                    const P2<V> D = XR[0][l], Bv = BR[0][l], Km = XB[2][l], Kp = XB[0][l];
-                    const V sx = chain_tail(a, chain_head(a, Km.x, Ojm.x, n.imx), D.x, n.ipx, Ojp.x, Kp.x);
-                    const V sy = chain_tail(a, chain_head(a, Km.y, Ojm.y, n.imy), D.y, n.ipy, Ojp.y, Kp.y);
-                    num[2 * l] = Bv.x - sx;
-                    num[2 * l + 1] = Bv.y - sy;
-                    act[2 * l] = pvB && vl[l] && vx0;
-                    act[2 * l + 1] = pvB && vl[l] && vx1;
+                    const P2<V> D = XR[0][l], Bv = BR[0][l], Km = XB[MIRROR ? 0 : 2][l], Kp = XB[MIRROR ? 2 : 0][l];
+                    num[2 * l] = Bv.x - tail(l, 0, rule, head(l, 0, rule, Km.x, Ojm.x, n.imx), D.x, n.ipx, Ojp.x, Kp.x);
+                    num[2 * l + 1] = Bv.y - tail(l, 1, rule, head(l, 1, rule, Km.y, Ojm.y, n.imy), D.y, n.ipy, Ojp.y, Kp.y);
                 }
-                quotients(num, act, a.c3, rc3, fast, quo);
+                quotients(num, a.c3, rc3, fast, quo);
 #pragma unroll
                 for (int l = 0; l < 2; ++l) {
                     // openmg/solvers.py:68   x[i] = x[i] + (b[i] - Aix) / A[i, i]
-                    XR[0][l].x = act[2 * l] ? XR[0][l].x + quo[2 * l] : V(0);
-                    XR[0][l].y = act[2 * l + 1] ? XR[0][l].y + quo[2 * l + 1] : V(0);
+                    XR[0][l].x = XR[0][l].x + quo[2 * l];
+                    XR[0][l].y = XR[0][l].y + quo[2 * l + 1];
+                }
+                if (!pvB) {                                       // (uniform: a plane outside the grid stays zero)
+                    asm volatile("" ::: "memory");
+                    XR[0][0] = zero2; XR[0][1] = zero2;
                 }
             }
-            if ((SWEEP || MODE == 1) && inner && s - 1 >= z0 && s - 1 < z1) {
+            if ((SWEEP || MODE == 1) && s - 1 >= z0 && s - 1 < z1) {
                 // red of plane s - 1 became final in the previous step (stored here, not at the top: the
                 // vector memory pipe is busy with the step's loads there)
+                const unsigned base = unsigned(zphys(s - 1) * ps * W);
 #pragma unroll
-                for (int l = 0; l < 2; ++l)
-                    if (vl[l] && vx0) bstore2(ws, ((s - 1) * ps + lb[l]) * int(sizeof(V)), XR[1][l], vx1);
+                for (int l = 0; l < 2; ++l) put_pair(ws, lso[l] + base, XR[1][l]);
             }
             PLANE_STAMP(st_B)
             // C: black sweep of plane s - 1, and the residual of the rows it has just relaxed
-            P2<V> rb[2];
             {
                 const P2<V> jm = lds_pair(E2 + idx[0] - S), jp = lds_pair(E2 + idx[1] + S);
                 const P2<V> o0 = XR[1][0], o1 = XR[1][1];
-                V num[4], quo[4], head[4];
-                bool act[4];
+                V num[4], quo[4], hd[4];
                 Inline<V> nl[2];
                 P2<V> Jp[2];
 #pragma unroll
                 for (int l = 0; l < 2; ++l) {
-                    const int rule = (l + s) & 1;
+                    const int rule = (l + par + (MIRROR ? 1 : 0)) & 1;    // (par, not s: a constant in the two-steps form)
                     const P2<V> O = l ? o1 : o0, Ojm = l ? o0 : jm, Ojp = l ? jp : o1;
                     nl[l] = in_line(rule, O, E2[idx[l] + (rule ? 2 : -1)]);
                     Jp[l] = Ojp;
-                    const P2<V> D = XB[2][l], Bv = BB[l], Km = XR[2][l], Kp = XR[0][l];
-                    head[2 * l] = chain_head(a, Km.x, Ojm.x, nl[l].imx);
-                    head[2 * l + 1] = chain_head(a, Km.y, Ojm.y, nl[l].imy);
-                    num[2 * l] = Bv.x - chain_tail(a, head[2 * l], D.x, nl[l].ipx, Ojp.x, Kp.x);
-                    num[2 * l + 1] = Bv.y - chain_tail(a, head[2 * l + 1], D.y, nl[l].ipy, Ojp.y, Kp.y);
-                    act[2 * l] = pvC && vl[l] && vx0;
-                    act[2 * l + 1] = pvC && vl[l] && vx1;
+                    const P2<V> D = XB[2][l], Bv = BB[l], Km = XR[MIRROR ? 0 : 2][l], Kp = XR[MIRROR ? 2 : 0][l];
+                    hd[2 * l] = head(l, 0, rule, Km.x, Ojm.x, nl[l].imx);
+                    hd[2 * l + 1] = head(l, 1, rule, Km.y, Ojm.y, nl[l].imy);
+                    num[2 * l] = Bv.x - tail(l, 0, rule, hd[2 * l], D.x, nl[l].ipx, Ojp.x, Kp.x);
+                    num[2 * l + 1] = Bv.y - tail(l, 1, rule, hd[2 * l + 1], D.y, nl[l].ipy, Ojp.y, Kp.y);
                 }
-                if (SWEEP) quotients(num, act, a.c3, rc3, fast, quo);
+                if (SWEEP) quotients(num, a.c3, rc3, fast, quo);
 #pragma unroll
                 for (int l = 0; l < 2; ++l) {
                     if (!SWEEP) {
                         // the row's residual with the iterate as it is: the chain above IS a residual pass's
-                        rb[l].x = act[2 * l] ? num[2 * l] : V(0);
-                        rb[l].y = act[2 * l + 1] ? num[2 * l + 1] : V(0);
+                        rb[l].x = num[2 * l];
+                        rb[l].y = num[2 * l + 1];
                         continue;
                     }
-                    const P2<V> Bv = BB[l], Kp = XR[0][l];
-                    const V nx_ = act[2 * l] ? XB[2][l].x + quo[2 * l] : V(0);
-                    const V ny_ = act[2 * l + 1] ? XB[2][l].y + quo[2 * l + 1] : V(0);
+                    const int rule = (l + par + (MIRROR ? 1 : 0)) & 1;    // (par, not s: a constant in the two-steps form)
+                    const P2<V> Bv = BB[l], Kp = XR[MIRROR ? 2 : 0][l];
+                    const V nx_ = XB[2][l].x + quo[2 * l];
+                    const V ny_ = XB[2][l].y + quo[2 * l + 1];
                     // the same chain with the new x_i: what a residual pass over the updated vector computes
-                    const V tx_ = chain_tail(a, head[2 * l], nx_, nl[l].ipx, Jp[l].x, Kp.x);
-                    const V ty_ = chain_tail(a, head[2 * l + 1], ny_, nl[l].ipy, Jp[l].y, Kp.y);
-                    rb[l].x = act[2 * l] ? Bv.x - tx_ : V(0);
-                    rb[l].y = act[2 * l + 1] ? Bv.y - ty_ : V(0);
+                    rb[l].x = Bv.x - tail(l, 0, rule, hd[2 * l], nx_, nl[l].ipx, Jp[l].x, Kp.x);
+                    rb[l].y = Bv.y - tail(l, 1, rule, hd[2 * l + 1], ny_, nl[l].ipy, Jp[l].y, Kp.y);
                     XB[2][l].x = nx_;
                     XB[2][l].y = ny_;
                 }
+                if (!pvC) {                                       // (uniform)
+                    asm volatile("" ::: "memory");
+                    XB[2][0] = zero2; XB[2][1] = zero2;
+                    rb[0] = zero2; rb[1] = zero2;
+                }
             }
-            if ((SWEEP || MODE == 1) && inner && s - 2 >= z0 && s - 2 < z1) {
+            if ((SWEEP || MODE == 1) && s - 2 >= z0 && s - 2 < z1) {
                 // black of plane s - 2 became final in the previous step
+                const unsigned base = unsigned((a.nr + zphys(s - 2) * ps) * W);
 #pragma unroll
-                for (int l = 0; l < 2; ++l)
-                    if (vl[l] && vx0) bstore2(ws, (a.nr + (s - 2) * ps + lb[l]) * int(sizeof(V)), XB[3][l], vx1);
+                for (int l = 0; l < 2; ++l) put_pair(ws, lso[l] + base, XB[3][l]);
             }
             PLANE_STAMP(st_C)
-            // D: residual of the red rows of plane s - 2
+            // D's operands from the images, then the images the next step reads: after that this wave needs nothing of
+            // the old images any more and says so; the residuals and the restriction run while the neighbours catch up
+#pragma unroll
+            for (int l = 0; l < 2; ++l) d_nb[l] = E3[idx[l] + (((l + par + (MIRROR ? 1 : 0)) & 1) ? 2 : -1)];
+            d_jm = lds_pair(E3 + idx[0] - S);
+            d_jp = lds_pair(E3 + idx[1] + S);
+            V *const W1 = lds + (0 * 2 + (par ^ 1)) * BUF;
+            V *const W2 = lds + (1 * 2 + (par ^ 1)) * BUF;
+            V *const W3 = lds + (2 * 2 + (par ^ 1)) * BUF;
+#pragma unroll
+            for (int l = 0; l < 2; ++l) {
+                lds_put(W1 + idx[l], XB[0][l]);
+                lds_put(W2 + idx[l], XR[0][l]);
+                lds_put(W3 + idx[l], XB[2][l]);
+            }
+        }
+        PLANE_STAMP(st_cmp)
+        if (WSYNC) publish(s - s0 + 1);
+        else __syncthreads();
+        PLANE_STAMP(st_bar)
+        if (live) {
+            // D: residual of the red rows of plane s - 2 (of a plane outside the grid: a finite value that ends in no coarse
+            // slot and no norm)
             P2<V> rr[2];
             {
-                const P2<V> jm = lds_pair(E3 + idx[0] - S), jp = lds_pair(E3 + idx[1] + S);
+                const P2<V> jm = d_jm, jp = d_jp;
                 const P2<V> o0 = XB[3][0], o1 = XB[3][1];
 #pragma unroll
                 for (int l = 0; l < 2; ++l) {
-                    const int rule = (l + s) & 1;
+                    const int rule = (l + par + (MIRROR ? 1 : 0)) & 1;    // (par, not s: a constant in the two-steps form)
                     const P2<V> O = l ? o1 : o0, Ojm = l ? o0 : jm, Ojp = l ? jp : o1;
-                    const Inline<V> n = in_line(rule, O, E3[idx[l] + (rule ? 2 : -1)]);
-                    const P2<V> D = XR[2][l], Bv = BR[2][l], Km = XB[4][l], Kp = XB[2][l];
-                    const V sx = chain_tail(a, chain_head(a, Km.x, Ojm.x, n.imx), D.x, n.ipx, Ojp.x, Kp.x);
-                    const V sy = chain_tail(a, chain_head(a, Km.y, Ojm.y, n.imy), D.y, n.ipy, Ojp.y, Kp.y);
-                    const bool ok = pvD && vl[l];
-                    rr[l].x = (ok && vx0) ? Bv.x - sx : V(0);
-                    rr[l].y = (ok && vx1) ? Bv.y - sy : V(0);
+                    const Inline<V> n = in_line(rule, O, d_nb[l]);
+                    const P2<V> D = XR[2][l], Bv = BR[2][l], Km = XB[MIRROR ? 2 : 4][l], Kp = XB[MIRROR ? 4 : 2][l];
+                    rr[l].x = Bv.x - tail(l, 0, rule, head(l, 0, rule, Km.x, Ojm.x, n.imx), D.x, n.ipx, Ojp.x, Kp.x);
+                    rr[l].y = Bv.y - tail(l, 1, rule, head(l, 1, rule, Km.y, Ojm.y, n.imy), D.y, n.ipy, Ojp.y, Kp.y);
                 }
             }
             if (MODE == 0) {
@@ -734,77 +864,39 @@ __global__ __launch_bounds__(MAXT) void plane_kernel(const PlaneKArgs<V> a) {
                     ACC.x = madd(a.w, rr[0].x, ACC.x); ACC.y = madd(a.w, rr[0].y, ACC.y);
                     ACC.x = madd(a.w, rr[1].x, ACC.x); ACC.y = madd(a.w, rr[1].y, ACC.y);
                     ACC.x = madd(a.w, RB[1].x, ACC.x); ACC.y = madd(a.w, RB[1].y, ACC.y);
-                    if (inner && s - 2 >= z0 && s - 2 < z1) {
+                    if (s - 2 >= z0 && s - 2 < z1) {              // (uniform; the slots of a thread in the ring are none)
                         CO = ACC;
                         SLo = SLd;
                         if (PEER) CO_side = (((pside & 4) && s - 2 < z0 + 2 * PEER_CPLANES && s - 2 < a.z_base + 2 * PEER_CPLANES) ? 1 : 0) |
                                             (((pside & 8) && s - 2 >= z1 - 2 * PEER_CPLANES && s - 2 >= a.z_end - 2 * PEER_CPLANES) ? 2 : 0);
                         // the coarse level's first relaxation of a zero iterate, spelled like row_epilogue's
                         if (FIRST) {
-                            CX.x = (a.cdiag && SLd.x >= 0 && SLd.x < a.first_end) ? V(0) + (ACC.x - V(0)) / DG.x : V(0);
-                            CX.y = (a.cdiag && SLd.y >= 0 && SLd.y < a.first_end) ? V(0) + (ACC.y - V(0)) / DG.y : V(0);
+                            CX.x = (a.cdiag && SLd.x < unsigned(a.first_end) * unsigned(W)) ? V(0) + (ACC.x - V(0)) / DG.x : V(0);
+                            CX.y = (a.cdiag && SLd.y < unsigned(a.first_end) * unsigned(W)) ? V(0) + (ACC.y - V(0)) / DG.y : V(0);
                         }
-                        co_pending = true;
                     }
                 }
                 RB[0] = rb[0];
                 RB[1] = rb[1];
             }
-            if (NORM && inner) {
+            if (NORM) {
                 if (s - 1 >= z0 && s - 1 < z1) {
 #pragma unroll
                     for (int l = 0; l < 2; ++l) {
                         sq = fma(double(rb[l].x), double(rb[l].x), sq);
-                        sq = fma(double(rb[l].y), double(rb[l].y), sq);
+                        sqy = fma(double(rb[l].y), double(rb[l].y), sqy);
                     }
                 }
                 if (s - 2 >= z0 && s - 2 < z1) {
 #pragma unroll
                     for (int l = 0; l < 2; ++l) {
                         sq = fma(double(rr[l].x), double(rr[l].x), sq);
-                        sq = fma(double(rr[l].y), double(rr[l].y), sq);
+                        sqy = fma(double(rr[l].y), double(rr[l].y), sqy);
                     }
                 }
             }
-            // the images the next step reads
-            V *const W1 = lds + (0 * 2 + (par ^ 1)) * BUF;
-            V *const W2 = lds + (1 * 2 + (par ^ 1)) * BUF;
-            V *const W3 = lds + (2 * 2 + (par ^ 1)) * BUF;
-#pragma unroll
-            for (int l = 0; l < 2; ++l) {
-                lds_put(W1 + idx[l], XB[0][l]);
-                lds_put(W2 + idx[l], XR[0][l]);
-                lds_put(W3 + idx[l], XB[2][l]);
-            }
         }
         PLANE_STAMP(st_cmp)
-        // (double only: the fp32 passes were 10 % slower with it — 70 / 75.5 us against 63.5 / 68 with the barrier)
-        if (PLANE_WAVE_SYNC && sizeof(V) == 8) {
-            // A wave reads only LDS cells written by threads t +- 1 and t +- PX, i.e. by the waves within
-            // (PX + 63) / 64 of it: instead of a barrier of the whole workgroup — where eight waves waited for the
-            // slowest at every step: 1440 of a step's 7700 cycles — it publishes its progress and waits for those
-            // neighbours'.  The images are double buffered, so one wait per step covers both hazards: what a neighbour
-            // wrote for step s + 1 is there, and what it read for step s it has read.
-            const int cnt = s - s0 + 1, w = t >> 6, nw = int(blockDim.x) >> 6, reach = (PX + 63) >> 6;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            if ((t & 63) == 0) {
-                __hip_atomic_store(&s_step[w], cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                // a bounded wait, like the peer waits and the wavefront sweep's polls: a wave that never arrives (it
-                // cannot, short of a fault) sets bit 1 of *status — the host raises — instead of hanging the queue
-                for (int o = max(0, w - reach); o <= min(nw - 1, w + reach); ++o)
-                    for (unsigned polls = 0; __hip_atomic_load(&s_step[o], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < cnt; ++polls) {
-                        if (polls >= WAVE_SYNC_SPIN) {
-                            if (a.status) __hip_atomic_fetch_or(a.status, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            break;
-                        }
-                        __builtin_amdgcn_s_sleep(1);
-                    }
-            }
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        } else {
-            __syncthreads();
-        }
-        PLANE_STAMP(st_bar)
     };
     if (LA == 2) {
         for (int s = s0; s <= z1 + 1; s += 2) {          // s0 even, z1 + 1 odd: whole pairs of steps
@@ -833,9 +925,10 @@ __global__ __launch_bounds__(MAXT) void plane_kernel(const PlaneKArgs<V> a) {
         o[7] = __builtin_amdgcn_s_memtime() - st_entry;
     }
 #endif
-    if (MODE == 0 && co_pending) coarse_store(SLo, CO, CX, std::true_type());
+    if (MODE == 0 && z1 > z0) coarse_store(SLo, CO, CX, std::true_type());       // (the last step, z1 + 1, finished the chunk's last coarse plane)
     if (NORM) {
-        // fixed order: lanes of a wave (shuffle tree), then the waves in turn
+        // the squares of the tile's own cells inside the grid; fixed order: lanes of a wave (shuffle tree), then the waves in turn
+        sq = (inner && vcell) ? sq + (vx1 ? sqy : 0.0) : 0.0;
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) sq += __shfl_down(sq, off, 64);
         if ((t & 63) == 0) s_red[t >> 6] = sq;
@@ -2067,6 +2160,11 @@ void PlanePlan<V>::up(const V *x_old, V *x_new, const V *b, const Coarse &c, dou
     OMG_REQUIRE(part == 0 || (!peer && sweep && !g.dim2 && !block_level(g) && !(small_tile(g) && !out)),
                 "a pass in two launches: slabs' marching passes only");
     const int wgs = plane_part(g, k, part);
+    // the up pass of a whole grid marches from the last plane down (plane_kernel MIRROR); OMG_PLANE_MIRROR=0: upwards like the down pass
+    const char *mirror_env = getenv("OMG_PLANE_MIRROR");                 // (read per call: A/B runs flip it inside one process)
+    const bool mirror_on = !(mirror_env && mirror_env[0] == '0');
+    const bool mirror = mirror_on && !peer && part == 0 && !g.dim2 && !block_level(g) && !small_tile(g) && g.z_base == 0 && g.z_end == g.nz && g.kv0 == 0 &&
+                        g.kv1 == g.nz && g.kc_off == 0 && g.nzc * 2 == g.nz;
 #ifdef OMG_PLANE_STAMPS
     DevBuf<unsigned long long> sb;
     stamps_begin(k, g, sb);
@@ -2084,6 +2182,8 @@ void PlanePlan<V>::up(const V *x_old, V *x_new, const V *b, const Coarse &c, dou
         // postIterations = 0 (the reference's default): x_new = x_old + R^T e (+ the squares of its residual)
         OMG_REQUIRE(!peer, "plane pass without its sweep: not built for slabs with neighbours");
         if (!out && block_level(g)) launch_block<V, 1, false>(g, x_old, x_new, b, c, s);
+        else if (mirror && out) launch_plane(plane_kernel<V, 1, true, false, PLANE_LA, false, 512, false, false, true>, g, k, s);
+        else if (mirror) launch_plane(plane_kernel<V, 1, false, false, PLANE_LA, false, 512, false, false, true>, g, k, s);
         else if (out) launch_plane(plane_kernel<V, 1, true, false, PLANE_LA, false, 512, false, false>, g, k, s);
         else launch_plane(plane_kernel<V, 1, false, false, PLANE_LA, false, 512, false, false>, g, k, s);
     } else if (!peer && !out && block_level(g)) {
@@ -2094,6 +2194,9 @@ void PlanePlan<V>::up(const V *x_old, V *x_new, const V *b, const Coarse &c, dou
         else launch_plane(plane_kernel<V, 1, false, false, PLANE_LA, true>, g, k, s);
     } else if (small_tile(g) && !out) {
         launch_plane(plane_kernel<V, 1, false, false, 2, false, 128>, g, k, s);
+    } else if (mirror) {
+        if (out) launch_plane(plane_kernel<V, 1, true, false, PLANE_LA, false, 512, false, true, true>, g, k, s, wgs);
+        else launch_plane(plane_kernel<V, 1, false, false, PLANE_LA, false, 512, false, true, true>, g, k, s, wgs);
     } else if (out) {
         launch_plane(plane_kernel<V, 1, true, false, PLANE_LA>, g, k, s, wgs);
     } else {
