@@ -234,7 +234,8 @@ def class_bytes(h, meta, w):
     # zero), the up pass reads the coarse correction; 4 bytes per coarse cell for its slot in the coarse ordering
     coarse_plane = len(meta["level_rows"]) > 2 and h.level_flags(1)["plane"]
     plane_down = 3 * w * n + n_c * (w + 4 + (0 if coarse_plane else w))
-    plane_up = 3 * w * n + n_c * (w + 4)
+    # (the up pass is booked WITHOUT the 4 bytes per coarse cell of the slot map it also reads: 419 MB at 256^3)
+    plane_up = 3 * w * n + n_c * w
     csr = {
         "smoother_set_sweep": sum((w + 4) * z + 4 * (r + 1) + 3 * w * r for r, z in zip(set_rows, set_nnz)) / max(n_sets, 1) + w * n / max(n_sets, 1),
         "residual": res_csr,
@@ -280,14 +281,16 @@ def kernel_table(prof, steps, fmt, csr):
 def pmc_traffic(name, bytes_per_launch, w):
     """HBM traffic from the PMC counters cannot be collected from inside this process.  It is taken from a
     committed rocprofv3 pass of the same launch ONLY when that pass was made with the kernel sources of this
-    build (hash recorded in the profile) on the same problem."""
+    build (hash recorded in the profile) on the same problem.  Third value: the kernel's average duration in
+    that rocprofv3 run (the profiler's clock, beside this run's hipEvents)."""
     try:
         pmc = json.load(open(os.path.join(ROOT, "profiles", name)))
         if pmc.get("kernel_src_sha") == kernel_source_hash() and int(pmc["bytes_per_launch"]) == int(bytes_per_launch) and w == 8:
-            return pmc["traffic_bytes"], "NOT measured in this run: rocprofv3 --pmc passes of the same build, " + pmc["source"]
+            return (pmc["traffic_bytes"], "NOT measured in this run: rocprofv3 --pmc passes of the same build, " + pmc["source"],
+                    pmc.get("avg_duration_under_collection_us"))
     except (OSError, KeyError, ValueError):
         pass
-    return None, None
+    return None, None, None
 
 
 def config4_leg(size, grids, steps, warmup, repeats, sync_of):
@@ -380,7 +383,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--repeats", type=int, default=5,
+    ap.add_argument("--repeats", type=int, default=11,
                     help="timed regions of --steps cycles each; value = steps / median region time (BASELINE.md §3)")
     ap.add_argument("--size", type=int, default=256, help="grid extent per axis (default: BASELINE config 3)")
     ap.add_argument("--grids", type=int, default=5)
@@ -494,7 +497,7 @@ def main():
         # (DESIGN.md §5): per fine unknown 3 w (x read, b read, x written), per coarse unknown w (its right-hand
         # side) + 4 (its slot in the coarse ordering).  The operator itself costs nothing: seven coefficients.
         bytes_roof = fmt_b["plane_down"]
-        traffic, traffic_src = pmc_traffic("r04_pmc_plane_down.json", bytes_roof, w)
+        traffic, traffic_src, rocprof_us = pmc_traffic("r04_pmc_plane_down.json", bytes_roof, w)
         achieved = bytes_roof / avg_s / 1e9
         roofline = {"bound": "hbm", "kernel": "plane_kernel<down>: fine-grid red-black sweep + residual + restriction in one launch (plane.hip)",
                     "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -502,15 +505,18 @@ def main():
                     "bytes_per_launch": int(bytes_roof),
                     "bytes_definition": "per fine unknown: x read, b read, x written (3 w); per coarse unknown: right-hand side written (w) "
                                         "+ its slot in the coarse ordering read (4)",
-                    "avg_launch_us": round(avg_s * 1e6, 2), "avg_launch_us_source": "hipEvents on the kernel's own stream inside the timed regions; "
-                                                                                  "rocprofv3's duration of the same kernel: profiles/r04_bench_kernel_stats*.txt",
+                    "avg_launch_us": round(avg_s * 1e6, 2), "avg_launch_us_source": "hipEvents on the kernel's own stream inside the timed regions",
+                    "avg_launch_us_rocprof": rocprof_us,
+                    "avg_launch_us_rocprof_source": "NOT measured in this run: rocprofv3's average duration of the same kernel of the same build "
+                                                    "(profiles/r04_pmc_plane_down.json; per grid size over a whole bench run: "
+                                                    "profiles/r04_bench_kernel_stats_by_grid.txt)" if rocprof_us else None,
                     "launches_timed": launches,
                     "csr_equiv_bytes": int(csr_b["plane_down"]), "csr_equiv_GBps": round(csr_b["plane_down"] / avg_s / 1e9, 1),
                     "tiling": h.plane_info(0),
                     "level0_kernels": kernels}
     else:
         rows_c, nnz_c, res_csr, res_fmt, fmt_cov = residual_launch_bytes(h, meta, w)
-        traffic, traffic_src = pmc_traffic("r02_pmc_residual.json", res_fmt, w)
+        traffic, traffic_src, _ = pmc_traffic("r02_pmc_residual.json", res_fmt, w)
         achieved = res_fmt / avg_s / 1e9
         roofline = {"bound": "hbm", "kernel": "fine grid r = b - A x (%s)" % kernel_name(fmt_cov, "ROW_RESIDUAL", h.level_flags(0)["union_walk"]),
                     "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -538,7 +544,7 @@ def main():
     default_cycle = None
     if plane and args.smoother == "colour":
         h.resident_load(b)
-        t_d, _, n_d = timed_regions(h, syncer(h), args.steps, min(args.warmup, 3), min(repeats, 3), 1, 0, ())
+        t_d, _, n_d = timed_regions(h, syncer(h), args.steps, min(args.warmup, 3), min(repeats, 7), 1, 0, ())
         e_d = statistics.median(t_d)
         default_cycle = {"what": "same hierarchy and timed loop with the reference's default sweep counts V(1,0) "
                                  "(openmg/__init__.py:22-23), red-black ordering, plane passes",
@@ -644,10 +650,10 @@ def main():
     config4 = None
     if not args.no_config4 and args.dtype == "f64" and args.smoother == "colour":
         _PROBLEM.clear()                               # (the 256^3 7-point operator: 1.9 GB of host memory)
-        config4 = config4_leg(args.config4_size, args.grids, max(5, args.steps // 2), 3, min(repeats, 3), syncer)
+        config4 = config4_leg(args.config4_size, args.grids, max(5, args.steps // 2), 3, min(repeats, 7), syncer)
     config1 = None
     if not args.no_config1 and args.dtype == "f64" and args.smoother == "colour":
-        config1 = config1_leg(args.steps, 3, min(repeats, 3), syncer)
+        config1 = config1_leg(args.steps, 3, min(repeats, 9), syncer)
 
     cpu = None
     if not args.no_cpu:
