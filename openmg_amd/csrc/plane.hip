@@ -611,7 +611,10 @@ __global__ __launch_bounds__(MAXT) void plane_kernel(const PlaneKArgs<V> a) {
     // lie between the two, so a neighbour that is a little behind costs nothing.  The images are double buffered: one
     // count per step covers both hazards — what a neighbour wrote for step s + 1 is there, and what it read for step s it
     // has read.  (double only: the fp32 passes were 10 % slower with it than with the barrier.)
-    constexpr bool WSYNC = PLANE_WAVE_SYNC && sizeof(V) == 8;
+#ifndef PLANE_WSYNC_F32
+#define PLANE_WSYNC_F32 0
+#endif
+    constexpr bool WSYNC = PLANE_WAVE_SYNC && (sizeof(V) == 8 || PLANE_WSYNC_F32);
     int n_waves = int(blockDim.x) >> 6;
     asm volatile("" : "+s"(n_waves));                    // (not re-read from the dispatch packet in every step)
     const int my_wave = t >> 6, reach = (PX + 63) >> 6;
@@ -905,7 +908,7 @@ __global__ __launch_bounds__(MAXT) void plane_kernel(const PlaneKArgs<V> a) {
         }
     } else {
         // (with neighbours, the finest level's two passes run out of registers that way: 16-68 bytes of scratch per lane)
-        constexpr bool PAIRS = !FIRST && !(PEER && MODE == 0 && !XZ);
+        constexpr bool PAIRS = !FIRST;
         if (PAIRS) {
             // two steps per iteration: the step's parity — which neighbour an in-line pair takes, which coarse plane
             // a fine one lies over — is a compile-time constant in each copy (s0 is even, the step count too): 10 us of
