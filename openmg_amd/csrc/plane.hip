@@ -41,6 +41,12 @@
 
 #include "common.h"
 
+// -DOMG_PLANE_STAMPS: in-kernel cycle stamps per stage (tools/plane_stamps.py); -DOMG_PLANE_DBGARGS: only the switches
+// of OMG_PLANE_DBG that leave out part of a pass's memory traffic (tools/plane_dbg_times.py; wrong results, timing only)
+#if defined(OMG_PLANE_STAMPS) || defined(OMG_PLANE_DBGARGS)
+#define OMG_PLANE_DBG_ON 1
+#endif
+
 namespace omg {
 namespace {
 
@@ -72,6 +78,10 @@ template <> struct VecOf<float> {
     typedef type gtype __attribute__((aligned(4)));
 };
 
+// where a step issues its stores of x_new: 0 = behind stages B and C, 1 = at the step's top behind its loads, 2 = in front of them
+#ifndef PLANE_STORE_AT
+#define PLANE_STORE_AT 0
+#endif
 #ifndef PLANE_LOAD_AUX
 #define PLANE_LOAD_AUX 0             // cache policy of the passes' vector loads (experiments: 2 = nt)
 #endif
@@ -145,6 +155,9 @@ __device__ __forceinline__ void store2(V *p, const P2<V> &v, bool both) {
     }
 }
 
+#ifndef PLANE_LA_BIG
+#define PLANE_LA_BIG 1               // lookahead of the whole-grid passes of large levels (2: experiments; the registers do not allow it)
+#endif
 #ifndef PLANE_LA
 #define PLANE_LA 1
 #endif
@@ -195,7 +208,9 @@ struct PlaneKArgs {
     uint32_t *status;
 #ifdef OMG_PLANE_STAMPS
     unsigned long long *stamps;      // diagnostic build: per workgroup and wave, cycles spent waiting for loads / computing / at the barrier
-    int dbg;                         // ... OMG_PLANE_DBG bits: 1 no x stores, 2 no coarse stores, 4 x taken as zero (wrong results, timing only)
+#endif
+#ifdef OMG_PLANE_DBG_ON
+    int dbg;                         // ... OMG_PLANE_DBG bits: 1 no x stores, 2 no coarse stores, 4 no loads of x, 8 no loads of b (wrong results, timing only)
 #endif
 };
 
@@ -435,6 +450,9 @@ __global__ __launch_bounds__(MAXT) void plane_kernel(const PlaneKArgs<V> a) {
     // (a line of odd hx: the pair as two stores, the second one dropped where the line has ended)
     constexpr int XAUX = sizeof(V) == 8 ? PLANE_STORE_AUX : 0;
     auto put_pair = [&](const __amdgpu_buffer_rsrc_t &rs, unsigned off, const P2<V> &v) {
+#ifdef OMG_PLANE_DBG_ON
+        if (a.dbg & 1) return;
+#endif
         if (oddx) {
             bstore1<XAUX>(rs, int(off), v.x);
             bstore1<XAUX>(rs, int(vx1 ? off + unsigned(W) : unsigned(OOB)), v.y);
@@ -700,20 +718,44 @@ __global__ __launch_bounds__(MAXT) void plane_kernel(const PlaneKArgs<V> a) {
             SLt = slots_request(SLt_kc, par != 0);
             if (FIRST) DGt = coarse_vals((par || !a.cdiag) ? none : SLd);
         }
+        // x_new of the planes that became final in the previous step: red of plane s - 1, black of plane s - 2
+        auto store_final = [&]() {
+            if (!(SWEEP || MODE == 1)) return;
+            if (s - 1 >= z0 && s - 1 < z1) {
+                const unsigned base = unsigned(zphys(s - 1) * ps * W);
+#pragma unroll
+                for (int l = 0; l < 2; ++l) put_pair(ws, lso[l] + base, XR[1][l]);
+            }
+            if (s - 2 >= z0 && s - 2 < z1) {
+                const unsigned base = unsigned((a.nr + zphys(s - 2) * ps) * W);
+#pragma unroll
+                for (int l = 0; l < 2; ++l) put_pair(ws, lso[l] + base, XB[3][l]);
+            }
+        };
+        if (PLANE_STORE_AT == 2) store_final();
         {
             unsigned pXB = plane_off(1, s + LA + 1), pR = plane_off(0, s + LA), pBB = plane_off(1, s + LA - 1);
             asm volatile("" : "+s"(pXB), "+s"(pR), "+s"(pBB));
+#ifdef OMG_PLANE_DBG_ON
+            if (a.dbg & 4) { pXB = unsigned(OOB); }               // (timing experiments: no loads of x / of b — wrong results)
+            unsigned pR_b = pR;
+            if (a.dbg & 4) pR = unsigned(OOB);
+            if (a.dbg & 8) { pR_b = unsigned(OOB); pBB = unsigned(OOB); }
+#else
+            const unsigned pR_b = pR;
+#endif
 #pragma unroll
             for (int l = 0; l < 2; ++l) {
                 LXB[set][l] = XZ ? zero2 : fetch_at(xs, pXB, l);
                 LXR[set][l] = XZ ? zero2 : fetch_at(xs, pR, l);
-                LBR[set][l] = fetch_at(bs, pR, l);
+                LBR[set][l] = fetch_at(bs, pR_b, l);
                 LBB[set][l] = fetch_at(bs, pBB, l);
             }
         }
+        if (PLANE_STORE_AT == 1) store_final();
         // the coarse pair the previous (odd) step finished (uniform)
         if (MODE == 0 && !par && s - 3 >= z0 && s - 3 < z1) {
-#ifdef OMG_PLANE_STAMPS
+#ifdef OMG_PLANE_DBG_ON
             if (!(a.dbg & 2))
 #endif
             coarse_store(SLo, CO, CX, PB);
@@ -757,9 +799,8 @@ __global__ __launch_bounds__(MAXT) void plane_kernel(const PlaneKArgs<V> a) {
                     XR[0][0] = zero2; XR[0][1] = zero2;
                 }
             }
-            if ((SWEEP || MODE == 1) && s - 1 >= z0 && s - 1 < z1) {
-                // red of plane s - 1 became final in the previous step (stored here, not at the top: the
-                // vector memory pipe is busy with the step's loads there)
+            if (PLANE_STORE_AT == 0 && (SWEEP || MODE == 1) && s - 1 >= z0 && s - 1 < z1) {
+                // red of plane s - 1 became final in the previous step
                 const unsigned base = unsigned(zphys(s - 1) * ps * W);
 #pragma unroll
                 for (int l = 0; l < 2; ++l) put_pair(ws, lso[l] + base, XR[1][l]);
@@ -809,7 +850,7 @@ __global__ __launch_bounds__(MAXT) void plane_kernel(const PlaneKArgs<V> a) {
                     rb[0] = zero2; rb[1] = zero2;
                 }
             }
-            if ((SWEEP || MODE == 1) && s - 2 >= z0 && s - 2 < z1) {
+            if (PLANE_STORE_AT == 0 && (SWEEP || MODE == 1) && s - 2 >= z0 && s - 2 < z1) {
                 // black of plane s - 2 became final in the previous step
                 const unsigned base = unsigned((a.nr + zphys(s - 2) * ps) * W);
 #pragma unroll
@@ -1943,6 +1984,12 @@ PlaneKArgs<V> plane_args(const PlaneGeom &g, const V *x_old, V *x_new, const V *
     k.bc = c.b; k.xc = c.x; k.cdiag = c.diag; k.first_end = c.first_end; k.ec = c.e;
     k.status = status;
     k.zc_base = g.z_base; k.zc_stride = g.LZ; k.zc_len = g.LZ; k.zc_end = g.z_end; k.part_slot0 = 0;
+#ifdef OMG_PLANE_DBG_ON
+    {
+        const char *e = getenv("OMG_PLANE_DBG");
+        k.dbg = e ? atoi(e) : 0;
+    }
+#endif
     return k;
 }
 
@@ -1952,9 +1999,6 @@ void stamps_begin(PlaneKArgs<V> &k, const PlaneGeom &g, DevBuf<unsigned long lon
     buf.alloc(size_t(g.n_wg) * 8 * 8);
     OMG_HIP(hipMemset(buf.p, 0, buf.n * 8));
     k.stamps = buf.p;
-    const char *e = getenv("OMG_PLANE_DBG");
-    k.dbg = e ? atoi(e) : 0;
-
 }
 inline void stamps_end(const char *what, const PlaneGeom &g, DevBuf<unsigned long long> &buf, hipStream_t s) {
     OMG_HIP(hipStreamSynchronize(s));
@@ -2147,9 +2191,9 @@ void PlanePlan<V>::down(const V *x_old, V *x_new, const V *b, bool x_zero, const
         if (x_zero) launch_plane(plane_kernel<V, 0, false, true, 2, false, 128>, g, k, s);
         else launch_plane(plane_kernel<V, 0, false, false, 2, false, 128>, g, k, s);
     } else if (x_zero) {
-        launch_plane(plane_kernel<V, 0, false, true, PLANE_LA>, g, k, s, wgs);
+        launch_plane(plane_kernel<V, 0, false, true, PLANE_LA_BIG>, g, k, s, wgs);
     } else {
-        launch_plane(plane_kernel<V, 0, false, false, PLANE_LA>, g, k, s, wgs);
+        launch_plane(plane_kernel<V, 0, false, false, PLANE_LA_BIG>, g, k, s, wgs);
     }
 #ifdef OMG_PLANE_STAMPS
     stamps_end("down", g, sb, s);
@@ -2198,12 +2242,12 @@ void PlanePlan<V>::up(const V *x_old, V *x_new, const V *b, const Coarse &c, dou
     } else if (small_tile(g) && !out) {
         launch_plane(plane_kernel<V, 1, false, false, 2, false, 128>, g, k, s);
     } else if (mirror) {
-        if (out) launch_plane(plane_kernel<V, 1, true, false, PLANE_LA, false, 512, false, true, true>, g, k, s, wgs);
-        else launch_plane(plane_kernel<V, 1, false, false, PLANE_LA, false, 512, false, true, true>, g, k, s, wgs);
+        if (out) launch_plane(plane_kernel<V, 1, true, false, PLANE_LA_BIG, false, 512, false, true, true>, g, k, s, wgs);
+        else launch_plane(plane_kernel<V, 1, false, false, PLANE_LA_BIG, false, 512, false, true, true>, g, k, s, wgs);
     } else if (out) {
-        launch_plane(plane_kernel<V, 1, true, false, PLANE_LA>, g, k, s, wgs);
+        launch_plane(plane_kernel<V, 1, true, false, PLANE_LA_BIG>, g, k, s, wgs);
     } else {
-        launch_plane(plane_kernel<V, 1, false, false, PLANE_LA>, g, k, s, wgs);
+        launch_plane(plane_kernel<V, 1, false, false, PLANE_LA_BIG>, g, k, s, wgs);
     }
 #ifdef OMG_PLANE_STAMPS
     stamps_end("up", g, sb, s);
