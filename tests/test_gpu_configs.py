@@ -187,6 +187,39 @@ def test_config2_full_size_256_cubed_redblack_against_oracle():
     np.testing.assert_allclose(x, xo, rtol=1e-9, atol=1e-11)
 
 
+def test_config4_operator_family_at_128_cubed_fp32_on_the_27_point_kernels():
+    """configs[4]'s operator family well above the sizes the oracle finishes in seconds: 128^3, 5 grids, fp32 levels, the
+    whole setup on the device (omg_hierarchy_create_from_fine).  Every level below the coarsest runs the 27-point kernels;
+    size-independent checks: the iterate is the set-by-set schedule's bit for bit, batched cycles (deferred norms) give
+    the cycle-by-cycle bits, the device's norm is the norm of the iterate it returns (fp64 on the host, to fp32
+    rounding), the cycles contract, and the operation is homogeneous in b under a power of two to the bit."""
+    shape, grids = (128, 128, 128), 5
+    A0 = operators.stencil27_variable(shape)
+    b = A0 @ np.random.default_rng(12345).random(A0.shape[0])
+    b = b.astype(np.float32).astype(np.float64)
+    with _hip.Hierarchy.from_fine(A0, shape, grids - 1, "colour", dtype="float32") as h:
+        assert all(h.level_flags(l)["stencil27"] for l in range(grids - 1))
+        h.resident_load(b)
+        norms = [h.resident_cycle(1, 1) for _ in range(5)]
+        x = h.resident_fetch()
+        assert all(norms[k + 1] < norms[k] for k in range(4)), norms
+        true = float(np.linalg.norm(b - A0 @ x))
+        assert rel(norms[-1], true) < 2e-3, (norms[-1], true)          # (fp32 iterate and residual: cancellation in b - A x)
+        h.resident_load(b)
+        batch = h.resident_cycles(1, 1, 5)
+        assert np.array_equal(h.resident_fetch(), x)
+        assert all(rel(u, v) < 1e-6 for u, v in zip(batch, norms)), (batch, norms)
+        h.resident_load(4.0 * b)
+        n4 = [h.resident_cycle(1, 1) for _ in range(5)]
+        assert np.array_equal(h.resident_fetch(), 4.0 * x) and all(rel(u, 4.0 * v) < 1e-6 for u, v in zip(n4, norms))
+        h.use_plane(False)
+        assert not h.level_flags(0)["stencil27"]
+        h.resident_load(b)
+        sets = [h.resident_cycle(1, 1) for _ in range(5)]
+        assert np.array_equal(h.resident_fetch(), x)
+        assert all(rel(u, v) < 1e-6 for u, v in zip(sets, norms)), (sets, norms)
+
+
 # ------------------------------------------------------------------------------- configs[3] --
 def test_config3_problem_512_cubed_six_grids_on_one_gpu():
     """BASELINE configs[3]'s problem (512^3, 6 grids, red-black, V(1,1), fp64) — quoted on 8 GPUs, where
