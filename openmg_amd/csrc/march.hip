@@ -300,7 +300,8 @@ __global__ __launch_bounds__(128) void march_gs_kernel(MarchArgs<V> a) {
     const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(a.x, 0, vec_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t br = __builtin_amdgcn_make_buffer_rsrc(const_cast<V *>(a.b), 0, vec_bytes, 0x00020000);
     typedef BlockData<V, U> Block;
-    auto prefetch = [&](int blk, Block &d) {
+    // what a block needs of the tile's own lines and of lines nobody has relaxed yet (nothing here waits for another tile) ...
+    auto prefetch_own = [&](int blk, Block &d) {
         const int i0 = blk * U - skew;
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -317,6 +318,12 @@ __global__ __launch_bounds__(128) void march_gs_kernel(MarchArgs<V> a) {
 #pragma unroll
             for (int u = 0; u < U; ++u) d.ek[u] = buffer_at(xr, line + i0 + u + offK, V(0));
         }
+#pragma unroll
+        for (int w = 0; w < U / 4; ++w) d.codes[w] = a.codes[(size_t(tile) * a.n_grp + blk * (U / 4) + w) * 64 + lane];
+    };
+    // ... and the relaxed values of the -J / -K tiles' last lines (face slots)
+    auto prefetch_faces = [&](int blk, Block &d) {
+        const int i0 = blk * U - skew;
         if (lowJ) {
 #pragma unroll
             for (int u = 0; u < U; ++u) d.ej[u] = load_through(inJ + i0 + u);
@@ -325,8 +332,10 @@ __global__ __launch_bounds__(128) void march_gs_kernel(MarchArgs<V> a) {
 #pragma unroll
             for (int u = 0; u < U; ++u) d.ek[u] = load_through(inK + i0 + u);
         }
-#pragma unroll
-        for (int w = 0; w < U / 4; ++w) d.codes[w] = a.codes[(size_t(tile) * a.n_grp + blk * (U / 4) + w) * 64 + lane];
+    };
+    auto prefetch = [&](int blk, Block &d) {
+        prefetch_own(blk, d);
+        prefetch_faces(blk, d);
     };
 
     V xcur = a.x[line];                    // old value of the row of the lane's next step (row 0 first)
@@ -464,7 +473,11 @@ __global__ __launch_bounds__(128) void march_gs_kernel(MarchArgs<V> a) {
         if (lane == 0) lds_set(&s_ready, blk + 1);
     };
 
-    // Before anything else: wait, politely, until the tiles this one takes faces from have produced
+    // The first block's own operands are requested BEFORE the wait for the neighbours: they arrive while it lasts
+    // (a hop from tile to tile is ~2 us of load latency shorter: 62 hops at 256^3).
+    Block A, B;
+    prefetch_own(0, A);
+    // Then: wait, politely, until the tiles this one takes faces from have produced
     // their first rows.  Hundreds of tiles sit here when a sweep starts; polling all the slots of a
     // block from each of them takes memory bandwidth from the few tiles that can run ("255 pollers cut
     // chip bandwidth 37-71 %", MI355X_MICROARCH.md), so this polls ONE slot per lane and sleeps
@@ -487,8 +500,7 @@ __global__ __launch_bounds__(128) void march_gs_kernel(MarchArgs<V> a) {
         }
         if (a.dbg) t_wait += wall_clock64() - t0;
     }
-    Block A, B;
-    prefetch(0, A);
+    prefetch_faces(0, A);
     for (int blk = 0; blk < n_blk; blk += 2) {
         block(blk, A, B);
         if (blk + 1 < n_blk) block(blk + 1, B, A);
