@@ -41,6 +41,9 @@ namespace omg {
 
 namespace {
 
+#ifndef MARCH_NAP_MAX
+#define MARCH_NAP_MAX 64             // longest sleep (x 64 cycles) between two polls of a tile that waits for its first faces
+#endif
 constexpr int SYNC_WORDS = 16;     // ticket, finished tiles, error flag
 constexpr int SPIN_LIMIT = 1 << 20;
 constexpr int STORE_SPIN_LIMIT = 1 << 22;   // the storing wave's polls of its own computing wave (LDS), most of them ~1 us apart
@@ -494,7 +497,7 @@ __global__ __launch_bounds__(128) void march_gs_kernel(MarchArgs<V> a) {
             if (nap <= 1) __builtin_amdgcn_s_sleep(2);
             else if (nap <= 2) __builtin_amdgcn_s_sleep(8);
             else if (nap <= 4) __builtin_amdgcn_s_sleep(24);
-            else __builtin_amdgcn_s_sleep(64);
+            else __builtin_amdgcn_s_sleep(MARCH_NAP_MAX);
             ++nap;
             ++spins;
         }
