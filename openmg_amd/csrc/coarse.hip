@@ -253,6 +253,72 @@ __global__ __launch_bounds__(SINE_THREADS) void sine_solve_kernel(const V *__res
         if (place[q] >= 0) x[int(threadIdx.x) + q * SINE_THREADS] = V(sine_buf[place[q]]);
 }
 
+// The same solve for the 16 x 16 x 16 grid (the coarsest level of 256^3 with five grids and of 512^3 with six) with two
+// workgroup barriers instead of eight.  Sixteen waves; wave w owns PLANE k = w for the transforms along x and y (its own
+// 16 lines either way: what it wrote it reads back itself, LDS operations of a wave complete in order) and the z-LINES
+// (j = w, every i) for the transforms along z.  The right-hand side and the tables come straight from global memory
+// into the matrix instructions' operands, the result goes straight out of them; the forward transform along z, the
+// division by the eigenvalues and the inverse transform along z happen in registers (the D layout of
+// v_mfma_f64_16x16x4 — register r of lane l: row 4 r + l / 16, column l % 16 — IS the B layout of k-step r).
+// Order of the six transforms: x y z | z x y (the general kernel: x y z | x y z) — the same sums, associated as before
+// within each transform; 15.5 -> see DESIGN.md section 5e.
+template <typename V>
+__global__ __launch_bounds__(SINE_THREADS) void sine_cube16_kernel(const V *__restrict__ b, V *__restrict__ x, const double *__restrict__ tables,
+                                                                   const double *__restrict__ lambda) {
+    constexpr int N = 16, PX = N + 1;
+    __shared__ double buf[N * N * PX];                 // (i, j, k) at (k N + j) PX + i
+    const int lane = int(threadIdx.x) & 63, w = int(threadIdx.x) >> 6;
+    const int c = lane & 15, k4 = lane >> 4;
+    // A operands: lane 16 k + i holds S[i][k]; k-step ks: k = 4 ks + k4
+    double sx[4], sy[4], sz[4], lam[4], rhs[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        sx[ks] = tables[(0 * N + c) * N + 4 * ks + k4];
+        sy[ks] = tables[(1 * N + c) * N + 4 * ks + k4];
+        sz[ks] = tables[(2 * N + c) * N + 4 * ks + k4];
+        rhs[ks] = double(b[(w * N + c) * N + 4 * ks + k4]);                 // line (k = w, j = c), element i = 4 ks + k4
+        lam[ks] = lambda[((4 * ks + k4) * N + w) * N + c];                  // element (i = c, j = w, k = 4 ks + k4)
+    }
+    auto transform = [&](const double (&S)[4], const double (&in)[4]) -> v4d {
+        v4d acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(S[ks], in[ks], acc, 0, 0, 0);
+        return acc;
+    };
+    double in[4];
+    // ---- forward along x and y, plane k = w -------------------------------------------------------------------
+    v4d acc = transform(sx, rhs);                      // rows i' = 4 r + k4 of line j = c
+#pragma unroll
+    for (int r = 0; r < 4; ++r) buf[(w * N + c) * PX + 4 * r + k4] = acc[r];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) in[ks] = buf[(w * N + 4 * ks + k4) * PX + c];       // line (k = w, i = c), element j
+    acc = transform(sy, in);                           // rows j' = 4 r + k4 of line i = c
+#pragma unroll
+    for (int r = 0; r < 4; ++r) buf[(w * N + 4 * r + k4) * PX + c] = acc[r];
+    __syncthreads();
+    // ---- along z: forward, the division, inverse — lines (j = w, i = c), in registers -----------------------------
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) in[ks] = buf[((4 * ks + k4) * N + w) * PX + c];
+    acc = transform(sz, in);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) in[r] = acc[r] / lam[r];
+    acc = transform(sz, in);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) buf[((4 * r + k4) * N + w) * PX + c] = acc[r];
+    __syncthreads();
+    // ---- inverse along x and y, plane k = w; the result leaves from the matrix instruction's registers --------------
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) in[ks] = buf[(w * N + c) * PX + 4 * ks + k4];
+    acc = transform(sx, in);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) buf[(w * N + c) * PX + 4 * r + k4] = acc[r];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) in[ks] = buf[(w * N + 4 * ks + k4) * PX + c];
+    acc = transform(sy, in);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) x[(w * N + 4 * r + k4) * N + c] = V(acc[r]);
+}
+
 // Is A a constant-coefficient SYMMETRIC star stencil on a lexicographically numbered grid whose boundary rows
 // drop the entries of missing neighbours?  (extents and the four coefficients: diagonal, x, y, z couplings)
 bool detect_symmetric_star(const HostCsr &A, int64_t &nx, int64_t &ny, int64_t &nz, double (&c)[4]) {
@@ -543,7 +609,10 @@ void CoarseSolver<V>::solve(const V *b, V *x, hipStream_t s) const {
     if (P == 0) {
         const int E = std::max(sx, std::max(sy, sz)) <= 16 ? 16 : 32;
         const size_t lds = (size_t(sx + 1) * size_t(sy) * size_t(sz) + 2 + size_t(sx + sy + sz) * size_t(E)) * sizeof(double);
-        if (E == 16) {
+        static const bool cube16 = [] { const char *e = getenv("OMG_SINE_CUBE16"); return !(e && e[0] == '0'); }();
+        if (E == 16 && sx == 16 && sy == 16 && sz == 16 && cube16) {
+            hipLaunchKernelGGL((sine_cube16_kernel<V>), dim3(1), dim3(SINE_THREADS), 0, s, b, x, sine.p, lambda.p);
+        } else if (E == 16) {
             hipLaunchKernelGGL((sine_solve_kernel<V, 16>), dim3(1), dim3(SINE_THREADS), lds, s, b, x, sx, sy, sz, sine.p, lambda.p);
         } else {
             if (lds > size_t(64) * 1024)
