@@ -82,6 +82,13 @@ template <> struct VecOf<float> {
 #ifndef PLANE_STORE_AT
 #define PLANE_STORE_AT 0
 #endif
+// the last PLANE_WT_STEPS steps of a chunk store x_new with cache policy PLANE_WT_AUX (16 = sc1: written through)
+#ifndef PLANE_WT_STEPS
+#define PLANE_WT_STEPS 0
+#endif
+#ifndef PLANE_WT_AUX
+#define PLANE_WT_AUX 16
+#endif
 #ifndef PLANE_LOAD_AUX
 #define PLANE_LOAD_AUX 0             // cache policy of the passes' vector loads (experiments: 2 = nt)
 #endif
@@ -449,6 +456,9 @@ __global__ __launch_bounds__(MAXT) void plane_kernel(const PlaneKArgs<V> a) {
     };
     // (a line of odd hx: the pair as two stores, the second one dropped where the line has ended)
     constexpr int XAUX = sizeof(V) == 8 ? PLANE_STORE_AUX : 0;
+    // wt (uniform): the chunk's last planes are written THROUGH the L2 (sc1) — what a pass leaves dirty there is written
+    // back at the kernel's end, in front of the next launch (PLANE_WT_STEPS)
+    bool wt = false;
     auto put_pair = [&](const __amdgpu_buffer_rsrc_t &rs, unsigned off, const P2<V> &v) {
 #ifdef OMG_PLANE_DBG_ON
         if (a.dbg & 1) return;
@@ -456,6 +466,8 @@ __global__ __launch_bounds__(MAXT) void plane_kernel(const PlaneKArgs<V> a) {
         if (oddx) {
             bstore1<XAUX>(rs, int(off), v.x);
             bstore1<XAUX>(rs, int(vx1 ? off + unsigned(W) : unsigned(OOB)), v.y);
+        } else if (PLANE_WT_STEPS > 0 && wt) {
+            bstore2<PLANE_WT_AUX>(rs, int(off), v, true);
         } else {
             bstore2(rs, int(off), v, true);
         }
@@ -658,6 +670,7 @@ __global__ __launch_bounds__(MAXT) void plane_kernel(const PlaneKArgs<V> a) {
     auto step = [&](auto PARC, const int s, auto PB) {
         constexpr bool PEER_STEP = PEER && decltype(PB)::value;
         const int par = PARC;                            // (a compile-time constant after inlining when LA == 2)
+        if (PLANE_WT_STEPS > 0) wt = s >= z1 + 1 - PLANE_WT_STEPS;
         const int set = LA == 2 ? par : 0;               // the registers this step's loads arrive in, and its requests go to
         // The step's loads are taken HERE, behind the barrier — not where the compiler would sink the copies
         // into the state registers (the bottom of the previous step, in front of the barrier): a whole step
