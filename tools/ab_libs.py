@@ -22,12 +22,18 @@ for _ in range(5):
     t.append((time.perf_counter() - t0) / 40)
 print("MS %%.5f" %% (1e3 * sorted(t)[2]))
 ''' % ROOT
+# an argument NAME=VALUE instead of a library path: the default library with that environment variable set
 libs = sys.argv[1:3]
 n = int(sys.argv[3]) if len(sys.argv) > 3 else 5
 res = {l: [] for l in libs}
 for i in range(n):
     for l in libs:
-        env = dict(os.environ, OMG_LIB_PATH=os.path.join(ROOT, l))
+        if "=" in l and not l.endswith(".so"):
+            env = dict(os.environ)
+            for kv in l.split("+"):                 # (several variables: A=1+B=2)
+                env[kv.split("=", 1)[0]] = kv.split("=", 1)[1]
+        else:
+            env = dict(os.environ, OMG_LIB_PATH=os.path.join(ROOT, l))
         out = subprocess.run([sys.executable, "-c", CHILD], env=env, capture_output=True, text=True).stdout
         ms = [float(x.split()[1]) for x in out.splitlines() if x.startswith("MS ")]
         if ms:
