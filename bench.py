@@ -650,7 +650,7 @@ def main():
     config4 = None
     if not args.no_config4 and args.dtype == "f64" and args.smoother == "colour":
         _PROBLEM.clear()                               # (the 256^3 7-point operator: 1.9 GB of host memory)
-        config4 = config4_leg(args.config4_size, args.grids, max(5, args.steps // 2), 3, min(repeats, 7), syncer)
+        config4 = config4_leg(args.config4_size, args.grids, max(10, args.steps), 3, min(repeats, 7), syncer)
     config1 = None
     if not args.no_config1 and args.dtype == "f64" and args.smoother == "colour":
         config1 = config1_leg(args.steps, 3, min(repeats, 9), syncer)
