@@ -58,14 +58,22 @@ struct DevBuf {
     T *p = nullptr;
     size_t n = 0;
     size_t shift = 0;
+    bool owned = true;               // false: a view into another buffer (borrow())
     DevBuf() = default;
     explicit DevBuf(size_t count) { alloc(count); }
     DevBuf(const DevBuf &) = delete;
     DevBuf &operator=(const DevBuf &) = delete;
-    DevBuf(DevBuf &&o) noexcept : p(o.p), n(o.n), shift(o.shift) { o.p = nullptr; o.n = 0; o.shift = 0; }
+    DevBuf(DevBuf &&o) noexcept : p(o.p), n(o.n), shift(o.shift), owned(o.owned) { o.p = nullptr; o.n = 0; o.shift = 0; o.owned = true; }
     DevBuf &operator=(DevBuf &&o) noexcept {
-        if (this != &o) { release(); p = o.p; n = o.n; shift = o.shift; o.p = nullptr; o.n = 0; o.shift = 0; }
+        if (this != &o) { release(); p = o.p; n = o.n; shift = o.shift; owned = o.owned; o.p = nullptr; o.n = 0; o.shift = 0; o.owned = true; }
         return *this;
+    }
+    // count elements at ptr, inside an allocation somebody else owns and keeps alive (with the slack this type promises)
+    void borrow(T *ptr, size_t count) {
+        release();
+        p = ptr;
+        n = count;
+        owned = false;
     }
     ~DevBuf() { release(); }
     // shift (bytes, a multiple of 64): the vector starts that much further into its allocation — large vectors that a
@@ -90,10 +98,11 @@ struct DevBuf {
         if (poison) OMG_HIP(hipDeviceSynchronize());      // (the fill is in place before any stream writes the array)
     }
     void release() {
-        if (p) (void)hipFree(reinterpret_cast<char *>(p) - DEVBUF_SLACK - shift);
+        if (p && owned) (void)hipFree(reinterpret_cast<char *>(p) - DEVBUF_SLACK - shift);
         p = nullptr;
         n = 0;
         shift = 0;
+        owned = true;
     }
     void upload(const T *host, size_t count, hipStream_t s) {
         if (count) OMG_HIP(hipMemcpyAsync(p, host, count * sizeof(T), hipMemcpyHostToDevice, s));

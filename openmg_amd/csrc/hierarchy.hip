@@ -72,6 +72,7 @@ struct Level {
     // 27-point grid stencil with per-row coefficients under the 2x2x2 aggregation, 8-colour Gauss-Seidel (BASELINE
     // configs[4]): the cycle over this level runs the octant-layout kernels of stencil27.hip (common.h Stencil27Plan)
     std::unique_ptr<Stencil27Plan<V>> s27;
+    DevBuf<char> pool;               // OMG_VEC_POOL=1: x, tmp, b of a large plane level as three views into ONE allocation
     // A plane level's cycle never touches the row-kernel format of A and R (nor r, the block partials, the
     // sweep plan): they are built on first use — by a cycle with pre = 0 or post = 0, a single-level
     // operation, a format query — from the operator the plan describes (ensure_format; OMG_PLANE_LAZY=0: at creation)
@@ -383,6 +384,28 @@ void coarse_solve_level(Hier<V> *h) {
 enum NormState { NORM_NONE = 0, NORM_LAST_SET = 1, NORM_PLANE = 2, NORM_S27 = 3 };
 
 // Does the cycle over this level run the 27-point kernels of stencil27.hip?  (Switched with the plane passes.)
+// The three vectors a large fused level's passes stream side by side (x, its out-of-place twin, b) come out of ONE
+// allocation, each starting 2 MiB-aligned + its stagger (common.h vector_stagger): one request to the driver instead of
+// three.  Measured at 256^3 over seven alternating processes (tools/ab_libs.py): 0.2758 against 0.2832 ms per cycle, and
+// the spread between processes shrinks from 1.3 % to 0.7 % — where three separate allocations land relative to each
+// other is what made a process "fast" or "slow".  OMG_VEC_POOL=0: three allocations.
+template <typename V>
+bool pooled_vectors(Level<V> &L) {
+    static const bool on = [] { const char *e = getenv("OMG_VEC_POOL"); return !(e && e[0] == '0'); }();
+    if (!on || !(L.plane || L.s27) || L.n < (int64_t(1) << 20)) return false;
+    if (L.pool.p) return true;
+    auto env = [](const char *name, size_t dflt) { const char *e = getenv(name); return e && e[0] ? size_t(atoll(e)) / 64 * 64 : dflt; };
+    const size_t off1 = env("OMG_POOL_OFF1", vector_stagger(1)), off2 = env("OMG_POOL_OFF2", vector_stagger(2)), pad = env("OMG_POOL_PAD", 0);
+    const size_t MB2 = size_t(2) << 20, bytes = size_t(L.n) * sizeof(V);
+    const size_t span = (bytes + 2 * DEVBUF_SLACK + std::max(off1, off2) + MB2 - 1) / MB2 * MB2 + pad;
+    L.pool.alloc(3 * span);
+    char *base = L.pool.p;
+    L.x.borrow(reinterpret_cast<V *>(base + DEVBUF_SLACK), size_t(L.n));
+    L.tmp.borrow(reinterpret_cast<V *>(base + span + DEVBUF_SLACK + off1), size_t(L.n));
+    L.b.borrow(reinterpret_cast<V *>(base + 2 * span + DEVBUF_SLACK + off2), size_t(L.n));
+    return true;
+}
+
 template <typename V>
 bool use_s27(const Hier<V> *h, const Level<V> &L) {
     return L.s27 && !h->no_plane;
@@ -881,14 +904,16 @@ std::unique_ptr<Hier<V>> create(int n_levels, const omg_csr *A, const omg_csr *R
                 L.r_out.upload(co.inv.data(), co.inv.size(), h->stream);
                 OMG_HIP(hipStreamSynchronize(h->stream));
             }
-            if (L.plane) L.tmp.alloc(L.n, vector_stagger(1));
-            if (L.s27) L.tmp.alloc(L.n);
+            if (L.plane && !pooled_vectors(L)) L.tmp.alloc(L.n, vector_stagger(1));
+            if (L.s27 && !pooled_vectors(L)) L.tmp.alloc(L.n);
             if ((L.plane || L.s27) && !getenv_flag0("OMG_PLANE_LAZY")) L.format_pending = true;
             else if (L.s27) { L.format_pending = true; ensure_format(h.get(), l); }      // (from the padded operator)
             else build_format(h.get(), l, A[l], R[l]);
         }
-        L.x.alloc(std::max<int64_t>(L.n, 1));
-        L.b.alloc(std::max<int64_t>(L.n, 1), L.plane ? vector_stagger(2) : 0);
+        if (!L.pool.p) {
+            L.x.alloc(std::max<int64_t>(L.n, 1));
+            L.b.alloc(std::max<int64_t>(L.n, 1), L.plane ? vector_stagger(2) : 0);
+        }
         // (finite from the start: the 27-point sweeps multiply the slot of a neighbour that does not exist — a zero
         // coefficient — with whatever the vectors hold at the index the slot's shift lands on)
         L.x.zero(h->stream);
@@ -1031,12 +1056,14 @@ std::unique_ptr<Hier<V>> create_from_fine(const omg_csr &A0, int dim, const int6
                 L.r_out.alloc(size_t(h->lv[size_t(l) + 1].n));
                 fill_ordering_device(co.closed_form, co.cf_nx, co.cf_ny, co.cf_nz, nullptr, L.r_out.p, h->stream);
             }
-            if (L.plane) L.tmp.alloc(L.n, vector_stagger(1));
-            if (L.s27) L.tmp.alloc(L.n);
+            if (L.plane && !pooled_vectors(L)) L.tmp.alloc(L.n, vector_stagger(1));
+            if (L.s27 && !pooled_vectors(L)) L.tmp.alloc(L.n);
             L.format_pending = true;
         }
-        L.x.alloc(std::max<int64_t>(L.n, 1));
-        L.b.alloc(std::max<int64_t>(L.n, 1), L.plane ? vector_stagger(2) : 0);
+        if (!L.pool.p) {
+            L.x.alloc(std::max<int64_t>(L.n, 1));
+            L.b.alloc(std::max<int64_t>(L.n, 1), L.plane ? vector_stagger(2) : 0);
+        }
         // (finite from the start: the 27-point sweeps multiply the slot of a neighbour that does not exist — a zero
         // coefficient — with whatever the vectors hold at the index the slot's shift lands on)
         L.x.zero(h->stream);
