@@ -69,10 +69,13 @@ struct DevBuf {
         return *this;
     }
     // count elements at ptr, inside an allocation somebody else owns and keeps alive (with the slack this type promises)
-    void borrow(T *ptr, size_t count) {
+    // (shift_bytes: how far behind the owner's first element the view starts — the allocation's base is then
+    // p - DEVBUF_SLACK - shift for views as for owners: dist.hip's IPC export)
+    void borrow(T *ptr, size_t count, size_t shift_bytes = 0) {
         release();
         p = ptr;
         n = count;
+        shift = shift_bytes;
         owned = false;
     }
     ~DevBuf() { release(); }

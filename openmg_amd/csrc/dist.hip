@@ -20,6 +20,7 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <array>
 #include <cmath>
 #include <cstring>
 #include <memory>
@@ -849,6 +850,7 @@ struct PDLevel {
     int nx = 0, ny = 0, nzo = 0;              // cells per line, lines per plane, owned planes
     int64_t pc = 0, n_ext = 0;                // one colour's values per plane; values of the extended slab
     PlanePlan<double> plan;
+    DevBuf<char> pool;                        // x, tmp, b are views into it (one allocation), or empty
     DevBuf<double> x, tmp, b;
     double *xp = nullptr, *tp = nullptr;
     DevBuf<int32_t> cmap;                     // coarse slab (natural, extended) -> slot in the next level's ordering (not the last level)
@@ -1439,7 +1441,22 @@ std::unique_ptr<PlaneDist> pd_create(int rank, int n_ranks, int nx, int ny, int 
         double c[7];
         for (int e = 0; e < 7; ++e) c[e] = coef7[7 * l + e];
         L.plan.build_slab(lx, ly, lz, PD_GHOST, PD_GHOST, rank == 0, rank == n_ranks - 1, c, w);
-        L.x.alloc(size_t(L.n_ext)); L.tmp.alloc(size_t(L.n_ext), vector_stagger(1)); L.b.alloc(size_t(L.n_ext), vector_stagger(2));
+        {
+            // OMG_DIST_VEC_POOL=1: one allocation for the three vectors the passes stream side by side, as hierarchy.hip
+            // pooled_vectors does for whole grids (there: -2.6 % per cycle).  Measured on a slab with its ghost planes
+            // (`bench.py --dist 1`): 0.2944 against 0.2905 ms per cycle — slower, so three allocations stay the default here.
+            static const bool pool_on = [] { const char *e = getenv("OMG_DIST_VEC_POOL"); return e && e[0] == '1'; }();
+            if (pool_on) {
+                const size_t MB2 = size_t(2) << 20, bytes = size_t(L.n_ext) * sizeof(double);
+                const size_t span = (bytes + 2 * DEVBUF_SLACK + vector_stagger(2) + MB2 - 1) / MB2 * MB2;
+                L.pool.alloc(3 * span);
+                L.x.borrow(reinterpret_cast<double *>(L.pool.p), size_t(L.n_ext), 0);
+                L.tmp.borrow(reinterpret_cast<double *>(L.pool.p + span + vector_stagger(1)), size_t(L.n_ext), span + vector_stagger(1));
+                L.b.borrow(reinterpret_cast<double *>(L.pool.p + 2 * span + vector_stagger(2)), size_t(L.n_ext), 2 * span + vector_stagger(2));
+            } else {
+                L.x.alloc(size_t(L.n_ext)); L.tmp.alloc(size_t(L.n_ext), vector_stagger(1)); L.b.alloc(size_t(L.n_ext), vector_stagger(2));
+            }
+        }
         L.x.zero(d->stream); L.tmp.zero(d->stream); L.b.zero(d->stream);
         L.xp = L.x.p; L.tp = L.tmp.p;
         lx /= 2; ly /= 2; lz /= 2;
@@ -1955,12 +1972,21 @@ int omg_pdist_p2p_open(omg_pdist *d, int peer_rank, const void *handles64, int c
         std::vector<void *> bufs, own;
         std::vector<size_t> shift;
         pd_own_buffers(dd, own, &shift);                      // (the peer's vectors sit in their allocations as mine do)
+        // (vectors that share an allocation share a handle: it is opened once)
+        std::vector<std::pair<std::array<char, 64>, void *>> opened;
         for (int i = 0; i < count; ++i) {
-            hipIpcMemHandle_t h;
-            std::memcpy(&h, static_cast<const char *>(handles64) + 64 * i, 64);
+            std::array<char, 64> key;
+            std::memcpy(key.data(), static_cast<const char *>(handles64) + 64 * i, 64);
             void *base = nullptr;
-            OMG_HIP(hipIpcOpenMemHandle(&base, h, hipIpcMemLazyEnablePeerAccess));
-            P.mapped.push_back(base);
+            for (const auto &o : opened)
+                if (o.first == key) base = o.second;
+            if (!base) {
+                hipIpcMemHandle_t h;
+                std::memcpy(&h, key.data(), 64);
+                OMG_HIP(hipIpcOpenMemHandle(&base, h, hipIpcMemLazyEnablePeerAccess));
+                P.mapped.push_back(base);
+                opened.emplace_back(key, base);
+            }
             bufs.push_back(static_cast<char *>(base) + DEVBUF_SLACK + shift[size_t(i)]);
         }
         pd_attach(dd, peer_rank, bufs);
