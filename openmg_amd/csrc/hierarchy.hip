@@ -394,15 +394,19 @@ bool pooled_vectors(Level<V> &L) {
     static const bool on = [] { const char *e = getenv("OMG_VEC_POOL"); return !(e && e[0] == '0'); }();
     if (!on || !(L.plane || L.s27) || L.n < (int64_t(1) << 20)) return false;
     if (L.pool.p) return true;
-    auto env = [](const char *name, size_t dflt) { const char *e = getenv(name); return e && e[0] ? size_t(atoll(e)) / 64 * 64 : dflt; };
+    auto env = [](const char *name, size_t dflt) { const char *e = getenv(name); return e && e[0] ? (size_t(atoll(e)) < 64 ? size_t(atoll(e)) : size_t(atoll(e)) / 64 * 64) : dflt; };
     const size_t off1 = env("OMG_POOL_OFF1", vector_stagger(1)), off2 = env("OMG_POOL_OFF2", vector_stagger(2)), pad = env("OMG_POOL_PAD", 0);
     const size_t MB2 = size_t(2) << 20, bytes = size_t(L.n) * sizeof(V);
     const size_t span = (bytes + 2 * DEVBUF_SLACK + std::max(off1, off2) + MB2 - 1) / MB2 * MB2 + pad;
     L.pool.alloc(3 * span);
     char *base = L.pool.p;
+    // order: x, b, x's twin (OMG_POOL_ORDER=0: x, twin, b).  With b in the middle four of four processes ran 0.260 ms per
+    // cycle where the other order gave 0.266-0.274 on the same box; on a second box both orders fell into two populations
+    // (0.260 / 0.273) from process to process: where the allocation lands physically still matters, and is not ours to choose
+    const bool b_mid = env("OMG_POOL_ORDER", 1) != 0;
     L.x.borrow(reinterpret_cast<V *>(base + DEVBUF_SLACK), size_t(L.n));
-    L.tmp.borrow(reinterpret_cast<V *>(base + span + DEVBUF_SLACK + off1), size_t(L.n));
-    L.b.borrow(reinterpret_cast<V *>(base + 2 * span + DEVBUF_SLACK + off2), size_t(L.n));
+    L.tmp.borrow(reinterpret_cast<V *>(base + (b_mid ? 2 : 1) * span + DEVBUF_SLACK + off1), size_t(L.n));
+    L.b.borrow(reinterpret_cast<V *>(base + (b_mid ? 1 : 2) * span + DEVBUF_SLACK + off2), size_t(L.n));
     return true;
 }
 
