@@ -24,4 +24,12 @@ for _ in range(20):
     h.resident_cycle(1, 1, want_norm=False)
 prof = h.profile_read()
 h.profile_enable(False)
-print("steady ms per cycle %.4f  %s" % (1e3 * sorted(t)[2], {k: round(1e3 * ms / c, 1) for k, (c, ms) in prof.items() if c and "plane" in k}), flush=True)
+xcc = ""
+if os.path.exists("/tmp/xcc_probe.so"):
+    import ctypes
+    lib = ctypes.CDLL("/tmp/xcc_probe.so")
+    buf = (ctypes.c_uint * 480)()
+    if lib.xcc_map(240, 512, 110 * 1024, buf) == 0:
+        ids = [buf[2 * i] & 15 for i in range(240)]
+        xcc = " xcc of workgroups 0..15: %s; b %% 8 holds for %d of 240" % ("".join(str(v) for v in ids[:16]), sum(1 for i, v in enumerate(ids) if v == (i + ids[0]) % 8))
+print("steady ms per cycle %.4f  %s" % (1e3 * sorted(t)[2], {k: round(1e3 * ms / c, 1) for k, (c, ms) in prof.items() if c and "plane" in k}) + xcc, flush=True)
