@@ -353,7 +353,7 @@ __global__ void plane_wait_kernel(const uint32_t *f0, const uint32_t *f1, const 
 // SWEEP = false: the pass without its relaxation — a cycle with preIterations = 0 (down: residual of the iterate as
 // it is + restriction; x_new is not written) or postIterations = 0, the reference's default (openmg/__init__.py:22-23;
 // up: x_new = x_old + R^T e and the squares of ITS residual): the same pipeline, stages B and C form no quotient
-// MIRROR (up, whole grids): the march runs from the grid's LAST plane to its first — plane index and coarse plane index
+// MIRROR (up; whole grids, and slabs whose neighbours are reached by exchanges): the march runs from the LAST plane to the first — plane index and coarse plane index
 // mirrored where global memory is addressed, the two k neighbours exchanged in the row chains, the in-line rule's parity
 // flipped (nz is even) — so that the pass starts where the down pass before it ended and ends where the next cycle's
 // down pass starts: what those passes touched last is the likeliest to be still in the memory-side cache.  A sweep of
@@ -439,7 +439,9 @@ __global__ __launch_bounds__(MAXT) void plane_kernel(const PlaneKArgs<V> a) {
 
     // a pair of the level vector: colour (0 red, 1 black), plane k (uniform), line ja + l; 0 outside the grid
     auto zphys = [&](int k) -> int { return MIRROR ? a.nz - 1 - k : k; };          // the plane a march index stands for
-    auto zcphys = [&](int kc) -> int { return MIRROR ? a.nzc - 1 - kc : kc; };
+    // the coarse plane (index into the coarse vectors, which may carry more ghost planes than half the fine ones: kc_off)
+    // under the fine planes 2 kc, 2 kc + 1 of the march
+    auto cplane = [&](int kc) -> int { return MIRROR ? (a.nz / 2 - 1 + a.kc_off) - kc : kc + a.kc_off; };
     auto plane_off = [&](int colour, int k) -> unsigned {
         return (k >= a.kv0 && k < a.kv1) ? unsigned(((colour ? a.nr : 0) + zphys(k) * ps) * W) : unsigned(OOB);
     };
@@ -483,14 +485,14 @@ __global__ __launch_bounds__(MAXT) void plane_kernel(const PlaneKArgs<V> a) {
     // ... in two halves, so that the load has no consumer in the step that issues it: the request
     // (raw words of the slot map; nothing is fetched for a lane that needs none) and, a step later, the offsets
     auto slots_request = [&](int kc, bool want) -> v2u {
-        kc += a.kc_off;
+        kc = cplane(kc);
         const bool ok = want && a.cmap && kc >= 0 && kc < a.nzc;
-        return __builtin_amdgcn_raw_buffer_load_b64(ms, int(cb4 + (ok ? unsigned(zcphys(kc) * a.nyc * a.nxc * 4) : unsigned(OOB))), 0, 0);   // (second word unused when !vx1)
+        return __builtin_amdgcn_raw_buffer_load_b64(ms, int(cb4 + (ok ? unsigned(kc * a.nyc * a.nxc * 4) : unsigned(OOB))), 0, 0);   // (second word unused when !vx1)
     };
     auto slots_commit = [&](const v2u &m, int kc, bool want) -> v2u {
-        kc += a.kc_off;
+        kc = cplane(kc);
         const bool ok = want && kc >= 0 && kc < a.nzc;
-        const unsigned u = ok ? 0u : unsigned(OOB), cn = ok ? unsigned(zcphys(kc) * a.nyc * a.nxc * W) : 0u;
+        const unsigned u = ok ? 0u : unsigned(OOB), cn = ok ? unsigned(kc * a.nyc * a.nxc * W) : 0u;
         // (no slot map: the coarse level in natural order.  cb4 of a lane without coarse cells is an offset behind the
         // buffers already, and stays one under the masks)
         const unsigned s0_ = a.cmap ? m.x * unsigned(W) : cn + cb4 * unsigned(W / 4), s1_ = a.cmap ? m.y * unsigned(W) : cn + cb4 * unsigned(W / 4) + unsigned(W);
@@ -2223,8 +2225,11 @@ void PlanePlan<V>::up(const V *x_old, V *x_new, const V *b, const Coarse &c, dou
     // the up pass of a whole grid marches from the last plane down (plane_kernel MIRROR); OMG_PLANE_MIRROR=0: upwards like the down pass
     const char *mirror_env = getenv("OMG_PLANE_MIRROR");                 // (read per call: A/B runs flip it inside one process)
     const bool mirror_on = !(mirror_env && mirror_env[0] == '0');
-    const bool mirror = mirror_on && !peer && part == 0 && !g.dim2 && !block_level(g) && !small_tile(g) && g.z_base == 0 && g.z_end == g.nz && g.kv0 == 0 &&
-                        g.kv1 == g.nz && g.kc_off == 0 && g.nzc * 2 == g.nz;
+    // (slabs too, where the neighbours are reached by exchanges and not by the pass's own stores: as many ghost planes in
+    // front of the owned ones as behind them, so the mirrored march covers the same planes; the planes that exist in the
+    // global grid, kv0 .. kv1, are handed over in march coordinates)
+    const bool mirror = mirror_on && !peer && part == 0 && !g.dim2 && !block_level(g) && !small_tile(g) && (g.nz & 1) == 0 && g.z_base == g.nz - g.z_end;
+    if (mirror) { k.kv0 = g.nz - g.kv1; k.kv1 = g.nz - g.kv0; }
 #ifdef OMG_PLANE_STAMPS
     DevBuf<unsigned long long> sb;
     stamps_begin(k, g, sb);
