@@ -1450,9 +1450,10 @@ std::unique_ptr<PlaneDist> pd_create(int rank, int n_ranks, int nx, int ny, int 
                 const size_t MB2 = size_t(2) << 20, bytes = size_t(L.n_ext) * sizeof(double);
                 const size_t span = (bytes + 2 * DEVBUF_SLACK + vector_stagger(2) + MB2 - 1) / MB2 * MB2;
                 L.pool.alloc(3 * span);
+                // (order x, b, x's twin, as hierarchy.hip has it)
                 L.x.borrow(reinterpret_cast<double *>(L.pool.p), size_t(L.n_ext), 0);
-                L.tmp.borrow(reinterpret_cast<double *>(L.pool.p + span + vector_stagger(1)), size_t(L.n_ext), span + vector_stagger(1));
-                L.b.borrow(reinterpret_cast<double *>(L.pool.p + 2 * span + vector_stagger(2)), size_t(L.n_ext), 2 * span + vector_stagger(2));
+                L.b.borrow(reinterpret_cast<double *>(L.pool.p + span + vector_stagger(2)), size_t(L.n_ext), span + vector_stagger(2));
+                L.tmp.borrow(reinterpret_cast<double *>(L.pool.p + 2 * span + vector_stagger(1)), size_t(L.n_ext), 2 * span + vector_stagger(1));
             } else {
                 L.x.alloc(size_t(L.n_ext)); L.tmp.alloc(size_t(L.n_ext), vector_stagger(1)); L.b.alloc(size_t(L.n_ext), vector_stagger(2));
             }
