@@ -262,6 +262,14 @@ __global__ __launch_bounds__(SINE_THREADS) void sine_solve_kernel(const V *__res
 // v_mfma_f64_16x16x4 — register r of lane l: row 4 r + l / 16, column l % 16 — IS the B layout of k-step r).
 // Order of the six transforms: x y z | z x y (the general kernel: x y z | x y z) — the same sums, associated as before
 // within each transform; 15.5 -> see DESIGN.md section 5e.
+// Lanes of ONE wave exchange values through LDS: the stores of all lanes must be complete and visible before any lane's
+// loads of the transposed addresses (nothing kept the compiler from reordering the may-alias accesses).
+__device__ __forceinline__ void wave_lds_exchange() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 template <typename V>
 __global__ __launch_bounds__(SINE_THREADS) void sine_cube16_kernel(const V *__restrict__ b, V *__restrict__ x, const double *__restrict__ tables,
                                                                    const double *__restrict__ lambda) {
@@ -290,6 +298,7 @@ __global__ __launch_bounds__(SINE_THREADS) void sine_cube16_kernel(const V *__re
     v4d acc = transform(sx, rhs);                      // rows i' = 4 r + k4 of line j = c
 #pragma unroll
     for (int r = 0; r < 4; ++r) buf[(w * N + c) * PX + 4 * r + k4] = acc[r];
+    wave_lds_exchange();
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) in[ks] = buf[(w * N + 4 * ks + k4) * PX + c];       // line (k = w, i = c), element j
     acc = transform(sy, in);                           // rows j' = 4 r + k4 of line i = c
@@ -312,6 +321,7 @@ __global__ __launch_bounds__(SINE_THREADS) void sine_cube16_kernel(const V *__re
     acc = transform(sx, in);
 #pragma unroll
     for (int r = 0; r < 4; ++r) buf[(w * N + c) * PX + 4 * r + k4] = acc[r];
+    wave_lds_exchange();
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) in[ks] = buf[(w * N + 4 * ks + k4) * PX + c];
     acc = transform(sy, in);

@@ -108,10 +108,17 @@ struct Hier {
     bool no_fuse = [] { const char *e = getenv("OMG_NO_FUSE"); return e && e[0] == '1'; }();
     // OMG_PLANE=0 (at creation): no plane-pipelined passes; set by omg_hierarchy_use_plane afterwards
     bool no_plane = false;
-    // graph
+    // graph: a captured cycle bakes the levels' current / scratch vector pointers in, and a cycle may leave them
+    // swapped (out-of-place sweeps: Jacobi, the 27-point pair launches, the plane passes) — so a graph is keyed by the
+    // pointer state it was captured FROM and records the state it leaves; a cycle with an odd number of swaps gets a
+    // second graph for the other phase (one graph replayed from the wrong phase recomputed cycle 1 forever)
+    struct GraphSlot {
+        hipGraphExec_t exec = nullptr;
+        int pre = -1, post = -1;
+        std::vector<V *> before, after;      // xp, tp of every level
+    };
     bool want_graph = false;
-    hipGraphExec_t gexec = nullptr;
-    int g_pre = -1, g_post = -1;
+    std::vector<GraphSlot> graphs;
     // profile
     unsigned profiling = 0;   // bit c set: time level-0 launches of class c
     std::vector<ProfEvent> events;
@@ -123,7 +130,7 @@ struct Hier {
     Hier(const Hier &) = delete;
     Hier &operator=(const Hier &) = delete;
     ~Hier() {
-        if (gexec) (void)hipGraphExecDestroy(gexec);
+        for (auto &g : graphs) if (g.exec) (void)hipGraphExecDestroy(g.exec);
         for (auto &e : events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
         for (auto &e : event_pool) (void)hipEventDestroy(e);
         if (own) (void)hipStreamDestroy(own);
@@ -460,8 +467,9 @@ int cycle_body(Hier<V> *h, int l, int pre, int post, bool want_norm = false, dou
         // 27-point per-row-coefficient level (stencil27.hip): sweeps as four pair launches, out of place; the last
         // pre-smoothing sweep leaves the residuals of its final rows, the others' are formed inside the restriction
         Stencil27Plan<V> &P = *L.s27;
-        const bool child_fused = l + 1 < last && (use_s27(h, C) || use_plane(h, C, pre, post));
-        const bool child_zero = child_fused && pre >= 1;       // such a child's first sweep never reads its zero iterate
+        // (a 27-point child's first sweep never reads its zero iterate; a plane child's down pass only when it IS the
+        // cycle's one pre-smoothing sweep — with more, smooth_level runs before it on the iterate as stored)
+        const bool child_zero = l + 1 < last && ((use_s27(h, C) && pre >= 1) || (use_plane(h, C, pre, post) && pre == 1));
         bool zero_now = x_zero;
         if (x_zero && pre == 0) {
             OMG_HIP(hipMemsetAsync(L.xp, 0, size_t(L.n) * sizeof(V), h->stream));
@@ -674,9 +682,16 @@ double read_norm(Hier<V> *h) {
 
 template <typename V>
 void drop_graph(Hier<V> *h) {
-    if (h->gexec) (void)hipGraphExecDestroy(h->gexec);
-    h->gexec = nullptr;
-    h->g_pre = h->g_post = -1;
+    for (auto &g : h->graphs) if (g.exec) (void)hipGraphExecDestroy(g.exec);
+    h->graphs.clear();
+}
+
+template <typename V>
+std::vector<V *> pointer_state(const Hier<V> *h) {
+    std::vector<V *> s;
+    s.reserve(2 * h->lv.size());
+    for (const Level<V> &L : h->lv) { s.push_back(L.xp); s.push_back(L.tp); }
+    return s;
 }
 
 // One level-0 cycle + residual norm into norm_dev; optionally replayed from a hipGraph.
@@ -692,11 +707,17 @@ void run_cycle0(Hier<V> *h, int pre, int post) {
         body();
         return;
     }
-    if (!h->gexec || h->g_pre != pre || h->g_post != post) {
-        drop_graph(h);
-        // Jacobi swaps xp/tp: an odd number of sweeps per cycle would leave the graph's
-        // baked-in pointers out of phase with the next replay.
-        if (h->smoother == OMG_SMOOTH_JACOBI && ((pre + post) & 1)) { body(); return; }
+    const std::vector<V *> cur = pointer_state(h);
+    auto restore = [&](const std::vector<V *> &st) {
+        for (size_t l = 0; l < h->lv.size(); ++l) { h->lv[l].xp = st[2 * l]; h->lv[l].tp = st[2 * l + 1]; }
+    };
+    typename Hier<V>::GraphSlot *slot = nullptr;
+    for (auto &g : h->graphs)
+        if (g.pre == pre && g.post == post && g.before == cur) slot = &g;
+    if (!slot) {
+        // (two phases of one (pre, post) at most: anything else — other sweep counts, a state no captured cycle
+        // leaves — starts over)
+        if (h->graphs.size() >= 2 || (!h->graphs.empty() && (h->graphs[0].pre != pre || h->graphs[0].post != post))) drop_graph(h);
         hipGraph_t g = nullptr;
         OMG_HIP(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
         try {
@@ -704,19 +725,26 @@ void run_cycle0(Hier<V> *h, int pre, int post) {
         } catch (...) {
             (void)hipStreamEndCapture(h->stream, &g);
             if (g) (void)hipGraphDestroy(g);
+            restore(cur);
             throw;
         }
         OMG_HIP(hipStreamEndCapture(h->stream, &g));
-        hipError_t e = hipGraphInstantiate(&h->gexec, g, nullptr, nullptr, 0);
+        typename Hier<V>::GraphSlot ns;
+        ns.pre = pre;
+        ns.post = post;
+        ns.before = cur;
+        ns.after = pointer_state(h);               // (the capture ran the host side of the cycle: the swaps are made)
+        hipError_t e = hipGraphInstantiate(&ns.exec, g, nullptr, nullptr, 0);
         (void)hipGraphDestroy(g);
         if (e != hipSuccess) {
-            h->gexec = nullptr;
+            restore(cur);
             throw Error(OMG_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e));
         }
-        h->g_pre = pre;
-        h->g_post = post;
+        h->graphs.push_back(std::move(ns));
+        slot = &h->graphs.back();
     }
-    OMG_HIP(hipGraphLaunch(h->gexec, h->stream));
+    OMG_HIP(hipGraphLaunch(slot->exec, h->stream));
+    restore(slot->after);
 }
 
 template <typename V>

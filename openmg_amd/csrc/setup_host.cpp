@@ -4,6 +4,8 @@
 #include <atomic>
 #include <cstring>
 #include <string>
+#include <map>
+#include <memory>
 #include <mutex>
 #include <thread>
 #include <unordered_map>
@@ -946,14 +948,27 @@ void download_staged(void *host, const void *dev, size_t bytes, hipStream_t s) {
         OMG_HIP(hipStreamSynchronize(s));
         return;
     }
-    // two pinned buffers and their events, made once per process and shared (one copy at a time)
-    static std::mutex mu;
-    static void *pin[2] = {nullptr, nullptr};
-    static hipEvent_t ev[2] = {nullptr, nullptr};
-    std::lock_guard<std::mutex> lock(mu);
+    // two pinned buffers and their events per DEVICE, made on first use and shared (one copy at a time per device: events
+    // belong to the device that was current when they were made, and a process may drive several — PlaneDistGroup,
+    // replicated hierarchies)
+    struct Staging { std::mutex mu; void *pin[2] = {nullptr, nullptr}; hipEvent_t ev[2] = {nullptr, nullptr}; };
+    static std::mutex table_mu;
+    static std::map<int, std::unique_ptr<Staging>> table;
+    int device = 0;
+    OMG_HIP(hipGetDevice(&device));
+    Staging *st;
+    {
+        std::lock_guard<std::mutex> lock(table_mu);
+        auto &slot = table[device];
+        if (!slot) slot.reset(new Staging);
+        st = slot.get();
+    }
+    std::lock_guard<std::mutex> lock(st->mu);
+    void **pin = st->pin;
+    hipEvent_t *ev = st->ev;
     if (!pin[0]) {
         for (int i = 0; i < 2; ++i) {
-            OMG_HIP(hipHostMalloc(&pin[i], CH, hipHostMallocDefault));
+            OMG_HIP(hipHostMalloc(&pin[i], CH, hipHostMallocPortable));
             OMG_HIP(hipEventCreateWithFlags(&ev[i], hipEventDisableTiming));
         }
     }

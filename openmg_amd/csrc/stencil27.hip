@@ -491,7 +491,6 @@ __global__ __launch_bounds__(256, S27_WAVES) void s27_residual_kernel(const S27K
             for (int u = 0; u < SG; ++u) {
                 const int s = g0 + u;
                 if (s >= 27) continue;
-            if (s >= 27) continue;
                 const Nb nb = neighbour(px, py, pz, s);
                 cf[u] = ldv<S27_COEF_AUX>(kc, ok ? t.cbase + s * 64 * RG : NONE, (VR *)nullptr);
                 x[u] = ldv(xs, ok ? nb.colour * a.na + t.a0 + nb.sk * lhyhx + nb.sj * lhx + nb.si : NONE, (VR *)nullptr);
@@ -811,6 +810,8 @@ void Stencil27Plan<V>::prolong(V *x, const V *e, const int32_t *cmap, hipStream_
 template <typename V>
 HostCsr Stencil27Plan<V>::operator_csr(hipStream_t s) const {
     const int64_t nx = g.nx, ny = g.ny, nz = g.nz, n = nx * ny * nz;
+    // (the padded operator has 27 n entries behind int32 row pointers: a level that large has no set-by-set twin)
+    OMG_REQUIRE(27 * n < (int64_t(1) << 31), "27-point level: the row-kernel format of the padded operator needs 27 n < 2^31 entries");
     std::vector<V> host(coef.n);
     OMG_HIP(hipMemcpyAsync(host.data(), coef.p, coef.n * sizeof(V), hipMemcpyDeviceToHost, s));
     OMG_HIP(hipStreamSynchronize(s));
