@@ -29,7 +29,7 @@ CASES = [
     ("plane", (32, 32, 32), 3, "colour", [(0, 1), (1, 0), (2, 1), (1, 1), (0, 0)]),
     ("plane2d", (64, 64), 3, "colour", [(1, 0), (2, 0), (1, 1)]),
     ("jacobi2d", (64, 64), 3, "jacobi", [(2, 0), (1, 0), (2, 1), (1, 1)]),
-    ("sets", (12, 10, 8), 2, "jacobi", [(1, 0), (2, 1)]),
+    ("sets", (8, 8, 8), 2, "jacobi", [(1, 0), (2, 1)]),
 ]
 
 
