@@ -420,6 +420,44 @@ int omg_pdist_group_create(int n, omg_pdist **ranks, omg_pdist_group **out);
 int omg_pdist_group_destroy(omg_pdist_group *g);
 int omg_pdist_group_cycles(omg_pdist_group *g, int n_cycles, double *norms /* nullable */);
 
+/* ---- 27-point slabs (csrc/dist27.hip, round 5): the multi-GPU cycle of 27-point grid stencils with per-row
+ * coefficients (BASELINE configs[4]) on the kernels of csrc/stencil27.hip.  (No reference counterpart: openmg is
+ * single-process; the cycle is openmg/__init__.py:151-236.)  A rank owns nz_global / n_ranks planes of each of the
+ * n_levels distributed levels (halved per level, even on every one) plus one ghost AGGREGATE plane on either side; the
+ * sweeps relax colours 0 .. 3 of the upper ghost plane redundantly, so ONE exchange of ghost planes serves a whole
+ * 8-colour sweep: per V(p, q) cycle p + q exchanges on the finest level, 1 + p + q on the others, one all-gather above
+ * the replicated `tail` (an ordinary hierarchy over the levels below the slabs, borrowed), one all-reduce per batch.
+ * A_rows: this rank's rows of the finest operator (its planes, C order) with GLOBAL column indices — every row the full
+ * 27-point stencil of its in-grid neighbours, ascending columns; the Galerkin products of the distributed levels are
+ * made per rank on the device.  omg_sdist_coarse_*: this rank's rows (global columns) of the operator below the
+ * slabs — the control plane gathers them and builds the tail.  dtype: OMG_DTYPE_F64 / OMG_DTYPE_F32 (vectors,
+ * coefficients and messages).  The iterate is bit-identical to the single-GPU hierarchy's for every number of ranks
+ * (tests/test_gpu_dist27.py). */
+typedef struct omg_sdist omg_sdist;
+typedef struct omg_sdist_group omg_sdist_group;
+int omg_sdist_create(int rank, int n_ranks, int nx, int ny, int nz_global, int n_levels, const omg_csr *A_rows, double weight, int dtype,
+                     omg_sdist **out);
+int omg_sdist_destroy(omg_sdist *d);
+int omg_sdist_coarse_size(omg_sdist *d, int64_t *n_rows, int64_t *n_cols, int64_t *nnz);
+int omg_sdist_coarse_fetch(omg_sdist *d, int32_t *indptr, int32_t *indices, double *data);
+int omg_sdist_set_tail(omg_sdist *d, omg_hierarchy *tail);
+/* joins the communicator; collective: also fetches the neighbour's coefficient rows of the ghost planes */
+int omg_sdist_connect(omg_sdist *d, const void *unique_id128);
+int omg_sdist_rccl_ranks(omg_sdist *d, int *count);
+/* out8: nx, ny, owned planes, aggregates per lane, workgroups, waves per workgroup of `level`; distributed levels;
+ * halo exchanges the last omg_sdist_cycles call enqueued on this rank */
+int omg_sdist_info(omg_sdist *d, int level, int64_t *out8);
+int omg_sdist_load(omg_sdist *d, const double *b_local, const double *x0_local /* NULL = zeros */);
+int omg_sdist_fetch(omg_sdist *d, double *x_local);
+int omg_sdist_sync(omg_sdist *d);
+/* n_cycles V(pre, post) cycles (openmg/__init__.py:22-23: the reference's default is V(1, 0)), every cycle's GLOBAL
+ * residual norm (:227) computed and returned; collective */
+int omg_sdist_cycles(omg_sdist *d, int pre, int post, int n_cycles, double *norms /* nullable */);
+/* all ranks in one process on one GPU, device copies in place of RCCL (verification) */
+int omg_sdist_group_create(int n, omg_sdist **ranks, omg_sdist_group **out);
+int omg_sdist_group_destroy(omg_sdist_group *g);
+int omg_sdist_group_cycles(omg_sdist_group *g, int pre, int post, int n_cycles, double *norms /* nullable */);
+
 #ifdef __cplusplus
 }
 #endif

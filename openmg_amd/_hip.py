@@ -130,6 +130,21 @@ SIGNATURES = {
     "omg_pdist_group_create": (_I, [_I, _P, _PP]),
     "omg_pdist_group_destroy": (_I, [_P]),
     "omg_pdist_group_cycles": (_I, [_P, _I, _P]),
+    "omg_sdist_create": (_I, [_I, _I, _I, _I, _I, _I, _CSR, _D, _I, _PP]),
+    "omg_sdist_destroy": (_I, [_P]),
+    "omg_sdist_coarse_size": (_I, [_P, _I64P, _I64P, _I64P]),
+    "omg_sdist_coarse_fetch": (_I, [_P, _P, _P, _P]),
+    "omg_sdist_set_tail": (_I, [_P, _P]),
+    "omg_sdist_connect": (_I, [_P, _P]),
+    "omg_sdist_rccl_ranks": (_I, [_P, _IP]),
+    "omg_sdist_info": (_I, [_P, _I, _I64P]),
+    "omg_sdist_load": (_I, [_P, _P, _P]),
+    "omg_sdist_fetch": (_I, [_P, _P]),
+    "omg_sdist_sync": (_I, [_P]),
+    "omg_sdist_cycles": (_I, [_P, _I, _I, _I, _P]),
+    "omg_sdist_group_create": (_I, [_I, _P, _PP]),
+    "omg_sdist_group_destroy": (_I, [_P]),
+    "omg_sdist_group_cycles": (_I, [_P, _I, _I, _I, _P]),
     "omg_dist_connect": (_I, [_P, _P]),
     "omg_dist_rccl_ranks": (_I, [_P, _IP]),
     "omg_dist_load": (_I, [_P, _P, _P]),

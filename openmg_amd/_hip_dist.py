@@ -347,3 +347,104 @@ class PlaneDistGroup:
             self._g = None
         for r in self.ranks:
             r.close()
+
+
+# ---- 27-point slabs (omg_sdist_*) ----------------------------------------------------------------
+class Slab27Rank:
+    """One rank's slab of a 27-point hierarchy with per-row coefficients on the octant-layout kernels (omg_sdist).
+    shape: the GLOBAL finest grid (planes, lines, cells); A_rows: this rank's rows of the finest operator with global
+    columns (dist.stencil27_variable_rows); n_levels distributed levels; the Galerkin products are made on the device.
+    After construction: coarse_rows() -> gather over the ranks -> a tail hierarchy -> set_tail()."""
+
+    def __init__(self, rank, n_ranks, shape, A_rows, n_levels, weight=0.125, dtype="float64"):
+        nz, ny, nx = (int(s) for s in shape)
+        A = as_csr(A_rows)
+        h = ctypes.c_void_p()
+        view = csr_view(A)
+        check(lib().omg_sdist_create(int(rank), int(n_ranks), nx, ny, nz, int(n_levels), ctypes.byref(view), float(weight),
+                                     dtype_code(dtype), ctypes.byref(h)))
+        self._h = h
+        self._tail = None
+        self.rank, self.n_ranks, self.n_levels = int(rank), int(n_ranks), int(n_levels)
+        self.n_local = nx * ny * (nz // int(n_ranks))
+
+    def coarse_rows(self):
+        """This rank's rows of the operator below the slabs, global columns (scipy CSR)."""
+        nr, nc, nnz = ctypes.c_int64(0), ctypes.c_int64(0), ctypes.c_int64(0)
+        check(lib().omg_sdist_coarse_size(self._h, ctypes.byref(nr), ctypes.byref(nc), ctypes.byref(nnz)))
+        indptr = np.empty(nr.value + 1, dtype=np.int32)
+        indices = np.empty(max(nnz.value, 1), dtype=np.int32)
+        data = np.empty(max(nnz.value, 1), dtype=np.float64)
+        check(lib().omg_sdist_coarse_fetch(self._h, indptr.ctypes.data, indices.ctypes.data, data.ctypes.data))
+        return sp.csr_matrix((data[:nnz.value], indices[:nnz.value], indptr), shape=(nr.value, nc.value))
+
+    def set_tail(self, tail):
+        check(lib().omg_sdist_set_tail(self._h, tail._h))
+        self._tail = tail
+
+    def connect(self, unique_id):
+        buf = ctypes.create_string_buffer(bytes(unique_id), 128)
+        check(lib().omg_sdist_connect(self._h, buf))
+
+    def rccl_ranks(self):
+        n = ctypes.c_int(0)
+        check(lib().omg_sdist_rccl_ranks(self._h, ctypes.byref(n)))
+        return n.value
+
+    def info(self, level=0):
+        out = (ctypes.c_int64 * 8)()
+        check(lib().omg_sdist_info(self._h, int(level), out))
+        keys = ("nx", "ny", "owned_planes", "aggregates_per_lane", "workgroups", "waves_per_workgroup", "levels", "exchanges_last_call")
+        return dict(zip(keys, [int(v) for v in out]))
+
+    def load(self, b_local, x0_local=None):
+        b = vec(b_local, self.n_local)
+        x0 = None if x0_local is None else vec(x0_local, self.n_local)
+        check(lib().omg_sdist_load(self._h, b.ctypes.data, None if x0 is None else x0.ctypes.data))
+
+    def fetch(self):
+        x = np.empty(self.n_local, dtype=np.float64)
+        check(lib().omg_sdist_fetch(self._h, x.ctypes.data))
+        return x
+
+    def sync(self):
+        check(lib().omg_sdist_sync(self._h))
+
+    def cycles(self, pre, post, n_cycles):
+        norms = (ctypes.c_double * max(int(n_cycles), 1))()
+        check(lib().omg_sdist_cycles(self._h, int(pre), int(post), int(n_cycles), norms))
+        return [float(norms[k]) for k in range(int(n_cycles))]
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().omg_sdist_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Slab27Group:
+    """All ranks of a 27-point slab decomposition in one process on one GPU (device copies in place of RCCL)."""
+
+    def __init__(self, ranks):
+        self.ranks = list(ranks)
+        arr = (ctypes.c_void_p * len(self.ranks))(*[r._h for r in self.ranks])
+        g = ctypes.c_void_p()
+        check(lib().omg_sdist_group_create(len(self.ranks), arr, ctypes.byref(g)))
+        self._g = g
+
+    def cycles(self, pre, post, n_cycles):
+        norms = (ctypes.c_double * max(int(n_cycles), 1))()
+        check(lib().omg_sdist_group_cycles(self._g, int(pre), int(post), int(n_cycles), norms))
+        return [float(norms[k]) for k in range(int(n_cycles))]
+
+    def close(self):
+        if getattr(self, "_g", None):
+            lib().omg_sdist_group_destroy(self._g)
+            self._g = None
+        for r in self.ranks:
+            r.close()

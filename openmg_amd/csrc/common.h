@@ -532,6 +532,9 @@ struct DevCsrPlain {
 void galerkin_chain_device(const omg_csr &A0, int dim, const int64_t *shape, int n_restrictions, std::vector<DevCsrPlain> &A,
                            std::vector<DevCsrPlain> &R, hipStream_t s);
 HostCsr download_csr(const DevCsrPlain &M, hipStream_t s);
+// C = (R A) R^T for an aggregation R (every column of R owned by exactly one row) by the fused kernel, SciPy's
+// accumulation order, ascending columns; false: the operands do not qualify (setup_device.hip)
+bool rap_aggregation_device(const DevCsrPlain &R, const DevCsrPlain &A, DevCsrPlain &C, hipStream_t s);
 
 // Is R the plain 2 x 2 x 2 aggregation of an nx x ny x nz grid (openmg/operators.py:73-84: eight entries per coarse
 // cell in (dk, dj, di) order, ONE weight, ascending columns)?  w: that weight.  Host scan on many threads.
@@ -697,10 +700,23 @@ struct Stencil27Plan {
     DevBuf<V> res67;                  // residuals of colours 6 and 7, left by a sweep's last pair launch
     DevBuf<double> partials;          // 4 segments of n_wg block partials (+ SUM_FOLD): squared residuals
     bool have67 = false;              // res67 / segment 3 belong to the current iterate
+    // The grid lines (line = aggregate plane * hy + aggregate line) the launches work on: all of them on a whole grid.
+    // One rank's slab with a ghost aggregate plane on either side (dist27.hip): the owned planes' lines [live_lo,
+    // live_hi) — residuals, squares, the pair launches of colours 4 .. 7 —, for the pair launches of colours 0 .. 3
+    // [live_lo01, live_hi01): also the upper ghost plane's (relaxed redundantly); the prolongation takes every line.
+    int64_t live_lo = 0, live_hi = 0, live_lo01 = 0, live_hi01 = 0;
     // false: the level does not qualify (ord untouched).  A, R: the caller's CSR in natural numbering.
     bool build(const omg_csr &A, const omg_csr &R, Ordering &ord, hipStream_t s);
     // ... for an operator already in HBM on a known grid, restricted by the plain aggregation with weight w
     bool build_device(const DevCsrPlain &A, int nx, int ny, int nz, double w, Ordering &ord, hipStream_t s);
+    // ... for one rank's slab (stencil27.hip; throws when the rows do not qualify)
+    void build_slab(const DevCsrPlain &A, int nx, int ny, int nz_ext, bool first, bool last, double w, hipStream_t s);
+    bool tile(const DevCsrPlain &A, const S27Geom &q, int kz_lo, int kz_hi, int kb_lo, int kb_hi, hipStream_t s);
+    // the coefficient rows of colours 0 .. 3 of aggregate plane K as one contiguous array (plane_rows_count() values):
+    // a slab's upper ghost plane takes them from the neighbour's first owned plane
+    size_t plane_rows_count() const;
+    void pack_plane_rows(int K, V *buf, hipStream_t s) const;
+    void unpack_plane_rows(int K, const V *buf, hipStream_t s);
     // One sweep x_old -> x_new.  x_zero: x_old is zero and is not read.  norm_old (nullable: 4 n_wg doubles): also
     // the squares of b - A x_old.  last: leave the residuals of colours 6, 7 (res67) and, with norm_new (nullable,
     // same shape; only segment 3 is written), their squares.

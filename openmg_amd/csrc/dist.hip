@@ -16,8 +16,6 @@
 // The same schedule runs over a LOOPBACK group — several ranks living in one process on one
 // GPU, halos moved with device-to-device copies — which is how the distributed algorithm is
 // verified on a single-GPU box (tests/test_gpu_dist.py); only the thin RCCL calls differ.
-#include <dlfcn.h>
-#include <rccl/rccl.h>
 
 #include <algorithm>
 #include <array>
@@ -27,59 +25,11 @@
 #include <type_traits>
 
 #include "common.h"
+#include "rccl_dyn.h"
 
 namespace omg {
-namespace {
-
-// ---- RCCL, resolved at run time so that the library loads on hosts without it --------------
-struct Rccl {
-    void *handle = nullptr;
-    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
-    decltype(&ncclCommInitRank) CommInitRank = nullptr;
-    decltype(&ncclCommDestroy) CommDestroy = nullptr;
-    decltype(&ncclCommCount) CommCount = nullptr;
-    decltype(&ncclGetErrorString) GetErrorString = nullptr;
-    decltype(&ncclGroupStart) GroupStart = nullptr;
-    decltype(&ncclGroupEnd) GroupEnd = nullptr;
-    decltype(&ncclSend) Send = nullptr;
-    decltype(&ncclRecv) Recv = nullptr;
-    decltype(&ncclAllGather) AllGather = nullptr;
-    decltype(&ncclAllReduce) AllReduce = nullptr;
-
-    template <typename F>
-    void sym(F &fn, const char *name) {
-        fn = reinterpret_cast<F>(dlsym(handle, name));
-        if (!fn) throw Error(OMG_ERR_UNSUPPORTED, std::string("RCCL symbol missing: ") + name);
-    }
-    void load() {
-        if (handle) return;
-        // an already-loaded copy (e.g. the one PyTorch brought) wins; then the ROCm install
-        for (const char *n : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-            handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
-            if (handle) break;
-        }
-        if (!handle) throw Error(OMG_ERR_UNSUPPORTED, std::string("cannot load librccl: ") + dlerror());
-        sym(GetUniqueId, "ncclGetUniqueId");
-        sym(CommInitRank, "ncclCommInitRank");
-        sym(CommDestroy, "ncclCommDestroy");
-        sym(CommCount, "ncclCommCount");
-        sym(GetErrorString, "ncclGetErrorString");
-        sym(GroupStart, "ncclGroupStart");
-        sym(GroupEnd, "ncclGroupEnd");
-        sym(Send, "ncclSend");
-        sym(Recv, "ncclRecv");
-        sym(AllGather, "ncclAllGather");
-        sym(AllReduce, "ncclAllReduce");
-    }
-};
 Rccl g_rccl;
-
-#define OMG_NCCL(call)                                                                        \
-    do {                                                                                      \
-        ncclResult_t r_ = (call);                                                             \
-        if (r_ != ncclSuccess)                                                                \
-            throw omg::Error(OMG_ERR_HIP, std::string(#call) + ": " + g_rccl.GetErrorString(r_)); \
-    } while (0)
+namespace {
 
 template <typename V>
 struct DLevel {
@@ -110,10 +60,6 @@ __global__ void sqrt_kernel(double *v) { *v = sqrt(*v); }
 __global__ void sqrt_array_kernel(const double *v, double *out, int n) {
     for (int i = threadIdx.x; i < n; i += blockDim.x) out[i] = sqrt(v[i]);
 }
-
-template <typename V> struct NcclType;
-template <> struct NcclType<double> { static constexpr ncclDataType_t value = ncclDouble; };
-template <> struct NcclType<float> { static constexpr ncclDataType_t value = ncclFloat; };
 
 // One rank's slab, levels stored and computed in V (double: the reference's precision; float:
 // BASELINE configs[4] — halo messages are then half the bytes too).

@@ -573,6 +573,13 @@ void fill_ordering_device(int kind, int nx, int ny, int nz, int32_t *perm, int32
     OMG_HIP(hipGetLastError());
 }
 
+bool rap_aggregation_device(const DevCsrPlain &R, const DevCsrPlain &A, DevCsrPlain &C, hipStream_t s) {
+    omg_csr_result T;
+    if (!rap_aggregation(R, A, T, s)) return false;
+    as_devmat(std::move(T), C);
+    return true;
+}
+
 HostCsr download_csr(const DevCsrPlain &M, hipStream_t s) {
     HostCsr H;
     H.n_rows = M.n_rows; H.n_cols = M.n_cols; H.nnz = M.nnz;

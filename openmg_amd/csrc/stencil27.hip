@@ -157,6 +157,10 @@ struct S27KArgs {
     double *part_a, *part_b;         // block partials: sweep: old-residual squares / new-residual squares; residual: squares
     int hx, hy, L, G;
     int na, nl, ng;                  // rows per colour, lines per colour, waves per colour
+    // lines [line_lo, line_hi) are relaxed / evaluated by this launch, squares are taken of lines [sq_lo, sq_hi): all of
+    // them on a whole grid; on a slab with ghost aggregate planes (dist27.hip) the owned planes' lines, for the first two
+    // pair launches of a sweep also the upper ghost plane's
+    int line_lo, line_hi, sq_lo, sq_hi;
     unsigned vec_bytes, coef_bytes;  // 8 na sizeof(V); bytes of ONE colour's coefficients
     V w;
 };
@@ -177,6 +181,7 @@ struct Lane {
     int line, i0, a0, cbase;         // grid line of the colour, first aggregate in the line, a0 = line hx + i0, first coefficient
     unsigned mask;                   // bit r: aggregate i0 + r exists
     int lane;
+    bool counts;                     // the line's squares count towards the norm
 };
 template <typename V, int RG>
 __device__ __forceinline__ Lane<V, RG> lane_of(const S27KArgs<V> &a) {
@@ -186,7 +191,8 @@ __device__ __forceinline__ Lane<V, RG> lane_of(const S27KArgs<V> &a) {
     const int lw = t.lane / a.L;                      // line of the wave
     t.line = wave * a.G + lw;
     t.i0 = (t.lane - lw * a.L) * RG;
-    const bool live = wave < a.ng && lw < a.G && t.line < a.nl;
+    const bool live = wave < a.ng && lw < a.G && t.line >= a.line_lo && t.line < a.line_hi;
+    t.counts = t.line >= a.sq_lo && t.line < a.sq_hi;
     t.a0 = t.line * a.hx + t.i0;
     t.cbase = (wave * 27 * 64 + t.lane) * RG;
     t.mask = 0u;
@@ -195,6 +201,14 @@ __device__ __forceinline__ Lane<V, RG> lane_of(const S27KArgs<V> &a) {
         if (live && t.i0 + r < a.hx) t.mask |= 1u << r;
     if (wave >= a.ng) t.cbase = S27_OOB / int(sizeof(V));          // (a launch is padded to whole workgroups)
     return t;
+}
+
+// a workgroup none of whose lines is in the launch's range (slabs: the ghost planes' lines) leaves at once
+template <typename V>
+__device__ __forceinline__ bool block_dead(const S27KArgs<V> &a) {
+    const int wpb = int(blockDim.x) >> 6;
+    const int first = int(blockIdx.x) * wpb * a.G, end = first + wpb * a.G;
+    return end <= a.line_lo || first >= a.line_hi;
 }
 
 template <typename V>
@@ -246,6 +260,13 @@ __global__ __launch_bounds__(256, NOLD ? 1 : S27_WAVES) void s27_sweep_kernel(co
     static_assert(!(XZ && NOLD), "a zero iterate has no predecessor cycle");
     typedef Vec<V, RG> VR;
     constexpr int CA = 2 * PAIR, CB = CA + 1, PY = PAIR & 1, PZ = PAIR >> 1;
+    if (block_dead(a)) {
+        if (threadIdx.x == 0) {
+            if (NOLD) a.part_a[blockIdx.x] = 0.0;
+            if (LAST && a.part_b) a.part_b[blockIdx.x] = 0.0;
+        }
+        return;
+    }
     Lane<V, RG> tt = lane_of<V, RG>(a);
     const Lane<V, RG> &t = tt;
     const int lhx = a.hx, lhyhx = a.hx * a.hy;
@@ -314,7 +335,7 @@ __global__ __launch_bounds__(256, NOLD ? 1 : S27_WAVES) void s27_sweep_kernel(co
         // openmg/solvers.py:68   x[i] = x[i] + (b[i] - Aix) / A[i, i]
         const V v = xa.v[r] + (ba.v[r] - acc[r].total()) / diag_a.v[r];
         na_.v[r] = ((t.mask >> r) & 1u) ? v : V(0);
-        if (NOLD && ((t.mask >> r) & 1u)) add_sq(sq_old, double(ba.v[r] - aold[r].total()));
+        if (NOLD && ((t.mask >> r) & 1u) && t.counts) add_sq(sq_old, double(ba.v[r] - aold[r].total()));
         if (LAST) a3[r] = acc[r].s[3];
     }
     // the in-line neighbours of colour CB: aggregate i + 1 of this lane or the next lane's first; of colour CA's
@@ -381,7 +402,7 @@ __global__ __launch_bounds__(256, NOLD ? 1 : S27_WAVES) void s27_sweep_kernel(co
     for (int r = 0; r < RG; ++r) {
         const V v = xb.v[r] + (bb.v[r] - acc[r].total()) / diag_b.v[r];
         nb_.v[r] = ((t.mask >> r) & 1u) ? v : V(0);
-        if (NOLD && ((t.mask >> r) & 1u)) add_sq(sq_old, double(bb.v[r] - aold[r].total()));
+        if (NOLD && ((t.mask >> r) & 1u) && t.counts) add_sq(sq_old, double(bb.v[r] - aold[r].total()));
     }
     stv(xn, CA * a.na + t.a0, na_, t.mask);
     stv(xn, CB * a.na + t.a0, nb_, t.mask);
@@ -448,7 +469,7 @@ __global__ __launch_bounds__(256, NOLD ? 1 : S27_WAVES) void s27_sweep_kernel(co
         }
         stv(rr, t.a0, ra, t.mask);
         stv(rr, a.na + t.a0, rb, t.mask);
-        if (a.part_b) {
+        if (a.part_b && t.counts) {
 #pragma unroll
             for (int r = 0; r < RG; ++r) { add_sq(sq_new, double(ra.v[r])); add_sq(sq_new, double(rb.v[r])); }
         }
@@ -465,6 +486,10 @@ __global__ __launch_bounds__(256, NOLD ? 1 : S27_WAVES) void s27_sweep_kernel(co
 template <typename V, int RG, int NC, int MODE>
 __global__ __launch_bounds__(256, S27_WAVES) void s27_residual_kernel(const S27KArgs<V> a) {
     typedef Vec<V, RG> VR;
+    if (block_dead(a)) {
+        if (MODE == 1 && threadIdx.x == 0) a.part_a[blockIdx.x] = 0.0;
+        return;
+    }
     Lane<V, RG> tt = lane_of<V, RG>(a);
     const Lane<V, RG> &t = tt;
     const int lhx = a.hx, lhyhx = a.hx * a.hy;
@@ -508,7 +533,7 @@ __global__ __launch_bounds__(256, S27_WAVES) void s27_residual_kernel(const S27K
 #pragma unroll
         for (int r = 0; r < RG; ++r) {
             const V res = ((t.mask >> r) & 1u) ? bv.v[r] - acc[r].total() : V(0);
-            if (MODE == 1) add_sq(sq, double(res));
+            if (MODE == 1) { if (t.counts) add_sq(sq, double(res)); }
             else rsum[r] = madd(a.w, res, rsum[r]);
         }
     }
@@ -534,6 +559,7 @@ __global__ __launch_bounds__(256, S27_WAVES) void s27_residual_kernel(const S27K
 template <typename V, int RG>
 __global__ __launch_bounds__(256) void s27_prolong_kernel(const S27KArgs<V> a) {
     typedef Vec<V, RG> VR;
+    if (block_dead(a)) return;
     const Lane<V, RG> t = lane_of<V, RG>(a);
     if (!t.mask) return;
     const __amdgpu_buffer_rsrc_t xs = __builtin_amdgcn_make_buffer_rsrc(a.x_new, 0, a.vec_bytes, 0x00020000);
@@ -554,12 +580,16 @@ __global__ __launch_bounds__(256) void s27_prolong_kernel(const S27KArgs<V> a) {
 // ---- setup: the caller's CSR (natural numbering) -> the wave-tiled coefficient array; every row checked ----------
 // err: 0 fine, otherwise 1 + the first offending row (any of them)
 template <typename V>
+// Slabs (dist27.hip): the CSR is the rank's extended slab (ghost planes' rows empty); planes [kz_lo, kz_hi) of it exist in
+// the global grid (a neighbour outside is absent), the rows of planes [kb_lo, kb_hi) are tiled, the others left alone.
 __global__ __launch_bounds__(256) void s27_build_kernel(const int32_t *indptr, const int32_t *indices, const double *data,
-                                                        int nx, int ny, int nz, int L, int G, int RG, int64_t ng, V *coef, unsigned long long *err) {
+                                                        int nx, int ny, int nz, int kz_lo, int kz_hi, int kb_lo, int kb_hi, int L, int G, int RG, int64_t ng,
+                                                        V *coef, unsigned long long *err) {
     const int64_t n = int64_t(nx) * ny * nz;
     const int64_t row = int64_t(blockIdx.x) * 256 + threadIdx.x;
     if (row >= n) return;
     const int i = int(row % nx), j = int((row / nx) % ny), k = int(row / (int64_t(nx) * ny));
+    if (k < kb_lo || k >= kb_hi) return;
     const int hy = ny / 2;
     const int c = (i & 1) | ((j & 1) << 1) | ((k & 1) << 2);
     const int64_t line = int64_t(k >> 1) * hy + (j >> 1);
@@ -571,7 +601,7 @@ __global__ __launch_bounds__(256) void s27_build_kernel(const int32_t *indptr, c
     bool bad = false;
     for (int s = 0; s < 27; ++s) {
         const int dx = s % 3 - 1, dy = (s / 3) % 3 - 1, dz = s / 9 - 1;
-        const bool present = i + dx >= 0 && i + dx < nx && j + dy >= 0 && j + dy < ny && k + dz >= 0 && k + dz < nz;
+        const bool present = i + dx >= 0 && i + dx < nx && j + dy >= 0 && j + dy < ny && k + dz >= kz_lo && k + dz < kz_hi;
         V v = V(0);
         if (present) {
             if (p < pe && int64_t(indices[p]) == row + (int64_t(dz) * ny + dy) * nx + dx) {
@@ -602,6 +632,8 @@ S27KArgs<V> base_args(const Stencil27Plan<V> &P) {
     k.vec_bytes = unsigned(size_t(8) * size_t(g.na) * sizeof(V));
     k.coef_bytes = unsigned(size_t(g.ng) * 27 * 64 * size_t(g.rg) * sizeof(V));
     k.w = V(g.w);
+    k.line_lo = int(P.live_lo); k.line_hi = int(P.live_hi);
+    k.sq_lo = int(P.live_lo); k.sq_hi = int(P.live_hi);
     return k;
 }
 
@@ -631,8 +663,12 @@ void sweep_rg(const Stencil27Plan<V> &P, const V *x_old, V *x_new, const V *b, b
     k.x_old = x_old; k.x_new = x_new; k.b = b;
     const int nw = P.g.n_wg;
     k.part_b = (last && norm_new) ? norm_new + 3 * size_t(nw) : nullptr;
+    // (a slab: the colours 0 .. 3 of the upper ghost aggregate plane are relaxed here too — the neighbour's rows, its bits —
+    // so that colours 4 .. 7 of the last owned plane find them without an exchange inside the sweep)
+    k.line_lo = int(P.live_lo01); k.line_hi = int(P.live_hi01);
     k.part_a = norm_old;                      launch_pair<V, RG, 0>(P.g, k, x_zero, norm_old != nullptr, false, s);
     k.part_a = norm_old ? norm_old + nw : nullptr;     launch_pair<V, RG, 1>(P.g, k, x_zero, norm_old != nullptr, false, s);
+    k.line_lo = int(P.live_lo); k.line_hi = int(P.live_hi);
     k.part_a = norm_old ? norm_old + 2 * size_t(nw) : nullptr; launch_pair<V, RG, 2>(P.g, k, x_zero, norm_old != nullptr, false, s);
     k.part_a = norm_old ? norm_old + 3 * size_t(nw) : nullptr; launch_pair<V, RG, 3>(P.g, k, x_zero, norm_old != nullptr, last, s);
 }
@@ -712,16 +748,11 @@ bool Stencil27Plan<V>::build(const omg_csr &A, const omg_csr &R, Ordering &ord, 
     return true;
 }
 
+// the tiling of an nx x ny x nz grid (false: a line does not fit a wave, or the arrays would outgrow 32-bit byte offsets)
 template <typename V>
-bool Stencil27Plan<V>::build_device(const DevCsrPlain &A, int nx, int ny, int nz, double w, Ordering &ord, hipStream_t s) {
-    {
-        const char *e = getenv("OMG_STENCIL27");
-        if (e && e[0] == '0') return false;
-    }
+static bool s27_geometry(int nx, int ny, int nz, double w, S27Geom &q) {
     const int64_t n = int64_t(nx) * ny * nz;
-    if (n < 64 || n != A.n_rows || n != A.n_cols || (nx & 1) || (ny & 1) || (nz & 1) || ny < 2 || nz < 2) return false;
-    if (A.nnz != (3 * int64_t(nx) - 2) * (3 * int64_t(ny) - 2) * (3 * int64_t(nz) - 2)) return false;
-    S27Geom q;
+    if (n < 64 || (nx & 1) || (ny & 1) || (nz & 1) || ny < 2 || nz < 2) return false;
     q.nx = int(nx); q.ny = int(ny); q.nz = int(nz);
     q.hx = q.nx / 2; q.hy = q.ny / 2; q.hz = q.nz / 2;
     q.na = int64_t(q.hx) * q.hy * q.hz;
@@ -749,25 +780,46 @@ bool Stencil27Plan<V>::build_device(const DevCsrPlain &A, int nx, int ny, int nz
     q.w = double(V(w));
     const uint64_t coef_colour_bytes = uint64_t(q.ng) * 27 * 64 * uint64_t(q.rg) * sizeof(V);
     if (uint64_t(n) * sizeof(V) >= (uint64_t(1) << 31) || coef_colour_bytes >= (uint64_t(1) << 31)) return false;
-    {
-        SetupTimer tm("27-point level: check + tile the coefficients on the device");
-        DevBuf<unsigned long long> d_err(1);
-        OMG_HIP(hipMemsetAsync(d_err.p, 0xFF, sizeof(unsigned long long), s));
-        coef.alloc(size_t(8) * size_t(q.ng) * 27 * 64 * size_t(q.rg));
-        coef.zero(s);
-        hipLaunchKernelGGL(s27_build_kernel<V>, dim3(unsigned((n + 255) / 256)), dim3(256), 0, s, A.indptr.p, A.indices.p, A.data.p, q.nx, q.ny, q.nz,
-                           q.L, q.G, q.rg, q.ng, coef.p, d_err.p);
-        OMG_HIP(hipGetLastError());
-        unsigned long long err = 0;
-        OMG_HIP(hipMemcpyAsync(&err, d_err.p, sizeof(err), hipMemcpyDeviceToHost, s));
-        OMG_HIP(hipStreamSynchronize(s));
-        if (err != ~0ull) { coef.release(); return false; }
-    }
+    return true;
+}
+
+template <typename V>
+bool Stencil27Plan<V>::tile(const DevCsrPlain &A, const S27Geom &q, int kz_lo, int kz_hi, int kb_lo, int kb_hi, hipStream_t s) {
+    SetupTimer tm("27-point level: check + tile the coefficients on the device");
+    const int64_t n = int64_t(q.nx) * q.ny * q.nz;
+    DevBuf<unsigned long long> d_err(1);
+    OMG_HIP(hipMemsetAsync(d_err.p, 0xFF, sizeof(unsigned long long), s));
+    coef.alloc(size_t(8) * size_t(q.ng) * 27 * 64 * size_t(q.rg));
+    coef.zero(s);
+    hipLaunchKernelGGL(s27_build_kernel<V>, dim3(unsigned((n + 255) / 256)), dim3(256), 0, s, A.indptr.p, A.indices.p, A.data.p, q.nx, q.ny, q.nz,
+                       kz_lo, kz_hi, kb_lo, kb_hi, q.L, q.G, q.rg, q.ng, coef.p, d_err.p);
+    OMG_HIP(hipGetLastError());
+    unsigned long long err = 0;
+    OMG_HIP(hipMemcpyAsync(&err, d_err.p, sizeof(err), hipMemcpyDeviceToHost, s));
+    OMG_HIP(hipStreamSynchronize(s));
+    if (err != ~0ull) { coef.release(); return false; }
     g = q;
     res67.alloc(size_t(2) * size_t(g.na));
     partials.alloc(size_t(4) * size_t(g.n_wg) + SUM_FOLD);
     partials.zero(s);
     have67 = false;
+    live_lo = live_lo01 = 0;
+    live_hi = live_hi01 = g.nl;
+    return true;
+}
+
+template <typename V>
+bool Stencil27Plan<V>::build_device(const DevCsrPlain &A, int nx, int ny, int nz, double w, Ordering &ord, hipStream_t s) {
+    {
+        const char *e = getenv("OMG_STENCIL27");
+        if (e && e[0] == '0') return false;
+    }
+    const int64_t n = int64_t(nx) * ny * nz;
+    if (n != A.n_rows || n != A.n_cols) return false;
+    if (A.nnz != (3 * int64_t(nx) - 2) * (3 * int64_t(ny) - 2) * (3 * int64_t(nz) - 2)) return false;
+    S27Geom q;
+    if (!s27_geometry<V>(nx, ny, nz, w, q)) return false;
+    if (!tile(A, q, 0, nz, 0, nz, s)) return false;
     // the ordering: colour = octant, inside a colour the aggregates in natural order (what the greedy colouring of
     // such an operator gives: every lower-numbered neighbour of a cell lies in another octant position); its host
     // arrays are written on demand (materialise_ordering)
@@ -777,6 +829,56 @@ bool Stencil27Plan<V>::build_device(const DevCsrPlain &A, int nx, int ny, int nz
     for (int c = 0; c <= 8; ++c) ord.sets[size_t(c)] = int64_t(c) * g.na;
     ord.closed_form = 8; ord.cf_nx = nx; ord.cf_ny = ny; ord.cf_nz = nz;
     return true;
+}
+
+// One rank's slab of a 27-point level (dist27.hip).  A: the rows of the rank's OWNED planes in the numbering of its
+// extended slab — nz_ext = owned + 4 planes: one ghost AGGREGATE plane on either side, whose rows are empty here (the
+// upper one's even plane is filled from the neighbour afterwards: copy_plane_rows / pack_plane_rows).  first / last: the
+// slab lies at the global grid's lower / upper end (the ghost planes there do not exist: couplings to them are absent).
+template <typename V>
+void Stencil27Plan<V>::build_slab(const DevCsrPlain &A, int nx, int ny, int nz_ext, bool first, bool last, double w, hipStream_t s) {
+    const int64_t n = int64_t(nx) * ny * nz_ext;
+    OMG_REQUIRE(n == A.n_rows && n == A.n_cols && nz_ext >= 6, "27-point slab: operator does not match the extended slab");
+    S27Geom q;
+    OMG_REQUIRE(s27_geometry<V>(nx, ny, nz_ext, w, q), "27-point slab: the grid does not fit the kernels (even extents, nx <= 512 (float) / 256 (double), "
+                                                       "one colour's vector and coefficients below 2 GiB)");
+    OMG_REQUIRE(tile(A, q, first ? 2 : 0, last ? nz_ext - 2 : nz_ext, 2, nz_ext - 2, s),
+                "27-point slab: a row of the rank's planes is not the full 27-point stencil of its in-grid neighbours (sorted columns, finite, nonzero diagonal)");
+    // owned aggregate planes 1 .. hz - 2; colours 0 .. 3 are relaxed on the upper ghost plane too (where there is one)
+    live_lo = live_lo01 = int64_t(g.hy);
+    live_hi = int64_t(g.hy) * (g.hz - 1);
+    live_hi01 = last ? live_hi : int64_t(g.hy) * g.hz;
+}
+
+// colours 0 .. 3 of aggregate plane K, every slot: [colour][line J][slot][aggregate I] <-> the tiles
+template <typename V>
+__global__ void s27_plane_rows_kernel(V *coef, V *buf, int hx, int hy, int L, int G, int RG, int64_t ng, int K, int to_buf) {
+    const int64_t total = int64_t(4) * hy * 27 * hx;
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int I = int(e % hx), sl = int((e / hx) % 27), J = int((e / (int64_t(hx) * 27)) % hy), c = int(e / (int64_t(hx) * 27 * hy));
+        const int64_t line = int64_t(K) * hy + J, wave = line / G;
+        const int lane = int(line - wave * G) * L + I / RG, r = I % RG;
+        V *t = coef + ((size_t(c) * size_t(ng) + size_t(wave)) * 27 * 64 + size_t(lane)) * size_t(RG) + size_t(r) + size_t(sl) * 64 * size_t(RG);
+        if (to_buf) buf[e] = *t;
+        else *t = buf[e];
+    }
+}
+
+template <typename V>
+size_t Stencil27Plan<V>::plane_rows_count() const { return size_t(4) * size_t(g.hy) * 27 * size_t(g.hx); }
+
+template <typename V>
+void Stencil27Plan<V>::pack_plane_rows(int K, V *buf, hipStream_t s) const {
+    hipLaunchKernelGGL(s27_plane_rows_kernel<V>, dim3(unsigned(std::min<size_t>(4096, (plane_rows_count() + 255) / 256))), dim3(256), 0, s,
+                       const_cast<V *>(coef.p), buf, g.hx, g.hy, g.L, g.G, g.rg, g.ng, K, 1);
+    OMG_HIP(hipGetLastError());
+}
+
+template <typename V>
+void Stencil27Plan<V>::unpack_plane_rows(int K, const V *buf, hipStream_t s) {
+    hipLaunchKernelGGL(s27_plane_rows_kernel<V>, dim3(unsigned(std::min<size_t>(4096, (plane_rows_count() + 255) / 256))), dim3(256), 0, s,
+                       coef.p, const_cast<V *>(buf), g.hx, g.hy, g.L, g.G, g.rg, g.ng, K, 0);
+    OMG_HIP(hipGetLastError());
 }
 
 template <typename V>
@@ -803,6 +905,7 @@ template <typename V>
 void Stencil27Plan<V>::prolong(V *x, const V *e, const int32_t *cmap, hipStream_t s) {
     S27KArgs<V> k = base_args(*this);
     k.x_new = x; k.e = e; k.cmap = cmap;
+    k.line_lo = 0; k.line_hi = int(g.nl);                          // (a slab's ghost planes too: their coarse cells' corrections are known)
     with_rg<V>(g.rg, [&](auto RGC) { launch_s27(s27_prolong_kernel<V, decltype(RGC)::value>, g, k, s); });
     have67 = false;
 }

@@ -48,6 +48,132 @@ def plane_levels(shape, world, n_dist):
     return n
 
 
+def slab27_levels(shape, world, n_dist, dtype):
+    """How many levels the 27-point slab runner (csrc/dist27.hip) can distribute (0: not applicable): the first
+    n_dist - 1 levels, as long as every one of them has even extents, an even number (>= 2) of planes per rank and a
+    grid line that fits one wave (512 cells in fp32, 256 in fp64)."""
+    n = 0
+    nz, ny, nx = shape
+    line = 512 if dtype == "f32" else 256
+    for _ in range(max(0, n_dist - 1)):
+        if nz % world or (nz // world) % 2 or (nz // world) < 2 or ny % 2 or nx % 2 or nx > line:
+            break
+        n += 1
+        nz, ny, nx = nz // 2, ny // 2, nx // 2
+    return n
+
+
+def main_slab27(args, rank, world, shape, grids, n_levels, all_gather, td, torch, watchdog):
+    """BASELINE configs[4]: the 27-point variable-coefficient operator, 8-colour Gauss-Seidel, on slabs with ghost
+    aggregate planes run by the octant-layout kernels (omg_sdist_*): per-rank Galerkin products on the device, one
+    exchange per sweep."""
+    import numpy as np
+    from . import _hip, _hip_dist, dist, preflight
+    np_dtype = "float64" if args.dtype == "f64" else "float32"
+    w = 8 if args.dtype == "f64" else 4
+    t_setup = time.perf_counter()
+    plane = shape[1] * shape[2]
+    lo = rank * (shape[0] // world) * plane
+    hi = lo + (shape[0] // world) * plane
+    A_rows = dist.stencil27_variable_rows(shape, lo, hi)
+    n_glob = shape[0] * plane
+    u = np.random.default_rng(12345).random(n_glob)
+    b_loc = A_rows @ u
+    nnz_loc, n_loc = A_rows.nnz, hi - lo
+    del u
+    t_gen = time.perf_counter()
+    r = _hip_dist.Slab27Rank(rank, world, shape, A_rows, n_levels, 0.125, np_dtype)
+    del A_rows
+    # the operator below the slabs: every rank's rows gathered, the levels under it replicated as an ordinary hierarchy
+    coarse = dist.assemble_coarse(all_gather(r.coarse_rows()))
+    tshape = tuple(s >> n_levels for s in shape)
+    tgrids = grids - n_levels
+    tail = dist.make_tail(coarse, tshape, tgrids, smoother="colour", dtype=np_dtype)
+    del coarse
+    r.set_tail(tail)
+    if world > 1:
+        ident = [_hip_dist.rccl_unique_id() if rank == 0 else None]
+        td.broadcast_object_list(ident, src=0)
+        r.connect(ident[0])                                     # (collective: also the neighbours' coefficient rows)
+    r.load(b_loc)
+    setup_s = time.perf_counter() - t_setup
+    pre = post = 1
+    first_norm = preflight.run(rank, world, lambda: r.cycles(pre, post, 1)[0], all_gather, min(120.0, max(20.0, args.watchdog / 4.0)),
+                               where=lambda: "27-point slab cycle")
+    exchanges = r.info(0)["exchanges_last_call"]
+    r.load(b_loc)
+    trajectory = r.cycles(pre, post, 1)
+    for _ in range(args.warmup):
+        trajectory += r.cycles(pre, post, 1)
+    times = []
+    for _ in range(max(1, getattr(args, "repeats", 1))):
+        r.sync()
+        torch.cuda.synchronize()
+        td.barrier()
+        t0 = time.perf_counter()
+        region = r.cycles(pre, post, args.steps)         # K cycles back to back, every cycle's global norm computed
+        r.sync()
+        torch.cuda.synchronize()
+        td.barrier()
+        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+        td.all_reduce(t, op=td.ReduceOp.MAX)             # the slowest rank's time
+        times.append(float(t[0]))
+        trajectory += region
+    elapsed = statistics.median(times)
+    norm = r.cycles(pre, post, 1)[0]
+    rccl_ranks = r.rccl_ranks()
+    if rank == 0:
+        equiv = n_glob / float(256 ** 3)
+        # what a rank's fine-grid launches have to move per V(1,1) cycle (DESIGN.md section 5d): two sweeps of (27 + 2 + 4) w n
+        # and the residual of six of eight colours + restriction, (6/8 27 + 2 + 1) w n + w n / 8
+        sweep_bytes = (27 + 2 + 4) * w * n_loc
+        cycle_bytes = 2 * sweep_bytes + int((0.75 * 27 + 3) * w * n_loc) + w * n_loc // 8
+        src_sha, head = _bench_identity()
+        info = r.info(0)
+        out = {
+            "metric": "V-cycles/sec (256^3-unknown equivalents), 3-D 27-point variable-coefficient Poisson, weak scaling",
+            "value": round(args.steps / elapsed * equiv, 3),
+            "unit": "256^3-equivalent V-cycles/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": "3-D 27-point variable-coefficient Poisson (Q1 stiffness) %s, %d-grid V(1,1) cycle, 8-colour Gauss-Seidel, %s, "
+                                   "Galerkin products per rank on the device, 1-D slabs over %d GPUs: octant-layout kernels on slabs with "
+                                   "ghost aggregate planes, one exchange per sweep"
+                                   % ("x".join(map(str, shape)), grids, "fp64" if w == 8 else "fp32", world),
+                       "unknowns": n_glob, "unknowns_per_gpu": n_loc, "nnz_per_gpu": nnz_loc, "grids": grids,
+                       "distributed_grids": n_levels, "replicated_tail_grids": tgrids, "runner": "27-point slabs (omg_sdist)",
+                       "exchange": "RCCL grouped send/recv of ghost aggregate planes (colours 4..7 both ways after every sweep, colours 0..3 of the "
+                                   "coarse right-hand side after every restriction)",
+                       "halo_exchanges_per_cycle": exchanges, "rccl_ranks": rccl_ranks, "repeats": len(times),
+                       "preflight_norm": first_norm, "kernel_src_sha": src_sha, "git_head": head,
+                       "ms_per_step_all": [round(1e3 * t / args.steps, 4) for t in times],
+                       "pre": pre, "post": post, "cycles_per_s": round(args.steps / elapsed, 3),
+                       "final_residual_norm": norm, "norms_last_region_tail": trajectory[-3:],
+                       "workgroups": info["workgroups"], "aggregates_per_lane": info["aggregates_per_lane"],
+                       "generate_s": round(t_gen - t_setup, 2), "setup_s": round(setup_s, 2)},
+            # a LOWER bound of the fine-grid launches' rate: the bytes rank 0's fine-grid launches have to move per cycle over
+            # the WHOLE cycle's time (exchanges, coarser levels and the replicated tail included)
+            "roofline": {"bound": "hbm", "kernel": "rank 0's fine-grid launches per cycle: 2 sweeps (4 pair launches each) + residual of 6 colours + restriction "
+                                                   "(bytes needed / whole cycle time: a lower bound)",
+                         "achieved": round(cycle_bytes / (elapsed / args.steps) / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
+                         "frac": round(cycle_bytes / (elapsed / args.steps) / 1e9 / 8000.0, 4), "traffic": None,
+                         "bytes_per_cycle": cycle_bytes, "bytes_per_sweep": sweep_bytes},
+            "cpu_baseline": None,
+        }
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+        print(json.dumps(out))
+        sys.stdout.flush()
+    r.close()
+    tail.close()
+    watchdog.cancel()
+    td.barrier()
+    td.destroy_process_group()
+    return 0
+
+
 def main_plane(args, rank, world, shape, grids, n_levels, all_gather, td, torch, watchdog):
     """The 7-point red-black cycle as plane-pipelined passes on slabs with ghost planes (omg_pdist_*)."""
     import numpy as np
@@ -334,6 +460,11 @@ def main(args):
     if (args.stencil == "7pt" and args.smoother == "colour" and args.dtype == "f64" and n_plane >= 1
             and os.environ.get("OMG_DIST_PLANE", "1") != "0"):
         return main_plane(args, rank, world, shape, grids, n_plane, all_gather, td, torch, watchdog)
+    # 27-point operator with per-row coefficients, 8 colours: the octant-layout slab runner (OMG_DIST_SLAB27=0: the set-by-set
+    # runner below)
+    n_s27 = slab27_levels(shape, world, n_dist, args.dtype)
+    if args.stencil == "27var" and args.smoother == "colour" and n_s27 >= 1 and os.environ.get("OMG_DIST_SLAB27", "1") != "0":
+        return main_slab27(args, rank, world, shape, grids, n_s27, all_gather, td, torch, watchdog)
     part = dist.SlabPartition(shape, world, n_dist)
     lo, hi = part.rows(0, rank)
     w = 8 if args.dtype == "f64" else 4
