@@ -396,6 +396,9 @@ int omg_pdist_sync(omg_pdist *d);
 int omg_pdist_trace(omg_pdist *d, int enable);
 int omg_pdist_progress(omg_pdist *d, unsigned *word);
 int omg_pdist_cycles(omg_pdist *d, int n_cycles, double *norms /* nullable */);
+/* V(pre, post) with pre, post in {0, 1} — the reference's default is V(1, 0), openmg/__init__.py:22-23 — as the passes
+ * without their relaxation; over the RCCL exchanges (peer mode and split passes: V(1, 1) only)                      */
+int omg_pdist_cycles_ex(omg_pdist *d, int pre, int post, int n_cycles, double *norms /* nullable */);
 
 /* ---- peer mode: the slab exchanges as stores into the neighbours' memory over xGMI peer mappings ------------------
  * (no reference counterpart: openmg is single-process.)  The passes write their boundary planes straight into the
@@ -419,6 +422,7 @@ int omg_pdist_cycles_squares(omg_pdist *d, int n_cycles, double *squares);      
 int omg_pdist_group_create(int n, omg_pdist **ranks, omg_pdist_group **out);
 int omg_pdist_group_destroy(omg_pdist_group *g);
 int omg_pdist_group_cycles(omg_pdist_group *g, int n_cycles, double *norms /* nullable */);
+int omg_pdist_group_cycles_ex(omg_pdist_group *g, int pre, int post, int n_cycles, double *norms /* nullable */);
 
 /* ---- 27-point slabs (csrc/dist27.hip, round 5): the multi-GPU cycle of 27-point grid stencils with per-row
  * coefficients (BASELINE configs[4]) on the kernels of csrc/stencil27.hip.  (No reference counterpart: openmg is

@@ -127,6 +127,8 @@ SIGNATURES = {
     "omg_pdist_trace": (_I, [_P, _I]),
     "omg_pdist_progress": (_I, [_P, ctypes.POINTER(ctypes.c_uint)]),
     "omg_pdist_cycles": (_I, [_P, _I, _P]),
+    "omg_pdist_cycles_ex": (_I, [_P, _I, _I, _I, _P]),
+    "omg_pdist_group_cycles_ex": (_I, [_P, _I, _I, _I, _P]),
     "omg_pdist_group_create": (_I, [_I, _P, _PP]),
     "omg_pdist_group_destroy": (_I, [_P]),
     "omg_pdist_group_cycles": (_I, [_P, _I, _P]),

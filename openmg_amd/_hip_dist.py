@@ -259,12 +259,12 @@ class PlaneDistRank:
         check(lib().omg_pdist_progress(self._h, ctypes.byref(w)))
         return w.value >> 16, (w.value >> 8) & 0xFF, self.PHASES.get(w.value & 0xFF, "phase %d" % (w.value & 0xFF))
 
-    def cycles(self, n_cycles, reduce=None):
+    def cycles(self, n_cycles, reduce=None, pre=1, post=1):
         """n cycles -> every cycle's global residual norm.  reduce (peer mode without a communicator): a callable
-        taking this rank's list of squared-residual sums and returning the sums over all ranks."""
+        taking this rank's list of squared-residual sums and returning the sums over all ranks.  pre, post in {0, 1}."""
         norms = (ctypes.c_double * max(int(n_cycles), 1))()
         if reduce is None:
-            check(lib().omg_pdist_cycles(self._h, int(n_cycles), norms))
+            check(lib().omg_pdist_cycles_ex(self._h, int(pre), int(post), int(n_cycles), norms))
             out = [float(norms[k]) for k in range(int(n_cycles))]
         else:
             check(lib().omg_pdist_cycles_squares(self._h, int(n_cycles), norms))
@@ -333,9 +333,9 @@ class PlaneDistGroup:
         check(lib().omg_pdist_group_create(len(self.ranks), arr, ctypes.byref(g)))
         self._g = g
 
-    def cycles(self, n_cycles):
+    def cycles(self, n_cycles, pre=1, post=1):
         norms = (ctypes.c_double * max(int(n_cycles), 1))()
-        check(lib().omg_pdist_group_cycles(self._g, int(n_cycles), norms))
+        check(lib().omg_pdist_group_cycles_ex(self._g, int(pre), int(post), int(n_cycles), norms))
         for r in self.ranks:
             if r.p2p_status():
                 raise RuntimeError("rank %d: a bounded wait inside a pass gave up" % r.rank)

@@ -969,6 +969,9 @@ __global__ __launch_bounds__(256) void pd_gather_kernel(const double *src, int64
 struct PDExchange {
     std::vector<PlaneDist *> ranks;           // the ranks this process drives, ascending
     bool loopback = false;
+    // sweep counts of the running cycle (0 or 1 each: the reference's default is V(1, 0), openmg/__init__.py:22-23): the
+    // passes without their relaxation (plane.hip SWEEP = false) run on slabs whose neighbours are reached by exchanges
+    int pre = 1, post = 1;
 
     // ghost planes of a plane-major vector of level l (both colours): `count` planes from either neighbour
     bool exchanges() const { return loopback ? ranks.size() > 1 : ranks[0]->n_ranks > 1; }
@@ -1080,9 +1083,12 @@ struct PDExchange {
                 const PlanePlan<double>::Peer p = peer_of(d, l, true, first_of_batch);
                 L.plan.down(L.xp, L.tp, L.b.p, l > 0, c, d->stream, &p);
             } else {
-                L.plan.down(L.xp, L.tp, L.b.p, l > 0, c, (on_side || part == PlanePlan<double>::PART_EDGE) ? d->side : d->stream, nullptr, true, part);
+                // (pre = 0: the residual of the iterate as it is + the restriction; x_new is not written.  A level below the finest
+                // enters with a zero iterate that the pass does not write either, and the up pass reads it: cleared here)
+                if (pre == 0 && l > 0) OMG_HIP(hipMemsetAsync(L.xp, 0, size_t(L.n_ext) * sizeof(double), d->stream));
+                L.plan.down(L.xp, L.tp, L.b.p, l > 0, c, (on_side || part == PlanePlan<double>::PART_EDGE) ? d->side : d->stream, nullptr, pre >= 1, part);
             }
-            if (swap) std::swap(L.xp, L.tp);
+            if (swap && pre >= 1) std::swap(L.xp, L.tp);
         }
     }
     void up(int l, double *partials, int part = PlanePlan<double>::PART_ALL, bool swap = true, bool on_side = false) {
@@ -1097,7 +1103,7 @@ struct PDExchange {
                 const PlanePlan<double>::Peer p = peer_of(d, l, false, false);
                 L.plan.up(L.xp, L.tp, L.b.p, c, out, d->stream, &p);
             } else {
-                L.plan.up(L.xp, L.tp, L.b.p, c, out, (on_side || part == PlanePlan<double>::PART_EDGE) ? d->side : d->stream, nullptr, true, part);
+                L.plan.up(L.xp, L.tp, L.b.p, c, out, (on_side || part == PlanePlan<double>::PART_EDGE) ? d->side : d->stream, nullptr, post >= 1, part);
             }
             if (swap) std::swap(L.xp, L.tp);
         }
@@ -1264,7 +1270,7 @@ struct PDExchange {
         for (PlaneDist *d : ranks) {
             const int64_t plane = int64_t(d->cnx) * d->cny;
             const double *gathered = (d->p2p && (d->cycle_no & 1u)) ? d->full_b2.p : d->full_b.p;
-            if (omg_hierarchy_cycle_dev(d->tail, gathered, d->full_x.p, 1, 1, d->stream) != OMG_OK)
+            if (omg_hierarchy_cycle_dev(d->tail, gathered, d->full_x.p, pre, post, d->stream) != OMG_OK)
                 throw Error(OMG_ERR_HIP, std::string("replicated tail cycle: ") + omg_last_error());
             // planes [k0 - ghost, k0 + own + ghost) of the correction, clipped to the grid (the rest stays zero)
             const int64_t k0 = int64_t(d->rank) * d->cnzo, nzg = int64_t(d->n_ranks) * d->cnzo;
@@ -1280,6 +1286,8 @@ struct PDExchange {
     void cycle(double *squares_out = nullptr /* one rank only: where its sum of squares goes instead of norm2 */, bool first_of_batch = false) {
         const int nd = (int)ranks[0]->lv.size();
         for (PlaneDist *d : ranks) ++d->cycle_no;
+        OMG_REQUIRE(pre >= 0 && pre <= 1 && post >= 0 && post <= 1, "plane slabs: sweep counts of 0 or 1 (more sweeps: the set-by-set runner, omg_dist_*)");
+        OMG_REQUIRE((pre == 1 && post == 1) || (!p2p() && !split()), "plane slabs: cycles other than V(1,1) run over exchanges (no peer mode, no split passes)");
         if (p2p()) {
             // peer mode: no exchange launches — the passes store into their neighbours and wait for them (prime() has
             // run before the batch's first cycle)
@@ -2059,7 +2067,7 @@ int omg_pdist_sync(omg_pdist *d) {
 }
 
 /* n_cycles V(1,1) cycles, every cycle's global residual norm computed and returned; collective. */
-static int pd_cycles(omg_pdist *d, int n_cycles, double *norms, bool squares_only) {
+static int pd_cycles(omg_pdist *d, int pre, int post, int n_cycles, double *norms, bool squares_only) {
     return guarded([&] {
         OMG_REQUIRE(d && d->d && n_cycles >= 0, "bad argument");
         PlaneDist *dd = d->d.get();
@@ -2069,6 +2077,7 @@ static int pd_cycles(omg_pdist *d, int n_cycles, double *norms, bool squares_onl
         if (dd->norms.n < size_t(n_cycles)) dd->norms.alloc(size_t(n_cycles));
         PDExchange ex;
         ex.ranks = {dd};
+        ex.pre = pre; ex.post = post;
         if (dd->p2p) ex.prime();
         for (int k = 0; k < n_cycles; ++k) ex.cycle(dd->norms.p + k, k == 0);
         if (squares_only) { OMG_REQUIRE(norms, "null argument"); }
@@ -2078,10 +2087,12 @@ static int pd_cycles(omg_pdist *d, int n_cycles, double *norms, bool squares_onl
     });
 }
 
-int omg_pdist_cycles(omg_pdist *d, int n_cycles, double *norms) { return pd_cycles(d, n_cycles, norms, false); }
+int omg_pdist_cycles(omg_pdist *d, int n_cycles, double *norms) { return pd_cycles(d, 1, 1, n_cycles, norms, false); }
+/* V(pre, post) with pre, post in {0, 1} (openmg/__init__.py:22-23: the reference's default is V(1, 0)); RCCL exchanges only */
+int omg_pdist_cycles_ex(omg_pdist *d, int pre, int post, int n_cycles, double *norms) { return pd_cycles(d, pre, post, n_cycles, norms, false); }
 /* The same cycles; squares[k] = THIS rank's sum of squared residuals after cycle k — no collective (peer mode without
  * a communicator: the caller adds the ranks' values and takes the root). */
-int omg_pdist_cycles_squares(omg_pdist *d, int n_cycles, double *squares) { return pd_cycles(d, n_cycles, squares, true); }
+int omg_pdist_cycles_squares(omg_pdist *d, int n_cycles, double *squares) { return pd_cycles(d, 1, 1, n_cycles, squares, true); }
 
 /* All ranks of a decomposition in ONE process on one GPU: the same launches per rank, device copies in place of
  * the RCCL exchanges (verification of the schedule without several GPUs).  The ranks run on rank 0's stream. */
@@ -2105,11 +2116,15 @@ int omg_pdist_group_destroy(omg_pdist_group *g) {
     return OMG_OK;
 }
 
-int omg_pdist_group_cycles(omg_pdist_group *g, int n_cycles, double *norms) {
+int omg_pdist_group_cycles_ex(omg_pdist_group *g, int pre, int post, int n_cycles, double *norms);
+int omg_pdist_group_cycles(omg_pdist_group *g, int n_cycles, double *norms) { return omg_pdist_group_cycles_ex(g, 1, 1, n_cycles, norms); }
+
+int omg_pdist_group_cycles_ex(omg_pdist_group *g, int pre, int post, int n_cycles, double *norms) {
     return guarded([&] {
         OMG_REQUIRE(g && !g->ranks.empty() && n_cycles >= 0, "bad argument");
         PDExchange ex;
         ex.loopback = true;
+        ex.pre = pre; ex.post = post;
         for (omg_pdist *r : g->ranks) {
             OMG_REQUIRE(r->d->tail, "omg_pdist_set_tail has not been called on every rank");
             ex.ranks.push_back(r->d.get());

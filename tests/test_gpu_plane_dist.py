@@ -53,6 +53,31 @@ def test_plane_slabs_have_the_bits_of_the_single_gpu_cycle(shape, grids, n_dist)
         np.testing.assert_allclose(norms, want_norms, rtol=1e-13)
 
 
+@pytest.mark.parametrize("pre,post", [(1, 0), (0, 1), (0, 0)])
+def test_plane_slabs_run_the_reference_default_cycle(pre, post):
+    """V(1, 0) — the reference's default, openmg/__init__.py:22-23 —, V(0, 1), V(0, 0) on slabs: the passes without their
+    relaxation (plane.hip SWEEP = false) over the same exchanges; the bits of the single-GPU cycle.  More than one sweep
+    a side is refused (the set-by-set slab runner has them)."""
+    shape, grids, n_dist = (32, 32, 32), 4, 2
+    A, R, b, x0 = problem(shape, grids)
+    with _hip.Hierarchy(A, R, smoother="colour") as h:
+        h.resident_load(b, x0)
+        want_norms = [h.resident_cycle(pre, post) for _ in range(3)]
+        want = h.resident_fetch()
+    for n_ranks in (1, 2, 4, 8):
+        g = _hip_dist.PlaneDistGroup(slabs(A, R, shape, n_ranks, n_dist, b, x0))
+        try:
+            norms = g.cycles(2, pre, post) + g.cycles(1, pre, post)
+            got = np.concatenate([r.fetch() for r in g.ranks])
+            if n_ranks == 2:
+                with pytest.raises(_hip.HipError):
+                    g.cycles(1, 2, 1)
+        finally:
+            g.close()
+        assert np.array_equal(got, want), (pre, post, n_ranks, int(np.sum(got != want)))
+        np.testing.assert_allclose(norms, want_norms, rtol=1e-13)
+
+
 @pytest.mark.parametrize("mode", ["1", "2"])
 def test_split_passes_have_the_bits_of_whole_passes(monkeypatch, mode):
     """OMG_PDIST_SPLIT: every slab pass as two launches — the slab's first and last four planes on the (priority) side
