@@ -42,6 +42,7 @@ template <typename V>
 struct SLevel {
     int nx = 0, ny = 0, nzo = 0;              // cells per line, lines per plane, OWNED planes
     Stencil27Plan<V> plan;                    // on the extended slab: nzo + 4 planes
+    DevBuf<char> pool;                        // large levels: x, b, tmp as views into ONE allocation (hierarchy.hip pooled_vectors)
     DevBuf<V> x, tmp, b;
     V *xp = nullptr, *tp = nullptr;
     DevBuf<int32_t> cmap;                     // aggregate of the extended slab (natural index) -> slot in the next level's vectors
@@ -195,7 +196,21 @@ std::unique_ptr<SDist<V>> sd_create(int rank, int n_ranks, int nx, int ny, int n
         L.plan.build_slab(A, lx, ly, lz + 4, rank == 0, rank == n_ranks - 1, w, s);
         const S27Geom &g = L.plan.g;
         const size_t nv = size_t(8) * size_t(g.na);
-        L.x.alloc(nv); L.tmp.alloc(nv); L.b.alloc(nv);
+        {
+            // the three vectors the sweeps stream side by side out of one allocation, each 2 MiB-aligned + its stagger, b in the
+            // middle: what hierarchy.hip measured for whole grids (configs[4]: + 3 %); OMG_VEC_POOL=0: three allocations
+            static const bool pool_on = [] { const char *e = getenv("OMG_VEC_POOL"); return !(e && e[0] == '0'); }();
+            if (pool_on && nv >= (size_t(1) << 20)) {
+                const size_t MB2 = size_t(2) << 20, bytes = nv * sizeof(V);
+                const size_t span = (bytes + 2 * DEVBUF_SLACK + vector_stagger(2) + MB2 - 1) / MB2 * MB2;
+                L.pool.alloc(3 * span);
+                L.x.borrow(reinterpret_cast<V *>(L.pool.p + DEVBUF_SLACK), nv);
+                L.b.borrow(reinterpret_cast<V *>(L.pool.p + span + DEVBUF_SLACK + vector_stagger(2)), nv);
+                L.tmp.borrow(reinterpret_cast<V *>(L.pool.p + 2 * span + DEVBUF_SLACK + vector_stagger(1)), nv);
+            } else {
+                L.x.alloc(nv); L.tmp.alloc(nv); L.b.alloc(nv);
+            }
+        }
         L.x.zero(s); L.tmp.zero(s); L.b.zero(s);
         L.xp = L.x.p; L.tp = L.tmp.p;
         // the next level's operator: (R A) R^T with the aggregation of the extended slab; it comes out with ONE ghost plane
