@@ -653,11 +653,23 @@ struct PlanePlan {
         const int nzo = g.z_end - g.z_base;
         return nzo >= 3 * PLANE_EDGE ? g.ntx * g.nty * (2 + (nzo - 2 * PLANE_EDGE + g.LZ - 1) / g.LZ) : g.n_wg;
     }
+    // Slab neighbours reached by an exchange that runs on ANOTHER stream while the pass does (dist.hip, RCCL): the pass is
+    // ONE launch of inner chunks and — with the highest workgroup numbers, dispatched last — the slab's first and last
+    // PLANE_EDGE planes as short chunks of their own, which wait (bounded, status bit 0) until flag[i] holds seq[i] before
+    // they read a ghost plane; the inner chunks read none and never wait.
+    struct Gate {
+        const uint32_t *flag[4] = {nullptr, nullptr, nullptr, nullptr};
+        uint32_t seq[4] = {0, 0, 0, 0};
+        uint32_t *status = nullptr;
+        uint32_t spin = 1u << 21;
+    };
+    int gate_lz() const;              // planes per inner chunk of such a launch
+    int gate_partials() const;        // its workgroups = norm partials
     void down(const V *x_old, V *x_new, const V *b, bool x_zero, const Coarse &c, hipStream_t s, const Peer *peer = nullptr,
-              bool sweep = true, int part = PART_ALL) const;
-    // out (nullable): block partials of the squared residual norm, g.n_wg doubles
+              bool sweep = true, int part = PART_ALL, const Gate *gate = nullptr) const;
+    // out (nullable): also the squares of the residual of the NEW iterate, one partial per workgroup
     void up(const V *x_old, V *x_new, const V *b, const Coarse &c, double *out, hipStream_t s, const Peer *peer = nullptr,
-            bool sweep = true, int part = PART_ALL) const;
+            bool sweep = true, int part = PART_ALL, const Gate *gate = nullptr) const;
 };
 
 // ---- 27-point grid stencils with per-row coefficients: BASELINE configs[4] (stencil27.hip) ----------------

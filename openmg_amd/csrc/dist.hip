@@ -810,6 +810,10 @@ constexpr int PF_DOWN = 0;                    // + level: the neighbour's down p
 constexpr int PF_UP = 8;                      // + level: ... its up pass
 constexpr int PF_PRIME = 16;                  // the ghost planes a batch of cycles starts from have been written
 constexpr int PF_READY = 17;                  // the neighbour's stream has reached the start of the batch
+// gated passes (RCCL exchanges on the side stream while the pass runs): LOCAL words, raised by a one-thread launch on the
+// side stream behind the exchange — the ghost planes of x for the finest level's down pass / for its up pass, of the
+// correction for its up pass
+constexpr int PF_GATE_X = 18, PF_GATE_XU = 19, PF_GATE_C = 20;
 constexpr int PF_GATHER = 64;                 // + source rank (no direction): its planes of the tail's right-hand side
 constexpr int PD_STATUS = PD_FLAGS, PD_DONE = PD_FLAGS + 1, PD_COUNT = PD_FLAGS + 8;   // local words behind the flags
 inline int pf(int slot, int from) { return slot * 2 + from; }
@@ -856,7 +860,15 @@ struct PlaneDist {
     // profiles/r04_pdist_split_cost.txt) the two launches + their stream hand-overs cost a rank ~27 us of device time per
     // pass, ~165 us per cycle — more than the ~120 us of exchange latency and wire time they can hide at N = 8.
     bool split = [] { const char *e = getenv("OMG_PDIST_SPLIT"); return e && (e[0] == '1' || e[0] == '2'); }();
-    bool x0_posted = false;                   // the ghost planes of x for the next cycle's first pass are already on their way (ev_edge[1][0])
+    bool x0_posted = false;                   // the ghost planes of x for the next cycle's first pass are already on their way (ev_edge[1][0] / PF_GATE_X)
+    // Gated passes (round 5): the finest level's two passes run as ONE launch each whose edge chunks — the slab's first and
+    // last four planes, the highest workgroup numbers — wait on a device flag for their ghost planes, while the exchange
+    // that brings them runs on the side stream BESIDE the pass's inner chunks: the 3-plane exchange between up(k) and
+    // down(k + 1) and the correction's exchange in front of the finest up pass leave the critical path without a second
+    // launch (split passes: + 27 us each) and without peer stores.  OMG_PDIST_GATE=0: exchanges in stream order.
+    // (=2: also with ONE slab — no neighbour, no exchange: what the one-launch inner + edge form costs a rank in device time)
+    bool gate = [] { const char *e = getenv("OMG_PDIST_GATE"); return !(e && e[0] == '0'); }();
+    bool gate_forced = [] { const char *e = getenv("OMG_PDIST_GATE"); return e && e[0] == '2'; }();
     // progress of the DEVICE through a cycle, for a caller whose collective never completes (bench.py's preflight):
     // a word in pinned host memory the stream writes between the phases — (cycle << 16) | (level << 8) | phase,
     // phase 1 halo x, 2 halo b, 3 down pass, 4 halo x (for the up pass), 5 gather + tail, 6 halo of the correction,
@@ -1071,7 +1083,31 @@ struct PDExchange {
     }
     // part: PlanePlan::PART_ALL, or one of the two launches of a split pass (the EDGE launch goes to the side stream;
     // the vectors are swapped once, after the pass's last launch has been enqueued: swap)
-    void down(int l, bool first_of_batch = false, int part = PlanePlan<double>::PART_ALL, bool swap = true, bool on_side = false) {
+    // the finest level's passes gated on exchanges that run beside them (PlaneDist::gate)?  V(1,1) over RCCL / loopback copies,
+    // more than one slab, a slab thick enough for edge chunks of its own
+    bool gated0() const {
+        if (p2p() || pre != 1 || post != 1) return false;
+        bool forced = true;
+        for (PlaneDist *d : ranks) {
+            if (!d->gate || d->split || !d->lv[0].plan.can_split()) return false;
+            forced = forced && d->gate_forced;
+        }
+        return exchanges() || forced;
+    }
+    PlanePlan<double>::Gate gate_of(PlaneDist *d, int slot_a, int slot_b = -1) const {
+        PlanePlan<double>::Gate g;
+        g.flag[0] = d->flags.p + pf(slot_a, 0);
+        g.seq[0] = d->cycle_no;
+        if (slot_b >= 0) { g.flag[1] = d->flags.p + pf(slot_b, 0); g.seq[1] = d->cycle_no; }
+        g.status = d->flags.p + PD_STATUS;
+        g.spin = d->spin;
+        return g;
+    }
+    void raise(PlaneDist *d, hipStream_t st, int slot, uint32_t seq) {
+        hipLaunchKernelGGL(pd_signal_kernel, dim3(1), dim3(1), 0, st, d->flags.p + pf(slot, 0), static_cast<uint32_t *>(nullptr), seq);
+        OMG_HIP(hipGetLastError());
+    }
+    void down(int l, bool first_of_batch = false, int part = PlanePlan<double>::PART_ALL, bool swap = true, bool on_side = false, bool gated = false) {
         for (PlaneDist *d : ranks) {
             PDLevel &L = d->lv[l];
             const bool last = l + 1 == (int)d->lv.size();
@@ -1086,12 +1122,14 @@ struct PDExchange {
                 // (pre = 0: the residual of the iterate as it is + the restriction; x_new is not written.  A level below the finest
                 // enters with a zero iterate that the pass does not write either, and the up pass reads it: cleared here)
                 if (pre == 0 && l > 0) OMG_HIP(hipMemsetAsync(L.xp, 0, size_t(L.n_ext) * sizeof(double), d->stream));
-                L.plan.down(L.xp, L.tp, L.b.p, l > 0, c, (on_side || part == PlanePlan<double>::PART_EDGE) ? d->side : d->stream, nullptr, pre >= 1, part);
+                const PlanePlan<double>::Gate gt = gate_of(d, PF_GATE_X);
+                L.plan.down(L.xp, L.tp, L.b.p, l > 0, c, (on_side || part == PlanePlan<double>::PART_EDGE) ? d->side : d->stream, nullptr, pre >= 1, part,
+                            gated ? &gt : nullptr);
             }
             if (swap && pre >= 1) std::swap(L.xp, L.tp);
         }
     }
-    void up(int l, double *partials, int part = PlanePlan<double>::PART_ALL, bool swap = true, bool on_side = false) {
+    void up(int l, double *partials, int part = PlanePlan<double>::PART_ALL, bool swap = true, bool on_side = false, bool gated = false) {
         for (PlaneDist *d : ranks) {
             PDLevel &L = d->lv[l];
             const bool last = l + 1 == (int)d->lv.size();
@@ -1103,7 +1141,9 @@ struct PDExchange {
                 const PlanePlan<double>::Peer p = peer_of(d, l, false, false);
                 L.plan.up(L.xp, L.tp, L.b.p, c, out, d->stream, &p);
             } else {
-                L.plan.up(L.xp, L.tp, L.b.p, c, out, (on_side || part == PlanePlan<double>::PART_EDGE) ? d->side : d->stream, nullptr, post >= 1, part);
+                const PlanePlan<double>::Gate gt = gate_of(d, PF_GATE_XU, last ? -1 : PF_GATE_C);
+                L.plan.up(L.xp, L.tp, L.b.p, c, out, (on_side || part == PlanePlan<double>::PART_EDGE) ? d->side : d->stream, nullptr, post >= 1, part,
+                          gated ? &gt : nullptr);
             }
             if (swap) std::swap(L.xp, L.tp);
         }
@@ -1300,34 +1340,74 @@ struct PDExchange {
             return;
         }
         if (split()) { cycle_split(squares_out); return; }
-        halo(0, 0, 3);
+        const bool g0 = gated0();
+        if (g0) {
+            // the ghost planes of x the first pass reads were posted behind the previous cycle's last pass (side stream), or
+            // — the first cycle after a load — are exchanged here, in stream order
+            bool posted = true;
+            for (PlaneDist *d : ranks) posted = posted && d->x0_posted;
+            if (!posted) {
+                halo(0, 0, 3);
+                for (PlaneDist *d : ranks) raise(d, d->stream, PF_GATE_X, d->cycle_no);
+            }
+        } else {
+            halo(0, 0, 3);
+        }
         mark(0, 1);
         for (int l = 0; l < nd; ++l) {
             if (l > 0) { halo(l, 1, 2); mark(l, 2); }
-            down(l);
+            down(l, false, PlanePlan<double>::PART_ALL, true, false, g0 && l == 0);
             mark(l, 3);
             // the ghost planes for the up pass: on the side stream, beside the coarser levels (nothing before the up
             // pass reads or writes them, nor the planes they are copied from)
-            if (!exchanges()) continue;                           // one slab: no neighbour, no second stream
+            if (!exchanges() && !(g0 && l == 0)) continue;        // one slab: no neighbour, no second stream
             for (PlaneDist *d : ranks) {
                 OMG_HIP(hipEventRecord(d->ev_down[size_t(l)], d->stream));
                 OMG_HIP(hipStreamWaitEvent(d->side, d->ev_down[size_t(l)], 0));
             }
             halo(l, 0, 3, true);
-            for (PlaneDist *d : ranks) OMG_HIP(hipEventRecord(d->ev_halo[size_t(l)], d->side));
+            if (g0 && l == 0) { for (PlaneDist *d : ranks) raise(d, d->side, PF_GATE_XU, d->cycle_no); }
+            else { for (PlaneDist *d : ranks) OMG_HIP(hipEventRecord(d->ev_halo[size_t(l)], d->side)); }
         }
         tail_solve();
         mark(nd, 5);
         for (int l = nd - 1; l >= 0; --l) {
-            if (l + 1 < nd) { halo(l + 1, 0, 2); mark(l, 6); }    // ghost planes of the correction
-            if (exchanges())
+            const bool gl = g0 && l == 0;
+            if (l + 1 < nd) {                                     // ghost planes of the correction
+                if (gl) {
+                    // ... beside the finest up pass's inner chunks: its edge chunks wait for PF_GATE_C
+                    for (PlaneDist *d : ranks) {
+                        OMG_HIP(hipEventRecord(d->ev_main[1][1], d->stream));
+                        OMG_HIP(hipStreamWaitEvent(d->side, d->ev_main[1][1], 0));
+                    }
+                    halo(l + 1, 0, 2, true);
+                    for (PlaneDist *d : ranks) raise(d, d->side, PF_GATE_C, d->cycle_no);
+                } else {
+                    halo(l + 1, 0, 2);
+                }
+                mark(l, 6);
+            }
+            if (exchanges() && !gl)
                 for (PlaneDist *d : ranks) OMG_HIP(hipStreamWaitEvent(d->stream, d->ev_halo[size_t(l)], 0));
             mark(l, 4);
-            up(l, nullptr);
+            up(l, nullptr, PlanePlan<double>::PART_ALL, true, false, gl);
             mark(l, 7);
         }
+        if (g0) {
+            // the next cycle's first exchange, posted now: it runs beside that cycle's down pass, whose edge chunks wait for it
+            const char *pe = getenv("OMG_PDIST_GATE_POISON");
+            const bool poison = pe && pe[0] == '1';
+            for (PlaneDist *d : ranks) {
+                OMG_HIP(hipEventRecord(d->ev_main[1][0], d->stream));
+                OMG_HIP(hipStreamWaitEvent(d->side, d->ev_main[1][0], 0));
+            }
+            halo(0, 0, 3, true);
+            // (OMG_PDIST_GATE_POISON=1, tests: the flag is never raised — the next pass's bounded wait must give up and say so)
+            if (!poison) for (PlaneDist *d : ranks) raise(d, d->side, PF_GATE_X, d->cycle_no + 1);
+            for (PlaneDist *d : ranks) d->x0_posted = true;
+        }
         for (PlaneDist *d : ranks)
-            launch_sum(d->lv[0].plan.partials.p, d->lv[0].plan.g.n_wg, squares_out ? squares_out : d->norm2.p, d->stream);
+            launch_sum(d->lv[0].plan.partials.p, g0 ? d->lv[0].plan.gate_partials() : d->lv[0].plan.g.n_wg, squares_out ? squares_out : d->norm2.p, d->stream);
     }
     // a batch of cycles of ONE rank: slot k holds this rank's squares of cycle k; one all-reduce for all of them
     // (nothing on the device waits for a norm, so none is needed inside a cycle), then the roots in place
@@ -2020,6 +2100,7 @@ int omg_pdist_load(omg_pdist *d, const double *b_local, const double *x0_local) 
     return guarded([&] {
         OMG_REQUIRE(d && d->d && b_local, "null argument");
         PlaneDist *dd = d->d.get();
+        OMG_HIP(hipStreamSynchronize(dd->side));                  // (an exchange posted behind the last cycle may still be writing ghost planes)
         dd->x0_posted = false;                                    // (the next cycle exchanges the ghost planes of the new iterate itself)
         pd_put(dd, b_local, dd->lv[0].b.p);
         pd_put(dd, x0_local, dd->lv[0].xp);

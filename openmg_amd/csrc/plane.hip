@@ -192,6 +192,10 @@ struct PlaneKArgs {
     // slab's first and last PLANE_EDGE planes —, the INNER launch chunks of LZ planes between them; the norm's partial of a
     // workgroup then goes to slot part_slot0 + its number (the two launches fill one array)
     int zc_base, zc_stride, zc_len, zc_end, part_slot0;
+    // ONE launch of inner and edge chunks (PlanePlan::Gate: a slab whose ghost planes arrive by an exchange on another stream
+    // while the pass runs): workgroups [0, edge_wg0) take the inner chunks above, the others — dispatched last — the slab's
+    // first and last PLANE_EDGE planes, and wait for wait_flag[] before they read anything.  0: no such launch
+    int edge_wg0;
     V c0, c1, c2, c3, c4, c5, c6, w;
     int x_zero;
     int fast_div;                    // the diagonal's exponent is within 2^-400 .. 2^400 (quotients())
@@ -379,12 +383,18 @@ __global__ __launch_bounds__(MAXT) void plane_kernel(const PlaneKArgs<V> a) {
     // workgroup -> (tx, ty, tz).  Blocks b and b + 8 share an XCD (observed, speed only): give an
     // XCD a contiguous run of z chunks so that the tiles sharing a ring also share an L2.
     int L = int(blockIdx.x);
-    const int nwg = int(gridDim.x);
+    int nwg = int(gridDim.x);
+    const bool edge_wg = !PEER && a.edge_wg0 > 0 && L >= a.edge_wg0;      // (uniform; decided once, before the loop)
+    if (!PEER && a.edge_wg0 > 0) {
+        if (edge_wg) { L -= a.edge_wg0; nwg = 1; }
+        else nwg = a.edge_wg0;
+    }
     if ((nwg & 7) == 0) L = (L & 7) * (nwg >> 3) + (L >> 3);
     const int nxy = a.ntx * a.nty;
     const int tz = L / nxy, rem = L - tz * nxy;
     const int ty = rem / a.ntx, tx = rem - ty * a.ntx;
-    const int z0 = a.zc_base + tz * a.zc_stride, z1 = min(a.zc_end, z0 + a.zc_len);
+    const int z0 = edge_wg ? (tz ? a.z_end - PLANE_EDGE : a.z_base) : a.zc_base + tz * a.zc_stride;
+    const int z1 = edge_wg ? z0 + PLANE_EDGE : min(a.zc_end, z0 + a.zc_len);
     const int q = tx * a.TXq + px - 1;               // pair index in the line
     const int ja = ty * a.TY + 2 * py - 4;           // the thread's lines ja (even), ja + 1
     const bool vx0 = live && q >= 0 && 2 * q < a.hx, vx1 = live && q >= 0 && 2 * q + 1 < a.hx;
@@ -510,7 +520,7 @@ __global__ __launch_bounds__(MAXT) void plane_kernel(const PlaneKArgs<V> a) {
     const int row_a = 1 + 2 * py, col = 2 + 2 * px;
     const int idx[2] = {row_a * S + col, (row_a + 1) * S + col};
     for (int i = t; i < 6 * BUF; i += int(blockDim.x)) lds[i] = V(0);
-    if (PEER && a.fused_wait && t == 0) {
+    if (((PEER && a.fused_wait) || edge_wg) && t == 0) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) peer_wait(a.wait_flag[i], a.wait_seq[i], a.status, a.spin);
     }
@@ -2165,13 +2175,45 @@ void launch_plane(K kernel, const PlaneGeom &g, const PlaneKArgs<V> &k, hipStrea
     OMG_HIP(hipGetLastError());
 }
 
+// the one-launch form of a pass whose ghost planes are still on their way (PlanePlan::Gate): inner chunks, then edge chunks
 template <typename V>
-void PlanePlan<V>::down(const V *x_old, V *x_new, const V *b, bool x_zero, const Coarse &c, hipStream_t s, const Peer *peer, bool sweep, int part) const {
+int plane_gate(const PlaneGeom &g, PlaneKArgs<V> &k, const typename PlanePlan<V>::Gate &gate, int lz) {
+    const int nxy = g.ntx * g.nty, nzo = g.z_end - g.z_base;
+    k.zc_base = g.z_base + PLANE_EDGE; k.zc_stride = lz; k.zc_len = lz; k.zc_end = g.z_end - PLANE_EDGE; k.part_slot0 = 0;
+    k.edge_wg0 = nxy * ((nzo - 2 * PLANE_EDGE + lz - 1) / lz);
+    for (int i = 0; i < 4; ++i) { k.wait_flag[i] = gate.flag[i]; k.wait_seq[i] = gate.seq[i]; }
+    k.spin = gate.spin;
+    if (gate.status) k.status = gate.status;
+    return k.edge_wg0 + 2 * nxy;
+}
+
+template <typename V>
+int PlanePlan<V>::gate_lz() const {
+    // as many inner chunks as leave most of the edge workgroups a compute unit of their own from the start (the rest
+    // follow the first workgroups that finish): 256 compute units, one workgroup each
+    const int nxy = g.ntx * g.nty, nzo = g.z_end - g.z_base;
+    static const int forced = [] { const char *e = getenv("OMG_PLANE_GATE_LZ"); return e ? atoi(e) : 0; }();
+    if (forced >= 2) return forced / 2 * 2;
+    const int chunks = std::max(1, (256 - (2 * nxy * 5 + 5) / 6) / nxy);
+    const int lz = ((nzo - 2 * PLANE_EDGE + chunks - 1) / chunks + 1) / 2 * 2;
+    return std::max(lz, g.LZ);
+}
+
+template <typename V>
+int PlanePlan<V>::gate_partials() const {
+    const int nxy = g.ntx * g.nty, nzo = g.z_end - g.z_base;
+    return can_split() ? nxy * (2 + (nzo - 2 * PLANE_EDGE + gate_lz() - 1) / gate_lz()) : g.n_wg;
+}
+
+template <typename V>
+void PlanePlan<V>::down(const V *x_old, V *x_new, const V *b, bool x_zero, const Coarse &c, hipStream_t s, const Peer *peer, bool sweep, int part,
+                        const Gate *gate) const {
     PlaneKArgs<V> k = plane_args<V>(g, x_old, x_new, b, c, status);
     k.x_zero = x_zero ? 1 : 0;
     OMG_REQUIRE(part == 0 || (!peer && sweep && !g.dim2 && !block_level(g) && !c.x && !c.diag && !small_tile(g)),
                 "a pass in two launches: slabs' marching passes only");
-    const int wgs = plane_part(g, k, part);
+    OMG_REQUIRE(!gate || (part == 0 && !peer && sweep && can_split() && !c.x && !c.diag), "a gated pass: slabs' marching passes only");
+    const int wgs = gate ? plane_gate<V>(g, k, *gate, gate_lz()) : plane_part(g, k, part);
 #ifdef OMG_PLANE_STAMPS
     DevBuf<unsigned long long> sb;
     stamps_begin(k, g, sb);
@@ -2216,12 +2258,14 @@ void PlanePlan<V>::down(const V *x_old, V *x_new, const V *b, bool x_zero, const
 }
 
 template <typename V>
-void PlanePlan<V>::up(const V *x_old, V *x_new, const V *b, const Coarse &c, double *out, hipStream_t s, const Peer *peer, bool sweep, int part) const {
+void PlanePlan<V>::up(const V *x_old, V *x_new, const V *b, const Coarse &c, double *out, hipStream_t s, const Peer *peer, bool sweep, int part,
+                      const Gate *gate) const {
     PlaneKArgs<V> k = plane_args<V>(g, x_old, x_new, b, c, status);
     k.partials = out;
     OMG_REQUIRE(part == 0 || (!peer && sweep && !g.dim2 && !block_level(g) && !(small_tile(g) && !out)),
                 "a pass in two launches: slabs' marching passes only");
-    const int wgs = plane_part(g, k, part);
+    OMG_REQUIRE(!gate || (part == 0 && !peer && sweep && can_split()), "a gated pass: slabs' marching passes only");
+    const int wgs = gate ? plane_gate<V>(g, k, *gate, gate_lz()) : plane_part(g, k, part);
     // the up pass of a whole grid marches from the last plane down (plane_kernel MIRROR); OMG_PLANE_MIRROR=0: upwards like the down pass
     const char *mirror_env = getenv("OMG_PLANE_MIRROR");                 // (read per call: A/B runs flip it inside one process)
     const bool mirror_on = !(mirror_env && mirror_env[0] == '0');

@@ -78,6 +78,42 @@ def test_plane_slabs_run_the_reference_default_cycle(pre, post):
         np.testing.assert_allclose(norms, want_norms, rtol=1e-13)
 
 
+def test_gated_passes_have_the_bits_of_stream_ordered_exchanges_and_a_missing_exchange_raises(monkeypatch):
+    """Round 5: the finest level's passes as ONE launch whose edge chunks wait on a device flag while the exchange of their
+    ghost planes runs on the side stream beside the inner chunks (OMG_PDIST_GATE, default on).  Same bits as the
+    exchanges in stream order and as the single-GPU cycle; and when the flag is never raised (OMG_PDIST_GATE_POISON=1:
+    the exchange 'did not happen') the bounded wait gives up and the call RAISES instead of hanging the device."""
+    shape, grids, n_dist = (64, 32, 48), 4, 2
+    A, R, b, x0 = problem(shape, grids)
+    with _hip.Hierarchy(A, R, smoother="colour") as h:
+        h.resident_load(b, x0)
+        want_norms = [h.resident_cycle(1, 1) for _ in range(5)]
+        want = h.resident_fetch()
+    for gate in ("1", "0"):
+        monkeypatch.setenv("OMG_PDIST_GATE", gate)
+        for n_ranks in (2, 4):
+            g = _hip_dist.PlaneDistGroup(slabs(A, R, shape, n_ranks, n_dist, b, x0))
+            try:
+                norms = g.cycles(3) + g.cycles(2)
+                got = np.concatenate([r.fetch() for r in g.ranks])
+            finally:
+                g.close()
+            assert np.array_equal(got, want), (gate, n_ranks, int(np.sum(got != want)))
+            np.testing.assert_allclose(norms, want_norms, rtol=1e-13)
+    monkeypatch.setenv("OMG_PDIST_GATE", "1")
+    monkeypatch.setenv("OMG_P2P_SPIN", "2000")
+    g = _hip_dist.PlaneDistGroup(slabs(A, R, shape, 2, n_dist, b, x0))
+    try:
+        assert g.cycles(1) == want_norms[:1]
+        monkeypatch.setenv("OMG_PDIST_GATE_POISON", "1")
+        g.cycles(1)                                             # (this cycle's own ghost planes were posted before the switch)
+        with pytest.raises(RuntimeError, match="bounded wait"):
+            g.cycles(1)
+    finally:
+        monkeypatch.delenv("OMG_PDIST_GATE_POISON")
+        g.close()
+
+
 @pytest.mark.parametrize("mode", ["1", "2"])
 def test_split_passes_have_the_bits_of_whole_passes(monkeypatch, mode):
     """OMG_PDIST_SPLIT: every slab pass as two launches — the slab's first and last four planes on the (priority) side
