@@ -389,6 +389,10 @@ int omg_pdist_rccl_ranks(omg_pdist *d, int *count);
 int omg_pdist_load(omg_pdist *d, const double *b_local, const double *x0_local /* NULL = zeros */);   /* collective */
 int omg_pdist_fetch(omg_pdist *d, double *x_local);
 int omg_pdist_sync(omg_pdist *d);
+/* out8: distributed levels; 1 when the finest level's passes run GATED between neighbours (one launch of inner chunks and
+ * flag-gated edge chunks, the exchange beside it: csrc/dist.hip PlaneDist::gate); its tiling (cells per line, lines,
+ * planes per chunk), workgroups, threads per workgroup; planes per inner chunk of a gated pass */
+int omg_pdist_info(omg_pdist *d, int64_t *out8);
 /* omg_pdist_trace(1): the stream writes a progress word (pinned host memory) between the phases of a cycle;
  * omg_pdist_progress reads it without synchronising: (cycle << 16) | (level << 8) | phase, phase 1 halo of x, 2 halo of
  * b, 3 down pass, 4 halo of x for the up pass, 5 gather + replicated tail, 6 halo of the correction, 7 up pass —

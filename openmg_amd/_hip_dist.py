@@ -246,6 +246,12 @@ class PlaneDistRank:
     def sync(self):
         check(lib().omg_pdist_sync(self._h))
 
+    def info(self):
+        out = (ctypes.c_int64 * 8)()
+        check(lib().omg_pdist_info(self._h, out))
+        keys = ("levels", "gated", "tile_x", "tile_y", "tile_z", "workgroups", "threads", "gate_tile_z")
+        return dict(zip(keys, [int(v) for v in out]))
+
     PHASES = {0: "not started", 1: "halo exchange of x", 2: "halo exchange of the right-hand side", 3: "down pass",
               4: "halo exchange of x for the up pass", 5: "gather + replicated tail", 6: "halo exchange of the correction",
               7: "up pass"}

@@ -512,6 +512,11 @@ struct MarchPlan {
     DevBuf<int32_t> order;            // ticket -> tile: along the wavefront (anti-diagonals of the tile grid), so that the
                                       // tiles holding a CU are the ones next to run (empty: tickets are tile numbers)
     DevBuf<V> faceJ, faceK;           // [tile][line of the +J / +K face][row]: hand-over slots, unset (a marker NaN) between sweeps
+    // A 1-D grid (tridiagonal operator, any coefficients: openmg's own demo and test operators, BASELINE configs[0]): the
+    // sweep is a first-order recurrence x_i = f_i(x_{i-1}); ONE wave walks it (line_gs_kernel), the rows' coefficients as
+    // three arrays (a row without a neighbour: a zero coefficient)
+    bool line1 = false;
+    DevBuf<V> tri;                    // [3][n]: -I, diagonal, +I
     // false: the operator is not such a stencil (the caller keeps the level schedule)
     bool build(const omg_csr &A, hipStream_t s);
     void sweep(V *x, const V *b, hipStream_t s) const;   // one in-place lexicographic sweep

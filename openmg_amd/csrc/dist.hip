@@ -2139,6 +2139,19 @@ int omg_pdist_progress(omg_pdist *d, unsigned *word) {
     });
 }
 
+/* out8: distributed levels; 1 when the finest level's passes can run gated (inner + edge chunks in one launch); its tile
+ * (cells per line, lines, planes per chunk), workgroups, threads per workgroup, planes per inner chunk of a gated pass */
+int omg_pdist_info(omg_pdist *d, int64_t *out8) {
+    return guarded([&] {
+        OMG_REQUIRE(d && d->d && out8, "null");
+        const PlaneDist *dd = d->d.get();
+        const PlanePlan<double> &P = dd->lv[0].plan;
+        const int64_t v[8] = {int64_t(dd->lv.size()), (dd->gate && !dd->split && P.can_split()) ? 1 : 0, P.g.TX, P.g.TY, P.g.LZ, P.g.n_wg, P.g.threads,
+                              P.can_split() ? P.gate_lz() : 0};
+        for (int i = 0; i < 8; ++i) out8[i] = v[i];
+    });
+}
+
 int omg_pdist_sync(omg_pdist *d) {
     return guarded([&] {
         OMG_REQUIRE(d && d->d, "null");

@@ -528,6 +528,120 @@ __global__ __launch_bounds__(128) void march_gs_kernel(MarchArgs<V> a) {
     }
 }
 
+// ---- 1-D grids: the sweep as a first-order recurrence on ONE wave ---------------------------------------------------
+// openmg/solvers.py:56-68 on a tridiagonal operator: x_i <- x_i + (b_i - (a_i,i-1 x_i-1 + a_ii x_i + a_i,i+1 x_i+1)) / a_ii
+// with the NEW x_i-1 — every row waits for its predecessor, so the sweep is one chain of n links (a scan would associate
+// differently: not the reference's bits).  The tiled wavefront kernel above spends 250 ns per link on a 1-D grid (face
+// slots, shuffles, one lane busy); here a wave holds a block of 64 rows in registers (lane l: row base + l, loaded
+// coalesced, the next block requested a block ahead), every lane runs the SAME chain on wave-uniform operands
+// (v_readlane), and what is left on the dependent path per row is eight double operations: the stored-order chain from
+// +0 (three fmas), b - s, the quotient with the denominator's half hoisted (refined reciprocal per row, formed when the
+// block is loaded: the same instructions on the same operands as the division, march_gs_kernel's rule), x + q.
+// Every lane runs the SAME chain on operands all lanes read from ONE LDS address (a broadcast read: no bank conflict, no
+// vector-ALU instruction — with v_readlane the row's twelve operand dwords cost twelve more issue slots than the chain's
+// eight operations): the wave stages a block of 64 rows in LDS as [row][lo, di, up, r, x, b] (coalesced global loads, the
+// block after next requested meanwhile), walks it, leaves each row's result in LDS, and stores the block coalesced.
+// The quotient: the hoisted-reciprocal form for every row; afterwards the lanes form their own rows' numerators once
+// more IN PARALLEL (the same chain on the same operands: the same bits) and test them — a block in which some numerator
+// is outside the range that needs no scaling (or zero) is walked again with the division itself (march_gs_kernel's rule).
+constexpr int LINE_W = 8;            // values per staged row (six used; 64-byte rows: four 16-byte reads)
+template <typename V>
+struct LineRow {
+    V lo, di, up, r, x, b;
+};
+template <typename V>
+__device__ __forceinline__ LineRow<V> line_fetch(const V *x, const V *b, const V *tri, int n, int row) {
+    LineRow<V> k;
+    const bool ok = row < n;
+    k.x = ok ? x[row] : V(0);
+    k.b = ok ? b[row] : V(0);
+    k.lo = ok ? tri[row] : V(0);
+    k.di = ok ? tri[size_t(n) + row] : V(1);
+    k.up = ok ? tri[2 * size_t(n) + row] : V(0);
+    k.r = V(0);
+    return k;
+}
+template <typename V>
+__device__ __forceinline__ void line_stage(V *st, const LineRow<V> &k) {
+    st[0] = k.lo; st[1] = k.di; st[2] = k.up; st[3] = k.r; st[4] = k.x; st[5] = k.b;
+}
+
+template <typename V>
+__global__ __launch_bounds__(64) void line_gs_kernel(V *x, const V *b, const V *tri, int n) {
+    __shared__ __attribute__((aligned(16))) V s_rows[2][65][LINE_W];      // two blocks; row 64: the next block's first x
+    __shared__ V s_out[64];
+    const int lane = int(threadIdx.x);
+    V prev = V(0);                                     // the relaxed value of the previous row (wave-uniform)
+    LineRow<V> cur = line_fetch(x, b, tri, n, lane);
+    LineRow<V> nxt = line_fetch(x, b, tri, n, 64 + lane);
+    cur.r = refined_rcp(cur.di);
+    line_stage(&s_rows[0][lane][0], cur);
+    for (int base = 0, buf = 0; base < n; base += 64, buf ^= 1) {
+        // the next block into the other half (its first x is row 63's +I operand), the one after it requested
+        nxt.r = refined_rcp(nxt.di);
+        line_stage(&s_rows[buf ^ 1][lane][0], nxt);
+        if (lane == 0) s_rows[buf][64][4] = nxt.x;
+        const LineRow<V> after = line_fetch(x, b, tri, n, base + 128 + lane);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const int rows = min(64, n - base);
+        const V (*R)[LINE_W] = s_rows[buf];
+        auto walk = [&](auto FAST, V p) -> V {
+            struct Ops { V lo, di, up, r, xi, bi; };
+            auto ops_of = [&](int j) -> Ops { return Ops{R[j][0], R[j][1], R[j][2], R[j][3], R[j][4], R[j][5]}; };
+            auto link = [&](int j, const Ops &o, V xn) {
+                V s = madd(o.lo, p, V(0));
+                s = madd(o.di, o.xi, s);
+                s = madd(o.up, xn, s);
+                p = o.xi + quotient<decltype(FAST)::value>(o.bi - s, o.di, o.r);    // openmg/solvers.py:68
+                s_out[j] = p;
+            };
+            if (rows == 64) {
+                // a row's operands are read LA rows ahead of their use (an LDS round trip is longer than a row's chain)
+                constexpr int LA = 3;
+                Ops q[LA + 1];
+#pragma unroll
+                for (int j = 0; j < LA; ++j) q[j] = ops_of(j);
+#pragma unroll
+                for (int j = 0; j < 64; ++j) {
+                    q[(j + LA) % (LA + 1)] = ops_of(j + LA < 64 ? j + LA : 64);      // (row 64: only its x is there, and only that is used)
+                    link(j, q[j % (LA + 1)], q[(j + 1) % (LA + 1)].xi);
+                }
+            } else {
+                for (int j = 0; j < rows; ++j) link(j, ops_of(j), R[j + 1][4]);
+            }
+            return p;
+        };
+        V last = walk(std::true_type(), prev);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (sizeof(V) == 8) {
+            // every lane's own row once more: was its numerator one the hoisted reciprocal covers?
+            const V left = lane ? s_out[(lane - 1) & 63] : prev;
+            const V xn = lane + 1 < 64 ? __shfl_down(cur.x, 1, 64) : nxt.x;
+            V s = madd(cur.lo, left, V(0));
+            s = madd(cur.di, cur.x, s);
+            s = madd(cur.up, (base + lane + 1 < n) ? xn : V(0), s);
+            // (+0 — b_i equal to the row's sum, every row of a converged iterate — goes through the hoisted form like the
+            // division: q = +0 or -0 with the diagonal's sign, either way)
+            const V num = cur.b - s;
+            const bool bad = lane < rows && !plain_range(num) && __double_as_longlong(double(num)) != 0;
+            if (__builtin_amdgcn_ballot_w64(bad)) {
+                last = walk(std::false_type(), prev);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            }
+        }
+        prev = last;
+        if (lane < rows) x[base + lane] = s_out[lane];
+        cur = nxt;
+        nxt = after;
+    }
+}
+
 template <typename V>
 __global__ void fill_kernel(V *p, size_t n, V v) {
     for (size_t q = blockIdx.x * size_t(blockDim.x) + threadIdx.x; q < n; q += size_t(gridDim.x) * blockDim.x) p[q] = v;
@@ -557,6 +671,34 @@ bool MarchPlan<V>::build(const omg_csr &A, hipStream_t s) {
     const int64_t nz = lines / ny;
     if (ny == 1 && nz > 1) return false;
     const int64_t sj = nx, sk = nx * ny;
+    {
+        // a 1-D grid: any tridiagonal operator with ascending columns and diagonals the hoisted reciprocal covers
+        const char *e = getenv("OMG_MARCH_LINE");
+        if (ny == 1 && nz == 1 && !(e && e[0] == '0')) {
+            std::vector<V> t(size_t(3) * size_t(n), V(0));
+            for (int64_t r = 0; r < n; ++r) {
+                int last = -1;
+                for (int64_t q = A.indptr[r]; q < A.indptr[r + 1]; ++q) {
+                    const int64_t off = int64_t(A.indices[q]) - r;
+                    const int slot = off == -1 ? 0 : off == 0 ? 1 : off == 1 ? 2 : -1;
+                    if (slot <= last) return false;                       // not a neighbour, or not in column order
+                    last = slot;
+                    t[size_t(slot) * size_t(n) + size_t(r)] = V(A.data[q]);
+                }
+                const double d = double(t[size_t(n) + size_t(r)]);
+                if (!(std::fabs(d) >= 0x1p-400 && std::fabs(d) <= 0x1p400)) return false;
+            }
+            g.nx = int(nx); g.ny = 1; g.nz = 1;
+            g.TJ = 64; g.TK = 1; g.ntj = g.ntk = g.n_tiles = 1; g.T = g.nx; g.n_grp = 0; g.n_pat = 0;
+            tri.alloc(t.size());
+            tri.upload(t.data(), t.size(), s);
+            sync.alloc(SYNC_WORDS);
+            sync.zero(s);
+            OMG_HIP(hipStreamSynchronize(s));
+            line1 = true;
+            return true;
+        }
+    }
 
     // every row as seven coefficients in slot order; stored order must be slot order
     typedef std::array<double, 7> Pat;
@@ -696,6 +838,11 @@ bool MarchPlan<V>::build(const omg_csr &A, hipStream_t s) {
 
 template <typename V>
 void MarchPlan<V>::sweep(V *x, const V *b, hipStream_t s) const {
+    if (line1) {
+        hipLaunchKernelGGL(line_gs_kernel<V>, dim3(1), dim3(64), 0, s, x, b, tri.p, g.nx);
+        OMG_HIP(hipGetLastError());
+        return;
+    }
     MarchArgs<V> a;
     a.x = x; a.b = b; a.codes = codes.p; a.coef = coef.p; a.sync = sync.p; a.order = order.p;
     a.nx = g.nx; a.ny = g.ny; a.nz = g.nz; a.TJ = g.TJ; a.ntj = g.ntj; a.n_tiles = g.n_tiles;

@@ -52,6 +52,37 @@ def test_wavefront_sweep_has_the_bits_of_the_level_schedule(shape):
                                rtol=1e-12, atol=1e-14)
 
 
+@pytest.mark.parametrize("n", [2, 63, 64, 65, 1000, 4096])
+def test_one_wave_recurrence_on_1d_grids_has_the_bits_of_the_level_schedule(n):
+    """1-D grids (openmg's own demo / test operators, BASELINE configs[0]): the sweep as a first-order recurrence on one
+    wave (line_gs_kernel) for ANY tridiagonal operator — per-row coefficients, more than 256 distinct rows — with the
+    quotient's denominator half hoisted; rows whose numerator falls outside the range that needs no scaling make their
+    block repeat with the division itself.  openmg/solvers.py:56-68."""
+    rng = np.random.default_rng(21)
+    lo, up = -rng.random(n - 1) - 0.1, -rng.random(n - 1) - 0.1
+    di = 2.5 + rng.random(n)
+    A = sp.csr_matrix(sp.diags([lo, di, up], [-1, 0, 1]))
+    A.sort_indices()
+    b, x0 = rng.standard_normal(n), rng.standard_normal(n)
+    if n >= 64:
+        b[n // 2] = 1e300                              # a numerator beyond 2^400: that block takes the division
+        b[5] = 0.0
+    for its in (1, 3):
+        got = sweep(A, b, x0, its, march=True)
+        ref = sweep(A, b, x0, its, march=False)
+        assert np.array_equal(got, ref), (n, its, int(np.sum(got != ref)))
+    old = os.environ.get("OMG_MARCH_LINE")
+    os.environ["OMG_MARCH_LINE"] = "0"                 # the tiled wavefront kernel (or, for so many patterns, the level schedule)
+    try:
+        assert np.array_equal(sweep(A, b, x0, 2, march=True), sweep(A, b, x0, 2, march=False))
+    finally:
+        if old is None:
+            del os.environ["OMG_MARCH_LINE"]
+        else:
+            os.environ["OMG_MARCH_LINE"] = old
+    np.testing.assert_allclose(sweep(A, b, x0, 2, march=True), orc.gauss_seidel(A, b, x0.copy(), iterations=2), rtol=1e-12, atol=1e-14)
+
+
 def test_wavefront_sweep_is_deterministic_over_many_runs():
     """The tiles hand their faces over through HBM inside the launch: a stale read would show here."""
     rng = np.random.default_rng(12)
