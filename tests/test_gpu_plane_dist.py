@@ -84,6 +84,7 @@ def test_gated_passes_have_the_bits_of_stream_ordered_exchanges_and_a_missing_ex
     exchanges in stream order and as the single-GPU cycle; and when the flag is never raised (OMG_PDIST_GATE_POISON=1:
     the exchange 'did not happen') the bounded wait gives up and the call RAISES instead of hanging the device."""
     shape, grids, n_dist = (64, 128, 128), 4, 2
+    monkeypatch.setenv("OMG_PLANE_TILE", "64,16,8")            # (workgroups of four waves: slabs this small otherwise take two-wave tiles, which do not gate)
     A, R, b, x0 = problem(shape, grids)
     with _hip.Hierarchy(A, R, smoother="colour") as h:
         h.resident_load(b, x0)
