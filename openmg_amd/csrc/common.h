@@ -668,6 +668,13 @@ struct PlanePlan {
         uint32_t *status = nullptr;
         uint32_t spin = 1u << 21;
     };
+    // Does such a launch pay, and can it run at all?  Its edge workgroups spin on their compute units until the exchange
+    // has landed, and the exchange's own kernels (RCCL's, a copy's) need compute units too: with 2 x (xy tiles) >= 256
+    // edge workgroups every unit ends up holding a spinning one and nothing can raise the flag (measured: the 512 x 512 x 64
+    // slabs of the 8-rank shape, 128 xy tiles, ran into the bounded wait) — at most 192 of them; and a slab thinner than
+    // 96 planes spends more on its eight edge planes as chunks of their own (+ 25 % workgroup-steps at 64 planes) than the
+    // exchange it hides.
+    bool can_gate() const { return can_split() && 2 * g.ntx * g.nty <= 192 && (g.z_end - g.z_base) >= 96; }
     int gate_lz() const;              // planes per inner chunk of such a launch
     int gate_partials() const;        // its workgroups = norm partials
     void down(const V *x_old, V *x_new, const V *b, bool x_zero, const Coarse &c, hipStream_t s, const Peer *peer = nullptr,

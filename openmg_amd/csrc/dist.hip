@@ -1089,7 +1089,7 @@ struct PDExchange {
         if (p2p() || pre != 1 || post != 1) return false;
         bool forced = true;
         for (PlaneDist *d : ranks) {
-            if (!d->gate || d->split || !d->lv[0].plan.can_split()) return false;
+            if (!d->gate || d->split || !d->lv[0].plan.can_gate()) return false;
             forced = forced && d->gate_forced;
         }
         return exchanges() || forced;
@@ -1102,6 +1102,19 @@ struct PDExchange {
         g.status = d->flags.p + PD_STATUS;
         g.spin = d->spin;
         return g;
+    }
+    // OMG_PDIST_GATE_DEBUG=1: after a gated pass, wait for it and say what its waits saw (stderr)
+    void gate_report(const char *what) {
+        static const bool on = [] { const char *e = getenv("OMG_PDIST_GATE_DEBUG"); return e && e[0] == '1'; }();
+        if (!on) return;
+        for (PlaneDist *d : ranks) {
+            OMG_HIP(hipStreamSynchronize(d->stream));
+            uint32_t f[PD_FLAGS + 2];
+            OMG_HIP(hipMemcpy(f, d->flags.p, sizeof(f), hipMemcpyDeviceToHost));
+            fprintf(stderr, "[pdist gate] cycle %u rank %d after %s: status %u  GX %u  GXU %u  GC %u  (tile %d x %d x %d, gate chunk %d, %d workgroups)\n", d->cycle_no, d->rank,
+                    what, f[PD_STATUS], f[pf(PF_GATE_X, 0)], f[pf(PF_GATE_XU, 0)], f[pf(PF_GATE_C, 0)], d->lv[0].plan.g.TX, d->lv[0].plan.g.TY, d->lv[0].plan.g.LZ,
+                    d->lv[0].plan.gate_lz(), d->lv[0].plan.gate_partials());
+        }
     }
     void raise(PlaneDist *d, hipStream_t st, int slot, uint32_t seq) {
         hipLaunchKernelGGL(pd_signal_kernel, dim3(1), dim3(1), 0, st, d->flags.p + pf(slot, 0), static_cast<uint32_t *>(nullptr), seq);
@@ -1357,6 +1370,7 @@ struct PDExchange {
         for (int l = 0; l < nd; ++l) {
             if (l > 0) { halo(l, 1, 2); mark(l, 2); }
             down(l, false, PlanePlan<double>::PART_ALL, true, false, g0 && l == 0);
+            if (g0 && l == 0) gate_report("down(0)");
             mark(l, 3);
             // the ghost planes for the up pass: on the side stream, beside the coarser levels (nothing before the up
             // pass reads or writes them, nor the planes they are copied from)
@@ -1391,6 +1405,7 @@ struct PDExchange {
                 for (PlaneDist *d : ranks) OMG_HIP(hipStreamWaitEvent(d->stream, d->ev_halo[size_t(l)], 0));
             mark(l, 4);
             up(l, nullptr, PlanePlan<double>::PART_ALL, true, false, gl);
+            if (gl) gate_report("up(0)");
             mark(l, 7);
         }
         if (g0) {
@@ -2146,7 +2161,7 @@ int omg_pdist_info(omg_pdist *d, int64_t *out8) {
         OMG_REQUIRE(d && d->d && out8, "null");
         const PlaneDist *dd = d->d.get();
         const PlanePlan<double> &P = dd->lv[0].plan;
-        const int64_t v[8] = {int64_t(dd->lv.size()), (dd->gate && !dd->split && P.can_split()) ? 1 : 0, P.g.TX, P.g.TY, P.g.LZ, P.g.n_wg, P.g.threads,
+        const int64_t v[8] = {int64_t(dd->lv.size()), (dd->gate && !dd->split && P.can_gate()) ? 1 : 0, P.g.TX, P.g.TY, P.g.LZ, P.g.n_wg, P.g.threads,
                               P.can_split() ? P.gate_lz() : 0};
         for (int i = 0; i < 8; ++i) out8[i] = v[i];
     });

@@ -2212,7 +2212,7 @@ void PlanePlan<V>::down(const V *x_old, V *x_new, const V *b, bool x_zero, const
     k.x_zero = x_zero ? 1 : 0;
     OMG_REQUIRE(part == 0 || (!peer && sweep && !g.dim2 && !block_level(g) && !c.x && !c.diag && !small_tile(g)),
                 "a pass in two launches: slabs' marching passes only");
-    OMG_REQUIRE(!gate || (part == 0 && !peer && sweep && can_split() && !c.x && !c.diag), "a gated pass: slabs' marching passes only");
+    OMG_REQUIRE(!gate || (part == 0 && !peer && sweep && can_gate() && !c.x && !c.diag), "a gated pass: thick slabs' marching passes only");
     const int wgs = gate ? plane_gate<V>(g, k, *gate, gate_lz()) : plane_part(g, k, part);
 #ifdef OMG_PLANE_STAMPS
     DevBuf<unsigned long long> sb;
@@ -2264,7 +2264,7 @@ void PlanePlan<V>::up(const V *x_old, V *x_new, const V *b, const Coarse &c, dou
     k.partials = out;
     OMG_REQUIRE(part == 0 || (!peer && sweep && !g.dim2 && !block_level(g) && !(small_tile(g) && !out)),
                 "a pass in two launches: slabs' marching passes only");
-    OMG_REQUIRE(!gate || (part == 0 && !peer && sweep && can_split()), "a gated pass: slabs' marching passes only");
+    OMG_REQUIRE(!gate || (part == 0 && !peer && sweep && can_gate()), "a gated pass: thick slabs' marching passes only");
     const int wgs = gate ? plane_gate<V>(g, k, *gate, gate_lz()) : plane_part(g, k, part);
     // the up pass of a whole grid marches from the last plane down (plane_kernel MIRROR); OMG_PLANE_MIRROR=0: upwards like the down pass
     const char *mirror_env = getenv("OMG_PLANE_MIRROR");                 // (read per call: A/B runs flip it inside one process)

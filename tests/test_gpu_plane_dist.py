@@ -83,8 +83,8 @@ def test_gated_passes_have_the_bits_of_stream_ordered_exchanges_and_a_missing_ex
     ghost planes runs on the side stream beside the inner chunks (OMG_PDIST_GATE, default on).  Same bits as the
     exchanges in stream order and as the single-GPU cycle; and when the flag is never raised (OMG_PDIST_GATE_POISON=1:
     the exchange 'did not happen') the bounded wait gives up and the call RAISES instead of hanging the device."""
-    shape, grids, n_dist = (64, 128, 128), 4, 2
-    monkeypatch.setenv("OMG_PLANE_TILE", "64,16,8")            # (workgroups of four waves: slabs this small otherwise take two-wave tiles, which do not gate)
+    shape, grids, n_dist = (192, 64, 64), 4, 2                   # (a pass gates on slabs of >= 96 planes: PlanePlan::can_gate)
+    monkeypatch.setenv("OMG_PLANE_TILE", "64,16,16")           # (workgroups of four waves: slabs this small otherwise take two-wave tiles, which do not gate)
     A, R, b, x0 = problem(shape, grids)
     with _hip.Hierarchy(A, R, smoother="colour") as h:
         h.resident_load(b, x0)
@@ -94,7 +94,7 @@ def test_gated_passes_have_the_bits_of_stream_ordered_exchanges_and_a_missing_ex
         monkeypatch.setenv("OMG_PDIST_GATE", gate)
         for n_ranks in (2, 4):
             g = _hip_dist.PlaneDistGroup(slabs(A, R, shape, n_ranks, n_dist, b, x0))
-            assert g.ranks[0].info()["gated"] == int(gate), g.ranks[0].info()
+            assert g.ranks[0].info()["gated"] == (int(gate) if n_ranks == 2 else 0), g.ranks[0].info()
             try:
                 norms = g.cycles(3) + g.cycles(2)
                 got = np.concatenate([r.fetch() for r in g.ranks])
