@@ -393,6 +393,8 @@ int omg_pdist_sync(omg_pdist *d);
  * flag-gated edge chunks, the exchange beside it: csrc/dist.hip PlaneDist::gate); its tiling (cells per line, lines,
  * planes per chunk), workgroups, threads per workgroup; planes per inner chunk of a gated pass */
 int omg_pdist_info(omg_pdist *d, int64_t *out8);
+/* gated passes on / off (off at creation unless OMG_PDIST_GATE=1): the caller switches them on after a checked cycle */
+int omg_pdist_set_gate(omg_pdist *d, int enable);
 /* omg_pdist_trace(1): the stream writes a progress word (pinned host memory) between the phases of a cycle;
  * omg_pdist_progress reads it without synchronising: (cycle << 16) | (level << 8) | phase, phase 1 halo of x, 2 halo of
  * b, 3 down pass, 4 halo of x for the up pass, 5 gather + replicated tail, 6 halo of the correction, 7 up pass —

@@ -125,6 +125,7 @@ SIGNATURES = {
     "omg_pdist_fetch": (_I, [_P, _P]),
     "omg_pdist_sync": (_I, [_P]),
     "omg_pdist_info": (_I, [_P, _I64P]),
+    "omg_pdist_set_gate": (_I, [_P, _I]),
     "omg_pdist_trace": (_I, [_P, _I]),
     "omg_pdist_progress": (_I, [_P, ctypes.POINTER(ctypes.c_uint)]),
     "omg_pdist_cycles": (_I, [_P, _I, _P]),

@@ -246,6 +246,10 @@ class PlaneDistRank:
     def sync(self):
         check(lib().omg_pdist_sync(self._h))
 
+    def set_gate(self, enable=True):
+        """Gated passes (the finest level's passes as one launch whose edge chunks wait for exchanges that run beside them)."""
+        check(lib().omg_pdist_set_gate(self._h, 1 if enable else 0))
+
     def info(self):
         out = (ctypes.c_int64 * 8)()
         check(lib().omg_pdist_info(self._h, out))

@@ -867,7 +867,10 @@ struct PlaneDist {
     // down(k + 1) and the correction's exchange in front of the finest up pass leave the critical path without a second
     // launch (split passes: + 27 us each) and without peer stores.  OMG_PDIST_GATE=0: exchanges in stream order.
     // (=2: also with ONE slab — no neighbour, no exchange: what the one-launch inner + edge form costs a rank in device time)
-    bool gate = [] { const char *e = getenv("OMG_PDIST_GATE"); return !(e && e[0] == '0'); }();
+    // Off until somebody switches it on (omg_pdist_set_gate: bench.py does after one checked cycle with it reproduces the
+    // stream-ordered cycle's norm on every rank, as for peer mode; OMG_PDIST_GATE=1: from creation — the tests): whether the
+    // exchange's kernels find compute units beside the spinning edge workgroups cannot be verified on a one-GPU box.
+    bool gate = [] { const char *e = getenv("OMG_PDIST_GATE"); return e && (e[0] == '1' || e[0] == '2'); }();
     bool gate_forced = [] { const char *e = getenv("OMG_PDIST_GATE"); return e && e[0] == '2'; }();
     // progress of the DEVICE through a cycle, for a caller whose collective never completes (bench.py's preflight):
     // a word in pinned host memory the stream writes between the phases — (cycle << 16) | (level << 8) | phase,
@@ -2164,6 +2167,17 @@ int omg_pdist_info(omg_pdist *d, int64_t *out8) {
         const int64_t v[8] = {int64_t(dd->lv.size()), (dd->gate && !dd->split && P.can_gate()) ? 1 : 0, P.g.TX, P.g.TY, P.g.LZ, P.g.n_wg, P.g.threads,
                               P.can_split() ? P.gate_lz() : 0};
         for (int i = 0; i < 8; ++i) out8[i] = v[i];
+    });
+}
+
+int omg_pdist_set_gate(omg_pdist *d, int enable) {
+    return guarded([&] {
+        OMG_REQUIRE(d && d->d, "null");
+        PlaneDist *dd = d->d.get();
+        OMG_HIP(hipStreamSynchronize(dd->stream));
+        OMG_HIP(hipStreamSynchronize(dd->side));
+        dd->gate = enable != 0;
+        dd->x0_posted = false;                                    // (the next cycle exchanges its ghost planes in stream order first)
     });
 }
 

@@ -279,6 +279,30 @@ def main_plane(args, rank, world, shape, grids, n_levels, all_gather, td, torch,
             r.p2p_enable(0)
             notes = [n for n in all_gather(p2p_note) if n != "not tried"]
             p2p_note = "unavailable: " + (notes[0] if notes else "another rank failed")
+    # Gated passes over RCCL (csrc/dist.hip PlaneDist::gate): the finest level's passes as ONE launch each whose edge chunks
+    # wait on a device flag while the exchange of their ghost planes runs beside the inner chunks.  Tried only where the
+    # slabs qualify (>= 96 planes per rank, <= 192 edge workgroups) and peer mode is not in use; kept only if one checked
+    # cycle from the same start gives the stream-ordered cycle's norm on every rank.  OMG_DIST_GATE=0: not tried.
+    gate_note = "not applicable (slabs of fewer than 96 planes, or more than 192 edge workgroups)"
+    if not shared and not r.p2p_mode and world > 1 and os.environ.get("OMG_DIST_GATE", "1") != "0":
+        r.set_gate(True)
+        if all(all_gather(bool(r.info()["gated"]))):
+            r.load(b_loc)
+            try:
+                gated_norm = preflight.run(rank, world, lambda: run_cycles(2)[0], all_gather, min(120.0, max(20.0, args.watchdog / 4.0)),
+                                           where=lambda: "gated passes")
+                ok = abs(gated_norm - first_norm) <= 1e-12 * abs(first_norm)
+                note = "checked against the stream-ordered cycle: same norm" if ok else "norm %.17g, stream-ordered cycle gave %.17g" % (gated_norm, first_norm)
+            except RuntimeError as e:
+                ok, note = False, str(e)
+            if all(all_gather(bool(ok))):
+                gate_note = "on: " + note
+            else:
+                r.set_gate(False)
+                gate_note = "rejected: " + next(n for n in all_gather(note) if not n.startswith("checked"))
+        else:
+            r.set_gate(False)
+
     class CyclesFailed(RuntimeError):
         """Some rank's cycles raised inside a timed run; raised on EVERY rank at the same point."""
 
@@ -378,7 +402,7 @@ def main_plane(args, rank, world, shape, grids, n_levels, all_gather, td, torch,
                                    % ("x".join(map(str, shape)), grids, world),
                        "unknowns": n_glob, "unknowns_per_gpu": n_loc, "nnz_per_gpu": nnz_loc, "grids": grids,
                        "distributed_grids": n_levels, "replicated_tail_grids": tgrids, "runner": "plane slabs (omg_pdist)",
-                       "exchange": exchange, "peer_mode": p2p_note, "ranks_share_one_gpu": bool(shared),
+                       "exchange": exchange, "peer_mode": p2p_note, "gated_passes": gate_note, "ranks_share_one_gpu": bool(shared),
                        "rccl_ranks": rccl_ranks, "repeats": len(times), "preflight_norm": first_norm,
                        "kernel_src_sha": src_sha, "git_head": head,
                        "ms_per_step_all": [round(1e3 * t / args.steps, 4) for t in times],
