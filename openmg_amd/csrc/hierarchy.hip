@@ -73,6 +73,11 @@ struct Level {
     // configs[4]): the cycle over this level runs the octant-layout kernels of stencil27.hip (common.h Stencil27Plan)
     std::unique_ptr<Stencil27Plan<V>> s27;
     DevBuf<char> pool;               // OMG_VEC_POOL=1: x, tmp, b of a large plane level as three views into ONE allocation
+    // where the matrix-free SpMV of a plane level leaves its product: an allocation of its OWN, made on first use.  Written
+    // into the level's scratch vector — which shares an allocation with x, two spans further on — the same launch takes
+    // 57-62 us at 256^3 where it takes 45 into any separate allocation (profiles/r05_spmv_placement.txt: one process, the
+    // destinations in turn): read and write streams a fixed physical distance apart meet on the same banks
+    DevBuf<V> spmv_y;
     // A plane level's cycle never touches the row-kernel format of A and R (nor r, the block partials, the
     // sweep plan): they are built on first use — by a cycle with pre = 0 or post = 0, a single-level
     // operation, a format query — from the operator the plan describes (ensure_format; OMG_PLANE_LAZY=0: at creation)
@@ -1635,8 +1640,18 @@ int omg_resident_spmv_time(omg_hierarchy *h, int reps, double *avg_ms) {
             if (!mf) ensure_format(hh, 0);
             RowArgsT<V> a;
             a.x = L.xp; a.y = mf ? L.tp : L.r.p;
+            // (OMG_SPMV_Y=b / own, read at every call — placement experiments: the product written over the right-hand side, or
+            // into an allocation of its own, instead of the level's scratch vector)
+            if (mf && !L.spmv_y.p) L.spmv_y.alloc(size_t(L.n));
+            V *ymf = L.spmv_y.p;
+            DevBuf<V> own_y;
+            if (const char *e = getenv("OMG_SPMV_Y")) {
+                if (e[0] == 'b') ymf = L.b.p;
+                else if (e[0] == 't') ymf = L.tp;
+                else if (e[0] == 'o') { own_y.alloc(size_t(L.n), size_t(atoi(e + 1)) * 64); ymf = own_y.p; }
+            }
             auto once = [&] {
-                if (mf) L.plane->spmv(L.xp, L.tp, hh->stream);
+                if (mf) L.plane->spmv(L.xp, ymf, hh->stream);
                 else launch_rows(L.A, ROW_SPMV, -1, a, hh->stream);
             };
             once();                                                     // warm-up
@@ -1792,8 +1807,9 @@ int omg_level_spmv(omg_hierarchy *h, int level, const double *x, double *y) {
             load_vec(hh, level, x, L.xp);
             const bool mf = use_plane(hh, L, 1, 1) && !L.plane->g.jacobi;
             if (mf) {
-                L.plane->spmv(L.xp, L.tp, hh->stream);
-                fetch_vec<V>(hh, level, L.tp, y);
+                if (!L.spmv_y.p) L.spmv_y.alloc(size_t(L.n));
+                L.plane->spmv(L.xp, L.spmv_y.p, hh->stream);
+                fetch_vec<V>(hh, level, L.spmv_y.p, y);
             } else {
                 ensure_format(hh, level);
                 RowArgsT<V> a;

@@ -1062,6 +1062,82 @@ __global__ __launch_bounds__(256) void plane_spmv_kernel(const PlaneSpmvArgs<V> 
     bstore2<0>(ys, (same + lb) * int(sizeof(V)), out, two);
 }
 
+// The same product, marching along z (round 5).  plane_spmv_kernel above asks the L2 for every operand of every row: 6.5
+// loads per output pair, the k neighbours a plane apart — 4.0 TB/s of needed bytes, 0.51 of the HBM peak, bound by requests
+// not by HBM.  Here a thread owns ONE position (line j, pair q) of BOTH colours and walks a chunk of planes with the three
+// planes it needs of them in registers: the k neighbours, the same-position operand and the row's own value are its own
+// registers (each loaded once per chunk), only the j neighbours and the one in-line value beyond the pair come from the
+// cache (the neighbouring threads' own loads of the same step: L1 / L2 hits) — 3.5 loads per output pair.  Workgroups with
+// consecutive numbers inside an XCD take neighbouring line groups of one z chunk, so those hits stay in that XCD's L2.
+// Same chain, same operands: the bits of plane_spmv_kernel.
+template <typename V>
+struct PlaneSpmvMarchArgs {
+    PlaneSpmvArgs<V> s;
+    int qt, lpw, njg, nqt, lz;           // pairs per workgroup row, lines per workgroup, line groups, q tiles, planes per chunk
+};
+template <typename V>
+__global__ __launch_bounds__(512) void plane_spmv_march_kernel(const PlaneSpmvMarchArgs<V> m) {
+    const PlaneSpmvArgs<V> &a = m.s;
+    int L = int(blockIdx.x);
+    const int nwg = int(gridDim.x);
+    if ((nwg & 7) == 0) L = (L & 7) * (nwg >> 3) + (L >> 3);
+    const int per_chunk = m.njg * m.nqt;
+    const int zc = L / per_chunk, rem = L - zc * per_chunk;
+    const int jg = rem / m.nqt, qg = rem - jg * m.nqt;
+    const int t = int(threadIdx.x);
+    const int q = qg * m.qt + t % m.qt, j = jg * m.lpw + t / m.qt;
+    const bool live = t < m.qt * m.lpw && q < a.hq && j < a.ny;
+    const int h = 2 * q;
+    const bool two = h + 1 < a.hx;
+    const __amdgpu_buffer_rsrc_t xs = __builtin_amdgcn_make_buffer_rsrc(const_cast<V *>(a.x), 0, a.vec_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ys = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, a.vec_bytes, 0x00020000);
+    const int ps = a.ny * a.hx;
+    const int W = int(sizeof(V));
+    const int lb = j * a.hx + h;                                   // the pair's place in a plane of one colour
+    auto pair_at = [&](int colour, int k, int dj) -> P2<V> {
+        const bool ok = live && k >= 0 && k < a.nz && j + dj >= 0 && j + dj < a.ny;
+        P2<V> r = bload2(xs, ok ? ((colour ? a.nr : 0) + k * ps + lb + dj * a.hx) * W : OOB, V(0));
+        if (!two) r.y = V(0);
+        return r;
+    };
+    auto one_at = [&](int colour, int k, int hh) -> V {
+        const bool ok = live && hh >= 0 && hh < a.hx;
+        return bload1(xs, ok ? ((colour ? a.nr : 0) + k * ps + j * a.hx + hh) * W : OOB, V(0));
+    };
+    PlaneKArgs<V> c;                                              // (chain_head / chain_tail take the coefficients from there)
+    c.c0 = a.c0; c.c1 = a.c1; c.c2 = a.c2; c.c3 = a.c3; c.c4 = a.c4; c.c5 = a.c5; c.c6 = a.c6;
+    const int z0 = zc * m.lz, z1 = min(a.nz, z0 + m.lz);
+    P2<V> X[2][3];                                                // [colour][k - 1, k, k + 1]
+#pragma unroll
+    for (int col = 0; col < 2; ++col) { X[col][0] = pair_at(col, z0 - 1, 0); X[col][1] = pair_at(col, z0, 0); }
+    for (int k = z0; k < z1; ++k) {
+        P2<V> Jm[2], Jp[2];
+        V nb[2];
+        const int p = (j + k) & 1;
+#pragma unroll
+        for (int col = 0; col < 2; ++col) {
+            X[col][2] = pair_at(col, k + 1, 0);
+            Jm[col] = pair_at(col, k, -1);
+            Jp[col] = pair_at(col, k, 1);
+            // the value beyond the pair that the OTHER colour's row takes from this colour: rule of that row
+            const int rule = col ? p : 1 - p;                      // (row colour 1 - col: rule = (1 - col) ? 1 - p : p)
+            nb[col] = one_at(col, k, rule ? h + 2 : h - 1);
+        }
+#pragma unroll
+        for (int col = 0; col < 2; ++col) {
+            const int o = 1 - col;
+            const int rule = col ? 1 - p : p;
+            const Inline<V> n = in_line(rule, X[o][1], nb[o]);
+            P2<V> out;
+            out.x = chain_tail(c, chain_head(c, X[o][0].x, Jm[o].x, n.imx), X[col][1].x, n.ipx, Jp[o].x, X[o][2].x);
+            out.y = chain_tail(c, chain_head(c, X[o][0].y, Jm[o].y, n.imy), X[col][1].y, n.ipy, Jp[o].y, X[o][2].y);
+            if (live) bstore2<0>(ys, ((col ? a.nr : 0) + k * ps + lb) * W, out, two);
+        }
+#pragma unroll
+        for (int col = 0; col < 2; ++col) { X[col][0] = X[col][1]; X[col][1] = X[col][2]; }
+    }
+}
+
 // ---- small levels: a block of the grid per workgroup, whole in LDS ----------------------------------------------
 // A level of <= 64^3 cells is pure latency for the marching kernel above: LZ + 4 = 6 dependent steps of one wave each
 // (load round trip, red chain -> black chain -> residual chain, barrier), 12-15 us per pass whatever the size
@@ -2326,6 +2402,29 @@ void PlanePlan<V>::spmv(const V *x, V *y, hipStream_t s) const {
     a.vec_bytes = unsigned(n * int64_t(sizeof(V)));
     a.nr = int(n / 2); a.hx = g.hx; a.ny = g.ny; a.nz = g.nz; a.hq = (g.hx + 1) / 2;
     a.c0 = V(g.c[0]); a.c1 = V(g.c[1]); a.c2 = V(g.c[2]); a.c3 = V(g.c[3]); a.c4 = V(g.c[4]); a.c5 = V(g.c[5]); a.c6 = V(g.c[6]);
+    // the z-marching form (OMG_PLANE_SPMV=0: one thread per output pair, every operand from the cache); OMG_PLANE_SPMV_LZ:
+    // planes per chunk
+    static const int mode = [] { const char *e = getenv("OMG_PLANE_SPMV"); return e ? atoi(e) : 1; }();
+    static const int lz_env = [] { const char *e = getenv("OMG_PLANE_SPMV_LZ"); return e ? atoi(e) : 0; }();
+    if (mode != 0 && a.hq <= 256) {
+        PlaneSpmvMarchArgs<V> m;
+        m.s = a;
+        int qt = 1;
+        while (qt < a.hq) qt *= 2;                                  // pairs per workgroup row: a power of two >= the half line's pairs
+        static const int wg_threads = [] { const char *e = getenv("OMG_PLANE_SPMV_T"); return (e && atoi(e) == 512) ? 512 : 256; }();
+        qt = std::min(qt, wg_threads);
+        m.qt = qt; m.lpw = wg_threads / qt;
+        m.nqt = (a.hq + qt - 1) / qt;
+        m.njg = (g.ny + m.lpw - 1) / m.lpw;
+        // enough workgroups to fill the chip several times, chunks as long as that allows (two ring planes per chunk)
+        int lz = lz_env > 0 ? lz_env : 64;
+        while (lz > 4 && int64_t(m.njg) * m.nqt * ((g.nz + lz - 1) / lz) < 512) lz /= 2;
+        m.lz = lz;
+        const int64_t wgs = int64_t(m.njg) * m.nqt * ((g.nz + lz - 1) / lz);
+        hipLaunchKernelGGL(plane_spmv_march_kernel<V>, dim3(unsigned(wgs)), dim3(unsigned(wg_threads)), 0, s, m);
+        OMG_HIP(hipGetLastError());
+        return;
+    }
     const int64_t threads = 2 * int64_t(a.hq) * g.ny * g.nz;
     hipLaunchKernelGGL(plane_spmv_kernel<V>, dim3(unsigned((threads + 255) / 256)), dim3(256), 0, s, a);
     OMG_HIP(hipGetLastError());
