@@ -92,8 +92,6 @@ struct ProfEvent {
 template <typename V>
 struct Hier {
     using value_type = V;
-    DevBuf<char> arena;            // (OMG_POOL_ARENA=1: the pooled vectors of every level; declared before lv: released after the views)
-    size_t arena_used = 0;
     std::vector<Level<V>> lv;
     CoarseSolver<V> coarse;   // direct solve of the coarsest operator (common.h)
     DevBuf<double> norm_dev;
@@ -404,7 +402,7 @@ enum NormState { NORM_NONE = 0, NORM_LAST_SET = 1, NORM_PLANE = 2, NORM_S27 = 3 
 // the spread between processes shrinks from 1.3 % to 0.7 % — where three separate allocations land relative to each
 // other is what made a process "fast" or "slow".  OMG_VEC_POOL=0: three allocations.
 template <typename V>
-bool pooled_vectors(Level<V> &L, DevBuf<char> *arena = nullptr, size_t *arena_used = nullptr) {
+bool pooled_vectors(Level<V> &L) {
     static const bool on = [] { const char *e = getenv("OMG_VEC_POOL"); return !(e && e[0] == '0'); }();
     if (!on || !(L.plane || L.s27) || L.n < (int64_t(1) << 20)) return false;
     if (L.pool.p || L.x.p) return true;
@@ -412,23 +410,18 @@ bool pooled_vectors(Level<V> &L, DevBuf<char> *arena = nullptr, size_t *arena_us
     const size_t off1 = env("OMG_POOL_OFF1", vector_stagger(1)), off2 = env("OMG_POOL_OFF2", vector_stagger(2)), pad = env("OMG_POOL_PAD", 0);
     const size_t MB2 = size_t(2) << 20, bytes = size_t(L.n) * sizeof(V);
     const size_t span = (bytes + 2 * DEVBUF_SLACK + std::max(off1, off2) + MB2 - 1) / MB2 * MB2 + pad;
-    // OMG_POOL_ARENA=1 (experiment): every pooled level of a hierarchy out of ONE allocation, sized by the first (largest)
-    static const bool use_arena = [] { const char *e = getenv("OMG_POOL_ARENA"); return e && e[0] == '1'; }();
-    char *base;
-    if (use_arena && arena && arena_used) {
-        if (!arena->p) { arena->alloc(3 * span + 3 * span / 6 + 16 * MB2); *arena_used = 0; }
-        if (*arena_used + 3 * span > arena->n) return false;
-        base = arena->p + *arena_used;
-        *arena_used += 3 * span;
-    } else {
-        L.pool.alloc(3 * span);
-        base = L.pool.p;
-    }
+    // (every pooled level of a hierarchy out of ONE allocation — OMG_POOL_ARENA, round 4 — measured no different: removed)
+    L.pool.alloc(3 * span);
+    char *const base = L.pool.p;
     // order: x, b, x's twin (OMG_POOL_ORDER=0: x, twin, b).  With b in the middle four of four processes ran 0.260 ms per
     // cycle where the other order gave 0.266-0.274 on the same box; on a second box both orders fell into two populations
     // (0.260 / 0.273) from process to process: where the allocation lands physically still matters, and is not ours to choose
     const bool b_mid = env("OMG_POOL_ORDER", 1) != 0;
     L.x.borrow(reinterpret_cast<V *>(base + DEVBUF_SLACK), size_t(L.n));
+    // OMG_POOL_TMP_OWN=1 (experiment): x and b from the pool, x's twin an allocation of its own
+    static const bool tmp_own = [] { const char *e = getenv("OMG_POOL_TMP_OWN"); return e && e[0] == '1'; }();
+    if (tmp_own) L.tmp.alloc(size_t(L.n), off1);
+    else
     L.tmp.borrow(reinterpret_cast<V *>(base + (b_mid ? 2 : 1) * span + DEVBUF_SLACK + off1), size_t(L.n));
     L.b.borrow(reinterpret_cast<V *>(base + (b_mid ? 1 : 2) * span + DEVBUF_SLACK + off2), size_t(L.n));
     return true;
@@ -953,8 +946,8 @@ std::unique_ptr<Hier<V>> create(int n_levels, const omg_csr *A, const omg_csr *R
                 L.r_out.upload(co.inv.data(), co.inv.size(), h->stream);
                 OMG_HIP(hipStreamSynchronize(h->stream));
             }
-            if (L.plane && !pooled_vectors(L, &h->arena, &h->arena_used)) L.tmp.alloc(L.n, vector_stagger(1));
-            if (L.s27 && !pooled_vectors(L, &h->arena, &h->arena_used)) L.tmp.alloc(L.n);
+            if (L.plane && !pooled_vectors(L)) L.tmp.alloc(L.n, vector_stagger(1));
+            if (L.s27 && !pooled_vectors(L)) L.tmp.alloc(L.n);
             if ((L.plane || L.s27) && !getenv_flag0("OMG_PLANE_LAZY")) L.format_pending = true;
             else if (L.s27) { L.format_pending = true; ensure_format(h.get(), l); }      // (from the padded operator)
             else build_format(h.get(), l, A[l], R[l]);
@@ -1105,8 +1098,8 @@ std::unique_ptr<Hier<V>> create_from_fine(const omg_csr &A0, int dim, const int6
                 L.r_out.alloc(size_t(h->lv[size_t(l) + 1].n));
                 fill_ordering_device(co.closed_form, co.cf_nx, co.cf_ny, co.cf_nz, nullptr, L.r_out.p, h->stream);
             }
-            if (L.plane && !pooled_vectors(L, &h->arena, &h->arena_used)) L.tmp.alloc(L.n, vector_stagger(1));
-            if (L.s27 && !pooled_vectors(L, &h->arena, &h->arena_used)) L.tmp.alloc(L.n);
+            if (L.plane && !pooled_vectors(L)) L.tmp.alloc(L.n, vector_stagger(1));
+            if (L.s27 && !pooled_vectors(L)) L.tmp.alloc(L.n);
             L.format_pending = true;
         }
         if (!L.x.p) {

@@ -78,22 +78,11 @@ template <> struct VecOf<float> {
     typedef type gtype __attribute__((aligned(4)));
 };
 
-// where a step issues its stores of x_new: 0 = behind stages B and C, 1 = at the step's top behind its loads, 2 = in front of them
-#ifndef PLANE_STORE_AT
-#define PLANE_STORE_AT 0
-#endif
-// the last PLANE_WT_STEPS steps of a chunk store x_new with cache policy PLANE_WT_AUX (16 = sc1: written through)
-#ifndef PLANE_WT_STEPS
-#define PLANE_WT_STEPS 0
-#endif
-#ifndef PLANE_WT_AUX
-#define PLANE_WT_AUX 16
-#endif
-#ifndef PLANE_LOAD_AUX
-#define PLANE_LOAD_AUX 0             // cache policy of the passes' vector loads (experiments: 2 = nt)
-#endif
+// (Measured and removed in round 5, docs/HISTORY.md has the numbers: the step's stores of x_new at its top behind or in front
+// of its loads instead of behind stages B and C (+ 1 to + 3 us per pass); the chunk's last planes written through the L2;
+// non-temporal vector loads (+ 30 us: the rings stop sharing the L2).)
 __device__ __forceinline__ P2<double> bload2(__amdgpu_buffer_rsrc_t rs, int off, double) {
-    const v4u q = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, PLANE_LOAD_AUX);
+    const v4u q = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0);
     return {__builtin_bit_cast(double, v2u{q.x, q.y}), __builtin_bit_cast(double, v2u{q.z, q.w})};
 }
 __device__ __forceinline__ P2<float> bload2(__amdgpu_buffer_rsrc_t rs, int off, float) {
@@ -468,9 +457,6 @@ __global__ __launch_bounds__(MAXT) void plane_kernel(const PlaneKArgs<V> a) {
     };
     // (a line of odd hx: the pair as two stores, the second one dropped where the line has ended)
     constexpr int XAUX = sizeof(V) == 8 ? PLANE_STORE_AUX : 0;
-    // wt (uniform): the chunk's last planes are written THROUGH the L2 (sc1) — what a pass leaves dirty there is written
-    // back at the kernel's end, in front of the next launch (PLANE_WT_STEPS)
-    bool wt = false;
     auto put_pair = [&](const __amdgpu_buffer_rsrc_t &rs, unsigned off, const P2<V> &v) {
 #ifdef OMG_PLANE_DBG_ON
         if (a.dbg & 1) return;
@@ -478,8 +464,6 @@ __global__ __launch_bounds__(MAXT) void plane_kernel(const PlaneKArgs<V> a) {
         if (oddx) {
             bstore1<XAUX>(rs, int(off), v.x);
             bstore1<XAUX>(rs, int(vx1 ? off + unsigned(W) : unsigned(OOB)), v.y);
-        } else if (PLANE_WT_STEPS > 0 && wt) {
-            bstore2<PLANE_WT_AUX>(rs, int(off), v, true);
         } else {
             bstore2(rs, int(off), v, true);
         }
@@ -682,7 +666,6 @@ __global__ __launch_bounds__(MAXT) void plane_kernel(const PlaneKArgs<V> a) {
     auto step = [&](auto PARC, const int s, auto PB) {
         constexpr bool PEER_STEP = PEER && decltype(PB)::value;
         const int par = PARC;                            // (a compile-time constant after inlining when LA == 2)
-        if (PLANE_WT_STEPS > 0) wt = s >= z1 + 1 - PLANE_WT_STEPS;
         const int set = LA == 2 ? par : 0;               // the registers this step's loads arrive in, and its requests go to
         // The step's loads are taken HERE, behind the barrier — not where the compiler would sink the copies
         // into the state registers (the bottom of the previous step, in front of the barrier): a whole step
@@ -743,21 +726,6 @@ __global__ __launch_bounds__(MAXT) void plane_kernel(const PlaneKArgs<V> a) {
             SLt = slots_request(SLt_kc, par != 0);
             if (FIRST) DGt = coarse_vals((par || !a.cdiag) ? none : SLd);
         }
-        // x_new of the planes that became final in the previous step: red of plane s - 1, black of plane s - 2
-        auto store_final = [&]() {
-            if (!(SWEEP || MODE == 1)) return;
-            if (s - 1 >= z0 && s - 1 < z1) {
-                const unsigned base = unsigned(zphys(s - 1) * ps * W);
-#pragma unroll
-                for (int l = 0; l < 2; ++l) put_pair(ws, lso[l] + base, XR[1][l]);
-            }
-            if (s - 2 >= z0 && s - 2 < z1) {
-                const unsigned base = unsigned((a.nr + zphys(s - 2) * ps) * W);
-#pragma unroll
-                for (int l = 0; l < 2; ++l) put_pair(ws, lso[l] + base, XB[3][l]);
-            }
-        };
-        if (PLANE_STORE_AT == 2) store_final();
         {
             unsigned pXB = plane_off(1, s + LA + 1), pR = plane_off(0, s + LA), pBB = plane_off(1, s + LA - 1);
             asm volatile("" : "+s"(pXB), "+s"(pR), "+s"(pBB));
@@ -777,7 +745,6 @@ __global__ __launch_bounds__(MAXT) void plane_kernel(const PlaneKArgs<V> a) {
                 LBB[set][l] = fetch_at(bs, pBB, l);
             }
         }
-        if (PLANE_STORE_AT == 1) store_final();
         // the coarse pair the previous (odd) step finished (uniform)
         if (MODE == 0 && !par && s - 3 >= z0 && s - 3 < z1) {
 #ifdef OMG_PLANE_DBG_ON
@@ -824,7 +791,7 @@ __global__ __launch_bounds__(MAXT) void plane_kernel(const PlaneKArgs<V> a) {
                     XR[0][0] = zero2; XR[0][1] = zero2;
                 }
             }
-            if (PLANE_STORE_AT == 0 && (SWEEP || MODE == 1) && s - 1 >= z0 && s - 1 < z1) {
+            if ((SWEEP || MODE == 1) && s - 1 >= z0 && s - 1 < z1) {
                 // red of plane s - 1 became final in the previous step
                 const unsigned base = unsigned(zphys(s - 1) * ps * W);
 #pragma unroll
@@ -875,7 +842,7 @@ __global__ __launch_bounds__(MAXT) void plane_kernel(const PlaneKArgs<V> a) {
                     rb[0] = zero2; rb[1] = zero2;
                 }
             }
-            if (PLANE_STORE_AT == 0 && (SWEEP || MODE == 1) && s - 2 >= z0 && s - 2 < z1) {
+            if ((SWEEP || MODE == 1) && s - 2 >= z0 && s - 2 < z1) {
                 // black of plane s - 2 became final in the previous step
                 const unsigned base = unsigned((a.nr + zphys(s - 2) * ps) * W);
 #pragma unroll

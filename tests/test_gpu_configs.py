@@ -179,9 +179,16 @@ def test_config2_full_size_256_cubed_redblack_against_oracle():
     del Ao
     with _hip.Hierarchy(A, R, smoother="colour") as h:
         assert h.level_sets(0) == 2
+        # (the path the bench times: every smoothed level on the fused plane passes — the comparison with the oracle at full
+        # size is made on THAT path, not transitively through the set schedule)
+        assert all(h.level_flags(l)["plane"] for l in range(4))
         h.resident_load(b)
         norms = [h.resident_cycle(1, 1) for _ in range(2)]
         x = h.resident_fetch()
+        h.use_plane(False)
+        h.resident_load(b)
+        sets = [h.resident_cycle(1, 1) for _ in range(2)]
+        assert np.array_equal(h.resident_fetch(), x) and all(rel(u, v) < 1e-13 for u, v in zip(sets, norms))
     for k in range(2):
         assert rel(norms[k], norms_o[k]) < NORM_RTOL, (k, norms[k], norms_o[k])
     np.testing.assert_allclose(x, xo, rtol=1e-9, atol=1e-11)
@@ -218,6 +225,47 @@ def test_config4_operator_family_at_128_cubed_fp32_on_the_27_point_kernels():
         sets = [h.resident_cycle(1, 1) for _ in range(5)]
         assert np.array_equal(h.resident_fetch(), x)
         assert all(rel(u, v) < 1e-6 for u, v in zip(sets, norms)), (sets, norms)
+
+
+def test_config4_per_gpu_workload_256_cubed_fp32():
+    """configs[4]'s per-GPU workload at its full size: 256^3 27-point variable-coefficient operator (450 M stored entries:
+    ~15 s to generate), fp32 levels, 5 grids, the Galerkin products on the device.  Size-independent properties, as for
+    configs[3]: every smoothed level runs the 27-point kernels, the cycles contract, the device's norm is the norm of the
+    iterate it returns (fp64 on the host, to fp32 rounding), batched cycles give the cycle-by-cycle bits, and the cycle is
+    homogeneous in b under a power of two to the bit.  And the same workload as ONE slab of the multi-GPU runner
+    (csrc/dist27.hip: ghost aggregate planes, three slab levels over a replicated tail) gives the same iterate bit for bit."""
+    from openmg_amd import _hip_dist
+    shape, grids = (256, 256, 256), 5
+    A0 = operators.stencil27_variable(shape)
+    b = A0 @ np.random.default_rng(12345).random(A0.shape[0])
+    b = b.astype(np.float32).astype(np.float64)
+    with _hip.Hierarchy.from_fine(A0, shape, grids - 1, "colour", dtype="float32") as h:
+        assert all(h.level_flags(l)["stencil27"] for l in range(grids - 1))
+        h.resident_load(b)
+        norms = [h.resident_cycle(1, 1) for _ in range(4)]
+        x = h.resident_fetch()
+        assert all(norms[k + 1] < norms[k] for k in range(3)), norms
+        true = float(np.linalg.norm(b - A0 @ x))
+        assert rel(norms[-1], true) < 5e-3, (norms[-1], true)
+        h.resident_load(b)
+        batch = h.resident_cycles(1, 1, 4)
+        assert np.array_equal(h.resident_fetch(), x)
+        assert all(rel(u, v) < 1e-6 for u, v in zip(batch, norms)), (batch, norms)
+        h.resident_load(4.0 * b)
+        n4 = h.resident_cycles(1, 1, 4)
+        assert np.array_equal(h.resident_fetch(), 4.0 * x) and all(rel(u, 4.0 * v) < 1e-6 for u, v in zip(n4, norms))
+    r = _hip_dist.Slab27Rank(0, 1, shape, A0, 3, dtype="float32")
+    del A0
+    tail = dist.make_tail(r.coarse_rows(), (32, 32, 32), 2, smoother="colour", dtype="float32")
+    try:
+        r.set_tail(tail)
+        r.load(b)
+        slab = r.cycles(1, 1, 4)
+        assert np.array_equal(r.fetch(), x)
+        assert all(rel(u, v) < 1e-6 for u, v in zip(slab, norms)), (slab, norms)
+    finally:
+        r.close()
+        tail.close()
 
 
 # ------------------------------------------------------------------------------- configs[3] --

@@ -1,5 +1,5 @@
 #!/bin/bash
-# A/B of stencil27.hip builds (openmg_amd/lib/libopenmg_hip_<name>.so, made with make EXTRA=-DS27_...): configs[4] at 256^3
+# A/B of stencil27.hip builds (openmg_amd/lib/libopenmg_hip_<name>.so, made with make EXTRA="-DOMG_EXPERIMENTS -DS27_..."): configs[4] at 256^3
 out=${1:-gpurun_out/s27_variants.txt}
 : > $out
 for lib in openmg_amd/lib/libopenmg_hip_*.so; do
