@@ -101,6 +101,13 @@ int omg_hierarchy_create_ex(int n_levels, const omg_csr *A, const omg_csr *R, in
 int omg_hierarchy_create_from_fine(const omg_csr *A_in, int dim, const int64_t *shape, int n_restrictions, int smoother, double omega,
                                    int dtype, omg_hierarchy **out);
 
+/* New values for the fine operator of a hierarchy made by omg_hierarchy_create_from_fine whose smoothed levels all run the
+ * 27-point kernels (BASELINE configs[4]: "Galerkin RAP rebuilt on-device"; what the reference would do is run
+ * operators.coeffecientList again, openmg/operators.py:144-188): data = the CSR's value array in the SAME pattern, nnz
+ * doubles, in host memory or — on_device != 0 — already in HBM.  Level 0 is re-tiled, every Galerkin product re-formed
+ * on the device in one pass per level (closed form of the aggregation on a grid, SciPy's accumulation order: the bits of
+ * a fresh setup), the coarsest operator factorised anew.  The resident right-hand side and iterate stay. */
+int omg_hierarchy_update_fine(omg_hierarchy *h, const double *data, int64_t nnz, int on_device);
 int omg_hierarchy_dtype(const omg_hierarchy *h, int *dtype);
 int omg_hierarchy_destroy(omg_hierarchy *h);
 /* Run on a caller-owned hipStream_t instead of the hierarchy's own stream (NULL = own). */

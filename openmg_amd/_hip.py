@@ -59,6 +59,7 @@ SIGNATURES = {
     "omg_hierarchy_create_ex": (_I, [_I, _CSR, _CSR, _I, _D, _I, _PP]),
     "omg_hierarchy_create_from_fine": (_I, [_CSR, _I, _I64P, _I, _I, _D, _I, _PP]),
     "omg_hierarchy_dtype": (_I, [_P, _IP]),
+    "omg_hierarchy_update_fine": (_I, [_P, _P, ctypes.c_int64, _I]),
     "omg_hierarchy_destroy": (_I, [_P]),
     "omg_hierarchy_set_stream": (_I, [_P, _P]),
     "omg_hierarchy_sync": (_I, [_P]),
@@ -316,6 +317,16 @@ class Hierarchy:
         self._h = h
         self._A = self._R = None
         return self
+
+    def update_fine(self, data, on_device=False):
+        """New values for the fine operator, same pattern (omg_hierarchy_update_fine).  data: the CSR's value array as a
+        float64 NumPy array, or — on_device — (device pointer, number of entries)."""
+        if on_device:
+            ptr, nnz = data
+            check(lib().omg_hierarchy_update_fine(self._h, ctypes.c_void_p(int(ptr)), int(nnz), 1))
+        else:
+            d = np.ascontiguousarray(data, dtype=np.float64)
+            check(lib().omg_hierarchy_update_fine(self._h, d.ctypes.data, d.size, 0))
 
     def close(self):
         if getattr(self, "_h", None):

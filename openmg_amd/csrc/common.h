@@ -764,6 +764,13 @@ struct Stencil27Plan {
     // neighbour as a zero entry on the row's own column (doubles of the stored V); and the aggregation.
     HostCsr operator_csr(hipStream_t s) const;
     HostCsr restriction_csr() const;
+    // New coefficients, and the Galerkin product of this level in closed form (stencil27.hip s27_rap_kernel: one pass over
+    // the operator, SciPy's accumulation order).  The operator comes as the caller's CSR values behind `indptr` (the
+    // level's own pattern: every row its in-grid neighbours in column order) or, indptr == null, as a dense [row][27]
+    // double array (an absent neighbour a zero).  write_fine: its entries go into this level's tiles (as V);
+    // coarse_dense (nullable): the coarse operator as such an array; coarse (nullable): ... and into that level's tiles.
+    // Throws when a value is not finite as V or a diagonal is zero.
+    void rap_from(const int32_t *indptr, const double *vals, bool write_fine, double *coarse_dense, Stencil27Plan<V> *coarse, hipStream_t s);
 };
 
 }  // namespace omg

@@ -104,6 +104,12 @@ struct Hier {
     int smoother = OMG_SMOOTH_GS_LEX;
     double omega = 1.0;
     hipStream_t own = nullptr, stream = nullptr;
+    // omg_hierarchy_update_fine (a hierarchy set up on the device whose smoothed levels all run the 27-point kernels): the
+    // fine operator's row pointers (the values come with every update), its grid, and per level >= 1 the Galerkin
+    // operator as a dense [row][27] double array — the next product's input
+    DevBuf<int32_t> indptr0;
+    int64_t nnz0 = 0;
+    std::vector<DevBuf<double>> dense27;
     // resident state
     bool resident = false;
     // OMG_NO_FUSE=1: never fuse the last smoother set with the residual / norm (A/B switch;
@@ -1083,6 +1089,15 @@ std::unique_ptr<Hier<V>> create_from_fine(const omg_csr &A0, int dim, const int6
         if (s) { (void)hipStreamSynchronize(s); (void)hipStreamDestroy(s); }
     });
     struct Joiner { std::thread &t; ~Joiner() { if (t.joinable()) t.join(); } } joiner{inverter};
+    {
+        // (new coefficients later: omg_hierarchy_update_fine needs the fine pattern's row pointers, nothing else of the operators)
+        bool all27 = dim == 3;
+        for (int l = 0; l + 1 < n_levels; ++l) all27 = all27 && bool(h->lv[size_t(l)].s27);
+        if (all27) {
+            h->indptr0 = std::move(dA[0].indptr);
+            h->nnz0 = dA[0].nnz;
+        }
+    }
     dA.clear();                                                    // (the fused paths hold what they need of the operators)
     dR.clear();
     for (int l = 0; l < n_levels; ++l) {
@@ -1131,6 +1146,71 @@ std::unique_ptr<Hier<V>> create_from_fine(const omg_csr &A0, int dim, const int6
     if (inv_code != OMG_OK) throw Error(inv_code, inv_msg);
     OMG_HIP(hipStreamSynchronize(h->stream));
     return h;
+}
+
+// New coefficients for the fine operator of a hierarchy that create_from_fine set up with 27-point levels throughout (same
+// pattern, new values: BASELINE configs[4]'s "Galerkin RAP rebuilt on-device"; openmg/operators.py:144-188 is what the
+// reference would run again): level 0 is re-tiled and every Galerkin product re-formed in HBM by s27_rap_kernel — each
+// operator of the chain read once —, the coarsest operator factorised anew.  vals: the CSR's data array, host or device.
+template <typename V>
+void update_fine(Hier<V> *h, const double *vals, int64_t nnz, bool on_device) {
+    OMG_REQUIRE(h->indptr0.p, "omg_hierarchy_update_fine: needs a hierarchy made by omg_hierarchy_create_from_fine whose smoothed levels all run the 27-point kernels");
+    OMG_REQUIRE(vals && nnz == h->nnz0, "omg_hierarchy_update_fine: the value array must have the fine operator's number of entries");
+    const int last = (int)h->lv.size() - 1;
+    OMG_HIP(hipStreamSynchronize(h->stream));
+    drop_graph(h);
+    DevBuf<double> up;
+    if (!on_device) {
+        SetupTimer tm("update: upload the new values");
+        up.alloc(size_t(nnz));
+        OMG_HIP(hipMemcpyAsync(up.p, vals, size_t(nnz) * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        vals = up.p;
+    }
+    if (h->dense27.size() != h->lv.size()) h->dense27.resize(h->lv.size());
+    for (int l = 0; l < last; ++l) {
+        SetupTimer tm("update: tiles + Galerkin product of a level (one pass)");
+        Level<V> &L = h->lv[size_t(l)];
+        DevBuf<double> &out = h->dense27[size_t(l) + 1];
+        const size_t need = size_t(h->lv[size_t(l) + 1].n) * 27;
+        if (out.n < need) out.alloc(need);
+        Stencil27Plan<V> *C = l + 1 < last ? h->lv[size_t(l) + 1].s27.get() : nullptr;
+        // (a level's tiles below the finest were written as the `coarse` of the level above)
+        L.s27->rap_from(l == 0 ? h->indptr0.p : nullptr, l == 0 ? vals : h->dense27[size_t(l)].p, l == 0, out.p, C, h->stream);
+        L.format_pending = true;                                   // (its row-kernel side, if it was ever built, is of the old operator)
+    }
+    // the coarsest operator: its present, nonzero entries as CSR (what the Galerkin chain hands create_from_fine), factorised anew
+    Level<V> &Lc = h->lv.back();
+    const Stencil27Plan<V> &P = *h->lv[size_t(last) - 1].s27;
+    const int cx = P.g.hx, cy = P.g.hy, cz = P.g.hz;
+    std::vector<double> host(size_t(Lc.n) * 27);
+    OMG_HIP(hipMemcpyAsync(host.data(), h->dense27[size_t(last)].p, host.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    OMG_HIP(hipStreamSynchronize(h->stream));
+    HostCsr Ac;
+    Ac.n_rows = Ac.n_cols = Lc.n;
+    Ac.indptr.resize(size_t(Lc.n) + 1);
+    Ac.indices.reserve(host.size());
+    Ac.data.reserve(host.size());
+    for (int64_t r = 0; r < Lc.n; ++r) {
+        Ac.indptr[size_t(r)] = int32_t(Ac.indices.size());
+        const int i = int(r % cx), j = int((r / cx) % cy), k = int(r / (int64_t(cx) * cy));
+        for (int sl = 0; sl < 27; ++sl) {
+            const int dx = sl % 3 - 1, dy = (sl / 3) % 3 - 1, dz = sl / 9 - 1;
+            const bool present = i + dx >= 0 && i + dx < cx && j + dy >= 0 && j + dy < cy && k + dz >= 0 && k + dz < cz;
+            const double v = host[size_t(r) * 27 + size_t(sl)];
+            if (!present || v == 0.0) continue;                       // (exact zeros are not stored: csr_matmat drops them)
+            Ac.indices.push_back(int32_t(r + (int64_t(dz) * cy + dy) * cx + dx));
+            Ac.data.push_back(v);
+        }
+    }
+    Ac.indptr[size_t(Lc.n)] = int32_t(Ac.indices.size());
+    Ac.nnz = int64_t(Ac.indices.size());
+    check_diagonal(view(Ac), last);
+    {
+        SetupTimer tm("update: coarse factorisation");
+        Lc.A.upload(Ac, Lc.ord.sets, h->stream);
+        h->coarse.build(Ac, h->stream);
+    }
+    OMG_HIP(hipStreamSynchronize(h->stream));
 }
 
 // A throw-away single operator for the standalone entry points.
@@ -1227,6 +1307,12 @@ int omg_hierarchy_create_from_fine(const omg_csr *A_in, int dim, const int64_t *
         if (dtype == OMG_DTYPE_F32) h->f = create_from_fine<float>(*A_in, dim, shape, n_restrictions, smoother, omega);
         else h->d = create_from_fine<double>(*A_in, dim, shape, n_restrictions, smoother, omega);
         *out = h.release();
+    });
+}
+
+int omg_hierarchy_update_fine(omg_hierarchy *h, const double *data, int64_t nnz, int on_device) {
+    return guarded([&] {
+        with(h, [&](auto *hh) { update_fine(hh, data, nnz, on_device != 0); });
     });
 }
 

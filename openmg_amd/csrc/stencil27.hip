@@ -977,6 +977,136 @@ HostCsr Stencil27Plan<V>::restriction_csr() const {
     return R;
 }
 
+// ---- new coefficients into an existing level, and the Galerkin product in closed form (round 5) ---------------------
+// openmg/operators.py:184-186 for the plain 2 x 2 x 2 aggregation of a 27-point level: A_c(I, I + D) = sum over the fine
+// cells j of aggregate I + D, ascending, of w (R A)(I, j), and (R A)(I, j) = sum over the fine rows k of aggregate I,
+// ascending, of w a(k, j) — SciPy's accumulation order, which the one-wave-per-coarse-row hash kernel of setup_device.hip
+// reproduces for ANY aggregation at 7.2 ms for the 256^3 operator.  On a grid the j that a coarse row touches are the 4 x 4 x 4
+// cells around its aggregate, each fed by fixed (child, slot) pairs: a thread takes one coarse row, streams its eight fine
+// rows once (27 values each; a neighbour outside the grid is a zero), adds w a(k, j) into 64 registers in the order
+// above, and forms the 27 coarse entries from them.  The same thread writes the fine rows' coefficients into the fine
+// level's tiles (as V) — new values for an existing level — and the coarse row into the next level's tiles and into a
+// dense [row][27] double array, which is the next product's input: the whole chain of a hierarchy reads every operator once.
+// Same additions in the same order as the hash kernel, products by w exact (w is a power of two, checked by the caller):
+// the same bits (tests/test_gpu_update.py).
+template <typename V>
+struct S27RapArgs {
+    const int32_t *indptr;           // CSR input (the caller's operator): row pointers; null: dense [row][27] input
+    const double *vals;
+    int nx, ny, nz;                  // the fine grid
+    V *fine_coef;                    // the fine level's tiles (null: not written)
+    int fL, fG, fRG; int64_t fng;
+    double *coarse_dense;            // [coarse row][27] (null: not written)
+    V *coarse_coef;                  // the coarse level's tiles (null: the coarse level is not a 27-point level)
+    int cL, cG, cRG; int64_t cng;
+    double w;
+    unsigned long long *err;         // smallest offending fine row + 1
+};
+
+template <typename V, bool CSR_IN>
+__global__ __launch_bounds__(256) void s27_rap_kernel(const S27RapArgs<V> a) {
+    const int hx = a.nx / 2, hy = a.ny / 2, hz = a.nz / 2;
+    const int64_t nc = int64_t(hx) * hy * hz;
+    const int64_t crow = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    if (crow >= nc) return;
+    const int I = int(crow % hx), J = int((crow / hx) % hy), K = int(crow / (int64_t(hx) * hy));
+    double RA[64];
+#pragma unroll
+    for (int q = 0; q < 64; ++q) RA[q] = 0.0;
+    const int64_t line = int64_t(K) * hy + J, wave = line / a.fG;
+    const int lane = int(line - wave * a.fG) * a.fL + I / a.fRG, rr = I % a.fRG;
+    bool bad = false;
+    int64_t bad_row = 0;
+#pragma unroll
+    for (int child = 0; child < 8; ++child) {
+        const int di = child & 1, dj = (child >> 1) & 1, dk = child >> 2;
+        const int i = 2 * I + di, j = 2 * J + dj, k = 2 * K + dk;
+        const int64_t row = (int64_t(k) * a.ny + j) * a.nx + i;
+        const bool xm = i > 0, xp = i + 1 < a.nx, ym = j > 0, yp = j + 1 < a.ny, zm = k > 0, zp = k + 1 < a.nz;
+        int64_t p = CSR_IN ? int64_t(a.indptr[row]) : row * 27;
+        V *tile = a.fine_coef ? a.fine_coef + ((size_t(child) * size_t(a.fng) + size_t(wave)) * 27 * 64 + size_t(lane)) * size_t(a.fRG) + size_t(rr) : nullptr;
+#pragma unroll
+        for (int sl = 0; sl < 27; ++sl) {
+            const int dx = sl % 3 - 1, dy = (sl / 3) % 3 - 1, dz = sl / 9 - 1;
+            const bool present = (dx < 0 ? xm : dx > 0 ? xp : true) && (dy < 0 ? ym : dy > 0 ? yp : true) && (dz < 0 ? zm : dz > 0 ? zp : true);
+            double v = 0.0;
+            if (CSR_IN) {
+                if (present) v = a.vals[p++];
+            } else {
+                v = a.vals[p + sl];
+            }
+            if (tile) {
+                const V t = V(v);
+                const double back = double(t);
+                if (!(back - back == 0.0) || (sl == 13 && !(back != 0.0))) { bad = true; bad_row = row; }
+                tile[size_t(sl) * 64 * size_t(a.fRG)] = t;
+            }
+            // (R A)(I, j): cell j at (dk + dz + 1, dj + dy + 1, di + dx + 1) of the 4 x 4 x 4 cells around the aggregate; the rows
+            // k in ascending order = the children in this loop's order
+            const int q = ((dk + dz + 1) * 4 + (dj + dy + 1)) * 4 + (di + dx + 1);
+            RA[q] = __dadd_rn(RA[q], __dmul_rn(a.w, v));
+        }
+    }
+    if (bad) atomicMin(a.err, (unsigned long long)(bad_row + 1));
+    // the coarse row: slot D = (Dz, Dy, Dx) takes the cells of aggregate I + D — along an axis cell 0 for -1, cells 1, 2
+    // for 0, cell 3 for +1 —, ascending
+    const int c_colour = (I & 1) | ((J & 1) << 1) | ((K & 1) << 2);
+    V *ctile = nullptr;
+    if (a.coarse_coef) {
+        const int chy = hy / 2;
+        const int64_t cline = int64_t(K >> 1) * chy + (J >> 1), cwave = cline / a.cG;
+        const int clane = int(cline - cwave * a.cG) * a.cL + (I >> 1) / a.cRG, cr = (I >> 1) % a.cRG;
+        ctile = a.coarse_coef + ((size_t(c_colour) * size_t(a.cng) + size_t(cwave)) * 27 * 64 + size_t(clane)) * size_t(a.cRG) + size_t(cr);
+    }
+#pragma unroll
+    for (int sl = 0; sl < 27; ++sl) {
+        const int Dx = sl % 3 - 1, Dy = (sl / 3) % 3 - 1, Dz = sl / 9 - 1;
+        const int x0 = Dx < 0 ? 0 : Dx == 0 ? 1 : 3, x1 = Dx == 0 ? 3 : x0 + 1;
+        const int y0 = Dy < 0 ? 0 : Dy == 0 ? 1 : 3, y1 = Dy == 0 ? 3 : y0 + 1;
+        const int z0 = Dz < 0 ? 0 : Dz == 0 ? 1 : 3, z1 = Dz == 0 ? 3 : z0 + 1;
+        double sum = 0.0;
+#pragma unroll
+        for (int z = z0; z < z1; ++z)
+#pragma unroll
+            for (int y = y0; y < y1; ++y)
+#pragma unroll
+                for (int x = x0; x < x1; ++x) sum = __dadd_rn(sum, __dmul_rn(RA[(z * 4 + y) * 4 + x], a.w));
+        if (a.coarse_dense) a.coarse_dense[crow * 27 + sl] = sum;
+        if (ctile) ctile[size_t(sl) * 64 * size_t(a.cRG)] = V(sum);
+    }
+}
+
+template <typename V>
+void Stencil27Plan<V>::rap_from(const int32_t *indptr, const double *vals, bool write_fine, double *coarse_dense, Stencil27Plan<V> *coarse, hipStream_t s) {
+    S27RapArgs<V> a;
+    std::memset(&a, 0, sizeof(a));
+    a.indptr = indptr; a.vals = vals;
+    a.nx = g.nx; a.ny = g.ny; a.nz = g.nz;
+    a.fine_coef = write_fine ? coef.p : nullptr;
+    a.fL = g.L; a.fG = g.G; a.fRG = g.rg; a.fng = g.ng;
+    a.coarse_dense = coarse_dense;
+    if (coarse) {
+        OMG_REQUIRE(coarse->g.nx == g.hx && coarse->g.ny == g.hy && coarse->g.nz == g.hz, "internal: the coarse 27-point level does not sit under this one");
+        a.coarse_coef = coarse->coef.p;
+        a.cL = coarse->g.L; a.cG = coarse->g.G; a.cRG = coarse->g.rg; a.cng = coarse->g.ng;
+    }
+    a.w = g.w;
+    DevBuf<unsigned long long> d_err(1);
+    OMG_HIP(hipMemsetAsync(d_err.p, 0xFF, sizeof(unsigned long long), s));
+    a.err = d_err.p;
+    const int64_t nc = g.na;
+    if (indptr) hipLaunchKernelGGL((s27_rap_kernel<V, true>), dim3(unsigned((nc + 255) / 256)), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((s27_rap_kernel<V, false>), dim3(unsigned((nc + 255) / 256)), dim3(256), 0, s, a);
+    OMG_HIP(hipGetLastError());
+    unsigned long long err = 0;
+    OMG_HIP(hipMemcpyAsync(&err, d_err.p, sizeof(err), hipMemcpyDeviceToHost, s));
+    OMG_HIP(hipStreamSynchronize(s));
+    if (err != ~0ull)
+        throw Error(OMG_ERR_INVALID, "27-point level: new coefficient of row " + std::to_string(err - 1) + " is not finite as the level's type, or its diagonal is zero");
+    have67 = false;
+    if (coarse) coarse->have67 = false;
+}
+
 template struct Stencil27Plan<double>;
 template struct Stencil27Plan<float>;
 
