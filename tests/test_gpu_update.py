@@ -30,7 +30,7 @@ def test_updated_hierarchy_is_the_freshly_built_one(shape, grids, dtype):
     x0 = rng.standard_normal(A2.shape[0])
     if dtype == "float32":
         b, x0 = b.astype(np.float32).astype(np.float64), x0.astype(np.float32).astype(np.float64)
-    with _hip.Hierarchy.from_fine(A2, shape, grids - 1, "colour", dtype=dtype) as fresh, \\
+    with _hip.Hierarchy.from_fine(A2, shape, grids - 1, "colour", dtype=dtype) as fresh, \
             _hip.Hierarchy.from_fine(A1, shape, grids - 1, "colour", dtype=dtype) as h:
         assert all(h.level_flags(l)["stencil27"] for l in range(grids - 1))
         want = run(fresh, b, x0, 1, 1, 3)
@@ -68,7 +68,8 @@ def test_update_is_refused_where_it_does_not_apply():
         with pytest.raises(_hip.HipError):
             h.update_fine(A.data[:-1])                           # not the pattern's number of entries
         bad = A.data.copy()
-        bad[A.indptr[100] + 13] = 0.0                            # a zero diagonal (row 100 is an interior row: slot 13)
+        interior = (5 * 16 + 5) * 16 + 5                         # cell (5, 5, 5): all 27 neighbours, the diagonal is entry 13
+        bad[A.indptr[interior] + 13] = 0.0
         with pytest.raises(_hip.HipError):
             h.update_fine(bad)
         h.update_fine(A.data)
