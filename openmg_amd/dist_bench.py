@@ -354,13 +354,18 @@ def main_plane(args, rank, world, shape, grids, n_levels, all_gather, td, torch,
     try:
         times, trajectory = timed_run()
     except CyclesFailed as e:
-        if not (r.p2p_mode and not shared):
+        if r.p2p_mode and not shared:
+            # peer mode gave up somewhere: every rank is here (the failure was agreed inside timed_run); the RCCL
+            # exchanges are the checked fallback
+            r.p2p_enable(0)
+            exchange = "RCCL grouped send/recv of ghost planes"
+            p2p_note = "rejected DURING the timed run (%s): the reported run is the RCCL one" % e
+        elif gate_note.startswith("on"):
+            # a gated pass's bounded wait gave up: back to the exchanges in stream order, on every rank
+            r.set_gate(False)
+            gate_note = "rejected DURING the timed run (%s): the reported run has the exchanges in stream order" % e
+        else:
             raise
-        # peer mode gave up somewhere: every rank is here (the failure was agreed inside timed_run); the RCCL
-        # exchanges are the checked fallback
-        r.p2p_enable(0)
-        exchange = "RCCL grouped send/recv of ghost planes"
-        p2p_note = "rejected DURING the timed run (%s): the reported run is the RCCL one" % e
         times, trajectory = timed_run()
     if r.p2p_mode and not shared:
         # every norm of the timed peer-mode run against the same cycles over RCCL (untimed): a hand-over that went
