@@ -331,7 +331,7 @@ def config4_leg(size, grids, steps, warmup, repeats, sync_of):
         us = 1e3 * ms / cnt
         traffic, traffic_src = None, None
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r04_pmc_s27_sweep.json")))
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r05_pmc_s27_sweep.json")))
             if pmc.get("kernel_src_sha") == kernel_source_hash() and size == 256:
                 traffic = pmc["traffic_bytes"]
                 traffic_src = "NOT measured in this run: rocprofv3 --pmc passes of the same build, " + pmc["source"]
@@ -344,6 +344,16 @@ def config4_leg(size, grids, steps, warmup, repeats, sync_of):
                            "bytes_definition": "27 coefficients per row (27 w n) + b read, x written (2 w n) + the iterate read once per launch (4 w n)",
                            "csr_equiv_bytes": (w + 4) * nnz + 4 * (n + 8) + 3 * w * n + 8 * w * n,
                            "csr_equiv_GBps": round(((w + 4) * nnz + 4 * (n + 8) + 3 * w * n + 8 * w * n) / us / 1e3, 1)}
+    # new coefficients into the same hierarchy (omg_hierarchy_update_fine: level 0 re-tiled, every Galerkin product re-formed
+    # on the device by the closed-form streaming kernel, the coarsest operator's inverse anew) — from host memory here
+    try:
+        t4 = time.perf_counter()
+        h.update_fine(A0.data)
+        out["update_fine_s"] = round(time.perf_counter() - t4, 3)
+        out["update_fine_what"] = "omg_hierarchy_update_fine with the values in HOST memory (3.6 GB over PCIe included); device-resident values: profiles/r05_update_fine.txt"
+    except Exception as ex:                                     # noqa: BLE001 - reported, not fatal for the bench line
+        out["update_fine_s"] = None
+        out["update_fine_what"] = "failed: %s" % ex
     # the whole level-0 kernel table (untimed region)
     h.profile_enable(True)
     for _ in range(min(steps, 10)):
@@ -351,6 +361,30 @@ def config4_leg(size, grids, steps, warmup, repeats, sync_of):
     tab = h.profile_read()
     h.profile_enable(False)
     out["level0_kernels"] = {k: {"launches_per_cycle": c / min(steps, 10), "avg_us": round(1e3 * m / c, 2)} for k, (c, m) in tab.items() if c}
+    h.close()
+    return out
+
+
+def config0_leg(steps, warmup, repeats, sync_of):
+    """BASELINE configs[0] — the reference's own CPU-runnable case: 1-D Poisson N = 4096 (operators.poisson: 4, -1), 3 grids,
+    the reference's lexicographic Gauss-Seidel (openmg/solvers.py:56-68), V(1,1), fp64.  A 1-D sweep is a first-order
+    recurrence: one wave walks it (march.hip line_gs_kernel)."""
+    import numpy as np
+    from openmg_amd import _hip, operators
+    shape = (4096,)
+    A0 = operators.poisson(shape[0], sparse=True)
+    b = A0 @ np.random.default_rng(12345).random(A0.shape[0])
+    R = operators.restrictionList(shape, 1, 8)
+    A = operators.coeffecientList(A0, R)
+    h = _hip.Hierarchy(A, R, smoother="gs")
+    h.resident_load(b)
+    times, _, norms = timed_regions(h, sync_of(h), steps, warmup, repeats, 1, 1, ())
+    e = statistics.median(times)
+    out = {"what": "BASELINE configs[0]: 1-D Poisson N = 4096, 3 grids, the reference's lexicographic Gauss-Seidel, V(1,1), fp64; same timed loop as `value`",
+           "vcycles_per_s": round(steps / e, 1), "ms_per_step": round(1e3 * e / steps, 4), "grids": len(A),
+           "row_updates_per_cycle": 2 * sum(int(M.shape[0]) for M in A[:-1]),
+           "ns_per_row_update_incl_everything": round(1e9 * e / steps / (2 * sum(int(M.shape[0]) for M in A[:-1])), 1),
+           "norms_last_region_tail": norms[-2:]}
     h.close()
     return out
 
@@ -497,7 +531,7 @@ def main():
         # (DESIGN.md §5): per fine unknown 3 w (x read, b read, x written), per coarse unknown w (its right-hand
         # side) + 4 (its slot in the coarse ordering).  The operator itself costs nothing: seven coefficients.
         bytes_roof = fmt_b["plane_down"]
-        traffic, traffic_src, rocprof_us = pmc_traffic("r04_pmc_plane_down.json", bytes_roof, w)
+        traffic, traffic_src, rocprof_us = pmc_traffic("r05_pmc_plane_down.json", bytes_roof, w)
         achieved = bytes_roof / avg_s / 1e9
         roofline = {"bound": "hbm", "kernel": "plane_kernel<down>: fine-grid red-black sweep + residual + restriction in one launch (plane.hip)",
                     "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -508,8 +542,8 @@ def main():
                     "avg_launch_us": round(avg_s * 1e6, 2), "avg_launch_us_source": "hipEvents on the kernel's own stream inside the timed regions",
                     "avg_launch_us_rocprof": rocprof_us,
                     "avg_launch_us_rocprof_source": "NOT measured in this run: rocprofv3's average duration of the same kernel of the same build "
-                                                    "(profiles/r04_pmc_plane_down.json; per grid size over a whole bench run: "
-                                                    "profiles/r04_bench_kernel_stats_by_grid.txt)" if rocprof_us else None,
+                                                    "(profiles/r05_pmc_plane_down.json; per grid size over a whole bench run: "
+                                                    "profiles/r05_bench_kernel_stats_by_grid.txt)" if rocprof_us else None,
                     "launches_timed": launches,
                     "csr_equiv_bytes": int(csr_b["plane_down"]), "csr_equiv_GBps": round(csr_b["plane_down"] / avg_s / 1e9, 1),
                     "tiling": h.plane_info(0),
@@ -651,6 +685,9 @@ def main():
     if not args.no_config4 and args.dtype == "f64" and args.smoother == "colour":
         _PROBLEM.clear()                               # (the 256^3 7-point operator: 1.9 GB of host memory)
         config4 = config4_leg(args.config4_size, args.grids, max(10, args.steps), 3, min(repeats, 7), syncer)
+    config0 = None
+    if not args.no_config1 and args.dtype == "f64":
+        config0 = config0_leg(args.steps, 3, min(repeats, 5), syncer)
     config1 = None
     if not args.no_config1 and args.dtype == "f64" and args.smoother == "colour":
         config1 = config1_leg(args.steps, 3, min(repeats, 9), syncer)
@@ -695,6 +732,12 @@ def main():
                    "smoother": args.smoother, "hipgraph": bool(args.graph),
                    "plane_levels": [bool(f) for f in meta.get("plane_levels", [])],
                    "repeats": repeats, "ms_per_step_all": [round(1e3 * t / args.steps, 4) for t in times],
+                   # the two populations of processes (~5 % apart, the same for everything a process
+                   # creates): which one this run landed in, by its steady regions (the first regions of any process are ~3 % slower)
+                   "process_population": {"steady_ms_per_step": round(1e3 * min(times[len(times) // 2:]) / args.steps, 4),
+                                          "first_region_ms_per_step": round(1e3 * times[0] / args.steps, 4),
+                                          "which": ("fast" if 1e3 * min(times[len(times) // 2:]) / args.steps <= 0.272 else "slow") if (args.size == 256 and w == 8 and plane) else None,
+                                          "rule": "256^3 fp64 headline: steady cycle <= 0.272 ms = the fast population (0.258-0.270), above = the slow one (0.273-0.290)"},
                    "final_residual_norm": norm,
                    "norms": "every cycle of a timed region computes its residual norm (all K are returned at the region's end): "
                             + ("the up pass of the fine grid leaves the squared residuals of its rows as one partial per workgroup, "
@@ -719,6 +762,7 @@ def main():
         "default_cycle": default_cycle,
         "dropin": dropin,
         "config4": config4,
+        "config0": config0,
         "config1": config1,
         "set_schedule": set_path,
         "csr_path": csr_path,

@@ -1,9 +1,9 @@
 #!/bin/bash
 # Everything under profiles/rNN_* from ONE gpurun call (run from the repository root on the GPU box):
-#     gpurun -- "OMG_GIT_HEAD=$(git rev-parse HEAD) bash tools/collect_profiles.sh r04"
+#     gpurun -- "OMG_GIT_HEAD=$(git rev-parse HEAD) bash tools/collect_profiles.sh r05"
 # (the variable goes INSIDE the command: gpurun does not forward the caller's environment, and the box has no .git)
 # writes gpurun_out/fin/<prefix>_*; copy what is to be judged into profiles/.
-p=${1:-r04}
+p=${1:-r05}
 root=$(cd "$(dirname "$0")/.." && pwd)
 out=$root/gpurun_out/fin
 rm -rf "$out"; mkdir -p "$out"
@@ -53,5 +53,12 @@ for m in 0 1; do PYTHONPATH=$root timeout 200 rocprofv3 --kernel-trace --output-
 python3 $root/tools/peer_mode_table.py $out/peer0 $out/peer1 > $out/${p}_peer_mode.txt 2>&1
 python3 $root/tools/level_times.py $out/cyc/c_kernel_trace.csv > $out/${p}_level_times.txt 2>&1
 cd "$root"
+# round 5: configs[4] through the multi-GPU code path with one rank (27-point slabs, omg_sdist), the matrix-free SpMV and where
+# it writes, configs[0], update_fine, one slab against the single-GPU hierarchy
+timeout 600 python bench.py --dist 1 --stencil 27var --dtype f32 --steps 20 --repeats 5 2>/dev/null | tail -1 > $out/${p}_bench_dist1_27var_f32.json
+PYTHONPATH=$root timeout 300 python tools/spmv_place.py 2>&1 | tail -1 > $out/${p}_spmv_destinations.txt
+timeout 300 python tools/spmv_probe.py 256 2>&1 > $out/${p}_spmv_probe.txt; OMG_PLANE_SPMV=0 timeout 300 python tools/spmv_probe.py 256 >> $out/${p}_spmv_probe.txt 2>&1
+OMG_SETUP_TIMING=1 timeout 600 python tools/update_probe.py 256 5 2>&1 | grep -E "update|norm" | tail -12 > $out/${p}_update_probe.txt
+timeout 900 python tools/slab27_ab.py 256 3 2>&1 | tail -4 > $out/${p}_slab27_vs_single.txt
 rm -rf $out/trace $out/cyc $out/lex $out/pmc $out/pmc27 $out/peer0 $out/peer1 $out/c4b $out/c4s
 ls -la $out
