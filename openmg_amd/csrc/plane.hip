@@ -1908,6 +1908,19 @@ void PlanePlan<V>::tune(V *x, V *tmp, const V *b, const Coarse &c, hipStream_t s
         };
         for (const auto &t : more0) add(from(t));
         for (const auto &t : more1) add(from(t));
+        // OMG_PLANE_TUNE_EXTRA="TX,TY,LZ;TX,TY,LZ;...": more tilings to time on the large levels (a tiling that does not fit is skipped)
+        if (const char *e = getenv("OMG_PLANE_TUNE_EXTRA")) {
+            const char *q = e;
+            while (*q) {
+                int t3[3];
+                if (sscanf(q, "%d,%d,%d", &t3[0], &t3[1], &t3[2]) == 3 && t3[0] >= 4 && t3[1] >= 2 && t3[2] >= 2) {
+                    PlaneGeom c = from({round_up(t3[0], 4), round_up(t3[1], 2), round_up(t3[2], 2)});
+                    if (c.lds_bytes <= size_t(160) * 1024) add(c);
+                }
+                while (*q && *q != ';') ++q;
+                if (*q == ';') ++q;
+            }
+        }
     }
     if (cand.size() < 2) return;
     // One decision per process and shape: the norm's partial sums follow the tiles, and two hierarchies of one process
