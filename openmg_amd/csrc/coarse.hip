@@ -431,10 +431,15 @@ void CoarseSolver<V>::build(const HostCsr &A, hipStream_t s) {
         for (int64_t i = 0; i < n; ++i) ident[i] = int32_t(i);
         DevBuf<int32_t> d_map;
         put(d_map, ident, s);
-        DevBuf<double> W((size_t)(n) * (size_t)(2 * n)), inv64((size_t)(n) * (size_t)(n));
+        const size_t nn = (size_t)(n) * (size_t)(n);
+        DevBuf<double> W_own, inv64_own;
+        DevBuf<double> &W = retain_workspace ? ws_aug : W_own, &inv64 = retain_workspace ? ws_inv64 : inv64_own;
+        if (W.n != 2 * nn) W.alloc(2 * nn);
+        if (inv64.n != nn) inv64.alloc(nn);
+        if (retain_workspace && ws_keep.n != nn) ws_keep.alloc(nn);
         fill_augmented_from_csr(d_ptr.p, d_idx.p, d_val.p, n, d_map.p, d_map.p, n, W.p, s);
-        gauss_jordan_inverse(W.p, n, inv64.p, s);
-        inv.alloc((size_t)(n) * (size_t)(n));
+        gauss_jordan_inverse(W.p, n, inv64.p, s, retain_workspace ? ws_keep.p : nullptr);
+        if (inv.n != nn) inv.alloc(nn);
         hipLaunchKernelGGL((narrow_kernel<V>), dim3(grid1d(n * n)), dim3(256), 0, s, inv64.p, inv.p, n * n);
         OMG_HIP(hipStreamSynchronize(s));
         bytes = (size_t)(n) * (size_t)(n) * sizeof(V);

@@ -441,7 +441,7 @@ void launch_dense_gemv_rows(const V *M, const V *v, V *out, int64_t rows, int64_
 void dense_inverse_from_csr(const DevCsr &A, double *Minv, hipStream_t s);
 // dense.hip building blocks: Gauss-Jordan on a prepared [M | I] (n x 2n, destroyed), and the
 // preparation of that matrix from a sub-block of a plain device CSR (maps < 0: not in the block)
-void gauss_jordan_inverse(double *W, int64_t n, double *Minv, hipStream_t s);
+void gauss_jordan_inverse(double *W, int64_t n, double *Minv, hipStream_t s, double *keep_ws = nullptr);      // keep_ws: n * n doubles of scratch, or null
 void fill_augmented_from_csr(const int32_t *indptr, const int32_t *indices, const double *data, int64_t n_rows,
                              const int32_t *rmap, const int32_t *cmap, int64_t m, double *W, hipStream_t s);
 
@@ -482,6 +482,10 @@ struct CoarseSolver {
     int sx = 0, sy = 0, sz = 0;
     DevBuf<double> sine, lambda;      // the three tables (sx^2, sy^2, sz^2 doubles, row-major), the n eigenvalues
     size_t bytes = 0;                 // device bytes one solve reads
+    // the explicit inverse's work arrays ([A | I], the inverse in double, a copy of A for the check): kept between builds once
+    // a hierarchy takes new coefficients (omg_hierarchy_update_fine) — three allocations of hundreds of MB cost ~2 ms per build
+    bool retain_workspace = false;
+    DevBuf<double> ws_aug, ws_inv64, ws_keep;
     void build(const HostCsr &A, hipStream_t s);
     bool build_sine(const HostCsr &A, hipStream_t s);       // P = 0 when the operator qualifies
     void solve(const V *b, V *x, hipStream_t s) const;     // original numbering, device pointers

@@ -136,64 +136,107 @@ int grid1d(int64_t n) {
 // The column-by-column elimination above sweeps the whole augmented matrix once per PIVOT: 4 n launches and O(n^3) bytes of
 // HBM traffic — 190 ms for the 4096 unknowns of a 16^3 coarsest level with per-row coefficients (BASELINE configs[4]; the
 // constant-coefficient headline takes the sine transform instead).  Here 64 pivots at a time: the 64 x 64 diagonal block is
-// inverted in LDS (partial pivoting INSIDE the block: just the method for its inverse), row block K becomes D^-1 R_K, and
-// every other row block R_i <- R_i - A_iK R_K as 64 x 64 x 64 tile products — one sweep of the active columns (left of
-// the pivots the matrix is already the identity, right of them the inverse's columns are still untouched: n columns in
-// all) per 64 pivots, 3 launches per block.  No pivoting ACROSS blocks: exact for the symmetric positive definite /
+// inverted in registers (partial pivoting INSIDE the block: just the method for its inverse), row block K becomes D^-1 R_K, and
+// every other row block R_i <- R_i - A_iK R_K as 64 x 64 x 64 tile products on the fp64 matrix cores — one sweep of the
+// active columns (left of the pivots the matrix is already the identity, right of them the inverse's columns are still
+// untouched: n columns in all) per 64 pivots, 3 launches per block.  Tiles that hold only zeros — below and right of a
+// banded operator's band, which is what a grid's coarsest operator is — are found as the step's operands are staged and
+// skipped: a third of the products remain.  No pivoting ACROSS blocks: exact for the symmetric positive definite /
 // diagonally dominant operators a Galerkin hierarchy ends in; the caller checks the result against the operator and falls
 // back to the pivoted elimination where it is not an inverse.
 constexpr int GJB = 64;
+typedef double gj_v4d __attribute__((ext_vector_type(4)));
 
-// D^-1 of the diagonal block [k0, k0 + nb) by Gauss-Jordan with partial pivoting in LDS -> dinv (GJB x GJB, row-major)
-__global__ __launch_bounds__(256) void gjb_diag_kernel(const double *W, int64_t ld, int64_t k0, int nb, double *dinv, int *singular) {
-    __shared__ double D[GJB][2 * GJB + 1];
-    __shared__ int s_piv;
-    __shared__ double s_col[GJB];
-    const int t = int(threadIdx.x);
-    for (int q = t; q < GJB * 2 * GJB; q += 256) {
-        const int r = q / (2 * GJB), c = q % (2 * GJB);
-        double v;
-        if (c < GJB) v = (r < nb && c < nb) ? W[(k0 + r) * ld + k0 + c] : (r == c ? 1.0 : 0.0);
-        else v = (c - GJB == r) ? 1.0 : 0.0;
-        D[r][c] = v;
-    }
-    __syncthreads();
-    for (int k = 0; k < nb; ++k) {
-        if (t < 64) {
-            // lanes = rows: the largest magnitude of column k among rows >= k (ties: the smallest row)
-            double v = (t >= k && t < nb) ? fabs(D[t][k]) : -1.0;
-            int idx = t;
+// max over the wave of an unsigned key -> every lane (row_shr 1, 2, 4, 8 within the rows of 16, then the rows' last lanes
+// broadcast along: the total is in lane 63)
+__device__ __forceinline__ unsigned wave_max_u32(unsigned x) {
+    x = max(x, unsigned(__builtin_amdgcn_update_dpp(0, int(x), 0x111, 0xf, 0xf, false)));
+    x = max(x, unsigned(__builtin_amdgcn_update_dpp(0, int(x), 0x112, 0xf, 0xf, false)));
+    x = max(x, unsigned(__builtin_amdgcn_update_dpp(0, int(x), 0x114, 0xf, 0xf, false)));
+    x = max(x, unsigned(__builtin_amdgcn_update_dpp(0, int(x), 0x118, 0xf, 0xf, false)));
+    x = max(x, unsigned(__builtin_amdgcn_update_dpp(0, int(x), 0x142, 0xa, 0xf, false)));
+    x = max(x, unsigned(__builtin_amdgcn_update_dpp(0, int(x), 0x143, 0xc, 0xf, false)));
+    return unsigned(__builtin_amdgcn_readlane(int(x), 63));
+}
+__device__ __forceinline__ double lane_value(double v, int lane_uniform) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane_uniform), hi = __builtin_amdgcn_readlane(__double2hiint(v), lane_uniform);
+    return __hiloint2double(hi, lo);
+}
+
+// D^-1 of the diagonal block [k0, k0 + nb) -> dinv (GJB x GJB, row-major).  Gauss-Jordan on [D | I], a lane per ROW and a
+// wave per 32 of the 128 columns, all in registers (the loop over the pivots is unrolled: the pivot's column is a fixed
+// register).  Pivoting is implicit — the pivot of column k is the unused row with the largest magnitude as far as the
+// upper word of the double tells (exponent and 20 bits: any such row is as good a pivot) — rows stay in their lanes and the
+// lane that was pivot k ends up holding row k of the inverse.  Per pivot: the wave that owns column k finds the pivot's
+// lane (a DPP reduction), publishes the column, the lane and the pivot's reciprocal (ONE workgroup barrier, double
+// buffered), every wave takes the pivot row's 32 values of its own columns out of that lane (v_readlane), scales them and
+// eliminates.  (The first version kept [D | I] in LDS with five barriers per pivot: 261 us per block; this one: see DESIGN.md.)
+// (FRESH: the block was written by this workgroup a moment ago — loads that do not stop at this compute unit's L1)
+template <bool FRESH>
+__device__ __forceinline__ void gjb_diag_block(const double *W, int64_t ld, int64_t k0, int nb, double *dinv, int *singular) {
+    __shared__ double s_col[2][GJB];
+    __shared__ double s_rp[2];
+    __shared__ int s_p[2];
+    const int t = int(threadIdx.x), w = t >> 6, lane = t & 63;
+    double row[32];
 #pragma unroll
-            for (int off = 32; off > 0; off >>= 1) {
-                const double ov = __shfl_down(v, off, 64);
-                const int oi = __shfl_down(idx, off, 64);
-                if (ov > v || (ov == v && oi < idx)) { v = ov; idx = oi; }
+    for (int c = 0; c < 32; ++c) {
+        const int col = 32 * w + c;
+        double v;
+        if (col < GJB) {
+            v = lane == col ? 1.0 : 0.0;
+            if (lane < nb && col < nb) {
+                const double *const src = W + (k0 + lane) * ld + k0 + col;
+                v = FRESH ? __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *src;
             }
-            if (t == 0) {
-                s_piv = idx;
-                if (!(v > 0.0) || !isfinite(v)) *singular = 1;
-            }
+        } else {
+            v = (col - GJB == lane) ? 1.0 : 0.0;
         }
-        __syncthreads();
-        const int p = s_piv;
-        if (p != k && t < 2 * GJB) {
-            const double a = D[k][t], b2 = D[p][t];
-            D[k][t] = b2;
-            D[p][t] = a;
-        }
-        __syncthreads();
-        const double pv = D[k][k];
-        if (t < GJB) s_col[t] = D[t][k];
-        __syncthreads();
-        if (t < 2 * GJB) D[k][t] = D[k][t] / pv;
-        __syncthreads();
-        for (int q = t; q < GJB * 2 * GJB; q += 256) {
-            const int r = q / (2 * GJB), c = q % (2 * GJB);
-            if (r != k && r < nb) D[r][c] -= s_col[r] * D[k][c];
-        }
-        __syncthreads();
+        row[c] = v;
     }
-    for (int q = t; q < GJB * GJB; q += 256) dinv[q] = D[q / GJB][GJB + q % GJB];
+    bool used = lane >= nb;
+    int mine = lane;                                   // the pivot this lane's row was (rows beyond nb: identity rows)
+#pragma unroll
+    for (int k = 0; k < GJB; ++k) {
+        if (k >= nb) continue;                         // (uniform)
+        const int par = k & 1;
+        if (w == (k >> 5)) {
+            const double v = row[k & 31];
+            const unsigned key = used ? 0u : (unsigned(__double2hiint(v)) & 0x7fffffffu);
+            const unsigned m = wave_max_u32(key);
+            const unsigned long long eq = __builtin_amdgcn_ballot_w64(!used && key == m);
+            const int p = eq ? int(__builtin_ctzll(eq)) : 0;
+            const double pv = lane_value(v, p);
+            double r = __builtin_amdgcn_rcp(pv);
+            r = fma(r, fma(-pv, r, 1.0), r);
+            r = fma(r, fma(-pv, r, 1.0), r);
+            s_col[par][lane] = v;
+            if (lane == 0) {
+                s_p[par] = p;
+                s_rp[par] = r;
+                if (m == 0u || m >= 0x7ff00000u) *singular = 1;      // no pivot to speak of (zero / denormal column), or inf / nan
+            }
+        }
+        __syncthreads();
+        const int p = __builtin_amdgcn_readfirstlane(s_p[par]);
+        const double rp = s_rp[par];
+        const double f = s_col[par][lane];
+        const bool piv = lane == p;
+#pragma unroll
+        for (int c = 0; c < 32; ++c) {
+            const double pr = lane_value(row[c], p) * rp;      // the scaled pivot row: the same in every lane
+            const double e = fma(-f, pr, row[c]);
+            row[c] = piv ? pr : e;
+        }
+        if (piv) { used = true; mine = k; }
+    }
+    if (w >= 2) {
+#pragma unroll
+        for (int c = 0; c < 32; ++c) dinv[mine * GJB + 32 * (w - 2) + c] = row[c];
+    }
+}
+__global__ __launch_bounds__(256) void gjb_diag_kernel(const double *W, int64_t ld, int64_t k0, int nb, double *dinv, int *singular) {
+    gjb_diag_block<false>(W, ld, k0, nb, dinv, singular);
 }
 
 // column tile `ct` of the active columns of block step k0 .. k1: left of the matrix [k1, n), then the inverse's [n, n + k1)
@@ -204,95 +247,156 @@ __device__ __forceinline__ int64_t gjb_col0(int64_t ct, int64_t n, int64_t k1, i
     return n + (ct - left_tiles) * GJB;
 }
 
-// blockIdx.x < col_tiles: row block K <- D^-1 (row block K) on that column tile; the others: the pivot columns of 64 rows
-// into `panel` (n x GJB), which the elimination reads while the matrix's own copy is being overwritten
+// The matrix-core tiles below: v_mfma_f64_16x16x4 — A: lane 16 k + i holds A[i][k], B: lane 16 k + j holds B[k][j],
+// D: register r of lane l holds row 4 r + l / 16 of column l % 16 (coarse.hip uses the same layout).
+
+// Workgroups [0, col_groups): two column tiles each, two waves per tile (the upper / lower 32 rows of the result) — row
+// block K <- D^-1 (row block K) there, unless the tile holds only zeros (col_flag says which).  Both waves hold the whole
+// tile before either overwrites it.  The others, one per row tile: the pivot columns of its 64 rows, NEGATED and transposed,
+// into `panel` (GJB x n_pad: the elimination's A operand, read while the matrix's own copy is overwritten), row_flag: any nonzero.
 __global__ __launch_bounds__(256) void gjb_rowblock_kernel(double *W, int64_t n, int64_t ld, int64_t k0, int nb, const double *dinv, double *panel,
-                                                           int col_tiles) {
-    __shared__ double Dv[GJB][GJB + 1];
-    __shared__ double Rk[GJB][GJB + 1];
-    const int t = int(threadIdx.x);
-    if (int(blockIdx.x) >= col_tiles) {
-        const int64_t r0 = int64_t(int(blockIdx.x) - col_tiles) * GJB;
+                                                           int64_t n_pad, int col_tiles, int col_groups, int *row_flag, int *col_flag) {
+    const int t = int(threadIdx.x), w = t >> 6, lane = t & 63;
+    if (int(blockIdx.x) >= col_groups) {
+        __shared__ double tile[GJB][GJB + 1];
+        const int rt = int(blockIdx.x) - col_groups;
+        const int64_t r0 = int64_t(rt) * GJB;
+        int any = 0;
         for (int q = t; q < GJB * GJB; q += 256) {
-            const int64_t r = r0 + q / GJB;
-            const int c = q % GJB;
-            if (r < n) panel[r * GJB + c] = c < nb ? W[r * ld + k0 + c] : 0.0;
+            const int r = q / GJB, c = q % GJB;
+            const double v = (r0 + r < n && c < nb) ? W[(r0 + r) * ld + k0 + c] : 0.0;
+            any |= v != 0.0;
+            tile[r][c] = -v;
         }
+        any = __syncthreads_or(any);
+        for (int q = t; q < GJB * GJB; q += 256) {
+            const int c = q / GJB, r = q % GJB;
+            panel[int64_t(c) * n_pad + r0 + r] = tile[r][c];
+        }
+        if (t == 0) row_flag[rt] = any;
         return;
     }
-    int64_t c_end;
-    const int64_t c0 = gjb_col0(blockIdx.x, n, k0 + nb, c_end);
-    for (int q = t; q < GJB * GJB; q += 256) {
-        const int r = q / GJB, c = q % GJB;
-        Dv[r][c] = dinv[q];
-        Rk[r][c] = (r < nb && c0 + c < c_end) ? W[(k0 + r) * ld + c0 + c] : 0.0;
-    }
-    __syncthreads();
-    const int ty = t / 16, tx = t % 16;
-    double acc[4][4] = {{0.0}};
-    for (int k = 0; k < nb; ++k) {
-        double av[4], bv[4];
+    const int ct = 2 * int(blockIdx.x) + (w >> 1), half = w & 1;
+    const bool have = ct < col_tiles;
+    int64_t c_end = 0;
+    const int64_t c0 = have ? gjb_col0(ct, n, k0 + nb, c_end) : 0;
+    const int q4 = lane >> 4, j = lane & 15;
+    // the whole 64 x 64 tile of row block K first (it is overwritten in place): b[ks][jt] = R[4 ks + q4][16 jt + j]
+    double b[16][4], a[16][2];
+    bool any = false;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) av[r] = Dv[ty * 4 + r][k];
+    for (int ks = 0; ks < 16; ++ks) {
 #pragma unroll
-        for (int c = 0; c < 4; ++c) bv[c] = Rk[k][tx * 4 + c];
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-            for (int c = 0; c < 4; ++c) acc[r][c] = fma(av[r], bv[c], acc[r][c]);
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const int rr = ty * 4 + r;
-            const int64_t cc = c0 + tx * 4 + c;
-            if (rr < nb && cc < c_end) W[(k0 + rr) * ld + cc] = acc[r][c];
+        for (int jt = 0; jt < 4; ++jt) {
+            const int r = 4 * ks + q4;
+            const int64_t cc = c0 + 16 * jt + j;
+            const double v = (have && r < nb && cc < c_end) ? W[(k0 + r) * ld + cc] : 0.0;
+            any = any || v != 0.0;
+            b[ks][jt] = v;
         }
+#pragma unroll
+        for (int it = 0; it < 2; ++it) a[ks][it] = dinv[(32 * half + 16 * it + j) * GJB + 4 * ks + q4];      // (lane 16 k + i: here i = j, k = q4)
+    }
+    const bool some = __builtin_amdgcn_ballot_w64(any) != 0;
+    if (have && half == 0 && lane == 0) col_flag[ct] = some ? 1 : 0;
+    __syncthreads();
+    if (!some) return;
+    gj_v4d acc[2][4];
+#pragma unroll
+    for (int it = 0; it < 2; ++it)
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt) acc[it][jt] = gj_v4d{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks)
+#pragma unroll
+        for (int it = 0; it < 2; ++it)
+#pragma unroll
+            for (int jt = 0; jt < 4; ++jt) acc[it][jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ks][it], b[ks][jt], acc[it][jt], 0, 0, 0);
+#pragma unroll
+    for (int it = 0; it < 2; ++it)
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int rr = 32 * half + 16 * it + 4 * r + q4;
+                const int64_t cc = c0 + 16 * jt + j;
+                if (rr < nb && cc < c_end) W[(k0 + rr) * ld + cc] = acc[it][jt][r];
+            }
 }
 
-// R_i <- R_i - A_iK R_K on a 64 x 64 tile (row tile blockIdx.y, skipping block K; column tile blockIdx.x of the active columns)
-__global__ __launch_bounds__(256) void gjb_eliminate_kernel(double *W, int64_t n, int64_t ld, int64_t k0, int nb, const double *panel) {
-    const int64_t r0 = int64_t(blockIdx.y) * GJB;
-    if (r0 == k0) return;
-    __shared__ double Ap[GJB][GJB + 1];
-    __shared__ double Rk[GJB][GJB + 1];
-    const int t = int(threadIdx.x);
-    int64_t c_end;
-    const int64_t c0 = gjb_col0(blockIdx.x, n, k0 + nb, c_end);
-    for (int q = t; q < GJB * GJB; q += 256) {
-        const int r = q / GJB, c = q % GJB;
-        Ap[r][c] = (r0 + r < n) ? panel[(r0 + r) * GJB + c] : 0.0;
-        Rk[r][c] = (r < nb && c0 + c < c_end) ? W[(k0 + r) * ld + c0 + c] : 0.0;
+// R_i <- R_i - A_iK R_K, a wave per 64 x 32 half tile (a workgroup: one row tile, two column tiles; row block K and the
+// tiles either of whose operands is all zeros are skipped).  Operands go straight from global memory / L2 into the matrix
+// instructions' registers, half of the k-steps' at a time; two waves per SIMD, one's loads under the other's products.
+// next_rt >= 0: the FIRST workgroup takes the next step's row tile (it exchanges places with that tile's own workgroup) and,
+// its tiles done, inverts the next diagonal block — column tile 0 there — into dinv: the chain of 64 dependent pivots
+// runs beside this step's other tiles instead of behind them.  (On a second stream with events it cost more than it hid:
+// 14.8 against 10.7 ms per 4096 x 4096 inverse.)
+template <typename = void>
+__device__ __forceinline__ void gjb_eliminate_tile(double *W, int64_t n, int64_t ld, int64_t k0, int nb, const double *panel, int64_t n_pad, int rt, int ct,
+                                                   int half, int lane, int64_t c0, int64_t c_end) {
+    const int64_t r0 = int64_t(rt) * GJB;
+    const int q4 = lane >> 4, j = lane & 15;
+    gj_v4d acc[4][2];
+    const double *const pa = panel + r0 + j;           // A[i][k] = panel[k * n_pad + r0 + i] (already negated)
+#pragma unroll
+    for (int it = 0; it < 4; ++it)
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int64_t rr = r0 + 16 * it + 4 * r + q4, cc = c0 + 16 * jt + j;
+                acc[it][jt][r] = (rr < n && cc < c_end) ? W[rr * ld + cc] : 0.0;
+            }
+    // (two phases of eight k-steps: all 256 registers would be needed for the operands of all sixteen at once)
+#pragma unroll
+    for (int ph = 0; ph < 2; ++ph) {
+        double a[8][4], b[8][2];
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            const int kk = 4 * (8 * ph + ks) + q4;
+#pragma unroll
+            for (int it = 0; it < 4; ++it) a[ks][it] = pa[int64_t(kk) * n_pad + 16 * it];
+#pragma unroll
+            for (int jt = 0; jt < 2; ++jt) {
+                const int64_t cc = c0 + 16 * jt + j;
+                b[ks][jt] = (kk < nb && cc < c_end) ? W[(k0 + kk) * ld + cc] : 0.0;
+            }
+        }
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+            for (int it = 0; it < 4; ++it)
+#pragma unroll
+                for (int jt = 0; jt < 2; ++jt) acc[it][jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ks][it], b[ks][jt], acc[it][jt], 0, 0, 0);
     }
+#pragma unroll
+    for (int it = 0; it < 4; ++it)
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int64_t rr = r0 + 16 * it + 4 * r + q4, cc = c0 + 16 * jt + j;
+                if (rr < n && cc < c_end) W[rr * ld + cc] = acc[it][jt][r];
+            }
+}
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void gjb_eliminate_kernel(double *W, int64_t n, int64_t ld, int64_t k0, int nb, const double *panel, int64_t n_pad,
+                          int row_tiles, int col_tiles, const int *row_flag, const int *col_flag, int next_rt, int next_nb, double *dinv, int *singular) {
+    const int t = int(threadIdx.x), w = t >> 6, lane = t & 63;
+    int rt = int(blockIdx.y);
+    if (next_rt >= 0) rt = rt == 0 ? next_rt : rt == next_rt ? 0 : rt;
+    const bool inverts = next_rt >= 0 && blockIdx.x == 0 && blockIdx.y == 0;      // (uniform over the workgroup)
+    const int ct = 2 * int(blockIdx.x) + (w >> 1), half = w & 1;
+    if (rt < row_tiles && ct < col_tiles && int64_t(rt) * GJB != k0 && row_flag[rt] && col_flag[ct]) {
+        int64_t c_end;
+        const int64_t c0 = gjb_col0(ct, n, k0 + nb, c_end) + 32 * half;
+        gjb_eliminate_tile(W, n, ld, k0, nb, panel, n_pad, rt, ct, half, lane, c0, c_end);
+    }
+    if (!inverts) return;
+    __threadfence();                                   // the tile's new values: out of this compute unit before any wave reads them back
     __syncthreads();
-    const int ty = t / 16, tx = t % 16;
-    double acc[4][4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const int64_t rr = r0 + ty * 4 + r, cc = c0 + tx * 4 + c;
-            acc[r][c] = (rr < n && cc < c_end) ? W[rr * ld + cc] : 0.0;
-        }
-    for (int k = 0; k < nb; ++k) {
-        double av[4], bv[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) av[r] = Ap[ty * 4 + r][k];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) bv[c] = Rk[k][tx * 4 + c];
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-            for (int c = 0; c < 4; ++c) acc[r][c] = fma(-av[r], bv[c], acc[r][c]);
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const int64_t rr = r0 + ty * 4 + r, cc = c0 + tx * 4 + c;
-            if (rr < n && cc < c_end) W[rr * ld + cc] = acc[r][c];
-        }
+    gjb_diag_block<true>(W, ld, k0 + nb, next_nb, dinv, singular);
 }
 
 // || M (Minv v) - v ||_inf / || v ||_inf for one fixed vector: is Minv an inverse of M?  (M: n x n row-major)
@@ -313,17 +417,29 @@ __global__ __launch_bounds__(256) void gjb_matvec_kernel(const double *M, int64_
 // true: Minv holds the inverse.  W = [M | I] is destroyed either way; `keep` (n x n) must hold a copy of M.
 bool blocked_inverse(double *W, int64_t n, const double *keep, double *Minv, hipStream_t s) {
     const int64_t ld = 2 * n;
-    DevBuf<double> dinv(size_t(GJB) * GJB), panel(size_t(n) * GJB);
-    DevBuf<int> flag(1);
+    const int64_t row_tiles = (n + GJB - 1) / GJB, n_pad = row_tiles * GJB;
+    DevBuf<double> dinv(size_t(GJB) * GJB), panel(size_t(n_pad) * GJB);
+    DevBuf<int> flag(1), tile_flag(size_t(2 * row_tiles + 2));
     flag.zero(s);
-    const int64_t row_tiles = (n + GJB - 1) / GJB;
+    int *const row_flag = tile_flag.p, *const col_flag = tile_flag.p + row_tiles;
+    // Look-ahead: the next diagonal block is final as soon as ITS tile of this step's elimination is — the first workgroup of
+    // the elimination takes that tile and then inverts the block (gjb_eliminate_kernel); OMG_DENSE_LOOKAHEAD=0: a launch of its own
+    static const bool lookahead = [] { const char *e = getenv("OMG_DENSE_LOOKAHEAD"); return !(e && e[0] == '0'); }();
+    hipLaunchKernelGGL(gjb_diag_kernel, dim3(1), dim3(256), 0, s, W, ld, int64_t(0), int(std::min<int64_t>(GJB, n)), dinv.p, flag.p);
     for (int64_t k0 = 0; k0 < n; k0 += GJB) {
         const int nb = int(std::min<int64_t>(GJB, n - k0));
         const int64_t k1 = k0 + nb;
         const int col_tiles = int((n - k1 + GJB - 1) / GJB + (k1 + GJB - 1) / GJB);
-        hipLaunchKernelGGL(gjb_diag_kernel, dim3(1), dim3(256), 0, s, W, ld, k0, nb, dinv.p, flag.p);
-        hipLaunchKernelGGL(gjb_rowblock_kernel, dim3(unsigned(col_tiles + row_tiles)), dim3(256), 0, s, W, n, ld, k0, nb, dinv.p, panel.p, col_tiles);
-        hipLaunchKernelGGL(gjb_eliminate_kernel, dim3(unsigned(col_tiles), unsigned(row_tiles)), dim3(256), 0, s, W, n, ld, k0, nb, panel.p);
+        const int col_groups = (col_tiles + 1) / 2;
+        const bool more = k1 < n;
+        const int nb1 = more ? int(std::min<int64_t>(GJB, n - k1)) : 0;
+        hipLaunchKernelGGL(gjb_rowblock_kernel, dim3(unsigned(col_groups + row_tiles)), dim3(256), 0, s, W, n, ld, k0, nb, dinv.p, panel.p, n_pad,
+                           col_tiles, col_groups, row_flag, col_flag);
+        const dim3 egrid(unsigned((col_tiles + 1) / 2), unsigned(row_tiles));
+        const bool fused = lookahead && more;
+        hipLaunchKernelGGL(gjb_eliminate_kernel, egrid, dim3(256), 0, s, W, n, ld, k0, nb, panel.p, n_pad, int(row_tiles), col_tiles, row_flag, col_flag,
+                           fused ? int(k1 / GJB) : -1, nb1, dinv.p, flag.p);
+        if (more && !fused) hipLaunchKernelGGL(gjb_diag_kernel, dim3(1), dim3(256), 0, s, W, ld, k1, nb1, dinv.p, flag.p);
     }
     OMG_HIP(hipGetLastError());
     hipLaunchKernelGGL(extract_inverse_kernel, dim3(grid1d(n * n)), dim3(256), 0, s, W, n, Minv);
@@ -366,16 +482,18 @@ __global__ void restore_aug_kernel(const double *keep, int64_t n, double *W) {
 // Gauss-Jordan with partial pivoting on a prepared augmented matrix W = [M | I] (row-major
 // n x 2n, destroyed); the inverse goes to Minv (n*n doubles).  ~4 n dependent launches — or, for n >= 256, the blocked
 // form above first (OMG_DENSE_BLOCKED=0: never), checked against M.
-void gauss_jordan_inverse(double *W, int64_t n, double *Minv, hipStream_t s) {
+void gauss_jordan_inverse(double *W, int64_t n, double *Minv, hipStream_t s, double *keep_ws) {
     if (n == 0) return;
     const int64_t ld = 2 * n;
     {
         static const bool blocked = [] { const char *e = getenv("OMG_DENSE_BLOCKED"); return !(e && e[0] == '0'); }();
         if (blocked && n >= 256) {
-            DevBuf<double> keep((size_t)(n) * (size_t)(n));
-            hipLaunchKernelGGL(copy_block_kernel, dim3(grid1d(n * n)), dim3(256), 0, s, W, n, ld, keep.p);
-            if (blocked_inverse(W, n, keep.p, Minv, s)) return;
-            hipLaunchKernelGGL(restore_aug_kernel, dim3(grid1d(n * ld)), dim3(256), 0, s, keep.p, n, W);
+            DevBuf<double> keep_own;
+            if (!keep_ws) keep_own.alloc((size_t)(n) * (size_t)(n));
+            double *const keep = keep_ws ? keep_ws : keep_own.p;
+            hipLaunchKernelGGL(copy_block_kernel, dim3(grid1d(n * n)), dim3(256), 0, s, W, n, ld, keep);
+            if (blocked_inverse(W, n, keep, Minv, s)) return;
+            hipLaunchKernelGGL(restore_aug_kernel, dim3(grid1d(n * ld)), dim3(256), 0, s, keep, n, W);
             OMG_HIP(hipGetLastError());
         }
     }

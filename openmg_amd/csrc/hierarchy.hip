@@ -1208,6 +1208,7 @@ void update_fine(Hier<V> *h, const double *vals, int64_t nnz, bool on_device) {
     {
         SetupTimer tm("update: coarse factorisation");
         Lc.A.upload(Ac, Lc.ord.sets, h->stream);
+        h->coarse.retain_workspace = true;                          // (a hierarchy that is updated once is updated again)
         h->coarse.build(Ac, h->stream);
     }
     OMG_HIP(hipStreamSynchronize(h->stream));

@@ -1003,51 +1003,108 @@ struct S27RapArgs {
     unsigned long long *err;         // smallest offending fine row + 1
 };
 
-template <typename V, bool CSR_IN>
-__global__ __launch_bounds__(256) void s27_rap_kernel(const S27RapArgs<V> a) {
+template <typename F, int... Is>
+__device__ __forceinline__ void static_for_impl(F &&f, std::integer_sequence<int, Is...>) { (f(std::integral_constant<int, Is>()), ...); }
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F &&f) { static_for_impl(f, std::make_integer_sequence<int, N>()); }
+typedef double rap_d2 __attribute__((ext_vector_type(2)));
+typedef rap_d2 rap_d2u __attribute__((aligned(8)));
+
+// Threads -> coarse rows: first the rows with 1 <= I <= hx - 2, line by line, then the two ends of every line.  Of the
+// first kind a thread's two fine rows of a (dj, dk) are 54 CONSECUTIVE values of the CSR input wherever their lines are
+// inside the grid in y and z — taken as 27 16-byte loads (8-byte aligned: the rows start anywhere): every cache line of the
+// input is touched by 4 loads of one lane instead of 16 (with 8-byte loads the lanes' lines, 432 bytes apart, fell out of
+// the L1 between two of them: 3.7 ms for the 3.6 GB of the 256^3 operator).  Rows at the grid's faces walk
+// their present entries one by one as before.
+template <typename V, bool CSR_IN, bool WRITE_FINE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void s27_rap_kernel(const S27RapArgs<V> a) {
     const int hx = a.nx / 2, hy = a.ny / 2, hz = a.nz / 2;
-    const int64_t nc = int64_t(hx) * hy * hz;
-    const int64_t crow = int64_t(blockIdx.x) * 256 + threadIdx.x;
-    if (crow >= nc) return;
-    const int I = int(crow % hx), J = int((crow / hx) % hy), K = int(crow / (int64_t(hx) * hy));
+    const int64_t lines = int64_t(hy) * hz, nc = lines * hx;
+    const int64_t idx = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    if (idx >= nc) return;
+    const int hx2 = hx > 2 ? hx - 2 : 0;
+    const int64_t n_mid = lines * hx2;
+    int I;
+    int64_t line;
+    if (idx < n_mid) { line = idx / hx2; I = 1 + int(idx - line * hx2); }
+    else {
+        const int64_t e = idx - n_mid;                 // the lines' ends: 2 per line (hx > 2), else all hx cells of it
+        const int per = hx - hx2;
+        line = e / per;
+        const int o = int(e - line * per);
+        I = (hx2 && o) ? hx - 1 : o;
+    }
+    const int J = int(line % hy), K = int(line / hy);
+    const int64_t crow = line * hx + I;
+    const bool mid_x = I >= 1 && I <= hx - 2;
     double RA[64];
 #pragma unroll
     for (int q = 0; q < 64; ++q) RA[q] = 0.0;
-    const int64_t line = int64_t(K) * hy + J, wave = line / a.fG;
+    const int64_t wave = line / a.fG;
     const int lane = int(line - wave * a.fG) * a.fL + I / a.fRG, rr = I % a.fRG;
-    bool bad = false;
-    int64_t bad_row = 0;
+    unsigned bad = 0;                                  // bit c: a value of child c is wrong (branch-free throughout: a select per value, not a jump)
 #pragma unroll
-    for (int child = 0; child < 8; ++child) {
-        const int di = child & 1, dj = (child >> 1) & 1, dk = child >> 2;
-        const int i = 2 * I + di, j = 2 * J + dj, k = 2 * K + dk;
-        const int64_t row = (int64_t(k) * a.ny + j) * a.nx + i;
-        const bool xm = i > 0, xp = i + 1 < a.nx, ym = j > 0, yp = j + 1 < a.ny, zm = k > 0, zp = k + 1 < a.nz;
-        int64_t p = CSR_IN ? int64_t(a.indptr[row]) : row * 27;
-        V *tile = a.fine_coef ? a.fine_coef + ((size_t(child) * size_t(a.fng) + size_t(wave)) * 27 * 64 + size_t(lane)) * size_t(a.fRG) + size_t(rr) : nullptr;
-#pragma unroll
-        for (int sl = 0; sl < 27; ++sl) {
-            const int dx = sl % 3 - 1, dy = (sl / 3) % 3 - 1, dz = sl / 9 - 1;
-            const bool present = (dx < 0 ? xm : dx > 0 ? xp : true) && (dy < 0 ? ym : dy > 0 ? yp : true) && (dz < 0 ? zm : dz > 0 ? zp : true);
-            double v = 0.0;
-            if (CSR_IN) {
-                if (present) v = a.vals[p++];
-            } else {
-                v = a.vals[p + sl];
-            }
-            if (tile) {
+    for (int pair = 0; pair < 4; ++pair) {
+        const int dj = pair & 1, dk = pair >> 1;
+        const int j = 2 * J + dj, k = 2 * K + dk;
+        const int64_t row0 = (int64_t(k) * a.ny + j) * a.nx + 2 * I;
+        const bool ym = j > 0, yp = j + 1 < a.ny, zm = k > 0, zp = k + 1 < a.nz;
+        V *tp = a.fine_coef + ((size_t(2 * pair) * size_t(a.fng) + size_t(wave)) * 27 * 64 + size_t(lane)) * size_t(a.fRG) + size_t(rr);
+        // one value of child (di, dj, dk), slot sl: into the fine tiles, and w a(k, j) into (R A)(I, j) — cell j at
+        // (dk + dz + 1, dj + dy + 1, di + dx + 1) of the 4 x 4 x 4 cells around the aggregate; the rows k in ascending order =
+        // the children in this loop's order (di fastest)
+        auto consume = [&](auto DI, auto SL, double v) {
+            constexpr int di = decltype(DI)::value, sl = decltype(SL)::value;
+            constexpr int dx = sl % 3 - 1, dy = (sl / 3) % 3 - 1, dz = sl / 9 - 1;
+            if (WRITE_FINE) {
                 const V t = V(v);
                 const double back = double(t);
-                if (!(back - back == 0.0) || (sl == 13 && !(back != 0.0))) { bad = true; bad_row = row; }
-                tile[size_t(sl) * 64 * size_t(a.fRG)] = t;
+                const bool wrong = !(back - back == 0.0) || (sl == 13 && !(back != 0.0));
+                bad |= wrong ? 1u << (2 * pair + di) : 0u;
+                // (the values arrive in the tiles' order — child di, slot by slot —: ONE running address, not 54 of them in registers)
+                *tp = t;
+                tp += sl == 26 ? (ptrdiff_t(a.fng) * 27 - 26) * 64 * ptrdiff_t(a.fRG) : 64 * ptrdiff_t(a.fRG);
+                asm volatile("" : "+v"(tp));
             }
-            // (R A)(I, j): cell j at (dk + dz + 1, dj + dy + 1, di + dx + 1) of the 4 x 4 x 4 cells around the aggregate; the rows
-            // k in ascending order = the children in this loop's order
             const int q = ((dk + dz + 1) * 4 + (dj + dy + 1)) * 4 + (di + dx + 1);
             RA[q] = __dadd_rn(RA[q], __dmul_rn(a.w, v));
+            asm volatile("" : "+v"(RA[q]));            // (the sum is formed HERE: left to itself the compiler keeps a pair's 54 loaded values until all have arrived)
+        };
+        const bool fast = CSR_IN ? (mid_x && ym && yp && zm && zp) : true;
+        if (fast) {
+            const double *const src = a.vals + (CSR_IN ? int64_t(a.indptr[row0]) : row0 * 27);
+            static_for<27>([&](auto M) {
+                constexpr int m = decltype(M)::value;
+                const rap_d2 c = *reinterpret_cast<const rap_d2u *>(src + 2 * m);
+                consume(std::integral_constant<int, (2 * m) / 27>(), std::integral_constant<int, (2 * m) % 27>(), c.x);
+                consume(std::integral_constant<int, (2 * m + 1) / 27>(), std::integral_constant<int, (2 * m + 1) % 27>(), c.y);
+                // (nine loads in flight per lane at a time: left alone the compiler requests all 108 of a thread ahead of
+                // everything — 450 registers, one wave per SIMD)
+                if (m % 9 == 8) asm volatile("" ::: "memory");
+            });
+        } else {
+            static_for<2>([&](auto DI) {
+                constexpr int di = decltype(DI)::value;
+                const int i = 2 * I + di;
+                const bool xm = i > 0, xp = i + 1 < a.nx;
+                const int64_t p0 = int64_t(a.indptr[row0 + di]);
+                int64_t p = p0;
+                static_for<27>([&](auto SL) {
+                    constexpr int sl = decltype(SL)::value;
+                    constexpr int dx = sl % 3 - 1, dy = (sl / 3) % 3 - 1, dz = sl / 9 - 1;
+                    const bool present = (dx < 0 ? xm : dx > 0 ? xp : true) && (dy < 0 ? ym : dy > 0 ? yp : true) && (dz < 0 ? zm : dz > 0 ? zp : true);
+                    const double got = a.vals[present ? p : p0];       // (a slot that is not there: the row's first entry, not used)
+                    p += present ? 1 : 0;
+                    consume(DI, SL, present ? got : 0.0);
+                });
+            });
         }
     }
-    if (bad) atomicMin(a.err, (unsigned long long)(bad_row + 1));
+    if (bad) {
+        const int child = __builtin_ctz(bad);          // (the children's rows ascend with their number)
+        const int64_t row = (int64_t(2 * K + (child >> 2)) * a.ny + 2 * J + ((child >> 1) & 1)) * a.nx + 2 * I + (child & 1);
+        atomicMin(a.err, (unsigned long long)(row + 1));
+    }
     // the coarse row: slot D = (Dz, Dy, Dx) takes the cells of aggregate I + D — along an axis cell 0 for -1, cells 1, 2
     // for 0, cell 3 for +1 —, ascending
     const int c_colour = (I & 1) | ((J & 1) << 1) | ((K & 1) << 2);
@@ -1095,8 +1152,11 @@ void Stencil27Plan<V>::rap_from(const int32_t *indptr, const double *vals, bool 
     OMG_HIP(hipMemsetAsync(d_err.p, 0xFF, sizeof(unsigned long long), s));
     a.err = d_err.p;
     const int64_t nc = g.na;
-    if (indptr) hipLaunchKernelGGL((s27_rap_kernel<V, true>), dim3(unsigned((nc + 255) / 256)), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((s27_rap_kernel<V, false>), dim3(unsigned((nc + 255) / 256)), dim3(256), 0, s, a);
+    const dim3 grid(unsigned((nc + 255) / 256));
+    if (indptr && write_fine) hipLaunchKernelGGL((s27_rap_kernel<V, true, true>), grid, dim3(256), 0, s, a);
+    else if (indptr) hipLaunchKernelGGL((s27_rap_kernel<V, true, false>), grid, dim3(256), 0, s, a);
+    else if (write_fine) hipLaunchKernelGGL((s27_rap_kernel<V, false, true>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((s27_rap_kernel<V, false, false>), grid, dim3(256), 0, s, a);
     OMG_HIP(hipGetLastError());
     unsigned long long err = 0;
     OMG_HIP(hipMemcpyAsync(&err, d_err.p, sizeof(err), hipMemcpyDeviceToHost, s));
