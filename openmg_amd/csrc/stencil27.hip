@@ -1012,16 +1012,28 @@ typedef rap_d2 rap_d2u __attribute__((aligned(8)));
 
 // Threads -> coarse rows: first the rows with 1 <= I <= hx - 2, line by line, then the two ends of every line.  Of the
 // first kind a thread's two fine rows of a (dj, dk) are 54 CONSECUTIVE values of the CSR input wherever their lines are
-// inside the grid in y and z — taken as 27 16-byte loads (8-byte aligned: the rows start anywhere): every cache line of the
-// input is touched by 4 loads of one lane instead of 16 (with 8-byte loads the lanes' lines, 432 bytes apart, fell out of
-// the L1 between two of them: 3.7 ms for the 3.6 GB of the 256^3 operator).  Rows at the grid's faces walk
-// their present entries one by one as before.
+// inside the grid in y and z, and the chunks of consecutive threads follow one another in memory.  A lane that walked its
+// own chunk (432 bytes from its neighbour's) touched a cache line of its own with every load, 64 lines per instruction,
+// and with eight waves on a compute unit the lines were gone from the L1 before the lane's next load came back to them:
+// 16.5 GB from L2 to L1 for 3.7 GB of input (PMC), 3.7 ms with 8-byte loads, 2.9 ms with 16-byte ones.  So the WAVE fetches
+// its threads' chunks together — lane l of load u takes the 16 bytes at position 128 u + 2 l of the wave's concatenated
+// chunks (unit stride wherever the chunks are contiguous: every line is requested once), through 27.6 KB of LDS per
+// wave — and every thread then takes its 54 values out of LDS (27 16-byte reads, the lanes 432 bytes apart:
+// conflict-free) in the order the sums want them: 1.5-1.8 ms.  (Staged 16 / 22 / 32 threads at a time — less LDS, eight
+// waves per compute unit instead of four, the next group's loads in flight — 2.0 / 2.0 / 1.8-2.1 ms: the threads that wait
+// for their group cost more than the occupancy gives; one-wave workgroups 3.5 ms.)  Rows at the grid's faces have fewer
+// entries: their threads walk them one by one as before, by themselves.
+constexpr int RAP_WAVES = 4, RAP_LOADS = 64 * 54 / 128;      // 27 loads of 64 x 16 bytes: the 54 values of 64 threads
 template <typename V, bool CSR_IN, bool WRITE_FINE>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void s27_rap_kernel(const S27RapArgs<V> a) {
+__global__ __launch_bounds__(64 * RAP_WAVES) void s27_rap_kernel(const S27RapArgs<V> a) {
+    __shared__ __attribute__((aligned(16))) double s_stage[RAP_WAVES][RAP_LOADS * 128];
+    __shared__ int64_t s_base[RAP_WAVES][64];
     const int hx = a.nx / 2, hy = a.ny / 2, hz = a.nz / 2;
     const int64_t lines = int64_t(hy) * hz, nc = lines * hx;
-    const int64_t idx = int64_t(blockIdx.x) * 256 + threadIdx.x;
-    if (idx >= nc) return;
+    const int wv = int(threadIdx.x) >> 6, ln = int(threadIdx.x) & 63;
+    int64_t idx = int64_t(blockIdx.x) * (64 * RAP_WAVES) + threadIdx.x;
+    const bool valid = idx < nc;                       // (a thread behind the last row still fetches for its wave)
+    if (!valid) idx = nc - 1;
     const int hx2 = hx > 2 ? hx - 2 : 0;
     const int64_t n_mid = lines * hx2;
     int I;
@@ -1043,9 +1055,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int64_t wave = line / a.fG;
     const int lane = int(line - wave * a.fG) * a.fL + I / a.fRG, rr = I % a.fRG;
     unsigned bad = 0;                                  // bit c: a value of child c is wrong (branch-free throughout: a select per value, not a jump)
-#pragma unroll
-    for (int pair = 0; pair < 4; ++pair) {
-        const int dj = pair & 1, dk = pair >> 1;
+    auto wave_sync = [] {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+    static_for<4>([&](auto PAIR) __attribute__((always_inline)) {
+        constexpr int pair = decltype(PAIR)::value;
+        constexpr int dj = pair & 1, dk = pair >> 1;
         const int j = 2 * J + dj, k = 2 * K + dk;
         const int64_t row0 = (int64_t(k) * a.ny + j) * a.nx + 2 * I;
         const bool ym = j > 0, yp = j + 1 < a.ny, zm = k > 0, zp = k + 1 < a.nz;
@@ -1053,13 +1070,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         // one value of child (di, dj, dk), slot sl: into the fine tiles, and w a(k, j) into (R A)(I, j) — cell j at
         // (dk + dz + 1, dj + dy + 1, di + dx + 1) of the 4 x 4 x 4 cells around the aggregate; the rows k in ascending order =
         // the children in this loop's order (di fastest)
-        auto consume = [&](auto DI, auto SL, double v) {
+        auto consume = [&](auto DI, auto SL, double v) __attribute__((always_inline)) {
             constexpr int di = decltype(DI)::value, sl = decltype(SL)::value;
             constexpr int dx = sl % 3 - 1, dy = (sl / 3) % 3 - 1, dz = sl / 9 - 1;
             if (WRITE_FINE) {
                 const V t = V(v);
-                const double back = double(t);
-                const bool wrong = !(back - back == 0.0) || (sl == 13 && !(back != 0.0));
+                const bool wrong = !__builtin_isfinite(t) || (sl == 13 && t == V(0));
                 bad |= wrong ? 1u << (2 * pair + di) : 0u;
                 // (the values arrive in the tiles' order — child di, slot by slot —: ONE running address, not 54 of them in registers)
                 *tp = t;
@@ -1070,36 +1086,52 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             RA[q] = __dadd_rn(RA[q], __dmul_rn(a.w, v));
             asm volatile("" : "+v"(RA[q]));            // (the sum is formed HERE: left to itself the compiler keeps a pair's 54 loaded values until all have arrived)
         };
-        const bool fast = CSR_IN ? (mid_x && ym && yp && zm && zp) : true;
+        const bool fast = valid && (CSR_IN ? (mid_x && ym && yp && zm && zp) : true);
+        wave_sync();                                   // (the previous pair's readers are done with the bases and the stage)
+        s_base[wv][ln] = fast ? (CSR_IN ? int64_t(a.indptr[row0]) : row0 * 27) : int64_t(-1);
+        wave_sync();
+        // lane ln of load u: the 16 bytes at doubles 128 u + 2 ln of the wave's concatenated chunks = thread (128 u + 2 ln) / 54's;
+        // all 27 requested before the first is put down (one latency, not 27)
+        rap_d2 got[RAP_LOADS];
+#pragma unroll
+        for (int u = 0; u < RAP_LOADS; ++u) {
+            const unsigned f = 128u * unsigned(u) + 2u * unsigned(ln);
+            const unsigned owner = f / 54u, o = f - 54u * owner;
+            const int64_t base = s_base[wv][owner];
+            got[u] = base >= 0 ? *reinterpret_cast<const rap_d2u *>(a.vals + base + o) : rap_d2{0.0, 0.0};
+        }
+#pragma unroll
+        for (int u = 0; u < RAP_LOADS; ++u) *reinterpret_cast<rap_d2 *>(&s_stage[wv][128 * u + 2 * ln]) = got[u];
+        wave_sync();
         if (fast) {
-            const double *const src = a.vals + (CSR_IN ? int64_t(a.indptr[row0]) : row0 * 27);
-            static_for<27>([&](auto M) {
+            const double *const src = &s_stage[wv][54 * ln];
+            static_for<27>([&](auto M) __attribute__((always_inline)) {
                 constexpr int m = decltype(M)::value;
-                const rap_d2 c = *reinterpret_cast<const rap_d2u *>(src + 2 * m);
+                const rap_d2 c = *reinterpret_cast<const rap_d2 *>(src + 2 * m);
                 consume(std::integral_constant<int, (2 * m) / 27>(), std::integral_constant<int, (2 * m) % 27>(), c.x);
                 consume(std::integral_constant<int, (2 * m + 1) / 27>(), std::integral_constant<int, (2 * m + 1) % 27>(), c.y);
-                // (nine loads in flight per lane at a time: left alone the compiler requests all 108 of a thread ahead of
-                // everything — 450 registers, one wave per SIMD)
-                if (m % 9 == 8) asm volatile("" ::: "memory");
+                if (m % 6 == 5) asm volatile("" ::: "memory");     // (six reads in flight at a time: all 27 would take 108 registers)
             });
-        } else {
-            static_for<2>([&](auto DI) {
+        }
+        if (valid && !fast) {
+            static_for<2>([&](auto DI) __attribute__((always_inline)) {
                 constexpr int di = decltype(DI)::value;
                 const int i = 2 * I + di;
                 const bool xm = i > 0, xp = i + 1 < a.nx;
                 const int64_t p0 = int64_t(a.indptr[row0 + di]);
                 int64_t p = p0;
-                static_for<27>([&](auto SL) {
+                static_for<27>([&](auto SL) __attribute__((always_inline)) {
                     constexpr int sl = decltype(SL)::value;
                     constexpr int dx = sl % 3 - 1, dy = (sl / 3) % 3 - 1, dz = sl / 9 - 1;
                     const bool present = (dx < 0 ? xm : dx > 0 ? xp : true) && (dy < 0 ? ym : dy > 0 ? yp : true) && (dz < 0 ? zm : dz > 0 ? zp : true);
-                    const double got = a.vals[present ? p : p0];       // (a slot that is not there: the row's first entry, not used)
+                    const double got1 = a.vals[present ? p : p0];      // (a slot that is not there: the row's first entry, not used)
                     p += present ? 1 : 0;
-                    consume(DI, SL, present ? got : 0.0);
+                    consume(DI, SL, present ? got1 : 0.0);
                 });
             });
         }
-    }
+    });
+    if (!valid) return;
     if (bad) {
         const int child = __builtin_ctz(bad);          // (the children's rows ascend with their number)
         const int64_t row = (int64_t(2 * K + (child >> 2)) * a.ny + 2 * J + ((child >> 1) & 1)) * a.nx + 2 * I + (child & 1);
@@ -1152,11 +1184,12 @@ void Stencil27Plan<V>::rap_from(const int32_t *indptr, const double *vals, bool 
     OMG_HIP(hipMemsetAsync(d_err.p, 0xFF, sizeof(unsigned long long), s));
     a.err = d_err.p;
     const int64_t nc = g.na;
-    const dim3 grid(unsigned((nc + 255) / 256));
-    if (indptr && write_fine) hipLaunchKernelGGL((s27_rap_kernel<V, true, true>), grid, dim3(256), 0, s, a);
-    else if (indptr) hipLaunchKernelGGL((s27_rap_kernel<V, true, false>), grid, dim3(256), 0, s, a);
-    else if (write_fine) hipLaunchKernelGGL((s27_rap_kernel<V, false, true>), grid, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((s27_rap_kernel<V, false, false>), grid, dim3(256), 0, s, a);
+    constexpr int T = 64 * RAP_WAVES;
+    const dim3 grid(unsigned((nc + T - 1) / T));
+    if (indptr && write_fine) hipLaunchKernelGGL((s27_rap_kernel<V, true, true>), grid, dim3(T), 0, s, a);
+    else if (indptr) hipLaunchKernelGGL((s27_rap_kernel<V, true, false>), grid, dim3(T), 0, s, a);
+    else if (write_fine) hipLaunchKernelGGL((s27_rap_kernel<V, false, true>), grid, dim3(T), 0, s, a);
+    else hipLaunchKernelGGL((s27_rap_kernel<V, false, false>), grid, dim3(T), 0, s, a);
     OMG_HIP(hipGetLastError());
     unsigned long long err = 0;
     OMG_HIP(hipMemcpyAsync(&err, d_err.p, sizeof(err), hipMemcpyDeviceToHost, s));
