@@ -17,7 +17,7 @@
 //     make EXTRA="-DOMG_EXPERIMENTS -DS27_SG=9"
 #if !defined(OMG_EXPERIMENTS) && (defined(PLANE_STORE_AUX) || defined(PLANE_LA_BIG) || defined(PLANE_LA) || defined(PLANE_WAVE_SYNC) || \
                                   defined(PLANE_WSYNC_F32) || defined(S27_COEF_AUX) || defined(S27_SG) || defined(S27_WAVES) ||        \
-                                  defined(MARCH_NAP_MAX) || defined(OMG_ROWBLK_NNZ))
+                                  defined(MARCH_NAP_MAX) || defined(OMG_ROWBLK_NNZ) || defined(PLANE_SETPRIO))
 #error "tuning switches are experiments: add -DOMG_EXPERIMENTS"
 #endif
 

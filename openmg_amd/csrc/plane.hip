@@ -757,6 +757,9 @@ __global__ __launch_bounds__(MAXT) void plane_kernel(const PlaneKArgs<V> a) {
         // the images this step reads are complete, and the neighbours have read the ones it overwrites (see `publish` below)
         if (WSYNC) await(s - s0);
         PLANE_STAMP(st_bar)
+#ifdef PLANE_SETPRIO
+        __builtin_amdgcn_s_setprio(PLANE_SETPRIO);      // (experiment, VERDICT r4 item 5 (ii): the wave that computes ahead of the wave that waits)
+#endif
         P2<V> d_jm = zero2, d_jp = zero2;                         // stage D's values from the images, taken before they are handed over
         V d_nb[2] = {V(0), V(0)};
         P2<V> rb[2] = {zero2, zero2};                             // stage C's residuals (black rows of plane s - 1)
@@ -866,6 +869,9 @@ __global__ __launch_bounds__(MAXT) void plane_kernel(const PlaneKArgs<V> a) {
             }
         }
         PLANE_STAMP(st_cmp)
+#ifdef PLANE_SETPRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
         if (WSYNC) publish(s - s0 + 1);
         else __syncthreads();
         PLANE_STAMP(st_bar)
