@@ -94,6 +94,28 @@ def test_direct_solve_against_superlu(monkeypatch, case):
         np.testing.assert_allclose(sub, want, rtol=1e-10, atol=1e-12 * scale)
 
 
+def test_explicit_inverse_without_a_usable_diagonal_block_falls_back_to_pivoting(monkeypatch):
+    """The blocked Gauss-Jordan (csrc/dense.hip) pivots only INSIDE its 64 x 64 diagonal blocks.  An operator whose
+    diagonal blocks are singular (a shift by 100 columns plus small noise off the diagonal blocks) makes it give up —
+    the singular flag or the check against the operator — and the pivoted column-by-column elimination takes over: same
+    answer as SuperLU (openmg/solvers.py:16-26)."""
+    rng = np.random.default_rng(17)
+    for n in (512, 700):
+        P = sp.csr_matrix((np.ones(n), (np.arange(n), (np.arange(n) + 100) % n)), shape=(n, n))
+        noise = sp.random(n, n, density=0.01, random_state=np.random.RandomState(3), format="csr") * 0.05
+        blocks = (np.arange(n)[:, None] // 64) == (np.arange(n)[None, :] // 64)
+        A = sp.csr_matrix((3.0 * P + noise).toarray() * ~blocks)          # every diagonal block: exactly zero
+        A.eliminate_zeros()
+        b = rng.standard_normal(n)
+        want = spla.spsolve(sp.csc_matrix(A), b)
+        monkeypatch.setenv("OMG_COARSE_BLOCKS", "1")
+        got = _hip.direct_solve(A, b)
+        np.testing.assert_allclose(got, want, rtol=1e-9, atol=1e-11 * np.abs(want).max())
+        monkeypatch.setenv("OMG_DENSE_BLOCKED", "0")                   # (read once per process: either way the pivoted path answers)
+        np.testing.assert_allclose(_hip.direct_solve(A, b), want, rtol=1e-9, atol=1e-11 * np.abs(want).max())
+        monkeypatch.delenv("OMG_DENSE_BLOCKED")
+
+
 def test_direct_solve_limits_are_reported():
     """Neither small nor banded: the reference's SuperLU would still solve it; the device solver says
     OMG_ERR_UNSUPPORTED instead of running out of memory (README, Limits)."""

@@ -20,7 +20,7 @@ def run(h, b, x0, pre, post, cycles):
 
 
 @pytest.mark.parametrize("dtype", ["float64", "float32"])
-@pytest.mark.parametrize("shape,grids", [((16, 16, 16), 3), ((32, 32, 32), 4), ((16, 24, 16), 3)])
+@pytest.mark.parametrize("shape,grids", [((16, 16, 16), 3), ((32, 32, 32), 4), ((16, 24, 16), 3), ((8, 16, 8), 3), ((12, 8, 12), 3)])
 def test_updated_hierarchy_is_the_freshly_built_one(shape, grids, dtype):
     A1 = operators.stencil27_variable(shape, seed=1)
     A2 = operators.stencil27_variable(shape, seed=2)
