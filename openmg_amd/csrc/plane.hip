@@ -210,7 +210,7 @@ struct PlaneKArgs {
     unsigned long long *stamps;      // diagnostic build: per workgroup and wave, cycles spent waiting for loads / computing / at the barrier
 #endif
 #ifdef OMG_PLANE_DBG_ON
-    int dbg;                         // ... OMG_PLANE_DBG bits: 1 no x stores, 2 no coarse stores, 4 no loads of x, 8 no loads of b (wrong results, timing only)
+    int dbg;                         // ... OMG_PLANE_DBG bits: 1 no x stores, 2 no coarse stores, 4 no loads of x, 8 no loads of b, 16 no loads of the neighbouring chunks' planes (wrong results, timing only)
 #endif
 };
 
@@ -730,6 +730,11 @@ __global__ __launch_bounds__(MAXT) void plane_kernel(const PlaneKArgs<V> a) {
             unsigned pXB = plane_off(1, s + LA + 1), pR = plane_off(0, s + LA), pBB = plane_off(1, s + LA - 1);
             asm volatile("" : "+s"(pXB), "+s"(pR), "+s"(pBB));
 #ifdef OMG_PLANE_DBG_ON
+            if (a.dbg & 16) {                                     // (timing experiment: the chunk's fill planes — those of its neighbours in z — not loaded)
+                if (s + LA + 1 < z0 || s + LA + 1 >= z1) pXB = unsigned(OOB);
+                if (s + LA < z0 || s + LA >= z1) pR = unsigned(OOB);
+                if (s + LA - 1 < z0 || s + LA - 1 >= z1) pBB = unsigned(OOB);
+            }
             if (a.dbg & 4) { pXB = unsigned(OOB); }               // (timing experiments: no loads of x / of b — wrong results)
             unsigned pR_b = pR;
             if (a.dbg & 4) pR = unsigned(OOB);
