@@ -60,5 +60,9 @@ PYTHONPATH=$root timeout 300 python tools/spmv_place.py 2>&1 | tail -1 > $out/${
 timeout 300 python tools/spmv_probe.py 256 2>&1 > $out/${p}_spmv_probe.txt; OMG_PLANE_SPMV=0 timeout 300 python tools/spmv_probe.py 256 >> $out/${p}_spmv_probe.txt 2>&1
 OMG_SETUP_TIMING=1 timeout 600 python tools/update_probe.py 256 5 2>&1 | grep -E "update|norm" | tail -12 > $out/${p}_update_probe.txt
 timeout 900 python tools/slab27_ab.py 256 3 2>&1 | tail -4 > $out/${p}_slab27_vs_single.txt
-rm -rf $out/trace $out/cyc $out/lex $out/pmc $out/pmc27 $out/peer0 $out/peer1 $out/c4b $out/c4s
+cd /tmp
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/upd -o u -- python3 $root/tools/update_probe.py 256 5 > /dev/null 2>&1
+grep -E "Name|gjb_|s27_rap|s27_build|extract_inverse|copy_block|narrow_kernel|fill_aug|csr_scatter" $out/upd/u_kernel_stats.csv > $out/${p}_update_kernel_stats.csv
+cd "$root"
+rm -rf $out/trace $out/cyc $out/lex $out/pmc $out/pmc27 $out/peer0 $out/peer1 $out/c4b $out/c4s $out/upd
 ls -la $out
