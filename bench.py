@@ -354,6 +354,23 @@ def config4_leg(size, grids, steps, warmup, repeats, sync_of):
     except Exception as ex:                                     # noqa: BLE001 - reported, not fatal for the bench line
         out["update_fine_s"] = None
         out["update_fine_what"] = "failed: %s" % ex
+    # ... and with the values already in HBM (a tensor's storage), the second of two calls + one cycle
+    try:
+        import torch
+        dev_vals = torch.from_numpy(np.ascontiguousarray(A0.data)).cuda()
+        torch.cuda.synchronize()
+        for _ in range(2):
+            t5 = time.perf_counter()
+            h.update_fine((dev_vals.data_ptr(), int(dev_vals.numel())), on_device=True)
+            t6 = time.perf_counter()
+            h.resident_cycle(1, 1, want_norm=True)
+            t7 = time.perf_counter()
+        out["update_fine_device_ms"] = round(1e3 * (t6 - t5), 2)
+        out["update_fine_device_plus_cycle_ms"] = round(1e3 * (t7 - t5), 2)
+        del dev_vals
+    except Exception as ex:                                     # noqa: BLE001
+        out["update_fine_device_ms"] = None
+        out["update_fine_device_what"] = "failed: %s" % ex
     # the whole level-0 kernel table (untimed region)
     h.profile_enable(True)
     for _ in range(min(steps, 10)):
