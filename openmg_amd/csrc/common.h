@@ -61,6 +61,20 @@ struct SetupTimer {
 // paired gathers of rows_union_kernel (x[c], x[c + 1] in one load, c = -1 for a first row whose
 // neighbour does not exist) may start one element in front of it.
 constexpr size_t DEVBUF_SLACK = 64;
+// Device memory whose 2 MiB pieces are separate physical allocations, mapped into ONE virtual range in a shuffled order
+// (HIP's virtual-memory API).  Why anybody would want that: hierarchy.hip place_finest_pool — where the large vectors of
+// the finest level land PHYSICALLY decides between pass speeds 7 % apart, a physically contiguous allocation is the worst
+// case (another 12 %), and what the driver hands out for an ordinary hipMalloc lies somewhere in between, differently in
+// every process.  scattered_alloc returns nullptr where the API is not available (the caller allocates ordinarily).
+struct ScatteredBlock {
+    void *va = nullptr;
+    size_t total = 0;
+    std::vector<hipMemGenericAllocationHandle_t> handles;
+};
+std::vector<ScatteredBlock> &scattered_registry();
+void *scattered_alloc(size_t bytes, size_t chunk_bytes);
+bool scattered_free(void *va);                                  // false: not one of ours
+
 template <typename T>
 struct DevBuf {
     T *p = nullptr;
@@ -89,11 +103,19 @@ struct DevBuf {
     ~DevBuf() { release(); }
     // shift (bytes, a multiple of 64): the vector starts that much further into its allocation — large vectors that a
     // kernel streams side by side are staggered so that they do not walk the memory channels in lockstep
-    void alloc(size_t count, size_t shift_bytes = 0) {
+    // placement: 0 ordinary; 1 physically contiguous (hipDeviceMallocContiguous: an experiment, the slowest there is);
+    // >= 2: scattered pieces of that many MiB (scattered_alloc); either falls back to an ordinary allocation
+    void alloc(size_t count, size_t shift_bytes = 0, int placement = 0) {
         release();
         n = count;
         char *raw = nullptr;
-        OMG_HIP(hipMalloc(reinterpret_cast<void **>(&raw), count * sizeof(T) + 2 * DEVBUF_SLACK + shift_bytes));
+        const size_t total = count * sizeof(T) + 2 * DEVBUF_SLACK + shift_bytes;
+        if (placement == 1 && hipExtMallocWithFlags(reinterpret_cast<void **>(&raw), total, hipDeviceMallocContiguous) != hipSuccess) {
+            (void)hipGetLastError();
+            raw = nullptr;
+        }
+        if (placement >= 2) raw = static_cast<char *>(scattered_alloc(total, size_t(placement) << 20));
+        if (!raw) OMG_HIP(hipMalloc(reinterpret_cast<void **>(&raw), total));
         shift = shift_bytes;
         p = reinterpret_cast<T *>(raw + DEVBUF_SLACK + shift_bytes);
         // OMG_POISON=1 (tests): fresh device memory holds NaN patterns instead of whatever the allocator hands out (zeros
@@ -109,7 +131,10 @@ struct DevBuf {
         if (poison) OMG_HIP(hipDeviceSynchronize());      // (the fill is in place before any stream writes the array)
     }
     void release() {
-        if (p && owned) (void)hipFree(reinterpret_cast<char *>(p) - DEVBUF_SLACK - shift);
+        if (p && owned) {
+            char *const raw = reinterpret_cast<char *>(p) - DEVBUF_SLACK - shift;
+            if (!scattered_free(raw)) (void)hipFree(raw);
+        }
         p = nullptr;
         n = 0;
         shift = 0;
@@ -655,6 +680,8 @@ struct PlanePlan {
     // Large levels: times the candidate tilings on these vectors (contents destroyed) and keeps the fastest
     // (OMG_PLANE_TUNE=0 / OMG_PLANE_TILE: no timing).
     void tune(V *x, V *tmp, const V *b, const Coarse &c, hipStream_t s, bool finest = true);
+    // microseconds per down + up pass with the chosen tiling on these vectors (one untimed pair, then `pairs` timed ones)
+    float time_pair(V *x, V *tmp, const V *b, const Coarse &c, hipStream_t s, bool finest, int pairs);
     // sweep = false: the pass without its relaxation (a cycle with preIterations = 0 / postIterations = 0): down then
     // leaves x_new untouched (the iterate stays in x_old), up writes x_new = x_old + R^T e
     // part: a pass as TWO launches (slabs with RCCL exchanges, dist.hip): PART_EDGE = the slab's first and last PLANE_EDGE

@@ -9,6 +9,8 @@
 #include <cmath>
 #include <cstring>
 #include <memory>
+#include <array>
+#include <map>
 #include <mutex>
 #include <thread>
 #include <type_traits>
@@ -16,6 +18,80 @@
 #include "common.h"
 
 namespace omg {
+
+// ---- scattered device memory (common.h) -------------------------------------------------------------------------------
+std::vector<ScatteredBlock> &scattered_registry() {
+    static std::vector<ScatteredBlock> r;
+    return r;
+}
+static std::mutex &scattered_mutex() {
+    static std::mutex m;
+    return m;
+}
+void *scattered_alloc(size_t bytes, size_t chunk_bytes) {
+    int device = 0;
+    if (hipGetDevice(&device) != hipSuccess) return nullptr;
+    hipMemAllocationProp prop;
+    std::memset(&prop, 0, sizeof(prop));
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id = device;
+    size_t gran = 0;
+    if (hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended) != hipSuccess || gran == 0) { (void)hipGetLastError(); return nullptr; }
+    const size_t chunk = (std::max(chunk_bytes, gran) + gran - 1) / gran * gran;
+    const size_t n = (bytes + chunk - 1) / chunk;
+    ScatteredBlock blk;
+    blk.total = n * chunk;
+    auto undo = [&](size_t mapped) {
+        if (mapped) (void)hipMemUnmap(blk.va, mapped * chunk);
+        for (auto h : blk.handles) (void)hipMemRelease(h);
+        if (blk.va) (void)hipMemAddressFree(blk.va, blk.total);
+        (void)hipGetLastError();
+    };
+    if (hipMemAddressReserve(&blk.va, blk.total, chunk, nullptr, 0) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    blk.handles.reserve(n);
+    for (size_t i = 0; i < n; ++i) {
+        hipMemGenericAllocationHandle_t h;
+        if (hipMemCreate(&h, chunk, &prop, 0) != hipSuccess) { undo(0); return nullptr; }
+        blk.handles.push_back(h);
+    }
+    // piece i of the virtual range <- the perm(i)-th allocation: a fixed pseudo-random permutation (Fisher-Yates over an LCG)
+    std::vector<size_t> perm(n);
+    for (size_t i = 0; i < n; ++i) perm[i] = i;
+    uint64_t state = 0x9E3779B97F4A7C15ull;
+    for (size_t i = n; i > 1; --i) {
+        state = state * 6364136223846793005ull + 1442695040888963407ull;
+        std::swap(perm[i - 1], perm[size_t((state >> 33) % i)]);
+    }
+    for (size_t i = 0; i < n; ++i)
+        if (hipMemMap(static_cast<char *>(blk.va) + i * chunk, chunk, 0, blk.handles[perm[i]], 0) != hipSuccess) { undo(i); return nullptr; }
+    hipMemAccessDesc acc;
+    std::memset(&acc, 0, sizeof(acc));
+    acc.location.type = hipMemLocationTypeDevice;
+    acc.location.id = device;
+    acc.flags = hipMemAccessFlagsProtReadWrite;
+    if (hipMemSetAccess(blk.va, blk.total, &acc, 1) != hipSuccess) { undo(n); return nullptr; }
+    void *const va = blk.va;
+    std::lock_guard<std::mutex> lock(scattered_mutex());
+    scattered_registry().push_back(std::move(blk));
+    return va;
+}
+bool scattered_free(void *va) {
+    ScatteredBlock blk;
+    {
+        std::lock_guard<std::mutex> lock(scattered_mutex());
+        auto &r = scattered_registry();
+        size_t i = 0;
+        while (i < r.size() && r[i].va != va) ++i;
+        if (i == r.size()) return false;
+        blk = std::move(r[i]);
+        r.erase(r.begin() + long(i));
+    }
+    (void)hipMemUnmap(blk.va, blk.total);
+    for (auto h : blk.handles) (void)hipMemRelease(h);
+    (void)hipMemAddressFree(blk.va, blk.total);
+    return true;
+}
 
 static thread_local std::string g_last_error;
 void set_last_error(const std::string &m) { g_last_error = m; }
@@ -73,6 +149,7 @@ struct Level {
     // configs[4]): the cycle over this level runs the octant-layout kernels of stencil27.hip (common.h Stencil27Plan)
     std::unique_ptr<Stencil27Plan<V>> s27;
     DevBuf<char> pool;               // OMG_VEC_POOL=1: x, tmp, b of a large plane level as three views into ONE allocation
+    size_t pool_span = 0, pool_off1 = 0, pool_off2 = 0;      // ... its layout (pool_views)
     // where the matrix-free SpMV of a plane level leaves its product: an allocation of its OWN, made on first use.  Written
     // into the level's scratch vector — which shares an allocation with x, two spans further on — the same launch takes
     // 57-62 us at 256^3 where it takes 45 into any separate allocation (profiles/r05_spmv_placement.txt: one process, the
@@ -408,17 +485,40 @@ enum NormState { NORM_NONE = 0, NORM_LAST_SET = 1, NORM_PLANE = 2, NORM_S27 = 3 
 // the spread between processes shrinks from 1.3 % to 0.7 % — where three separate allocations land relative to each
 // other is what made a process "fast" or "slow".  OMG_VEC_POOL=0: three allocations.
 template <typename V>
+void pool_views(Level<V> &L, char *base, size_t span, size_t off1, size_t off2);
+// How the k-th candidate for the pool of a level whose placement is timed (place_finest_pool) is allocated: 0 ordinary
+// hipMalloc, n >= 2: scattered pieces of n MiB (common.h DevBuf::alloc; 1: physically contiguous — an experiment).
+// OMG_POOL_PLACE=n: every candidate that way.
+inline int pool_placement(int k) {
+    static const int forced = [] { const char *e = getenv("OMG_POOL_PLACE"); return e && e[0] ? atoi(e) : -1; }();
+    if (forced >= 0) return forced;
+    static const int kinds[] = {0, 32, 0, 2, 32, 0, 2, 8};
+    return kinds[size_t(k) % (sizeof(kinds) / sizeof(kinds[0]))];
+}
+struct PoolLayout { size_t span, off1, off2; };
+template <typename V>
+PoolLayout pool_layout(int64_t n) {
+    auto env = [](const char *name, size_t dflt) { const char *e = getenv(name); return e && e[0] ? (size_t(atoll(e)) < 64 ? size_t(atoll(e)) : size_t(atoll(e)) / 64 * 64) : dflt; };
+    const size_t off1 = env("OMG_POOL_OFF1", vector_stagger(1)), off2 = env("OMG_POOL_OFF2", vector_stagger(2)), pad = env("OMG_POOL_PAD", 0);
+    const size_t MB2 = size_t(2) << 20, bytes = size_t(n) * sizeof(V);
+    return {(bytes + 2 * DEVBUF_SLACK + std::max(off1, off2) + MB2 - 1) / MB2 * MB2 + pad, off1, off2};
+}
+constexpr int64_t POOL_TRIAL_MIN = int64_t(1) << 23;       // levels from 8 M unknowns: the placement of their pool is timed (place_finest_pool)
+template <typename V>
 bool pooled_vectors(Level<V> &L) {
     static const bool on = [] { const char *e = getenv("OMG_VEC_POOL"); return !(e && e[0] == '0'); }();
     if (!on || !(L.plane || L.s27) || L.n < (int64_t(1) << 20)) return false;
     if (L.pool.p || L.x.p) return true;
-    auto env = [](const char *name, size_t dflt) { const char *e = getenv(name); return e && e[0] ? (size_t(atoll(e)) < 64 ? size_t(atoll(e)) : size_t(atoll(e)) / 64 * 64) : dflt; };
-    const size_t off1 = env("OMG_POOL_OFF1", vector_stagger(1)), off2 = env("OMG_POOL_OFF2", vector_stagger(2)), pad = env("OMG_POOL_PAD", 0);
-    const size_t MB2 = size_t(2) << 20, bytes = size_t(L.n) * sizeof(V);
-    const size_t span = (bytes + 2 * DEVBUF_SLACK + std::max(off1, off2) + MB2 - 1) / MB2 * MB2 + pad;
+    const PoolLayout q = pool_layout<V>(L.n);
     // (every pooled level of a hierarchy out of ONE allocation — OMG_POOL_ARENA, round 4 — measured no different: removed)
-    L.pool.alloc(3 * span);
-    char *const base = L.pool.p;
+    L.pool.alloc(3 * q.span);
+    pool_views(L, L.pool.p, q.span, q.off1, q.off2);
+    return true;
+}
+
+template <typename V>
+void pool_views(Level<V> &L, char *base, size_t span, size_t off1, size_t off2) {
+    auto env = [](const char *name, size_t dflt) { const char *e = getenv(name); return e && e[0] ? size_t(atoll(e)) : dflt; };
     // order: x, b, x's twin (OMG_POOL_ORDER=0: x, twin, b).  With b in the middle four of four processes ran 0.260 ms per
     // cycle where the other order gave 0.266-0.274 on the same box; on a second box both orders fell into two populations
     // (0.260 / 0.273) from process to process: where the allocation lands physically still matters, and is not ours to choose
@@ -430,7 +530,72 @@ bool pooled_vectors(Level<V> &L) {
     else
     L.tmp.borrow(reinterpret_cast<V *>(base + (b_mid ? 2 : 1) * span + DEVBUF_SLACK + off1), size_t(L.n));
     L.b.borrow(reinterpret_cast<V *>(base + (b_mid ? 1 : 2) * span + DEVBUF_SLACK + off2), size_t(L.n));
-    return true;
+    L.pool_span = span; L.pool_off1 = off1; L.pool_off2 = off2;
+}
+
+// WHERE the finest level's pool lands in HBM decides the speed of its passes: at 256^3 fp64 a down + up pass takes 174-179 us
+// on some allocations and 187-197 us on others — the "two populations of processes" of rounds 3 and 4, in truth a
+// property of each allocation (tools/population_probe.py: three hierarchies made in turn by one process: slow, fast, fast;
+// neither the virtual addresses nor the clocks say anything; re-placing the level's other arrays changes nothing; a
+// physically CONTIGUOUS pool is the slowest of all, 210-220 us; pieces of 2 / 8 / 32 MiB mapped in a shuffled order are
+// fast on some boxes every time and on others no better than hipMalloc: profiles/r05_pool_placement.txt).  Nothing a
+// process can ask for decides it, so the placement is MEASURED like the tiling: candidates are allocated one after another
+// (ordinary and scattered ones in turn, all held until the end so that each is different memory), the level's own down +
+// up pass is timed on each, and the search ends when a candidate is 4.5 % faster than the slowest seen — both kinds have
+// shown themselves — or as fast as the best this process has ever had for the shape, or after OMG_POOL_TRIALS (6).
+template <typename V>
+void place_finest_pool(Hier<V> *h) {
+    static const int trials = [] { const char *e = getenv("OMG_POOL_TRIALS"); return e && e[0] ? atoi(e) : 6; }();
+    if (trials < 2 || h->lv.size() < 2) return;
+    Level<V> &L = h->lv[0], &C = h->lv[1];
+    if (!L.plane || !L.pool.p || !L.pool_span || L.n < POOL_TRIAL_MIN || L.tmp.owned) return;
+    SetupTimer tm("placement of the finest level's vectors (timed)");
+    typename PlanePlan<V>::Coarse c;
+    c.map = L.r_out.p;
+    c.b = C.b.p;
+    c.e = C.xp;
+    auto timed = [&]() -> float {
+        L.x.zero(h->stream); L.tmp.zero(h->stream); L.b.zero(h->stream); C.x.zero(h->stream);
+        return L.plane->time_pair(L.x.p, L.tmp.p, L.b.p, c, h->stream, true, 4);
+    };
+    static std::mutex mu;
+    static std::map<std::array<int64_t, 2>, float> best_ever;       // (unknowns, bytes per value) -> us
+    const std::array<int64_t, 2> key = {L.n, int64_t(sizeof(V))};
+    float known = 0.0f;
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        const auto it = best_ever.find(key);
+        if (it != best_ever.end()) known = it->second;
+    }
+    // (the candidates are held together: no more than 8 GB of them — two for a 512^3 level)
+    const int max_trials = int(std::min<size_t>(size_t(trials), std::max<size_t>(2, (size_t(8) << 30) / (3 * L.pool_span))));
+    float best = timed(), worst = best;
+    std::vector<DevBuf<char>> held;                       // (the losers: kept until the end, so that a candidate is not the memory just given back)
+    const bool debug = SetupTimer::on();
+    if (debug) fprintf(stderr, "[omg setup] finest level's pool, candidate 0 (hipMalloc): %.1f us per down + up\n", best);
+    for (int k = 1; k < max_trials; ++k) {
+        if ((k >= 2 && best <= 0.955f * worst) || (known > 0.0f && best <= 1.02f * known)) break;
+        DevBuf<char> alt;
+        alt.alloc(3 * L.pool_span, 0, pool_placement(k));
+        std::swap(L.pool, alt);                           // L.pool: the candidate, alt: the best so far
+        pool_views(L, L.pool.p, L.pool_span, L.pool_off1, L.pool_off2);
+        const float t = timed();
+        if (debug) fprintf(stderr, "[omg setup] finest level's pool, candidate %d (placement %d): %.1f us per down + up\n", k, pool_placement(k), t);
+        worst = std::max(worst, t);
+        if (t < best) best = t;
+        else std::swap(L.pool, alt);                      // the candidate lost
+        held.push_back(std::move(alt));
+    }
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        float &e = best_ever[key];
+        if (e == 0.0f || best < e) e = best;
+    }
+    pool_views(L, L.pool.p, L.pool_span, L.pool_off1, L.pool_off2);
+    L.x.zero(h->stream); L.tmp.zero(h->stream); L.b.zero(h->stream); C.x.zero(h->stream);
+    L.xp = L.x.p;
+    L.tp = L.tmp.p;
+    OMG_HIP(hipStreamSynchronize(h->stream));
 }
 
 template <typename V>
@@ -983,6 +1148,7 @@ std::unique_ptr<Hier<V>> create(int n_levels, const omg_csr *A, const omg_csr *R
         L.plane->tune(L.xp, L.tp, L.b.p, c, h->stream, l == 0);
         OMG_HIP(hipStreamSynchronize(h->stream));
     }
+    place_finest_pool(h.get());
     { SetupTimer tm("wait for the coarse factorisation"); inverter.join(); }
     if (inv_code != OMG_OK) throw Error(inv_code, inv_msg);
     OMG_HIP(hipStreamSynchronize(h->stream));
@@ -1142,6 +1308,7 @@ std::unique_ptr<Hier<V>> create_from_fine(const omg_csr &A0, int dim, const int6
         L.plane->tune(L.xp, L.tp, L.b.p, c, h->stream, l == 0);
         OMG_HIP(hipStreamSynchronize(h->stream));
     }
+    place_finest_pool(h.get());
     { SetupTimer tm("wait for the coarse factorisation"); inverter.join(); }
     if (inv_code != OMG_OK) throw Error(inv_code, inv_msg);
     OMG_HIP(hipStreamSynchronize(h->stream));

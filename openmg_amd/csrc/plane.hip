@@ -1990,6 +1990,27 @@ void PlanePlan<V>::tune(V *x, V *tmp, const V *b, const Coarse &c, hipStream_t s
 }
 
 template <typename V>
+float PlanePlan<V>::time_pair(V *x, V *tmp, const V *b, const Coarse &c, hipStream_t s, bool finest, int pairs) {
+    hipEvent_t e0, e1;
+    OMG_HIP(hipEventCreate(&e0));
+    OMG_HIP(hipEventCreate(&e1));
+    down(x, tmp, b, !finest, c, s);
+    up(tmp, x, b, c, finest ? partials.p : nullptr, s);
+    OMG_HIP(hipEventRecord(e0, s));
+    for (int r = 0; r < pairs; ++r) {
+        down(x, tmp, b, !finest, c, s);
+        up(tmp, x, b, c, finest ? partials.p : nullptr, s);
+    }
+    OMG_HIP(hipEventRecord(e1, s));
+    OMG_HIP(hipEventSynchronize(e1));
+    float ms = 0.0f;
+    OMG_HIP(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return 1e3f * ms / float(std::max(pairs, 1));
+}
+
+template <typename V>
 HostCsr PlanePlan<V>::operator_csr() const {
     const int64_t nx = g.nx, ny = g.ny, nz = g.nz, n = nx * ny * nz, sj = nx, sk = nx * ny;
     HostCsr A;

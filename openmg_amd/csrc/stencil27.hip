@@ -789,7 +789,9 @@ bool Stencil27Plan<V>::tile(const DevCsrPlain &A, const S27Geom &q, int kz_lo, i
     const int64_t n = int64_t(q.nx) * q.ny * q.nz;
     DevBuf<unsigned long long> d_err(1);
     OMG_HIP(hipMemsetAsync(d_err.p, 0xFF, sizeof(unsigned long long), s));
-    coef.alloc(size_t(8) * size_t(q.ng) * 27 * 64 * size_t(q.rg));
+    // (OMG_S27_PLACE: how a large level's tiles are placed — common.h DevBuf::alloc; experiment, default ordinary)
+    static const int place = [] { const char *e = getenv("OMG_S27_PLACE"); return e && e[0] ? atoi(e) : 0; }();
+    coef.alloc(size_t(8) * size_t(q.ng) * 27 * 64 * size_t(q.rg), 0, n >= (int64_t(1) << 23) ? place : 0);
     coef.zero(s);
     hipLaunchKernelGGL(s27_build_kernel<V>, dim3(unsigned((n + 255) / 256)), dim3(256), 0, s, A.indptr.p, A.indices.p, A.data.p, q.nx, q.ny, q.nz,
                        kz_lo, kz_hi, kb_lo, kb_hi, q.L, q.G, q.rg, q.ng, coef.p, d_err.p);
