@@ -749,12 +749,13 @@ def main():
                    "smoother": args.smoother, "hipgraph": bool(args.graph),
                    "plane_levels": [bool(f) for f in meta.get("plane_levels", [])],
                    "repeats": repeats, "ms_per_step_all": [round(1e3 * t / args.steps, 4) for t in times],
-                   # the two populations of processes (~5 % apart, the same for everything a process
-                   # creates): which one this run landed in, by its steady regions (the first regions of any process are ~3 % slower)
+                   # the two kinds of allocation of the finest level's vectors (the level's passes ~7 % apart;
+                   # hierarchy.hip place_finest_pool searches for the fast kind at setup): which one this hierarchy ended up with,
+                   # by its steady regions (the first regions of any process are ~3 % slower)
                    "process_population": {"steady_ms_per_step": round(1e3 * min(times[len(times) // 2:]) / args.steps, 4),
                                           "first_region_ms_per_step": round(1e3 * times[0] / args.steps, 4),
                                           "which": ("fast" if 1e3 * min(times[len(times) // 2:]) / args.steps <= 0.272 else "slow") if (args.size == 256 and w == 8 and plane) else None,
-                                          "rule": "256^3 fp64 headline: steady cycle <= 0.272 ms = the fast population (0.258-0.270), above = the slow one (0.273-0.290)"},
+                                          "rule": "256^3 fp64 headline: steady cycle <= 0.272 ms = the finest level's vectors are the fast kind of allocation (0.258-0.270), above = the slow kind (0.273-0.290); profiles/r05_pool_placement.txt"},
                    "final_residual_norm": norm,
                    "norms": "every cycle of a timed region computes its residual norm (all K are returned at the region's end): "
                             + ("the up pass of the fine grid leaves the squared residuals of its rows as one partial per workgroup, "
