@@ -567,8 +567,8 @@ void place_finest_pool(Hier<V> *h) {
         const auto it = best_ever.find(key);
         if (it != best_ever.end()) known = it->second;
     }
-    // (the candidates are held together: no more than 8 GB of them — two for a 512^3 level)
-    const int max_trials = int(std::min<size_t>(size_t(trials), std::max<size_t>(2, (size_t(8) << 30) / (3 * L.pool_span))));
+    // (the candidates are held together: no more than 16 GB of them — five for a 512^3 level)
+    const int max_trials = int(std::min<size_t>(size_t(trials), std::max<size_t>(2, (size_t(16) << 30) / (3 * L.pool_span))));
     float best = timed(), worst = best;
     std::vector<DevBuf<char>> held;                       // (the losers: kept until the end, so that a candidate is not the memory just given back)
     const bool debug = SetupTimer::on();
@@ -650,6 +650,47 @@ void place_s27_tiles(Hier<V> *h) {
     }
     L.x.zero(h->stream); L.tmp.zero(h->stream); L.b.zero(h->stream);
     OMG_HIP(hipStreamSynchronize(h->stream));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+}
+
+// The matrix-free SpMV's destination (an allocation of its own: DESIGN.md section 4) is placed like the level's pool — by
+// timing: 45 us per launch on some allocations, 57-69 on others at 256^3 fp64.
+template <typename V>
+void ensure_spmv_y(Hier<V> *h, Level<V> &L) {
+    if (L.spmv_y.p) return;
+    L.spmv_y.alloc(size_t(L.n));
+    static const int trials = [] { const char *e = getenv("OMG_SPMV_TRIALS"); return e && e[0] ? atoi(e) : 5; }();
+    if (trials < 2 || !L.plane || L.n < POOL_TRIAL_MIN) return;
+    hipEvent_t e0, e1;
+    OMG_HIP(hipEventCreate(&e0));
+    OMG_HIP(hipEventCreate(&e1));
+    auto timed = [&]() -> float {
+        L.plane->spmv(L.xp, L.spmv_y.p, h->stream);
+        OMG_HIP(hipEventRecord(e0, h->stream));
+        for (int r = 0; r < 4; ++r) L.plane->spmv(L.xp, L.spmv_y.p, h->stream);
+        OMG_HIP(hipEventRecord(e1, h->stream));
+        OMG_HIP(hipEventSynchronize(e1));
+        float ms = 0.0f;
+        OMG_HIP(hipEventElapsedTime(&ms, e0, e1));
+        return 1e3f * ms / 4.0f;
+    };
+    float best = timed(), worst = best;
+    const bool debug = SetupTimer::on();
+    if (debug) fprintf(stderr, "[omg setup] SpMV destination, candidate 0: %.1f us per launch\n", best);
+    std::vector<DevBuf<V>> held;
+    for (int k = 1; k < trials; ++k) {
+        if (k >= 2 && best <= 0.955f * worst) break;
+        DevBuf<V> alt;
+        alt.alloc(size_t(L.n), 0, pool_placement(k));
+        std::swap(L.spmv_y, alt);
+        const float t = timed();
+        if (debug) fprintf(stderr, "[omg setup] SpMV destination, candidate %d (placement %d): %.1f us per launch\n", k, pool_placement(k), t);
+        worst = std::max(worst, t);
+        if (t < best) best = t;
+        else std::swap(L.spmv_y, alt);
+        held.push_back(std::move(alt));
+    }
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
 }
@@ -1947,7 +1988,7 @@ int omg_resident_spmv_time(omg_hierarchy *h, int reps, double *avg_ms) {
             a.x = L.xp; a.y = mf ? L.tp : L.r.p;
             // (OMG_SPMV_Y=b / own, read at every call — placement experiments: the product written over the right-hand side, or
             // into an allocation of its own, instead of the level's scratch vector)
-            if (mf && !L.spmv_y.p) L.spmv_y.alloc(size_t(L.n));
+            if (mf) ensure_spmv_y(hh, L);
             V *ymf = L.spmv_y.p;
             DevBuf<V> own_y;
             if (const char *e = getenv("OMG_SPMV_Y")) {
@@ -2112,7 +2153,7 @@ int omg_level_spmv(omg_hierarchy *h, int level, const double *x, double *y) {
             load_vec(hh, level, x, L.xp);
             const bool mf = use_plane(hh, L, 1, 1) && !L.plane->g.jacobi;
             if (mf) {
-                if (!L.spmv_y.p) L.spmv_y.alloc(size_t(L.n));
+                ensure_spmv_y(hh, L);
                 L.plane->spmv(L.xp, L.spmv_y.p, hh->stream);
                 fetch_vec<V>(hh, level, L.spmv_y.p, y);
             } else {
