@@ -1556,6 +1556,39 @@ std::unique_ptr<PlaneDist> pd_create(int rank, int n_ranks, int nx, int ny, int 
         c.b = last ? d->cb.p : d->lv[1].b.p;
         c.e = last ? d->ce.p : d->lv[1].xp;
         L.plan.tune(L.xp, L.tp, L.b.p, c, d->stream);
+        // ... and WHERE its three vectors lie: the passes run 7 % apart on different allocations of the same vectors
+        // (hierarchy.hip place_finest_pool, profiles/r05_pool_placement.txt), and with one process per GPU the slowest rank
+        // sets the cycle.  Candidates (hipMalloc only: a neighbour may map these vectors over hipIpc) until one is 4.5 %
+        // faster than the slowest seen or OMG_PDIST_TRIALS (5) are tried, no more than 16 GB held.
+        static const int trials = [] { const char *e = getenv("OMG_PDIST_TRIALS"); return e && e[0] ? atoi(e) : 5; }();
+        const size_t triple = 3 * size_t(L.n_ext) * sizeof(double);
+        const int max_trials = int(std::min<size_t>(size_t(std::max(trials, 1)), std::max<size_t>(2, (size_t(16) << 30) / std::max<size_t>(triple, 1))));
+        if (!L.pool.p && trials >= 2 && L.n_ext >= (int64_t(1) << 23)) {
+            auto timed = [&]() -> float {
+                L.x.zero(d->stream); L.tmp.zero(d->stream); L.b.zero(d->stream);
+                if (last) d->cb.zero(d->stream); else d->lv[1].b.zero(d->stream);
+                return L.plan.time_pair(L.x.p, L.tmp.p, L.b.p, c, d->stream, true, 4);
+            };
+            const bool debug = SetupTimer::on();
+            float best = timed(), worst = best;
+            if (debug) fprintf(stderr, "[omg setup] rank %d: slab vectors, candidate 0: %.1f us per down + up\n", rank, best);
+            struct Triple { DevBuf<double> x, tmp, b; };
+            std::vector<Triple> held;
+            for (int k = 1; k < max_trials; ++k) {
+                if (k >= 2 && best <= 0.955f * worst) break;
+                Triple t;
+                t.x.alloc(size_t(L.n_ext)); t.tmp.alloc(size_t(L.n_ext), vector_stagger(1)); t.b.alloc(size_t(L.n_ext), vector_stagger(2));
+                std::swap(L.x, t.x); std::swap(L.tmp, t.tmp); std::swap(L.b, t.b);
+                const float us = timed();
+                if (debug) fprintf(stderr, "[omg setup] rank %d: slab vectors, candidate %d: %.1f us per down + up\n", rank, k, us);
+                worst = std::max(worst, us);
+                if (us < best) best = us;
+                else { std::swap(L.x, t.x); std::swap(L.tmp, t.tmp); std::swap(L.b, t.b); }
+                held.push_back(std::move(t));
+            }
+            L.b.zero(d->stream);
+            L.xp = L.x.p; L.tp = L.tmp.p;
+        }
         L.x.zero(d->stream); L.tmp.zero(d->stream);
         if (last) d->cb.zero(d->stream); else d->lv[1].b.zero(d->stream);
         OMG_HIP(hipStreamSynchronize(d->stream));
