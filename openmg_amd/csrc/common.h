@@ -149,6 +149,16 @@ struct DevBuf {
     void zero(hipStream_t s) { if (n) OMG_HIP(hipMemsetAsync(p, 0, n * sizeof(T), s)); }
 };
 
+// How the k-th candidate of a placement search (hierarchy.hip place_finest_pool, Stencil27Plan::place_tiles, ...) is
+// allocated: 0 ordinary hipMalloc, n >= 2: scattered pieces of n MiB (DevBuf::alloc; 1: physically contiguous — an
+// experiment).  OMG_POOL_PLACE=n: every candidate that way.
+inline int pool_placement(int k) {
+    const char *e = getenv("OMG_POOL_PLACE");
+    if (e && e[0]) return atoi(e);
+    static const int kinds[] = {0, 32, 0, 2, 32, 0, 2, 8};
+    return kinds[size_t(k) % (sizeof(kinds) / sizeof(kinds[0]))];
+}
+
 // The vectors a plane pass streams side by side (x_old, x_new, b: plane.hip) start k * 256 bytes into their allocations
 // (hipMalloc returns them all at the same offset of a 2 MiB page, so at every index they would otherwise sit on the
 // same memory channel): measured at 256^3 over five processes each, down pass 103.4-104.1 us in four of five with
@@ -784,6 +794,8 @@ struct Stencil27Plan {
     // the squares of b - A x_old.  last: leave the residuals of colours 6, 7 (res67) and, with norm_new (nullable,
     // same shape; only segment 3 is written), their squares.
     void sweep(const V *x_old, V *x_new, const V *b, bool x_zero, double *norm_old, bool last, double *norm_new, hipStream_t s);
+    // a large level's tiles placed by timing (see the definition); x, tmp, b: the level's vectors, overwritten
+    void place_tiles(V *x, V *tmp, V *b, hipStream_t s);
     // coarse right-hand side = R (b - A x) (cmap: coarse natural index -> slot in the coarse ordering, null: identity).
     // use67: the residuals of colours 6, 7 are taken from res67.
     void residual_restrict(const V *x, const V *b, bool use67, const int32_t *cmap, V *bc, hipStream_t s);

@@ -486,15 +486,6 @@ enum NormState { NORM_NONE = 0, NORM_LAST_SET = 1, NORM_PLANE = 2, NORM_S27 = 3 
 // other is what made a process "fast" or "slow".  OMG_VEC_POOL=0: three allocations.
 template <typename V>
 void pool_views(Level<V> &L, char *base, size_t span, size_t off1, size_t off2);
-// How the k-th candidate for the pool of a level whose placement is timed (place_finest_pool) is allocated: 0 ordinary
-// hipMalloc, n >= 2: scattered pieces of n MiB (common.h DevBuf::alloc; 1: physically contiguous — an experiment).
-// OMG_POOL_PLACE=n: every candidate that way.
-inline int pool_placement(int k) {
-    static const int forced = [] { const char *e = getenv("OMG_POOL_PLACE"); return e && e[0] ? atoi(e) : -1; }();
-    if (forced >= 0) return forced;
-    static const int kinds[] = {0, 32, 0, 2, 32, 0, 2, 8};
-    return kinds[size_t(k) % (sizeof(kinds) / sizeof(kinds[0]))];
-}
 struct PoolLayout { size_t span, off1, off2; };
 template <typename V>
 PoolLayout pool_layout(int64_t n) {
@@ -545,7 +536,10 @@ void pool_views(Level<V> &L, char *base, size_t span, size_t off1, size_t off2) 
 // shown themselves — or as fast as the best this process has ever had for the shape, or after OMG_POOL_TRIALS (6).
 template <typename V>
 void place_finest_pool(Hier<V> *h) {
-    static const int trials = [] { const char *e = getenv("OMG_POOL_TRIALS"); return e && e[0] ? atoi(e) : 6; }();
+    // (read at every call, like OMG_PLACE_KEEP_LAST=1 — tests: the newest candidate is kept whatever its time, no early stop)
+    const char *env_trials = getenv("OMG_POOL_TRIALS");
+    const int trials = env_trials && env_trials[0] ? atoi(env_trials) : 6;
+    const bool keep_last = getenv("OMG_PLACE_KEEP_LAST") != nullptr;
     if (trials < 2 || h->lv.size() < 2) return;
     Level<V> &L = h->lv[0], &C = h->lv[1];
     if (!L.plane || !L.pool.p || !L.pool_span || L.n < POOL_TRIAL_MIN || L.tmp.owned) return;
@@ -574,7 +568,7 @@ void place_finest_pool(Hier<V> *h) {
     const bool debug = SetupTimer::on();
     if (debug) fprintf(stderr, "[omg setup] finest level's pool, candidate 0 (hipMalloc): %.1f us per down + up\n", best);
     for (int k = 1; k < max_trials; ++k) {
-        if ((k >= 2 && best <= 0.955f * worst) || (known > 0.0f && best <= 1.02f * known)) break;
+        if (!keep_last && ((k >= 2 && best <= 0.955f * worst) || (known > 0.0f && best <= 1.02f * known))) break;
         DevBuf<char> alt;
         alt.alloc(3 * L.pool_span, 0, pool_placement(k));
         std::swap(L.pool, alt);                           // L.pool: the candidate, alt: the best so far
@@ -582,7 +576,7 @@ void place_finest_pool(Hier<V> *h) {
         const float t = timed();
         if (debug) fprintf(stderr, "[omg setup] finest level's pool, candidate %d (placement %d): %.1f us per down + up\n", k, pool_placement(k), t);
         worst = std::max(worst, t);
-        if (t < best) best = t;
+        if (t < best || keep_last) best = std::min(best, t);
         else std::swap(L.pool, alt);                      // the candidate lost
         held.push_back(std::move(alt));
     }
@@ -598,60 +592,15 @@ void place_finest_pool(Hier<V> *h) {
     OMG_HIP(hipStreamSynchronize(h->stream));
 }
 
-// The same for a large 27-point level's coefficient tiles (1.8 GB at 256^3 fp32: what its sweeps stream): one sweep takes
-// 388-391 us on some allocations of the tiles and 432-448 us on others (profiles/r05_pool_placement.txt, section 7; where
-// the level's VECTORS lie moves it by 1 %).  Candidates — a copy of the tiles in another allocation, hipMalloc and
-// scattered pieces in turn — are timed with the level's own sweep until one is 4.5 % faster than the slowest seen or
-// OMG_S27_TRIALS (4) are tried; no more than 8 GB of them are held.
+// The same for a large 27-point level's coefficient tiles (Stencil27Plan::place_tiles, stencil27.hip)
 template <typename V>
 void place_s27_tiles(Hier<V> *h) {
-    static const int trials = [] { const char *e = getenv("OMG_S27_TRIALS"); return e && e[0] ? atoi(e) : 4; }();
-    if (trials < 2 || h->lv.size() < 2) return;
+    if (h->lv.size() < 2) return;
     Level<V> &L = h->lv[0];
     if (!L.s27 || !L.tmp.p || L.n < POOL_TRIAL_MIN) return;
-    Stencil27Plan<V> &P = *L.s27;
-    if (!P.coef.p) return;
-    SetupTimer tm("placement of the finest 27-point level's tiles (timed)");
-    const int max_trials = int(std::min<size_t>(size_t(trials), std::max<size_t>(2, (size_t(8) << 30) / (P.coef.n * sizeof(V)))));
-    hipEvent_t e0, e1;
-    OMG_HIP(hipEventCreate(&e0));
-    OMG_HIP(hipEventCreate(&e1));
-    auto timed = [&]() -> float {
-        L.x.zero(h->stream); L.tmp.zero(h->stream); L.b.zero(h->stream);
-        P.sweep(L.x.p, L.tmp.p, L.b.p, false, nullptr, false, nullptr, h->stream);
-        OMG_HIP(hipEventRecord(e0, h->stream));
-        for (int r = 0; r < 2; ++r) {
-            P.sweep(L.tmp.p, L.x.p, L.b.p, false, nullptr, false, nullptr, h->stream);
-            P.sweep(L.x.p, L.tmp.p, L.b.p, false, nullptr, false, nullptr, h->stream);
-        }
-        OMG_HIP(hipEventRecord(e1, h->stream));
-        OMG_HIP(hipEventSynchronize(e1));
-        float ms = 0.0f;
-        OMG_HIP(hipEventElapsedTime(&ms, e0, e1));
-        return 1e3f * ms / 4.0f;
-    };
-    const bool debug = SetupTimer::on();
-    float best = timed(), worst = best;
-    if (debug) fprintf(stderr, "[omg setup] 27-point tiles, candidate 0 (as built): %.1f us per sweep\n", best);
-    std::vector<DevBuf<V>> held;
-    for (int k = 1; k < max_trials; ++k) {
-        if (k >= 2 && best <= 0.955f * worst) break;
-        DevBuf<V> alt;
-        alt.alloc(P.coef.n, 0, pool_placement(k + 1));               // (k = 1: hipMalloc again, then 2 MiB pieces, 32 MiB pieces, ...)
-        OMG_HIP(hipMemcpyAsync(alt.p, P.coef.p, P.coef.n * sizeof(V), hipMemcpyDeviceToDevice, h->stream));
-        OMG_HIP(hipStreamSynchronize(h->stream));
-        std::swap(P.coef, alt);                                       // P.coef: the candidate, alt: the best so far
-        const float t = timed();
-        if (debug) fprintf(stderr, "[omg setup] 27-point tiles, candidate %d (placement %d): %.1f us per sweep\n", k, pool_placement(k + 1), t);
-        worst = std::max(worst, t);
-        if (t < best) best = t;
-        else std::swap(P.coef, alt);
-        held.push_back(std::move(alt));
-    }
+    L.s27->place_tiles(L.x.p, L.tmp.p, L.b.p, h->stream);
     L.x.zero(h->stream); L.tmp.zero(h->stream); L.b.zero(h->stream);
     OMG_HIP(hipStreamSynchronize(h->stream));
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
 }
 
 // The matrix-free SpMV's destination (an allocation of its own: DESIGN.md section 4) is placed like the level's pool — by

@@ -1202,6 +1202,63 @@ void Stencil27Plan<V>::rap_from(const int32_t *indptr, const double *vals, bool 
     if (coarse) coarse->have67 = false;
 }
 
+// WHERE a large level's coefficient tiles (1.8 GB at 256^3 fp32: what its sweeps stream) lie in HBM moves the sweep: 388-391 us
+// on some allocations and 432-448 us on others (profiles/r05_pool_placement.txt, section 7; where the level's VECTORS lie
+// moves it by 1 %) — as for the plane levels' vectors (hierarchy.hip place_finest_pool), nothing a process can ask the driver
+// for decides it.  So: candidates — a copy of the tiles in another allocation, hipMalloc and scattered pieces in turn — are
+// timed with the level's own sweep until one is 4.5 % faster than the slowest seen or OMG_S27_TRIALS (4) are tried; no more
+// than 8 GB of them are held.
+template <typename V>
+void Stencil27Plan<V>::place_tiles(V *x, V *tmp, V *b, hipStream_t s) {
+    const char *e = getenv("OMG_S27_TRIALS");
+    const int trials = e && e[0] ? atoi(e) : 4;
+    const bool keep_last = getenv("OMG_PLACE_KEEP_LAST") != nullptr;       // (tests: the newest candidate is kept whatever its time)
+    if (trials < 2 || !coef.p || int64_t(g.nx) * g.ny * g.nz < (int64_t(1) << 23)) return;
+    SetupTimer tm("placement of a large 27-point level's tiles (timed)");
+    const int64_t n = int64_t(g.nx) * g.ny * g.nz;
+    const int max_trials = int(std::min<size_t>(size_t(trials), std::max<size_t>(2, (size_t(8) << 30) / (coef.n * sizeof(V)))));
+    hipEvent_t e0, e1;
+    OMG_HIP(hipEventCreate(&e0));
+    OMG_HIP(hipEventCreate(&e1));
+    auto timed = [&]() -> float {
+        OMG_HIP(hipMemsetAsync(x, 0, size_t(n) * sizeof(V), s));
+        OMG_HIP(hipMemsetAsync(tmp, 0, size_t(n) * sizeof(V), s));
+        OMG_HIP(hipMemsetAsync(b, 0, size_t(n) * sizeof(V), s));
+        sweep(x, tmp, b, false, nullptr, false, nullptr, s);
+        OMG_HIP(hipEventRecord(e0, s));
+        for (int r = 0; r < 2; ++r) {
+            sweep(tmp, x, b, false, nullptr, false, nullptr, s);
+            sweep(x, tmp, b, false, nullptr, false, nullptr, s);
+        }
+        OMG_HIP(hipEventRecord(e1, s));
+        OMG_HIP(hipEventSynchronize(e1));
+        float ms = 0.0f;
+        OMG_HIP(hipEventElapsedTime(&ms, e0, e1));
+        return 1e3f * ms / 4.0f;
+    };
+    const bool debug = SetupTimer::on();
+    float best = timed(), worst = best;
+    if (debug) fprintf(stderr, "[omg setup] 27-point tiles, candidate 0 (as built): %.1f us per sweep\n", best);
+    std::vector<DevBuf<V>> held;
+    for (int k = 1; k < max_trials; ++k) {
+        if (!keep_last && k >= 2 && best <= 0.955f * worst) break;
+        DevBuf<V> alt;
+        alt.alloc(coef.n, 0, pool_placement(k + 1));                   // (k = 1: hipMalloc again, then 2 MiB pieces, 32 MiB pieces, ...)
+        OMG_HIP(hipMemcpyAsync(alt.p, coef.p, coef.n * sizeof(V), hipMemcpyDeviceToDevice, s));
+        OMG_HIP(hipStreamSynchronize(s));
+        std::swap(coef, alt);                                           // coef: the candidate, alt: the best so far
+        const float t = timed();
+        if (debug) fprintf(stderr, "[omg setup] 27-point tiles, candidate %d (placement %d): %.1f us per sweep\n", k, pool_placement(k + 1), t);
+        worst = std::max(worst, t);
+        if (t < best || keep_last) best = std::min(best, t);
+        else std::swap(coef, alt);
+        held.push_back(std::move(alt));
+    }
+    OMG_HIP(hipStreamSynchronize(s));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+}
+
 template struct Stencil27Plan<double>;
 template struct Stencil27Plan<float>;
 
