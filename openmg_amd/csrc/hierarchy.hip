@@ -540,7 +540,7 @@ void place_finest_pool(Hier<V> *h) {
     const char *env_trials = getenv("OMG_POOL_TRIALS");
     const int trials = env_trials && env_trials[0] ? atoi(env_trials) : 6;
     const bool keep_last = getenv("OMG_PLACE_KEEP_LAST") != nullptr;
-    if (trials < 2 || h->lv.size() < 2) return;
+    if ((trials < 2 && !getenv("OMG_POOL_REFINE")) || h->lv.size() < 2) return;
     Level<V> &L = h->lv[0], &C = h->lv[1];
     if (!L.plane || !L.pool.p || !L.pool_span || L.n < POOL_TRIAL_MIN || L.tmp.owned) return;
     SetupTimer tm("placement of the finest level's vectors (timed)");
@@ -586,6 +586,30 @@ void place_finest_pool(Hier<V> *h) {
         if (e == 0.0f || best < e) e = best;
     }
     pool_views(L, L.pool.p, L.pool_span, L.pool_off1, L.pool_off2);
+    // Where no candidate stood out — every pool the slow kind, or all alike — the search goes on vector by vector: an allocation
+    // of its own for one of the three (OMG_POOL_REFINE = candidates per vector, default 4), kept where the passes get 1.5 %
+    // faster.  (The times BETWEEN the two kinds are steps: 174 us with all three vectors on the fast kind of memory, + 6 us
+    // for each one that is not — profiles/r05_pool_placement.txt, section 10.)
+    {
+        const char *e = getenv("OMG_POOL_REFINE");
+        const bool established = (held.size() >= 1 && best <= 0.955f * worst) || (known > 0.0f && best <= 1.02f * known);
+        const int K = e && e[0] ? atoi(e) : ((keep_last || trials < 2) ? 0 : established ? 2 : 4);     // (a fast pool still gains 1-2 % now and then)
+        DevBuf<V> *vecs[3] = {&L.tmp, &L.b, &L.x};
+        const size_t shifts[3] = {L.pool_off1, L.pool_off2, 0};
+        std::vector<DevBuf<V>> losers;
+        for (int v = 0; v < 3 && K > 0; ++v) {
+            for (int k = 1; k <= K; ++k) {
+                DevBuf<V> alt;
+                alt.alloc(size_t(L.n), shifts[v], pool_placement(k + v));
+                std::swap(*vecs[v], alt);
+                const float t = timed();
+                if (debug) fprintf(stderr, "[omg setup] finest level's vector %d, candidate %d (placement %d): %.1f us (best so far %.1f)\n", v, k, pool_placement(k + v), t, best);
+                if (t <= 0.985f * best) { best = t; losers.push_back(std::move(alt)); break; }
+                std::swap(*vecs[v], alt);
+                losers.push_back(std::move(alt));
+            }
+        }
+    }
     L.x.zero(h->stream); L.tmp.zero(h->stream); L.b.zero(h->stream); C.x.zero(h->stream);
     L.xp = L.x.p;
     L.tp = L.tmp.p;
