@@ -532,8 +532,9 @@ void pool_views(Level<V> &L, char *base, size_t span, size_t off1, size_t off2) 
 // fast on some boxes every time and on others no better than hipMalloc: profiles/r05_pool_placement.txt).  Nothing a
 // process can ask for decides it, so the placement is MEASURED like the tiling: candidates are allocated one after another
 // (ordinary and scattered ones in turn, all held until the end so that each is different memory), the level's own down +
-// up pass is timed on each, and the search ends when a candidate is 4.5 % faster than the slowest seen — both kinds have
-// shown themselves — or as fast as the best this process has ever had for the shape, or after OMG_POOL_TRIALS (6).
+// up pass is timed on each, and the search ends when a candidate is good (the passes at 4.5 TB/s of needed bytes), or as fast
+// as the best this process has ever had for the shape, or 7 % faster than the slowest of three or more, or after
+// OMG_POOL_TRIALS (6); then, where none was good, vector by vector (below).
 template <typename V>
 void place_finest_pool(Hier<V> *h) {
     // (read at every call, like OMG_PLACE_KEEP_LAST=1 — tests: the newest candidate is kept whatever its time, no early stop)
@@ -563,12 +564,16 @@ void place_finest_pool(Hier<V> *h) {
     }
     // (the candidates are held together: no more than 16 GB of them — five for a 512^3 level)
     const int max_trials = int(std::min<size_t>(size_t(trials), std::max<size_t>(2, (size_t(16) << 30) / (3 * L.pool_span))));
+    // "good": the pair of passes moves its 6 w n bytes at 4.5 TB/s or more (179 us at 256^3 fp64: what all three vectors on the
+    // fast kind of memory give; one of them elsewhere: 180-186 us) — where a level's shape never reaches that, every candidate is tried
+    const double pair_bytes = 6.0 * double(sizeof(V)) * double(L.n);
+    auto good = [&](float us) { return pair_bytes / (double(us) * 1e-6) >= 4.5e12; };
     float best = timed(), worst = best;
     std::vector<DevBuf<char>> held;                       // (the losers: kept until the end, so that a candidate is not the memory just given back)
     const bool debug = SetupTimer::on();
     if (debug) fprintf(stderr, "[omg setup] finest level's pool, candidate 0 (hipMalloc): %.1f us per down + up\n", best);
     for (int k = 1; k < max_trials; ++k) {
-        if (!keep_last && ((k >= 2 && best <= 0.955f * worst) || (known > 0.0f && best <= 1.02f * known))) break;
+        if (!keep_last && (good(best) || (k >= 3 && best <= 0.93f * worst) || (known > 0.0f && best <= 1.02f * known))) break;
         DevBuf<char> alt;
         alt.alloc(3 * L.pool_span, 0, pool_placement(k));
         std::swap(L.pool, alt);                           // L.pool: the candidate, alt: the best so far
@@ -586,14 +591,14 @@ void place_finest_pool(Hier<V> *h) {
         if (e == 0.0f || best < e) e = best;
     }
     pool_views(L, L.pool.p, L.pool_span, L.pool_off1, L.pool_off2);
-    // Where no candidate stood out — every pool the slow kind, or all alike — the search goes on vector by vector: an allocation
+    // Where no candidate was good, the search goes on vector by vector: an allocation
     // of its own for one of the three (OMG_POOL_REFINE = candidates per vector, default 4), kept where the passes get 1.5 %
     // faster.  (The times BETWEEN the two kinds are steps: 174 us with all three vectors on the fast kind of memory, + 6 us
     // for each one that is not — profiles/r05_pool_placement.txt, section 10.)
     {
         const char *e = getenv("OMG_POOL_REFINE");
-        const bool established = (held.size() >= 1 && best <= 0.955f * worst) || (known > 0.0f && best <= 1.02f * known);
-        const int K = e && e[0] ? atoi(e) : ((keep_last || trials < 2) ? 0 : established ? 2 : 4);     // (a fast pool still gains 1-2 % now and then)
+        const bool established = good(best) || (known > 0.0f && best <= 1.02f * known);
+        const int K = e && e[0] ? atoi(e) : ((keep_last || trials < 2 || established) ? 0 : 4);
         DevBuf<V> *vecs[3] = {&L.tmp, &L.b, &L.x};
         const size_t shifts[3] = {L.pool_off1, L.pool_off2, 0};
         std::vector<DevBuf<V>> losers;
@@ -633,7 +638,7 @@ template <typename V>
 void ensure_spmv_y(Hier<V> *h, Level<V> &L) {
     if (L.spmv_y.p) return;
     L.spmv_y.alloc(size_t(L.n));
-    static const int trials = [] { const char *e = getenv("OMG_SPMV_TRIALS"); return e && e[0] ? atoi(e) : 5; }();
+    static const int trials = [] { const char *e = getenv("OMG_SPMV_TRIALS"); return e && e[0] ? atoi(e) : 8; }();
     if (trials < 2 || !L.plane || L.n < POOL_TRIAL_MIN) return;
     hipEvent_t e0, e1;
     OMG_HIP(hipEventCreate(&e0));
@@ -641,19 +646,19 @@ void ensure_spmv_y(Hier<V> *h, Level<V> &L) {
     auto timed = [&]() -> float {
         L.plane->spmv(L.xp, L.spmv_y.p, h->stream);
         OMG_HIP(hipEventRecord(e0, h->stream));
-        for (int r = 0; r < 4; ++r) L.plane->spmv(L.xp, L.spmv_y.p, h->stream);
+        for (int r = 0; r < 8; ++r) L.plane->spmv(L.xp, L.spmv_y.p, h->stream);
         OMG_HIP(hipEventRecord(e1, h->stream));
         OMG_HIP(hipEventSynchronize(e1));
         float ms = 0.0f;
         OMG_HIP(hipEventElapsedTime(&ms, e0, e1));
-        return 1e3f * ms / 4.0f;
+        return 1e3f * ms / 8.0f;
     };
     float best = timed(), worst = best;
     const bool debug = SetupTimer::on();
     if (debug) fprintf(stderr, "[omg setup] SpMV destination, candidate 0: %.1f us per launch\n", best);
     std::vector<DevBuf<V>> held;
     for (int k = 1; k < trials; ++k) {
-        if (k >= 2 && best <= 0.955f * worst) break;
+        if (2.0 * double(sizeof(V)) * double(L.n) / (double(best) * 1e-6) >= 5.15e12) break;     // good: x read and y written at 5.15 TB/s (52 us at 256^3 fp64; the fast kind 43-45 — 47-50 in these short timings —, the others 57-70)
         DevBuf<V> alt;
         alt.alloc(size_t(L.n), 0, pool_placement(k));
         std::swap(L.spmv_y, alt);
