@@ -1558,8 +1558,8 @@ std::unique_ptr<PlaneDist> pd_create(int rank, int n_ranks, int nx, int ny, int 
         L.plan.tune(L.xp, L.tp, L.b.p, c, d->stream);
         // ... and WHERE its three vectors lie: the passes run 7 % apart on different allocations of the same vectors
         // (hierarchy.hip place_finest_pool, profiles/r05_pool_placement.txt), and with one process per GPU the slowest rank
-        // sets the cycle.  Candidates (hipMalloc only: a neighbour may map these vectors over hipIpc) until one is 4.5 %
-        // faster than the slowest seen or OMG_PDIST_TRIALS (5) are tried, no more than 16 GB held.
+        // sets the cycle.  Candidates (hipMalloc only: a neighbour may map these vectors over hipIpc) until one is good
+        // (the passes at 4.5 TB/s of needed bytes) or OMG_PDIST_TRIALS (5) are tried, no more than 16 GB held.
         static const int trials = [] { const char *e = getenv("OMG_PDIST_TRIALS"); return e && e[0] ? atoi(e) : 5; }();
         const size_t triple = 3 * size_t(L.n_ext) * sizeof(double);
         const int max_trials = int(std::min<size_t>(size_t(std::max(trials, 1)), std::max<size_t>(2, (size_t(16) << 30) / std::max<size_t>(triple, 1))));
@@ -1575,7 +1575,7 @@ std::unique_ptr<PlaneDist> pd_create(int rank, int n_ranks, int nx, int ny, int 
             struct Triple { DevBuf<double> x, tmp, b; };
             std::vector<Triple> held;
             for (int k = 1; k < max_trials; ++k) {
-                if (k >= 2 && best <= 0.955f * worst) break;
+                if (6.0 * 8.0 * double(L.n_ext) / (double(best) * 1e-6) >= 4.5e12 || (k >= 3 && best <= 0.93f * worst)) break;     // (good: as hierarchy.hip has it)
                 Triple t;
                 t.x.alloc(size_t(L.n_ext)); t.tmp.alloc(size_t(L.n_ext), vector_stagger(1)); t.b.alloc(size_t(L.n_ext), vector_stagger(2));
                 std::swap(L.x, t.x); std::swap(L.tmp, t.tmp); std::swap(L.b, t.b);

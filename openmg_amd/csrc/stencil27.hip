@@ -1206,8 +1206,8 @@ void Stencil27Plan<V>::rap_from(const int32_t *indptr, const double *vals, bool 
 // on some allocations and 432-448 us on others (profiles/r05_pool_placement.txt, section 7; where the level's VECTORS lie
 // moves it by 1 %) — as for the plane levels' vectors (hierarchy.hip place_finest_pool), nothing a process can ask the driver
 // for decides it.  So: candidates — a copy of the tiles in another allocation, hipMalloc and scattered pieces in turn — are
-// timed with the level's own sweep until one is 4.5 % faster than the slowest seen or OMG_S27_TRIALS (4) are tried; no more
-// than 8 GB of them are held.
+// timed with the level's own sweep until one is good (the sweep at 5.5 TB/s of its needed bytes) or OMG_S27_TRIALS (4) are
+// tried; no more than 8 GB of them are held.
 template <typename V>
 void Stencil27Plan<V>::place_tiles(V *x, V *tmp, V *b, hipStream_t s) {
     const char *e = getenv("OMG_S27_TRIALS");
@@ -1237,11 +1237,14 @@ void Stencil27Plan<V>::place_tiles(V *x, V *tmp, V *b, hipStream_t s) {
         return 1e3f * ms / 4.0f;
     };
     const bool debug = SetupTimer::on();
+    // "good": a sweep moves its (27 + 6) w n bytes at 5.5 TB/s or more (403 us at 256^3 fp32: the fast kind 367-395, the others 416-448)
+    const double sweep_bytes = 33.0 * double(sizeof(V)) * double(n);
+    auto good = [&](float us) { return sweep_bytes / (double(us) * 1e-6) >= 5.5e12; };
     float best = timed(), worst = best;
     if (debug) fprintf(stderr, "[omg setup] 27-point tiles, candidate 0 (as built): %.1f us per sweep\n", best);
     std::vector<DevBuf<V>> held;
     for (int k = 1; k < max_trials; ++k) {
-        if (!keep_last && k >= 2 && best <= 0.955f * worst) break;
+        if (!keep_last && (good(best) || (k >= 3 && best <= 0.93f * worst))) break;
         DevBuf<V> alt;
         alt.alloc(coef.n, 0, pool_placement(k + 1));                   // (k = 1: hipMalloc again, then 2 MiB pieces, 32 MiB pieces, ...)
         OMG_HIP(hipMemcpyAsync(alt.p, coef.p, coef.n * sizeof(V), hipMemcpyDeviceToDevice, s));
