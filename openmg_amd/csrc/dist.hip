@@ -1577,7 +1577,8 @@ std::unique_ptr<PlaneDist> pd_create(int rank, int n_ranks, int nx, int ny, int 
             for (int k = 1; k < max_trials; ++k) {
                 if (6.0 * 8.0 * double(L.n_ext) / (double(best) * 1e-6) >= 4.5e12 || (k >= 3 && best <= 0.93f * worst)) break;     // (good: as hierarchy.hip has it)
                 Triple t;
-                t.x.alloc(size_t(L.n_ext)); t.tmp.alloc(size_t(L.n_ext), vector_stagger(1)); t.b.alloc(size_t(L.n_ext), vector_stagger(2));
+                try { t.x.alloc(size_t(L.n_ext)); t.tmp.alloc(size_t(L.n_ext), vector_stagger(1)); t.b.alloc(size_t(L.n_ext), vector_stagger(2)); }
+                catch (const Error &) { (void)hipGetLastError(); break; }      // (no memory for another candidate: what there is stays)
                 std::swap(L.x, t.x); std::swap(L.tmp, t.tmp); std::swap(L.b, t.b);
                 const float us = timed();
                 if (debug) fprintf(stderr, "[omg setup] rank %d: slab vectors, candidate %d: %.1f us per down + up\n", rank, k, us);

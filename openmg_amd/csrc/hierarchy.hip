@@ -575,7 +575,7 @@ void place_finest_pool(Hier<V> *h) {
     for (int k = 1; k < max_trials; ++k) {
         if (!keep_last && (good(best) || (k >= 3 && best <= 0.93f * worst) || (known > 0.0f && best <= 1.02f * known))) break;
         DevBuf<char> alt;
-        alt.alloc(3 * L.pool_span, 0, pool_placement(k));
+        try { alt.alloc(3 * L.pool_span, 0, pool_placement(k)); } catch (const Error &) { (void)hipGetLastError(); break; }       // (no memory for another candidate: what there is stays)
         std::swap(L.pool, alt);                           // L.pool: the candidate, alt: the best so far
         pool_views(L, L.pool.p, L.pool_span, L.pool_off1, L.pool_off2);
         const float t = timed();
@@ -605,7 +605,7 @@ void place_finest_pool(Hier<V> *h) {
         for (int v = 0; v < 3 && K > 0; ++v) {
             for (int k = 1; k <= K; ++k) {
                 DevBuf<V> alt;
-                alt.alloc(size_t(L.n), shifts[v], pool_placement(k + v));
+                try { alt.alloc(size_t(L.n), shifts[v], pool_placement(k + v)); } catch (const Error &) { (void)hipGetLastError(); break; }
                 std::swap(*vecs[v], alt);
                 const float t = timed();
                 if (debug) fprintf(stderr, "[omg setup] finest level's vector %d, candidate %d (placement %d): %.1f us (best so far %.1f)\n", v, k, pool_placement(k + v), t, best);
@@ -660,7 +660,7 @@ void ensure_spmv_y(Hier<V> *h, Level<V> &L) {
     for (int k = 1; k < trials; ++k) {
         if (2.0 * double(sizeof(V)) * double(L.n) / (double(best) * 1e-6) >= 5.15e12) break;     // good: x read and y written at 5.15 TB/s (52 us at 256^3 fp64; the fast kind 43-45 — 47-50 in these short timings —, the others 57-70)
         DevBuf<V> alt;
-        alt.alloc(size_t(L.n), 0, pool_placement(k));
+        try { alt.alloc(size_t(L.n), 0, pool_placement(k)); } catch (const Error &) { (void)hipGetLastError(); break; }
         std::swap(L.spmv_y, alt);
         const float t = timed();
         if (debug) fprintf(stderr, "[omg setup] SpMV destination, candidate %d (placement %d): %.1f us per launch\n", k, pool_placement(k), t);

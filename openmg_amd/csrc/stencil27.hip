@@ -1246,7 +1246,8 @@ void Stencil27Plan<V>::place_tiles(V *x, V *tmp, V *b, hipStream_t s) {
     for (int k = 1; k < max_trials; ++k) {
         if (!keep_last && (good(best) || (k >= 3 && best <= 0.93f * worst))) break;
         DevBuf<V> alt;
-        alt.alloc(coef.n, 0, pool_placement(k + 1));                   // (k = 1: hipMalloc again, then 2 MiB pieces, 32 MiB pieces, ...)
+        try { alt.alloc(coef.n, 0, pool_placement(k + 1)); }           // (k = 1: hipMalloc again, then 2 MiB pieces, 32 MiB pieces, ...)
+        catch (const Error &) { (void)hipGetLastError(); break; }       // (no memory for another candidate: what there is stays)
         OMG_HIP(hipMemcpyAsync(alt.p, coef.p, coef.n * sizeof(V), hipMemcpyDeviceToDevice, s));
         OMG_HIP(hipStreamSynchronize(s));
         std::swap(coef, alt);                                           // coef: the candidate, alt: the best so far
