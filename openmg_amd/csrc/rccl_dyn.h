@@ -3,6 +3,7 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
+#include <cstdlib>
 #include <string>
 
 #include "common.h"
@@ -30,10 +31,17 @@ struct Rccl {
     }
     void load() {
         if (handle) return;
+        // OMG_RCCL_LIB: the library to take the eleven symbols from instead (RTLD_LOCAL: its names must not shadow a
+        // real librccl PyTorch has loaded).  tests/fake_rccl builds one that lets ranks SHARING a GPU run these call
+        // sites; a path that does not load is an error, never a silent fall back to the real library.
+        if (const char *over = getenv("OMG_RCCL_LIB"); over && *over) {
+            handle = dlopen(over, RTLD_NOW | RTLD_LOCAL);
+            if (!handle) throw Error(OMG_ERR_UNSUPPORTED, std::string("OMG_RCCL_LIB: cannot load ") + over + ": " + dlerror());
+        }
         // an already-loaded copy (e.g. the one PyTorch brought) wins; then the ROCm install
         for (const char *n : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-            handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
             if (handle) break;
+            handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
         }
         if (!handle) throw Error(OMG_ERR_UNSUPPORTED, std::string("cannot load librccl: ") + dlerror());
         sym(GetUniqueId, "ncclGetUniqueId");

@@ -63,6 +63,105 @@ def slab27_levels(shape, world, n_dist, dtype):
     return n
 
 
+def _median_ms(run, sync, steps, warmup, repeats=3):
+    run(max(1, warmup))
+    times = []
+    for _ in range(repeats):
+        sync()
+        t0 = time.perf_counter()
+        run(steps)
+        sync()
+        times.append((time.perf_counter() - t0) / steps)
+    return 1e3 * statistics.median(times)
+
+
+def one_gpu_baselines_plane(args, shape, grids, torch):
+    """The two one-GPU numbers an N-GPU line of the 7-point workload is read against, measured by rank 0 ON ITS OWN GPU in
+    the same run (the other ranks wait): (i) BASELINE configs[2] as `bench.py --gpus 1` runs it — (256 s)^3, `--grids`
+    grids, the single-GPU hierarchy (`vs_n1_config2`: what a weak-scaling ratio over the driver's N = 1 line means, a ratio
+    between two DIFFERENT hierarchies); (ii) the SAME global problem and hierarchy on one GPU — one slab holding every
+    plane, same passes, no exchanges (`vs_one_gpu_same_problem`: the strong-scaling speed-up of this run).
+    OMG_BENCH_BASELINES=0 skips both (keys stay, values None)."""
+    from . import _hip, _hip_dist, operators
+    out = {"n1_config2_ms_per_cycle": None, "one_gpu_same_problem_ms_per_cycle": None}
+    if os.environ.get("OMG_BENCH_BASELINES", "1") == "0":
+        return out
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("_omg_bench", os.path.join(root, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+
+    def sync_of(obj):
+        def sync():
+            obj.sync()
+            torch.cuda.synchronize()
+        return sync
+
+    h, b, _ = mod.build_problem(args.size, args.grids, args.smoother, "float64")
+    try:
+        h.resident_load(b)
+        out["n1_config2_ms_per_cycle"] = round(_median_ms(lambda k: h.resident_cycles(1, 1, k), sync_of(h), args.steps, args.warmup), 4)
+    finally:
+        h.close()
+        mod._PROBLEM.clear()
+    del b
+    n_levels = plane_levels(shape, 1, max(2, min(args.dist_grids, grids)))
+    coef = [[v / 16.0 ** l for v in (-1.0, -1.0, -1.0, 6.0, -1.0, -1.0, -1.0)] for l in range(n_levels)]
+    tshape = tuple(s >> n_levels for s in shape)
+    tgrids = grids - n_levels
+    At = operators.stencil_poisson(tshape) / 16.0 ** n_levels
+    Rt = operators.restrictionList(tshape, tgrids - 2, 8) if tgrids >= 2 else []
+    tail = _hip.Hierarchy(operators.coeffecientList(At, Rt), Rt, smoother=args.smoother)
+    d = _hip_dist.PlaneDistRank(0, 1, shape, coef, 0.125, tail)
+    try:
+        d.load(np.random.default_rng(12345).random(d.n_local))
+        out["one_gpu_same_problem_ms_per_cycle"] = round(_median_ms(lambda k: d.cycles(k), sync_of(d), args.steps, args.warmup), 4)
+    finally:
+        d.close()
+        tail.close()
+    return out
+
+
+def one_gpu_baselines_slab27(args, shape, grids, torch, np_dtype):
+    """As one_gpu_baselines_plane, for the 27-point workload: (i) ONE slab of the N = 1 problem ((256 s)^3, `--grids` grids:
+    what `bench.py --gpus 1 --dist 1 --stencil 27var` runs), (ii) one slab holding the whole global problem — measured only
+    while that operator's CSR (27 nnz per row, 12 bytes each on the host) stays under ~12 GB, i.e. up to N = 2."""
+    from . import _hip_dist, dist
+    out = {"n1_config4_ms_per_cycle": None, "one_gpu_same_problem_ms_per_cycle": None, "note": None}
+    if os.environ.get("OMG_BENCH_BASELINES", "1") == "0":
+        return out
+
+    def one_slab(shp, g):
+        n_lv = slab27_levels(shp, 1, max(2, min(args.dist_grids, g)), args.dtype)
+        n = shp[0] * shp[1] * shp[2]
+        A_rows = dist.stencil27_variable_rows(shp, 0, n)
+        b = A_rows @ np.random.default_rng(12345).random(n)
+        d = _hip_dist.Slab27Rank(0, 1, shp, A_rows, n_lv, 0.125, np_dtype)
+        del A_rows
+        tail = dist.make_tail(dist.assemble_coarse([d.coarse_rows()]), tuple(v >> n_lv for v in shp), g - n_lv, smoother="colour", dtype=np_dtype)
+        d.set_tail(tail)
+        try:
+            d.load(b)
+
+            def sync():
+                d.sync()
+                torch.cuda.synchronize()
+            return round(_median_ms(lambda k: d.cycles(1, 1, k), sync, args.steps, args.warmup), 4)
+        finally:
+            d.close()
+            tail.close()
+
+    s1 = int(args.size)
+    out["n1_config4_ms_per_cycle"] = one_slab((s1, s1, s1), args.grids)
+    if shape[0] * shape[1] * shape[2] <= 2 * 256 ** 3:
+        out["one_gpu_same_problem_ms_per_cycle"] = one_slab(shape, grids)
+    else:
+        out["note"] = "the same problem on one GPU was not measured: its host CSR (%.0f GB) is beyond one rank's set-up budget" % (
+            12e-9 * 27 * shape[0] * shape[1] * shape[2])
+    return out
+
+
 def main_slab27(args, rank, world, shape, grids, n_levels, all_gather, td, torch, watchdog):
     """BASELINE configs[4]: the 27-point variable-coefficient operator, 8-colour Gauss-Seidel, on slabs with ghost
     aggregate planes run by the octant-layout kernels (omg_sdist_*): per-rank Galerkin products on the device, one
@@ -122,6 +221,10 @@ def main_slab27(args, rank, world, shape, grids, n_levels, all_gather, td, torch
     elapsed = statistics.median(times)
     norm = r.cycles(pre, post, 1)[0]
     rccl_ranks = r.rccl_ranks()
+    r.sync()
+    td.barrier()
+    base = one_gpu_baselines_slab27(args, shape, grids, torch, np_dtype) if rank == 0 and world > 1 else None
+    td.barrier()
     if rank == 0:
         equiv = n_glob / float(256 ** 3)
         # what a rank's fine-grid launches have to move per V(1,1) cycle: two sweeps of (27 + 2 + 4) w n
@@ -147,12 +250,18 @@ def main_slab27(args, rank, world, shape, grids, n_levels, all_gather, td, torch
                        "exchange": "RCCL grouped send/recv of ghost aggregate planes (colours 4..7 both ways after every sweep, colours 0..3 of the "
                                    "coarse right-hand side after every restriction)",
                        "halo_exchanges_per_cycle": exchanges, "rccl_ranks": rccl_ranks, "repeats": len(times),
+                       "ranks_share_one_gpu": os.environ.get("OMG_DIST_SHARED_GPU", "0") in ("1", "rccl") and world > 1,
                        "preflight_norm": first_norm, "kernel_src_sha": src_sha, "git_head": head,
                        "ms_per_step_all": [round(1e3 * t / args.steps, 4) for t in times],
                        "pre": pre, "post": post, "cycles_per_s": round(args.steps / elapsed, 3),
                        "final_residual_norm": norm, "norms_last_region_tail": trajectory[-3:],
                        "workgroups": info["workgroups"], "aggregates_per_lane": info["aggregates_per_lane"],
                        "generate_s": round(t_gen - t_setup, 2), "setup_s": round(setup_s, 2)},
+            "vs_n1_config2": (round((args.steps / elapsed * equiv) / ((args.size / 256.0) ** 3 * 1e3 / base["n1_config4_ms_per_cycle"]), 4)
+                              if base and base["n1_config4_ms_per_cycle"] else None),
+            "vs_one_gpu_same_problem": (round(base["one_gpu_same_problem_ms_per_cycle"] / (1e3 * elapsed / args.steps), 4)
+                                        if base and base["one_gpu_same_problem_ms_per_cycle"] else None),
+            "one_gpu_baselines": base,
             # a LOWER bound of the fine-grid launches' rate: the bytes rank 0's fine-grid launches have to move per cycle over
             # the WHOLE cycle's time (exchanges, coarser levels and the replicated tail included)
             "roofline": {"bound": "hbm", "kernel": "rank 0's fine-grid launches per cycle: 2 sweeps (4 pair launches each) + residual of 6 colours + restriction "
@@ -199,7 +308,10 @@ def main_plane(args, rank, world, shape, grids, n_levels, all_gather, td, torch,
     # OMG_DIST_SHARED_GPU=1: every rank on GPU 0 — a REHEARSAL of the multi-process path (launcher, rendezvous, preflight,
     # hipIpc peer mappings, flags between processes) where there is one GPU; RCCL cannot put two ranks on one device, so
     # the exchanges are peer stores with wait launches and the norms are added over gloo.  Not a scaling measurement.
+    # OMG_DIST_SHARED_GPU=rccl (with OMG_RCCL_LIB naming tests/fake_rccl's library): every rank on GPU 0 too, but through the
+    # RCCL call sites themselves — communicators, grouped send / recv, all-gather, all-reduce — as on N GPUs.
     shared = os.environ.get("OMG_DIST_SHARED_GPU", "0") == "1" and world > 1
+    shared_rccl = os.environ.get("OMG_DIST_SHARED_GPU", "0") == "rccl" and world > 1
 
     def reduce(squares):
         t = torch.tensor(squares, dtype=torch.float64)
@@ -234,6 +346,9 @@ def main_plane(args, rank, world, shape, grids, n_levels, all_gather, td, torch,
     if shared:
         exchange = "peer stores between PROCESSES SHARING ONE GPU (hipIpc mappings, wait launches): a rehearsal, not a scaling measurement"
         p2p_note = "required (no RCCL between ranks on one device)"
+    elif shared_rccl:
+        exchange = "grouped send/recv of ghost planes through the RCCL call sites, ranks SHARING ONE GPU (test stand-in for librccl): a rehearsal, not a scaling measurement"
+        p2p_note = "not tried (ranks share a GPU)"
     elif want != "0" and (world > 1 or want == "1") and all((shape[0] >> l) // world >= 4 for l in range(n_levels)):
         def agree(ok):
             return all(all_gather(bool(ok)))
@@ -388,6 +503,10 @@ def main_plane(args, rank, world, shape, grids, n_levels, all_gather, td, torch,
     elapsed = statistics.median(times)
     norm = run_cycles(1)[0]
     rccl_ranks = r.rccl_ranks()
+    r.sync()
+    td.barrier()
+    base = one_gpu_baselines_plane(args, shape, grids, torch) if rank == 0 and world > 1 else None
+    td.barrier()
     if rank == 0:
         equiv = n_glob / float(256 ** 3)
         # per cycle a rank's two fine-grid passes move 3 w per owned unknown + (w + 4) per coarse one, each
@@ -407,7 +526,7 @@ def main_plane(args, rank, world, shape, grids, n_levels, all_gather, td, torch,
                                    % ("x".join(map(str, shape)), grids, world),
                        "unknowns": n_glob, "unknowns_per_gpu": n_loc, "nnz_per_gpu": nnz_loc, "grids": grids,
                        "distributed_grids": n_levels, "replicated_tail_grids": tgrids, "runner": "plane slabs (omg_pdist)",
-                       "exchange": exchange, "peer_mode": p2p_note, "gated_passes": gate_note, "ranks_share_one_gpu": bool(shared),
+                       "exchange": exchange, "peer_mode": p2p_note, "gated_passes": gate_note, "ranks_share_one_gpu": bool(shared or shared_rccl),
                        "rccl_ranks": rccl_ranks, "repeats": len(times), "preflight_norm": first_norm,
                        "kernel_src_sha": src_sha, "git_head": head,
                        "ms_per_step_all": [round(1e3 * t / args.steps, 4) for t in times],
@@ -416,6 +535,14 @@ def main_plane(args, rank, world, shape, grids, n_levels, all_gather, td, torch,
                        "setup_s": round(setup_s, 2)},
             # a LOWER bound of the fine-grid passes' rate: the bytes both of rank 0's fine-grid passes have to move per
             # cycle over the WHOLE cycle's time (exchanges, coarser levels and the replicated tail included)
+            # the two one-GPU baselines of this line, measured by rank 0 in this run (one_gpu_baselines_plane): `value` over the
+            # N = 1 line's workload (configs[2]: another hierarchy, one grid fewer) in the same 256^3-equivalent unit, and this
+            # run's cycle rate over the SAME problem's on one GPU
+            "vs_n1_config2": (round((args.steps / elapsed * equiv) / ((args.size / 256.0) ** 3 * 1e3 / base["n1_config2_ms_per_cycle"]), 4)
+                              if base and base["n1_config2_ms_per_cycle"] else None),
+            "vs_one_gpu_same_problem": (round(base["one_gpu_same_problem_ms_per_cycle"] / (1e3 * elapsed / args.steps), 4)
+                                        if base and base["one_gpu_same_problem_ms_per_cycle"] else None),
+            "one_gpu_baselines": base,
             "roofline": {"bound": "hbm", "kernel": "rank 0's two fine-grid plane passes per cycle (bytes needed / whole cycle time: a lower bound)",
                          "achieved": round(2 * pass_bytes / (elapsed / args.steps) / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
                          "frac": round(2 * pass_bytes / (elapsed / args.steps) / 1e9 / 8000.0, 4), "traffic": None,
@@ -462,7 +589,7 @@ def main(args):
     from . import _hip, _hip_dist, dist
 
     _hip.require_gpu()
-    if os.environ.get("OMG_DIST_SHARED_GPU", "0") == "1":
+    if os.environ.get("OMG_DIST_SHARED_GPU", "0") in ("1", "rccl"):
         local = 0                                             # (rehearsal on one GPU: main_plane)
     torch.cuda.set_device(local)
     _hip_dist.set_device(local)
@@ -599,6 +726,7 @@ def main(args):
                        "unknowns": n_glob, "unknowns_per_gpu": n_loc, "nnz_per_gpu": nnz_loc, "grids": grids,
                        "distributed_grids": n_dist - 1, "replicated_tail_grids": grids - n_dist + 1,
                        "rccl_ranks": rccl_ranks, "repeats": len(times), "overlap_autotune": autotune,
+                       "ranks_share_one_gpu": os.environ.get("OMG_DIST_SHARED_GPU", "0") in ("1", "rccl") and world > 1,
                        "kernel_src_sha": _bench_identity()[0], "git_head": _bench_identity()[1],
                        "ms_per_step_all": [round(1e3 * t / args.steps, 4) for t in times],
                        "pre": pre, "post": post, "cycles_per_s": round(args.steps / elapsed, 3),

@@ -12,12 +12,17 @@ import bench
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+# the round whose final collection is tied to the committed kernel sources (earlier rounds' files are history)
+LATEST = "r06" if os.path.exists(os.path.join(ROOT, "profiles", "r06_pmc_plane_down.json")) else None
+ROUNDS = ["r03", "r05"] + (["r06"] if LATEST else [])
+
+
 def _load(name):
     with open(os.path.join(ROOT, "profiles", name)) as f:
         return json.loads(f.read().strip().splitlines()[-1]) if name.endswith("bench.json") else json.load(f)
 
 
-@pytest.mark.parametrize("rnd", ["r03", "r05"])
+@pytest.mark.parametrize("rnd", ROUNDS)
 def test_committed_bench_line_keeps_the_contract(rnd):
     d = _load(rnd + "_bench.json")
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
@@ -40,7 +45,7 @@ def test_committed_bench_line_keeps_the_contract(rnd):
         assert 0.0 < r["level0_kernels"][k]["frac"] <= 1.0 and r["level0_kernels"][k]["launches_per_cycle"] == 1.0
     assert d["reference_smoother"]["vcycles_per_s"] > 0 and all(d["reference_smoother"]["wavefront_levels"])
     assert re.fullmatch(r"[0-9a-f]{16}", d["config"]["kernel_src_sha"]) and re.fullmatch(r"[0-9a-f]{40}", d["config"]["git_head"])
-    if rnd == "r05":
+    if rnd >= "r05":
         # round 5's legs: the matrix-free fine-grid SpMV over the line VERDICT r4 drew, BASELINE configs[0] and [4] (the latter
         # with its own roofline and the coefficient update), which kind of allocation the finest level's vectors got
         assert 0.70 <= d["fine_grid_spmv"]["frac"] <= 1.0
@@ -52,7 +57,7 @@ def test_committed_bench_line_keeps_the_contract(rnd):
         assert d["default_cycle"]["plane"] and d["default_cycle"]["vcycles_per_s"] > 0
 
 
-@pytest.mark.parametrize("rnd", ["r03", "r05"])
+@pytest.mark.parametrize("rnd", ROUNDS)
 def test_pmc_traffic_is_tied_to_the_kernel_sources_it_was_measured_on(rnd):
     p = _load(rnd + "_pmc_plane_down.json")
     assert re.fullmatch(r"[0-9a-f]{16}", p["kernel_src_sha"]) and re.fullmatch(r"[0-9a-f]{40}", p["git_head_at_collection"])
@@ -61,10 +66,10 @@ def test_pmc_traffic_is_tied_to_the_kernel_sources_it_was_measured_on(rnd):
     assert p["traffic_bytes"] >= p["bytes_per_launch"]                           # over-fetch, never under
     h = bench.kernel_source_hash()
     assert re.fullmatch(r"[0-9a-f]{16}", h) and h == bench.kernel_source_hash()
-    if rnd == "r05":
+    if rnd == LATEST:
         # the round's final collection was made on the sources as they are committed: the profiles are this build's
         assert h == p["kernel_src_sha"], "openmg_amd/csrc changed after the round's profiles were collected"
-        q = _load("r05_pmc_s27_sweep.json")
+        q = _load(rnd + "_pmc_s27_sweep.json")
         assert q["kernel_src_sha"] == h and q["traffic_bytes"] == q["read_bytes"] + q["write_bytes"]
     d = _load(rnd + "_bench.json")
     if d["roofline"]["traffic"] is not None:                                     # only a run of the profiled build may carry it

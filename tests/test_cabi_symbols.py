@@ -51,3 +51,20 @@ def test_no_gpu_fails_loudly():
     p = {"problemShape": (16,), "gridLevels": 1, "cycles": 1}
     with pytest.raises(_hip.HipError):
         openmg_amd.mgSolve(openmg_amd.operators.poisson(16, sparse=True), np.ones(16), p)
+
+
+def test_rccl_stand_in_exports_what_the_library_resolves_and_the_product_never_names_it():
+    """tests/fake_rccl (the test-only librccl stand-in of tests/test_gpu_rccl_shim.py) defines every symbol csrc/rccl_dyn.h
+    resolves with dlsym; the product reaches it only through OMG_RCCL_LIB."""
+    text = open(os.path.join(ROOT, "openmg_amd", "csrc", "rccl_dyn.h")).read()
+    wanted = sorted(set(re.findall(r'sym\(\w+, "(nccl\w+)"\)', text)))
+    assert len(wanted) == 11
+    path = os.path.join(ROOT, "tests", "fake_rccl", "libfake_rccl.so")
+    assert os.path.exists(path), "tests/fake_rccl/libfake_rccl.so is not built (__graft_entry__.build() makes it)"
+    handle = ctypes.CDLL(path, mode=os.RTLD_LOCAL)
+    for name in wanted + ["frccl_status", "frccl_identity"]:
+        assert hasattr(handle, name), name
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "openmg_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cpp", ".h")):
+                assert "fake_rccl/libfake" not in open(os.path.join(dirpath, f)).read(), f

@@ -1,0 +1,207 @@
+"""Every N > 1 RCCL call site of csrc/dist.hip and csrc/dist27.hip executed by 2, 4 and 8 PROCESSES on one GPU.
+
+RCCL refuses two ranks on one device and the pool has one-GPU boxes, so libopenmg_hip.so takes the eleven RCCL symbols
+from a test-only stand-in (tests/fake_rccl, named by OMG_RCCL_LIB) that keeps what can deadlock a first 8-GPU run:
+stream-ordered device work, a send that holds its stream until the matching receive took the data, grouped sections,
+a collective communicator set-up — and turns a wait that never ends into an error.  Checked per runner: the iterate bit
+for bit the single-GPU result, every rank holding the same norms, the communicator's size, the shim's status word."""
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from openmg_amd import _hip, _hip_dist, launch, operators
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+SHIM = os.path.join(HERE, "fake_rccl", "libfake_rccl.so")
+
+
+def run_ranks(tmp_path, world, mode, shape, grids, n_dist, dtype="float64", extra="", timeout=600):
+    assert os.path.exists(SHIM), "tests/fake_rccl/libfake_rccl.so is not built (__graft_entry__.build() makes it)"
+    os.environ["OMG_RCCL_LIB"] = SHIM                        # (child_env copies os.environ)
+    try:
+        import io
+        err = io.StringIO()
+        code = launch.spawn_ranks(world, [sys.executable, os.path.join(HERE, "rccl_worker.py"), mode, str(tmp_path),
+                                          "x".join(map(str, shape)), str(grids), str(n_dist), dtype, extra],
+                                  timeout_s=timeout, out=err, err=err)
+    finally:
+        del os.environ["OMG_RCCL_LIB"]
+    assert code == 0, err.getvalue()[-4000:]
+    out = [dict(np.load(os.path.join(str(tmp_path), "rank%d.npz" % r))) for r in range(world)]
+    for r, o in enumerate(out):
+        assert int(o["rccl_ranks"]) == world, (r, o["rccl_ranks"])
+        assert str(o["shim"]).startswith("fake_rccl"), o["shim"]
+        assert int(o["shim_status"]) == 0, "rank %d: a bounded wait inside the stand-in gave up" % r
+        assert np.array_equal(o["norms"], out[0]["norms"]), (r, o["norms"], out[0]["norms"])   # all ranks: the same bits
+    return out
+
+
+def plane_reference(shape, grids, n_dist, world):
+    """ONE slab holding every plane (tests/test_gpu_plane_dist.py: bit-identical to the single-GPU hierarchy)."""
+    from test_gpu_plane import hierarchy
+    coef = [[v / 16.0 ** l for v in (-1.0, -1.0, -1.0, 6.0, -1.0, -1.0, -1.0)] for l in range(n_dist)]
+    tshape = tuple(s >> n_dist for s in shape)
+    At, Rt = hierarchy(tshape, grids - n_dist, scale=1.0 / 16.0 ** n_dist)
+    per = int(np.prod(shape)) // world
+    b = np.concatenate([np.random.default_rng([31, r]).random(per) for r in range(world)])
+    x0 = np.concatenate([np.random.default_rng([32, r]).standard_normal(per) for r in range(world)])
+    d = _hip_dist.PlaneDistRank(0, 1, shape, coef, 0.125, _hip.Hierarchy(At, Rt, smoother="colour"))
+    g = _hip_dist.PlaneDistGroup([d])
+    try:
+        d.load(b, x0)
+        norms = g.cycles(2) + g.cycles(1)
+        x = d.fetch()
+        d.load(b, x0)
+        norms += g.cycles(2, pre=1, post=0)
+        x10 = d.fetch()
+    finally:
+        g.close()
+    return norms, x, x10
+
+
+PLANE = [(2, (32, 32, 32), 4, 2, ""), (4, (64, 32, 48), 4, 2, ""), (8, (64, 64, 64), 5, 2, ""), (8, (128, 32, 32), 5, 3, ""),
+         (2, (192, 64, 64), 4, 1, "gate")]
+
+
+@pytest.mark.parametrize("world,shape,grids,n_dist,extra", PLANE)
+def test_plane_slabs_over_the_rccl_call_sites(tmp_path, world, shape, grids, n_dist, extra):
+    """omg_pdist_*: two communicators (cycle + side stream), ghost-plane send / recv both ways, the all-gather below the
+    slabs, the batched norm all-reduce; V(1,1) and the reference's default V(1,0)."""
+    out = run_ranks(tmp_path, world, "plane", shape, grids, n_dist, extra=extra)
+    norms, x, x10 = plane_reference(shape, grids, n_dist, world)
+    got = np.concatenate([o["x"] for o in out])
+    assert np.array_equal(got, x), int(np.sum(got != x))
+    got10 = np.concatenate([o["x10"] for o in out])
+    assert np.array_equal(got10, x10), int(np.sum(got10 != x10))
+    np.testing.assert_allclose(out[0]["norms"], norms, rtol=1e-13)
+
+
+def test_plane_slabs_at_the_eight_gpu_shape(tmp_path):
+    """bench.py --gpus 8's problem itself: (512, 512, 512), 6 grids, eight slabs of 512 x 512 x 64 (then 32, 16 planes)
+    above a replicated 64^3 hierarchy — every rank a process, every exchange through the RCCL call sites."""
+    world, shape, grids, n_dist = 8, (512, 512, 512), 6, 3
+    out = run_ranks(tmp_path, world, "plane", shape, grids, n_dist, timeout=900)
+    norms, x, x10 = plane_reference(shape, grids, n_dist, world)
+    for r in range(world):
+        per = x.size // world
+        assert np.array_equal(out[r]["x"], x[r * per:(r + 1) * per]), r
+        assert np.array_equal(out[r]["x10"], x10[r * per:(r + 1) * per]), r
+    np.testing.assert_allclose(out[0]["norms"], norms, rtol=1e-13)
+    assert norms[2] < norms[1] < norms[0]
+
+
+def sets_reference(shape, grids, smoother, dtype, cycles=4):
+    n = int(np.prod(shape))
+    b = operators.stencil_poisson(shape) @ np.random.default_rng(12345).random(n)
+    R = [operators.restriction(tuple(s // 2 ** l for s in shape)) for l in range(grids - 1)]
+    A = operators.coeffecientList(operators.stencil_poisson(shape), R)
+    with _hip.Hierarchy(A, R, smoother=smoother, omega=0.8, dtype=dtype) as h:
+        h.resident_load(b)
+        norms = [h.resident_cycle(1, 1) for _ in range(cycles)]
+        return norms, h.resident_fetch()
+
+
+SETS = [(2, (32, 32, 32), 4, 3, "float64", "colour"), (4, (64, 32, 64), 4, 2, "float64", "colour"), (8, (64, 64, 64), 5, 2, "float64", "colour"),
+        (4, (32, 32, 32), 4, 2, "float32", "colour"), (2, (16, 16, 16), 3, 2, "float64", "gs"), (2, (16, 16, 16), 3, 2, "float64", "jacobi")]
+
+
+@pytest.mark.parametrize("world,shape,grids,n_dist,dtype,smoother", SETS)
+def test_set_by_set_runner_over_the_rccl_call_sites(tmp_path, world, shape, grids, n_dist, dtype, smoother):
+    """omg_dist_* (Runner): halo send / recv after every smoother set, boundary-first pairs on the second stream, the
+    coarse right-hand side's all-gather / send-recv, norm all-reduces (omg_dist_cycle and the batched omg_dist_cycles)."""
+    out = run_ranks(tmp_path, world, "sets", shape, grids, n_dist, dtype=dtype, extra=smoother)
+    norms, x = sets_reference(shape, grids, smoother, dtype)
+    got = np.concatenate([o["x"] for o in out])
+    if smoother == "colour":
+        assert np.array_equal(got, x), int(np.sum(got != x))
+    else:                                                   # (boundary rows are summed as stored: test_gpu_dist.py)
+        np.testing.assert_allclose(got, x, rtol=1e-12, atol=1e-14)
+    np.testing.assert_allclose(out[0]["norms"], norms, rtol=1e-12 if dtype == "float64" else 1e-5)
+
+
+def slab27_reference(shape, grids, dtype):
+    A0 = operators.stencil27_variable(shape)
+    R = operators.restrictionList(shape, grids - 2, 1)
+    A = operators.coeffecientList(A0, R)
+    n = A0.shape[0]
+    b = A0 @ np.random.default_rng(11).random(n)
+    x0 = np.random.default_rng(12).standard_normal(n)
+    if dtype == "float32":
+        b, x0 = b.astype(np.float32).astype(np.float64), x0.astype(np.float32).astype(np.float64)
+    res = {}
+    norms = []
+    with _hip.Hierarchy(A, R, smoother="colour", dtype=dtype) as h:
+        for pre, post in ((1, 1), (1, 0), (2, 1)):
+            h.resident_load(b, x0)
+            norms += h.resident_cycles(pre, post, 3)
+            res["x%d%d" % (pre, post)] = h.resident_fetch()
+    return norms, res
+
+
+SLAB27 = [(2, (16, 16, 16), 3, 2, "float64"), (4, (32, 16, 32), 4, 3, "float32"), (8, (32, 16, 32), 4, 2, "float64"),
+          (8, (64, 32, 64), 4, 2, "float32")]
+
+
+@pytest.mark.parametrize("world,shape,grids,n_dist,dtype", SLAB27)
+def test_27_point_slabs_over_the_rccl_call_sites(tmp_path, world, shape, grids, n_dist, dtype):
+    """omg_sdist_* (csrc/dist27.hip): the neighbours' coefficient rows at connect, colours 4..7 of the boundary aggregate
+    planes after every sweep, the coarse right-hand side's colours 0..3, the all-gather below the slabs, the batch's norm
+    all-reduce — BASELINE configs[4]'s operator, three sweep-count pairs."""
+    out = run_ranks(tmp_path, world, "slab27", shape, grids, n_dist, dtype=dtype)
+    norms, res = slab27_reference(shape, grids, dtype)
+    for key, want in res.items():
+        got = np.concatenate([o[key] for o in out])
+        assert np.array_equal(got, want), (key, int(np.sum(got != want)))
+    np.testing.assert_allclose(out[0]["norms"], norms, rtol=1e-12 if dtype == "float64" else 1e-6)
+    assert int(out[1]["exchanges"]) == 3 * ((2 + 1) + (n_dist - 1) * (1 + 2 + 1))
+
+
+def test_27_point_slabs_at_the_eight_gpu_rank_shape(tmp_path):
+    """configs[4]'s per-rank shape — a 512 x 512 x 64 slab, fp32 — through dist27.hip's RCCL path: two processes over
+    (128, 512, 512).  Too large for a single-GPU comparison inside the suite's time; the size-independent properties:
+    every rank holds the same norms, they contract, and the two ranks' iterates are finite and differ (each worked)."""
+    world, shape, grids, n_dist = 2, (128, 512, 512), 5, 2
+    out = run_ranks(tmp_path, world, "slab27", shape, grids, n_dist, dtype="float32", timeout=1500)
+    n = out[0]["norms"]
+    assert np.all(np.isfinite(n)) and n[2] < n[1] < n[0]
+    for o in out:
+        assert np.all(np.isfinite(o["x11"])) and np.linalg.norm(o["x11"]) > 0
+
+
+def rehearsal(args, timeout=900):
+    import subprocess
+    env = dict(os.environ, OMG_DIST_SHARED_GPU="rccl", OMG_RCCL_LIB=SHIM)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       text=True, timeout=timeout)
+    assert p.returncode == 0, p.stderr[-4000:]
+    return json.loads(p.stdout.strip().splitlines()[-1])
+
+
+def test_bench_gpus_8_rehearsal_through_the_rccl_call_sites():
+    """`bench.py --gpus 8` end to end — launcher, gloo rendezvous, two communicators, preflight, timed regions, the JSON
+    line with n_gpus = 8 — with the eight rank processes on this GPU."""
+    d = rehearsal(["--gpus", "8", "--no-cpu", "--size", "64", "--steps", "4", "--warmup", "1", "--repeats", "2"])
+    assert d["n_gpus"] == 8 and d["scaling"] == "weak" and d["value"] > 0 and d["steps"] == 4
+    c = d["config"]
+    assert c["ranks_share_one_gpu"] is True and c["rccl_ranks"] == 8 and c["runner"].startswith("plane slabs")
+    assert "RCCL call sites" in c["exchange"]
+    tail = c["norms_last_region_tail"]
+    assert all(np.isfinite(tail)) and tail[-1] < tail[0]
+    for key in ("vs_n1_config2", "vs_one_gpu_same_problem"):
+        assert key in d, key
+
+
+def test_bench_gpus_2_config4_rehearsal_through_the_rccl_call_sites():
+    """`bench.py --gpus 2 --stencil 27var --dtype f32`: BASELINE configs[4]'s runner, two rank processes."""
+    d = rehearsal(["--gpus", "2", "--stencil", "27var", "--dtype", "f32", "--no-cpu", "--size", "32", "--steps", "3", "--warmup", "1", "--repeats", "2"])
+    assert d["n_gpus"] == 2 and d["dtype"] == "f32" and d["value"] > 0
+    c = d["config"]
+    assert c["rccl_ranks"] == 2 and c["runner"].startswith("27-point slabs") and c["ranks_share_one_gpu"] is True
+    tail = c["norms_last_region_tail"]
+    assert all(np.isfinite(tail)) and tail[-1] < tail[0]
