@@ -621,6 +621,22 @@ def main():
             t0 = time.perf_counter()
             x_d, info_d = openmg_amd.mgCycle(A_l, b_h, 0, R_l, prm, initial=x_d)
             calls.append(time.perf_counter() - t0)
+        # the same chain with b, initial and uOut as DEVICE arrays and the list members taken on trust (they are the objects
+        # of the calls above): nothing but the norm crosses PCIe (omg_vcycle_dev)
+        b_t = torch.from_numpy(b_h).cuda()
+        x_t, info_t = openmg_amd.mgCycle(A_l, b_t, 0, R_l, dict(prm, trustOperators=True))
+        dev_calls = []
+        for _ in range(8):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            x_t, info_t = openmg_amd.mgCycle(A_l, b_t, 0, R_l, dict(prm, trustOperators=True), initial=x_t)
+            torch.cuda.synchronize()
+            dev_calls.append(time.perf_counter() - t0)
+        x_chk = None
+        for _ in range(9):
+            x_chk, info_chk = openmg_amd.mgCycle(A_l, b_h, 0, R_l, prm, initial=x_chk)
+        dev_same = bool(np.array_equal(x_t.cpu().numpy(), x_chk)) and info_t["norm"] == info_chk["norm"]
+        del b_t, x_t
         openmg_amd.clear_cache()
         p_s = {"problemShape": (args.size,) * 3, "gridLevels": args.grids - 1, "cycles": 20, "threshold": 0,
                "preIterations": 1, "postIterations": 1, "smoother": "colour", "dtype": np_dtype}
@@ -640,6 +656,10 @@ def main():
                   "mgcycle_call_ms": round(1e3 * statistics.median(calls), 2),
                   "mgcycle_call_ms_all": [round(1e3 * t, 2) for t in calls],
                   "mgcycle_norm": info_d["norm"],
+                  "mgcycle_device_arrays_call_ms": round(1e3 * statistics.median(dev_calls), 3),
+                  "mgcycle_device_arrays_call_ms_all": [round(1e3 * t, 3) for t in dev_calls],
+                  "mgcycle_device_arrays_what": "b, initial, uOut as PyTorch-ROCm tensors, parameters['trustOperators'] = True (no checksum of the "
+                                                "lists: the same objects as the calls before); nine chained calls give the bits of nine host-array calls: %s" % dev_same,
                   "mgsolve_20_cycles_s": round(solve_s, 3), "mgsolve_20_cycles_giveinfo_s": round(solve_info_s, 3),
                   "mgsolve_same_iterate_both_routes": same,
                   "mgsolve_norm": info_s["norm"], "mgsolve_cycles": info_s["cycle"]}
@@ -722,6 +742,32 @@ def main():
                             os.cpu_count() or 0),
                "fine_grid_spmv_GBps": round(cpu_spmv, 2)}
 
+    # What the driver's record keeps of a line is its scalars (nested tables under `config` / `roofline` and the legs' own
+    # objects are dropped): the figures the other legs exist for are therefore ALSO flat scalars of `roofline` / `config`.
+    #  * SURVEY 8(d) as it is worded — the fine-grid SpMV over plain int32 CSR (1 740 111 876 B at 256^3), the `csr_path` leg;
+    #  * the cycle with the reference's own (lexicographic) smoother; BASELINE configs[4]'s cycle and its sweep's fraction;
+    #  * traffic_ratio: HBM bytes the PMC passes counted for the roofline kernel over the bytes it has to move.
+    if csr_path is not None and "fine_grid_spmv" in csr_path:
+        roofline["csr_spmv_bytes"] = csr_path["fine_grid_spmv"]["bytes_per_launch"]
+        roofline["csr_spmv_us"] = csr_path["fine_grid_spmv"]["avg_launch_us"]
+        roofline["csr_spmv_frac"] = csr_path["fine_grid_spmv"]["frac"]
+        roofline["csr_cycle_vcycles_per_s"] = csr_path["vcycles_per_s"]
+    roofline["matrix_free_spmv_frac"] = fine_spmv["frac"]
+    roofline["matrix_free_spmv_us"] = fine_spmv["avg_launch_us"]
+    if dropin is not None:
+        roofline["mgcycle_host_arrays_call_ms"] = dropin["mgcycle_call_ms"]
+        roofline["mgcycle_device_arrays_call_ms"] = dropin["mgcycle_device_arrays_call_ms"]
+    if lex_path is not None:
+        roofline["reference_smoother_vcycles_per_s"] = lex_path["vcycles_per_s"]
+    if config4 is not None:
+        roofline["config4_vcycles_per_s"] = config4.get("vcycles_per_s")
+        roofline["config4_sweep_frac"] = (config4.get("roofline") or {}).get("frac")
+    if roofline.get("traffic") and roofline.get("bytes_per_launch"):
+        roofline["traffic_ratio"] = round(roofline["traffic"] / float(roofline["bytes_per_launch"]), 4)
+    steady_ms = round(1e3 * min(times[len(times) // 2:]) / args.steps, 4)
+    headline_shape = args.size == 256 and w == 8 and plane
+    population = ("fast" if steady_ms <= 0.272 else "slow") if headline_shape else None
+
     out = {
         "metric": "V-cycles/sec, 3-D 7-point Poisson %d^3" % args.size,
         "value": round(args.steps / elapsed, 3),
@@ -752,10 +798,12 @@ def main():
                    # the two kinds of allocation of the finest level's vectors (the level's passes ~7 % apart;
                    # hierarchy.hip place_finest_pool searches for the fast kind at setup): which one this hierarchy ended up with,
                    # by its steady regions (the first regions of any process are ~3 % slower)
-                   "process_population": {"steady_ms_per_step": round(1e3 * min(times[len(times) // 2:]) / args.steps, 4),
+                   "process_population": {"steady_ms_per_step": steady_ms,
                                           "first_region_ms_per_step": round(1e3 * times[0] / args.steps, 4),
-                                          "which": ("fast" if 1e3 * min(times[len(times) // 2:]) / args.steps <= 0.272 else "slow") if (args.size == 256 and w == 8 and plane) else None,
+                                          "which": population,
                                           "rule": "256^3 fp64 headline: steady cycle <= 0.272 ms = the finest level's vectors are the fast kind of allocation (0.258-0.270), above = the slow kind (0.273-0.290); profiles/r05_pool_placement.txt"},
+                   # (the same, flat: the driver's record keeps scalars only)
+                   "process_population_which": population, "process_population_steady_ms": steady_ms,
                    "final_residual_norm": norm,
                    "norms": "every cycle of a timed region computes its residual norm (all K are returned at the region's end): "
                             + ("the up pass of the fine grid leaves the squared residuals of its rows as one partial per workgroup, "

@@ -65,6 +65,8 @@ typedef struct omg_csr_result omg_csr_result; /* device-built CSR waiting to be 
 const char *omg_last_error(void);
 int omg_device_count(int *count);
 int omg_set_device(int device);
+/* every stream of the current device idle (before device arrays another library produced are handed to omg_vcycle_dev) */
+int omg_device_synchronize(void);
 /* Build identification (git-independent): returns a static string. */
 const char *omg_version(void);
 
@@ -182,6 +184,16 @@ int omg_vcycle_ex(omg_hierarchy *h, int level, const double *b, const double *x_
  * OMG_ERR_INVALID.                                                                        */
 int omg_solve(omg_hierarchy *h, const double *b, double *x, int pre, int post,
               int max_cycles, double threshold, int *cycles_done, double *norm);
+
+/* replaces: openmg.mgCycle(A, b, level, R, parameters, initial) (openmg/__init__.py:151-236) for a caller whose b, initial
+ * and uOut are DEVICE arrays (double, natural numbering; e.g. the result of the previous call): omg_vcycle_ex without the
+ * PCIe copies — only the norm comes back to the host; the call returns when the outputs are complete.  x_in_dev NULL:
+ * zeros (:191-192); x_pre_dev (NULL: not wanted; may be x_in_dev) receives the pre-smoothed iterate (Q2).               */
+int omg_vcycle_dev(omg_hierarchy *h, int level, const double *b_dev, const double *x_in_dev, double *x_out_dev,
+                   double *x_pre_dev, int pre, int post, double *norm);
+/* omg_resident_load / omg_resident_fetch for device arrays (mgSolve for a caller on the GPU: openmg/__init__.py:112-138) */
+int omg_resident_load_dev(omg_hierarchy *h, const double *b_dev, const double *x0_dev /* NULL = zeros */);
+int omg_resident_fetch_dev(omg_hierarchy *h, double *x_dev);
 
 /* Device-pointer cycle: b_dev, x_dev are level-0 DEVICE vectors in natural numbering, x starts
  * from zero, work is enqueued on hip_stream (NULL = the hierarchy's own) without host sync. */

@@ -13,13 +13,19 @@ Extra keys understood in the `parameters` dict (ignored by the reference):
     'omega'     relaxation weight for 'jacobi' (default 2/3)
     'dtype'     'float64' (default, the reference's precision) or 'float32': the precision the
                 levels are stored and computed in on the device (inputs / outputs stay float64)
+    'trustOperators'  mgCycle only, default False: when the caller passes the SAME list members (object identity) it
+                passed on an earlier call — e.g. infoDict['A'] / infoDict['R'] handed back unchanged — the per-call
+                checksum of every byte of the lists (what recognises an operator edited in place) is skipped
+
+`b` and `initial` may be DEVICE arrays (objects with `__cuda_array_interface__`, e.g. PyTorch-ROCm tensors: contiguous
+float64): mgCycle / mgSolve then return a device array of the same kind and only the norm crosses PCIe.
 """
 import weakref
 
 import numpy as np
 import scipy.sparse as sp
 
-from . import _hip
+from . import _devarray, _hip
 from . import operators, solvers, tools
 from .solvers import coarseSolve, smooth, smoothToThreshold
 
@@ -108,7 +114,15 @@ def _fingerprint(A, R, n_levels, code, omega, dtype):
     return (tuple(one(M) for M in A[:n_levels]), tuple(one(M) for M in R[:n_levels - 1]), code, omega, dtype)
 
 
-def _hierarchy_for(A, R, n_levels, code, omega, dtype=_hip.DTYPE_F64):
+def _hierarchy_for(A, R, n_levels, code, omega, dtype=_hip.DTYPE_F64, trust=False):
+    if trust:
+        # parameters['trustOperators']: the caller vouches that list members it has passed before are unchanged; an entry
+        # built from the very same objects (identity, not equality) and the same smoother / precision is taken as it is
+        for h, members, how in _cache.values():
+            if (how == (code, omega, dtype) and len(members[0]) == n_levels
+                    and all(a is m for a, m in zip(A[:n_levels], members[0]))
+                    and all(r is m for r, m in zip(R[:n_levels - 1], members[1]))):
+                return h
     key = _fingerprint(A, R, n_levels, code, omega, dtype)
     entry = _cache.get(key)
     if entry is None:
@@ -116,7 +130,7 @@ def _hierarchy_for(A, R, n_levels, code, omega, dtype=_hip.DTYPE_F64):
             _cache.pop(next(iter(_cache)))[0].close()
         members = (list(A[:n_levels]), list(R[:n_levels - 1]))
         h = _hip.Hierarchy(members[0], members[1], smoother=code, omega=omega, dtype=dtype)
-        entry = _cache[key] = (h, members)
+        entry = _cache[key] = (h, members, (code, omega, dtype))
     return entry[0]
 
 
@@ -165,8 +179,13 @@ def mgSolve(A_in, b, parameters):
         A = operators.coeffecientList(A_in, R, dense=dense, verbose=verbose)
         hierarchy = _hip.Hierarchy(A, R, smoother=code, omega=omega, dtype=_dtype_of(parameters))
     depth = parameters["coarsestLevel"]
+    b_on_device = _devarray.is_device_array(b)
     try:
-        hierarchy.resident_load(np.asarray(b, dtype=np.float64).reshape(-1))
+        if b_on_device:
+            _devarray.synchronize()
+            hierarchy.resident_load_dev(_devarray.address(b, hierarchy.sizes[0], "b"))
+        else:
+            hierarchy.resident_load(np.asarray(b, dtype=np.float64).reshape(-1))
         if verbose:
             _announce_descent(depth)
         norm = hierarchy.resident_cycle(pre, post)
@@ -194,7 +213,11 @@ def mgSolve(A_in, b, parameters):
             norm = hierarchy.resident_cycle(pre, post)
             if verbose:
                 print("Residual norm from cycle %d is %f." % (cycle, norm))
-        result = hierarchy.resident_fetch()
+        if b_on_device:
+            result = _devarray.empty_like(b, hierarchy.sizes[0])
+            hierarchy.resident_fetch_dev(_devarray.address(result, hierarchy.sizes[0], "result"))
+        else:
+            result = hierarchy.resident_fetch()
     finally:
         hierarchy.close()
 
@@ -264,16 +287,32 @@ def mgCycle(A, b, level, R, parameters, initial=None):
         raise IndexError("parameters['coarsestLevel'] = %d but only %d operators / %d restrictions given"
                          % (coarsest, len(A), len(R)))
     code, omega = _smoother_of(parameters)
-    b = np.asarray(b, dtype=np.float64).reshape(-1)
+    on_device = _devarray.is_device_array(b)
+    if _devarray.is_device_array(initial) and not on_device:
+        raise TypeError("mgCycle: `initial` is a device array but `b` is not; pass both on the device or both on the host")
+    if not on_device:
+        b = np.asarray(b, dtype=np.float64).reshape(-1)
     if level >= coarsest:
         # the reference's `else` branch (:229-234): direct solve with A[level], norm 0
+        if on_device:
+            raise ValueError("mgCycle at the coarsest level with device arrays: use solvers.coarseSolve on host arrays")
         return solvers.coarseSolve(A[level], b), {"norm": 0}
-    hierarchy = _hierarchy_for(A, R, coarsest + 1, code, omega, _dtype_of(parameters))
+    hierarchy = _hierarchy_for(A, R, coarsest + 1, code, omega, _dtype_of(parameters), trust=bool(parameters.get("trustOperators", False)))
     if parameters.get("verbose", False):
         for l in range(level, coarsest):
             print(l * " " + "calling mgCycle at level %i" % l)
         print(coarsest * " " + "direct solving at level %i" % coarsest)
     pre = parameters["preIterations"]
+    if on_device:
+        # b, initial, uOut in HBM: only the norm crosses PCIe (omg_vcycle_dev).  Q2 as on the host: with pre-smoothing the
+        # caller's `initial` holds the pre-smoothed iterate afterwards; uOut is a new array (:220 / :224).
+        n = hierarchy.sizes[level]
+        _devarray.synchronize()
+        x_in = None if initial is None else _devarray.address(initial, n, "initial")
+        out = _devarray.empty_like(b, n)
+        norm = hierarchy.vcycle_dev(_devarray.address(b, n, "b"), x_in, _devarray.address(out, n, "uOut"),
+                                    x_in if (x_in is not None and pre > 0) else None, pre, parameters["postIterations"], level=level)
+        return out, {"norm": norm}
     x_in = None if initial is None else np.ascontiguousarray(np.asarray(initial, dtype=np.float64).reshape(-1))
     x = np.empty(b.size)                    # uOut is a new array (openmg/__init__.py:220 / :224)
     in_place = (pre > 0 and isinstance(initial, np.ndarray) and initial.dtype == np.float64 and initial.flags.writeable

@@ -74,6 +74,10 @@ SIGNATURES = {
     "omg_format_selftest": (_I, [_CSR, _I, _I64P]),
     "omg_vcycle": (_I, [_P, _I, _P, _P, _I, _I, _DP]),
     "omg_vcycle_ex": (_I, [_P, _I, _P, _P, _P, _P, _I, _I, _DP]),
+    "omg_vcycle_dev": (_I, [_P, _I, _P, _P, _P, _P, _I, _I, _DP]),
+    "omg_resident_load_dev": (_I, [_P, _P, _P]),
+    "omg_resident_fetch_dev": (_I, [_P, _P]),
+    "omg_device_synchronize": (_I, []),
     "omg_solve": (_I, [_P, _P, _P, _I, _I, _I, _D, _IP, _DP]),
     "omg_resident_load": (_I, [_P, _P, _P]),
     "omg_resident_cycle": (_I, [_P, _I, _I, _DP]),
@@ -366,6 +370,21 @@ class Hierarchy:
         check(lib().omg_vcycle_ex(self._h, level, b.ctypes.data, None if x_in is None else x_in.ctypes.data, x_out.ctypes.data,
                                   None if x_pre is None else x_pre.ctypes.data, int(pre), int(post), ctypes.byref(norm)))
         return norm.value
+
+    def vcycle_dev(self, b_ptr, x_in_ptr, x_out_ptr, x_pre_ptr, pre, post, level=0):
+        """omg_vcycle_dev: vcycle_ex on DEVICE arrays given by address (double, natural numbering; 0 / None: absent).
+        Returns the norm; the outputs are complete on return."""
+        norm = ctypes.c_double(0.0)
+        check(lib().omg_vcycle_dev(self._h, level, ctypes.c_void_p(int(b_ptr)), ctypes.c_void_p(int(x_in_ptr or 0)),
+                                   ctypes.c_void_p(int(x_out_ptr)), ctypes.c_void_p(int(x_pre_ptr or 0)), int(pre), int(post),
+                                   ctypes.byref(norm)))
+        return norm.value
+
+    def resident_load_dev(self, b_ptr, x0_ptr=None):
+        check(lib().omg_resident_load_dev(self._h, ctypes.c_void_p(int(b_ptr)), ctypes.c_void_p(int(x0_ptr or 0))))
+
+    def resident_fetch_dev(self, x_ptr):
+        check(lib().omg_resident_fetch_dev(self._h, ctypes.c_void_p(int(x_ptr))))
 
     def solve(self, b, x, pre, post, max_cycles, threshold):
         n = self.sizes[0]

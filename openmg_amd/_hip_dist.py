@@ -277,6 +277,8 @@ class PlaneDistRank:
             check(lib().omg_pdist_cycles_ex(self._h, int(pre), int(post), int(n_cycles), norms))
             out = [float(norms[k]) for k in range(int(n_cycles))]
         else:
+            if (int(pre), int(post)) != (1, 1):
+                raise ValueError("cycles(reduce=...) runs V(1,1) only (omg_pdist_cycles_squares has no sweep counts)")
             check(lib().omg_pdist_cycles_squares(self._h, int(n_cycles), norms))
             out = [float(v) ** 0.5 for v in reduce([float(norms[k]) for k in range(int(n_cycles))])]
         status = self.p2p_status()

@@ -624,7 +624,7 @@ void CoarseSolver<V>::solve(const V *b, V *x, hipStream_t s) const {
     if (P == 0) {
         const int E = std::max(sx, std::max(sy, sz)) <= 16 ? 16 : 32;
         const size_t lds = (size_t(sx + 1) * size_t(sy) * size_t(sz) + 2 + size_t(sx + sy + sz) * size_t(E)) * sizeof(double);
-        static const bool cube16 = [] { const char *e = getenv("OMG_SINE_CUBE16"); return !(e && e[0] == '0'); }();
+        static const bool cube16 = [] { const char *e = experiment_env("OMG_SINE_CUBE16"); return !(e && e[0] == '0'); }();
         if (E == 16 && sx == 16 && sy == 16 && sz == 16 && cube16) {
             hipLaunchKernelGGL((sine_cube16_kernel<V>), dim3(1), dim3(SINE_THREADS), 0, s, b, x, sine.p, lambda.p);
         } else if (E == 16) {

@@ -23,6 +23,19 @@
 
 namespace omg {
 
+// Run-time switches come in two kinds.  The SUPPORTED ones (INTEGRATION.md lists them: paths a test, a tool or the bench
+// selects) are read with getenv.  The switches of past tuning experiments are read through experiment_env: in an ordinary
+// build that is nullptr — the shipped default — and only a library built with -DOMG_EXPERIMENTS listens to them.
+inline const char *experiment_env(const char *name) {
+#ifdef OMG_EXPERIMENTS
+    return getenv(name);
+#else
+    (void)name;
+    return nullptr;
+#endif
+}
+inline bool experiment_flag0(const char *name) { const char *e = experiment_env(name); return e && e[0] == '0'; }   // switched OFF
+
 // ---- errors -------------------------------------------------------------------------
 struct Error : std::runtime_error {
     int code;
@@ -69,6 +82,7 @@ constexpr size_t DEVBUF_SLACK = 64;
 struct ScatteredBlock {
     void *va = nullptr;
     size_t total = 0;
+    size_t chunk = 0;                                           // every hipMemMap of the range covers this many bytes
     std::vector<hipMemGenericAllocationHandle_t> handles;
 };
 std::vector<ScatteredBlock> &scattered_registry();
@@ -165,7 +179,7 @@ inline int pool_placement(int k) {
 // 256 bytes against 106-111 us (two populations) with 0, 128, 512, 1 Ki, 2 Ki, 4 Ki, 64 Ki or 1 Mi.  OMG_VEC_STAGGER
 // overrides the 256.
 inline size_t vector_stagger(int k) {
-    static const long bytes = [] { const char *e = getenv("OMG_VEC_STAGGER"); return e ? atol(e) : 256L; }();
+    static const long bytes = [] { const char *e = experiment_env("OMG_VEC_STAGGER"); return e ? atol(e) : 256L; }();
     return size_t(bytes > 0 ? bytes : 0) / 64 * 64 * size_t(k);
 }
 

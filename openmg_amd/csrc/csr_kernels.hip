@@ -1085,8 +1085,8 @@ __global__ __launch_bounds__(NT) void rows_union_kernel(KArgs<V> a, int blk0, un
 int launch_flags() {
     static int v = -1;
     if (v < 0) {
-        const char *e = getenv("OMG_XCD_REMAP");
-        const char *n = getenv("OMG_NT_LOADS");
+        const char *e = experiment_env("OMG_XCD_REMAP");
+        const char *n = experiment_env("OMG_NT_LOADS");
         v = ((e && e[0] == '1') ? 1 : 0) | ((n && n[0] == '0') ? 0 : 2);
     }
     return v;
@@ -1130,7 +1130,7 @@ void launch_mode(const DevCsrT<V> &A, int64_t blk0, int64_t nblk, const KArgs<V>
         return;
     }
     const int flags = launch_flags();
-    static const int group = [] { const char *e = getenv("OMG_XCD_GROUP"); return e ? atoi(e) : 0; }();
+    static const int group = [] { const char *e = experiment_env("OMG_XCD_GROUP"); return e ? atoi(e) : 0; }();
     const int remap = (nblk < 64) ? 0 : (group > 1 ? group : (flags & 1));
     // small operators live in L2 / Infinity Cache across cycles: keep them cacheable
     const bool ntl = (flags & 2) && A.nnz * int64_t(4 + sizeof(V)) > (int64_t(192) << 20);

@@ -424,7 +424,7 @@ bool blocked_inverse(double *W, int64_t n, const double *keep, double *Minv, hip
     int *const row_flag = tile_flag.p, *const col_flag = tile_flag.p + row_tiles;
     // Look-ahead: the next diagonal block is final as soon as ITS tile of this step's elimination is — the first workgroup of
     // the elimination takes that tile and then inverts the block (gjb_eliminate_kernel); OMG_DENSE_LOOKAHEAD=0: a launch of its own
-    static const bool lookahead = [] { const char *e = getenv("OMG_DENSE_LOOKAHEAD"); return !(e && e[0] == '0'); }();
+    static const bool lookahead = [] { const char *e = experiment_env("OMG_DENSE_LOOKAHEAD"); return !(e && e[0] == '0'); }();
     hipLaunchKernelGGL(gjb_diag_kernel, dim3(1), dim3(256), 0, s, W, ld, int64_t(0), int(std::min<int64_t>(GJB, n)), dinv.p, flag.p);
     for (int64_t k0 = 0; k0 < n; k0 += GJB) {
         const int nb = int(std::min<int64_t>(GJB, n - k0));

@@ -1108,7 +1108,7 @@ struct PDExchange {
     }
     // OMG_PDIST_GATE_DEBUG=1: after a gated pass, wait for it and say what its waits saw (stderr)
     void gate_report(const char *what) {
-        static const bool on = [] { const char *e = getenv("OMG_PDIST_GATE_DEBUG"); return e && e[0] == '1'; }();
+        static const bool on = [] { const char *e = experiment_env("OMG_PDIST_GATE_DEBUG"); return e && e[0] == '1'; }();
         if (!on) return;
         for (PlaneDist *d : ranks) {
             OMG_HIP(hipStreamSynchronize(d->stream));
@@ -1497,7 +1497,7 @@ std::unique_ptr<PlaneDist> pd_create(int rank, int n_ranks, int nx, int ny, int 
             // OMG_DIST_VEC_POOL=1: one allocation for the three vectors the passes stream side by side, as hierarchy.hip
             // pooled_vectors does for whole grids (there: -2.6 % per cycle).  Measured on a slab with its ghost planes
             // (`bench.py --dist 1`): 0.2944 against 0.2905 ms per cycle — slower, so three allocations stay the default here.
-            static const bool pool_on = [] { const char *e = getenv("OMG_DIST_VEC_POOL"); return e && e[0] == '1'; }();
+            static const bool pool_on = [] { const char *e = experiment_env("OMG_DIST_VEC_POOL"); return e && e[0] == '1'; }();
             if (pool_on) {
                 const size_t MB2 = size_t(2) << 20, bytes = size_t(L.n_ext) * sizeof(double);
                 const size_t span = (bytes + 2 * DEVBUF_SLACK + vector_stagger(2) + MB2 - 1) / MB2 * MB2;
@@ -1560,7 +1560,7 @@ std::unique_ptr<PlaneDist> pd_create(int rank, int n_ranks, int nx, int ny, int 
         // (hierarchy.hip place_finest_pool, profiles/r05_pool_placement.txt), and with one process per GPU the slowest rank
         // sets the cycle.  Candidates (hipMalloc only: a neighbour may map these vectors over hipIpc) until one is good
         // (the passes at 4.5 TB/s of needed bytes) or OMG_PDIST_TRIALS (5) are tried, no more than 16 GB held.
-        static const int trials = [] { const char *e = getenv("OMG_PDIST_TRIALS"); return e && e[0] ? atoi(e) : 5; }();
+        static const int trials = [] { const char *e = experiment_env("OMG_PDIST_TRIALS"); return e && e[0] ? atoi(e) : 5; }();
         const size_t triple = 3 * size_t(L.n_ext) * sizeof(double);
         const int max_trials = int(std::min<size_t>(size_t(std::max(trials, 1)), std::max<size_t>(2, (size_t(16) << 30) / std::max<size_t>(triple, 1))));
         if (!L.pool.p && trials >= 2 && L.n_ext >= (int64_t(1) << 23)) {

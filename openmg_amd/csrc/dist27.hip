@@ -199,7 +199,7 @@ std::unique_ptr<SDist<V>> sd_create(int rank, int n_ranks, int nx, int ny, int n
         {
             // the three vectors the sweeps stream side by side out of one allocation, each 2 MiB-aligned + its stagger, b in the
             // middle: what hierarchy.hip measured for whole grids (configs[4]: + 3 %); OMG_VEC_POOL=0: three allocations
-            static const bool pool_on = [] { const char *e = getenv("OMG_VEC_POOL"); return !(e && e[0] == '0'); }();
+            static const bool pool_on = [] { const char *e = experiment_env("OMG_VEC_POOL"); return !(e && e[0] == '0'); }();
             if (pool_on && nv >= (size_t(1) << 20)) {
                 const size_t MB2 = size_t(2) << 20, bytes = nv * sizeof(V);
                 const size_t span = (bytes + 2 * DEVBUF_SLACK + vector_stagger(2) + MB2 - 1) / MB2 * MB2;

@@ -28,6 +28,21 @@ static std::mutex &scattered_mutex() {
     static std::mutex m;
     return m;
 }
+// Tear a block down the way it was put up: ONE hipMemUnmap per hipMemMap (the runtime unmaps per mapping — a single call over
+// a range of many mappings need not undo any of them, and releasing the handles would then leave the pages mapped: a leak
+// of the whole block for the life of the process), then the handles, then the address range.  Every failure is reported.
+static void scattered_release(ScatteredBlock &blk, size_t mapped) {
+    auto report = [](const char *what, hipError_t e) {
+        if (e == hipSuccess) return;
+        (void)hipGetLastError();
+        fprintf(stderr, "libopenmg_hip: scattered block: %s failed: %s (device memory may stay allocated)\n", what, hipGetErrorString(e));
+    };
+    for (size_t i = 0; i < mapped; ++i) report("hipMemUnmap", hipMemUnmap(static_cast<char *>(blk.va) + i * blk.chunk, blk.chunk));
+    for (auto h : blk.handles) report("hipMemRelease", hipMemRelease(h));
+    blk.handles.clear();
+    if (blk.va) report("hipMemAddressFree", hipMemAddressFree(blk.va, blk.total));
+    blk.va = nullptr;
+}
 void *scattered_alloc(size_t bytes, size_t chunk_bytes) {
     int device = 0;
     if (hipGetDevice(&device) != hipSuccess) return nullptr;
@@ -42,12 +57,8 @@ void *scattered_alloc(size_t bytes, size_t chunk_bytes) {
     const size_t n = (bytes + chunk - 1) / chunk;
     ScatteredBlock blk;
     blk.total = n * chunk;
-    auto undo = [&](size_t mapped) {
-        if (mapped) (void)hipMemUnmap(blk.va, mapped * chunk);
-        for (auto h : blk.handles) (void)hipMemRelease(h);
-        if (blk.va) (void)hipMemAddressFree(blk.va, blk.total);
-        (void)hipGetLastError();
-    };
+    blk.chunk = chunk;
+    auto undo = [&](size_t mapped) { scattered_release(blk, mapped); };
     if (hipMemAddressReserve(&blk.va, blk.total, chunk, nullptr, 0) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
     blk.handles.reserve(n);
     for (size_t i = 0; i < n; ++i) {
@@ -87,9 +98,9 @@ bool scattered_free(void *va) {
         blk = std::move(r[i]);
         r.erase(r.begin() + long(i));
     }
-    (void)hipMemUnmap(blk.va, blk.total);
-    for (auto h : blk.handles) (void)hipMemRelease(h);
-    (void)hipMemAddressFree(blk.va, blk.total);
+    // unlike hipFree, unmapping does not wait for work that still uses the range
+    if (hipDeviceSynchronize() != hipSuccess) (void)hipGetLastError();
+    scattered_release(blk, blk.handles.size());
     return true;
 }
 
@@ -497,7 +508,7 @@ PoolLayout pool_layout(int64_t n) {
 constexpr int64_t POOL_TRIAL_MIN = int64_t(1) << 23;       // levels from 8 M unknowns: the placement of their pool is timed (place_finest_pool)
 template <typename V>
 bool pooled_vectors(Level<V> &L) {
-    static const bool on = [] { const char *e = getenv("OMG_VEC_POOL"); return !(e && e[0] == '0'); }();
+    static const bool on = [] { const char *e = experiment_env("OMG_VEC_POOL"); return !(e && e[0] == '0'); }();
     if (!on || !(L.plane || L.s27) || L.n < (int64_t(1) << 20)) return false;
     if (L.pool.p || L.x.p) return true;
     const PoolLayout q = pool_layout<V>(L.n);
@@ -516,7 +527,7 @@ void pool_views(Level<V> &L, char *base, size_t span, size_t off1, size_t off2) 
     const bool b_mid = env("OMG_POOL_ORDER", 1) != 0;
     L.x.borrow(reinterpret_cast<V *>(base + DEVBUF_SLACK), size_t(L.n));
     // OMG_POOL_TMP_OWN=1 (experiment): x and b from the pool, x's twin an allocation of its own
-    static const bool tmp_own = [] { const char *e = getenv("OMG_POOL_TMP_OWN"); return e && e[0] == '1'; }();
+    static const bool tmp_own = [] { const char *e = experiment_env("OMG_POOL_TMP_OWN"); return e && e[0] == '1'; }();
     if (tmp_own) L.tmp.alloc(size_t(L.n), off1);
     else
     L.tmp.borrow(reinterpret_cast<V *>(base + (b_mid ? 2 : 1) * span + DEVBUF_SLACK + off1), size_t(L.n));
@@ -746,7 +757,7 @@ int cycle_body(Hier<V> *h, int l, int pre, int post, bool want_norm = false, dou
         return want_norm ? NORM_S27 : NORM_NONE;
     }
     // OMG_PLANE_HALVES=1|2 (debugging, not under hipGraph): only the down / only the up pass plane-pipelined
-    static const int halves = [] { const char *e = getenv("OMG_PLANE_HALVES"); return (e && (e[0] == '1' || e[0] == '2')) ? e[0] - '0' : 3; }();
+    static const int halves = [] { const char *e = experiment_env("OMG_PLANE_HALVES"); return (e && (e[0] == '1' || e[0] == '2')) ? e[0] - '0' : 3; }();
     if (use_plane(h, L, pre, post) && halves == 2 && !x_zero && pre >= 1 && post >= 1) {
         const bool res_done = smooth_level(h, l, pre, FUSE_RESIDUAL, nullptr, first_done);
         residual_level(h, l, L.r.p, res_done);
@@ -911,6 +922,20 @@ void fetch_vec(Hier<V> *h, int l, const V *src, double *host) {
         download_staged(host, L.nat.p, size_t(L.n) * sizeof(double), h->stream);
     }
     check_march(h);
+}
+
+// The same two for a caller whose vectors already live in HBM (double, natural numbering): device-to-device
+template <typename V>
+void load_vec_dev(Hier<V> *h, int l, const double *dev, V *dst) {
+    Level<V> &L = h->lv[l];
+    if (direct_io(L)) OMG_HIP(hipMemcpyAsync(dst, dev, L.n * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    else launch_gather<double, V>(dev, L.ord.identity ? nullptr : L.perm.p, dst, L.n, h->stream);
+}
+template <typename V>
+void fetch_vec_dev(Hier<V> *h, int l, const V *src, double *dev) {
+    Level<V> &L = h->lv[l];
+    if (direct_io(L)) OMG_HIP(hipMemcpyAsync(dev, src, L.n * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    else launch_scatter<V, double>(src, L.ord.identity ? nullptr : L.perm.p, dev, L.n, h->stream);
 }
 
 template <typename V>
@@ -1194,7 +1219,7 @@ std::unique_ptr<Hier<V>> create(int n_levels, const omg_csr *A, const omg_csr *R
             }
             if (L.plane && !pooled_vectors(L)) L.tmp.alloc(L.n, vector_stagger(1));
             if (L.s27 && !pooled_vectors(L)) L.tmp.alloc(L.n);
-            if ((L.plane || L.s27) && !getenv_flag0("OMG_PLANE_LAZY")) L.format_pending = true;
+            if ((L.plane || L.s27) && !experiment_flag0("OMG_PLANE_LAZY")) L.format_pending = true;
             else if (L.s27) { L.format_pending = true; ensure_format(h.get(), l); }      // (from the padded operator)
             else build_format(h.get(), l, A[l], R[l]);
         }
@@ -1223,9 +1248,11 @@ std::unique_ptr<Hier<V>> create(int n_levels, const omg_csr *A, const omg_csr *R
         L.plane->tune(L.xp, L.tp, L.b.p, c, h->stream, l == 0);
         OMG_HIP(hipStreamSynchronize(h->stream));
     }
+    // (first: the coarse factorisation's kernels on their own stream beside the timed passes would make a candidate look slow
+    // and the decision depend on the overlap)
+    { SetupTimer tm("wait for the coarse factorisation"); inverter.join(); }
     place_finest_pool(h.get());
     place_s27_tiles(h.get());
-    { SetupTimer tm("wait for the coarse factorisation"); inverter.join(); }
     if (inv_code != OMG_OK) throw Error(inv_code, inv_msg);
     OMG_HIP(hipStreamSynchronize(h->stream));
     return h;
@@ -1384,9 +1411,11 @@ std::unique_ptr<Hier<V>> create_from_fine(const omg_csr &A0, int dim, const int6
         L.plane->tune(L.xp, L.tp, L.b.p, c, h->stream, l == 0);
         OMG_HIP(hipStreamSynchronize(h->stream));
     }
+    // (first: the coarse factorisation's kernels on their own stream beside the timed passes would make a candidate look slow
+    // and the decision depend on the overlap)
+    { SetupTimer tm("wait for the coarse factorisation"); inverter.join(); }
     place_finest_pool(h.get());
     place_s27_tiles(h.get());
-    { SetupTimer tm("wait for the coarse factorisation"); inverter.join(); }
     if (inv_code != OMG_OK) throw Error(inv_code, inv_msg);
     OMG_HIP(hipStreamSynchronize(h->stream));
     return h;
@@ -1522,6 +1551,10 @@ int omg_device_count(int *count) {
 
 int omg_set_device(int device) {
     return guarded([&] { require_device(); OMG_HIP(hipSetDevice(device)); });
+}
+
+int omg_device_synchronize(void) {
+    return guarded([&] { require_device(); OMG_HIP(hipDeviceSynchronize()); });
 }
 
 int omg_hierarchy_create_ex(int n_levels, const omg_csr *A, const omg_csr *R, int smoother,
@@ -1757,6 +1790,78 @@ int omg_vcycle_ex(omg_hierarchy *h, int level, const double *b, const double *x_
             else if (x_pre && x_in) { if (x_pre != x_in) std::memcpy(x_pre, x_in, size_t(L.n) * sizeof(double)); }
             else if (x_pre) std::memset(x_pre, 0, size_t(L.n) * sizeof(double));
             if (norm) *norm = nv;
+        });
+    });
+}
+
+// omg_vcycle_ex for a caller whose b / initial / uOut are DEVICE arrays (double, natural numbering): openmg.mgCycle
+// (openmg/__init__.py:151-236) chained on the GPU — nothing but the norm (8 bytes) crosses PCIe.  x_in_dev NULL: zeros;
+// x_pre_dev (may be x_in_dev): the iterate after the pre-smoothing (Q2), the input's copy / zeros where none ran.
+int omg_vcycle_dev(omg_hierarchy *h, int level, const double *b_dev, const double *x_in_dev, double *x_out_dev, double *x_pre_dev,
+                   int pre, int post, double *norm) {
+    return guarded([&] {
+        with(h, [&](auto *hh) {
+            using V = value_of<decltype(hh)>;
+            check_level(hh, level);
+            OMG_REQUIRE(b_dev && x_out_dev, "b / x_out is null");
+            OMG_REQUIRE(pre >= 0 && post >= 0, "negative sweep count");
+            auto &L = hh->lv[level];
+            const int last = (int)hh->lv.size() - 1;
+            hh->resident = false;
+            load_vec_dev(hh, level, b_dev, L.b.p);
+            if (x_in_dev) load_vec_dev(hh, level, x_in_dev, L.xp);
+            else OMG_HIP(hipMemsetAsync(L.xp, 0, size_t(L.n) * sizeof(V), hh->stream));
+            const bool want_pre = x_pre_dev && level < last && pre > 0;
+            if (want_pre) {
+                if (hh->pre_buf.n < size_t(L.n)) hh->pre_buf.alloc(size_t(L.n));
+                hh->pre_level = level;
+            }
+            int part = NORM_NONE;
+            try {
+                part = cycle_body(hh, level, pre, post, level < last);
+            } catch (...) {
+                hh->pre_level = -1;
+                throw;
+            }
+            hh->pre_level = -1;
+            if (level < last) finish_norm(hh, level, part);
+            fetch_vec_dev<V>(hh, level, L.xp, x_out_dev);
+            if (want_pre) fetch_vec_dev<V>(hh, level, hh->pre_buf.p, x_pre_dev);
+            else if (x_pre_dev && x_in_dev) { if (x_pre_dev != x_in_dev) OMG_HIP(hipMemcpyAsync(x_pre_dev, x_in_dev, size_t(L.n) * sizeof(double), hipMemcpyDeviceToDevice, hh->stream)); }
+            else if (x_pre_dev) OMG_HIP(hipMemsetAsync(x_pre_dev, 0, size_t(L.n) * sizeof(double), hh->stream));
+            const double nv = level < last ? read_norm(hh) : 0.0;     // (synchronises the stream: the outputs are complete on return)
+            if (level >= last) { OMG_HIP(hipStreamSynchronize(hh->stream)); check_march(hh); }
+            if (norm) *norm = nv;
+        });
+    });
+}
+
+// omg_resident_load / omg_resident_fetch with device arrays (double, natural numbering): mgSolve for a caller on the GPU
+int omg_resident_load_dev(omg_hierarchy *h, const double *b_dev, const double *x0_dev) {
+    return guarded([&] {
+        with(h, [&](auto *hh) {
+            using V = value_of<decltype(hh)>;
+            check_level(hh, 0);
+            OMG_REQUIRE(b_dev, "b is null");
+            auto &L = hh->lv[0];
+            load_vec_dev(hh, 0, b_dev, L.b.p);
+            if (x0_dev) load_vec_dev(hh, 0, x0_dev, L.xp);
+            else OMG_HIP(hipMemsetAsync(L.xp, 0, L.n * sizeof(V), hh->stream));
+            OMG_HIP(hipStreamSynchronize(hh->stream));
+            hh->resident = true;
+        });
+    });
+}
+
+int omg_resident_fetch_dev(omg_hierarchy *h, double *x_dev) {
+    return guarded([&] {
+        with(h, [&](auto *hh) {
+            using V = value_of<decltype(hh)>;
+            check_level(hh, 0);
+            OMG_REQUIRE(hh->resident && x_dev, "nothing resident / x is null");
+            fetch_vec_dev<V>(hh, 0, hh->lv[0].xp, x_dev);
+            OMG_HIP(hipStreamSynchronize(hh->stream));
+            check_march(hh);
         });
     });
 }

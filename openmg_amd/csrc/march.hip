@@ -620,7 +620,10 @@ __global__ __launch_bounds__(64) void line_gs_kernel(V *x, const V *b, const V *
         if (sizeof(V) == 8) {
             // every lane's own row once more: was its numerator one the hoisted reciprocal covers?
             const V left = lane ? s_out[(lane - 1) & 63] : prev;
-            const V xn = lane + 1 < 64 ? __shfl_down(cur.x, 1, 64) : nxt.x;
+            // (both shuffles with every lane active; lane 63's upper neighbour is row base + 64: the NEXT block's lane 0)
+            const V x_down = __shfl_down(cur.x, 1, 64);
+            const V x_next0 = __shfl(nxt.x, 0, 64);
+            const V xn = lane + 1 < 64 ? x_down : x_next0;
             V s = madd(cur.lo, left, V(0));
             s = madd(cur.di, cur.x, s);
             s = madd(cur.up, (base + lane + 1 < n) ? xn : V(0), s);
@@ -813,7 +816,7 @@ bool MarchPlan<V>::build(const omg_csr &A, hipStream_t s) {
         ord.reserve(size_t(g.n_tiles));
         for (int d = 0; d <= g.ntj + g.ntk - 2; ++d)
             for (int K = std::max(0, d - (g.ntj - 1)); K <= std::min(d, g.ntk - 1); ++K) ord.push_back(K * g.ntj + (d - K));
-        const char *e = getenv("OMG_MARCH_ORDER");
+        const char *e = experiment_env("OMG_MARCH_ORDER");
         if (!(e && e[0] == '0')) {
             order.alloc(ord.size());
             order.upload(ord.data(), ord.size(), s);
@@ -848,13 +851,13 @@ void MarchPlan<V>::sweep(V *x, const V *b, hipStream_t s) const {
     a.nx = g.nx; a.ny = g.ny; a.nz = g.nz; a.TJ = g.TJ; a.ntj = g.ntj; a.n_tiles = g.n_tiles;
     a.T = g.T; a.n_grp = g.n_grp; a.n_pat = g.n_pat; a.n = g.nx * g.ny * g.nz;
     a.faceJ = faceJ.p; a.faceK = faceK.p;
-    static const int steps = [] { const char *e = getenv("OMG_MARCH_STEPS"); return e ? atoi(e) : 8; }();   // steps per block
+    static const int steps = [] { const char *e = experiment_env("OMG_MARCH_STEPS"); return e ? atoi(e) : 8; }();   // steps per block
     static const bool debug = [] { const char *e = getenv("OMG_MARCH_DEBUG"); return e && e[0] == '1'; }();
     DevBuf<long long> dbg;
     a.dbg = nullptr;
     if (debug) { dbg.alloc(size_t(8) * g.n_tiles); dbg.zero(s); a.dbg = dbg.p; }
     // workers: one per CU (a pad of dynamic LDS keeps a second one off the CU), each taking tiles until none is left
-    static const int workers = [] { const char *e = getenv("OMG_MARCH_WORKERS"); return e ? atoi(e) : 256; }();
+    static const int workers = [] { const char *e = experiment_env("OMG_MARCH_WORKERS"); return e ? atoi(e) : 256; }();
     const bool persistent = workers > 0 && g.n_tiles > workers;
     const dim3 grid((unsigned)(persistent ? workers : g.n_tiles));
     const size_t pad = persistent ? size_t(56) * 1024 : 0;

@@ -1622,7 +1622,7 @@ bool PlanePlan<V>::build(const omg_csr &A, const omg_csr &R, Ordering &ord, bool
     if ((nx & 1) || (ny & 1) || (!dim2 && (nz & 1)) || ny < 2) return false;
     if (jacobi && !dim2) return false;                 // weighted Jacobi: the 2-D tile passes only
     {
-        const char *e = getenv("OMG_PLANE_2D");
+        const char *e = experiment_env("OMG_PLANE_2D");
         if (dim2 && e && e[0] == '0') return false;
     }
     const int64_t sj = nx, sk = nx * ny;
@@ -1796,7 +1796,7 @@ bool PlanePlan<V>::build_device(const DevCsrPlain &A, int nx, int ny, int nz, do
     if ((nx & 1) || (ny & 1) || (!dim2 && (nz & 1)) || ny < 2) return false;
     if (jacobi && !dim2) return false;
     {
-        const char *e = getenv("OMG_PLANE_2D");
+        const char *e = experiment_env("OMG_PLANE_2D");
         if (dim2 && e && e[0] == '0') return false;
     }
     const int64_t want = dim2 ? 5 * n - 2 * nx - 2 * ny : 7 * n - 2 * (int64_t(nx) * ny + int64_t(ny) * nz + int64_t(nx) * nz);
@@ -1882,15 +1882,15 @@ void PlanePlan<V>::build_slab(int nx, int ny, int nz_own, int ghost, int ghost_c
 template <typename V>
 void PlanePlan<V>::tune(V *x, V *tmp, const V *b, const Coarse &c, hipStream_t s, bool finest) {
     {
-        const char *e = getenv("OMG_PLANE_TUNE");
+        const char *e = experiment_env("OMG_PLANE_TUNE");
         int forced[3];
         if ((e && e[0] == '0') || env_int3("OMG_PLANE_TILE", forced)) return;
     }
     if (g.dim2 || int64_t(g.nx) * g.ny * (g.z_end - g.z_base) < (int64_t(1) << 21)) return;
     // Candidates: the winner of either cost model and the next few of each (OMG_PLANE_TUNE_K per model, default 0: measured in round 4, profiles/r04_plane_tune_candidates.txt: none beat the winners) —
     // neither model predicts the other's winner, nor always the fastest tiling; all are TIMED on the level's own vectors.
-    static const int keep = [] { const char *e = getenv("OMG_PLANE_TUNE_K"); return e ? std::max(0, atoi(e)) : 0; }();
-    static const bool debug = [] { const char *e = getenv("OMG_PLANE_TUNE_DEBUG"); return e && e[0] == '1'; }();
+    static const int keep = [] { const char *e = experiment_env("OMG_PLANE_TUNE_K"); return e ? std::max(0, atoi(e)) : 0; }();
+    static const bool debug = [] { const char *e = experiment_env("OMG_PLANE_TUNE_DEBUG"); return e && e[0] == '1'; }();
     std::vector<PlaneGeom> cand;
     {
         std::vector<std::array<int, 3>> more0, more1;
@@ -1920,7 +1920,7 @@ void PlanePlan<V>::tune(V *x, V *tmp, const V *b, const Coarse &c, hipStream_t s
         for (const auto &t : more0) add(from(t));
         for (const auto &t : more1) add(from(t));
         // OMG_PLANE_TUNE_EXTRA="TX,TY,LZ;TX,TY,LZ;...": more tilings to time on the large levels (a tiling that does not fit is skipped)
-        if (const char *e = getenv("OMG_PLANE_TUNE_EXTRA")) {
+        if (const char *e = experiment_env("OMG_PLANE_TUNE_EXTRA")) {
             const char *q = e;
             while (*q) {
                 int t3[3];
@@ -2280,7 +2280,7 @@ int PlanePlan<V>::gate_lz() const {
     // as many inner chunks as leave most of the edge workgroups a compute unit of their own from the start (the rest
     // follow the first workgroups that finish): 256 compute units, one workgroup each
     const int nxy = g.ntx * g.nty, nzo = g.z_end - g.z_base;
-    static const int forced = [] { const char *e = getenv("OMG_PLANE_GATE_LZ"); return e ? atoi(e) : 0; }();
+    static const int forced = [] { const char *e = experiment_env("OMG_PLANE_GATE_LZ"); return e ? atoi(e) : 0; }();
     if (forced >= 2) return forced / 2 * 2;
     const int chunks = std::max(1, (256 - (2 * nxy * 5 + 5) / 6) / nxy);
     const int lz = ((nzo - 2 * PLANE_EDGE + chunks - 1) / chunks + 1) / 2 * 2;
@@ -2423,7 +2423,7 @@ void PlanePlan<V>::spmv(const V *x, V *y, hipStream_t s) const {
         m.s = a;
         int qt = 1;
         while (qt < a.hq) qt *= 2;                                  // pairs per workgroup row: a power of two >= the half line's pairs
-        static const int wg_threads = [] { const char *e = getenv("OMG_PLANE_SPMV_T"); return (e && atoi(e) == 512) ? 512 : 256; }();
+        static const int wg_threads = [] { const char *e = experiment_env("OMG_PLANE_SPMV_T"); return (e && atoi(e) == 512) ? 512 : 256; }();
         qt = std::min(qt, wg_threads);
         m.qt = qt; m.lpw = wg_threads / qt;
         m.nqt = (a.hq + qt - 1) / qt;

@@ -668,7 +668,7 @@ HostFormat<V> encode_csr(const HostCsr &A, const std::vector<int64_t> &sets_in) 
         // long rows (27-point stencils ...): one thread per row would leave most of the
         // workgroup idle in rows_kernel's row phase, so four lanes share a row and a block holds
         // at most ROWBLK_THREADS / 4 rows per pass
-        const char *e = getenv("OMG_LANES_PER_ROW");
+        const char *e = experiment_env("OMG_LANES_PER_ROW");
         lanes = e ? atoi(e) : (avg > 16.0 ? 4 : 1);
         if (lanes != 4) lanes = 1;
         if (lanes == 4) max_rows = ROWBLK_THREADS / 4;

@@ -761,7 +761,7 @@ static bool s27_geometry(int nx, int ny, int nz, double w, S27Geom &q) {
     q.nl = int64_t(q.hy) * q.hz;
     {
         // small levels: fewer aggregates per lane and one-wave workgroups, so that the launch still spreads over the chip
-        const char *e = getenv("OMG_S27_RG");
+        const char *e = experiment_env("OMG_S27_RG");
         const int forced = e ? atoi(e) : 0;
         for (;;) {
             q.L = (q.hx + q.rg - 1) / q.rg;
@@ -790,7 +790,7 @@ bool Stencil27Plan<V>::tile(const DevCsrPlain &A, const S27Geom &q, int kz_lo, i
     DevBuf<unsigned long long> d_err(1);
     OMG_HIP(hipMemsetAsync(d_err.p, 0xFF, sizeof(unsigned long long), s));
     // (OMG_S27_PLACE: how a large level's tiles are placed — common.h DevBuf::alloc; experiment, default ordinary)
-    static const int place = [] { const char *e = getenv("OMG_S27_PLACE"); return e && e[0] ? atoi(e) : 0; }();
+    static const int place = [] { const char *e = experiment_env("OMG_S27_PLACE"); return e && e[0] ? atoi(e) : 0; }();
     coef.alloc(size_t(8) * size_t(q.ng) * 27 * 64 * size_t(q.rg), 0, n >= (int64_t(1) << 23) ? place : 0);
     coef.zero(s);
     hipLaunchKernelGGL(s27_build_kernel<V>, dim3(unsigned((n + 255) / 256)), dim3(256), 0, s, A.indptr.p, A.indices.p, A.data.p, q.nx, q.ny, q.nz,
@@ -1163,7 +1163,12 @@ __global__ __launch_bounds__(64 * RAP_WAVES) void s27_rap_kernel(const S27RapArg
 #pragma unroll
                 for (int x = x0; x < x1; ++x) sum = __dadd_rn(sum, __dmul_rn(RA[(z * 4 + y) * 4 + x], a.w));
         if (a.coarse_dense) a.coarse_dense[crow * 27 + sl] = sum;
-        if (ctile) ctile[size_t(sl) * 64 * size_t(a.cRG)] = V(sum);
+        if (ctile) {
+            // what s27_build_kernel checks on a fresh level: finite as the level's type, a diagonal that is not zero
+            const V cv = V(sum);
+            if (!isfinite(cv) || (sl == 13 && cv == V(0))) atomicMin(a.err, (1ull << 62) | (unsigned long long)(crow + 1));
+            ctile[size_t(sl) * 64 * size_t(a.cRG)] = cv;
+        }
     }
 }
 
@@ -1196,6 +1201,9 @@ void Stencil27Plan<V>::rap_from(const int32_t *indptr, const double *vals, bool 
     unsigned long long err = 0;
     OMG_HIP(hipMemcpyAsync(&err, d_err.p, sizeof(err), hipMemcpyDeviceToHost, s));
     OMG_HIP(hipStreamSynchronize(s));
+    if (err != ~0ull && (err >> 62))
+        throw Error(OMG_ERR_INVALID, "27-point level: the Galerkin product's row " + std::to_string((err & ~(3ull << 62)) - 1) +
+                                         " of the next level is not finite as the level's type, or its diagonal is zero");
     if (err != ~0ull)
         throw Error(OMG_ERR_INVALID, "27-point level: new coefficient of row " + std::to_string(err - 1) + " is not finite as the level's type, or its diagonal is zero");
     have67 = false;
