@@ -145,6 +145,44 @@ __global__ __launch_bounds__(256) void interior_correct_kernel(const V *__restri
     if (lane == 0) x[perm[o + i]] = y[o + i] - acc;
 }
 
+// One step of the block chain (CoarseSolver P == -1) over block [r0, r0 + m): the workgroup forms the step's vector in LDS
+// — forward t = b_k - A_{k,k-1} z_{k-1}, backward t = A_{k,k+1} x_{k+1}, from the rows' entries outside their block —, then
+// a wave takes four rows of D'_k^-1 at a time.  Forward: z_k = D'^-1 t (and x_k = z_k in the last block); backward:
+// x_k = z_k - D'^-1 t.
+constexpr int CHAIN_ROWS = 16;      // rows of the block per workgroup (four per wave)
+template <typename V, bool BACK>
+__global__ __launch_bounds__(256) void chain_step_kernel(const V *__restrict__ dinv, int64_t m, int64_t r0, const int32_t *__restrict__ ptr,
+                                                         const int32_t *__restrict__ idx, const V *__restrict__ val,
+                                                         const V *__restrict__ b, const V *src, V *z, V *x, int last) {
+    extern __shared__ unsigned char s_raw[];
+    V *s_t = reinterpret_cast<V *>(s_raw);
+    for (int64_t q = threadIdx.x; q < m; q += 256) {
+        V acc = V(0);
+        for (int32_t p = ptr[r0 + q]; p < ptr[r0 + q + 1]; ++p) acc += val[p] * src[idx[p]];
+        s_t[q] = BACK ? acc : b[r0 + q] - acc;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int64_t q0 = int64_t(blockIdx.x) * CHAIN_ROWS + (threadIdx.x >> 6) * 4;
+    V acc[4] = {V(0), V(0), V(0), V(0)};
+    const V *row[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) row[r] = dinv + min(q0 + r, m - 1) * m;
+    for (int64_t j = lane; j < m; j += 64) {
+        const V t = s_t[j];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[r] += row[r][j] * t;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const V v = wsum(acc[r]);
+        if (lane == 0 && q0 + r < m) {
+            if (BACK) x[r0 + q0 + r] = z[r0 + q0 + r] - v;
+            else { z[r0 + q0 + r] = v; if (last) x[r0 + q0 + r] = v; }
+        }
+    }
+}
+
 struct HostSub {            // small host CSR / CSC piece
     std::vector<int32_t> ptr, idx;
     std::vector<double> val;
@@ -422,11 +460,14 @@ void CoarseSolver<V>::build(const HostCsr &A, hipStream_t s) {
     put(d_ptr, plain_ptr, s);
     put(d_idx, A.indices, s);
     put(d_val, A.data, s);
+    {   // OMG_COARSE_CHAIN=1 forces the block chain (tests: small operators through the path large ones take)
+        const char *e = getenv("OMG_COARSE_CHAIN");
+        if ((P == 1 && n > 16384) || (e && e[0] == '1' && n >= 4)) {
+            build_chain(A, d_ptr.p, d_idx.p, d_val.p, s);
+            return;
+        }
+    }
     if (P == 1) {
-        if (n > 16384)
-            throw Error(OMG_ERR_UNSUPPORTED, "coarsest level has " + std::to_string(n) + " unknowns and a half-bandwidth of " +
-                                                 std::to_string(band) + ": neither the explicit inverse (n <= 16384) nor "
-                                                 "substructuring along the band applies — use more gridLevels");
         std::vector<int32_t> ident((size_t)(n));
         for (int64_t i = 0; i < n; ++i) ident[i] = int32_t(i);
         DevBuf<int32_t> d_map;
@@ -578,6 +619,95 @@ void CoarseSolver<V>::build(const HostCsr &A, hipStream_t s) {
     bytes = ((size_t)(h_boff[P]) + (size_t)(g) * (size_t)(g) + corr) * sizeof(V);
 }
 
+// The block chain (common.h CoarseSolver, P == -1).  openmg/solvers.py:16-26 solves ANY coarsest operator; this is the
+// path that has no size limit but memory: n bs values of V for the K inverses.
+template <typename V>
+void CoarseSolver<V>::build_chain(const HostCsr &A, const int32_t *d_ptr, const int32_t *d_idx, const double *d_val, hipStream_t s) {
+    // block size: the half-bandwidth, in multiples of 64 (forced runs on tiny operators: at least 2 blocks where possible)
+    bs = std::max<int64_t>((w + 63) / 64 * 64, 64);
+    {
+        const char *e = getenv("OMG_COARSE_CHAIN_BS");      // (tests: several blocks on small operators; must be >= the half-bandwidth)
+        if (e && atol(e) >= w) bs = atol(e);
+    }
+    bs = std::min(bs, n);
+    K = int((n + bs - 1) / bs);
+    const size_t lds_need = size_t(bs) * sizeof(V);
+    size_t free_b = 0, total_b = 0;
+    OMG_HIP(hipMemGetInfo(&free_b, &total_b));
+    const double need = double(K) * double(bs) * double(bs) * sizeof(V) + 4.0 * double(bs) * double(bs) * sizeof(double);
+    if (lds_need > size_t(128) << 10 || need > 0.8 * double(free_b))
+        throw Error(OMG_ERR_UNSUPPORTED, "coarsest level has " + std::to_string(n) + " unknowns and a half-bandwidth of " + std::to_string(w) +
+                                             ": the block elimination along the band would need " + std::to_string(int64_t(need / 1e9)) +
+                                             " GB of device memory (" + std::to_string(int64_t(free_b / 1e9)) + " GB free) and " +
+                                             std::to_string(lds_need >> 10) + " KB of LDS per step (128) — use more gridLevels");
+    P = -1;
+    // every row's entries outside its own block, original columns (the solve's couplings)
+    HostSub lo, up;
+    lo.ptr.assign(size_t(n) + 1, 0);
+    up.ptr.assign(size_t(n) + 1, 0);
+    for (int64_t r = 0; r < n; ++r) {
+        const int64_t k = r / bs, c0 = k * bs, c1 = std::min(n, c0 + bs);
+        for (int32_t p = A.indptr[r]; p < A.indptr[r + 1]; ++p) {
+            const int64_t c = A.indices[p];
+            if (c < c0) { OMG_REQUIRE(c >= c0 - bs, "block chain: an entry reaches beyond the neighbouring block"); lo.idx.push_back(int32_t(c)); lo.val.push_back(A.data[p]); }
+            else if (c >= c1) { OMG_REQUIRE(c < c1 + bs, "block chain: an entry reaches beyond the neighbouring block"); up.idx.push_back(int32_t(c)); up.val.push_back(A.data[p]); }
+        }
+        lo.ptr[size_t(r) + 1] = int32_t(lo.idx.size());
+        up.ptr[size_t(r) + 1] = int32_t(up.idx.size());
+    }
+    std::vector<V> keep1, keep2;
+    put(lo_ptr, lo.ptr, s); put(lo_idx, lo.idx, s); put_values(lo_val, lo.val, s, keep1);
+    put(up_ptr, up.ptr, s); put(up_idx, up.idx, s); put_values(up_val, up.val, s, keep2);
+    dinv.alloc(size_t(K) * size_t(bs) * size_t(bs));
+    z.alloc(size_t(n));
+    DevBuf<double> W(size_t(bs) * size_t(2 * bs)), inv64(size_t(bs) * size_t(bs)), T(size_t(bs) * size_t(bs)), keep(size_t(bs) * size_t(bs));
+    std::vector<int32_t> rmap(size_t(n), -1);
+    DevBuf<int32_t> d_rmap{size_t(n)}, c_ptr, c_idx, r_ptr, r_idx;
+    DevBuf<double> c_val, r_val;
+    for (int k = 0; k < K; ++k) {
+        const int64_t r0 = int64_t(k) * bs, m = std::min(n, r0 + bs) - r0;
+        if (k > 0) for (int64_t i = r0 - bs; i < r0; ++i) rmap[size_t(i)] = -1;
+        for (int64_t i = 0; i < m; ++i) rmap[size_t(r0 + i)] = int32_t(i);
+        d_rmap.upload(rmap.data(), size_t(n), s);
+        OMG_HIP(hipStreamSynchronize(s));
+        fill_augmented_from_csr(d_ptr, d_idx, d_val, n, d_rmap.p, d_rmap.p, m, W.p, s);          // [D_k | I]
+        if (k > 0) {
+            // D'_k = D_k - A_{k,k-1} (D'_{k-1}^-1 A_{k-1,k}): the couplings are sparse, so the update is two passes over the
+            // previous inverse's entries, not a dense product.  X = D'_{k-1}^-1 A_{k-1,k} (mp x m), column-wise access to
+            // A_{k-1,k}; then the left half of W -= A_{k,k-1} X.
+            const int64_t p0 = r0 - bs, mp = bs;
+            HostSub col, row;                                  // A_{k-1,k} by columns (rows local to block k-1); A_{k,k-1} by rows (columns local)
+            std::vector<std::vector<std::pair<int32_t, double>>> cols{size_t(m)};
+            for (int64_t r = p0; r < r0; ++r)
+                for (int32_t p = up.ptr[size_t(r)]; p < up.ptr[size_t(r) + 1]; ++p) cols[size_t(up.idx[size_t(p)] - r0)].emplace_back(int32_t(r - p0), up.val[size_t(p)]);
+            col.ptr.assign(size_t(m) + 1, 0);
+            for (int64_t c = 0; c < m; ++c) {
+                for (auto &e : cols[size_t(c)]) { col.idx.push_back(e.first); col.val.push_back(e.second); }
+                col.ptr[size_t(c) + 1] = int32_t(col.idx.size());
+            }
+            row.ptr.assign(size_t(m) + 1, 0);
+            for (int64_t q = 0; q < m; ++q) {
+                for (int32_t p = lo.ptr[size_t(r0 + q)]; p < lo.ptr[size_t(r0 + q) + 1]; ++p) { row.idx.push_back(int32_t(lo.idx[size_t(p)] - p0)); row.val.push_back(lo.val[size_t(p)]); }
+                row.ptr[size_t(q) + 1] = int32_t(row.idx.size());
+            }
+            put(c_ptr, col.ptr, s); put(c_idx, col.idx, s); put(c_val, col.val, s);
+            put(r_ptr, row.ptr, s); put(r_idx, row.idx, s); put(r_val, row.val, s);
+            hipLaunchKernelGGL(couple_kernel, dim3(grid1d(mp * m)), dim3(256), 0, s, inv64.p, mp, c_ptr.p, c_idx.p, c_val.p, m, T.p);
+            hipLaunchKernelGGL(schur_kernel, dim3(grid1d(m * m)), dim3(256), 0, s, r_ptr.p, r_idx.p, r_val.p, m, T.p, W.p, 2 * m);
+            OMG_HIP(hipGetLastError());
+        }
+        gauss_jordan_inverse(W.p, m, inv64.p, s, keep.p);
+        hipLaunchKernelGGL((narrow_kernel<V>), dim3(grid1d(m * m)), dim3(256), 0, s, inv64.p, dinv.p + size_t(k) * size_t(bs) * size_t(bs), m * m);
+        OMG_HIP(hipGetLastError());
+        OMG_HIP(hipStreamSynchronize(s));                      // (the host staging of this block is reused)
+    }
+    if (lds_need > size_t(48) << 10) {
+        OMG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(chain_step_kernel<V, false>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_need)));
+        OMG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(chain_step_kernel<V, true>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_need)));
+    }
+    bytes = (size_t(2 * K - 1) * size_t(bs) * size_t(bs)) * sizeof(V);
+}
+
 template <typename V>
 bool CoarseSolver<V>::build_sine(const HostCsr &A, hipStream_t s) {
     int64_t gx = 0, gy = 0, gz = 0;
@@ -639,6 +769,20 @@ void CoarseSolver<V>::solve(const V *b, V *x, hipStream_t s) const {
     }
     if (P == 1) {
         launch_dense_gemv<V>(inv.p, b, x, n, s);
+        return;
+    }
+    if (P == -1) {
+        for (int k = 0; k < K; ++k) {
+            const int64_t r0 = int64_t(k) * bs, m = std::min(n, r0 + bs) - r0;
+            hipLaunchKernelGGL((chain_step_kernel<V, false>), dim3(unsigned((m + CHAIN_ROWS - 1) / CHAIN_ROWS)), dim3(256), size_t(m) * sizeof(V), s,
+                               dinv.p + size_t(k) * size_t(bs) * size_t(bs), m, r0, lo_ptr.p, lo_idx.p, lo_val.p, b, z.p, z.p, x, k == K - 1 ? 1 : 0);
+        }
+        for (int k = K - 2; k >= 0; --k) {
+            const int64_t r0 = int64_t(k) * bs;
+            hipLaunchKernelGGL((chain_step_kernel<V, true>), dim3(unsigned((bs + CHAIN_ROWS - 1) / CHAIN_ROWS)), dim3(256), size_t(bs) * sizeof(V), s,
+                               dinv.p + size_t(k) * size_t(bs) * size_t(bs), bs, r0, up_ptr.p, up_idx.p, up_val.p, b, x, z.p, x, 0);
+        }
+        OMG_HIP(hipGetLastError());
         return;
     }
     hipLaunchKernelGGL((interior_solve_kernel<V>), dim3((unsigned)n_wg), dim3(256), 0, s, binv.p, binv_off.p, blk_off.p,

@@ -510,7 +510,7 @@ void fill_augmented_from_csr(const int32_t *indptr, const int32_t *indices, cons
 template <typename V>
 struct CoarseSolver {
     int64_t n = 0;
-    int P = 1;                        // interior blocks; 1 = explicit inverse; 0 = sine transforms (below)
+    int P = 1;                        // interior blocks; 1 = explicit inverse; 0 = sine transforms, -1 = block chain (below)
     DevBuf<V> inv;                    // P == 1: n x n
     int64_t n_int = 0, g = 0, w = 0;  // interior / separator unknowns, half-bandwidth
     DevBuf<V> binv, sinv;             // concatenated B_k (row-major m_k x m_k); S^-1 (g x g)
@@ -535,6 +535,18 @@ struct CoarseSolver {
     // a hierarchy takes new coefficients (omg_hierarchy_update_fine) — three allocations of hundreds of MB cost ~2 ms per build
     bool retain_workspace = false;
     DevBuf<double> ws_aug, ws_inv64, ws_keep;
+    // P == -1: block elimination ALONG THE BAND, factors in HBM — what is left when neither the explicit inverse (n <= 16384)
+    // nor substructuring (separators and interior blocks through 48 KB of LDS) applies: with blocks of bs >= half-bandwidth
+    // rows the operator is block tridiagonal, D'_0 = D_0, D'_k = D_k - A_{k,k-1} D'_{k-1}^-1 A_{k-1,k}; the K explicit
+    // inverses D'_k^-1 (bs x bs each: n bs values in all) are kept.  A solve is 2 K - 1 dependent launches: forward
+    // z_k = D'_k^-1 (b_k - A_{k,k-1} z_{k-1}), backward x_k = z_k - D'_k^-1 A_{k,k+1} x_{k+1}.  Limited by memory only.
+    int64_t bs = 0;
+    int K = 0;
+    DevBuf<V> dinv;                   // block k at k bs bs, row-major m_k x m_k
+    DevBuf<int32_t> lo_ptr, lo_idx, up_ptr, up_idx;   // every row's entries left of / right of its own block (original columns)
+    DevBuf<V> lo_val, up_val;
+    DevBuf<V> z;
+    void build_chain(const HostCsr &A, const int32_t *d_ptr, const int32_t *d_idx, const double *d_val, hipStream_t s);
     void build(const HostCsr &A, hipStream_t s);
     bool build_sine(const HostCsr &A, hipStream_t s);       // P = 0 when the operator qualifies
     void solve(const V *b, V *x, hipStream_t s) const;     // original numbering, device pointers
