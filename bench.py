@@ -406,6 +406,62 @@ def config0_leg(steps, warmup, repeats, sync_of):
     return out
 
 
+def var7_leg(size, grids, steps, warmup, repeats, sync_of):
+    """A 7-point operator with PER-ROW coefficients (openmg_amd.operators.stencil7_variable: finite volumes of
+    -div(kappa grad u), kappa over two decades) — the ordinary variable-coefficient input of mgSolve — on the headline's
+    grid: size^3, `grids` grids, red-black, V(1,1), fp64.  Large levels run each half of the cycle as one launch (var7.hip);
+    the same hierarchy set by set (omg_hierarchy_use_plane(0)) in the same timed loop beside it, and that both give the same bits."""
+    import numpy as np
+    from openmg_amd import _hip, operators
+    shape = (size,) * 3
+    A0 = operators.stencil7_variable(shape)
+    b = A0 @ np.random.default_rng(12345).random(A0.shape[0])
+    R = operators.restrictionList(shape, grids - 2, 8)
+    A = operators.coeffecientList(A0, R)
+    t0 = time.perf_counter()
+    h = _hip.Hierarchy(A, R, smoother="colour")
+    setup = time.perf_counter() - t0
+    flags = [bool(h.level_flags(l)["var7"]) for l in range(len(R))]
+    h.resident_load(b)
+    times, _, norms = timed_regions(h, sync_of(h), steps, warmup, repeats, 1, 1, ())
+    e = statistics.median(times)
+    # the finest level's two launches, hipEvents on the hierarchy's stream (an untimed region)
+    h.profile_enable(["plane_down", "plane_up"])
+    h.resident_cycles(1, 1, steps)
+    prof = h.profile_read()
+    h.profile_enable(False)
+    x_fused = h.resident_fetch()
+    h.use_plane(False)
+    h.resident_load(b)
+    h.resident_cycles(1, 1, warmup + steps * (repeats + 1))             # (the cycles the fused path has run)
+    same = bool(np.array_equal(h.resident_fetch(), x_fused))
+    h.resident_load(b)
+    times_s, _, _ = timed_regions(h, sync_of(h), steps, warmup, min(repeats, 3), 1, 1, ())
+    es = statistics.median(times_s)
+    n = A0.shape[0]
+    w = 8
+    # what one pass of the finest level has to move, symmetric storage: the diagonal and three couplings (4 w), x read, b read,
+    # x written (3 w) per unknown; + w (+ 4 for its slot) per coarse unknown
+    pass_bytes = 7 * w * n + (w + 4) * (n // 8)
+    out = {"what": "3-D 7-point operator with per-row coefficients (finite volumes, kappa over two decades) %d^3, %d grids, red-black V(1,1), "
+                   "fp64: fused passes on the levels of 128^3 and more (var7.hip), same timed loop as `value`" % (size, len(A)),
+           "vcycles_per_s": round(steps / e, 1), "ms_per_step": round(1e3 * e / steps, 4),
+           "ms_per_step_all": [round(1e3 * t / steps, 4) for t in times],
+           "set_schedule_vcycles_per_s": round(steps / es, 1), "same_bits_as_the_set_schedule": same,
+           "fused_levels": flags, "hierarchy_s": round(setup, 2), "norms_last_region_tail": norms[-2:]}
+    if prof and prof.get("plane_down") and prof["plane_down"][0] and prof.get("plane_up") and prof["plane_up"][0]:
+        d_us = 1e3 * prof["plane_down"][1] / prof["plane_down"][0]
+        u_us = 1e3 * prof["plane_up"][1] / prof["plane_up"][0]
+        out["roofline"] = {"bound": "hbm", "kernel": "var7_pass_kernel<down> of the finest level: last pre-smoothing sweep + residual + restriction in one launch",
+                           "bytes_per_launch": pass_bytes, "avg_launch_us": round(d_us, 1), "up_pass_avg_launch_us": round(u_us, 1),
+                           "achieved": round(pass_bytes / d_us / 1e3, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": round(pass_bytes / d_us / 1e3 / HBM_PEAK_GBS, 4),
+                           "bytes_definition": "per fine unknown: diagonal + three couplings (symmetric storage, 4 w), x read, b read, x written (3 w); per coarse "
+                                               "unknown: right-hand side written (w) + its slot read (4)"}
+    h.close()
+    return out
+
+
 def config1_leg(steps, warmup, repeats, sync_of):
     """BASELINE configs[1]: 2-D 5-point Poisson 1024^2, 4 grids, fp64: weighted Jacobi (the smoother the config names)
     and red-black Gauss-Seidel (fused tile passes), V(1,1), same timed loop."""
@@ -722,6 +778,9 @@ def main():
     if not args.no_config4 and args.dtype == "f64" and args.smoother == "colour":
         _PROBLEM.clear()                               # (the 256^3 7-point operator: 1.9 GB of host memory)
         config4 = config4_leg(args.config4_size, args.grids, max(10, args.steps), 3, min(repeats, 7), syncer)
+    var7 = None
+    if not args.no_config1 and args.dtype == "f64" and args.smoother == "colour":
+        var7 = var7_leg(args.size, args.grids, args.steps, 3, min(repeats, 5), syncer)
     config0 = None
     if not args.no_config1 and args.dtype == "f64":
         config0 = config0_leg(args.steps, 3, min(repeats, 5), syncer)
@@ -759,6 +818,9 @@ def main():
         roofline["mgcycle_device_arrays_call_ms"] = dropin["mgcycle_device_arrays_call_ms"]
     if lex_path is not None:
         roofline["reference_smoother_vcycles_per_s"] = lex_path["vcycles_per_s"]
+    if var7 is not None:
+        roofline["var7_vcycles_per_s"] = var7["vcycles_per_s"]
+        roofline["var7_set_schedule_vcycles_per_s"] = var7["set_schedule_vcycles_per_s"]
     if config4 is not None:
         roofline["config4_vcycles_per_s"] = config4.get("vcycles_per_s")
         roofline["config4_sweep_frac"] = (config4.get("roofline") or {}).get("frac")
@@ -830,6 +892,7 @@ def main():
         "config4": config4,
         "config0": config0,
         "config1": config1,
+        "var7": var7,
         "set_schedule": set_path,
         "csr_path": csr_path,
         "reference_smoother": lex_path,

@@ -131,6 +131,8 @@ int omg_hierarchy_level_fused(const omg_hierarchy *h, int level, int *fused);
 #define OMG_LEVEL_MARCH            32  /* lexicographic Gauss-Seidel runs as one wavefront launch per sweep (march.hip) */
 #define OMG_LEVEL_PLANE            64  /* red-black sweeps of a grid star stencil: each half of a V(>=1, >=1) cycle over this
                                         * level (openmg/__init__.py:201-210 and :214-227) is ONE plane-pipelined launch (plane.hip) */
+#define OMG_LEVEL_VAR7             256 /* 7-point grid stencil with per-row coefficients under the 2x2x2 aggregation, red-black:
+                                        * each half of the cycle over this level is one launch (var7.hip) */
 #define OMG_LEVEL_STENCIL27        128 /* 27-point grid stencil with per-row coefficients under the 2x2x2 aggregation, 8-colour
                                         * Gauss-Seidel (BASELINE configs[4]): the cycle over this level runs the octant-layout
                                         * kernels of stencil27.hip — four launches per sweep, the coefficients streamed once each */

@@ -759,6 +759,41 @@ struct PlanePlan {
             bool sweep = true, int part = PART_ALL, const Gate *gate = nullptr) const;
 };
 
+// ---- 7-point grid stencils with PER-ROW coefficients (var7.hip) ---------------------------------------------------
+// The ordinary real input of mgSolve (openmg/__init__.py:28: any A_in; operators.py:178): -div(kappa grad u) on a grid.
+// A level whose operator holds, in every row, exactly the in-grid neighbours of a 7-point stencil on a lexicographically
+// numbered grid of even extents (columns ascending: -K, -J, -I, diagonal, +I, +J, +K) with ARBITRARY coefficients,
+// restricted by the plain 2 x 2 x 2 aggregation, smoothed red-black (parity colours, what the greedy colouring finds).
+// The set-by-set schedule walks the operator 3.5 times per V(1,1) cycle in eight level launches; here each half of the
+// cycle is ONE launch, as for the constant-coefficient levels (PlanePlan): down = last pre-smoothing sweep + residual +
+// restriction (openmg/__init__.py:201, :209, :210), up = prolongation + correction + first post-smoothing sweep + the
+// norm's squares (:214, :220/:224, :216-222, :227).  A workgroup owns an (x, y) tile with a ring relaxed redundantly
+// (red two cells, black one) and marches along z; the iterate's planes live in LDS, the coefficients — seven arrays in the
+// vectors' own colour layout; or, where the operator is symmetric bit for bit, the diagonal and the three "+" couplings,
+// each read by both rows it couples — are streamed from HBM with unit stride.  Same chains, same division, same bits as
+// the row kernels on the same operator (tests/test_gpu_var7.py against omg_hierarchy_use_plane(0)).
+template <typename V>
+struct Var7Plan {
+    int nx = 0, ny = 0, nz = 0;
+    double w = 0.0;                   // the aggregation's one weight
+    bool sym = false;                 // a(i, j) == a(j, i) bit for bit: the "-" arrays are not kept
+    int tx = 0, ty = 0, lz = 0, ntx = 0, nty = 0, ntz = 0, threads = 0;
+    int64_t n_wg = 0;
+    DevBuf<V> cD, cM[3], cP[3];       // [colour-ordered slot]; M / P index: 0 = I, 1 = J, 2 = K
+    DevBuf<double> partials;          // one per workgroup: the up pass's share of ||b - A x||^2
+    // false: the level does not qualify (nothing changed).  A, R: the caller's CSR in natural numbering; ord: the level's
+    // ordering as the colouring made it (must be the parity ordering, red first).
+    bool build(const omg_csr &A, const omg_csr &R, const Ordering &ord, hipStream_t s);
+    struct Coarse {
+        const int32_t *map = nullptr; // coarse natural index -> slot in the coarse ordering (null: identity)
+        V *b = nullptr;               // down: coarse right-hand side
+        const V *e = nullptr;         // up: coarse correction
+    };
+    // sweep = false: the pass without its relaxation (down leaves x_new untouched: the iterate stays in x_old)
+    void down(const V *x_old, V *x_new, const V *b, bool x_zero, const Coarse &c, hipStream_t s, bool sweep = true) const;
+    void up(const V *x_old, V *x_new, const V *b, const Coarse &c, double *out, hipStream_t s, bool sweep = true) const;
+};
+
 // ---- 27-point grid stencils with per-row coefficients: BASELINE configs[4] (stencil27.hip) ----------------
 // A level whose operator holds, in every row, exactly the in-grid neighbours of a 27-point stencil on a
 // lexicographically numbered grid of even extents (columns ascending: slot s = 9 (dz + 1) + 3 (dy + 1) + dx + 1) with

@@ -159,6 +159,9 @@ struct Level {
     // 27-point grid stencil with per-row coefficients under the 2x2x2 aggregation, 8-colour Gauss-Seidel (BASELINE
     // configs[4]): the cycle over this level runs the octant-layout kernels of stencil27.hip (common.h Stencil27Plan)
     std::unique_ptr<Stencil27Plan<V>> s27;
+    // 7-point grid stencil with per-row coefficients, red-black (the ordinary variable-coefficient input): each half of the
+    // cycle over this level is one launch of var7.hip (common.h Var7Plan); the row-kernel format exists beside it
+    std::unique_ptr<Var7Plan<V>> var7;
     DevBuf<char> pool;               // OMG_VEC_POOL=1: x, tmp, b of a large plane level as three views into ONE allocation
     size_t pool_span = 0, pool_off1 = 0, pool_off2 = 0;      // ... its layout (pool_views)
     // where the matrix-free SpMV of a plane level leaves its product: an allocation of its OWN, made on first use.  Written
@@ -487,7 +490,7 @@ void coarse_solve_level(Hier<V> *h) {
 }
 
 // What a cycle leaves of the entry level's residual norm (openmg/__init__.py:227)
-enum NormState { NORM_NONE = 0, NORM_LAST_SET = 1, NORM_PLANE = 2, NORM_S27 = 3 };
+enum NormState { NORM_NONE = 0, NORM_LAST_SET = 1, NORM_PLANE = 2, NORM_S27 = 3, NORM_VAR7 = 4 };
 
 // Does the cycle over this level run the 27-point kernels of stencil27.hip?  (Switched with the plane passes.)
 // The three vectors a large fused level's passes stream side by side (x, its out-of-place twin, b) come out of ONE
@@ -689,6 +692,11 @@ bool use_s27(const Hier<V> *h, const Level<V> &L) {
     return L.s27 && !h->no_plane;
 }
 
+template <typename V>
+bool use_var7(const Hier<V> *h, const Level<V> &L) {
+    return L.var7 && !h->no_plane;
+}
+
 // Do both halves of a cycle over this level run as plane-pipelined launches?  (Any sweep counts: with
 // pre = 0 or post = 0 — the reference's default is V(1,0), openmg/__init__.py:22-23 — the pass runs
 // without its relaxation.)
@@ -824,6 +832,38 @@ int cycle_body(Hier<V> *h, int l, int pre, int post, bool want_norm = false, dou
             return smooth_level(h, l, post - 1, want_norm ? FUSE_NORM : FUSE_NONE, nullptr, false, post_slot) ? NORM_LAST_SET : NORM_NONE;
         return out ? NORM_PLANE : NORM_NONE;
     }
+    if (use_var7(h, L)) {
+        // 7-point per-row-coefficient level (var7.hip): all but the last pre-smoothing sweep set by set (in place), the last
+        // one inside the down pass; the up pass holds the first post-smoothing sweep and the norm's squares
+        Var7Plan<V> &P = *L.var7;
+        if (pre > 1) smooth_level(h, l, pre - 1, FUSE_NONE, nullptr, first_done);
+        const bool child_zero = l + 1 < last && ((use_var7(h, C) && pre == 1) || (use_plane(h, C, pre, post) && pre == 1) || (use_s27(h, C) && pre >= 1));
+        if (l + 1 < last && !child_zero) {
+            if (!use_s27(h, C)) ensure_format(h, l + 1);
+            OMG_HIP(hipMemsetAsync(C.xp, 0, size_t(C.n) * sizeof(V), h->stream));      // :191-192
+        }
+        typename Var7Plan<V>::Coarse c;
+        c.map = L.r_out.p;
+        c.b = C.b.p;
+        {
+            Prof<V> p(h, l, 5);
+            P.down(L.xp, L.tp, L.b.p, x_zero && pre == 1, c, h->stream, pre >= 1);       // :201 (last sweep), :209, :210
+        }
+        if (pre >= 1) std::swap(L.xp, L.tp);
+        else if (x_zero) OMG_HIP(hipMemsetAsync(L.xp, 0, size_t(L.n) * sizeof(V), h->stream));
+        if (l == h->pre_level) OMG_HIP(hipMemcpyAsync(h->pre_buf.p, L.xp, size_t(L.n) * sizeof(V), hipMemcpyDeviceToDevice, h->stream));
+        cycle_body(h, l + 1, pre, post, false, nullptr, false, nullptr, child_zero);      // :213
+        c.e = C.xp;
+        double *out = (want_norm && post <= 1) ? (post_slot ? post_slot : P.partials.p) : nullptr;
+        {
+            Prof<V> p(h, l, 6);
+            P.up(L.xp, L.tp, L.b.p, c, out, h->stream, post >= 1);                       // :214, :220/:224, first sweep of :216-222 (, :227)
+        }
+        std::swap(L.xp, L.tp);
+        if (post > 1)
+            return smooth_level(h, l, post - 1, want_norm ? FUSE_NORM : FUSE_NONE, nullptr, false, post_slot) ? NORM_LAST_SET : NORM_NONE;
+        return out ? NORM_VAR7 : NORM_NONE;
+    }
     const bool res_done = smooth_level(h, l, pre, FUSE_RESIDUAL, pre_slot, first_done);   // :201 (+ last set's share of :209)
     if (l == h->pre_level) OMG_HIP(hipMemcpyAsync(h->pre_buf.p, L.xp, size_t(L.n) * sizeof(V), hipMemcpyDeviceToDevice, h->stream));
     residual_level(h, l, L.r.p, res_done);                          // :209
@@ -846,6 +886,9 @@ void finish_norm(Hier<V> *h, int l, int state, double *out = nullptr) {
     if (state == NORM_PLANE) {
         Level<V> &L = h->lv[l];
         launch_sum_sqrt(L.plane->partials.p, L.plane->g.n_wg, out ? out : h->norm_dev.p, h->stream);
+    } else if (state == NORM_VAR7) {
+        Level<V> &L = h->lv[l];
+        launch_sum_sqrt(L.var7->partials.p, L.var7->n_wg, out ? out : h->norm_dev.p, h->stream);
     } else if (state == NORM_S27) {
         // the rows the last post-smoothing launch made final have left their squares (segment 3); the others' now
         Level<V> &L = h->lv[l];
@@ -1199,6 +1242,11 @@ std::unique_ptr<Hier<V>> create(int n_levels, const omg_csr *A, const omg_csr *R
         }
         SetupTimer tm("ordering (colouring / level schedule / wavefront plan)");
         order_level(L, A[l], smoother, h->stream);
+        if (smoother == OMG_SMOOTH_GS_COLOUR && !getenv_flag0("OMG_VAR7")) {
+            SetupTimer tv("7-point level with per-row coefficients: does it qualify (+ its coefficient arrays)");
+            std::unique_ptr<Var7Plan<V>> v7(new Var7Plan<V>);
+            if (v7->build(A[l], R[l], L.ord, h->stream)) L.var7 = std::move(v7);
+        }
     }
     for (int l = 0; l < n_levels; ++l) {
         Lv &L = h->lv[l];
@@ -1219,6 +1267,7 @@ std::unique_ptr<Hier<V>> create(int n_levels, const omg_csr *A, const omg_csr *R
             }
             if (L.plane && !pooled_vectors(L)) L.tmp.alloc(L.n, vector_stagger(1));
             if (L.s27 && !pooled_vectors(L)) L.tmp.alloc(L.n);
+            if (L.var7 && !L.tmp.p) L.tmp.alloc(L.n);
             if ((L.plane || L.s27) && !experiment_flag0("OMG_PLANE_LAZY")) L.format_pending = true;
             else if (L.s27) { L.format_pending = true; ensure_format(h.get(), l); }      // (from the padded operator)
             else build_format(h.get(), l, A[l], R[l]);
@@ -1662,7 +1711,8 @@ int omg_hierarchy_level_flags(const omg_hierarchy *h, int level, int *flags) {
                      ((smoothed && hh->lv[level].A.all_union()) ? OMG_LEVEL_UNION_WALK : 0) |
                      ((smoothed && hh->lv[level].march) ? OMG_LEVEL_MARCH : 0) |
                      ((smoothed && hh->lv[level].plane && !hh->no_plane) ? OMG_LEVEL_PLANE : 0) |
-                     ((smoothed && hh->lv[level].s27 && !hh->no_plane) ? OMG_LEVEL_STENCIL27 : 0);
+                     ((smoothed && hh->lv[level].s27 && !hh->no_plane) ? OMG_LEVEL_STENCIL27 : 0) |
+                     ((smoothed && hh->lv[level].var7 && !hh->no_plane) ? OMG_LEVEL_VAR7 : 0);
         });
     });
 }
@@ -2013,7 +2063,7 @@ int omg_resident_cycles(omg_hierarchy *h, int pre, int post, int n_cycles, doubl
             if (!single) ensure_format(hh, 0);
             // (a plane-pipelined cycle with post > 1 ends set by set: its first launch is no PRENORM launch)
             const bool defer = !single && !getenv_flag("OMG_NO_PRENORM") && can_prenorm(hh, hh->lv[0], pre, post) &&
-                               !use_plane(hh, hh->lv[0], pre, post);
+                               !use_plane(hh, hh->lv[0], pre, post) && !use_var7(hh, hh->lv[0]);
             // Deferred norms: cycle k's block partials are collected in slot k of a batch buffer — the
             // last set's by its fused post-smoothing launch, the first set's by cycle k + 1's first
             // launch — and ALL slots of a chunk are added up by one launch at the chunk's end (the

@@ -176,6 +176,41 @@ def _q1_element_stiffness():
     return K, corners
 
 
+def stencil7_variable(shape, seed=2024):
+    """7-point variable-coefficient operator (NOT in the reference; the ordinary real input of mgSolve): cell-centred
+    finite volumes of -div(kappa grad u) on a box of `shape` cells, homogeneous Dirichlet boundary, kappa =
+    exp(U(-1, 1) ln 10) per cell (two decades, as BASELINE configs[4] draws it) from default_rng(seed); the coupling of two
+    cells is the harmonic mean of their coefficients.  Symmetric (bit for bit) positive definite.  C-order numbering,
+    sorted CSR with int32 indices."""
+    shape = tuple(int(s) for s in shape)
+    if len(shape) != 3:
+        raise ValueError("stencil7_variable needs a 3-D shape")
+    nz, ny, nx = shape
+    rng = np.random.default_rng(seed)
+    kap = np.exp(rng.uniform(-1.0, 1.0, size=(nz + 2, ny + 2, nx + 2)) * np.log(10.0))     # cells incl. one boundary layer
+
+    def face(a, b):
+        return 2.0 * a * b / (a + b)
+    c = kap[1:-1, 1:-1, 1:-1]
+    w = {(0, 0, -1): face(c, kap[1:-1, 1:-1, :-2]), (0, 0, 1): face(c, kap[1:-1, 1:-1, 2:]),
+         (0, -1, 0): face(c, kap[1:-1, :-2, 1:-1]), (0, 1, 0): face(c, kap[1:-1, 2:, 1:-1]),
+         (-1, 0, 0): face(c, kap[:-2, 1:-1, 1:-1]), (1, 0, 0): face(c, kap[2:, 1:-1, 1:-1])}
+    diag = ((((w[(-1, 0, 0)] + w[(0, -1, 0)]) + w[(0, 0, -1)]) + w[(0, 0, 1)]) + w[(0, 1, 0)]) + w[(1, 0, 0)]
+    n = nx * ny * nz
+    idx = np.arange(n, dtype=np.int64).reshape(nz, ny, nx)
+    rows, cols, vals = [idx.ravel()], [idx.ravel()], [diag.ravel()]
+    for (dz, dy, dx), ww in w.items():
+        sel = (slice(max(0, -dz), nz - max(0, dz)), slice(max(0, -dy), ny - max(0, dy)), slice(max(0, -dx), nx - max(0, dx)))
+        rows.append(idx[sel].ravel())
+        cols.append((idx[sel] + (dz * ny + dy) * nx + dx).ravel())
+        vals.append(-ww[sel].ravel())
+    A = sp.csr_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(n, n))
+    A.sort_indices()
+    A.indices = A.indices.astype(np.int32)
+    A.indptr = A.indptr.astype(np.int32)
+    return A
+
+
 def stencil27_variable(shape, seed=2024, rows=None):
     """27-point variable-coefficient operator of BASELINE.json configs[4] as SURVEY.md 8(d)
     specifies it (NOT in the reference): Q1 finite-element stiffness of -div(kappa grad u) on a
