@@ -65,6 +65,9 @@ typedef struct omg_csr_result omg_csr_result; /* device-built CSR waiting to be 
 const char *omg_last_error(void);
 int omg_device_count(int *count);
 int omg_set_device(int device);
+/* free / total memory of the current device (hipMemGetInfo): what a caller sizes its problem by; tests check that
+ * destroying a hierarchy gives everything back */
+int omg_device_mem_info(int64_t *free_bytes, int64_t *total_bytes);
 /* every stream of the current device idle (before device arrays another library produced are handed to omg_vcycle_dev) */
 int omg_device_synchronize(void);
 /* Build identification (git-independent): returns a static string. */

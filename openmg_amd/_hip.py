@@ -78,6 +78,7 @@ SIGNATURES = {
     "omg_resident_load_dev": (_I, [_P, _P, _P]),
     "omg_resident_fetch_dev": (_I, [_P, _P]),
     "omg_device_synchronize": (_I, []),
+    "omg_device_mem_info": (_I, [_I64P, _I64P]),
     "omg_solve": (_I, [_P, _P, _P, _I, _I, _I, _D, _IP, _DP]),
     "omg_resident_load": (_I, [_P, _P, _P]),
     "omg_resident_cycle": (_I, [_P, _I, _I, _DP]),
@@ -201,6 +202,13 @@ def lib():
 def check(code):
     if code != OMG_OK:
         raise HipError(code, lib().omg_last_error().decode("utf-8", "replace"))
+
+
+def device_mem_info():
+    """(free, total) bytes of the current device."""
+    f, t = ctypes.c_int64(0), ctypes.c_int64(0)
+    check(lib().omg_device_mem_info(ctypes.byref(f), ctypes.byref(t)))
+    return f.value, t.value
 
 
 def device_count():

@@ -1602,6 +1602,17 @@ int omg_set_device(int device) {
     return guarded([&] { require_device(); OMG_HIP(hipSetDevice(device)); });
 }
 
+int omg_device_mem_info(int64_t *free_bytes, int64_t *total_bytes) {
+    return guarded([&] {
+        OMG_REQUIRE(free_bytes && total_bytes, "null argument");
+        require_device();
+        size_t f = 0, t = 0;
+        OMG_HIP(hipMemGetInfo(&f, &t));
+        *free_bytes = int64_t(f);
+        *total_bytes = int64_t(t);
+    });
+}
+
 int omg_device_synchronize(void) {
     return guarded([&] { require_device(); OMG_HIP(hipDeviceSynchronize()); });
 }

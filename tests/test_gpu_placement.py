@@ -44,18 +44,15 @@ def test_scattered_candidates_are_given_back(monkeypatch):
     """Every candidate of the placement searches — hipMalloc or scattered pieces mapped with the virtual-memory API — is
     device memory again once the hierarchy is gone: free memory (hipMemGetInfo) after create / destroy with scattered
     candidates forced is what it was (round 5's ADVICE: one hipMemUnmap over many mappings need not undo any)."""
-    import torch
     shape = (256, 128, 256)
     A0 = operators.stencil_poisson(shape)
     monkeypatch.setenv("OMG_POOL_PLACE", "2")
     monkeypatch.setenv("OMG_POOL_TRIALS", "3")
     monkeypatch.setenv("OMG_PLACE_KEEP_LAST", "1")
     run(A0, shape, 3, "float64")                          # (code object, streams, caches: allocated once)
-    torch.cuda.synchronize()
-    free0 = torch.cuda.mem_get_info()[0]
+    free0 = _hip.device_mem_info()[0]
     for _ in range(3):
         run(A0, shape, 3, "float64")
-    torch.cuda.synchronize()
-    free1 = torch.cuda.mem_get_info()[0]
+    free1 = _hip.device_mem_info()[0]
     # three hierarchies x three candidates of 3 x 67 MB: a leak would be >= 600 MB
     assert free0 - free1 < 64 << 20, (free0, free1)
