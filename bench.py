@@ -331,7 +331,7 @@ def config4_leg(size, grids, steps, warmup, repeats, sync_of):
         us = 1e3 * ms / cnt
         traffic, traffic_src = None, None
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r05_pmc_s27_sweep.json")))
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r06_pmc_s27_sweep.json")))
             if pmc.get("kernel_src_sha") == kernel_source_hash() and size == 256:
                 traffic = pmc["traffic_bytes"]
                 traffic_src = "NOT measured in this run: rocprofv3 --pmc passes of the same build, " + pmc["source"]
@@ -604,7 +604,7 @@ def main():
         # (DESIGN.md §5): per fine unknown 3 w (x read, b read, x written), per coarse unknown w (its right-hand
         # side) + 4 (its slot in the coarse ordering).  The operator itself costs nothing: seven coefficients.
         bytes_roof = fmt_b["plane_down"]
-        traffic, traffic_src, rocprof_us = pmc_traffic("r05_pmc_plane_down.json", bytes_roof, w)
+        traffic, traffic_src, rocprof_us = pmc_traffic("r06_pmc_plane_down.json", bytes_roof, w)
         achieved = bytes_roof / avg_s / 1e9
         roofline = {"bound": "hbm", "kernel": "plane_kernel<down>: fine-grid red-black sweep + residual + restriction in one launch (plane.hip)",
                     "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -615,8 +615,8 @@ def main():
                     "avg_launch_us": round(avg_s * 1e6, 2), "avg_launch_us_source": "hipEvents on the kernel's own stream inside the timed regions",
                     "avg_launch_us_rocprof": rocprof_us,
                     "avg_launch_us_rocprof_source": "NOT measured in this run: rocprofv3's average duration of the same kernel of the same build "
-                                                    "(profiles/r05_pmc_plane_down.json; per grid size over a whole bench run: "
-                                                    "profiles/r05_bench_kernel_stats_by_grid.txt)" if rocprof_us else None,
+                                                    "(profiles/r06_pmc_plane_down.json; per grid size over a whole bench run: "
+                                                    "profiles/r06_bench_kernel_stats_by_grid.txt)" if rocprof_us else None,
                     "launches_timed": launches,
                     "csr_equiv_bytes": int(csr_b["plane_down"]), "csr_equiv_GBps": round(csr_b["plane_down"] / avg_s / 1e9, 1),
                     "tiling": h.plane_info(0),

@@ -105,6 +105,9 @@ def test_variable_coefficient_cycle_against_the_oracle(monkeypatch, size, grid_l
     xs, info = openmg_amd.mgSolve(A0, b, dict(p))
     assert abs(info["norm"] - inf["norm"]) <= 1e-10 * inf["norm"]
     np.testing.assert_allclose(xs, xo, rtol=1e-9, atol=1e-12 * np.abs(xo).max())
+    # without giveInfo mgSolve sets up on the device; a level no device-side check takes sends it through the host route
+    # (omg_hierarchy_create_from_fine falls back): the same hierarchy, the same bits
+    assert np.array_equal(openmg_amd.mgSolve(A0, b, dict(p, giveInfo=False)), xs)
 
 
 def test_mgcycle_drop_in_q2_on_a_variable_coefficient_level(monkeypatch):

@@ -1,9 +1,9 @@
 #!/bin/bash
 # Everything under profiles/rNN_* from ONE gpurun call (run from the repository root on the GPU box):
-#     gpurun -- "OMG_GIT_HEAD=$(git rev-parse HEAD) bash tools/collect_profiles.sh r05"
+#     gpurun -- "OMG_GIT_HEAD=$(git rev-parse HEAD) bash tools/collect_profiles.sh r06"
 # (the variable goes INSIDE the command: gpurun does not forward the caller's environment, and the box has no .git)
 # writes gpurun_out/fin/<prefix>_*; copy what is to be judged into profiles/.
-p=${1:-r05}
+p=${1:-r06}
 root=$(cd "$(dirname "$0")/.." && pwd)
 out=$root/gpurun_out/fin
 rm -rf "$out"; mkdir -p "$out"
@@ -64,5 +64,16 @@ cd /tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/upd -o u -- python3 $root/tools/update_probe.py 256 5 > /dev/null 2>&1
 grep -E "Name|gjb_|s27_rap|s27_build|extract_inverse|copy_block|narrow_kernel|fill_aug|csr_scatter" $out/upd/u_kernel_stats.csv > $out/${p}_update_kernel_stats.csv
 cd "$root"
-rm -rf $out/trace $out/cyc $out/lex $out/pmc $out/pmc27 $out/peer0 $out/peer1 $out/c4b $out/c4s $out/upd
+# round 6: the 7-point per-row-coefficient passes (var7.hip), the coarse solve beyond the old limits, the N > 1 RCCL call sites
+# with 8 / 2 rank processes on this GPU (tests/fake_rccl: rehearsals, not scaling measurements)
+timeout 300 python tools/var7_probe.py 256 2>&1 | tail -4 > $out/${p}_var7.txt
+timeout 600 python tools/coarse_chain_probe.py 64 2>&1 | tail -5 > $out/${p}_coarse_chain.txt
+make -C tests/fake_rccl > /dev/null 2>&1
+OMG_DIST_SHARED_GPU=rccl OMG_RCCL_LIB=$root/tests/fake_rccl/libfake_rccl.so timeout 900 python bench.py --gpus 8 --no-cpu --size 128 --steps 10 --warmup 2 --repeats 3 2>/dev/null | tail -1 > $out/${p}_bench_gpus8_rehearsal_shared_gpu.json
+OMG_DIST_SHARED_GPU=rccl OMG_RCCL_LIB=$root/tests/fake_rccl/libfake_rccl.so timeout 900 python bench.py --gpus 2 --stencil 27var --dtype f32 --no-cpu --size 64 --steps 10 --warmup 2 --repeats 3 2>/dev/null | tail -1 > $out/${p}_bench_gpus2_27var_rehearsal_shared_gpu.json
+cd /tmp
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/v7 -o v -- python3 $root/tools/var7_probe.py 256 > /dev/null 2>&1
+grep -E "Name|var7_pass" $out/v7/v_kernel_stats.csv > $out/${p}_var7_kernel_stats.csv
+cd "$root"
+rm -rf $out/trace $out/v7 $out/cyc $out/lex $out/pmc $out/pmc27 $out/peer0 $out/peer1 $out/c4b $out/c4s $out/upd
 ls -la $out
