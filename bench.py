@@ -459,6 +459,20 @@ def var7_leg(size, grids, steps, warmup, repeats, sync_of):
                            "bytes_definition": "per fine unknown: diagonal + three couplings (symmetric storage, 4 w), x read, b read, x written (3 w); per coarse "
                                                "unknown: right-hand side written (w) + its slot read (4)"}
     h.close()
+    # the same operator with the reference's OWN smoother (lexicographic Gauss-Seidel, openmg/solvers.py:56-68; the default of
+    # the drop-in): per-row coefficients have no pattern table — a third wave streams the rows' coefficients (march.hip, round 6;
+    # as a level schedule of 3 n - 2 launches per sweep this cycle took 18 ms)
+    t0 = time.perf_counter()
+    hl = _hip.Hierarchy(A, R, smoother="gs")
+    setup_l = time.perf_counter() - t0
+    hl.resident_load(b)
+    lsteps = max(4, steps // 2)
+    times_l, _, norms_l = timed_regions(hl, sync_of(hl), lsteps, 2, min(repeats, 3), 1, 1, ())
+    el = statistics.median(times_l)
+    out["reference_smoother"] = {"vcycles_per_s": round(lsteps / el, 1), "ms_per_step": round(1e3 * el / lsteps, 4),
+                                 "wavefront_levels": [bool(hl.level_flags(l)["march"]) for l in range(len(R))],
+                                 "hierarchy_s": round(setup_l, 2), "norms_last_region_tail": norms_l[-2:]}
+    hl.close()
     return out
 
 
@@ -821,6 +835,7 @@ def main():
     if var7 is not None:
         roofline["var7_vcycles_per_s"] = var7["vcycles_per_s"]
         roofline["var7_set_schedule_vcycles_per_s"] = var7["set_schedule_vcycles_per_s"]
+        roofline["var7_reference_smoother_vcycles_per_s"] = var7["reference_smoother"]["vcycles_per_s"]
     if config4 is not None:
         roofline["config4_vcycles_per_s"] = config4.get("vcycles_per_s")
         roofline["config4_sweep_frac"] = (config4.get("roofline") or {}).get("frac")

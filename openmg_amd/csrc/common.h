@@ -590,6 +590,11 @@ struct MarchPlan {
     // three arrays (a row without a neighbour: a zero coefficient)
     bool line1 = false;
     DevBuf<V> tri;                    // [3][n]: -I, diagonal, +I
+    // More than 256 distinct rows (per-row coefficients: the ordinary variable-coefficient input): no pattern table — every
+    // row's seven coefficients as the tiles consume them, [tile][step][8][lane], streamed by a third wave of the workgroup
+    // into an LDS ring one block ahead of the computing wave (round 6)
+    bool per_row = false;
+    DevBuf<V> rowc;
     // false: the operator is not such a stencil (the caller keeps the level schedule)
     bool build(const omg_csr &A, hipStream_t s);
     void sweep(V *x, const V *b, hipStream_t s) const;   // one in-place lexicographic sweep

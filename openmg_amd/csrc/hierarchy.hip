@@ -1242,7 +1242,8 @@ std::unique_ptr<Hier<V>> create(int n_levels, const omg_csr *A, const omg_csr *R
         }
         SetupTimer tm("ordering (colouring / level schedule / wavefront plan)");
         order_level(L, A[l], smoother, h->stream);
-        if (smoother == OMG_SMOOTH_GS_COLOUR && !getenv_flag0("OMG_VAR7")) {
+        // (OMG_PLANE=0 asks for the set-by-set schedule: no fused path of any kind)
+        if (smoother == OMG_SMOOTH_GS_COLOUR && !getenv_flag0("OMG_VAR7") && !getenv_flag0("OMG_PLANE")) {
             SetupTimer tv("7-point level with per-row coefficients: does it qualify (+ its coefficient arrays)");
             std::unique_ptr<Var7Plan<V>> v7(new Var7Plan<V>);
             if (v7->build(A[l], R[l], L.ord, h->stream)) L.var7 = std::move(v7);

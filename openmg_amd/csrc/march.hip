@@ -55,6 +55,7 @@ struct MarchArgs {
     const V *b;
     const uint32_t *codes;
     const V *coef;
+    const V *rowc;       // per-row mode: [tile][step][8][lane]
     const int32_t *order;
     uint32_t *sync;
     V *faceJ, *faceK;
@@ -173,18 +174,30 @@ constexpr int RING = 4;            // blocks of results between the computing wa
 //     them), and a write-through face store takes about a microsecond.  It hands each block's results
 //     to the STORING wave through an LDS ring; that wave writes x, the face slots the +J / +K tiles
 //     wait for, and "unset" into the slots this tile has consumed.
-template <typename V, int U>
-__global__ __launch_bounds__(128) void march_gs_kernel(MarchArgs<V> a) {
-    __shared__ V s_coef[256 * 8];
+//   * ROWS (per-row coefficients): a third, LOADING wave streams the rows' coefficients — [tile][step][8][lane] in HBM, unit
+//     stride across the wave — into an LDS ring CRING blocks deep (the launch's dynamic LDS, which also keeps a second
+//     worker off the compute unit), one block ahead of the computing wave, and forms each row's refined reciprocal on the way;
+//     the computing wave reads its row's eight entries where the pattern table's entries were read.
+constexpr int CRING = 3;
+template <typename V, int U, bool ROWS>
+__global__ __launch_bounds__(ROWS ? 192 : 128) void march_gs_kernel(MarchArgs<V> a) {
+    constexpr int NTH = ROWS ? 192 : 128;
+    __shared__ V s_coef[ROWS ? 8 : 256 * 8];
     __shared__ V s_ring[RING][U][64];
     __shared__ int s_tile;
     __shared__ int s_ready, s_taken;           // blocks the computing wave has put into the ring / the storing wave has taken out
+    __shared__ int s_cready;                   // ROWS: blocks of coefficients the loading wave has put into its ring
+    extern __shared__ __attribute__((aligned(16))) unsigned char march_dyn[];
+    V *const s_cring = reinterpret_cast<V *>(march_dyn);      // ROWS: [CRING][U][8][64]
     const int lane = threadIdx.x & 63;
-    const bool storer = threadIdx.x >= 64;
-    for (int q = threadIdx.x; q < a.n_pat * 8; q += 128) {
-        V c = a.coef[q];
-        if ((q & 7) == 7) c = refined_rcp(a.coef[q - 4]);
-        s_coef[q] = c;
+    const bool storer = threadIdx.x >= 64 && threadIdx.x < 128;
+    const bool loader = ROWS && threadIdx.x >= 128;
+    if (!ROWS) {
+        for (int q = threadIdx.x; q < a.n_pat * 8; q += NTH) {
+            V c = a.coef[q];
+            if ((q & 7) == 7) c = refined_rcp(a.coef[q - 4]);
+            s_coef[q] = c;
+        }
     }
     // A workgroup is a WORKER: it takes tiles by ticket until none is left.  Tickets run along the wavefront (a.order:
     // anti-diagonals of the tile grid), so the tiles a tile takes faces from (earlier tickets) are done or in some
@@ -199,6 +212,7 @@ __global__ __launch_bounds__(128) void march_gs_kernel(MarchArgs<V> a) {
         s_tile = int(t) < a.n_tiles ? (a.order ? a.order[t] : (int)t) : -1;
         s_ready = 0;
         s_taken = 0;
+        s_cready = 0;
     }
     __syncthreads();
     const int tile = __builtin_amdgcn_readfirstlane(s_tile);
@@ -231,7 +245,35 @@ __global__ __launch_bounds__(128) void march_gs_kernel(MarchArgs<V> a) {
     auto lds_flag = [&](int *f) { return __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
     auto lds_set = [&](int *f, int v) { __hip_atomic_store(f, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
 
-    if (storer) {
+    if (loader) {
+        // block blk of this tile's coefficients into ring slot blk % CRING, once the computing wave is done with block
+        // blk - CRING (s_ready counts the blocks it has finished)
+        const V *src = a.rowc + size_t(tile) * size_t(n_blk * U) * 512 + lane;
+        for (int blk = 0; blk < n_blk; ++blk) {
+            int polls = 0;
+            while (lds_flag(&s_ready) < blk - CRING + 1 && polls < STORE_SPIN_LIMIT) {
+                if (polls < 4096) __builtin_amdgcn_s_sleep(1);
+                else __builtin_amdgcn_s_sleep(32);
+                ++polls;
+            }
+            if (polls >= STORE_SPIN_LIMIT) spins = SPIN_LIMIT;
+            asm volatile("" ::: "memory");
+            V *const dst = s_cring + size_t(blk % CRING) * (U * 512) + lane;
+#pragma unroll
+            for (int u = 0; u < U; u += 2) {
+                V v[16];
+#pragma unroll
+                for (int e = 0; e < 16; ++e) v[e] = src[(size_t(blk) * U + u) * 512 + e * 64];
+                v[7] = refined_rcp(v[3]);
+                v[15] = refined_rcp(v[11]);
+#pragma unroll
+                for (int e = 0; e < 16; ++e) dst[u * 512 + e * 64] = v[e];
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (lane == 0) lds_set(&s_cready, blk + 1);
+        }
+        if (__any(spins >= SPIN_LIMIT) && lane == 0) store_through(a.sync + 2, 1u);
+    } else if (storer) {
         const __amdgpu_buffer_rsrc_t xw = __builtin_amdgcn_make_buffer_rsrc(a.x, 0, unsigned(a.n) * unsigned(sizeof(V)), 0x00020000);
         for (int blk = 0; blk < n_blk; ++blk) {
             const int i0 = blk * U - skew;
@@ -321,8 +363,10 @@ __global__ __launch_bounds__(128) void march_gs_kernel(MarchArgs<V> a) {
 #pragma unroll
             for (int u = 0; u < U; ++u) d.ek[u] = buffer_at(xr, line + i0 + u + offK, V(0));
         }
+        if (!ROWS) {
 #pragma unroll
-        for (int w = 0; w < U / 4; ++w) d.codes[w] = a.codes[(size_t(tile) * a.n_grp + blk * (U / 4) + w) * 64 + lane];
+            for (int w = 0; w < U / 4; ++w) d.codes[w] = a.codes[(size_t(tile) * a.n_grp + blk * (U / 4) + w) * 64 + lane];
+        }
     };
     // ... and the relaxed values of the -J / -K tiles' last lines (face slots)
     auto prefetch_faces = [&](int blk, Block &d) {
@@ -348,6 +392,7 @@ __global__ __launch_bounds__(128) void march_gs_kernel(MarchArgs<V> a) {
     // UNI: every row of the block has the same pattern, its table entries are in cu[] (no LDS reads)
     V cu[8];
     int cu_code = -1;
+    const V *cring_blk = s_cring + lane;       // ROWS: the current block's coefficients in the loading wave's ring
     auto steps = [&](auto full_tag, auto fast_tag, auto uni_tag, int i0, const Block &cur, V (&out)[U]) {
         constexpr bool FULL = decltype(full_tag)::value;
         constexpr bool FAST = decltype(fast_tag)::value;
@@ -358,7 +403,10 @@ __global__ __launch_bounds__(128) void march_gs_kernel(MarchArgs<V> a) {
             const int i = i0 + u;
             const bool act = FULL || (valid && i >= 0 && i < nx);
             V c[8];
-            if (UNI) {
+            if (ROWS) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) c[e] = cring_blk[u * 512 + e * 64];
+            } else if (UNI) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) c[e] = cu[e];
             } else {
@@ -418,7 +466,7 @@ __global__ __launch_bounds__(128) void march_gs_kernel(MarchArgs<V> a) {
         return true;
     };
 
-    int taken_seen = 0;
+    int taken_seen = 0, cready_seen = 0;
     auto wait_at_least = [&](int *flag, int need, int &seen) {
         if (seen >= need) return;
         long long t0 = 0;
@@ -465,7 +513,11 @@ __global__ __launch_bounds__(128) void march_gs_kernel(MarchArgs<V> a) {
         // 3. U steps
         V out[U];
         const bool full = whole && T0 >= max_skew && T0 + U <= nx;     // every lane is inside its line for all U steps
-        if (full && uniform_pattern(cur)) steps_checked(std::true_type(), std::true_type(), i0, cur, out);
+        if (ROWS) {
+            wait_at_least(&s_cready, blk + 1, cready_seen);
+            cring_blk = s_cring + size_t(blk % CRING) * (U * 512) + lane;
+        }
+        if (!ROWS && full && uniform_pattern(cur)) steps_checked(std::true_type(), std::true_type(), i0, cur, out);
         else if (full) steps_checked(std::true_type(), std::false_type(), i0, cur, out);
         else steps_checked(std::false_type(), std::false_type(), i0, cur, out);
         // 4. hand the results to the storing wave
@@ -710,6 +762,7 @@ bool MarchPlan<V>::build(const omg_csr &A, hipStream_t s) {
     std::vector<uint8_t> code((size_t)n);
     std::vector<std::vector<Pat>> local(nt);
     std::atomic<bool> ok(true);
+    std::atomic<bool> many(false);            // more than 256 distinct rows: the per-row form (below) instead of the pattern table
     auto scan = [&](int t) {
         const int64_t lo = n * t / nt, hi = n * (t + 1) / nt;
         std::vector<Pat> &pats = local[t];
@@ -739,7 +792,7 @@ bool MarchPlan<V>::build(const omg_csr &A, hipStream_t s) {
             size_t f = 0;
             while (f < pats.size() && memcmp(&pats[f], &p, sizeof(Pat))) ++f;
             if (f == pats.size()) {
-                if (pats.size() >= 256) { ok = false; return; }
+                if (pats.size() >= 256) { many = true; ok = false; return; }
                 pats.push_back(p);
             }
             hit = f;
@@ -752,19 +805,56 @@ bool MarchPlan<V>::build(const omg_csr &A, hipStream_t s) {
         scan(0);
         for (auto &q : th) q.join();
     }
-    if (!ok) return false;
     std::vector<Pat> pats;
     std::vector<std::vector<uint8_t>> remap(nt);
-    for (int t = 0; t < nt; ++t)
-        for (const Pat &p : local[t]) {
-            size_t f = 0;
-            while (f < pats.size() && memcmp(&pats[f], &p, sizeof(Pat))) ++f;
-            if (f == pats.size()) {
-                if (pats.size() >= 256) return false;
-                pats.push_back(p);
+    if (ok) {
+        for (int t = 0; t < nt && !many; ++t)
+            for (const Pat &p : local[t]) {
+                size_t f = 0;
+                while (f < pats.size() && memcmp(&pats[f], &p, sizeof(Pat))) ++f;
+                if (f == pats.size()) {
+                    if (pats.size() >= 256) { many = true; break; }
+                    pats.push_back(p);
+                }
+                remap[t].push_back((uint8_t)f);
             }
-            remap[t].push_back((uint8_t)f);
-        }
+    }
+    if (!ok && !many) return false;
+    const bool rows_mode = many.load();
+    if (rows_mode) {
+        // (OMG_MARCH_ROWS=0: operators with more than 256 distinct rows keep the level schedule, as before round 6)
+        const char *e = getenv("OMG_MARCH_ROWS");
+        if (e && e[0] == '0') return false;
+        // the whole operator once more: the same structural test, no table
+        std::atomic<bool> fine(true);
+        auto check = [&](int t) {
+            const int64_t lo = n * t / nt, hi = n * (t + 1) / nt;
+            for (int64_t r = lo; r < hi && fine.load(std::memory_order_relaxed); ++r) {
+                const int64_t i = r % nx, jl = (r / nx) % ny, kl = r / sk;
+                int last = -1;
+                double diag = 0.0;
+                for (int64_t q = A.indptr[r]; q < A.indptr[r + 1]; ++q) {
+                    const int64_t off = int64_t(A.indices[q]) - r;
+                    int slot = -1;
+                    if (off == 0) { slot = 3; diag = A.data[q]; }
+                    else if (off == -1 && i > 0) slot = 2;
+                    else if (off == 1 && i + 1 < nx) slot = 4;
+                    else if (off == -sj && jl > 0) slot = 1;
+                    else if (off == sj && jl + 1 < ny) slot = 5;
+                    else if (off == -sk && kl > 0) slot = 0;
+                    else if (off == sk && kl + 1 < nz) slot = 6;
+                    if (slot <= last) { fine = false; return; }
+                    last = slot;
+                }
+                if (!(std::fabs(diag) >= 0x1p-400 && std::fabs(diag) <= 0x1p400)) { fine = false; return; }
+            }
+        };
+        std::vector<std::thread> th;
+        for (int t = 1; t < nt; ++t) th.emplace_back(check, t);
+        check(0);
+        for (auto &q : th) q.join();
+        if (!fine) return false;
+    }
 
     g.nx = (int)nx; g.ny = (int)ny; g.nz = (int)nz;
     g.TJ = nz > 1 ? 8 : 64;
@@ -776,9 +866,56 @@ bool MarchPlan<V>::build(const omg_csr &A, hipStream_t s) {
     g.n_grp = 2 * ((g.T + 7) / 8);
     g.n_pat = (int)pats.size();
 
+    per_row = rows_mode;
+    if (rows_mode) {
+        // every row's seven coefficients as the tiles consume them: [tile][step][8][lane], steps padded to whole blocks of 8
+        // (entry 7 — the refined reciprocal of the diagonal — is formed by the loading wave); a step outside the lane's line:
+        // zeros and a diagonal of one
+        const int Tpad = (g.T + 7) / 8 * 8;
+        if (uint64_t(g.n_tiles) * uint64_t(Tpad) * 512u * sizeof(V) > (uint64_t(24) << 30)) return false;
+        std::vector<V> rc(size_t(g.n_tiles) * size_t(Tpad) * 512, V(0));
+        auto fill = [&](int t) {
+            for (int tile = t; tile < g.n_tiles; tile += nt) {
+                const int J = tile % g.ntj, K = tile / g.ntj;
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int jj = lane % g.TJ, kk = lane / g.TJ;
+                    const int j = J * g.TJ + jj, k = K * g.TK + kk;
+                    const bool valid = j < g.ny && k < g.nz;
+                    const int64_t line = valid ? (int64_t(k) * ny + j) * nx : 0;
+                    for (int st = 0; st < Tpad; ++st) {
+                        V *const o = rc.data() + (size_t(tile) * size_t(Tpad) + size_t(st)) * 512 + size_t(lane);
+                        const int i = st - jj - kk;
+                        o[3 * 64] = V(1);
+                        if (!valid || i < 0 || i >= nx) continue;
+                        const int64_t r = line + i;
+                        const int64_t jl = (r / nx) % ny, kl = r / sk;
+                        for (int64_t q = A.indptr[r]; q < A.indptr[r + 1]; ++q) {
+                            const int64_t off = int64_t(A.indices[q]) - r;
+                            int slot = 3;
+                            if (off == -1) slot = 2;
+                            else if (off == 1) slot = 4;
+                            else if (off == -sj && jl > 0) slot = 1;
+                            else if (off == sj && jl + 1 < ny) slot = 5;
+                            else if (off == -sk && kl > 0) slot = 0;
+                            else if (off == sk && kl + 1 < nz) slot = 6;
+                            o[size_t(slot) * 64] = V(A.data[q]);
+                        }
+                    }
+                }
+            }
+        };
+        std::vector<std::thread> th;
+        for (int t = 1; t < nt; ++t) th.emplace_back(fill, t);
+        fill(0);
+        for (auto &q : th) q.join();
+        rowc.alloc(rc.size());
+        rowc.upload(rc.data(), rc.size(), s);
+        OMG_HIP(hipStreamSynchronize(s));
+    }
     // the codes as the tiles consume them: one 4-byte word per (tile, group of four steps, lane)
-    std::vector<uint32_t> words(size_t(g.n_tiles) * g.n_grp * 64);
+    std::vector<uint32_t> words(rows_mode ? size_t(64) : size_t(g.n_tiles) * g.n_grp * 64);
     auto arrange = [&](int t) {
+        if (rows_mode) return;
         for (int tile = t; tile < g.n_tiles; tile += nt) {
             const int J = tile % g.ntj, K = tile / g.ntj;
             for (int lane = 0; lane < 64; ++lane) {
@@ -847,7 +984,7 @@ void MarchPlan<V>::sweep(V *x, const V *b, hipStream_t s) const {
         return;
     }
     MarchArgs<V> a;
-    a.x = x; a.b = b; a.codes = codes.p; a.coef = coef.p; a.sync = sync.p; a.order = order.p;
+    a.x = x; a.b = b; a.codes = codes.p; a.coef = coef.p; a.rowc = rowc.p; a.sync = sync.p; a.order = order.p;
     a.nx = g.nx; a.ny = g.ny; a.nz = g.nz; a.TJ = g.TJ; a.ntj = g.ntj; a.n_tiles = g.n_tiles;
     a.T = g.T; a.n_grp = g.n_grp; a.n_pat = g.n_pat; a.n = g.nx * g.ny * g.nz;
     a.faceJ = faceJ.p; a.faceK = faceK.p;
@@ -861,17 +998,29 @@ void MarchPlan<V>::sweep(V *x, const V *b, hipStream_t s) const {
     const bool persistent = workers > 0 && g.n_tiles > workers;
     const dim3 grid((unsigned)(persistent ? workers : g.n_tiles));
     const size_t pad = persistent ? size_t(56) * 1024 : 0;
+    if (per_row) {
+        // the loading wave's ring IS the dynamic LDS (98 KB in double: nothing else fits beside it on the compute unit)
+        const size_t ring = size_t(CRING) * 8 * 512 * sizeof(V);
+        static bool allowed_rows = false;
+        if (!allowed_rows) {
+            OMG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(march_gs_kernel<V, 8, true>), hipFuncAttributeMaxDynamicSharedMemorySize, int(ring)));
+            allowed_rows = true;
+        }
+        hipLaunchKernelGGL((march_gs_kernel<V, 8, true>), grid, dim3(192), ring, s, a);
+        OMG_HIP(hipGetLastError());
+    } else {
     if (pad) {
         static bool allowed = false;                          // (per instantiation of sweep<V>)
         if (!allowed) {
-            OMG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(march_gs_kernel<V, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, int(pad)));
-            OMG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(march_gs_kernel<V, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, int(pad)));
+            OMG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(march_gs_kernel<V, 4, false>), hipFuncAttributeMaxDynamicSharedMemorySize, int(pad)));
+            OMG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(march_gs_kernel<V, 8, false>), hipFuncAttributeMaxDynamicSharedMemorySize, int(pad)));
             allowed = true;
         }
     }
-    if (steps == 4) hipLaunchKernelGGL((march_gs_kernel<V, 4>), grid, dim3(128), pad, s, a);
-    else hipLaunchKernelGGL((march_gs_kernel<V, 8>), grid, dim3(128), pad, s, a);
+    if (steps == 4) hipLaunchKernelGGL((march_gs_kernel<V, 4, false>), grid, dim3(128), pad, s, a);
+    else hipLaunchKernelGGL((march_gs_kernel<V, 8, false>), grid, dim3(128), pad, s, a);
     OMG_HIP(hipGetLastError());
+    }
     if (debug) {
         std::vector<long long> h(size_t(8) * g.n_tiles);
         dbg.download(h.data(), h.size(), s);
