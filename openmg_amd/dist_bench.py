@@ -223,7 +223,12 @@ def main_slab27(args, rank, world, shape, grids, n_levels, all_gather, td, torch
     rccl_ranks = r.rccl_ranks()
     r.sync()
     td.barrier()
-    base = one_gpu_baselines_slab27(args, shape, grids, torch, np_dtype) if rank == 0 and world > 1 else None
+    base = None
+    if rank == 0 and world > 1:
+        try:
+            base = one_gpu_baselines_slab27(args, shape, grids, torch, np_dtype)
+        except Exception as e:                                  # noqa: BLE001
+            base = {"n1_config4_ms_per_cycle": None, "one_gpu_same_problem_ms_per_cycle": None, "note": None, "error": "%s: %s" % (type(e).__name__, e)}
     td.barrier()
     if rank == 0:
         equiv = n_glob / float(256 ** 3)
@@ -517,7 +522,12 @@ def main_plane(args, rank, world, shape, grids, n_levels, all_gather, td, torch,
     rccl_ranks = r.rccl_ranks()
     r.sync()
     td.barrier()
-    base = one_gpu_baselines_plane(args, shape, grids, torch) if rank == 0 and world > 1 else None
+    base = None
+    if rank == 0 and world > 1:
+        try:                                                    # (a baseline that fails must not cost the run its line)
+            base = one_gpu_baselines_plane(args, shape, grids, torch)
+        except Exception as e:                                  # noqa: BLE001
+            base = {"n1_config2_ms_per_cycle": None, "one_gpu_same_problem_ms_per_cycle": None, "error": "%s: %s" % (type(e).__name__, e)}
     td.barrier()
     if rank == 0:
         equiv = n_glob / float(256 ** 3)
