@@ -440,9 +440,9 @@ def var7_leg(size, grids, steps, warmup, repeats, sync_of):
     es = statistics.median(times_s)
     n = A0.shape[0]
     w = 8
-    # what one pass of the finest level has to move, symmetric storage: the diagonal and three couplings (4 w), x read, b read,
-    # x written (3 w) per unknown; + w (+ 4 for its slot) per coarse unknown
-    pass_bytes = 7 * w * n + (w + 4) * (n // 8)
+    # what one pass of the finest level has to move: the row's seven coefficients (7 w), x read, b read, x written (3 w) per
+    # unknown; + w (+ 4 for its slot) per coarse unknown
+    pass_bytes = 10 * w * n + (w + 4) * (n // 8)
     out = {"what": "3-D 7-point operator with per-row coefficients (finite volumes, kappa over two decades) %d^3, %d grids, red-black V(1,1), "
                    "fp64: fused passes on the levels of 128^3 and more (var7.hip), same timed loop as `value`" % (size, len(A)),
            "vcycles_per_s": round(steps / e, 1), "ms_per_step": round(1e3 * e / steps, 4),
@@ -456,7 +456,7 @@ def var7_leg(size, grids, steps, warmup, repeats, sync_of):
                            "bytes_per_launch": pass_bytes, "avg_launch_us": round(d_us, 1), "up_pass_avg_launch_us": round(u_us, 1),
                            "achieved": round(pass_bytes / d_us / 1e3, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": round(pass_bytes / d_us / 1e3 / HBM_PEAK_GBS, 4),
-                           "bytes_definition": "per fine unknown: diagonal + three couplings (symmetric storage, 4 w), x read, b read, x written (3 w); per coarse "
+                           "bytes_definition": "per fine unknown: the row's seven coefficients (7 w), x read, b read, x written (3 w); per coarse "
                                                "unknown: right-hand side written (w) + its slot read (4)"}
     h.close()
     # the same operator with the reference's OWN smoother (lexicographic Gauss-Seidel, openmg/solvers.py:56-68; the default of

@@ -535,8 +535,12 @@ bool Var7Plan<V>::build(const omg_csr &A, const omg_csr &R, const Ordering &ord,
             if (j + 1 < gy && std::memcmp(&hP[1][size_t(sl)], &hM[1][size_t(slot(i, j + 1, k))], sizeof(V)) != 0) symm = false;
             if (k + 1 < gz && std::memcmp(&hP[2][size_t(sl)], &hM[2][size_t(slot(i, j, k + 1))], sizeof(V)) != 0) symm = false;
         }
-        sym = symm;
-        if (const char *e = getenv("OMG_VAR7_SYM")) { if (e[0] == '0') sym = false; }       // (tests: the seven-array form on a symmetric operator)
+        // Measured at 256^3 fp64 (profiles/r06_var7.txt): the four-array form is no faster than the seven-array one (0.940
+        // against 0.925 ms per cycle) — a coupling's second reader comes an interval or two after its first, and by then an
+        // XCD's 32 workgroups have pushed it out of the L2 — so the seven arrays are the default and OMG_VAR7_SYM=1 asks for
+        // the symmetric form where the operator allows it.
+        const char *e = getenv("OMG_VAR7_SYM");
+        sym = symm && e && e[0] == '1';
     }
     nx = int(gx); ny = int(gy); nz = int(gz);
     w = wv;

@@ -41,7 +41,7 @@ print("setup %.2f s; level flags %s" % (time.perf_counter() - t, h.level_flags(0
 h.resident_load(b)
 norms = h.resident_cycles(1, 1, 10)
 t0 = time.perf_counter()
-h.resident_cycles(1, 1, 40)
+h.resident_cycles(1, 1, int(os.environ.get("PROBE_CYCLES", "40")))
 dt = (time.perf_counter() - t0) / 40
 print("variable-coefficient 7-point %d^3: %.3f ms per cycle, %.1f V-cycles/s; norms %.3e -> %.3e; sets %d" % (size, 1e3 * dt, 1 / dt, norms[0], norms[-1], h.level_sets(0)))
 x_fused = h.resident_fetch()
@@ -49,7 +49,7 @@ h.use_plane(False)
 h.resident_load(b)
 h.resident_cycles(1, 1, 10)
 t0 = time.perf_counter()
-h.resident_cycles(1, 1, 40)
+h.resident_cycles(1, 1, int(os.environ.get("PROBE_CYCLES", "40")))
 dt = (time.perf_counter() - t0) / 40
 print("... the same hierarchy set by set (omg_hierarchy_use_plane(0)): %.3f ms per cycle, %.1f V-cycles/s; same bits: %s" % (1e3 * dt, 1 / dt, np.array_equal(h.resident_fetch(), x_fused)))
 print(h.format_info(0, "A", 0))
