@@ -786,9 +786,15 @@ struct Var7Plan {
     int64_t n_wg = 0;
     DevBuf<V> cD, cM[3], cP[3];       // [colour-ordered slot]; M / P index: 0 = I, 1 = J, 2 = K
     DevBuf<double> partials;          // one per workgroup: the up pass's share of ||b - A x||^2
-    // false: the level does not qualify (nothing changed).  A, R: the caller's CSR in natural numbering; ord: the level's
-    // ordering as the colouring made it (must be the parity ordering, red first).
-    bool build(const omg_csr &A, const omg_csr &R, const Ordering &ord, hipStream_t s);
+    // false: the level does not qualify (nothing changed).  A, R: the caller's CSR in natural numbering.  true: ord = the
+    // level's colour ordering in closed form (parity colours, red first — what the greedy colouring of such a stencil gives,
+    // without its sequential pass over the rows; OMG_PLANE_CHECK_ORDER=1 compares the two).
+    bool build(const omg_csr &A, const omg_csr &R, Ordering &ord, hipStream_t s);
+    // The operator and the restriction as the caller's CSR had them (natural numbering, ascending columns; the values as the
+    // level holds them): what the row kernels' format of the level is built from when something asks for it
+    // (hierarchy.hip ensure_format) — a cycle over the fused passes never does.
+    HostCsr operator_csr(hipStream_t s) const;
+    HostCsr restriction_csr() const;
     struct Coarse {
         const int32_t *map = nullptr; // coarse natural index -> slot in the coarse ordering (null: identity)
         V *b = nullptr;               // down: coarse right-hand side

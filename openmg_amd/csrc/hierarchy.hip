@@ -1138,8 +1138,8 @@ void ensure_format(Hier<V> *h, int l) {
     if (l + 1 < (int)h->lv.size()) materialise_ordering(h->lv[l + 1].ord);   //  orderings as device arrays only until here)
     // (a 27-point level: from the operator PADDED to 27 entries per row, so that the row kernels associate every row's
     // sum as the kernels of stencil27.hip do)
-    const HostCsr A = L.s27 ? L.s27->operator_csr(h->stream) : L.plane->operator_csr();
-    const HostCsr R = L.s27 ? L.s27->restriction_csr() : L.plane->restriction_csr();
+    const HostCsr A = L.s27 ? L.s27->operator_csr(h->stream) : L.var7 ? L.var7->operator_csr(h->stream) : L.plane->operator_csr();
+    const HostCsr R = L.s27 ? L.s27->restriction_csr() : L.var7 ? L.var7->restriction_csr() : L.plane->restriction_csr();
     L.format_pending = false;
     build_format(h, l, view(A), view(R));
 }
@@ -1240,14 +1240,22 @@ std::unique_ptr<Hier<V>> create(int n_levels, const omg_csr *A, const omg_csr *R
                 continue;
             }
         }
-        SetupTimer tm("ordering (colouring / level schedule / wavefront plan)");
-        order_level(L, A[l], smoother, h->stream);
         // (OMG_PLANE=0 asks for the set-by-set schedule: no fused path of any kind)
         if (smoother == OMG_SMOOTH_GS_COLOUR && !getenv_flag0("OMG_VAR7") && !getenv_flag0("OMG_PLANE")) {
-            SetupTimer tv("7-point level with per-row coefficients: does it qualify (+ its coefficient arrays)");
+            SetupTimer tv("7-point level with per-row coefficients: does it qualify (+ its coefficient arrays, its parity ordering)");
             std::unique_ptr<Var7Plan<V>> v7(new Var7Plan<V>);
-            if (v7->build(A[l], R[l], L.ord, h->stream)) L.var7 = std::move(v7);
+            if (v7->build(A[l], R[l], L.ord, h->stream)) {
+                L.var7 = std::move(v7);
+                if (getenv_flag("OMG_PLANE_CHECK_ORDER")) {
+                    const Ordering g = make_ordering(A[l], smoother);
+                    OMG_REQUIRE(g.sets == L.ord.sets && g.perm == L.ord.perm && g.inv == L.ord.inv,
+                                "internal: the parity ordering differs from the greedy colouring");
+                }
+                continue;
+            }
         }
+        SetupTimer tm("ordering (colouring / level schedule / wavefront plan)");
+        order_level(L, A[l], smoother, h->stream);
     }
     for (int l = 0; l < n_levels; ++l) {
         Lv &L = h->lv[l];
@@ -1269,7 +1277,7 @@ std::unique_ptr<Hier<V>> create(int n_levels, const omg_csr *A, const omg_csr *R
             if (L.plane && !pooled_vectors(L)) L.tmp.alloc(L.n, vector_stagger(1));
             if (L.s27 && !pooled_vectors(L)) L.tmp.alloc(L.n);
             if (L.var7 && !L.tmp.p) L.tmp.alloc(L.n);
-            if ((L.plane || L.s27) && !experiment_flag0("OMG_PLANE_LAZY")) L.format_pending = true;
+            if ((L.plane || L.s27 || L.var7) && !experiment_flag0("OMG_PLANE_LAZY")) L.format_pending = true;
             else if (L.s27) { L.format_pending = true; ensure_format(h.get(), l); }      // (from the padded operator)
             else build_format(h.get(), l, A[l], R[l]);
         }
@@ -1949,7 +1957,7 @@ int omg_hierarchy_cycle_dev(omg_hierarchy *h, const double *b_dev, double *x_dev
                 else launch_gather<double, V>(b_dev, perm, L.b.p, L.n, hh->stream);
                 bool first = false, zero_in = false;
                 if (hh->lv.size() > 1) {
-                    zero_in = (use_plane(hh, L, pre, post) && pre == 1) || (use_s27(hh, L) && pre >= 1);   // the down pass / first sweep does not read a zero iterate
+                    zero_in = (use_plane(hh, L, pre, post) && pre == 1) || (use_s27(hh, L) && pre >= 1) || (use_var7(hh, L) && pre == 1);   // the down pass / first sweep does not read a zero iterate
                     if (!zero_in) {
                         // x starts from zero: the first relaxation launch is a pointwise b / diag (restrict_level).  The
                         // diagonal comes from the row-kernel format, which a plane level builds on first use: BEFORE it
@@ -2072,17 +2080,18 @@ int omg_resident_cycles(omg_hierarchy *h, int pre, int post, int n_cycles, doubl
                 check_march(hh);
                 return;
             }
-            if (!single) ensure_format(hh, 0);
+            const bool v7 = !single && use_var7(hh, hh->lv[0]);       // (its cycle never touches the row-kernel format)
+            if (!single && !v7) ensure_format(hh, 0);
             // (a plane-pipelined cycle with post > 1 ends set by set: its first launch is no PRENORM launch)
-            const bool defer = !single && !getenv_flag("OMG_NO_PRENORM") && can_prenorm(hh, hh->lv[0], pre, post) &&
-                               !use_plane(hh, hh->lv[0], pre, post) && !use_var7(hh, hh->lv[0]);
+            const bool defer = !single && !v7 && !getenv_flag("OMG_NO_PRENORM") && can_prenorm(hh, hh->lv[0], pre, post) &&
+                               !use_plane(hh, hh->lv[0], pre, post);
             // Deferred norms: cycle k's block partials are collected in slot k of a batch buffer — the
             // last set's by its fused post-smoothing launch, the first set's by cycle k + 1's first
             // launch — and ALL slots of a chunk are added up by one launch at the chunk's end (the
             // additions of launch_sum_sqrt, same bits).  The last cycle of a chunk has no successor
             // in it: the usual norm launch.
             constexpr int CHUNK = 64;
-            const int64_t nb = single ? 0 : hh->lv[0].A.n_blocks();
+            const int64_t nb = (single || v7) ? 0 : hh->lv[0].A.n_blocks();
             if (defer && hh->batch_partials.n < size_t(CHUNK) * size_t(nb)) hh->batch_partials.alloc(size_t(CHUNK) * size_t(nb));
             for (int k0 = 0; k0 < n_cycles; k0 += CHUNK) {
                 const int cnt = std::min(CHUNK, n_cycles - k0);

@@ -432,7 +432,7 @@ void launch_pass(const Var7Args<V> &a, bool down, bool sym, int64_t n_wg, hipStr
 }  // namespace
 
 template <typename V>
-bool Var7Plan<V>::build(const omg_csr &A, const omg_csr &R, const Ordering &ord, hipStream_t s) {
+bool Var7Plan<V>::build(const omg_csr &A, const omg_csr &R, Ordering &ord, hipStream_t s) {
     const int64_t n = A.n_rows;
     // (below 128^3 the set-by-set schedule's launches are short and a pass of a few workgroups is not: measured at 64^3 and
     // 32^3, profiles/r06_var7.txt.  OMG_VAR7_MIN: tests put small levels through the passes)
@@ -458,8 +458,6 @@ bool Var7Plan<V>::build(const omg_csr &A, const omg_csr &R, const Ordering &ord,
     if (gz < 4 || (gx & 1) || (gy & 1) || (gz & 1) || gx > (1 << 14) || gy > (1 << 14) || gz > (1 << 14)) return false;
     if (n >= (int64_t(1) << 31)) return false;
     const int64_t sj = gx, sk = gx * gy, nh_ = n / 2, hx_ = gx / 2;
-    // the ordering: parity colours, red (even i + j + k) first, each colour in natural order
-    if (ord.identity || ord.sets.size() != 3 || ord.sets[1] != nh_ || int64_t(ord.perm.size()) != n) return false;
     // the restriction: the plain 2 x 2 x 2 aggregation with one weight, columns ascending
     if (R.n_rows != n / 8 || R.n_cols != n || R.nnz != n) return false;
     const double wv = R.data[0];
@@ -479,7 +477,6 @@ bool Var7Plan<V>::build(const omg_csr &A, const omg_csr &R, const Ordering &ord,
                 for (int64_t r = lo; r < hi && good; ++r) {
                     const int64_t i = r % gx, j = (r / gx) % gy, k = r / sk;
                     const int64_t sl = slot(i, j, k);
-                    if (ord.perm[size_t(sl)] != int32_t(r)) { good = false; break; }
                     const int64_t want[7] = {k > 0 ? r - sk : -1, j > 0 ? r - sj : -1, i > 0 ? r - 1 : -1, r,
                                              i + 1 < gx ? r + 1 : -1, j + 1 < gy ? r + sj : -1, k + 1 < gz ? r + sk : -1};
                     int32_t p = A.indptr[r];
@@ -573,7 +570,85 @@ bool Var7Plan<V>::build(const omg_csr &A, const omg_csr &R, const Ordering &ord,
     partials.alloc(size_t(n_wg) + 64);
     partials.zero(s);
     OMG_HIP(hipStreamSynchronize(s));
+    // the ordering: parity colours, red (even i + j + k) first, each colour in natural order — slot = colour n / 2 + row / 2
+    ord = Ordering();
+    ord.identity = false;
+    ord.sets = {0, n / 2, n};
+    ord.closed_form = 2; ord.cf_nx = nx; ord.cf_ny = ny; ord.cf_nz = nz;
+    materialise_ordering(ord);
     return true;
+}
+
+template <typename V>
+HostCsr Var7Plan<V>::operator_csr(hipStream_t s) const {
+    const int64_t gx = nx, gy = ny, gz = nz, n = gx * gy * gz, nh_ = n / 2, hx_ = gx / 2, sj = gx, sk = gx * gy;
+    std::vector<V> hD((size_t)(n)), hM[3], hP[3];
+    cD.download(hD.data(), size_t(n), s);
+    for (int d = 0; d < 3; ++d) {
+        hP[d].resize(size_t(n));
+        cP[d].download(hP[d].data(), size_t(n), s);
+        if (!sym) { hM[d].resize(size_t(n)); cM[d].download(hM[d].data(), size_t(n), s); }
+    }
+    OMG_HIP(hipStreamSynchronize(s));
+    auto slot = [&](int64_t i, int64_t j, int64_t k) { return ((i + j + k) & 1) * nh_ + (k * gy + j) * hx_ + (i >> 1); };
+    HostCsr A;
+    A.n_rows = A.n_cols = n;
+    A.indptr.resize(size_t(n) + 1);
+    A.indptr[0] = 0;
+    for (int64_t r = 0; r < n; ++r) {
+        const int64_t i = r % gx, j = (r / gx) % gy, k = r / sk;
+        A.indptr[size_t(r) + 1] = A.indptr[size_t(r)] + int32_t(1 + (i > 0) + (i + 1 < gx) + (j > 0) + (j + 1 < gy) + (k > 0) + (k + 1 < gz));
+    }
+    A.nnz = A.indptr[size_t(n)];
+    A.indices.resize(size_t(A.nnz));
+    A.data.resize(size_t(A.nnz));
+    const unsigned hw = std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
+    const int64_t nt = std::max<int64_t>(1, std::min<int64_t>(hw, n / 65536));
+    std::vector<std::thread> th;
+    for (int64_t t = 0; t < nt; ++t)
+        th.emplace_back([&, t] {
+            for (int64_t r = n * t / nt; r < n * (t + 1) / nt; ++r) {
+                const int64_t i = r % gx, j = (r / gx) % gy, k = r / sk;
+                const size_t sl = size_t(slot(i, j, k));
+                int32_t p = A.indptr[size_t(r)];
+                auto put = [&](int64_t col, V v) { A.indices[size_t(p)] = int32_t(col); A.data[size_t(p)] = double(v); ++p; };
+                if (k > 0) put(r - sk, sym ? hP[2][size_t(slot(i, j, k - 1))] : hM[2][sl]);
+                if (j > 0) put(r - sj, sym ? hP[1][size_t(slot(i, j - 1, k))] : hM[1][sl]);
+                if (i > 0) put(r - 1, sym ? hP[0][size_t(slot(i - 1, j, k))] : hM[0][sl]);
+                put(r, hD[sl]);
+                if (i + 1 < gx) put(r + 1, hP[0][sl]);
+                if (j + 1 < gy) put(r + sj, hP[1][sl]);
+                if (k + 1 < gz) put(r + sk, hP[2][sl]);
+            }
+        });
+    for (auto &x : th) x.join();
+    return A;
+}
+
+template <typename V>
+HostCsr Var7Plan<V>::restriction_csr() const {
+    const int64_t gx = nx, gy = ny, gz = nz, n = gx * gy * gz, sj = gx, sk = gx * gy;
+    const int64_t nxc = gx / 2, nyc = gy / 2, nc = n / 8;
+    HostCsr R;
+    R.n_rows = nc;
+    R.n_cols = n;
+    R.nnz = n;
+    R.indptr.resize(size_t(nc) + 1);
+    R.indices.resize(size_t(n));
+    R.data.resize(size_t(n));
+    for (int64_t cr = 0; cr <= nc; ++cr) R.indptr[size_t(cr)] = int32_t(8 * cr);
+    for (int64_t cr = 0; cr < nc; ++cr) {
+        const int64_t I = cr % nxc, J = (cr / nxc) % nyc, K = cr / (nxc * nyc);
+        int64_t p = 8 * cr;
+        for (int dk = 0; dk < 2; ++dk)
+            for (int dj = 0; dj < 2; ++dj)
+                for (int di = 0; di < 2; ++di, ++p) {
+                    R.indices[size_t(p)] = int32_t((2 * K + dk) * sk + (2 * J + dj) * sj + 2 * I + di);
+                    R.data[size_t(p)] = w;
+                }
+    }
+    (void)gz;
+    return R;
 }
 
 namespace {
