@@ -473,6 +473,14 @@ def var7_leg(size, grids, steps, warmup, repeats, sync_of):
                                  "wavefront_levels": [bool(hl.level_flags(l)["march"]) for l in range(len(R))],
                                  "hierarchy_s": round(setup_l, 2), "norms_last_region_tail": norms_l[-2:]}
     hl.close()
+    # what a caller of the drop-in pays on this input: mgSolve for 20 cycles including its whole setup — on the device when
+    # nobody asks for the operator lists (round 6: the large levels' rows are checked and scattered into their coefficient
+    # arrays in HBM, the small levels below them fetched and coded by the host)
+    import openmg_amd
+    p_s = {"problemShape": shape, "gridLevels": grids - 1, "cycles": 20, "threshold": 0, "preIterations": 1, "postIterations": 1, "smoother": "colour"}
+    t0 = time.perf_counter()
+    openmg_amd.mgSolve(A0, b, dict(p_s))
+    out["mgsolve_20_cycles_s"] = round(time.perf_counter() - t0, 3)
     return out
 
 
@@ -836,6 +844,7 @@ def main():
         roofline["var7_vcycles_per_s"] = var7["vcycles_per_s"]
         roofline["var7_set_schedule_vcycles_per_s"] = var7["set_schedule_vcycles_per_s"]
         roofline["var7_reference_smoother_vcycles_per_s"] = var7["reference_smoother"]["vcycles_per_s"]
+        roofline["var7_mgsolve_20_cycles_s"] = var7["mgsolve_20_cycles_s"]
     if config4 is not None:
         roofline["config4_vcycles_per_s"] = config4.get("vcycles_per_s")
         roofline["config4_sweep_frac"] = (config4.get("roofline") or {}).get("frac")

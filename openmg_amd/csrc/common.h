@@ -790,6 +790,10 @@ struct Var7Plan {
     // level's colour ordering in closed form (parity colours, red first — what the greedy colouring of such a stencil gives,
     // without its sequential pass over the rows; OMG_PLANE_CHECK_ORDER=1 compares the two).
     bool build(const omg_csr &A, const omg_csr &R, Ordering &ord, hipStream_t s);
+    // The same for an operator that is already in HBM (mgSolve's setup on the device, omg_hierarchy_create_from_fine), on a
+    // grid the caller knows, restricted by the plain aggregation with weight w: one kernel checks the rows and scatters their
+    // coefficients into the seven arrays.  ord gets its sets and closed form only (perm / inv stay on the device).
+    bool build_device(const DevCsrPlain &A, int nx, int ny, int nz, double w, Ordering &ord, hipStream_t s);
     // The operator and the restriction as the caller's CSR had them (natural numbering, ascending columns; the values as the
     // level holds them): what the row kernels' format of the level is built from when something asks for it
     // (hierarchy.hip ensure_format) — a cycle over the fused passes never does.

@@ -1350,6 +1350,13 @@ std::unique_ptr<Hier<V>> create_from_fine(const omg_csr &A0, int dim, const int6
         nz = dim == 3 ? int(shape[0] >> l) : 1;
     };
     bool all = smoother == OMG_SMOOTH_GS_COLOUR || (smoother == OMG_SMOOTH_JACOBI && dim == 2);
+    // Round 6: a hierarchy whose LARGE levels qualify (7-point levels with per-row coefficients take the fused passes from
+    // 128^3 up) keeps them on the device; the small levels below — a few hundred thousand rows — are fetched and ordered / coded
+    // by the host as the ordinary route would (host_level), each a few milliseconds.
+    constexpr int64_t HOST_LEVEL_MAX = int64_t(1) << 19;
+    std::vector<char> host_level((size_t)(n_levels), 0);
+    std::vector<HostCsr> hostA((size_t)(n_levels)), hostR((size_t)(n_levels));
+    bool any_var7 = false;
     for (int l = 0; all && l + 1 < n_levels; ++l) {
         Lv &L = h->lv[size_t(l)];
         L.n = dA[size_t(l)].n_rows;
@@ -1366,6 +1373,23 @@ std::unique_ptr<Hier<V>> create_from_fine(const omg_csr &A0, int dim, const int6
         std::unique_ptr<Stencil27Plan<V>> s27(new Stencil27Plan<V>);
         if (smoother == OMG_SMOOTH_GS_COLOUR && dim == 3 && s27->build_device(dA[size_t(l)], nx, ny, nz, w, L.ord, h->stream)) {
             L.s27 = std::move(s27);
+            continue;
+        }
+        if (smoother == OMG_SMOOTH_GS_COLOUR && dim == 3 && !getenv_flag0("OMG_VAR7") && !getenv_flag0("OMG_PLANE")) {
+            std::unique_ptr<Var7Plan<V>> v7(new Var7Plan<V>);
+            if (v7->build_device(dA[size_t(l)], nx, ny, nz, w, L.ord, h->stream)) {
+                L.var7 = std::move(v7);
+                any_var7 = true;
+                continue;
+            }
+        }
+        if (any_var7 && L.n <= HOST_LEVEL_MAX) {
+            host_level[size_t(l)] = 1;
+            hostA[size_t(l)] = download_csr(dA[size_t(l)], h->stream);
+            hostR[size_t(l)] = download_csr(dR[size_t(l)], h->stream);
+            check_diagonal(view(hostA[size_t(l)]), l);
+            SetupTimer tm("ordering (colouring / level schedule / wavefront plan)");
+            order_level(L, view(hostA[size_t(l)]), smoother, h->stream);
             continue;
         }
         all = false;
@@ -1430,19 +1454,36 @@ std::unique_ptr<Hier<V>> create_from_fine(const omg_csr &A0, int dim, const int6
     for (int l = 0; l < n_levels; ++l) {
         Lv &L = h->lv[size_t(l)];
         if (!L.ord.identity) {
-            // slot -> natural row, for the gathers at the host boundary: written by a kernel
             L.perm.alloc(L.n);
-            fill_ordering_device(L.ord.closed_form, L.ord.cf_nx, L.ord.cf_ny, L.ord.cf_nz, L.perm.p, nullptr, h->stream);
+            if (L.ord.closed_form) {
+                // slot -> natural row, for the gathers at the host boundary: written by a kernel
+                fill_ordering_device(L.ord.closed_form, L.ord.cf_nx, L.ord.cf_ny, L.ord.cf_nz, L.perm.p, nullptr, h->stream);
+            } else {
+                L.perm.upload(L.ord.perm.data(), L.n, h->stream);         // (a level the host ordered)
+                OMG_HIP(hipStreamSynchronize(h->stream));
+            }
         }
         if (l + 1 < n_levels) {
-            const Ordering &co = h->lv[size_t(l) + 1].ord;
+            Ordering &co = h->lv[size_t(l) + 1].ord;
             if (!co.identity) {
                 L.r_out.alloc(size_t(h->lv[size_t(l) + 1].n));
-                fill_ordering_device(co.closed_form, co.cf_nx, co.cf_ny, co.cf_nz, nullptr, L.r_out.p, h->stream);
+                if (co.closed_form) {
+                    fill_ordering_device(co.closed_form, co.cf_nx, co.cf_ny, co.cf_nz, nullptr, L.r_out.p, h->stream);
+                } else {
+                    L.r_out.upload(co.inv.data(), co.inv.size(), h->stream);
+                    OMG_HIP(hipStreamSynchronize(h->stream));
+                }
             }
             if (L.plane && !pooled_vectors(L)) L.tmp.alloc(L.n, vector_stagger(1));
             if (L.s27 && !pooled_vectors(L)) L.tmp.alloc(L.n);
-            L.format_pending = true;
+            if (L.var7 && !L.tmp.p) L.tmp.alloc(L.n);
+            if (host_level[size_t(l)]) {
+                // (the restriction's rows land in the coarse level's ordering: a closed-form one is written out for that)
+                materialise_ordering(co);
+                build_format(h.get(), l, view(hostA[size_t(l)]), view(hostR[size_t(l)]));
+            } else {
+                L.format_pending = true;
+            }
         }
         if (!L.x.p) {
             L.x.alloc(std::max<int64_t>(L.n, 1));

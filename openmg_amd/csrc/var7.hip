@@ -431,14 +431,113 @@ void launch_pass(const Var7Args<V> &a, bool down, bool sym, int64_t n_wg, hipStr
 
 }  // namespace
 
+namespace {
+// every row of a natural-numbered device CSR against the 7-point pattern of its grid position; its coefficients into the
+// seven colour-layout arrays (a neighbour outside the grid: an explicit zero); the first offending row into *err
 template <typename V>
-bool Var7Plan<V>::build(const omg_csr &A, const omg_csr &R, Ordering &ord, hipStream_t s) {
-    const int64_t n = A.n_rows;
+__global__ void var7_scatter_kernel(const int32_t *indptr, const int32_t *indices, const double *data, int nx, int ny, int nz,
+                                    V *cD, V *cM0, V *cM1, V *cM2, V *cP0, V *cP1, V *cP2, unsigned long long *err) {
+    const long long n = (long long)nx * ny * nz;
+    const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    const long long sj = nx, sk = (long long)nx * ny;
+    const int i = int(r % nx), j = int((r / nx) % ny), k = int(r / sk);
+    const long long sl = (long long)((i + j + k) & 1) * (n / 2) + r / 2;
+    const long long want[7] = {k > 0 ? r - sk : -1, j > 0 ? r - sj : -1, i > 0 ? r - 1 : -1, r,
+                               i + 1 < nx ? r + 1 : -1, j + 1 < ny ? r + sj : -1, k + 1 < nz ? r + sk : -1};
+    V *const out[7] = {cM2, cM1, cM0, cD, cP0, cP1, cP2};
+    int p = indptr[r];
+    const int pe = indptr[r + 1];
+    bool good = true;
+#pragma unroll
+    for (int e = 0; e < 7; ++e) {
+        V v = V(0);
+        if (want[e] >= 0) {
+            if (p < pe && (long long)indices[p] == want[e]) {
+                v = V(data[p]);
+                ++p;
+                if (!isfinite(v) || (e == 3 && v == V(0))) good = false;
+            } else {
+                good = false;
+            }
+        }
+        out[e][sl] = v;
+    }
+    if (p != pe) good = false;
+    if (!good) atomicMin(err, (unsigned long long)(r + 1));
+}
+
+template <typename V>
+void var7_tiling(Var7Plan<V> &P) {
+    // tiles: 64 x 16 on wide grids, narrower below
+    P.tx = P.nx >= 64 ? 64 : P.nx >= 32 ? 32 : 16;
+    if (P.tx == 64 && int64_t((P.nx + 63) / 64) * ((P.ny + 15) / 16) * ((P.nz + 15) / 16) < 256) P.tx = 32;    // (a launch of fewer workgroups than compute units)
+    if (const char *e = experiment_env("OMG_VAR7_TX")) { const int v = atoi(e); if (v == 16 || v == 32 || v == 64) P.tx = v; }
+    P.ty = 16;
+    P.threads = P.tx == 64 ? 1024 : P.tx == 32 ? 512 : 320;
+    P.ntx = (P.nx + P.tx - 1) / P.tx;
+    P.nty = (P.ny + P.ty - 1) / P.ty;
+    // chunks of planes: ONE workgroup per compute unit (its images fill the unit's LDS) — 256^3 fp64: 64 tiles x 4 chunks of
+    // 64 planes 0.94 ms per cycle, 8 chunks of 34 (two rounds of workgroups, 15 % more ring planes) 1.02, 2 chunks 1.46
+    {
+        const int64_t tiles = int64_t(P.ntx) * P.nty;
+        const int64_t want = std::max<int64_t>(1, 256 / tiles);
+        P.lz = int((P.nz + want - 1) / want);
+        P.lz = std::max(8, (P.lz + 1) & ~1);
+    }
+    if (const char *e = experiment_env("OMG_VAR7_LZ")) P.lz = std::max(2, atoi(e) & ~1);
+    P.ntz = (P.nz + P.lz - 1) / P.lz;
+    P.n_wg = int64_t(P.ntx) * P.nty * P.ntz;
+}
+
+int64_t var7_min_rows() {
     // (below 128^3 the set-by-set schedule's launches are short and a pass of a few workgroups is not: measured at 64^3 and
     // 32^3, profiles/r06_var7.txt.  OMG_VAR7_MIN: tests put small levels through the passes)
     int64_t n_min = int64_t(1) << 21;
     if (const char *e = getenv("OMG_VAR7_MIN")) n_min = std::max<int64_t>(4096, atoll(e));
-    if (n < n_min || A.n_cols != n || (n & 1)) return false;
+    return n_min;
+}
+}  // namespace
+
+template <typename V>
+bool Var7Plan<V>::build_device(const DevCsrPlain &A, int gx, int gy, int gz, double wv, Ordering &ord, hipStream_t s) {
+    const int64_t n = A.n_rows;
+    if (n < var7_min_rows() || A.n_cols != n || int64_t(gx) * gy * gz != n) return false;
+    if (gx < 4 || gy < 4 || gz < 4 || (gx & 1) || (gy & 1) || (gz & 1) || gx > (1 << 14) || gy > (1 << 14) || gz > (1 << 14)) return false;
+    if (n >= (int64_t(1) << 31)) return false;
+    cD.alloc(size_t(n));
+    for (int d = 0; d < 3; ++d) { cM[d].alloc(size_t(n)); cP[d].alloc(size_t(n)); }
+    DevBuf<unsigned long long> d_err(1);
+    OMG_HIP(hipMemsetAsync(d_err.p, 0xFF, sizeof(unsigned long long), s));
+    hipLaunchKernelGGL((var7_scatter_kernel<V>), dim3(unsigned((n + 255) / 256)), dim3(256), 0, s, A.indptr.p, A.indices.p, A.data.p, gx, gy, gz,
+                       cD.p, cM[0].p, cM[1].p, cM[2].p, cP[0].p, cP[1].p, cP[2].p, d_err.p);
+    OMG_HIP(hipGetLastError());
+    unsigned long long err = 0;
+    OMG_HIP(hipMemcpyAsync(&err, d_err.p, sizeof(err), hipMemcpyDeviceToHost, s));
+    OMG_HIP(hipStreamSynchronize(s));
+    if (err != ~0ull) {
+        cD.release();
+        for (int d = 0; d < 3; ++d) { cM[d].release(); cP[d].release(); }
+        return false;
+    }
+    nx = gx; ny = gy; nz = gz;
+    w = wv;
+    sym = false;
+    var7_tiling(*this);
+    partials.alloc(size_t(n_wg) + 64);
+    partials.zero(s);
+    OMG_HIP(hipStreamSynchronize(s));
+    ord = Ordering();
+    ord.identity = false;
+    ord.sets = {0, n / 2, n};
+    ord.closed_form = 2; ord.cf_nx = nx; ord.cf_ny = ny; ord.cf_nz = nz;     // perm / inv: on the device (fill_ordering_device), on the host on demand
+    return true;
+}
+
+template <typename V>
+bool Var7Plan<V>::build(const omg_csr &A, const omg_csr &R, Ordering &ord, hipStream_t s) {
+    const int64_t n = A.n_rows;
+    if (n < var7_min_rows() || A.n_cols != n || (n & 1)) return false;
     // grid extents from the first missing coupling (as the other plans read them)
     auto has = [&](int64_t r, int64_t col) {
         for (int32_t p = A.indptr[r]; p < A.indptr[r + 1]; ++p)
@@ -541,25 +640,7 @@ bool Var7Plan<V>::build(const omg_csr &A, const omg_csr &R, Ordering &ord, hipSt
     }
     nx = int(gx); ny = int(gy); nz = int(gz);
     w = wv;
-    // tiles: 64 x 16 on wide grids, narrower below; chunks of planes so that the launch has ~2 workgroups per compute unit
-    tx = nx >= 64 ? 64 : nx >= 32 ? 32 : 16;
-    if (tx == 64 && int64_t((nx + 63) / 64) * ((ny + 15) / 16) * ((nz + 15) / 16) < 256) tx = 32;    // (a launch of fewer workgroups than compute units)
-    if (const char *e = experiment_env("OMG_VAR7_TX")) { const int v = atoi(e); if (v == 16 || v == 32 || v == 64) tx = v; }
-    ty = 16;
-    threads = tx == 64 ? 1024 : tx == 32 ? 512 : 320;
-    ntx = (nx + tx - 1) / tx;
-    nty = (ny + ty - 1) / ty;
-    // chunks of planes: ONE workgroup per compute unit (its images fill the unit's LDS) — 256^3 fp64: 64 tiles x 4 chunks of
-    // 64 planes 0.94 ms per cycle, 8 chunks of 34 (two rounds of workgroups, 15 % more ring planes) 1.02, 2 chunks 1.46
-    {
-        const int64_t tiles = int64_t(ntx) * nty;
-        const int64_t want = std::max<int64_t>(1, 256 / tiles);
-        lz = int((nz + want - 1) / want);
-        lz = std::max(8, (lz + 1) & ~1);
-    }
-    if (const char *e = experiment_env("OMG_VAR7_LZ")) lz = std::max(2, atoi(e) & ~1);
-    ntz = (nz + lz - 1) / lz;
-    n_wg = int64_t(ntx) * nty * ntz;
+    var7_tiling(*this);
     auto put = [&](DevBuf<V> &d, const std::vector<V> &h) {
         d.alloc(size_t(n));
         d.upload(h.data(), size_t(n), s);

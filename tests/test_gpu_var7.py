@@ -105,9 +105,13 @@ def test_variable_coefficient_cycle_against_the_oracle(monkeypatch, size, grid_l
     xs, info = openmg_amd.mgSolve(A0, b, dict(p))
     assert abs(info["norm"] - inf["norm"]) <= 1e-10 * inf["norm"]
     np.testing.assert_allclose(xs, xo, rtol=1e-9, atol=1e-12 * np.abs(xo).max())
-    # without giveInfo mgSolve sets up on the device; a level no device-side check takes sends it through the host route
-    # (omg_hierarchy_create_from_fine falls back): the same hierarchy, the same bits
+    # without giveInfo mgSolve sets up on the device (omg_hierarchy_create_from_fine): the Galerkin chain, the check of every
+    # large level's rows and its coefficient arrays in HBM; the small levels below the fused ones are fetched and coded by the
+    # host.  The same hierarchy, the same bits — with every level fused and with the last smoothed level left to the host
     assert np.array_equal(openmg_amd.mgSolve(A0, b, dict(p, giveInfo=False)), xs)
+    monkeypatch.setenv("OMG_VAR7_MIN", str(size ** 3))
+    assert np.array_equal(openmg_amd.mgSolve(A0, b, dict(p, giveInfo=False)), xs)
+    assert np.array_equal(openmg_amd.mgSolve(A0, b, dict(p))[0], xs)
 
 
 def test_mgcycle_drop_in_q2_on_a_variable_coefficient_level(monkeypatch):
