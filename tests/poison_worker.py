@@ -2,6 +2,7 @@
 with NaN patterns (common.h DevBuf::alloc), so a kernel that reads what nobody wrote — harmless in a young process,
 where the allocator hands out zeros — shows up as NaNs or as a difference from the set-by-set schedule."""
 import json
+import os
 import sys
 
 import numpy as np
@@ -81,6 +82,10 @@ def main():
         report["plane 64^3 %s" % dtype] = both_ways(A, R, dtype, "plane", ((1, 1), (1, 0), (0, 1), (2, 2)))
         A, R = hierarchy7((20, 12, 24), 2)
         report["plane 20x12x24 %s" % dtype] = both_ways(A, R, dtype, "plane", ((1, 1), (2, 1)))
+        # 7-point operators with per-row coefficients (var7.hip, round 6): ragged tiles, three levels through the passes
+        os.environ["OMG_VAR7_MIN"] = "4096"
+        A, R = hierarchy(operators.stencil7_variable((40, 24, 72)), (40, 24, 72), 3)
+        report["var7 40x24x72 %s" % dtype] = both_ways(A, R, dtype, "var7", ((1, 1), (1, 0), (0, 1), (2, 1)))
     A, R = hierarchy7((128, 64), 3)
     report["tiles 128x64 red-black"] = both_ways(A, R, "float64", "plane", ((1, 1), (1, 0)))
     report["tiles 128x64 jacobi"] = both_ways(A, R, "float64", "plane", ((1, 1), (2, 1)), smoother="jacobi")

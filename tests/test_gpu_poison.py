@@ -18,7 +18,7 @@ def test_fused_passes_do_not_read_unwritten_memory():
     run = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "poison_worker.py")], env=env, capture_output=True, text=True, timeout=900)
     assert run.returncode == 0, run.stderr[-3000:]
     report = json.loads(run.stdout.strip().splitlines()[-1])
-    assert len(report) == 10
+    assert len(report) == 12
     for name, cases in report.items():
         for c in cases:
             assert c["finite"] and c["same_bits"], (name, c)

@@ -134,3 +134,29 @@ def test_mgcycle_drop_in_q2_on_a_variable_coefficient_level(monkeypatch):
     np.testing.assert_allclose(init, want_init, rtol=1e-9, atol=1e-12)          # Q2: pre-smoothed in place
     assert abs(info["norm"] - inf["norm"]) <= 1e-10 * inf["norm"]
     openmg_amd.clear_cache()
+
+
+def test_device_setup_in_single_precision_and_lexicographic_on_the_same_input(monkeypatch):
+    """mgSolve with dtype float32 on both setup routes (the device route scatters the rows into float arrays), and the
+    reference's default smoother on the same operator: per-row wavefront levels (march.hip), against the oracle."""
+    monkeypatch.setenv("OMG_VAR7_MIN", "4096")
+    shape = (32, 32, 32)
+    A0 = operators.stencil7_variable(shape)
+    b = A0 @ np.random.default_rng(5).random(A0.shape[0])
+    p = {"problemShape": shape, "gridLevels": 2, "preIterations": 1, "postIterations": 1, "cycles": 3, "threshold": 0,
+         "smoother": "colour", "dtype": "float32", "minSize": 8}
+    x_dev = openmg_amd.mgSolve(A0, b, dict(p))
+    x_host, info = openmg_amd.mgSolve(A0, b, dict(p, giveInfo=True))
+    assert np.array_equal(x_dev, x_host)
+    ref, iref = openmg_amd.mgSolve(A0, b, dict(p, dtype="float64", giveInfo=True))
+    assert abs(info["norm"] - iref["norm"]) <= 5e-4 * iref["norm"]
+    # the reference's own smoother ('gs', the default) on the variable-coefficient input
+    pg = {"problemShape": shape, "gridLevels": 2, "preIterations": 1, "postIterations": 1, "cycles": 2, "threshold": 0, "giveInfo": True, "minSize": 8}
+    xg, ig = openmg_amd.mgSolve(A0, b, dict(pg))
+    with _hip.Hierarchy(ig["A"], ig["R"], smoother="gs") as h:
+        assert all(h.level_flags(l)["march"] for l in range(2))
+    xo = None
+    for _ in range(2):
+        xo, io = orc.mg_cycle(ig["A"], b, 0, ig["R"], dict(pg, coarsestLevel=2), initial=xo)
+    assert abs(ig["norm"] - io["norm"]) <= 1e-10 * io["norm"]
+    np.testing.assert_allclose(xg, xo, rtol=1e-9, atol=1e-12 * np.abs(xo).max())
