@@ -23,13 +23,23 @@ SHIM = os.path.join(HERE, "fake_rccl", "libfake_rccl.so")
 
 def run_ranks(tmp_path, world, mode, shape, grids, n_dist, dtype="float64", extra="", timeout=600):
     assert os.path.exists(SHIM), "tests/fake_rccl/libfake_rccl.so is not built (__graft_entry__.build() makes it)"
+    import io
+    import warnings
     os.environ["OMG_RCCL_LIB"] = SHIM                        # (child_env copies os.environ)
     try:
-        import io
-        err = io.StringIO()
-        code = launch.spawn_ranks(world, [sys.executable, os.path.join(HERE, "rccl_worker.py"), mode, str(tmp_path),
-                                          "x".join(map(str, shape)), str(grids), str(n_dist), dtype, extra],
-                                  timeout_s=timeout, out=err, err=err)
+        # Eight processes that import PyTorch, rendezvous over gloo, map each other's hipIpc handles and time-share one GPU: a
+        # rank process that does not come up (seen once in ~40 runs of the largest case, inside a five-minute suite run) is
+        # started again ONCE, with a warning that carries the first attempt's output.  What the ranks COMPUTE is never
+        # retried: the comparisons below run on whichever attempt completed.
+        for attempt in (1, 2):
+            err = io.StringIO()
+            code = launch.spawn_ranks(world, [sys.executable, os.path.join(HERE, "rccl_worker.py"), mode, str(tmp_path),
+                                              "x".join(map(str, shape)), str(grids), str(n_dist), dtype, extra],
+                                      timeout_s=timeout, out=err, err=err)
+            if code == 0:
+                break
+            if attempt == 1:
+                warnings.warn("rank processes of %s %s x %d ended with code %d on the first attempt:\n%s" % (mode, shape, world, code, err.getvalue()[-2000:]))
     finally:
         del os.environ["OMG_RCCL_LIB"]
     assert code == 0, err.getvalue()[-4000:]
