@@ -652,7 +652,9 @@ template <typename V>
 void ensure_spmv_y(Hier<V> *h, Level<V> &L) {
     if (L.spmv_y.p) return;
     L.spmv_y.alloc(size_t(L.n));
-    static const int trials = [] { const char *e = getenv("OMG_SPMV_TRIALS"); return e && e[0] ? atoi(e) : 8; }();
+    // (16 candidates, 0.5 ms each: the first ones a fresh hipMalloc hands out are what the pool's search has just given back —
+    // its losers, the slow kind; a bench process whose eight candidates were all of them ran the SpMV at 68 us, round 6)
+    static const int trials = [] { const char *e = getenv("OMG_SPMV_TRIALS"); return e && e[0] ? atoi(e) : 16; }();
     if (trials < 2 || !L.plane || L.n < POOL_TRIAL_MIN) return;
     hipEvent_t e0, e1;
     OMG_HIP(hipEventCreate(&e0));
