@@ -97,6 +97,36 @@ def main():
             norms += r.cycles(pre, post, 3)
             result["x%d%d" % (pre, post)] = r.fetch()
         result["exchanges"] = r.info()["exchanges_last_call"]
+    elif mode == "stall":
+        # a schedule that would DEADLOCK RCCL — rank 1 never posts the receives rank 0's sends wait for — must end as an
+        # error after the stand-in's bounded wait (FRCCL_TIMEOUT_S), not as a hung GPU: rank 0 runs one cycle alone
+        from test_gpu_plane import hierarchy
+        coef = [[v / 16.0 ** l for v in (-1.0, -1.0, -1.0, 6.0, -1.0, -1.0, -1.0)] for l in range(n_dist)]
+        At, Rt = hierarchy(tuple(s >> n_dist for s in shape), grids - n_dist, scale=1.0 / 16.0 ** n_dist)
+        tail = _hip.Hierarchy(At, Rt, smoother="colour")
+        tails.append(tail)
+        r = _hip_dist.PlaneDistRank(rank, world, shape, coef, 0.125, tail)
+        r.connect(*ids(2))
+        r.load(np.random.default_rng([31, rank]).random(per))
+        norms = r.cycles(1)                                 # (both ranks: a cycle that completes)
+        lib = ctypes.CDLL(shim)
+        assert int(lib.frccl_status()) == 0
+        td.barrier()
+        outcome = "completed"
+        if rank == 0:
+            try:
+                r.cycles(1)                                 # rank 1 does not take part
+                r.sync()
+            except Exception as e:                          # noqa: BLE001 - an error is one of the two acceptable endings
+                outcome = "raised: %s" % e
+            result["status_after"] = int(lib.frccl_status())
+        else:
+            result["status_after"] = 0
+        result["outcome"] = outcome
+        result["x"] = np.zeros(1)
+        np.savez(os.path.join(out_dir, "rank%d.npz" % rank), **result)
+        td.barrier()
+        os._exit(0)                                         # (no orderly tear-down of a communicator whose peer has gone)
     else:
         raise SystemExit("unknown mode " + mode)
     r.sync()

@@ -184,6 +184,24 @@ def test_27_point_slabs_at_the_eight_gpu_rank_shape(tmp_path):
         assert np.all(np.isfinite(o["x11"])) and np.linalg.norm(o["x11"]) > 0
 
 
+def test_a_schedule_that_would_deadlock_ends_as_an_error_not_as_a_hang(tmp_path, monkeypatch):
+    """The stand-in keeps RCCL's blocking semantics, so a rank that runs a cycle its neighbour does not take part in waits
+    for receives that never come — on real hardware a hung job.  Here every wait is bounded (FRCCL_TIMEOUT_S): the lone
+    rank's call returns or raises within seconds and the stand-in's status word says that a wait gave up."""
+    import time
+    monkeypatch.setenv("FRCCL_TIMEOUT_S", "3")
+    monkeypatch.setenv("OMG_RCCL_LIB", SHIM)
+    import io
+    err = io.StringIO()
+    t0 = time.perf_counter()
+    code = launch.spawn_ranks(2, [sys.executable, os.path.join(HERE, "rccl_worker.py"), "stall", str(tmp_path), "32x32x32", "4", "2", "float64", ""],
+                              timeout_s=240, out=err, err=err)
+    assert code == 0, err.getvalue()[-3000:]
+    assert time.perf_counter() - t0 < 200
+    o = dict(np.load(os.path.join(str(tmp_path), "rank0.npz")))
+    assert int(o["status_after"]) == 1 or str(o["outcome"]).startswith("raised"), (o["status_after"], o["outcome"])
+
+
 def rehearsal(args, timeout=900):
     import subprocess
     env = dict(os.environ, OMG_DIST_SHARED_GPU="rccl", OMG_RCCL_LIB=SHIM)
