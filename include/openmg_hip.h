@@ -488,6 +488,16 @@ int omg_sdist_sync(omg_sdist *d);
  * residual norm (:227) computed and returned; collective */
 int omg_sdist_cycles(omg_sdist *d, int pre, int post, int n_cycles, double *norms /* nullable */);
 /* all ranks in one process on one GPU, device copies in place of RCCL (verification) */
+/* Peer mode for the halo exchanges of the 27-point slabs (round 6): stores into the neighbours' ghost planes ordered by
+ * flags, in place of the grouped ncclSend / ncclRecv launches — the calls of omg_pdist_p2p_* with 1 + 3 per level handles
+ * (flag words, then x / tmp / b of every level); a rank opens its two NEIGHBOURS' only.  The gather below the slabs and the
+ * norm's reduction stay on the communicator (omg_sdist_connect).  status bit 0: a bounded wait (OMG_P2P_SPIN polls) gave up. */
+int omg_sdist_p2p_handle_count(omg_sdist *d, int *count);
+int omg_sdist_p2p_handles(omg_sdist *d, void *handles64, int capacity);
+int omg_sdist_p2p_open(omg_sdist *d, int peer_rank, const void *handles64, int count);
+int omg_sdist_p2p_local(omg_sdist *d, omg_sdist *other);
+int omg_sdist_p2p_enable(omg_sdist *d, int mode /* 0 | 1 */);
+int omg_sdist_p2p_status(omg_sdist *d, unsigned *status);
 int omg_sdist_group_create(int n, omg_sdist **ranks, omg_sdist_group **out);
 int omg_sdist_group_destroy(omg_sdist_group *g);
 int omg_sdist_group_cycles(omg_sdist_group *g, int pre, int post, int n_cycles, double *norms /* nullable */);

@@ -137,6 +137,12 @@ SIGNATURES = {
     "omg_pdist_cycles": (_I, [_P, _I, _P]),
     "omg_pdist_cycles_ex": (_I, [_P, _I, _I, _I, _P]),
     "omg_pdist_group_cycles_ex": (_I, [_P, _I, _I, _I, _P]),
+    "omg_sdist_p2p_handle_count": (_I, [_P, _P]),
+    "omg_sdist_p2p_handles": (_I, [_P, _P, _I]),
+    "omg_sdist_p2p_open": (_I, [_P, _I, _P, _I]),
+    "omg_sdist_p2p_local": (_I, [_P, _P]),
+    "omg_sdist_p2p_enable": (_I, [_P, _I]),
+    "omg_sdist_p2p_status": (_I, [_P, _P]),
     "omg_pdist_group_create": (_I, [_I, _P, _PP]),
     "omg_pdist_group_destroy": (_I, [_P]),
     "omg_pdist_group_cycles": (_I, [_P, _I, _P]),

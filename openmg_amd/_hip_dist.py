@@ -425,7 +425,38 @@ class Slab27Rank:
     def cycles(self, pre, post, n_cycles):
         norms = (ctypes.c_double * max(int(n_cycles), 1))()
         check(lib().omg_sdist_cycles(self._h, int(pre), int(post), int(n_cycles), norms))
-        return [float(norms[k]) for k in range(int(n_cycles))]
+        out = [float(norms[k]) for k in range(int(n_cycles))]
+        if self.p2p_mode and self.p2p_status():
+            raise RuntimeError("rank %d: a bounded wait for a neighbour's flag gave up (the peer-store exchanges did not "
+                               "complete); the results of this batch are not valid" % self.rank)
+        return out
+
+    # ---- peer mode for the halo exchanges (include/openmg_hip.h: omg_sdist_p2p_*) ----
+    p2p_mode = 0
+
+    def p2p_handles(self):
+        """bytes: this rank's IPC handles, for its neighbours' p2p_open."""
+        n = ctypes.c_int(0)
+        check(lib().omg_sdist_p2p_handle_count(self._h, ctypes.byref(n)))
+        buf = ctypes.create_string_buffer(64 * n.value)
+        check(lib().omg_sdist_p2p_handles(self._h, buf, n.value))
+        return bytes(buf.raw)
+
+    def p2p_open(self, peer_rank, handles):
+        buf = ctypes.create_string_buffer(bytes(handles), len(handles))
+        check(lib().omg_sdist_p2p_open(self._h, int(peer_rank), buf, len(handles) // 64))
+
+    def p2p_local(self, other):
+        check(lib().omg_sdist_p2p_local(self._h, other._h))
+
+    def p2p_enable(self, mode):
+        check(lib().omg_sdist_p2p_enable(self._h, int(mode)))
+        self.p2p_mode = int(mode)
+
+    def p2p_status(self):
+        v = ctypes.c_uint(0)
+        check(lib().omg_sdist_p2p_status(self._h, ctypes.byref(v)))
+        return v.value
 
     def close(self):
         if getattr(self, "_h", None):
@@ -442,8 +473,16 @@ class Slab27Rank:
 class Slab27Group:
     """All ranks of a 27-point slab decomposition in one process on one GPU (device copies in place of RCCL)."""
 
-    def __init__(self, ranks):
+    def __init__(self, ranks, p2p=0):
+        """p2p 1: the ranks store into each other's ghost planes (peer mode) instead of the copies."""
         self.ranks = list(ranks)
+        if p2p:
+            for a in self.ranks:
+                for b in self.ranks:
+                    if abs(a.rank - b.rank) == 1:
+                        a.p2p_local(b)
+            for a in self.ranks:
+                a.p2p_enable(p2p)
         arr = (ctypes.c_void_p * len(self.ranks))(*[r._h for r in self.ranks])
         g = ctypes.c_void_p()
         check(lib().omg_sdist_group_create(len(self.ranks), arr, ctypes.byref(g)))
@@ -452,6 +491,9 @@ class Slab27Group:
     def cycles(self, pre, post, n_cycles):
         norms = (ctypes.c_double * max(int(n_cycles), 1))()
         check(lib().omg_sdist_group_cycles(self._g, int(pre), int(post), int(n_cycles), norms))
+        for r in self.ranks:
+            if r.p2p_mode and r.p2p_status():
+                raise RuntimeError("rank %d: a bounded wait for a neighbour's flag gave up" % r.rank)
         return [float(norms[k]) for k in range(int(n_cycles))]
 
     def close(self):

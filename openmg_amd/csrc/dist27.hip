@@ -28,6 +28,7 @@
 // The same schedule runs over a LOOPBACK group (all ranks in one process on one GPU, device copies in place of RCCL):
 // tests/test_gpu_dist27.py compares it bit for bit with the single-GPU hierarchy.
 #include <algorithm>
+#include <array>
 #include <cstring>
 #include <memory>
 #include <type_traits>
@@ -65,6 +66,21 @@ struct SDist {
     DevBuf<V> rows_out, rows_in;              // setup: the coefficient rows of one aggregate plane
     hipStream_t own = nullptr, stream = nullptr;
     ncclComm_t comm = nullptr;
+    // Peer mode (round 6; dist.hip's PlaneDist has its own form): the halo exchanges as stores into the neighbours' ghost
+    // planes — hipIpc mappings between processes, plain pointers inside one — ordered by flags instead of grouped
+    // ncclSend / ncclRecv launches.  pflags (in MY memory, written by the neighbours): [0] / [1] "data of exchange k has
+    // landed" from rank - 1 / rank + 1, [2] / [3] "I am done reading my ghost planes of exchange k - 1: overwrite them" from
+    // rank - 1 / rank + 1, [8] status (bit 0: a bounded wait gave up), [9] the push launch's workgroup counter.
+    struct PeerBufs {
+        uint32_t *flags = nullptr;
+        std::vector<V *> x, tmp, b;
+        std::vector<void *> mapped;           // IPC mappings to close
+    };
+    DevBuf<uint32_t> pflags;
+    PeerBufs peer[2];                         // 0: rank - 1, 1: rank + 1
+    int p2p = 0;
+    uint32_t pseq = 0;                        // exchanges so far (the same on every rank: one schedule)
+    uint32_t p2p_spin = 1u << 22;
     bool rows_exchanged = false;              // the upper ghost planes hold the neighbour's coefficient rows
     bool ghosts_current = false;              // the ghost planes of b and x on the finest level are exchanged since the last load
     bool loaded = false;
@@ -74,6 +90,8 @@ struct SDist {
     SDist(const SDist &) = delete;
     SDist &operator=(const SDist &) = delete;
     ~SDist() {
+        for (PeerBufs &P : peer)
+            for (void *m : P.mapped) (void)hipIpcCloseMemHandle(m);
         if (comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(comm);
         if (own) (void)hipStreamDestroy(own);
     }
@@ -145,6 +163,66 @@ __global__ void add_arrays_kernel(double *acc, const double *v, int n) {
 __global__ void sqrt_arrays_kernel(const double *v, double *out, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = sqrt(v[i]);
+}
+
+// ---- peer-store exchange ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void sp_wait(const uint32_t *flag, uint32_t seq, uint32_t *status, uint32_t spin) {
+    if (!flag) return;
+    for (uint32_t n = 0;; ++n) {
+        const uint32_t v = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (int32_t(v - seq) >= 0) break;
+        if (n >= spin) { __hip_atomic_fetch_or(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
+        __builtin_amdgcn_s_sleep(16);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+}
+// "overwrite my ghost planes": everything this rank's stream has done before (all readers of the ghost values of the
+// previous exchange) is complete when this one-thread launch runs
+__global__ void sp_ack_kernel(uint32_t *lo, uint32_t *hi, uint32_t seq) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+    if (lo) __hip_atomic_store(lo, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (hi) __hip_atomic_store(hi, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+constexpr int SP_RUNS = 16;
+template <typename V>
+struct SpPush {
+    const V *src[SP_RUNS];
+    V *dst[SP_RUNS];
+    int dir[SP_RUNS];                 // 0: into rank - 1, 1: into rank + 1
+    int n_runs;
+    long long count;                  // values per run
+    const uint32_t *ack[2];           // my flags: the neighbour allows the overwrite
+    uint32_t *data[2];                // the neighbours' flags: my data has landed
+    uint32_t *done;                   // my workgroup counter
+    uint32_t *status;
+    uint32_t seq, spin;
+};
+// one workgroup row per run (blockIdx.y): wait for the target's permission, copy, and — the launch's last workgroup —
+// tell the neighbours
+template <typename V>
+__global__ __launch_bounds__(256) void sp_push_kernel(const SpPush<V> a) {
+    const int run = int(blockIdx.y);
+    if (threadIdx.x == 0) sp_wait(a.ack[a.dir[run]], a.seq, a.status, a.spin);
+    __syncthreads();
+    const V *const src = a.src[run];
+    V *const dst = a.dst[run];
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < a.count; i += (long long)gridDim.x * blockDim.x) dst[i] = src[i];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t n_wg = gridDim.x * gridDim.y;
+        const uint32_t before = __hip_atomic_fetch_add(a.done, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        if (before == n_wg - 1) {
+            __hip_atomic_store(a.done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+            for (int e = 0; e < 2; ++e)
+                if (a.data[e]) __hip_atomic_store(a.data[e], a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+__global__ void sp_wait_kernel(const uint32_t *lo, const uint32_t *hi, uint32_t seq, uint32_t *status, uint32_t spin) {
+    sp_wait(lo, seq, status, spin);
+    sp_wait(hi, seq, status, spin);
 }
 
 template <typename V>
@@ -345,6 +423,7 @@ struct SExchange {
             const int dn_lo = what == 0 ? 4 : 0, dn_hi = what == 2 ? 4 : 8;         // ... downwards
             const bool lo_nb = d->rank > 0, hi_nb = d->rank + 1 < d->n_ranks;
             if (lo_nb || hi_nb) ++d->exchanges;
+            if (d->p2p) continue;                                                    // (below: in phases over the ranks)
             if (loopback) {
                 // (only the receives: every rank pulls from its neighbours' owned planes)
                 if (lo_nb) {
@@ -376,6 +455,73 @@ struct SExchange {
                 OMG_NCCL(g_rccl.GroupEnd());
             }
         }
+        halo_p2p(l, what);
+    }
+
+    // Peer mode: the same planes as stores into the neighbours' ghost planes.  Three launches per rank — permission, push
+    // (which waits for the neighbours' permission itself), wait for the neighbours' data — enqueued phase by phase over the
+    // ranks this process drives, so that a loopback group (every rank on ONE stream) never waits for a flag a later launch
+    // of the same stream would raise; with one rank per process the phases are simply consecutive on its stream.
+    void halo_p2p(int l, int what) {
+        const int up_lo = what == 2 ? 8 : 4, up_hi = 8;
+        const int dn_lo = what == 0 ? 4 : 0, dn_hi = what == 2 ? 4 : 8;
+        bool any = false;
+        for (D *d : ranks) any = any || d->p2p;
+        if (!any) return;
+        for (D *d : ranks) {
+            OMG_REQUIRE(d->p2p, "peer mode must be on for every rank of the group");
+            ++d->pseq;
+            const bool lo_nb = d->rank > 0, hi_nb = d->rank + 1 < d->n_ranks;
+            if (!lo_nb && !hi_nb) continue;
+            // my permission lands in rank - 1's "ack from rank + 1" [3] and in rank + 1's "ack from rank - 1" [2]
+            hipLaunchKernelGGL(sp_ack_kernel, dim3(1), dim3(1), 0, d->stream, lo_nb ? d->peer[0].flags + 3 : nullptr,
+                               hi_nb ? d->peer[1].flags + 2 : nullptr, d->pseq);
+        }
+        for (D *d : ranks) {
+            const bool lo_nb = d->rank > 0, hi_nb = d->rank + 1 < d->n_ranks;
+            if (!lo_nb && !hi_nb) continue;
+            SLevel<V> &L = d->lv[size_t(l)];
+            const int64_t na = L.plan.g.na, pl = L.pl();
+            const int hz = L.plan.g.hz;
+            const bool in_x = L.xp == L.x.p;                                         // (the neighbours have swapped as often as I have)
+            V *mine = what == 2 ? L.b.p : L.xp;
+            auto theirs = [&](int e) -> V * {
+                const typename D::PeerBufs &P = d->peer[e];
+                return what == 2 ? P.b[size_t(l)] : in_x ? P.x[size_t(l)] : P.tmp[size_t(l)];
+            };
+            SpPush<V> a;
+            std::memset(&a, 0, sizeof(a));
+            int n = 0;
+            if (hi_nb)
+                for (int c = up_lo; c < up_hi; ++c, ++n) { a.src[n] = mine + c * na + int64_t(hz - 2) * pl; a.dst[n] = theirs(1) + c * na; a.dir[n] = 1; }
+            if (lo_nb)
+                for (int c = dn_lo; c < dn_hi; ++c, ++n) { a.src[n] = mine + c * na + pl; a.dst[n] = theirs(0) + c * na + int64_t(hz - 1) * pl; a.dir[n] = 0; }
+            OMG_REQUIRE(n <= SP_RUNS, "internal: too many runs in one exchange");
+            a.n_runs = n;
+            a.count = pl;
+            a.ack[0] = lo_nb ? d->pflags.p + 2 : nullptr;
+            a.ack[1] = hi_nb ? d->pflags.p + 3 : nullptr;
+            a.data[0] = lo_nb ? d->peer[0].flags + 1 : nullptr;                      // rank - 1's "data from rank + 1"
+            a.data[1] = hi_nb ? d->peer[1].flags + 0 : nullptr;                      // rank + 1's "data from rank - 1"
+            a.done = d->pflags.p + 9;
+            a.status = d->pflags.p + 8;
+            a.seq = d->pseq;
+            a.spin = d->p2p_spin;
+            if (n) {
+                const unsigned gx = unsigned(std::max<int64_t>(1, std::min<int64_t>(32, (pl + 2047) / 2048)));
+                hipLaunchKernelGGL((sp_push_kernel<V>), dim3(gx, unsigned(n)), dim3(256), 0, d->stream, a);
+            } else {
+                // (nothing travels from this rank in this exchange, but its neighbours wait for its flag)
+                hipLaunchKernelGGL(sp_ack_kernel, dim3(1), dim3(1), 0, d->stream, a.data[0], a.data[1], d->pseq);
+            }
+        }
+        for (D *d : ranks) {
+            const bool lo_nb = d->rank > 0, hi_nb = d->rank + 1 < d->n_ranks;
+            if (!lo_nb && !hi_nb) continue;
+            hipLaunchKernelGGL(sp_wait_kernel, dim3(1), dim3(1), 0, d->stream, lo_nb ? d->pflags.p + 0 : nullptr, hi_nb ? d->pflags.p + 1 : nullptr,
+                               d->pseq, d->pflags.p + 8, d->p2p_spin);
+        }
+        OMG_HIP(hipGetLastError());
     }
 
     // right-hand side of the level below the slabs: gathered, solved by the replicated tail, this rank's planes (and
@@ -551,6 +697,35 @@ template <typename HP>
 using value_of = typename std::remove_pointer<HP>::type::value_type;
 }  // namespace
 
+namespace {
+template <typename V>
+void sd_own_buffers(SDist<V> *d, std::vector<void *> &out, std::vector<size_t> &shift) {
+    if (!d->pflags.p) {
+        d->pflags.alloc(64);
+        d->pflags.zero(d->stream);
+        OMG_HIP(hipStreamSynchronize(d->stream));
+    }
+    out = {d->pflags.p};
+    shift = {d->pflags.shift};
+    for (auto &L : d->lv) {
+        out.push_back(L.x.p); out.push_back(L.tmp.p); out.push_back(L.b.p);
+        shift.push_back(L.x.shift); shift.push_back(L.tmp.shift); shift.push_back(L.b.shift);
+    }
+}
+template <typename V>
+void sd_attach(SDist<V> *d, int peer_rank, const std::vector<void *> &bufs) {
+    OMG_REQUIRE(peer_rank == d->rank - 1 || peer_rank == d->rank + 1, "peer mode maps the slab's two neighbours only");
+    auto &P = d->peer[peer_rank == d->rank - 1 ? 0 : 1];
+    P.flags = static_cast<uint32_t *>(bufs[0]);
+    P.x.clear(); P.tmp.clear(); P.b.clear();
+    for (size_t l = 0; l < d->lv.size(); ++l) {
+        P.x.push_back(static_cast<V *>(bufs[1 + 3 * l]));
+        P.tmp.push_back(static_cast<V *>(bufs[2 + 3 * l]));
+        P.b.push_back(static_cast<V *>(bufs[3 + 3 * l]));
+    }
+}
+}  // namespace
+
 extern "C" {
 
 int omg_sdist_create(int rank, int n_ranks, int nx, int ny, int nz_global, int n_levels, const omg_csr *A_rows, double weight, int dtype,
@@ -702,6 +877,119 @@ int omg_sdist_cycles(omg_sdist *d, int pre, int post, int n_cycles, double *norm
             SExchange<V> ex;
             ex.ranks = {dd};
             ex.run(pre, post, n_cycles, norms);
+        });
+    });
+}
+
+/* ---- peer mode for the halo exchanges ----------------------------------------------------------
+ * As omg_pdist_p2p_*: every rank exports IPC handles of what its neighbours store into — its flag words, then x / tmp / b
+ * of every level: 1 + 3 per level handles of 64 bytes —, the control plane hands them round, a rank opens its NEIGHBOURS'
+ * (omg_sdist_p2p_open; same process: omg_sdist_p2p_local), then omg_sdist_p2p_enable(1).  The gather below the slabs and
+ * the norm's reduction stay on the communicator. */
+int omg_sdist_p2p_handle_count(omg_sdist *d, int *count) {
+    return guarded([&] {
+        OMG_REQUIRE(count, "null argument");
+        with(d, [&](auto *dd) { *count = 1 + 3 * int(dd->lv.size()); });
+    });
+}
+
+int omg_sdist_p2p_handles(omg_sdist *d, void *handles64, int capacity) {
+    return guarded([&] {
+        OMG_REQUIRE(handles64, "null argument");
+        with(d, [&](auto *dd) {
+            std::vector<void *> bufs;
+            std::vector<size_t> shift;
+            sd_own_buffers(dd, bufs, shift);
+            OMG_REQUIRE(capacity >= int(bufs.size()), "handle buffer too small");
+            OMG_HIP(hipStreamSynchronize(dd->stream));
+            for (size_t i = 0; i < bufs.size(); ++i) {
+                hipIpcMemHandle_t h;
+                OMG_HIP(hipIpcGetMemHandle(&h, static_cast<char *>(bufs[i]) - DEVBUF_SLACK - shift[i]));     // (the allocation's base)
+                std::memcpy(static_cast<char *>(handles64) + 64 * i, &h, 64);
+            }
+        });
+    });
+}
+
+int omg_sdist_p2p_open(omg_sdist *d, int peer_rank, const void *handles64, int count) {
+    return guarded([&] {
+        OMG_REQUIRE(handles64, "null argument");
+        with(d, [&](auto *dd) {
+            OMG_REQUIRE(peer_rank == dd->rank - 1 || peer_rank == dd->rank + 1, "peer mode maps the slab's two neighbours only");
+            OMG_REQUIRE(peer_rank >= 0 && peer_rank < dd->n_ranks && count == 1 + 3 * int(dd->lv.size()), "bad peer rank / handle count");
+            auto &P = dd->peer[peer_rank == dd->rank - 1 ? 0 : 1];
+            OMG_REQUIRE(P.mapped.empty(), "peer already opened");
+            std::vector<void *> own, bufs;
+            std::vector<size_t> shift;
+            sd_own_buffers(dd, own, shift);                  // (the neighbour's vectors sit in their allocations as mine do)
+            std::vector<std::pair<std::array<char, 64>, void *>> opened;
+            for (int i = 0; i < count; ++i) {
+                std::array<char, 64> key;
+                std::memcpy(key.data(), static_cast<const char *>(handles64) + 64 * i, 64);
+                void *base = nullptr;
+                for (const auto &o : opened)
+                    if (o.first == key) base = o.second;
+                if (!base) {
+                    hipIpcMemHandle_t h;
+                    std::memcpy(&h, key.data(), 64);
+                    OMG_HIP(hipIpcOpenMemHandle(&base, h, hipIpcMemLazyEnablePeerAccess));
+                    P.mapped.push_back(base);
+                    opened.emplace_back(key, base);
+                }
+                bufs.push_back(static_cast<char *>(base) + DEVBUF_SLACK + shift[size_t(i)]);
+            }
+            sd_attach(dd, peer_rank, bufs);
+        });
+    });
+}
+
+int omg_sdist_p2p_local(omg_sdist *d, omg_sdist *other) {
+    return guarded([&] {
+        OMG_REQUIRE(d && other && bool(d->f) == bool(other->f), "null argument / mixed dtypes");
+        with(d, [&](auto *dd) {
+            using V = value_of<decltype(dd)>;
+            SDist<V> *oo;
+            if constexpr (std::is_same<V, double>::value) oo = other->d.get();
+            else oo = other->f.get();
+            OMG_REQUIRE(oo && oo->n_ranks == dd->n_ranks && oo->lv.size() == dd->lv.size(), "not another rank of the same decomposition");
+            std::vector<void *> bufs;
+            std::vector<size_t> shift;
+            sd_own_buffers(oo, bufs, shift);
+            sd_attach(dd, oo->rank, bufs);
+        });
+    });
+}
+
+int omg_sdist_p2p_enable(omg_sdist *d, int mode) {
+    return guarded([&] {
+        OMG_REQUIRE(mode == 0 || mode == 1, "bad argument");
+        with(d, [&](auto *dd) {
+            if (mode) {
+                std::vector<void *> bufs;
+                std::vector<size_t> shift;
+                sd_own_buffers(dd, bufs, shift);                // (my own flag words exist)
+                if (dd->rank > 0) OMG_REQUIRE(dd->peer[0].flags, "peer mode: rank - 1's buffers have not been opened");
+                if (dd->rank + 1 < dd->n_ranks) OMG_REQUIRE(dd->peer[1].flags, "peer mode: rank + 1's buffers have not been opened");
+                if (const char *e = getenv("OMG_P2P_SPIN")) dd->p2p_spin = uint32_t(std::max(1l, atol(e)));
+            }
+            OMG_HIP(hipStreamSynchronize(dd->stream));
+            dd->p2p = mode;
+        });
+    });
+}
+
+/* bit 0: a wait for a neighbour's flag gave up since the last call (the results since then are not to be used) */
+int omg_sdist_p2p_status(omg_sdist *d, unsigned *status) {
+    return guarded([&] {
+        OMG_REQUIRE(status, "null argument");
+        with(d, [&](auto *dd) {
+            uint32_t v = 0;
+            if (dd->pflags.p) {
+                OMG_HIP(hipMemcpyAsync(&v, dd->pflags.p + 8, 4, hipMemcpyDeviceToHost, dd->stream));
+                OMG_HIP(hipMemsetAsync(dd->pflags.p + 8, 0, 4, dd->stream));
+                OMG_HIP(hipStreamSynchronize(dd->stream));
+            }
+            *status = v;
         });
     });
 }

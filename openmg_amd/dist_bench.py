@@ -200,6 +200,50 @@ def main_slab27(args, rank, world, shape, grids, n_levels, all_gather, td, torch
     first_norm = preflight.run(rank, world, lambda: r.cycles(pre, post, 1)[0], all_gather, min(120.0, max(20.0, args.watchdog / 4.0)),
                                where=lambda: "27-point slab cycle")
     exchanges = r.info(0)["exchanges_last_call"]
+    # Peer mode for the halo exchanges (omg_sdist_p2p_*, round 6): on request only (OMG_DIST_P2P=1) — tried after the RCCL
+    # preflight, kept only if every rank mapped its neighbours and one checked cycle from the same start gives the RCCL
+    # cycle's norm on every rank.  (There is no fallback inside the timed regions as the plane slabs have: a wait that gives
+    # up there raises.)
+    exchange = ("RCCL grouped send/recv of ghost aggregate planes (colours 4..7 both ways after every sweep, colours 0..3 of the "
+                "coarse right-hand side after every restriction)")
+    p2p_note = "not tried (OMG_DIST_P2P=1 asks for it)"
+    if world > 1 and os.environ.get("OMG_DIST_P2P", "auto") == "1":
+        devices = all_gather(int(torch.cuda.current_device()))
+        nbs = [q for q in (rank - 1, rank + 1) if 0 <= q < world]
+        try:
+            reach = all(_hip_dist.peer_access(devices[rank], devices[q]) for q in nbs)
+            mine = r.p2p_handles() if reach else None
+            note = None if reach else "rank %d's GPU cannot address a neighbour's memory (hipDeviceCanAccessPeer)" % rank
+        except Exception as e:                                  # noqa: BLE001 - any failure means "stay with RCCL"
+            mine, note = None, "export failed on rank %d: %s" % (rank, e)
+        handles = all_gather(mine)
+        ok = all(h is not None for h in handles)
+        if ok:
+            try:
+                for q in nbs:
+                    r.p2p_open(q, handles[q])
+                r.p2p_enable(1)
+            except Exception as e:                              # noqa: BLE001
+                ok, note = False, "mapping failed on rank %d: %s" % (rank, e)
+        if all(all_gather(bool(ok))):
+            r.load(b_loc)
+            try:
+                peer_norm = preflight.run(rank, world, lambda: r.cycles(pre, post, 1)[0], all_gather, min(120.0, max(20.0, args.watchdog / 4.0)),
+                                          where=lambda: "27-point slab cycle, peer stores")
+                ok = abs(peer_norm - first_norm) <= 1e-9 * abs(first_norm)
+                note = None if ok else "norm after one cycle %.17g, RCCL cycle gave %.17g" % (peer_norm, first_norm)
+            except RuntimeError as e:
+                ok, note = False, str(e)
+        else:
+            ok = False
+        if all(all_gather(bool(ok))):
+            exchange = "peer stores into the neighbours' ghost aggregate planes (xGMI), flags; the gather below the slabs and the norm's reduction over RCCL"
+            p2p_note = "checked against the RCCL cycle: same norm on every rank"
+        else:
+            if r.p2p_mode:
+                r.p2p_enable(0)
+            notes = [n for n in all_gather(note) if n]
+            p2p_note = "rejected: " + (notes[0] if notes else "another rank failed")
     r.load(b_loc)
     trajectory = r.cycles(pre, post, 1)
     for _ in range(args.warmup):
@@ -252,8 +296,7 @@ def main_slab27(args, rank, world, shape, grids, n_levels, all_gather, td, torch
                                    % ("x".join(map(str, shape)), grids, "fp64" if w == 8 else "fp32", world),
                        "unknowns": n_glob, "unknowns_per_gpu": n_loc, "nnz_per_gpu": nnz_loc, "grids": grids,
                        "distributed_grids": n_levels, "replicated_tail_grids": tgrids, "runner": "27-point slabs (omg_sdist)",
-                       "exchange": "RCCL grouped send/recv of ghost aggregate planes (colours 4..7 both ways after every sweep, colours 0..3 of the "
-                                   "coarse right-hand side after every restriction)",
+                       "exchange": exchange, "peer_mode": p2p_note,
                        "halo_exchanges_per_cycle": exchanges, "rccl_ranks": rccl_ranks, "repeats": len(times),
                        "ranks_share_one_gpu": os.environ.get("OMG_DIST_SHARED_GPU", "0") in ("1", "rccl") and world > 1,
                        "preflight_norm": first_norm, "kernel_src_sha": src_sha, "git_head": head,

@@ -86,6 +86,15 @@ def main():
         tails.append(tail)
         r.set_tail(tail)
         r.connect(ids(1)[0])                              # (collective: also the neighbours' coefficient rows)
+        if extra == "p2p":
+            # the halo exchanges as peer stores between the rank PROCESSES (hipIpc mappings of the neighbours' vectors and
+            # flags); the gather below the slabs and the norm's reduction stay on the communicator
+            handles = all_gather(r.p2p_handles())
+            for nb in (rank - 1, rank + 1):
+                if 0 <= nb < world:
+                    r.p2p_open(nb, handles[nb])
+            r.p2p_enable(1)
+            td.barrier()
         u = np.random.default_rng(11).random(n_glob)
         b = A_rows @ u
         x0 = np.random.default_rng(12).standard_normal(n_glob)[rank * per:(rank + 1) * per]

@@ -21,7 +21,7 @@ def single_gpu(shape, grids, dtype):
     return A, R, _hip.Hierarchy(A, R, smoother="colour", dtype=dtype)
 
 
-def slab_group(shape, world, n_levels, grids, dtype):
+def slab_group(shape, world, n_levels, grids, dtype, p2p=0):
     plane = shape[1] * shape[2]
     per = shape[0] // world
     ranks = [_hip_dist.Slab27Rank(r, world, shape, dist.stencil27_variable_rows(shape, r * per * plane, (r + 1) * per * plane), n_levels,
@@ -31,7 +31,7 @@ def slab_group(shape, world, n_levels, grids, dtype):
     tails = [dist.make_tail(coarse, tshape, grids - n_levels, smoother="colour", dtype=dtype) for _ in ranks]
     for r, t in zip(ranks, tails):
         r.set_tail(t)
-    return _hip_dist.Slab27Group(ranks), tails, coarse
+    return _hip_dist.Slab27Group(ranks, p2p=p2p), tails, coarse
 
 
 def close(a, b, tol=1e-12):
@@ -78,6 +78,63 @@ def test_slab_groups_have_the_bits_of_the_single_gpu_hierarchy(shape, grids, wor
         for t in tails:
             t.close()
         h.close()
+
+
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+@pytest.mark.parametrize("shape,grids,world,n_levels", [((16, 16, 16), 3, 2, 2), ((32, 16, 32), 4, 4, 3), ((32, 16, 32), 4, 8, 2), ((32, 24, 32), 3, 2, 2)])
+def test_peer_store_exchanges_have_the_bits_of_the_single_gpu_hierarchy(shape, grids, world, n_levels, dtype):
+    """Round 6 ("also give dist27 the peer-store exchange PlaneDist has"): the halo exchanges as stores into
+    the neighbours' ghost planes ordered by flags — permission, push, landed — instead of copies / grouped send-recv; the
+    same planes, the same bits, the same number of exchanges."""
+    A, R, h = single_gpu(shape, grids, dtype)
+    g, tails, _ = slab_group(shape, world, n_levels, grids, dtype, p2p=1)
+    try:
+        rng = np.random.default_rng(11)
+        b = A[0] @ rng.random(A[0].shape[0])
+        x0 = rng.standard_normal(A[0].shape[0])
+        if dtype == "float32":
+            b, x0 = b.astype(np.float32).astype(np.float64), x0.astype(np.float32).astype(np.float64)
+        per = b.size // world
+        for pre, post in ((1, 1), (1, 0), (2, 1), (0, 0)):
+            h.resident_load(b, x0)
+            want_norms = h.resident_cycles(pre, post, 3)
+            want_x = h.resident_fetch()
+            for r in g.ranks:
+                r.load(b[r.rank * per:(r.rank + 1) * per], x0[r.rank * per:(r.rank + 1) * per])
+            norms = g.cycles(pre, post, 3)
+            x = np.concatenate([r.fetch() for r in g.ranks])
+            assert np.array_equal(x, want_x), (shape, world, dtype, pre, post, int(np.sum(x != want_x)))
+            assert close(norms, want_norms, 1e-12 if dtype == "float64" else 1e-6)
+            assert g.ranks[1].info()["exchanges_last_call"] == 3 * ((pre + post) + (n_levels - 1) * (1 + pre + post))
+    finally:
+        g.close()
+        for t in tails:
+            t.close()
+        h.close()
+
+
+def test_a_peer_store_wait_gives_up_instead_of_hanging(monkeypatch):
+    """A neighbour that never answers (its buffers mapped, peer mode on, but it does not run the cycle): the bounded wait
+    (OMG_P2P_SPIN polls) ends, the call raises."""
+    monkeypatch.setenv("OMG_P2P_SPIN", "2000")
+    shape, world = (16, 16, 16), 2
+    plane, per = 256, 8
+    ranks = [_hip_dist.Slab27Rank(r, world, shape, dist.stencil27_variable_rows(shape, r * per * plane, (r + 1) * per * plane), 1) for r in range(world)]
+    coarse = dist.assemble_coarse([r.coarse_rows() for r in ranks])
+    tails = [dist.make_tail(coarse, (8, 8, 8), 2, smoother="colour") for _ in ranks]
+    for r, t in zip(ranks, tails):
+        r.set_tail(t)
+    g = _hip_dist.Slab27Group(ranks, p2p=1)                 # (neighbour rows exchanged, buffers mapped)
+    try:
+        b = np.random.default_rng(2).random(shape[0] * plane)
+        for r in ranks:
+            r.load(b[r.rank * per * plane:(r.rank + 1) * per * plane])
+        with pytest.raises((RuntimeError, _hip.HipError)):
+            ranks[0].cycles(1, 1, 1)                        # rank 1 does not take part
+    finally:
+        g.close()
+        for t in tails:
+            t.close()
 
 
 @pytest.mark.parametrize("pre,post", [(1, 1), (1, 0)])

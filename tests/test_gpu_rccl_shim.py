@@ -172,6 +172,19 @@ def test_27_point_slabs_over_the_rccl_call_sites(tmp_path, world, shape, grids, 
     assert int(out[1]["exchanges"]) == 3 * ((2 + 1) + (n_dist - 1) * (1 + 2 + 1))
 
 
+@pytest.mark.parametrize("world,shape,grids,n_dist,dtype", [(2, (16, 16, 16), 3, 2, "float64"), (4, (32, 16, 32), 4, 3, "float32"), (8, (64, 32, 64), 4, 2, "float32")])
+def test_27_point_slabs_with_peer_stores_between_processes(tmp_path, world, shape, grids, n_dist, dtype):
+    """omg_sdist_p2p_*: the halo exchanges of the 27-point slabs as stores into the neighbour PROCESSES' ghost planes
+    (hipIpc mappings, flags, bounded waits); the gather and the norm's reduction through the communicator.  Bit for bit the
+    single-GPU hierarchy, as over send / recv."""
+    out = run_ranks(tmp_path, world, "slab27", shape, grids, n_dist, dtype=dtype, extra="p2p")
+    norms, res = slab27_reference(shape, grids, dtype)
+    for key, want in res.items():
+        got = np.concatenate([o[key] for o in out])
+        assert np.array_equal(got, want), (key, int(np.sum(got != want)))
+    np.testing.assert_allclose(out[0]["norms"], norms, rtol=1e-12 if dtype == "float64" else 1e-6)
+
+
 def test_27_point_slabs_at_the_eight_gpu_rank_shape(tmp_path):
     """configs[4]'s per-rank shape — a 512 x 512 x 64 slab, fp32 — through dist27.hip's RCCL path: two processes over
     (128, 512, 512).  Too large for a single-GPU comparison inside the suite's time; the size-independent properties:
