@@ -797,6 +797,8 @@ def main(args):
                        "pre": pre, "post": post, "cycles_per_s": round(args.steps / elapsed, 3),
                        "final_residual_norm": norm, "norms_last_region_tail": region_norms[-3:],
                        "setup_s": round(setup_s, 2)},
+            # (the set-by-set runner measures no one-GPU baselines: the keys are there, empty)
+            "vs_n1_config2": None, "vs_one_gpu_same_problem": None, "one_gpu_baselines": None,
             # rank 0's y = A x over its own rows: bytes the launch has to move with the operator in
             # its device format over the launch time, frac <= 1 by construction;
             # the rate in SURVEY 8(d)'s plain-CSR bytes is csr_equiv_GBps

@@ -110,7 +110,9 @@ __global__ void __launch_bounds__(1024) xfer_kernel(const uint64_t *wait_ctr, ui
     if (wait_ctr) {
         if (threadIdx.x == 0) {
             const long long t0 = wall_clock64();
-            for (;;) {
+            // (once a wait has given up the schedule is broken: the launches still queued behind it do not wait their turn out)
+            const bool broken = __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0;
+            for (; !broken;) {
                 const uint64_t v = __hip_atomic_load(wait_ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 if (v >= wait_value) break;
                 if (wall_clock64() - t0 > ticks) {
