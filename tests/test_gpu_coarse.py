@@ -269,3 +269,15 @@ def test_coarsest_level_beyond_the_old_limits_is_solved():
         xo, inf = orc.mg_cycle(Ao, b0, 0, Ro, dict(p, coarsestLevel=1), initial=xo, smoother=sm)
     assert abs(info["norm"] - inf["norm"]) <= 1e-10 * inf["norm"]
     np.testing.assert_allclose(x, xo, rtol=1e-9, atol=1e-11 * np.abs(xo).max())
+
+
+def test_block_chain_at_a_size_superlu_does_not_finish_in_seconds():
+    """40^3 27-point variable-coefficient (64 000 unknowns, half-bandwidth 1641: 38 blocks, 0.9 GB of factors) — SuperLU
+    needs more than a minute here, so the check is the size-independent one: the solution's residual at rounding level, and the solve
+    is linear bit for bit in its right-hand side's scale (solve(2 b) = 2 solve(b): products with inverses and sums)."""
+    A = operators.stencil27_variable((40, 40, 40))
+    n = A.shape[0]
+    b = np.random.default_rng(4).standard_normal(n)
+    x = _hip.direct_solve(A, b)
+    assert np.linalg.norm(b - A @ x) <= 1e-12 * np.linalg.norm(b)
+    assert np.array_equal(_hip.direct_solve(A, 2.0 * b), 2.0 * x)

@@ -160,3 +160,47 @@ def test_device_setup_in_single_precision_and_lexicographic_on_the_same_input(mo
         xo, io = orc.mg_cycle(ig["A"], b, 0, ig["R"], dict(pg, coarsestLevel=2), initial=xo)
     assert abs(ig["norm"] - io["norm"]) <= 1e-10 * io["norm"]
     np.testing.assert_allclose(xg, xo, rtol=1e-9, atol=1e-12 * np.abs(xo).max())
+
+
+def test_full_size_256_cubed_through_size_independent_properties():
+    """The bench's `var7` workload itself — 256^3, 5 grids, kappa over two decades — where the sequential oracle is out of
+    reach: the fused passes give the bits of the set-by-set schedule, the device's norm is SciPy's ||b - A x|| of the fetched
+    iterate (1e-10), the cycle is linear bit for bit (cycle(2 b) = 2 cycle(b): every operation of the passes is), it contracts;
+    and the reference's own smoother on the same hierarchy (per-row wavefront levels) gives the level schedule's bits at 128^3."""
+    shape = (256, 256, 256)
+    A0 = operators.stencil7_variable(shape)
+    b = A0 @ np.random.default_rng(12345).random(A0.shape[0])
+    R = operators.restrictionList(shape, 3, 8)
+    A = operators.coeffecientList(A0, R)
+    with _hip.Hierarchy(A, R, smoother="colour") as h:
+        assert [h.level_flags(l)["var7"] for l in range(4)] == [True, True, False, False]
+        h.resident_load(b)
+        norms = h.resident_cycles(1, 1, 3)
+        x = h.resident_fetch()
+        host = float(np.linalg.norm(b - A0 @ x))
+        assert abs(norms[-1] - host) <= 1e-10 * host
+        assert norms[2] < norms[1] < norms[0]
+        h.resident_load(2.0 * b)
+        h.resident_cycles(1, 1, 3)
+        assert np.array_equal(h.resident_fetch(), 2.0 * x)
+        h.use_plane(False)
+        h.resident_load(b)
+        ns = h.resident_cycles(1, 1, 3)
+        assert np.array_equal(h.resident_fetch(), x)
+        np.testing.assert_allclose(ns, norms, rtol=1e-12)
+    # the reference's lexicographic sweep on per-row coefficients: wavefront launches against the level schedule, 128^3
+    import os
+    As, Rs = A[1:], R[1:]
+    bs = np.random.default_rng(5).random(As[0].shape[0])
+    out = {}
+    for march in ("1", "0"):
+        os.environ["OMG_MARCH"] = march
+        try:
+            with _hip.Hierarchy(As, Rs, smoother="gs") as h:
+                assert bool(h.level_flags(0)["march"]) == (march == "1")
+                h.resident_load(bs)
+                out[march] = (h.resident_cycles(1, 1, 2), h.resident_fetch())
+        finally:
+            del os.environ["OMG_MARCH"]
+    assert np.array_equal(out["1"][1], out["0"][1])
+    np.testing.assert_allclose(out["1"][0], out["0"][0], rtol=1e-12)
