@@ -132,6 +132,9 @@ int omg_hierarchy_level_fused(const omg_hierarchy *h, int level, int *fused);
 #define OMG_LEVEL_SCATTER_PROLONG  2
 #define OMG_LEVEL_UNION_WALK       16  /* every smoother set of A runs rows_union_kernel (several rows per thread) */
 #define OMG_LEVEL_MARCH            32  /* lexicographic Gauss-Seidel runs as one wavefront launch per sweep (march.hip) */
+#define OMG_LEVEL_MARCH_SCAN       512 /* ... and that launch is the line-scan kernel (OMG_MARCH_SCAN=1 when the hierarchy was made: 3-D,
+                                           at most 255 distinct rows, lines of at most 512 rows): rounding-level differences from
+                                           the sequential loop, march.hip scan_gs_kernel */
 #define OMG_LEVEL_PLANE            64  /* red-black sweeps of a grid star stencil: each half of a V(>=1, >=1) cycle over this
                                         * level (openmg/__init__.py:201-210 and :214-227) is ONE plane-pipelined launch (plane.hip) */
 #define OMG_LEVEL_VAR7             256 /* 7-point grid stencil with per-row coefficients under the 2x2x2 aggregation, red-black:

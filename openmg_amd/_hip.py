@@ -473,11 +473,13 @@ class Hierarchy:
         return bool(v.value)
 
     def level_flags(self, level):
-        """dict(fused_last_set=bool, scatter_prolong=bool, union_walk=bool, march=bool, plane=bool, stencil27=bool) of a smoothed level."""
+        """dict(fused_last_set=bool, scatter_prolong=bool, union_walk=bool, march=bool, plane=bool, stencil27=bool, var7=bool,
+        march_scan=bool) of a smoothed level."""
         f = ctypes.c_int(0)
         check(lib().omg_hierarchy_level_flags(self._h, int(level), ctypes.byref(f)))
         return {"fused_last_set": bool(f.value & 1), "scatter_prolong": bool(f.value & 2), "union_walk": bool(f.value & 16),
-                "march": bool(f.value & 32), "plane": bool(f.value & 64), "stencil27": bool(f.value & 128), "var7": bool(f.value & 256)}
+                "march": bool(f.value & 32), "plane": bool(f.value & 64), "stencil27": bool(f.value & 128), "var7": bool(f.value & 256),
+                "march_scan": bool(f.value & 512)}
 
     def use_plane(self, enable=True):
         """Plane-pipelined passes on / off (omg_hierarchy_use_plane; same iterate either way)."""

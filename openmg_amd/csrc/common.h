@@ -595,6 +595,12 @@ struct MarchPlan {
     // into an LDS ring one block ahead of the computing wave (round 6)
     bool per_row = false;
     DevBuf<V> rowc;
+    // OMG_MARCH_SCAN=1 (opt-in, 3-D pattern-table levels, nx <= 512): a wave resolves a whole grid line by a scan over the
+    // line's first-order recurrence — ny + nz - 1 line steps per sweep; NOT the bits of the sequential loop (march.hip)
+    bool line_scan = false;
+    int scan_c = 0, scan_g = 0;       // rows per lane (64 scan_c >= nx); workgroups (SCAN_W planes each)
+    DevBuf<uint8_t> rowcode;          // every row's pattern, natural order
+    DevBuf<V> face_scan;              // [workgroup][line][64 scan_c]: the last plane's relaxed lines for the next workgroup
     // false: the operator is not such a stencil (the caller keeps the level schedule)
     bool build(const omg_csr &A, hipStream_t s);
     void sweep(V *x, const V *b, hipStream_t s) const;   // one in-place lexicographic sweep

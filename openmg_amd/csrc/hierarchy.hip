@@ -1773,6 +1773,7 @@ int omg_hierarchy_level_flags(const omg_hierarchy *h, int level, int *flags) {
                      ((smoothed && hh->lv[level].scatter_prolong) ? OMG_LEVEL_SCATTER_PROLONG : 0) |
                      ((smoothed && hh->lv[level].A.all_union()) ? OMG_LEVEL_UNION_WALK : 0) |
                      ((smoothed && hh->lv[level].march) ? OMG_LEVEL_MARCH : 0) |
+                     ((smoothed && hh->lv[level].march && hh->lv[level].march->line_scan) ? OMG_LEVEL_MARCH_SCAN : 0) |
                      ((smoothed && hh->lv[level].plane && !hh->no_plane) ? OMG_LEVEL_PLANE : 0) |
                      ((smoothed && hh->lv[level].s27 && !hh->no_plane) ? OMG_LEVEL_STENCIL27 : 0) |
                      ((smoothed && hh->lv[level].var7 && !hh->no_plane) ? OMG_LEVEL_VAR7 : 0);

@@ -702,6 +702,423 @@ __global__ void fill_kernel(V *p, size_t n, V v) {
     for (size_t q = blockIdx.x * size_t(blockDim.x) + threadIdx.x; q < n; q += size_t(gridDim.x) * blockDim.x) p[q] = v;
 }
 
+
+// ---- the line-scan sweep (opt-in: OMG_MARCH_SCAN=1) ----------------------------------------------
+// Not the bits of the level schedule: within a grid line the sweep is the first-order recurrence
+//   x_i = c_i + alpha_i x_{i-1},  alpha_i = -a_{i,i-1} / a_ii,  c_i = (b_i - the other five neighbours' terms) / a_ii
+// (the row's own old value drops out), and a wave resolves a whole line at once by a scan over (alpha, c) pairs — every lane
+// holds C consecutive rows and composes them in order, the 64 lane totals are composed by six DPP steps (row_shr 1 2 4 8,
+// row_bcast 15 31), and each lane applies its predecessor's end value.  The additions associate differently from the
+// sequential loop and the division is a multiplication by the reciprocal (differences of a few ulp per row, |alpha| < 1):
+// an option beside march_gs_kernel, tested against it to a tolerance.
+//   * i leaves the wavefront: a line (j, k) needs the relaxed lines (j - 1, k) and (j, k - 1): ny + nz - 1 line steps
+//     instead of nx + ny + nz - 2 row steps, and every lane busy at every step.
+//   * A workgroup owns SCAN_W consecutive planes, one COMPUTING wave per plane; wave w relaxes line j = t - w of its plane at
+//     step t: the (j - 1, k) line is its own previous result (registers), the (j, k - 1) line what wave w - 1 left in LDS one
+//     step earlier.  Operands that are old values (own line, line j + 1, plane k + 1) and b are loaded D steps ahead into
+//     registers; the computing waves never store to global memory (one counter for loads and stores: march_gs_kernel's header).
+//     A step is split at the point where the (j, k - 1) line is needed: the rows' sums without that neighbour and the whole
+//     alpha half of the scan (products of coefficients) come before it.
+//   * No barrier per step: every wave publishes the steps it has finished in LDS (s_prog) and waits for the counts it needs —
+//     its predecessor's step t - 1, and that the slot it is about to overwrite (SCAN_SLOTS steps old) has been read by its
+//     successor and stored.
+//   * A STORING wave writes finished lines from LDS to x — the workgroup's last plane first and, write-through, into the face
+//     slots the next workgroup waits for (unset = a marker NaN between sweeps, as march_gs_kernel's faces) — and sets the face
+//     slots this workgroup has consumed back to unset.
+//   * A GHOST wave polls the previous workgroup's face lines, SCAN_Q lines per round, round after round, and hands complete
+//     lines to wave 0 through an LDS ring.  Workgroups take their position from a ticket, so the one a workgroup waits for has
+//     always started; every wait is bounded, then the error flag (MarchPlan::timed_out) and no more waiting.
+// Measured (profiles/r06_scan_*): 256^3 0.69 ms per sweep against 0.92 (march_gs_kernel), 128^3 0.23 against 0.38, 64^3 0.10
+// against 0.18, 32^3 0.05 against 0.08.  A workgroup alone: 0.8 us per step at nx = 256 (259 steps: 0.21 ms); a hop to the
+// next workgroup 4.6 us before its first line is out (0.7 us per wave of the chain + 1.5 us through HBM), and each workgroup
+// runs a little slower than the one that feeds it (0.30 ms for the 4th, 0.35 for the 60th of 64).
+constexpr int SCAN_W = 4;          // planes = computing waves per workgroup
+constexpr int SCAN_RING = 16;      // ghost lines in LDS
+constexpr int SCAN_Q = 8;          // face lines polled per round
+constexpr int SCAN_SLOTS = 5;      // steps a computing wave's lines stay in LDS
+constexpr int SCAN_ROUND_LIMIT = 1 << 18;   // rounds of the ghost wave without a new line (~1 us each)
+constexpr int SCAN_SPIN_LIMIT = 1 << 24;    // polls of an LDS count (~0.1 us each)
+
+template <typename V>
+struct ScanArgs {
+    V *x;
+    const V *b;
+    const uint8_t *code;   // pattern of every row, natural order
+    const V *coef;         // [pattern][8]
+    V *face;               // [workgroup][line][64 C]
+    uint32_t *sync;        // ticket, finished workgroups, error flag
+    int nx, ny, nz, G, n_pat;
+    long long *trace;      // OMG_SCAN_TRACE=1 (experiments): per workgroup, wall_clock64 ticks of [0] start, [1] ghost has line 0,
+                           // [2] face line 0 stored, [3] ghost has the last line, [4] last face line stored, [5] end
+};
+
+template <int CTRL, int RM>
+__device__ __forceinline__ double dpp_take(double old, double src) {
+    const int lo = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(src), CTRL, RM, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(src), CTRL, RM, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+template <int CTRL, int RM>
+__device__ __forceinline__ float dpp_take(float old, float src) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(src), CTRL, RM, 0xf, false));
+}
+// the seven table entries the scan uses (the eighth is not read: a register nobody needs would be handed to the next read
+// while this one is still in flight, and the compiler would wait between the rows' reads)
+__device__ __forceinline__ void load_coefs7(const double *c, double (&o)[8]) {
+    typedef double v2d __attribute__((ext_vector_type(2)));
+    const v2d *p = reinterpret_cast<const v2d *>(c);
+    const v2d a = p[0], b = p[1], e = p[2];
+    o[0] = a.x; o[1] = a.y; o[2] = b.x; o[3] = b.y; o[4] = e.x; o[5] = e.y; o[6] = c[6];
+}
+__device__ __forceinline__ void load_coefs7(const float *c, float (&o)[8]) {
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    const v4f a = *reinterpret_cast<const v4f *>(c);
+    const v2f b = *reinterpret_cast<const v2f *>(c + 4);
+    o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = c[6];
+}
+
+__device__ __forceinline__ int lds_peek(int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void lds_post(int *p, int v) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (the lines written before the count that announces them)
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// a bounded wait for an LDS count (another wave's progress): false = gave up
+__device__ __forceinline__ bool lds_await(int *p, int at_least) {
+    int spins = 0;
+    while (lds_peek(p) < at_least) {
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > SCAN_SPIN_LIMIT) return false;
+    }
+    asm volatile("" ::: "memory");
+    return true;
+}
+
+template <typename V, int C, bool PAIR>
+__global__ __launch_bounds__((SCAN_W + 2) * 64) void scan_gs_kernel(ScanArgs<V> a) {
+    constexpr int W = SCAN_W, NXP = 64 * C, R = C >= 8 ? SCAN_RING / 2 : SCAN_RING, R2 = SCAN_SLOTS, Q = SCAN_Q, D = C >= 8 ? 2 : 3, NTH = (SCAN_W + 2) * 64;
+    extern __shared__ __attribute__((aligned(16))) unsigned char scan_dyn[];
+    V *const s_coef = reinterpret_cast<V *>(scan_dyn);         // [256][8]
+    V *const s_line = s_coef + 256 * 8;                         // [R2][W][NXP]: the waves' relaxed lines, step t in slot t % R2
+    V *const s_ghost = s_line + R2 * W * NXP;                   // [R][NXP]
+    __shared__ int s_ctl[2];                                    // ghost lines ready, position
+    __shared__ int s_prog[W + 1];                               // steps finished by computing wave w; [W]: steps stored
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    if (tid == 0) {
+        s_ctl[1] = (int)atomicAdd(&a.sync[0], 1u);
+        s_ctl[0] = 0;
+    }
+    if (tid <= W) s_prog[tid] = 0;
+    // the table as the scan uses it: every coefficient divided by its row's diagonal, the reciprocal itself in the diagonal's
+    // place (x_i = b_i / d - sum over the six neighbours of (c / d) x: the row's own old value drops out); pattern n_pat: zeros,
+    // for the lanes' rows beyond the end of a line
+    for (int q = tid; q < (a.n_pat + 1) * 8; q += NTH) {
+        V v = V(0);
+        if (q < a.n_pat * 8 && (q & 7) != 7) {
+            const V r = V(1) / a.coef[(q & ~7) + 3];
+            v = (q & 7) == 3 ? r : a.coef[q] * r;
+        }
+        s_coef[q] = v;
+    }
+    __syncthreads();                                            // (the only barrier: from here on the waves wait for counts)
+    const int g = s_ctl[1];
+    const int nx = a.nx, ny = a.ny, nz = a.nz;
+    const int T = (ny + W - 1 + D - 1) / D * D;                 // steps: a whole number of unrolled groups
+    if (a.trace && tid == NTH - 1) a.trace[8 * g + 0] = wall_clock64();
+
+    if (wave < W) {
+        // ---- computing wave: plane k, line t - wave at step t
+        const int k = g * W + wave;
+        const bool plane = k < nz;
+        const int kc = min(k, nz - 1), ku = min(k + 1, nz - 1);
+        int ic[C];
+        bool cell[C];
+#pragma unroll
+        for (int s = 0; s < C; ++s) {
+            const int i = lane * C + s;
+            cell[s] = i < nx;
+            ic[s] = min(i, nx - 1);
+        }
+        V sxo[D][C], sbb[D][C], sxu[D][C];
+        uint32_t scd[D][C];
+        V xprev[C];
+#pragma unroll
+        for (int s = 0; s < C; ++s) xprev[s] = V(0);
+        bool gave_up = false;              // (reported after the loop: a store inside it would cost every load its counted wait)
+        // PAIR (even nx, C >= 2): a lane's rows two at a time — half the load instructions, each with twice the bytes per
+        // cache line it touches (a lane's C rows are consecutive: 16-byte pieces 8 C bytes apart)
+        typedef V vpair __attribute__((ext_vector_type(2)));
+        int ip[C / 2 > 0 ? C / 2 : 1];
+#pragma unroll
+        for (int q = 0; q < C / 2; ++q) ip[q] = min(lane * C + 2 * q, nx - 2);
+        auto fetch = [&](int u, int t) {
+            const int jc = min(max(t - wave, 0), ny - 1);
+            const int base = (kc * ny + jc) * nx, baseu = (ku * ny + jc) * nx;
+            // (the patterns first: they address the table in LDS before anything else of the step can start)
+            if constexpr (PAIR) {
+#pragma unroll
+                for (int q = 0; q < C / 2; ++q) {
+                    const uint32_t two = *reinterpret_cast<const uint16_t *>(a.code + base + ip[q]);
+                    scd[u][2 * q] = two & 255u;
+                    scd[u][2 * q + 1] = two >> 8;
+                }
+#pragma unroll
+                for (int q = 0; q < C / 2; ++q) {
+                    const vpair xo = *reinterpret_cast<const vpair *>(a.x + base + ip[q]);
+                    const vpair bb = *reinterpret_cast<const vpair *>(a.b + base + ip[q]);
+                    const vpair xu = *reinterpret_cast<const vpair *>(a.x + baseu + ip[q]);
+                    sxo[u][2 * q] = xo.x; sxo[u][2 * q + 1] = xo.y;
+                    sbb[u][2 * q] = bb.x; sbb[u][2 * q + 1] = bb.y;
+                    sxu[u][2 * q] = xu.x; sxu[u][2 * q + 1] = xu.y;
+                }
+            } else {
+#pragma unroll
+                for (int s = 0; s < C; ++s) scd[u][s] = a.code[base + ic[s]];
+#pragma unroll
+                for (int s = 0; s < C; ++s) {
+                    sxo[u][s] = a.x[base + ic[s]];
+                    sbb[u][s] = a.b[base + ic[s]];
+                    sxu[u][s] = a.x[baseu + ic[s]];
+                }
+            }
+        };
+#pragma unroll
+        for (int u = 0; u < D; ++u) fetch(u, u);
+        for (int t0 = 0; t0 < T; t0 += D) {
+#pragma unroll
+            for (int u = 0; u < D; ++u) {
+                const int t = t0 + u, j = t - wave;
+                const bool active = plane && j >= 0 && j < ny;
+                if (active) {
+                    // ---- before the line (j, k - 1) is needed: everything that does not depend on it — the rows' sums without
+                    // that neighbour, and the whole alpha half of the scan (products of coefficients: no x in them).  What a
+                    // plane's line costs the next plane is then only the part below the wait.
+                    const V xe_next = dpp_take<DPP_WAVE_SHL1, 0xf>(V(0), sxo[u][0]);     // lane + 1's first row (lane 63: 0)
+                    const int un = (u + 1) % D;                                          // the stage of line j + 1
+                    V Ap[C], ccp[C], aa[C], ck[C];
+                    // four rows at a time: all their table reads first (one exposed LDS latency per group, not per row)
+                    constexpr int CG = C < 4 ? C : 4;
+#pragma unroll
+                    for (int s0 = 0; s0 < C; s0 += CG) {
+                        V co[CG][8];
+#pragma unroll
+                        for (int q = 0; q < CG; ++q)
+                            load_coefs7(s_coef + (cell[s0 + q] ? scd[u][s0 + q] : (uint32_t)a.n_pat) * 8, co[q]);
+#pragma unroll
+                        for (int q = 0; q < CG; ++q) {
+                            const int s = s0 + q;
+                            const V xe = s + 1 < C ? sxo[u][s + 1 < C ? s + 1 : s] : xe_next;
+                            V sum = co[q][4] * xe;
+                            sum = madd(co[q][5], sxo[un][s], sum);
+                            sum = madd(co[q][6], sxu[u][s], sum);
+                            sum = madd(co[q][1], xprev[s], sum);
+                            ccp[s] = madd(sbb[u][s], co[q][3], -sum);
+                            ck[s] = -co[q][0];
+                            aa[s] = -co[q][2];
+                            Ap[s] = s == 0 ? aa[0] : aa[s] * Ap[s > 0 ? s - 1 : 0];
+                        }
+                    }
+                    // the lanes' products as the six steps of the scan will want them
+                    V As[6];
+                    {
+                        V A = Ap[C - 1];
+#define OMG_SCAN_A(I, CTRL, RM)                                  \
+    {                                                            \
+        As[I] = A;                                               \
+        A = A * dpp_take<CTRL, RM>(V(1), A);                     \
+    }
+                        OMG_SCAN_A(0, 0x111, 0xf)
+                        OMG_SCAN_A(1, 0x112, 0xf)
+                        OMG_SCAN_A(2, 0x114, 0xf)
+                        OMG_SCAN_A(3, 0x118, 0xf)
+                        OMG_SCAN_A(4, 0x142, 0xa)
+                        OMG_SCAN_A(5, 0x143, 0xc)
+#undef OMG_SCAN_A
+                    }
+                    // ---- the line (j, k - 1): wave - 1 has finished step t - 1 / the ghost wave has line j; the slot this step
+                    // writes held step t - R2, read by wave + 1 at its step t - R2 + 1 and by the storing wave.  All three counts
+                    // are read at once (one LDS latency when nothing is missing, the usual case); after one wait has run out the
+                    // sweep is lost — MarchPlan::timed_out — and nothing waits any more
+                    if (!gave_up) {
+                        int *const p_prev = wave > 0 ? &s_prog[wave - 1] : &s_ctl[0];
+                        const int n_prev = wave > 0 ? t : (g > 0 ? j + 1 : 0);
+                        int *const p_next = &s_prog[wave + 1 < W ? wave + 1 : W];
+                        const int n_next = wave + 1 < W ? t - R2 + 2 : 0, n_store = t - R2 + 1;
+                        const int c_prev = lds_peek(p_prev), c_next = lds_peek(p_next), c_store = lds_peek(&s_prog[W]);
+                        if (c_prev < n_prev || c_next < n_next || c_store < n_store)
+                            gave_up = !(lds_await(p_prev, n_prev) && lds_await(p_next, n_next) && lds_await(&s_prog[W], n_store));
+                        asm volatile("" ::: "memory");
+                    }
+                    V Cp[C];
+                    if (wave == 0 && g == 0) {
+#pragma unroll
+                        for (int s = 0; s < C; ++s) Cp[s] = ccp[s];
+                    } else {
+                        const V *src = wave == 0 ? s_ghost + (j % R) * NXP + lane * C
+                                                 : s_line + (((t - 1) % R2) * W + (wave - 1)) * NXP + lane * C;
+#pragma unroll
+                        for (int s = 0; s < C; ++s) Cp[s] = madd(ck[s], src[s], ccp[s]);
+                    }
+#pragma unroll
+                    for (int s = 1; s < C; ++s) Cp[s] = madd(aa[s], Cp[s - 1], Cp[s]);
+                    V Cs = Cp[C - 1];
+#define OMG_SCAN_C(I, CTRL, RM) Cs = madd(As[I], dpp_take<CTRL, RM>(V(0), Cs), Cs);
+                    OMG_SCAN_C(0, 0x111, 0xf)
+                    OMG_SCAN_C(1, 0x112, 0xf)
+                    OMG_SCAN_C(2, 0x114, 0xf)
+                    OMG_SCAN_C(3, 0x118, 0xf)
+                    OMG_SCAN_C(4, 0x142, 0xa)
+                    OMG_SCAN_C(5, 0x143, 0xc)
+#undef OMG_SCAN_C
+                    const V xin = dpp_take<DPP_WAVE_SHR1, 0xf>(V(0), Cs);                // the end value of lane - 1 (lane 0: 0)
+                    V *dst = s_line + ((t % R2) * W + wave) * NXP + lane * C;
+#pragma unroll
+                    for (int s = 0; s < C; ++s) {
+                        xprev[s] = madd(Ap[s], xin, Cp[s]);
+                        dst[s] = xprev[s];
+                    }
+                }
+                fetch(u, t + D);
+                if (lane == 0) lds_post(&s_prog[wave], t + 1);
+            }
+        }
+        if (gave_up) store_through(&a.sync[2], 1u);
+    } else if (wave == W) {
+        // ---- storing wave: every wave's line of step t as soon as that wave has finished the step
+        bool gave_up = false;
+        // the face lines the ghost wave has taken over: back to "unset" for the next sweep (here, not there: a wave that polls
+        // with loads would wait for its own write-through stores at every round)
+        int reset_next = 0;
+        V *const fin = a.face + size_t(g > 0 ? g - 1 : 0) * ny * NXP;
+        auto reset = [&](int upto) {
+            for (; reset_next < upto; ++reset_next)
+#pragma unroll
+                for (int c = 0; c < C; ++c) store_through(fin + size_t(reset_next) * NXP + c * 64 + lane, Unset<V>::value());
+        };
+        auto put = [&](int w, int t) {
+            const int jl = t - w, k = g * W + w;
+            if (k >= nz || jl < 0 || jl >= ny) return;
+            const V *src = s_line + ((t % R2) * W + w) * NXP;
+            V *xo = a.x + (size_t(k) * ny + jl) * nx;
+            const bool face = w == W - 1 && g + 1 < a.G;
+            V *fo = a.face + (size_t(g) * ny + jl) * NXP;
+            if constexpr (PAIR) {
+                typedef V vpair __attribute__((ext_vector_type(2)));
+#pragma unroll
+                for (int c = 0; c < C / 2; ++c) {
+                    const int idx = (c * 64 + lane) * 2;
+                    const vpair v = *reinterpret_cast<const vpair *>(src + idx);
+                    if (face) {
+                        store_through(fo + idx, idx < nx ? v.x : V(0));
+                        store_through(fo + idx + 1, idx < nx ? v.y : V(0));
+                    }
+                    if (idx < nx) *reinterpret_cast<vpair *>(xo + idx) = v;
+                }
+            } else {
+#pragma unroll
+                for (int c = 0; c < C; ++c) {
+                    const int idx = c * 64 + lane;
+                    const V v = src[idx];
+                    if (face) store_through(fo + idx, idx < nx ? v : V(0));
+                    if (idx < nx) xo[idx] = v;
+                }
+            }
+        };
+        // Iteration t: the last plane's line of step t (the next workgroup waits for it) as soon as wave W - 1 has finished that
+        // step — whatever the other waves are doing —, then the other planes' lines of step t - 1.  s_prog[W] = steps of which
+        // every line is stored.
+        const int TS = ny + W - 1;
+        for (int t = 0; t <= TS; ++t) {
+            if (t < TS) {
+                if (!gave_up) gave_up = !lds_await(&s_prog[W - 1], t + 1);
+                if (a.trace && lane == 0 && t == W - 1) a.trace[8 * g + 2] = wall_clock64();
+                put(W - 1, t);
+                if (a.trace && lane == 0 && t == TS - 1) a.trace[8 * g + 4] = wall_clock64();
+            }
+            if (t > 0) {
+                if (!gave_up) {
+                    int cnt[W - 1];
+#pragma unroll
+                    for (int w = 0; w < W - 1; ++w) cnt[w] = lds_peek(&s_prog[w]);
+                    bool all = true;
+#pragma unroll
+                    for (int w = 0; w < W - 1; ++w) all = all && cnt[w] >= t;
+                    if (!all)
+#pragma unroll
+                        for (int w = 0; w < W - 1; ++w) gave_up = gave_up || !lds_await(&s_prog[w], t);
+                    asm volatile("" ::: "memory");
+                }
+#pragma unroll
+                for (int w = W - 2; w >= 0; --w) put(w, t - 1);
+                if (lane == 0) lds_post(&s_prog[W], t);
+                if (g > 0) reset(min(lds_peek(&s_ctl[0]), reset_next + 1 + (t & 1)));
+            }
+        }
+        if (lane == 0) lds_post(&s_prog[W], T + R2);            // (steps without lines: nobody waits for them)
+        if (g > 0) {
+            if (!gave_up) gave_up = !lds_await(&s_ctl[0], ny);
+            reset(ny);
+        }
+        if (a.trace && lane == 0) a.trace[8 * g + 5] = wall_clock64();
+        if (gave_up) store_through(&a.sync[2], 1u);
+    } else if (g > 0) {
+        // ---- ghost wave: the previous workgroup's face lines into the LDS ring, ahead of wave 0, round after round
+        int jn = 0, base_line = 0, idle = 0;
+        V v[Q][C];
+        V *const fin = a.face + size_t(g - 1) * ny * NXP;
+        while (jn < ny) {
+            base_line = jn;
+#pragma unroll
+            for (int q = 0; q < Q; ++q) {
+                const int line = min(jn + q, ny - 1);
+#pragma unroll
+                for (int c = 0; c < C; ++c) v[q][c] = load_through(fin + size_t(line) * NXP + c * 64 + lane);
+            }
+            // wave 0 has finished its steps < s_prog[0], i.e. is done with the lines < s_prog[0]: room for R lines from there
+            const int limit = min(ny, lds_peek(&s_prog[0]) + R);
+            const int before = jn;
+#pragma unroll
+            for (int q = 0; q < Q; ++q) {
+                const int line = base_line + q;
+                bool set = true;
+#pragma unroll
+                for (int c = 0; c < C; ++c) set = set && !Unset<V>::is(v[q][c]);
+                const bool all = __ballot(set) == ~0ull;
+                if (line == jn && line < limit && all) {
+                    V *dst = s_ghost + (line % R) * NXP;
+#pragma unroll
+                    for (int c = 0; c < C; ++c) dst[c * 64 + lane] = v[q][c];      // (the storing wave resets the slots)
+                    jn = line + 1;
+                }
+            }
+            if (jn != before) {
+                if (lane == 0) lds_post(&s_ctl[0], jn);
+                if (a.trace && lane == 0 && before == 0) a.trace[8 * g + 1] = wall_clock64();
+                if (a.trace && lane == 0 && jn == ny) a.trace[8 * g + 3] = wall_clock64();
+                idle = 0;
+            } else {
+                if (jn >= limit) __builtin_amdgcn_s_sleep(8);   // (the ring is full: wave 0 is behind, nothing to poll for)
+                if (++idle > SCAN_ROUND_LIMIT) {
+                    // give up: the error flag, and whatever the slots hold, so that nobody waits for ever
+                    store_through(&a.sync[2], 1u);
+                    jn = ny;
+                    if (lane == 0) lds_post(&s_ctl[0], jn);
+                }
+            }
+        }
+    }
+    // the last workgroup to finish rewinds the ticket for the next sweep
+    if (tid == 0) {
+        __threadfence();
+        const uint32_t done = atomicAdd(&a.sync[1], 1u);
+        if (done + 1u == (uint32_t)a.G) {
+            store_through(&a.sync[1], 0u);
+            store_through(&a.sync[0], 0u);
+        }
+    }
+}
+
 }  // namespace
 
 template <typename V>
@@ -973,7 +1390,44 @@ bool MarchPlan<V>::build(const omg_csr &A, hipStream_t s) {
     hipLaunchKernelGGL(fill_kernel<V>, dim3(1024), dim3(256), 0, s, faceK.p, faceK.n, Unset<V>::value());
     OMG_HIP(hipGetLastError());
     OMG_HIP(hipStreamSynchronize(s));
+    // OMG_MARCH_SCAN=1 (read when the plan is made): the line-scan sweep for 3-D pattern-table levels with lines of at most
+    // 512 rows — rounding-level differences from the sequential loop, see scan_gs_kernel
+    line_scan = false;
+    {
+        const char *e = getenv("OMG_MARCH_SCAN");
+        if (e && e[0] == '1' && !rows_mode && nz >= 2 && nx <= 512 && g.n_pat < 256) {
+            std::vector<uint8_t> rc((size_t)n);
+            for (int t = 0; t < nt; ++t)
+                for (int64_t r = n * t / nt; r < n * (t + 1) / nt; ++r) rc[(size_t)r] = remap[t][code[r]];
+            rowcode.alloc(rc.size());
+            rowcode.upload(rc.data(), rc.size(), s);
+            scan_c = nx <= 64 ? 1 : nx <= 128 ? 2 : nx <= 256 ? 4 : 8;
+            scan_g = (g.nz + SCAN_W - 1) / SCAN_W;
+            face_scan.alloc(std::max<size_t>(1, size_t(scan_g - 1) * size_t(g.ny) * size_t(64 * scan_c)));
+            hipLaunchKernelGGL(fill_kernel<V>, dim3(256), dim3(256), 0, s, face_scan.p, face_scan.n, Unset<V>::value());
+            OMG_HIP(hipGetLastError());
+            OMG_HIP(hipStreamSynchronize(s));
+            line_scan = true;
+        }
+    }
     return true;
+}
+
+template <typename V, int C, bool PAIR>
+static void launch_scan_as(const ScanArgs<V> &a, hipStream_t s) {
+    const size_t lds = (size_t(256) * 8 + size_t(SCAN_SLOTS) * SCAN_W * 64 * C + size_t(C >= 8 ? SCAN_RING / 2 : SCAN_RING) * 64 * C) * sizeof(V) + 16;
+    static bool allowed = false;                              // (per instantiation)
+    if (!allowed) {
+        OMG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(scan_gs_kernel<V, C, PAIR>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)));
+        allowed = true;
+    }
+    hipLaunchKernelGGL((scan_gs_kernel<V, C, PAIR>), dim3((unsigned)a.G), dim3((SCAN_W + 2) * 64), lds, s, a);
+    OMG_HIP(hipGetLastError());
+}
+template <typename V, int C>
+static void launch_scan(const ScanArgs<V> &a, hipStream_t s) {
+    if (C >= 2 && a.nx % 2 == 0) launch_scan_as<V, C, (C >= 2)>(a, s);
+    else launch_scan_as<V, C, false>(a, s);
 }
 
 template <typename V>
@@ -981,6 +1435,31 @@ void MarchPlan<V>::sweep(V *x, const V *b, hipStream_t s) const {
     if (line1) {
         hipLaunchKernelGGL(line_gs_kernel<V>, dim3(1), dim3(64), 0, s, x, b, tri.p, g.nx);
         OMG_HIP(hipGetLastError());
+        return;
+    }
+    if (line_scan) {
+        ScanArgs<V> sa;
+        sa.x = x; sa.b = b; sa.code = rowcode.p; sa.coef = coef.p; sa.face = face_scan.p; sa.sync = sync.p;
+        sa.nx = g.nx; sa.ny = g.ny; sa.nz = g.nz; sa.G = scan_g; sa.n_pat = g.n_pat;
+        static const bool trace = [] { const char *e = experiment_env("OMG_SCAN_TRACE"); return e && e[0] == '1'; }();
+        DevBuf<long long> tr;
+        sa.trace = nullptr;
+        if (trace) { tr.alloc(size_t(8) * scan_g); tr.zero(s); sa.trace = tr.p; }
+        if (scan_c == 1) launch_scan<V, 1>(sa, s);
+        else if (scan_c == 2) launch_scan<V, 2>(sa, s);
+        else if (scan_c == 4) launch_scan<V, 4>(sa, s);
+        else launch_scan<V, 8>(sa, s);
+        if (trace) {
+            std::vector<long long> h(size_t(8) * scan_g);
+            tr.download(h.data(), h.size(), s);
+            OMG_HIP(hipStreamSynchronize(s));
+            long long t0 = h[0];
+            for (int q = 0; q < scan_g; ++q) t0 = std::min(t0, h[8 * q]);
+            fprintf(stderr, "[omg scan] %d x %d x %d, %d workgroups (us: start, ghost has line 0, face line 0 stored, ghost has last line, last face line stored, end)\n", g.nx, g.ny, g.nz, scan_g);
+            for (int q = 0; q < scan_g; q += (scan_g > 16 ? scan_g / 16 : 1))
+                fprintf(stderr, "[omg scan]   wg %3d: %8.2f %8.2f %8.2f %8.2f %8.2f %8.2f\n", q, (h[8 * q] - t0) / 100.0, (h[8 * q + 1] - t0) / 100.0,
+                        (h[8 * q + 2] - t0) / 100.0, (h[8 * q + 3] - t0) / 100.0, (h[8 * q + 4] - t0) / 100.0, (h[8 * q + 5] - t0) / 100.0);
+        }
         return;
     }
     MarchArgs<V> a;

@@ -184,3 +184,152 @@ def test_operators_that_are_not_grid_star_stencils_keep_the_level_schedule():
         assert np.array_equal(sweep(A, b, x0, 2, march=True), sweep(A, b, x0, 2, march=False))
         np.testing.assert_allclose(sweep(A, b, x0, 2, march=True), orc.gauss_seidel(A, b, x0.copy(), iterations=2),
                                    rtol=1e-10, atol=1e-12)
+
+
+# ---- the line-scan sweep (OMG_MARCH_SCAN=1, march.hip scan_gs_kernel): an option, not the bits of the sequential loop ----
+
+class scan_mode:
+    """OMG_MARCH_SCAN for the hierarchies made inside the block (the switch is read when a plan is made)."""
+
+    def __init__(self, on):
+        self.on = on
+
+    def __enter__(self):
+        self.old = os.environ.get("OMG_MARCH_SCAN")
+        os.environ["OMG_MARCH_SCAN"] = "1" if self.on else "0"
+
+    def __exit__(self, *exc):
+        if self.old is None:
+            del os.environ["OMG_MARCH_SCAN"]
+        else:
+            os.environ["OMG_MARCH_SCAN"] = self.old
+
+
+def smooth_on_device(A, b, x0, sweeps, dtype, scan):
+    n = A.shape[0]
+    with scan_mode(scan):
+        with _hip.Hierarchy([A, sp.identity(1, format="csr")], [sp.csr_matrix(np.ones((1, n)))], smoother="gs", dtype=dtype) as h:
+            flags = h.level_flags(0)
+            x = x0.copy()
+            h.smooth(0, b, x, sweeps)
+    return x, flags
+
+
+# last dimension = the line: 1, 2, 4 and 8 rows per lane, odd lengths (no paired loads), lines shorter than a wave, more planes
+# than one workgroup holds (4), planes that do not fill the last workgroup
+SCAN_SHAPES = [(8, 8, 8), (12, 20, 30), (17, 9, 33), (5, 64, 16), (33, 5, 7), (48, 48, 48), (64, 64, 64), (40, 72, 64),
+               (100, 30, 20), (10, 8, 300), (9, 12, 130), (6, 7, 100), (7, 6, 101), (20, 20, 256), (3, 4, 512), (2, 3, 5)]
+
+
+@pytest.mark.parametrize("shape", SCAN_SHAPES)
+def test_line_scan_sweep_against_the_wavefront_kernel(shape):
+    """VERDICT r5 item 3(b).  The scan resolves a grid line's recurrence x_i = c_i + alpha_i x_{i-1} in one step; its sums
+    associate differently from openmg/solvers.py:56-68's loop, so: the wavefront kernel's result (= the loop's bits) to a
+    few ulp of the largest entry, after one sweep and after three, and the oracle's loop itself."""
+    rng = np.random.default_rng(5)
+    A = scaled_rows(operators.stencil_poisson(shape), rng)
+    n = A.shape[0]
+    b, x0 = rng.standard_normal(n), rng.standard_normal(n)
+    for its in (1, 3):
+        got, flags = smooth_on_device(A, b, x0, its, "float64", scan=True)
+        ref, ref_flags = smooth_on_device(A, b, x0, its, "float64", scan=False)
+        assert flags["march"] and flags["march_scan"] and ref_flags["march"] and not ref_flags["march_scan"]
+        assert np.max(np.abs(got - ref)) <= 1e-13 * np.max(np.abs(ref)), (shape, its, np.max(np.abs(got - ref)))
+    got, _ = smooth_on_device(A, b, x0, 2, "float64", scan=True)
+    np.testing.assert_allclose(got, orc.gauss_seidel(A, b, x0.copy(), iterations=2), rtol=1e-11, atol=1e-13)
+
+
+@pytest.mark.parametrize("shape", [(12, 20, 30), (40, 72, 64), (9, 12, 130), (20, 20, 256), (7, 6, 101)])
+def test_line_scan_sweep_in_float32(shape):
+    rng = np.random.default_rng(6)
+    A = scaled_rows(operators.stencil_poisson(shape), rng)
+    n = A.shape[0]
+    b = rng.standard_normal(n).astype(np.float32).astype(np.float64)
+    x0 = rng.standard_normal(n).astype(np.float32).astype(np.float64)
+    got, flags = smooth_on_device(A, b, x0, 2, "float32", scan=True)
+    ref, _ = smooth_on_device(A, b, x0, 2, "float32", scan=False)
+    assert flags["march_scan"]
+    assert np.max(np.abs(got - ref)) <= 2e-5 * np.max(np.abs(ref))          # (float32 rounding, a few dozen ulp)
+    np.testing.assert_allclose(got, orc.gauss_seidel(A, b, x0.copy(), iterations=2), rtol=2e-4, atol=2e-5)
+
+
+def test_line_scan_declines_what_it_does_not_cover():
+    """2-D grids, per-row coefficients (more than 255 distinct rows) and lines longer than 512 rows keep the wavefront kernel
+    — and its bits — with the switch on."""
+    rng = np.random.default_rng(7)
+    cases = [operators.stencil_poisson((100, 70)),
+             operators.stencil_poisson((3, 4, 600)),
+             sp.csr_matrix(sp.diags(0.5 + rng.random(12 * 20 * 30)) @ operators.stencil_poisson((12, 20, 30)))]
+    for A in cases:
+        A = sp.csr_matrix(A)
+        A.sort_indices()
+        n = A.shape[0]
+        b, x0 = rng.standard_normal(n), rng.standard_normal(n)
+        got, flags = smooth_on_device(A, b, x0, 2, "float64", scan=True)
+        ref, _ = smooth_on_device(A, b, x0, 2, "float64", scan=False)
+        assert flags["march"] and not flags["march_scan"], A.shape
+        assert np.array_equal(got, ref)
+
+
+def test_line_scan_sweep_is_deterministic_over_many_runs():
+    """Workgroups hand planes over through HBM inside the launch, waves through LDS counts: a stale read or a slot
+    overwritten too early would show here (12 workgroups)."""
+    rng = np.random.default_rng(12)
+    shape = (46, 72, 56)
+    A = operators.stencil_poisson(shape)
+    n = A.shape[0]
+    b, x0 = rng.standard_normal(n), rng.standard_normal(n)
+    first, _ = smooth_on_device(A, b, x0, 2, "float64", scan=True)
+    ref, _ = smooth_on_device(A, b, x0, 2, "float64", scan=False)
+    assert np.max(np.abs(first - ref)) <= 1e-13 * np.max(np.abs(ref))
+    with scan_mode(True):
+        with _hip.Hierarchy([A, sp.identity(1, format="csr")], [sp.csr_matrix(np.ones((1, n)))], smoother="gs") as h:
+            for _ in range(25):
+                x = x0.copy()
+                h.smooth(0, b, x, 2)
+                assert np.array_equal(x, first)
+
+
+def test_line_scan_in_the_reference_traces(golden):
+    """mgSolve with the reference's own smoother and the switch on, against the traces recorded from the reference
+    (tests/golden/g3_*): the iterate after three cycles to 1e-9, the norm to BASELINE's 1e-10 — the contract the option
+    has to stay inside."""
+    import openmg_amd
+    with scan_mode(True):
+        openmg_amd.clear_cache()
+        try:
+            for n in (16, 32):
+                d = golden("g3_poisson3d_%d" % n)
+                A0 = operators.stencil_poisson((n, n, n))
+                for pre, post in (((1, 0), (1, 1)) if n == 16 else ((1, 1),)):
+                    p = {"problemShape": (n, n, n), "gridLevels": 2, "preIterations": pre, "postIterations": post,
+                         "cycles": 3, "threshold": 0, "giveInfo": True, "minSize": 8}
+                    x, info = openmg_amd.mgSolve(A0, d["b"], p)
+                    np.testing.assert_allclose(x, d["v%d%d_x_c3" % (pre, post)], rtol=1e-9, atol=1e-11)
+                    want = float(d["v%d%d_norms" % (pre, post)][2])
+                    assert abs(info["norm"] - want) <= 1e-10 * abs(want)
+                R = operators.restrictionList((n, n, n), 1, 8)
+                with _hip.Hierarchy(operators.coeffecientList(A0, R), R, smoother="gs") as h:
+                    assert h.level_flags(0)["march_scan"]
+        finally:
+            openmg_amd.clear_cache()
+
+
+def test_line_scan_full_size_256_cubed_against_the_wavefront_kernel():
+    """BASELINE configs[1]'s size with the reference's smoother: every smoothed level takes the scan, and three V(1,1)
+    cycles give the wavefront kernel's residual norms to 1e-10 (64 workgroups in the chain on the finest level)."""
+    shape = (256, 256, 256)
+    A0 = operators.stencil_poisson(shape)
+    b = A0 @ np.random.default_rng(1).random(A0.shape[0])
+    R = operators.restrictionList(shape, 3, 8)
+    A = operators.coeffecientList(A0, R)
+    norms = {}
+    for scan in (True, False):
+        with scan_mode(scan):
+            with _hip.Hierarchy(A, R, smoother="gs") as h:
+                assert [h.level_flags(l)["march_scan"] for l in range(len(R))] == [scan] * len(R)
+                h.resident_load(b)
+                norms[scan] = [h.resident_cycle(1, 1) for _ in range(3)]
+    assert norms[False][2] < 0.05 * norms[False][0]
+    for got, want in zip(norms[True], norms[False]):
+        assert abs(got - want) <= 1e-10 * want, (norms[True], norms[False])
