@@ -768,6 +768,7 @@ def main():
                                          "frac": round(spmv_csr / p_spmv_ms / 1e6 / HBM_PEAK_GBS, 4)}
         else:
             out["wavefront_levels"] = [bool(h2.level_flags(l)["march"]) for l in range(m2["grids"] - 1)]
+            out["line_scan_levels"] = [bool(h2.level_flags(l)["march_scan"]) for l in range(m2["grids"] - 1)]
             out["level_sets_fine_grid"] = h2.level_sets(0)
             out["norms_last_region_tail"] = n2[-3:]
         h2.close()
@@ -795,6 +796,15 @@ def main():
                        "same problem and timed loop with the reference's lexicographic Gauss-Seidel (openmg/solvers.py:56-68) "
                        "as the smoother; grid star stencils run a sweep as one wavefront launch (march.hip, "
                        "OMG_MARCH=0: one launch per level set), bit-identical either way", min(repeats, 3), False)
+        # ... and with the opt-in line-scan sweep (OMG_MARCH_SCAN=1, round 6: a wave resolves a grid line's recurrence at once;
+        # a few ulp per row away from the sequential loop's bits, inside the 1e-10 contract — tests/test_gpu_march.py)
+        scan_path = leg({"OMG_MARCH_SCAN": "1"}, "gs",
+                        "the reference's lexicographic Gauss-Seidel with OMG_MARCH_SCAN=1: the line-scan sweep (march.hip "
+                        "scan_gs_kernel), not bit-identical to the sequential loop", min(repeats, 3), False)
+        lex_path["line_scan"] = {k: scan_path[k] for k in ("vcycles_per_s", "ms_per_step", "ms_per_step_all", "line_scan_levels",
+                                                           "norms_last_region_tail")}
+        na, nb = lex_path["norms_last_region_tail"][-1], scan_path["norms_last_region_tail"][-1]
+        lex_path["line_scan"]["norm_rel_diff_from_the_wavefront_kernel"] = abs(na - nb) / max(abs(na), 1e-300)
 
     config4 = None
     if not args.no_config4 and args.dtype == "f64" and args.smoother == "colour":
@@ -840,6 +850,7 @@ def main():
         roofline["mgcycle_device_arrays_call_ms"] = dropin["mgcycle_device_arrays_call_ms"]
     if lex_path is not None:
         roofline["reference_smoother_vcycles_per_s"] = lex_path["vcycles_per_s"]
+        roofline["reference_smoother_line_scan_vcycles_per_s"] = lex_path["line_scan"]["vcycles_per_s"]
     if var7 is not None:
         roofline["var7_vcycles_per_s"] = var7["vcycles_per_s"]
         roofline["var7_set_schedule_vcycles_per_s"] = var7["set_schedule_vcycles_per_s"]

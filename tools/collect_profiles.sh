@@ -49,6 +49,10 @@ timeout 400 rocprofv3 --kernel-trace --output-format csv -d $out/c4s -o t -- pyt
 python3 $root/tools/trace_dump.py $out/c4s/t_kernel_trace.csv 60 > $out/${p}_config4_cycle_timeline.txt 2>&1
 timeout 300 rocprofv3 --kernel-trace --output-format csv -d $out/lex -o l -- python3 $root/tools/run_configs.py 0 4 5 > /dev/null 2>&1
 python3 $root/tools/march_trace.py $out/lex/l_kernel_trace.csv > $out/${p}_march_by_level.txt 2>&1
+# round 6: the opt-in line-scan sweep beside the wavefront kernel, per level of the 256^3 problem (V(1,1) cycles with each), and
+# whether its results agree
+timeout 300 rocprofv3 --kernel-trace --output-format csv -d $out/scan -o s -- python3 $root/tools/scan_probe.py time 256 > $out/scan_time.txt 2>/dev/null
+( grep "grids scan" $out/scan_time.txt; python3 $root/tools/scan_trace.py $out/scan/s_kernel_trace.csv ) > $out/${p}_scan_by_level.txt 2>&1
 for m in 0 1; do PYTHONPATH=$root timeout 200 rocprofv3 --kernel-trace --output-format csv -d $out/peer$m -o p -- python3 $root/tools/prof_pdist.py $m 20 > /dev/null 2>&1; done
 python3 $root/tools/peer_mode_table.py $out/peer0 $out/peer1 > $out/${p}_peer_mode.txt 2>&1
 python3 $root/tools/level_times.py $out/cyc/c_kernel_trace.csv > $out/${p}_level_times.txt 2>&1
