@@ -728,13 +728,15 @@ __global__ void fill_kernel(V *p, size_t n, V v) {
 //   * A GHOST wave polls the previous workgroup's face lines, SCAN_Q lines per round, round after round, and hands complete
 //     lines to wave 0 through an LDS ring.  Workgroups take their position from a ticket, so the one a workgroup waits for has
 //     always started; every wait is bounded, then the error flag (MarchPlan::timed_out) and no more waiting.
-// Measured (profiles/r06_scan_*): 256^3 0.69 ms per sweep against 0.92 (march_gs_kernel), 128^3 0.23 against 0.38, 64^3 0.10
+// Measured (profiles/r06_scan_*): 256^3 0.61 ms per sweep against 0.92 (march_gs_kernel), 128^3 0.21 against 0.38, 64^3 0.10
 // against 0.18, 32^3 0.05 against 0.08.  A workgroup alone: 0.8 us per step at nx = 256 (259 steps: 0.21 ms); a hop to the
-// next workgroup 4.6 us before its first line is out (0.7 us per wave of the chain + 1.5 us through HBM), and each workgroup
-// runs a little slower than the one that feeds it (0.30 ms for the 4th, 0.35 for the 60th of 64).
+// next workgroup 4.5 us before its first line is out (0.65 us per wave of the chain + 1.8 us through HBM and the poll), and
+// each workgroup runs a little slower than the one that feeds it (0.28 ms for the 4th, 0.33 for the 60th of 64).  The ghost
+// wave polls two lines per round and naps when it is half a ring ahead: eight lines per round cost 12 % of the sweep (the
+// wave shares a SIMD with a computing wave).
 constexpr int SCAN_W = 4;          // planes = computing waves per workgroup
 constexpr int SCAN_RING = 16;      // ghost lines in LDS
-constexpr int SCAN_Q = 8;          // face lines polled per round
+constexpr int SCAN_Q = 2;          // face lines polled per round
 constexpr int SCAN_SLOTS = 5;      // steps a computing wave's lines stay in LDS
 constexpr int SCAN_ROUND_LIMIT = 1 << 18;   // rounds of the ghost wave without a new line (~1 us each)
 constexpr int SCAN_SPIN_LIMIT = 1 << 24;    // polls of an LDS count (~0.1 us each)
@@ -979,8 +981,8 @@ __global__ __launch_bounds__((SCAN_W + 2) * 64) void scan_gs_kernel(ScanArgs<V> 
                         dst[s] = xprev[s];
                     }
                 }
+                if (lane == 0) lds_post(&s_prog[wave], t + 1);          // (first: the next plane's wave waits for this)
                 fetch(u, t + D);
-                if (lane == 0) lds_post(&s_prog[wave], t + 1);
             }
         }
         if (gave_up) store_through(&a.sync[2], 1u);
@@ -1094,6 +1096,7 @@ __global__ __launch_bounds__((SCAN_W + 2) * 64) void scan_gs_kernel(ScanArgs<V> 
             }
             if (jn != before) {
                 if (lane == 0) lds_post(&s_ctl[0], jn);
+                if (jn - (limit - R) > R / 2) __builtin_amdgcn_s_sleep(16);    // (well ahead of wave 0: leave the SIMD to the wave it shares it with)
                 if (a.trace && lane == 0 && before == 0) a.trace[8 * g + 1] = wall_clock64();
                 if (a.trace && lane == 0 && jn == ny) a.trace[8 * g + 3] = wall_clock64();
                 idle = 0;
