@@ -548,12 +548,12 @@ void pool_views(Level<V> &L, char *base, size_t span, size_t off1, size_t off2) 
 // (ordinary and scattered ones in turn, all held until the end so that each is different memory), the level's own down +
 // up pass is timed on each, and the search ends when a candidate is good (the passes at 4.5 TB/s of needed bytes), or as fast
 // as the best this process has ever had for the shape, or 7 % faster than the slowest of three or more, or after
-// OMG_POOL_TRIALS (6); then, where none was good, vector by vector (below).
+// OMG_POOL_TRIALS (8); then, where none was good, vector by vector (below).
 template <typename V>
 void place_finest_pool(Hier<V> *h) {
     // (read at every call, like OMG_PLACE_KEEP_LAST=1 — tests: the newest candidate is kept whatever its time, no early stop)
     const char *env_trials = getenv("OMG_POOL_TRIALS");
-    const int trials = env_trials && env_trials[0] ? atoi(env_trials) : 6;
+    const int trials = env_trials && env_trials[0] ? atoi(env_trials) : 8;
     const bool keep_last = getenv("OMG_PLACE_KEEP_LAST") != nullptr;
     if ((trials < 2 && !getenv("OMG_POOL_REFINE")) || h->lv.size() < 2) return;
     Level<V> &L = h->lv[0], &C = h->lv[1];
@@ -582,12 +582,43 @@ void place_finest_pool(Hier<V> *h) {
     // fast kind of memory give; one of them elsewhere: 180-186 us) — where a level's shape never reaches that, every candidate is tried
     const double pair_bytes = 6.0 * double(sizeof(V)) * double(L.n);
     auto good = [&](float us) { return pair_bytes / (double(us) * 1e-6) >= 4.5e12; };
+    // Round 6: the level's OTHER stream over x — the matrix-free fine-grid SpMV of the metric (omg_resident_spmv_time) — has
+    // its own opinion of where x lies: from a pool in 2 or 4 MiB pieces it takes 68 - 72 us whatever its destination, from
+    // one in 8 MiB pieces 44 or 60 - 70 (a property of the process: all of its 8 MiB pools or none), from 32 MiB pieces or an
+    // ordinary allocation 44 (profiles/r06_pool_piece_size.txt) — while the passes want the small pieces.  So a candidate
+    // that is good for the passes is also asked for its SpMV time (into an ordinary allocation), and the search goes on
+    // while the best pool is not good for both; between two pools within 2 % of each other for the passes the one the SpMV
+    // likes wins.  (OMG_POOL_SPMV=0: the passes alone decide, as before.)
+    DevBuf<V> spmv_probe_y;
+    hipEvent_t se0 = nullptr, se1 = nullptr;
+    const bool ask_spmv = !L.plane->g.jacobi && !getenv_flag0("OMG_POOL_SPMV");
+    const bool debug = SetupTimer::on();
+    auto spmv_ok = [&]() -> bool {
+        if (!ask_spmv) return true;
+        if (!spmv_probe_y.p) {
+            try { spmv_probe_y.alloc(size_t(L.n)); } catch (const Error &) { (void)hipGetLastError(); return true; }
+            OMG_HIP(hipEventCreate(&se0));
+            OMG_HIP(hipEventCreate(&se1));
+        }
+        L.plane->spmv(L.x.p, spmv_probe_y.p, h->stream);
+        OMG_HIP(hipEventRecord(se0, h->stream));
+        for (int r = 0; r < 6; ++r) L.plane->spmv(L.x.p, spmv_probe_y.p, h->stream);
+        OMG_HIP(hipEventRecord(se1, h->stream));
+        OMG_HIP(hipEventSynchronize(se1));
+        float ms = 0.0f;
+        OMG_HIP(hipEventElapsedTime(&ms, se0, se1));
+        const double us = 1e3 * double(ms) / 6.0;
+        if (debug) fprintf(stderr, "[omg setup]   ... its matrix-free SpMV: %.1f us per launch\n", us);
+        return 2.0 * double(sizeof(V)) * double(L.n) / (us * 1e-6) >= 5.15e12;        // (ensure_spmv_y's line: 52 us at 256^3 fp64)
+    };
     float best = timed(), worst = best;
     std::vector<DevBuf<char>> held;                       // (the losers: kept until the end, so that a candidate is not the memory just given back)
-    const bool debug = SetupTimer::on();
     if (debug) fprintf(stderr, "[omg setup] finest level's pool, candidate 0 (hipMalloc): %.1f us per down + up\n", best);
+    bool best_spmv = true;
+    auto settled = [&](int k) { return good(best) || (k >= 3 && best <= 0.93f * worst) || (known > 0.0f && best <= 1.02f * known); };
+    if (!keep_last && settled(1)) best_spmv = spmv_ok();
     for (int k = 1; k < max_trials; ++k) {
-        if (!keep_last && (good(best) || (k >= 3 && best <= 0.93f * worst) || (known > 0.0f && best <= 1.02f * known))) break;
+        if (!keep_last && settled(k) && best_spmv) break;
         DevBuf<char> alt;
         try { alt.alloc(3 * L.pool_span, 0, pool_placement(k)); } catch (const Error &) { (void)hipGetLastError(); break; }       // (no memory for another candidate: what there is stays)
         std::swap(L.pool, alt);                           // L.pool: the candidate, alt: the best so far
@@ -595,10 +626,18 @@ void place_finest_pool(Hier<V> *h) {
         const float t = timed();
         if (debug) fprintf(stderr, "[omg setup] finest level's pool, candidate %d (placement %d): %.1f us per down + up\n", k, pool_placement(k), t);
         worst = std::max(worst, t);
-        if (t < best || keep_last) best = std::min(best, t);
+        // (the SpMV is asked only where the passes' answer alone does not decide)
+        bool take = keep_last || t < 0.98f * best;
+        bool cand_spmv = true;
+        if (!keep_last && t <= 1.02f * best) {
+            cand_spmv = spmv_ok();
+            take = (cand_spmv && !best_spmv) || (t < best && (cand_spmv || !best_spmv)) || t < 0.98f * best;
+        }
+        if (take) { best = keep_last ? std::min(best, t) : t; best_spmv = cand_spmv; }
         else std::swap(L.pool, alt);                      // the candidate lost
         held.push_back(std::move(alt));
     }
+    if (se0) { (void)hipEventDestroy(se0); (void)hipEventDestroy(se1); }
     {
         std::lock_guard<std::mutex> lock(mu);
         float &e = best_ever[key];
