@@ -165,16 +165,16 @@ struct DevBuf {
 
 // How the k-th candidate of a placement search (hierarchy.hip place_finest_pool, Stencil27Plan::place_tiles, ...) is
 // allocated: 0 ordinary hipMalloc, n >= 2: scattered pieces of n MiB (DevBuf::alloc; 1: physically contiguous — an
-// experiment).  OMG_POOL_PLACE=n: every candidate that way.  Mostly 8 MiB pieces (round 6, profiles/r06_pool_piece_size.txt):
-// where the ordinary allocation is the slow kind for the plane passes, pieces of 2, 4 and 8 MiB are equally fast for them
-// (173 us per down + up against 191; 16 and 32 MiB pieces mostly are not), but the level's other stream over x, the
-// matrix-free SpMV, reads an x that lies in 2 or 4 MiB pieces at 68 - 72 us per launch whatever its destination, and one in
-// 8 MiB pieces at 44 us in about every other process (in 32 MiB pieces or an ordinary allocation: 44) — place_finest_pool
-// asks both.
+// experiment).  OMG_POOL_PLACE=n: every candidate that way.  The order (round 6, profiles/r06_pool_piece_size.txt): where the
+// ordinary allocation is the slow kind for the plane passes, pieces of 2, 4 and 8 MiB are fast for them on the first try (173 us
+// per down + up against 191), 16 and 32 MiB pieces once in three to six; the level's other stream over x, the matrix-free
+// SpMV, reads an x that lies in 2 or 4 MiB pieces at 68 - 72 us per launch whatever its destination, one in 8 MiB pieces at 44
+// us in four processes of five (all of a process's 8 MiB pools alike), one in 16 / 32 MiB pieces or an ordinary allocation
+// at 44.  place_finest_pool asks both: 8 MiB pieces first, then 16 / 32 among them.
 inline int pool_placement(int k) {
     const char *e = getenv("OMG_POOL_PLACE");
     if (e && e[0]) return atoi(e);
-    static const int kinds[] = {0, 8, 8, 32, 8, 2, 8, 32};
+    static const int kinds[] = {0, 8, 16, 8, 32, 16, 2, 32};
     return kinds[size_t(k) % (sizeof(kinds) / sizeof(kinds[0]))];
 }
 
